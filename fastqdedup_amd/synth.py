@@ -1,0 +1,93 @@
+"""Deterministic synthetic read keys.
+
+Counter-based: every base is a pure function of (seed, read index, position),
+so the numpy generator here and the HIP generator in ``csrc/synth.hip``
+(``fqd_synth_keys``) produce byte-identical keys; tests check that on the GPU.
+
+Model: ``M = max(1, n // copies)`` molecules; ``F = max(1, M // 4)`` inserts.
+Molecule ``m`` = ``umi`` random bases followed by the ``L - umi`` bases of
+insert ``h(seed, 1, m) mod F`` (so different molecules can share an insert --
+the same-fragment/different-UMI case that creates false bucket candidates).
+Read ``r`` copies molecule ``h(seed, 0, r) mod M`` (about Poisson(copies)
+copies each) and then, per base, becomes ``N`` with probability ``n_rate`` or
+one of the three other bases with probability ``sub_rate``
+(reference README.rst:120-122 motivates 1e-3).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+_MUL1 = np.uint64(0xBF58476D1CE4E5B9)
+_MUL2 = np.uint64(0x94D049BB133111EB)
+_STREAM = np.uint64(0xD1B54A32D192ED03)
+
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = x + _GOLD
+        z = (z ^ (z >> np.uint64(30))) * _MUL1
+        z = (z ^ (z >> np.uint64(27))) * _MUL2
+        return z ^ (z >> np.uint64(31))
+
+
+def stream_hash(seed: int, stream: int, idx: np.ndarray) -> np.ndarray:
+    """h(seed, stream, idx) = splitmix64(splitmix64(seed + stream * C) ^ idx)."""
+    with np.errstate(over="ignore"):
+        base = splitmix64(np.array([np.uint64(seed) + np.uint64(stream) * _STREAM],
+                                   dtype=np.uint64))[0]
+    return splitmix64(base ^ idx.astype(np.uint64))
+
+
+def rate_threshold(p: float) -> int:
+    """Probability -> threshold on the top 53 bits of a hash (exact on host and device)."""
+    return int(p * float(1 << 53))
+
+
+def synth_keys(n: int, length: int, umi: int, seed: int, *, copies: int = 4,
+               sub_rate: float = 1e-3, n_rate: float = 1e-4) -> np.ndarray:
+    """Returns an ``(n, length)`` uint8 array of ASCII keys (reads ``0 .. n`` of
+    an ``n``-read job). ``umi >= length`` makes every molecule fully random."""
+    return _synth(n, length, umi, seed, copies, sub_rate, n_rate, 0, n)
+
+
+def synth_keys_range(n_total: int, start: int, count: int, length: int, umi: int, seed: int, *,
+                     copies: int = 4, sub_rate: float = 1e-3, n_rate: float = 1e-4) -> np.ndarray:
+    """Reads ``start .. start+count`` of an ``n_total``-read job (one rank's shard)."""
+    return _synth(count, length, umi, seed, copies, sub_rate, n_rate, start, n_total)
+
+
+def _synth(n, length, umi, seed, copies, sub_rate, n_rate, start, n_total):
+    if n == 0:
+        return np.zeros((0, length), dtype=np.uint8)
+    umi = min(umi, length)
+    M = max(1, n_total // copies)
+    F = max(1, M // 4)
+    r = np.arange(start, start + n, dtype=np.uint64)
+    mol = stream_hash(seed, 0, r) % np.uint64(M)                      # (n,)
+    ins = stream_hash(seed, 1, mol) % np.uint64(F)                    # (n,)
+    out = np.empty((n, length), dtype=np.uint8)
+    thr_n = np.uint64(rate_threshold(n_rate))
+    thr_s = np.uint64(rate_threshold(n_rate) + rate_threshold(sub_rate))
+    rest = length - umi
+    for b in range(length):
+        if b < umi:
+            true = stream_hash(seed, 2, mol * np.uint64(umi) + np.uint64(b)) & np.uint64(3)
+        else:
+            true = stream_hash(seed, 3, ins * np.uint64(rest) + np.uint64(b - umi)) & np.uint64(3)
+        e = stream_hash(seed, 4, r * np.uint64(length) + np.uint64(b))
+        u = e >> np.uint64(11)
+        shift = np.uint64(1) + (e & np.uint64(0x7FF)) % np.uint64(3)
+        sub = (true + shift) & np.uint64(3)
+        code = np.where(u < thr_s, sub, true).astype(np.int64)
+        col = BASES[code]
+        col = np.where(u < thr_n, np.uint8(ord("N")), col)
+        out[:, b] = col
+    return out
+
+
+def fixed_offsets(n: int, length: int) -> np.ndarray:
+    return np.arange(n + 1, dtype=np.uint64) * np.uint64(length)
