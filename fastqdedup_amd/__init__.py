@@ -1,5 +1,20 @@
-"""fastqdedup_amd -- MI355X-native clustering hot path of fastqdedup.
+"""fastqdedup_amd -- the clustering hot path of fastqdedup on MI355X (gfx950).
 
-Placeholder; the host-side mirror of the reference interface is filled in
-below as the HIP library lands.
+Drop-in for the reference's ``Trie`` / ``within_distance`` /
+``cluster_dissection_*`` surface (reference src/fastqdedup/__init__.py:32-34,
+60-130), implemented as hand-written HIP kernels behind a C ABI
+(include/fqdedup_hip.h). No CPU fallback: without ``libfqdedup_hip.so`` and a
+gfx950 device every entry point raises.
 """
+from .core import (CLUSTER_DISSECTION_METHODS, DEFAULT_MAX_DISTANCE, ClusterResult, Trie,
+                   cluster_dissection_adjacency, cluster_dissection_directional,
+                   cluster_dissection_highest_count, cluster_keys, default_context,
+                   pack_strings, within_distance)
+from ._lib import Context
+
+__all__ = [
+    "CLUSTER_DISSECTION_METHODS", "ClusterResult", "Context", "DEFAULT_MAX_DISTANCE", "Trie",
+    "cluster_dissection_adjacency", "cluster_dissection_directional",
+    "cluster_dissection_highest_count", "cluster_keys", "default_context", "pack_strings",
+    "within_distance",
+]

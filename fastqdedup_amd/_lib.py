@@ -1,0 +1,343 @@
+"""ctypes binding of ``libfqdedup_hip.so`` (C ABI: include/fqdedup_hip.h).
+
+There is no CPU fallback anywhere in this package: if the library is missing or
+no gfx950 device is visible, ``load()`` / ``Context()`` raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfqdedup_hip.so")
+
+HOST, DEVICE = 0, 1
+METRIC_HAMMING, METRIC_EDIT = 0, 1
+METHODS = {"highest_count": 0, "adjacency": 1, "directional": 2}
+T_PACK, T_COLLAPSE, T_EDGES, T_COMPONENTS, T_DISSECT, T_PAIRS_KERNEL, T_COUNT = 0, 1, 2, 3, 4, 5, 8
+
+E_NOMEM, E_VALUE, E_LOOKUP, E_RUNTIME, E_DEVICE, E_STATE = -1, -2, -3, -4, -5, -6
+
+
+class Summary(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_counted", C.c_uint64), ("n_unique", C.c_uint64),
+                ("n_edges", C.c_uint64), ("n_clusters", C.c_uint64), ("n_kept", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class Shape(C.Structure):
+    _fields_ = [("planes", C.c_uint32), ("words", C.c_uint32), ("stride_words", C.c_uint32),
+                ("max_len", C.c_uint32), ("ragged", C.c_uint32), ("alphabet_size", C.c_uint32),
+                ("alphabet", C.c_uint8 * 128)]
+
+
+# every symbol include/fqdedup_hip.h declares (tests check the library exports them all)
+EXPORTS = [
+    "fqd_device_count", "fqd_global_error", "fqd_create", "fqd_destroy", "fqd_last_error",
+    "fqd_synchronize", "fqd_pack_keys", "fqd_configure", "fqd_scan_keys", "fqd_get_shape",
+    "fqd_collapse", "fqd_find_edges", "fqd_components", "fqd_dissect", "fqd_cluster",
+    "fqd_get_kept_read_ids", "fqd_get_unique_table", "fqd_export_packed", "fqd_import_packed",
+    "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
+    "fqd_within_distance", "fqd_contains", "fqd_stage_times", "fqd_edge_stats", "fqd_synth_keys",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m fastqdedup_amd.build` "
+            "(hipcc --offload-arch=gfx950). fastqdedup_amd has no CPU fallback.")
+    # torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's). Two HIP
+    # runtimes in one process fight over the device, so when torch is installed it
+    # is imported FIRST and the dynamic loader then binds this library to the
+    # runtime torch already loaded. Without torch the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
+    L.fqd_device_count.restype = C.c_int
+    L.fqd_global_error.restype = C.c_char_p
+    L.fqd_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.fqd_destroy.argtypes = [vp]
+    L.fqd_destroy.restype = None
+    L.fqd_last_error.argtypes = [vp]
+    L.fqd_last_error.restype = C.c_char_p
+    L.fqd_synchronize.argtypes = [vp]
+    L.fqd_pack_keys.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int]
+    L.fqd_configure.argtypes = [vp, vp, C.c_uint32, C.c_int]
+    L.fqd_scan_keys.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, vp,
+                                C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    L.fqd_get_shape.argtypes = [vp, C.POINTER(Shape)]
+    L.fqd_collapse.argtypes = [vp, vp, vp, C.c_int, u64p]
+    L.fqd_find_edges.argtypes = [vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32, u64p]
+    L.fqd_components.argtypes = [vp, u64p]
+    L.fqd_dissect.argtypes = [vp, C.c_int, u64p]
+    L.fqd_cluster.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Summary)]
+    L.fqd_get_kept_read_ids.argtypes = [vp, vp, C.c_int]
+    L.fqd_get_unique_table.argtypes = [vp, vp, vp, vp, vp, C.c_int]
+    L.fqd_export_packed.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.fqd_import_packed.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
+    L.fqd_export_unique.argtypes = [vp, vp, vp, vp, vp, C.c_int]
+    L.fqd_import_unique.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_int]
+    L.fqd_export_edges.argtypes = [vp, vp, C.c_int]
+    L.fqd_import_edges.argtypes = [vp, vp, C.c_uint64, C.c_int]
+    L.fqd_within_distance.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, C.c_int]
+    L.fqd_contains.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, C.c_int]
+    L.fqd_stage_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.fqd_edge_stats.argtypes = [vp, u64p, u64p, u64p]
+    L.fqd_synth_keys.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                 C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]
+    _lib = L
+    return L
+
+
+def _raise(code: int, msg: str):
+    if code == E_NOMEM:
+        raise MemoryError(msg)
+    if code == E_VALUE:
+        raise ValueError(msg)
+    if code == E_LOOKUP:
+        raise LookupError(msg)
+    raise RuntimeError(msg)
+
+
+def _ptr_mem(x):
+    """(pointer, mem kind, keepalive) of a numpy array (host) or torch tensor (device/host)."""
+    if x is None:
+        return None, HOST, None
+    if isinstance(x, np.ndarray):
+        if not x.flags["C_CONTIGUOUS"]:
+            x = np.ascontiguousarray(x)
+        return x.ctypes.data if x.size else _EMPTY.ctypes.data, HOST, x
+    if hasattr(x, "data_ptr"):  # torch tensor
+        if not x.is_contiguous():
+            x = x.contiguous()
+        return x.data_ptr() or _EMPTY.ctypes.data, (DEVICE if x.is_cuda else HOST), x
+    raise TypeError(f"expected numpy array or torch tensor, got {type(x).__name__}")
+
+
+_EMPTY = np.zeros(16, dtype=np.uint8)
+
+
+class Context:
+    """One device + one HIP stream + the workspace of one clustering job."""
+
+    def __init__(self, device: int = 0):
+        L = load()
+        h = C.c_void_p()
+        rc = L.fqd_create(int(device), C.byref(h))
+        if rc:
+            _raise(rc, L.fqd_global_error().decode())
+        self._h = h
+        self._L = L
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fqd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc: int):
+        if rc:
+            _raise(rc, self._L.fqd_last_error(self._h).decode())
+
+    # ---- stages ---------------------------------------------------------------
+    def _same_mem(self, *kinds):
+        ks = {k for k, present in kinds if present}
+        if len(ks) > 1:
+            raise ValueError("all buffers of one call must live on the same side (host or device)")
+        return ks.pop() if ks else HOST
+
+    def pack_keys(self, keys, offsets=None, key_len: int = 0):
+        kp, km, _k = _ptr_mem(keys)
+        op, om, _o = _ptr_mem(offsets)
+        if offsets is None:
+            nbytes = keys.numel() if hasattr(keys, "numel") else keys.size
+            if key_len <= 0:
+                if nbytes:
+                    raise ValueError("key_len must be positive when offsets is None")
+                n = 0
+            else:
+                if nbytes % key_len:
+                    raise ValueError("key buffer is not a multiple of key_len")
+                n = nbytes // key_len
+        else:
+            n = (offsets.numel() if hasattr(offsets, "numel") else offsets.size) - 1
+            if n < 0:
+                raise ValueError("offsets needs n+1 entries")
+        mem = self._same_mem((km, True), (om, offsets is not None))
+        self._ck(self._L.fqd_pack_keys(self._h, kp, op, n, int(key_len), mem))
+        return n
+
+    def configure(self, present128: Optional[np.ndarray], max_len: int = 0, ragged: bool = False):
+        if present128 is None:
+            self._ck(self._L.fqd_configure(self._h, None, 0, 0))
+            return
+        p = np.ascontiguousarray(present128, dtype=np.uint8)
+        assert p.size == 128
+        self._ck(self._L.fqd_configure(self._h, p.ctypes.data, int(max_len), int(bool(ragged))))
+
+    def scan_keys(self, keys, offsets=None, key_len: int = 0):
+        kp, km, _k = _ptr_mem(keys)
+        op, om, _o = _ptr_mem(offsets)
+        if offsets is None:
+            nbytes = keys.numel() if hasattr(keys, "numel") else keys.size
+            n = nbytes // key_len if key_len else 0
+        else:
+            n = (offsets.numel() if hasattr(offsets, "numel") else offsets.size) - 1
+        mem = self._same_mem((km, True), (om, offsets is not None))
+        present = np.zeros(128, dtype=np.uint8)
+        max_len, ragged = C.c_uint32(0), C.c_int(0)
+        self._ck(self._L.fqd_scan_keys(self._h, kp, op, n, int(key_len), mem, present.ctypes.data,
+                                       C.byref(max_len), C.byref(ragged)))
+        return present, int(max_len.value), bool(ragged.value)
+
+    def shape(self) -> Shape:
+        s = Shape()
+        self._ck(self._L.fqd_get_shape(self._h, C.byref(s)))
+        return s
+
+    def collapse(self, weights=None, read_ids=None) -> int:
+        wp, wm, _w = _ptr_mem(weights)
+        rp, rm, _r = _ptr_mem(read_ids)
+        mem = self._same_mem((wm, weights is not None), (rm, read_ids is not None))
+        u = C.c_uint64(0)
+        self._ck(self._L.fqd_collapse(self._h, wp, rp, mem, C.byref(u)))
+        return int(u.value)
+
+    def find_edges(self, max_distance: int, metric: int = METRIC_HAMMING, shard: int = 0,
+                   n_shards: int = 1) -> int:
+        e = C.c_uint64(0)
+        self._ck(self._L.fqd_find_edges(self._h, int(max_distance), int(metric), int(shard),
+                                        int(n_shards), C.byref(e)))
+        return int(e.value)
+
+    def components(self) -> int:
+        v = C.c_uint64(0)
+        self._ck(self._L.fqd_components(self._h, C.byref(v)))
+        return int(v.value)
+
+    def dissect(self, method: int) -> int:
+        v = C.c_uint64(0)
+        self._ck(self._L.fqd_dissect(self._h, int(method), C.byref(v)))
+        return int(v.value)
+
+    def cluster(self, weights=None, read_ids=None, *, max_distance: int = 1,
+                metric: int = METRIC_HAMMING, method: int = 2) -> dict:
+        wp, wm, _w = _ptr_mem(weights)
+        rp, rm, _r = _ptr_mem(read_ids)
+        mem = self._same_mem((wm, weights is not None), (rm, read_ids is not None))
+        s = Summary()
+        self._ck(self._L.fqd_cluster(self._h, wp, rp, mem, int(max_distance), int(metric),
+                                     int(method), C.byref(s)))
+        return s.as_dict()
+
+    # ---- results --------------------------------------------------------------
+    def kept_read_ids(self, n_kept: int, out=None):
+        if out is None:
+            out = np.empty(n_kept, dtype=np.uint64)
+        op, om, _o = _ptr_mem(out)
+        self._ck(self._L.fqd_get_kept_read_ids(self._h, op, om))
+        return out
+
+    def unique_table(self, n_unique: int, labels: bool = True, kept: bool = True):
+        first = np.empty(n_unique, dtype=np.uint64)
+        counts = np.empty(n_unique, dtype=np.uint32)
+        lab = np.empty(n_unique, dtype=np.uint32) if labels else None
+        kp = np.empty(n_unique, dtype=np.uint8) if kept else None
+        self._ck(self._L.fqd_get_unique_table(
+            self._h, first.ctypes.data, counts.ctypes.data,
+            lab.ctypes.data if labels else None, kp.ctypes.data if kept else None, HOST))
+        return first, counts, lab, kp
+
+    # ---- exchange (raw pointers; the caller owns the buffers) ----------------------
+    def export_packed(self, recs, lens, hashes):
+        rp, rm, _1 = _ptr_mem(recs)
+        lp, lm, _2 = _ptr_mem(lens)
+        hp, hm, _3 = _ptr_mem(hashes)
+        self._ck(self._L.fqd_export_packed(self._h, rp, lp, hp, rm))
+
+    def import_packed(self, recs, lens, n: int):
+        rp, rm, _1 = _ptr_mem(recs)
+        lp, lm, _2 = _ptr_mem(lens)
+        self._ck(self._L.fqd_import_packed(self._h, rp, lp, int(n), rm))
+
+    def export_unique(self, recs, lens, counts, first_ids):
+        rp, rm, _1 = _ptr_mem(recs)
+        lp, _m, _2 = _ptr_mem(lens)
+        cp, _m, _3 = _ptr_mem(counts)
+        fp, _m, _4 = _ptr_mem(first_ids)
+        self._ck(self._L.fqd_export_unique(self._h, rp, lp, cp, fp, rm))
+
+    def import_unique(self, recs, lens, counts, first_ids, n_unique: int):
+        rp, rm, _1 = _ptr_mem(recs)
+        lp, _m, _2 = _ptr_mem(lens)
+        cp, _m, _3 = _ptr_mem(counts)
+        fp, _m, _4 = _ptr_mem(first_ids)
+        self._ck(self._L.fqd_import_unique(self._h, rp, lp, cp, fp, int(n_unique), rm))
+
+    def export_edges(self, uv):
+        p, m, _ = _ptr_mem(uv)
+        self._ck(self._L.fqd_export_edges(self._h, p, m))
+
+    def import_edges(self, uv, n_edges: int):
+        p, m, _ = _ptr_mem(uv)
+        self._ck(self._L.fqd_import_edges(self._h, p, int(n_edges), m))
+
+    # ---- single calls ---------------------------------------------------------
+    def within_distance(self, a_bytes, a_off, b_bytes, b_off, max_distance: int, metric: int):
+        n = len(a_off) - 1
+        out = np.zeros(max(n, 1), dtype=np.uint8)
+        self._ck(self._L.fqd_within_distance(
+            self._h, a_bytes.ctypes.data, a_off.ctypes.data, b_bytes.ctypes.data, b_off.ctypes.data,
+            n, int(max_distance), int(metric), out.ctypes.data, HOST))
+        return out[:n]
+
+    def contains(self, q_bytes, q_off, max_distance: int, metric: int):
+        n = len(q_off) - 1
+        out = np.zeros(max(n, 1), dtype=np.uint8)
+        self._ck(self._L.fqd_contains(self._h, q_bytes.ctypes.data, q_off.ctypes.data, n,
+                                      int(max_distance), int(metric), out.ctypes.data, HOST))
+        return out[:n]
+
+    # ---- measurement ------------------------------------------------------------
+    def stage_times(self):
+        ms = (C.c_float * T_COUNT)()
+        ln = (C.c_uint32 * T_COUNT)()
+        self._ck(self._L.fqd_stage_times(self._h, ms, ln))
+        names = ["pack", "collapse", "edges", "components", "dissect", "pairs_kernel"]
+        return ({k: float(ms[i]) for i, k in enumerate(names)},
+                {k: int(ln[i]) for i, k in enumerate(names)})
+
+    def edge_stats(self):
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._L.fqd_edge_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"keys_gathered": int(a.value), "pairs_compared": int(b.value), "edges": int(c.value)}
+
+    def synth_keys(self, out_tensor, n_total: int, start: int, count: int, length: int, umi: int,
+                   seed: int, copies: int = 4, sub_rate: float = 1e-3, n_rate: float = 1e-4):
+        from .synth import rate_threshold
+        self._ck(self._L.fqd_synth_keys(self._h, out_tensor.data_ptr(), n_total, start, count, length,
+                                        umi, seed, copies, rate_threshold(n_rate),
+                                        rate_threshold(sub_rate)))
+
+    def synchronize(self):
+        self._ck(self._L.fqd_synchronize(self._h))

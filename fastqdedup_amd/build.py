@@ -1,0 +1,55 @@
+"""Builds ``libfqdedup_hip.so`` in-tree with hipcc for gfx950 (cross-compiles
+without a GPU). ``python -m fastqdedup_amd.build`` or ``__graft_entry__.build()``."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libfqdedup_hip.so")
+SOURCES = ["api.hip", "prims.hip", "pack.hip", "collapse.hip", "edges.hip", "graph.hip", "synth.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    headers = [os.path.join(CSRC, "fqd_internal.h"),
+               os.path.join(os.path.dirname(HERE), "include", "fqdedup_hip.h")]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + headers):
+            jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(f"{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr:
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,1030 @@
+// api.hip -- the C ABI of libfqdedup_hip.so (include/fqdedup_hip.h): context,
+// device buffers, stage orchestration, HIP-event timing. No kernels here.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fqdedup_hip.h"
+#include "fqd_internal.h"
+
+namespace {
+
+std::string g_global_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return hipSuccess;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = ((bytes + (bytes >> 4)) + 4095) & ~(size_t)4095;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess)
+            cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+enum Stage { ST_EMPTY = 0, ST_PACKED = 1, ST_UNIQUE = 2, ST_EDGES = 3, ST_LABELS = 4, ST_KEPT = 5 };
+
+// small device-side words read back by the host
+enum Ctr { C_BAD = 0, C_COLLISIONS = 1, C_CHANGED = 2, C_MINLEN = 3, C_MAXLEN = 4, C_N32 = 8 };
+enum Ctr64 { C64_EDGES = 0, C64_ROOTS = 1, C64_SUM = 2, C64_STATS = 3 /* 3,4,5 */, C64_N = 8 };
+
+}  // namespace
+
+struct fqd_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::string err;
+    int stage = ST_EMPTY;
+
+    bool forced = false;
+    uint8_t forced_present[128];
+    uint32_t forced_max_len = 0;
+    int forced_ragged = 0;
+
+    fqd_shape shape{};
+    KeyShape ks{};
+    DevBuf d_lut, d_ctr32, d_ctr64, d_present;
+
+    // stage 1
+    uint64_t n = 0;
+    DevBuf in_bytes, in_offsets, recs, lens, hashes;
+    // stage 2
+    uint64_t U = 0, n_counted = 0;
+    bool collapsed = false;  // unique table came from fqd_collapse (keys are pairwise distinct)
+    DevBuf in_weights, in_read_ids, hs_sorted, ids, ids_sorted, flags, run_idx, run_start, run_weight, live_flag,
+        live_idx, collision_runs;
+    DevBuf urecs, ulens, ucounts, ufirst;
+    // stage 3
+    uint64_t E = 0, edge_cap = 0;
+    DevBuf seg_hashes, sorted_hash, sorted_uid, uid_iota, edges;
+    fqd::PairStats last_stats{};
+    // stage 4
+    uint64_t n_clusters = 0;
+    DevBuf labels;
+    // stage 5
+    uint64_t n_kept = 0;
+    DevBuf best, state, blocked, kept, kept_u32, kept_scan, kept_ids, kept_ids_sorted;
+    // scratch
+    DevBuf tmp, stage_a, stage_b, stage_c, stage_d;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+    float ms[FQD_T_COUNT] = {0};
+    uint32_t launches[FQD_T_COUNT] = {0};
+};
+
+namespace {
+
+int fail(fqd_ctx *c, int code, const std::string &msg)
+{
+    if (c)
+        c->err = msg;
+    return code;
+}
+
+int hip_fail(fqd_ctx *c, hipError_t e, const char *what)
+{
+    // clear the sticky error so later calls report their own
+    (void)hipGetLastError();
+    return fail(c, e == hipErrorOutOfMemory ? FQD_E_NOMEM : FQD_E_DEVICE,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(c, call)                         \
+    do {                                         \
+        hipError_t e_ = (call);                  \
+        if (e_ != hipSuccess)                    \
+            return hip_fail((c), e_, #call);     \
+    } while (0)
+
+#define FQD_TRY(call)        \
+    do {                     \
+        int rc_ = (call);    \
+        if (rc_ != FQD_OK)   \
+            return rc_;      \
+    } while (0)
+
+int bind(fqd_ctx *c)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    return FQD_OK;
+}
+
+// Returns a device pointer for a caller buffer: the buffer itself (FQD_DEVICE)
+// or a staged copy (FQD_HOST).
+template <typename T>
+int to_device(fqd_ctx *c, const T *src, size_t count, int mem, DevBuf &staging, const T **out)
+{
+    if (!src) {
+        *out = nullptr;
+        return FQD_OK;
+    }
+    if (mem == FQD_DEVICE) {
+        *out = src;
+        return FQD_OK;
+    }
+    HIP_TRY(c, staging.reserve(count * sizeof(T) + 16));
+    if (count)
+        HIP_TRY(c, hipMemcpyAsync(staging.p, src, count * sizeof(T), hipMemcpyHostToDevice, c->st));
+    *out = staging.as<T>();
+    return FQD_OK;
+}
+
+template <typename T>
+int from_device(fqd_ctx *c, T *dst, const void *src, size_t count, int mem)
+{
+    if (!dst || !count)
+        return FQD_OK;
+    HIP_TRY(c, hipMemcpyAsync(dst, src, count * sizeof(T),
+                              mem == FQD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    return FQD_OK;
+}
+
+int read_ctr32(fqd_ctx *c, int idx, uint32_t *v)
+{
+    HIP_TRY(c, hipMemcpyAsync(v, c->d_ctr32.as<uint32_t>() + idx, 4, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    return FQD_OK;
+}
+
+int read_ctr64(fqd_ctx *c, int idx, unsigned long long *v, int count = 1)
+{
+    HIP_TRY(c, hipMemcpyAsync(v, c->d_ctr64.as<unsigned long long>() + idx, 8 * (size_t)count,
+                              hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    return FQD_OK;
+}
+
+int zero_ctr32(fqd_ctx *c, int idx, int count = 1)
+{
+    HIP_TRY(c, hipMemsetAsync(c->d_ctr32.as<uint32_t>() + idx, 0, 4 * (size_t)count, c->st));
+    return FQD_OK;
+}
+
+int zero_ctr64(fqd_ctx *c, int idx, int count = 1)
+{
+    HIP_TRY(c, hipMemsetAsync(c->d_ctr64.as<unsigned long long>() + idx, 0, 8 * (size_t)count, c->st));
+    return FQD_OK;
+}
+
+struct StageTimer {
+    fqd_ctx *c;
+    int slot;
+    StageTimer(fqd_ctx *ctx, int s) : c(ctx), slot(s) { (void)hipEventRecord(c->ev0, c->st); }
+    void stop()
+    {
+        (void)hipEventRecord(c->ev1, c->st);
+        (void)hipEventSynchronize(c->ev1);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess)
+            c->ms[slot] = ms;
+        c->launches[slot] = 1;
+    }
+};
+
+void build_alphabet(fqd_ctx *c, const uint8_t *present128, uint8_t *lut256)
+{
+    memset(lut256, 0xFF, 256);
+    memset(&c->shape.alphabet, 0, sizeof c->shape.alphabet);
+    uint32_t a = 0;
+    for (int b = 0; b < 128; b++)
+        if (present128[b]) {
+            lut256[b] = (uint8_t)a;
+            c->shape.alphabet[a] = (uint8_t)b;
+            a++;
+        }
+    c->shape.alphabet_size = a;
+    uint32_t k = 1;
+    while ((1u << k) < a)
+        k++;
+    c->shape.planes = k;
+}
+
+int set_geometry(fqd_ctx *c, uint32_t max_len, int ragged)
+{
+    c->shape.max_len = max_len;
+    c->shape.ragged = ragged ? 1 : 0;
+    c->shape.words = std::max<uint32_t>(1, (max_len + 31) / 32);
+    const uint64_t kw = (uint64_t)c->shape.planes * c->shape.words;
+    if (kw > 14000)
+        return fail(c, FQD_E_VALUE, "key of " + std::to_string(max_len) + " bases is too long for the LDS pack tile");
+    c->shape.stride_words = (uint32_t)((kw + 3) & ~3ull);
+    c->ks.planes = c->shape.planes;
+    c->ks.words = c->shape.words;
+    c->ks.stride = c->shape.stride_words;
+    c->ks.max_len = max_len;
+    c->ks.ragged = c->shape.ragged;
+    return FQD_OK;
+}
+
+int scan_keys_device(fqd_ctx *c, const uint8_t *d_bytes, const uint64_t *d_offsets, uint64_t n, uint64_t n_bytes,
+                     uint32_t fixed_len, uint8_t *present128, uint32_t *max_len, int *ragged)
+{
+    HIP_TRY(c, c->d_present.reserve(256 * 4));
+    HIP_TRY(c, hipMemsetAsync(c->d_present.p, 0, 256 * 4, c->st));
+    HIP_TRY(c, fqd::launch_scan_bytes(d_bytes, n_bytes, c->d_present.as<uint32_t>(), c->st));
+    uint32_t mm[2] = {fixed_len, fixed_len};
+    if (d_offsets && n) {
+        const uint32_t init[2] = {0xFFFFFFFFu, 0u};
+        HIP_TRY(c, hipMemcpyAsync(c->d_ctr32.as<uint32_t>() + C_MINLEN, init, 8, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(c, fqd::launch_scan_lens(d_offsets, n, c->d_ctr32.as<uint32_t>() + C_MINLEN, c->st));
+        HIP_TRY(c, hipMemcpyAsync(mm, c->d_ctr32.as<uint32_t>() + C_MINLEN, 8, hipMemcpyDeviceToHost, c->st));
+    } else if (!n) {
+        mm[0] = mm[1] = 0;
+    }
+    uint32_t seen[256];
+    HIP_TRY(c, hipMemcpyAsync(seen, c->d_present.p, sizeof seen, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    for (int b = 128; b < 256; b++)
+        if (seen[b])
+            return fail(c, FQD_E_VALUE, "Sequence must consist only of ASCII characters");
+    for (int b = 0; b < 128; b++)
+        present128[b] = seen[b] ? 1 : 0;
+    *max_len = mm[1];
+    *ragged = mm[0] != mm[1];
+    return FQD_OK;
+}
+
+uint64_t total_bytes_of(const uint64_t *offsets_host_or_null, uint64_t n, uint32_t fixed_len)
+{
+    return offsets_host_or_null ? offsets_host_or_null[n] : n * (uint64_t)fixed_len;
+}
+
+int sort_u64_pairs(fqd_ctx *c, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n,
+                   int bits)
+{
+    const size_t need = fqd::sort_pairs_u64_u32_temp(n, 0, bits);
+    HIP_TRY(c, c->tmp.reserve(need + 16));
+    HIP_TRY(c, fqd::sort_pairs_u64_u32(c->tmp.p, need, kin, kout, vin, vout, n, 0, bits, c->st));
+    return FQD_OK;
+}
+
+int sort_u32_pairs(fqd_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n)
+{
+    const size_t need = fqd::sort_pairs_u32_u32_temp(n, 0, 32);
+    HIP_TRY(c, c->tmp.reserve(need + 16));
+    HIP_TRY(c, fqd::sort_pairs_u32_u32(c->tmp.p, need, kin, kout, vin, vout, n, 0, 32, c->st));
+    return FQD_OK;
+}
+
+int scan_u32(fqd_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n)
+{
+    const size_t need = fqd::scan_u32_temp(n);
+    HIP_TRY(c, c->tmp.reserve(need + 16));
+    HIP_TRY(c, fqd::inclusive_scan_u32(c->tmp.p, need, in, out, n, c->st));
+    return FQD_OK;
+}
+
+int hash_bits_from_env()
+{
+    const char *e = getenv("FQD_HASH_BITS");  // tests narrow the hash to force collisions
+    if (!e)
+        return 64;
+    int b = atoi(e);
+    return b < 1 ? 1 : (b > 64 ? 64 : b);
+}
+
+}  // namespace
+
+// =============================================================================
+extern "C" {
+
+int fqd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char *fqd_global_error(void) { return g_global_error.c_str(); }
+
+int fqd_create(int device, fqd_ctx **out)
+{
+    if (!out)
+        return FQD_E_VALUE;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        g_global_error = "no HIP device visible: libfqdedup_hip needs an MI355X (gfx950); there is no CPU fallback";
+        return FQD_E_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        g_global_error = "device ordinal out of range";
+        return FQD_E_VALUE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        g_global_error = "hipGetDeviceProperties failed";
+        return FQD_E_DEVICE;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_global_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return FQD_E_DEVICE;
+    }
+    fqd_ctx *c = new fqd_ctx();
+    c->device = device;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&c->st) == hipSuccess &&
+              hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+              hipEventCreate(&c->evk0) == hipSuccess && hipEventCreate(&c->evk1) == hipSuccess &&
+              c->d_ctr32.reserve(C_N32 * 4) == hipSuccess && c->d_ctr64.reserve(C64_N * 8) == hipSuccess &&
+              c->d_lut.reserve(256) == hipSuccess;
+    if (!ok) {
+        g_global_error = "could not create stream/events/buffers on the device";
+        fqd_destroy(c);
+        return FQD_E_DEVICE;
+    }
+    *out = c;
+    return FQD_OK;
+}
+
+void fqd_destroy(fqd_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    if (c->st)
+        (void)hipStreamSynchronize(c->st);
+    DevBuf *bufs[] = {&c->d_lut, &c->d_ctr32, &c->d_ctr64, &c->d_present, &c->in_bytes, &c->in_offsets, &c->recs,
+                      &c->lens, &c->hashes, &c->in_weights, &c->in_read_ids, &c->hs_sorted, &c->ids, &c->ids_sorted,
+                      &c->flags, &c->run_idx, &c->run_start, &c->run_weight, &c->live_flag, &c->live_idx,
+                      &c->collision_runs, &c->urecs, &c->ulens, &c->ucounts, &c->ufirst, &c->seg_hashes,
+                      &c->sorted_hash, &c->sorted_uid, &c->uid_iota, &c->edges, &c->labels, &c->best, &c->state,
+                      &c->blocked, &c->kept, &c->kept_u32, &c->kept_scan, &c->kept_ids, &c->kept_ids_sorted, &c->tmp,
+                      &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d};
+    for (DevBuf *b : bufs)
+        b->release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->evk0) (void)hipEventDestroy(c->evk0);
+    if (c->evk1) (void)hipEventDestroy(c->evk1);
+    if (c->st) (void)hipStreamDestroy(c->st);
+    delete c;
+}
+
+const char *fqd_last_error(const fqd_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int fqd_synchronize(fqd_ctx *c)
+{
+    FQD_TRY(bind(c));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    return FQD_OK;
+}
+
+int fqd_configure(fqd_ctx *c, const uint8_t *present128, uint32_t max_len, int ragged)
+{
+    if (!present128) {
+        c->forced = false;
+        return FQD_OK;
+    }
+    for (int b = 0; b < 128; b++)
+        c->forced_present[b] = present128[b] ? 1 : 0;
+    c->forced = true;
+    c->forced_max_len = max_len;
+    c->forced_ragged = ragged;
+    return FQD_OK;
+}
+
+int fqd_scan_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, uint32_t fixed_len, int mem,
+                  uint8_t *present128, uint32_t *max_len, int *ragged)
+{
+    FQD_TRY(bind(c));
+    uint64_t n_bytes;
+    if (offsets) {
+        if (mem == FQD_HOST) {
+            n_bytes = offsets[n];
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(&n_bytes, offsets + n, 8, hipMemcpyDeviceToHost, c->st));
+            HIP_TRY(c, hipStreamSynchronize(c->st));
+        }
+    } else {
+        n_bytes = n * (uint64_t)fixed_len;
+    }
+    const uint8_t *d_bytes;
+    const uint64_t *d_off;
+    FQD_TRY(to_device(c, bytes, (size_t)n_bytes, mem, c->in_bytes, &d_bytes));
+    FQD_TRY(to_device(c, offsets, offsets ? (size_t)n + 1 : 0, mem, c->in_offsets, &d_off));
+    return scan_keys_device(c, d_bytes, offsets ? d_off : nullptr, n, n_bytes, fixed_len, present128, max_len, ragged);
+}
+
+int fqd_get_shape(const fqd_ctx *c, fqd_shape *out)
+{
+    if (!c || !out)
+        return FQD_E_VALUE;
+    *out = c->shape;
+    return FQD_OK;
+}
+
+int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, uint32_t fixed_len, int mem)
+{
+    FQD_TRY(bind(c));
+    c->stage = ST_EMPTY;
+    if (n >= 0xFFFFFFF0ull)
+        return fail(c, FQD_E_VALUE, "at most 2^32-16 keys per context");
+    if (mem == FQD_DEVICE && ((uintptr_t)bytes & 3u))
+        return fail(c, FQD_E_VALUE, "device key buffer must be 4-byte aligned");
+    uint64_t n_bytes;
+    if (offsets) {
+        if (mem == FQD_HOST) {
+            n_bytes = n ? offsets[n] : 0;
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(&n_bytes, offsets + n, 8, hipMemcpyDeviceToHost, c->st));
+            HIP_TRY(c, hipStreamSynchronize(c->st));
+        }
+    } else {
+        n_bytes = n * (uint64_t)fixed_len;
+    }
+    StageTimer timer(c, FQD_T_PACK);
+    const uint8_t *d_bytes;
+    const uint64_t *d_off = nullptr;
+    FQD_TRY(to_device(c, bytes, (size_t)n_bytes, mem, c->in_bytes, &d_bytes));
+    if (offsets)
+        FQD_TRY(to_device(c, offsets, (size_t)n + 1, mem, c->in_offsets, &d_off));
+
+    uint8_t present[128], lut[256];
+    uint32_t max_len = fixed_len;
+    int ragged = 0;
+    if (c->forced) {
+        memcpy(present, c->forced_present, 128);
+        max_len = c->forced_max_len;
+        ragged = c->forced_ragged;
+        if (!offsets && fixed_len != max_len)
+            ragged = 1;
+    } else {
+        FQD_TRY(scan_keys_device(c, d_bytes, d_off, n, n_bytes, fixed_len, present, &max_len, &ragged));
+    }
+    build_alphabet(c, present, lut);
+    FQD_TRY(set_geometry(c, max_len, ragged));
+    HIP_TRY(c, hipMemcpyAsync(c->d_lut.p, lut, 256, hipMemcpyHostToDevice, c->st));
+
+    const KeyShape sh = c->ks;
+    HIP_TRY(c, c->recs.reserve((size_t)n * sh.stride * 4 + 16));
+    HIP_TRY(c, c->hashes.reserve((size_t)n * 8 + 16));
+    if (sh.ragged)
+        HIP_TRY(c, c->lens.reserve((size_t)n * 4 + 16));
+    FQD_TRY(zero_ctr32(c, C_BAD));
+    HIP_TRY(c, fqd::launch_pack(d_bytes, n_bytes, d_off, n, fixed_len, sh, c->d_lut.as<uint8_t>(),
+                                c->recs.as<uint32_t>(), sh.ragged ? c->lens.as<uint32_t>() : nullptr,
+                                c->hashes.as<uint64_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+    uint32_t bad = 0;
+    FQD_TRY(read_ctr32(c, C_BAD, &bad));
+    timer.stop();
+    if (bad)
+        return fail(c, FQD_E_VALUE,
+                    c->forced ? "a key holds a byte outside the configured alphabet"
+                              : "Sequence must consist only of ASCII characters");
+    c->n = n;
+    c->stage = ST_PACKED;
+    return FQD_OK;
+}
+
+int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, int mem, uint64_t *n_unique)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_PACKED)
+        return fail(c, FQD_E_STATE, "fqd_collapse before fqd_pack_keys/fqd_import_packed");
+    c->stage = ST_PACKED;
+    const uint64_t n = c->n;
+    const KeyShape sh = c->ks;
+    StageTimer timer(c, FQD_T_COLLAPSE);
+    c->U = 0;
+    c->n_counted = 0;
+    if (n == 0) {
+        timer.stop();
+        c->stage = ST_UNIQUE;
+        if (n_unique)
+            *n_unique = 0;
+        return FQD_OK;
+    }
+    const uint32_t *d_w;
+    const uint64_t *d_ids;
+    FQD_TRY(to_device(c, weights, (size_t)n, mem, c->in_weights, &d_w));
+    FQD_TRY(to_device(c, read_ids, (size_t)n, mem, c->in_read_ids, &d_ids));
+
+    const int bits = hash_bits_from_env();
+    const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+    HIP_TRY(c, c->hs_sorted.reserve(n * 8 + 16));
+    HIP_TRY(c, c->ids.reserve(n * 4 + 16));
+    HIP_TRY(c, c->ids_sorted.reserve(n * 4 + 16));
+    HIP_TRY(c, c->flags.reserve(n * 4 + 16));
+    HIP_TRY(c, c->run_idx.reserve(n * 4 + 16));
+    HIP_TRY(c, fqd::launch_iota_u32(c->ids.as<uint32_t>(), n, c->st));
+    FQD_TRY(sort_u64_pairs(c, c->hashes.as<uint64_t>(), c->hs_sorted.as<uint64_t>(), c->ids.as<uint32_t>(),
+                           c->ids_sorted.as<uint32_t>(), n, bits));
+
+    uint32_t cap = (uint32_t)std::max<size_t>(1024, c->collision_runs.cap / 4);
+    for (;;) {
+        HIP_TRY(c, c->collision_runs.reserve((size_t)cap * 4));
+        FQD_TRY(zero_ctr32(c, C_COLLISIONS));
+        HIP_TRY(c, fqd::launch_head_flags(c->hs_sorted.as<uint64_t>(), c->ids_sorted.as<uint32_t>(),
+                                          c->recs.as<uint32_t>(), c->lens.as<uint32_t>(), n, sh, mask,
+                                          c->flags.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_COLLISIONS,
+                                          c->collision_runs.as<uint32_t>(), cap, c->st));
+        uint32_t n_coll = 0;
+        FQD_TRY(read_ctr32(c, C_COLLISIONS, &n_coll));
+        if (n_coll > cap) {
+            cap = n_coll + 1024;
+            continue;
+        }
+        HIP_TRY(c, fqd::launch_fix_collision_runs(c->hs_sorted.as<uint64_t>(), c->ids_sorted.as<uint32_t>(),
+                                                  c->recs.as<uint32_t>(), c->lens.as<uint32_t>(), n, sh, mask,
+                                                  c->flags.as<uint32_t>(), c->collision_runs.as<uint32_t>(), n_coll,
+                                                  c->st));
+        break;
+    }
+    FQD_TRY(scan_u32(c, c->flags.as<uint32_t>(), c->run_idx.as<uint32_t>(), n));
+    uint32_t n_runs = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_runs, c->run_idx.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+
+    HIP_TRY(c, c->run_start.reserve(((size_t)n_runs + 1) * 4 + 16));
+    HIP_TRY(c, c->run_weight.reserve((size_t)n_runs * 4 + 16));
+    HIP_TRY(c, c->live_flag.reserve((size_t)n_runs * 4 + 16));
+    HIP_TRY(c, c->live_idx.reserve((size_t)n_runs * 4 + 16));
+    HIP_TRY(c, fqd::launch_run_starts(c->flags.as<uint32_t>(), c->run_idx.as<uint32_t>(), n,
+                                      c->run_start.as<uint32_t>(), c->st));
+    HIP_TRY(c, fqd::launch_run_weights(c->run_start.as<uint32_t>(), n_runs, n, c->ids_sorted.as<uint32_t>(),
+                                       weights ? d_w : nullptr, c->run_weight.as<uint32_t>(),
+                                       c->live_flag.as<uint32_t>(), c->st));
+    FQD_TRY(scan_u32(c, c->live_flag.as<uint32_t>(), c->live_idx.as<uint32_t>(), n_runs));
+    uint32_t U32 = 0;
+    HIP_TRY(c, hipMemcpyAsync(&U32, c->live_idx.as<uint32_t>() + (n_runs - 1), 4, hipMemcpyDeviceToHost, c->st));
+    FQD_TRY(zero_ctr64(c, C64_SUM));
+    HIP_TRY(c, fqd::launch_sum_u32(c->run_weight.as<uint32_t>(), n_runs, c->d_ctr64.as<unsigned long long>() + C64_SUM,
+                                   c->st));
+    unsigned long long counted = 0;
+    FQD_TRY(read_ctr64(c, C64_SUM, &counted));
+    const uint64_t U = U32;
+    HIP_TRY(c, c->urecs.reserve(U * sh.stride * 4 + 16));
+    HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
+    HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
+    HIP_TRY(c, c->ufirst.reserve(U * 8 + 16));
+    HIP_TRY(c, fqd::launch_write_unique(c->run_start.as<uint32_t>(), c->run_weight.as<uint32_t>(),
+                                        c->live_flag.as<uint32_t>(), c->live_idx.as<uint32_t>(), n_runs,
+                                        c->ids_sorted.as<uint32_t>(), c->recs.as<uint32_t>(), c->lens.as<uint32_t>(),
+                                        read_ids ? d_ids : nullptr, sh, c->urecs.as<uint32_t>(),
+                                        c->ulens.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(),
+                                        c->st));
+    timer.stop();
+    c->U = U;
+    c->n_counted = counted;
+    c->collapsed = true;
+    c->stage = ST_UNIQUE;
+    if (n_unique)
+        *n_unique = U;
+    return FQD_OK;
+}
+
+int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uint32_t n_shards, uint64_t *n_edges)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_UNIQUE)
+        return fail(c, FQD_E_STATE, "fqd_find_edges before fqd_collapse/fqd_import_unique");
+    if (max_distance < 0)
+        return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
+    if (n_shards == 0 || shard >= n_shards)
+        return fail(c, FQD_E_VALUE, "bad shard");
+    const KeyShape sh = c->ks;
+    if (metric == FQD_METRIC_EDIT && !(max_distance <= 1 && !sh.ragged))
+        return fail(c, FQD_E_VALUE,
+                    "edit metric on device: only max_distance <= 1 with equal-length keys so far "
+                    "(there Levenshtein <= 1 equals Hamming <= 1)");
+    c->stage = ST_UNIQUE;
+    const uint64_t U = c->U;
+    StageTimer timer(c, FQD_T_EDGES);
+    c->E = 0;
+    c->ms[FQD_T_PAIRS_KERNEL] = 0;
+    c->launches[FQD_T_PAIRS_KERNEL] = 0;
+    c->last_stats = fqd::PairStats{0, 0, 0};
+    FQD_TRY(zero_ctr64(c, C64_EDGES));
+    FQD_TRY(zero_ctr64(c, C64_STATS, 3));
+    if (U >= 2 && (max_distance > 0 || !c->collapsed)) {
+        // with d >= max_len every segment split has empty segments: still correct (all keys of a
+        // length share the empty segment's bucket), just quadratic.
+        const uint32_t d = (uint32_t)max_distance;
+        const uint32_t nseg = d + 1;
+        HIP_TRY(c, c->seg_hashes.reserve((size_t)nseg * U * 4 + 16));
+        HIP_TRY(c, c->sorted_hash.reserve(U * 4 + 16));
+        HIP_TRY(c, c->sorted_uid.reserve(U * 4 + 16));
+        HIP_TRY(c, c->uid_iota.reserve(U * 4 + 16));
+        HIP_TRY(c, fqd::launch_iota_u32(c->uid_iota.as<uint32_t>(), U, c->st));
+        HIP_TRY(c, fqd::launch_segment_hashes(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, sh, nseg,
+                                              c->seg_hashes.as<uint32_t>(), c->st));
+        if (c->edge_cap < 1024 || !c->edges.p) {
+            c->edge_cap = std::max<uint64_t>(1024, U);
+            HIP_TRY(c, c->edges.reserve(c->edge_cap * 8));
+        }
+        c->edge_cap = c->edges.cap / 8;
+        unsigned long long have = 0;
+        for (uint32_t s = 0; s < nseg; s++) {
+            FQD_TRY(sort_u32_pairs(c, c->seg_hashes.as<uint32_t>() + (size_t)s * U, c->sorted_hash.as<uint32_t>(),
+                                   c->uid_iota.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), U));
+            for (;;) {
+                (void)hipEventRecord(c->evk0, c->st);
+                HIP_TRY(c, fqd::launch_bucket_pairs(
+                               c->sorted_hash.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), U,
+                               c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, s, nseg, shard, n_shards,
+                               c->edges.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_EDGES, c->edge_cap,
+                               reinterpret_cast<fqd::PairStats *>(c->d_ctr64.as<unsigned long long>() + C64_STATS),
+                               c->st));
+                (void)hipEventRecord(c->evk1, c->st);
+                unsigned long long now = 0;
+                FQD_TRY(read_ctr64(c, C64_EDGES, &now));
+                float kms = 0;
+                if (hipEventElapsedTime(&kms, c->evk0, c->evk1) == hipSuccess) {
+                    c->ms[FQD_T_PAIRS_KERNEL] += kms;
+                    c->launches[FQD_T_PAIRS_KERNEL] += 1;
+                }
+                if (now <= c->edge_cap) {
+                    have = now;
+                    break;
+                }
+                // the pass overflowed the edge buffer: grow to the known need, keep the
+                // earlier passes' edges, redo this pass
+                DevBuf bigger;
+                HIP_TRY(c, bigger.reserve((size_t)(now + now / 2 + 1024) * 8));
+                if (have)
+                    HIP_TRY(c, hipMemcpyAsync(bigger.p, c->edges.p, (size_t)have * 8, hipMemcpyDeviceToDevice, c->st));
+                HIP_TRY(c, hipStreamSynchronize(c->st));
+                c->edges.release();
+                c->edges = bigger;
+                c->edge_cap = c->edges.cap / 8;
+                HIP_TRY(c, hipMemcpyAsync(c->d_ctr64.as<unsigned long long>() + C64_EDGES, &have, 8,
+                                          hipMemcpyHostToDevice, c->st));
+                HIP_TRY(c, hipStreamSynchronize(c->st));
+            }
+        }
+        c->E = have;
+        unsigned long long st3[3];
+        FQD_TRY(read_ctr64(c, C64_STATS, st3, 3));
+        c->last_stats = fqd::PairStats{st3[0], st3[1], st3[2]};
+    }
+    timer.stop();
+    c->stage = ST_EDGES;
+    if (n_edges)
+        *n_edges = c->E;
+    return FQD_OK;
+}
+
+int fqd_components(fqd_ctx *c, uint64_t *n_clusters)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_EDGES)
+        return fail(c, FQD_E_STATE, "fqd_components before fqd_find_edges/fqd_import_edges");
+    c->stage = ST_EDGES;
+    const uint64_t U = c->U;
+    StageTimer timer(c, FQD_T_COMPONENTS);
+    HIP_TRY(c, c->labels.reserve(U * 4 + 16));
+    FQD_TRY(zero_ctr64(c, C64_ROOTS));
+    HIP_TRY(c, fqd::launch_uf_init(c->labels.as<uint32_t>(), U, c->st));
+    HIP_TRY(c, fqd::launch_uf_union(c->labels.as<uint32_t>(), c->edges.as<uint32_t>(), c->E, c->st));
+    HIP_TRY(c, fqd::launch_uf_flatten(c->labels.as<uint32_t>(), U, c->d_ctr64.as<unsigned long long>() + C64_ROOTS,
+                                      c->st));
+    unsigned long long roots = 0;
+    FQD_TRY(read_ctr64(c, C64_ROOTS, &roots));
+    timer.stop();
+    c->n_clusters = roots;
+    c->stage = ST_LABELS;
+    if (n_clusters)
+        *n_clusters = roots;
+    return FQD_OK;
+}
+
+int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_LABELS)
+        return fail(c, FQD_E_STATE, "fqd_dissect before fqd_components");
+    if (method < 0 || method > 2)
+        return fail(c, FQD_E_VALUE, "unknown cluster dissection method");
+    c->stage = ST_LABELS;
+    const uint64_t U = c->U, E = c->E;
+    const KeyShape sh = c->ks;
+    StageTimer timer(c, FQD_T_DISSECT);
+    HIP_TRY(c, c->best.reserve(U * 4 + 16));
+    HIP_TRY(c, c->state.reserve(U + 16));
+    HIP_TRY(c, c->kept.reserve(U + 16));
+    HIP_TRY(c, c->kept_u32.reserve(U * 4 + 16));
+    HIP_TRY(c, c->kept_scan.reserve(U * 4 + 16));
+    HIP_TRY(c, fqd::launch_dissect_init(c->best.as<uint32_t>(), c->state.as<uint8_t>(), U, c->st));
+    uint32_t *d_changed = c->d_ctr32.as<uint32_t>() + C_CHANGED;
+    if (method == FQD_METHOD_HIGHEST_COUNT) {
+        HIP_TRY(c, fqd::launch_highest_count(c->labels.as<uint32_t>(), c->ucounts.as<uint32_t>(),
+                                             c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, U,
+                                             c->best.as<uint32_t>(), c->st));
+    } else if (method == FQD_METHOD_DIRECTIONAL) {
+        for (uint64_t round = 0; E && round <= U; round++) {
+            FQD_TRY(zero_ctr32(c, C_CHANGED));
+            HIP_TRY(c, fqd::launch_directional_round(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
+                                                     c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh,
+                                                     c->best.as<uint32_t>(), d_changed, c->st));
+            uint32_t changed = 0;
+            FQD_TRY(read_ctr32(c, C_CHANGED, &changed));
+            if (!changed)
+                break;
+        }
+    } else {
+        HIP_TRY(c, c->blocked.reserve(U * 4 + 16));
+        HIP_TRY(c, hipMemsetAsync(c->blocked.p, 0, U * 4, c->st));
+        for (uint64_t round = 1; round <= U + 1; round++) {
+            FQD_TRY(zero_ctr32(c, C_CHANGED));
+            HIP_TRY(c, fqd::launch_adjacency_round(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
+                                                   c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, U,
+                                                   c->state.as<uint8_t>(), c->blocked.as<uint32_t>(), (uint32_t)round,
+                                                   d_changed, c->st));
+            uint32_t changed = 0;
+            FQD_TRY(read_ctr32(c, C_CHANGED, &changed));
+            if (!changed)
+                break;
+        }
+    }
+    c->n_kept = 0;
+    if (U) {
+        HIP_TRY(c, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
+                                          c->state.as<uint8_t>(), U, c->kept.as<uint8_t>(), c->kept_u32.as<uint32_t>(),
+                                          c->st));
+        FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), U));
+        uint32_t nk = 0;
+        HIP_TRY(c, hipMemcpyAsync(&nk, c->kept_scan.as<uint32_t>() + (U - 1), 4, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(c, hipStreamSynchronize(c->st));
+        c->n_kept = nk;
+        HIP_TRY(c, c->kept_ids.reserve((size_t)nk * 8 + 16));
+        HIP_TRY(c, c->kept_ids_sorted.reserve((size_t)nk * 8 + 16));
+        HIP_TRY(c, fqd::launch_gather_kept(c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(),
+                                           c->ufirst.as<uint64_t>(), U, c->kept_ids.as<uint64_t>(), c->st));
+        if (nk) {
+            const size_t need = fqd::sort_keys_u64_temp(nk);
+            HIP_TRY(c, c->tmp.reserve(need + 16));
+            HIP_TRY(c, fqd::sort_keys_u64(c->tmp.p, need, c->kept_ids.as<uint64_t>(),
+                                          c->kept_ids_sorted.as<uint64_t>(), nk, c->st));
+        }
+    }
+    timer.stop();
+    c->stage = ST_KEPT;
+    if (n_kept)
+        *n_kept = c->n_kept;
+    return FQD_OK;
+}
+
+int fqd_cluster(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, int mem, int max_distance, int metric,
+                int method, fqd_summary *out)
+{
+    if (max_distance < 0)
+        return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
+    FQD_TRY(fqd_collapse(c, weights, read_ids, mem, nullptr));
+    FQD_TRY(fqd_find_edges(c, max_distance, metric, 0, 1, nullptr));
+    FQD_TRY(fqd_components(c, nullptr));
+    FQD_TRY(fqd_dissect(c, method, nullptr));
+    if (out) {
+        out->n_reads = c->n;
+        out->n_counted = c->n_counted;
+        out->n_unique = c->U;
+        out->n_edges = c->E;
+        out->n_clusters = c->n_clusters;
+        out->n_kept = c->n_kept;
+    }
+    return FQD_OK;
+}
+
+int fqd_get_kept_read_ids(fqd_ctx *c, uint64_t *out, int mem)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_KEPT)
+        return fail(c, FQD_E_STATE, "no dissection result yet");
+    return from_device(c, out, c->kept_ids_sorted.p, (size_t)c->n_kept, mem);
+}
+
+int fqd_get_unique_table(fqd_ctx *c, uint64_t *first_ids, uint32_t *counts, uint32_t *labels, uint8_t *kept, int mem)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_UNIQUE)
+        return fail(c, FQD_E_STATE, "no unique table yet");
+    FQD_TRY(from_device(c, first_ids, c->ufirst.p, (size_t)c->U, mem));
+    FQD_TRY(from_device(c, counts, c->ucounts.p, (size_t)c->U, mem));
+    if (labels) {
+        if (c->stage < ST_LABELS)
+            return fail(c, FQD_E_STATE, "no component labels yet");
+        FQD_TRY(from_device(c, labels, c->labels.p, (size_t)c->U, mem));
+    }
+    if (kept) {
+        if (c->stage < ST_KEPT)
+            return fail(c, FQD_E_STATE, "no dissection result yet");
+        FQD_TRY(from_device(c, kept, c->kept.p, (size_t)c->U, mem));
+    }
+    return FQD_OK;
+}
+
+// ---- exchange -------------------------------------------------------------------
+int fqd_export_packed(fqd_ctx *c, uint32_t *recs, uint32_t *lens, uint64_t *hashes, int mem)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_PACKED)
+        return fail(c, FQD_E_STATE, "nothing packed");
+    FQD_TRY(from_device(c, recs, c->recs.p, (size_t)c->n * c->ks.stride, mem));
+    if (lens) {
+        if (c->ks.ragged) {
+            FQD_TRY(from_device(c, lens, c->lens.p, (size_t)c->n, mem));
+        } else {
+            std::vector<uint32_t> fill((size_t)c->n, c->ks.max_len);
+            if (mem == FQD_HOST)
+                memcpy(lens, fill.data(), fill.size() * 4);
+            else
+                HIP_TRY(c, hipMemcpy(lens, fill.data(), fill.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+    FQD_TRY(from_device(c, hashes, c->hashes.p, (size_t)c->n, mem));
+    return FQD_OK;
+}
+
+int fqd_import_packed(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, uint64_t n, int mem)
+{
+    FQD_TRY(bind(c));
+    if (!c->shape.planes || !c->ks.stride)
+        return fail(c, FQD_E_STATE, "fqd_import_packed needs a geometry (fqd_configure + fqd_pack_keys first)");
+    if (n >= 0xFFFFFFF0ull)
+        return fail(c, FQD_E_VALUE, "at most 2^32-16 keys per context");
+    const KeyShape sh = c->ks;
+    const hipMemcpyKind kind = mem == FQD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIP_TRY(c, c->recs.reserve((size_t)n * sh.stride * 4 + 16));
+    HIP_TRY(c, c->hashes.reserve((size_t)n * 8 + 16));
+    if (n)
+        HIP_TRY(c, hipMemcpyAsync(c->recs.p, recs, (size_t)n * sh.stride * 4, kind, c->st));
+    if (sh.ragged) {
+        if (!lens)
+            return fail(c, FQD_E_VALUE, "ragged geometry needs lens");
+        HIP_TRY(c, c->lens.reserve((size_t)n * 4 + 16));
+        if (n)
+            HIP_TRY(c, hipMemcpyAsync(c->lens.p, lens, (size_t)n * 4, kind, c->st));
+    }
+    HIP_TRY(c, fqd::launch_hash_records(c->recs.as<uint32_t>(), c->lens.as<uint32_t>(), n, sh,
+                                        c->hashes.as<uint64_t>(), c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    c->n = n;
+    c->stage = ST_PACKED;
+    return FQD_OK;
+}
+
+int fqd_export_unique(fqd_ctx *c, uint32_t *recs, uint32_t *lens, uint32_t *counts, uint64_t *first_ids, int mem)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_UNIQUE)
+        return fail(c, FQD_E_STATE, "no unique table yet");
+    FQD_TRY(from_device(c, recs, c->urecs.p, (size_t)c->U * c->ks.stride, mem));
+    if (lens) {
+        if (c->ks.ragged) {
+            FQD_TRY(from_device(c, lens, c->ulens.p, (size_t)c->U, mem));
+        } else {
+            std::vector<uint32_t> fill((size_t)c->U, c->ks.max_len);
+            if (mem == FQD_HOST)
+                memcpy(lens, fill.data(), fill.size() * 4);
+            else
+                HIP_TRY(c, hipMemcpy(lens, fill.data(), fill.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+    FQD_TRY(from_device(c, counts, c->ucounts.p, (size_t)c->U, mem));
+    FQD_TRY(from_device(c, first_ids, c->ufirst.p, (size_t)c->U, mem));
+    return FQD_OK;
+}
+
+int fqd_import_unique(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, const uint32_t *counts,
+                      const uint64_t *first_ids, uint64_t U, int mem)
+{
+    FQD_TRY(bind(c));
+    if (!c->shape.planes || !c->ks.stride)
+        return fail(c, FQD_E_STATE, "fqd_import_unique needs a geometry (fqd_configure + fqd_pack_keys first)");
+    if (U >= 0xFFFFFFF0ull)
+        return fail(c, FQD_E_VALUE, "at most 2^32-16 unique keys per context");
+    const KeyShape sh = c->ks;
+    const hipMemcpyKind kind = mem == FQD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIP_TRY(c, c->urecs.reserve(U * sh.stride * 4 + 16));
+    HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
+    HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
+    HIP_TRY(c, c->ufirst.reserve(U * 8 + 16));
+    if (U) {
+        HIP_TRY(c, hipMemcpyAsync(c->urecs.p, recs, U * sh.stride * 4, kind, c->st));
+        if (sh.ragged) {
+            if (!lens)
+                return fail(c, FQD_E_VALUE, "ragged geometry needs lens");
+            HIP_TRY(c, hipMemcpyAsync(c->ulens.p, lens, U * 4, kind, c->st));
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->ucounts.p, counts, U * 4, kind, c->st));
+        HIP_TRY(c, hipMemcpyAsync(c->ufirst.p, first_ids, U * 8, kind, c->st));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    c->U = U;
+    c->collapsed = false;  // imported rows may repeat a key (dissection of a caller's list)
+    c->stage = ST_UNIQUE;
+    return FQD_OK;
+}
+
+int fqd_export_edges(fqd_ctx *c, uint32_t *uv, int mem)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_EDGES)
+        return fail(c, FQD_E_STATE, "no edges yet");
+    return from_device(c, uv, c->edges.p, (size_t)c->E * 2, mem);
+}
+
+int fqd_import_edges(fqd_ctx *c, const uint32_t *uv, uint64_t E, int mem)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_UNIQUE)
+        return fail(c, FQD_E_STATE, "edges need a unique table first");
+    HIP_TRY(c, c->edges.reserve(E * 8 + 16));
+    c->edge_cap = c->edges.cap / 8;
+    if (E)
+        HIP_TRY(c, hipMemcpyAsync(c->edges.p, uv, E * 8,
+                                  mem == FQD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    c->E = E;
+    c->stage = ST_EDGES;
+    return FQD_OK;
+}
+
+// ---- single calls ---------------------------------------------------------------
+int fqd_within_distance(fqd_ctx *c, const uint8_t *a_bytes, const uint64_t *a_offsets, const uint8_t *b_bytes,
+                        const uint64_t *b_offsets, uint64_t n, int max_distance, int metric, uint8_t *out, int mem)
+{
+    FQD_TRY(bind(c));
+    if (!n)
+        return FQD_OK;
+    if (mem != FQD_HOST)
+        return fail(c, FQD_E_VALUE, "fqd_within_distance takes host buffers");
+    if (metric == FQD_METRIC_EDIT && max_distance > 64) {
+        // only refuse when the answer is not trivially decided by the lengths
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t la = a_offsets[i + 1] - a_offsets[i], lb = b_offsets[i + 1] - b_offsets[i];
+            if ((uint64_t)max_distance < std::max(la, lb) && (la > lb ? la - lb : lb - la) <= (uint64_t)max_distance)
+                return fail(c, FQD_E_VALUE, "edit distance bound above 64 is not supported on device");
+        }
+    }
+    const uint8_t *da, *db;
+    const uint64_t *dao, *dbo;
+    FQD_TRY(to_device(c, a_bytes, (size_t)a_offsets[n], FQD_HOST, c->stage_a, &da));
+    FQD_TRY(to_device(c, a_offsets, (size_t)n + 1, FQD_HOST, c->stage_b, &dao));
+    FQD_TRY(to_device(c, b_bytes, (size_t)b_offsets[n], FQD_HOST, c->stage_c, &db));
+    FQD_TRY(to_device(c, b_offsets, (size_t)n + 1, FQD_HOST, c->stage_d, &dbo));
+    HIP_TRY(c, c->tmp.reserve(n + 16));
+    HIP_TRY(c, fqd::launch_pairs_within(da, dao, db, dbo, n, max_distance, metric, c->tmp.as<uint8_t>(), c->st));
+    return from_device(c, out, c->tmp.p, (size_t)n, FQD_HOST);
+}
+
+int fqd_contains(fqd_ctx *c, const uint8_t *, const uint64_t *, uint64_t, int, int, uint8_t *, int)
+{
+    return fail(c, FQD_E_RUNTIME, "fqd_contains: not built yet");
+}
+
+// ---- measurement ----------------------------------------------------------------
+int fqd_stage_times(fqd_ctx *c, float *ms, uint32_t *launches)
+{
+    if (ms)
+        memcpy(ms, c->ms, sizeof c->ms);
+    if (launches)
+        memcpy(launches, c->launches, sizeof c->launches);
+    return FQD_OK;
+}
+
+int fqd_edge_stats(fqd_ctx *c, uint64_t *keys_gathered, uint64_t *pairs_compared, uint64_t *edges_emitted)
+{
+    if (keys_gathered) *keys_gathered = c->last_stats.keys_gathered;
+    if (pairs_compared) *pairs_compared = c->last_stats.pairs_compared;
+    if (edges_emitted) *edges_emitted = c->last_stats.edges;
+    return FQD_OK;
+}
+
+int fqd_synth_keys(fqd_ctx *c, uint8_t *out_device, uint64_t n_total, uint64_t start, uint64_t count, uint32_t length,
+                   uint32_t umi, uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub)
+{
+    FQD_TRY(bind(c));
+    if (!copies)
+        return fail(c, FQD_E_VALUE, "copies must be positive");
+    HIP_TRY(c, fqd::launch_synth(out_device, n_total, start, count, length, umi, seed, copies, thr_n, thr_sub, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    return FQD_OK;
+}
+
+}  // extern "C"

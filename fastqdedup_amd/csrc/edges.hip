@@ -1,0 +1,324 @@
+// edges.hip -- stage 3: neighbour search. Replaces TrieNode_FindNearest +
+// within_hamming_distance / within_edit_distance (reference
+// _triemodule.c:380-495, distances.h:8-88).
+//
+// Pigeonhole: cut every key into d+1 segments
+// [len*s/(d+1), len*(s+1)/(d+1)); two keys of equal length within Hamming
+// distance d agree exactly on at least one segment. Per segment s the unique
+// keys are sorted by a 32-bit hash of (len, s, segment bits) (prims.hip), which
+// makes every bucket a contiguous run; bucket_pairs_kernel compares all pairs
+// inside a run. A hash only proposes candidates: the pair kernel counts the
+// real mismatches on the full records. A pair is emitted in the pass of the
+// FIRST segment on which it truly agrees, so every edge appears exactly once.
+#include "fqd_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void segment_hashes_kernel(const uint32_t *__restrict__ urecs,
+                                                             const uint32_t *__restrict__ ulens, uint64_t U,
+                                                             KeyShape sh, uint32_t nseg,
+                                                             uint32_t *__restrict__ seg_hashes)
+{
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U)
+        return;
+    const uint32_t len = fqd_key_len(sh, ulens, u);
+    const uint32_t *rec = urecs + u * sh.stride;
+    const uint32_t K = sh.planes;
+    for (uint32_t s = 0; s < nseg; s++) {
+        uint32_t lo, hi;
+        fqd_segment(len, s, nseg, lo, hi);
+        uint32_t h = fqd_mix32(len * 0x9E3779B1u + s * 0x85EBCA77u + 0x165667B1u);
+        if (hi > lo) {
+            for (uint32_t w = lo >> 5; w <= ((hi - 1) >> 5); w++) {
+                const uint32_t m = fqd_range_mask(w, lo, hi);
+                for (uint32_t k = 0; k < K; k++) {
+                    h = (h + (rec[w * K + k] & m)) * 0x9E3779B1u;
+                    h ^= h >> 15;
+                }
+            }
+        }
+        seg_hashes[(uint64_t)s * U + u] = fqd_mix32(h);
+    }
+}
+
+// ---- the pair kernel -----------------------------------------------------------
+// One block = T consecutive positions of the bucket-sorted order. Keys that sit
+// in a bucket of >= 2 are gathered ONCE from HBM (one aligned record each) into
+// a word-major LDS tile (word j of key t at tile[j*T + t]: lanes t, t+1, ... hit
+// consecutive banks). Lane t then walks forward over the rest of its bucket,
+// XOR/OR/popcount per 32-base word with early exit; partners beyond the tile are
+// read from HBM. Hits are appended with one atomic per wave (ballot + popcount
+// of the lanes below).
+template <int K, bool USE_LDS>
+__global__ __launch_bounds__(256) void bucket_pairs_kernel(
+    const uint32_t *__restrict__ sorted_hash, const uint32_t *__restrict__ sorted_uid, uint64_t U,
+    const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t d, uint32_t seg,
+    uint32_t nseg, uint32_t shard, uint32_t n_shards, uint32_t *__restrict__ edges,
+    unsigned long long *__restrict__ edge_count, uint64_t edge_cap, fqd::PairStats *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t T = blockDim.x;
+    uint32_t *s_hash = smem;          // T
+    uint32_t *s_uid = smem + T;       // T
+    uint32_t *s_len = smem + 2 * T;   // T
+    uint32_t *tile = smem + 3 * T;    // KW * T when USE_LDS
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint64_t base = (uint64_t)blockIdx.x * T;
+    const uint64_t i = base + tid;
+    const bool valid = i < U;
+    const uint32_t W = sh.words, KW = W * K, stride = sh.stride;
+
+    const uint32_t h = valid ? sorted_hash[i] : 0u;
+    const uint32_t uid = valid ? sorted_uid[i] : 0u;
+    s_hash[tid] = h;
+    s_uid[tid] = uid;
+    __syncthreads();
+    bool prev_same = false, next_same = false;
+    if (valid) {
+        if (i > 0)
+            prev_same = (tid > 0 ? s_hash[tid - 1] : sorted_hash[i - 1]) == h;
+        if (i + 1 < U)
+            next_same = (tid + 1 < T ? s_hash[tid + 1] : sorted_hash[i + 1]) == h;
+    }
+    const bool mine = n_shards <= 1 || (h % n_shards) == shard;
+    const bool multi = valid && mine && (prev_same || next_same);
+    const uint32_t len = valid ? fqd_key_len(sh, ulens, uid) : 0u;
+    s_len[tid] = len;
+    const uint32_t *my_rec = urecs + (uint64_t)uid * stride;
+    if (USE_LDS && multi) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(my_rec);
+        for (uint32_t q = 0; q < stride / 4; q++) {
+            const uint4 v = src[q];
+            const uint32_t j = q * 4;
+            if (j + 0 < KW) tile[(j + 0) * T + tid] = v.x;
+            if (j + 1 < KW) tile[(j + 1) * T + tid] = v.y;
+            if (j + 2 < KW) tile[(j + 2) * T + tid] = v.z;
+            if (j + 3 < KW) tile[(j + 3) * T + tid] = v.w;
+        }
+    }
+    __syncthreads();
+
+    unsigned long long n_pairs = 0, n_hits = 0;
+    if (multi && next_same) {
+        for (uint64_t gj = i + 1; gj < U; gj++) {
+            const uint32_t j = (uint32_t)(gj - base);
+            const bool in_tile = j < T;
+            const uint32_t hj = in_tile ? s_hash[j] : sorted_hash[gj];
+            if (hj != h)
+                break;
+            const uint32_t uj = in_tile ? s_uid[j] : sorted_uid[gj];
+            const uint32_t lj = in_tile ? s_len[j] : fqd_key_len(sh, ulens, uj);
+            n_pairs++;
+            bool hit = false;
+            if (lj == len) {
+                const uint32_t *other = urecs + (uint64_t)uj * stride;
+                uint32_t dist = 0;
+                for (uint32_t w = 0; w < W && dist <= d; w++) {
+                    uint32_t dw = 0;
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        const uint32_t a = USE_LDS ? tile[(w * K + k) * T + tid] : my_rec[w * K + k];
+                        const uint32_t b = (USE_LDS && in_tile) ? tile[(w * K + k) * T + j] : other[w * K + k];
+                        dw |= a ^ b;
+                    }
+                    dist += __popc(dw);
+                }
+                if (dist <= d) {
+                    // emit only in the pass of the first truly agreeing segment
+                    hit = true;
+                    for (uint32_t s2 = 0; s2 < seg && hit; s2++) {
+                        uint32_t lo, hi;
+                        fqd_segment(len, s2, nseg, lo, hi);
+                        bool agree = true;
+                        if (hi > lo) {
+                            for (uint32_t w = lo >> 5; w <= ((hi - 1) >> 5) && agree; w++) {
+                                uint32_t dw = 0;
+#pragma unroll
+                                for (int k = 0; k < K; k++) {
+                                    const uint32_t a = USE_LDS ? tile[(w * K + k) * T + tid] : my_rec[w * K + k];
+                                    const uint32_t b =
+                                        (USE_LDS && in_tile) ? tile[(w * K + k) * T + j] : other[w * K + k];
+                                    dw |= a ^ b;
+                                }
+                                if (dw & fqd_range_mask(w, lo, hi))
+                                    agree = false;
+                            }
+                        }
+                        if (agree)
+                            hit = false;
+                    }
+                }
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                unsigned long long at = 0;
+                if ((int)lane == leader)
+                    at = atomicAdd(edge_count, (unsigned long long)__popcll(m));
+                at = __shfl(at, leader);
+                if (hit) {
+                    at += __popcll(m & fqd_lanemask_lt());
+                    if (at < edge_cap) {
+                        edges[2 * at] = uid < uj ? uid : uj;
+                        edges[2 * at + 1] = uid < uj ? uj : uid;
+                    }
+                    n_hits++;
+                }
+            }
+        }
+    }
+    if (stats) {
+        unsigned long long g = multi ? 1ull : 0ull;
+        for (int o = 32; o; o >>= 1) {
+            g += __shfl_xor(g, o);
+            n_pairs += __shfl_xor(n_pairs, o);
+            n_hits += __shfl_xor(n_hits, o);
+        }
+        if (lane == 0) {
+            if (g) atomicAdd(&stats->keys_gathered, g);
+            if (n_pairs) atomicAdd(&stats->pairs_compared, n_pairs);
+            if (n_hits) atomicAdd(&stats->edges, n_hits);
+        }
+    }
+}
+
+// ---- raw-byte predicates (single calls of the reference surface) ---------------
+
+// distances.h:8-31
+__device__ bool bytes_within_hamming(const uint8_t *a, uint64_t la, const uint8_t *b, uint64_t lb, int d)
+{
+    if (la != lb)
+        return false;
+    int budget = d;
+    for (uint64_t i = 0; i < la; i++)
+        if (a[i] != b[i] && --budget < 0)
+            return false;
+    return true;
+}
+
+// distances.h:33-88 computes exact bounded Levenshtein; here as a banded DP
+// (band 2d+1, values clamped at d+1), which gives the same predicate.
+constexpr int EDIT_MAX_D = 64;
+__device__ bool bytes_within_edit(const uint8_t *a, uint64_t la, const uint8_t *b, uint64_t lb, int d)
+{
+    const uint64_t gap = la > lb ? la - lb : lb - la;
+    if (d < 0 || gap > (uint64_t)d)
+        return false;
+    if ((uint64_t)d >= (la > lb ? la : lb))
+        return true;
+    if (d > EDIT_MAX_D)
+        d = EDIT_MAX_D;  // host refuses larger d unless trivially true
+    const int INF = d + 1, B = 2 * d + 1;
+    int prev[2 * EDIT_MAX_D + 2], cur[2 * EDIT_MAX_D + 2];
+    for (int k = 0; k < B; k++)
+        prev[k] = k >= d ? k - d : INF;  // row 0: D[0][j] = j
+    for (uint64_t i = 1; i <= la; i++) {
+        int row_min = INF;
+        for (int k = 0; k < B; k++) {
+            const int64_t j = (int64_t)i + k - d;
+            int v = INF;
+            if (j >= 0 && j <= (int64_t)lb) {
+                if (j == 0) {
+                    v = (int)(i > (uint64_t)INF ? INF : i);
+                } else {
+                    const int sub = prev[k] + (a[i - 1] != b[j - 1] ? 1 : 0);
+                    const int del = k + 1 < B ? prev[k + 1] + 1 : INF;
+                    const int ins = k > 0 ? cur[k - 1] + 1 : INF;
+                    v = sub < del ? sub : del;
+                    v = v < ins ? v : ins;
+                    if (v > INF)
+                        v = INF;
+                }
+            }
+            cur[k] = v;
+            row_min = v < row_min ? v : row_min;
+        }
+        if (row_min > d)
+            return false;
+        for (int k = 0; k < B; k++)
+            prev[k] = cur[k];
+    }
+    const int k = (int)((int64_t)lb - (int64_t)la + d);
+    return prev[k] <= d;
+}
+
+__global__ void pairs_within_kernel(const uint8_t *__restrict__ a, const uint64_t *__restrict__ ao,
+                                    const uint8_t *__restrict__ b, const uint64_t *__restrict__ bo, uint64_t n,
+                                    int d, int metric, uint8_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint8_t *pa = a + ao[i], *pb = b + bo[i];
+    const uint64_t la = ao[i + 1] - ao[i], lb = bo[i + 1] - bo[i];
+    out[i] = metric ? bytes_within_edit(pa, la, pb, lb, d) : bytes_within_hamming(pa, la, pb, lb, d);
+}
+
+}  // namespace
+
+namespace fqd {
+
+hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh,
+                                 uint32_t nseg, uint32_t *seg_hashes, hipStream_t st)
+{
+    if (U)
+        segment_hashes_kernel<<<(unsigned)((U + 255) / 256), 256, 0, st>>>(urecs, ulens, U, sh, nseg, seg_hashes);
+    return hipGetLastError();
+}
+
+hipError_t launch_bucket_pairs(const uint32_t *sorted_hash, const uint32_t *sorted_uid, uint64_t U,
+                               const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d, uint32_t seg,
+                               uint32_t nseg, uint32_t shard, uint32_t n_shards, uint32_t *edges,
+                               unsigned long long *edge_count, uint64_t edge_cap, PairStats *stats, hipStream_t st)
+{
+    if (!U)
+        return hipSuccess;
+    const uint32_t KW = sh.planes * sh.words;
+    uint32_t T = 256;
+    const uint32_t budget = 60 * 1024;
+    bool use_lds = true;
+    while (T > 64 && (3 + KW) * T * 4 > budget)
+        T >>= 1;
+    if ((3 + KW) * T * 4 > budget) {
+        use_lds = false;
+        T = 256;
+    }
+    const uint32_t lds = (3 + (use_lds ? KW : 0)) * T * 4;
+    const unsigned grid = (unsigned)((U + T - 1) / T);
+#define FQD_PAIRS_CASE(KK)                                                                                   \
+    case KK:                                                                                                 \
+        if (use_lds)                                                                                         \
+            bucket_pairs_kernel<KK, true><<<grid, T, lds, st>>>(sorted_hash, sorted_uid, U, urecs, ulens, sh, d, \
+                                                                seg, nseg, shard, n_shards, edges, edge_count,   \
+                                                                edge_cap, stats);                                \
+        else                                                                                                 \
+            bucket_pairs_kernel<KK, false><<<grid, T, lds, st>>>(sorted_hash, sorted_uid, U, urecs, ulens, sh, d, \
+                                                                 seg, nseg, shard, n_shards, edges, edge_count,   \
+                                                                 edge_cap, stats);                                \
+        break;
+    switch (sh.planes) {
+        FQD_PAIRS_CASE(1)
+        FQD_PAIRS_CASE(2)
+        FQD_PAIRS_CASE(3)
+        FQD_PAIRS_CASE(4)
+        FQD_PAIRS_CASE(5)
+        FQD_PAIRS_CASE(6)
+        FQD_PAIRS_CASE(7)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef FQD_PAIRS_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_pairs_within(const uint8_t *a, const uint64_t *ao, const uint8_t *b, const uint64_t *bo,
+                               uint64_t n, int d, int metric, uint8_t *out, hipStream_t st)
+{
+    if (n)
+        pairs_within_kernel<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(a, ao, b, bo, n, d, metric, out);
+    return hipGetLastError();
+}
+
+}  // namespace fqd

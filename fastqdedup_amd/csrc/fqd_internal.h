@@ -1,0 +1,234 @@
+// fqd_internal.h -- shared between the translation units of libfqdedup_hip.so.
+//
+// Record layout (DESIGN.md "data layout"): a key of `len` bases over an alphabet
+// of A symbols is stored as K = ceil(log2 A) bit planes. Symbol codes are the
+// ranks of the symbols in ASCII order, so comparing codes compares bytes the way
+// Python's str ordering does (reference __init__.py:68,99,111 sort (count, key)).
+// Base p lives in bit (p & 31) of 32-base word (p >> 5): LSB-first, which is what
+// a wave64 __ballot produces. Word w of plane k is rec[w * K + k]; positions
+// >= len hold code 0; words past K * W up to `stride` (a multiple of 4 u32, so
+// records are 16-byte aligned) are 0.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+struct KeyShape {
+    uint32_t planes;     // K
+    uint32_t words;      // W = ceil(max_len / 32)
+    uint32_t stride;     // u32 words per record, multiple of 4
+    uint32_t max_len;
+    uint32_t ragged;     // 1: per-key lengths in lens[]; 0: every key is max_len long
+};
+
+#define FQD_WAVE 64
+
+// ---- device helpers ---------------------------------------------------------
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ uint64_t fqd_mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint32_t fqd_mix32(uint32_t h)
+{
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    return h ^ (h >> 16);
+}
+
+__device__ __forceinline__ uint32_t fqd_key_len(const KeyShape &sh, const uint32_t *lens, uint64_t i)
+{
+    return sh.ragged ? lens[i] : sh.max_len;
+}
+
+// 64-bit hash of a whole record (all K*W words) and its length.
+__device__ __forceinline__ uint64_t fqd_hash_record(const uint32_t *rec, uint32_t n_words, uint32_t len)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)len * 0xD1B54A32D192ED03ull);
+    for (uint32_t j = 0; j + 1 < n_words; j += 2) {
+        uint64_t v = (uint64_t)rec[j] | ((uint64_t)rec[j + 1] << 32);
+        h = (h ^ v) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 32;
+    }
+    if (n_words & 1) {
+        h = (h ^ rec[n_words - 1]) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 32;
+    }
+    return fqd_mix64(h);
+}
+
+// Mismatching positions of word w between records a and b (one bit per base).
+template <int K>
+__device__ __forceinline__ uint32_t fqd_diff_word(const uint32_t *a, const uint32_t *b, uint32_t w)
+{
+    uint32_t d = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        d |= a[w * K + k] ^ b[w * K + k];
+    return d;
+}
+
+__device__ __forceinline__ uint32_t fqd_diff_word_dyn(const uint32_t *a, const uint32_t *b, uint32_t w,
+                                                      uint32_t K)
+{
+    uint32_t d = 0;
+    for (uint32_t k = 0; k < K; k++)
+        d |= a[w * K + k] ^ b[w * K + k];
+    return d;
+}
+
+__device__ __forceinline__ uint32_t fqd_code_at(const uint32_t *rec, uint32_t w, uint32_t bit, uint32_t K)
+{
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < K; k++)
+        c |= ((rec[w * K + k] >> bit) & 1u) << k;
+    return c;
+}
+
+// Python str order of two DIFFERENT keys given as records: >0 when a > b.
+__device__ __forceinline__ int fqd_key_cmp(const uint32_t *a, uint32_t la, const uint32_t *b, uint32_t lb,
+                                           uint32_t K, uint32_t W)
+{
+    for (uint32_t w = 0; w < W; w++) {
+        uint32_t d = fqd_diff_word_dyn(a, b, w, K);
+        if (d) {
+            uint32_t bit = (uint32_t)__ffs((int)d) - 1u;
+            uint32_t pos = w * 32u + bit;
+            // a position past the end of the shorter key: the shorter key is a proper
+            // prefix up to here only if no earlier difference -- which is the case.
+            if (pos >= la || pos >= lb)
+                return la < lb ? -1 : 1;
+            return fqd_code_at(a, w, bit, K) < fqd_code_at(b, w, bit, K) ? -1 : 1;
+        }
+    }
+    return la < lb ? -1 : (la > lb ? 1 : 0);
+}
+
+// Bits of 32-base word w that fall inside base range [lo, hi).
+__device__ __forceinline__ uint32_t fqd_range_mask(uint32_t w, uint32_t lo, uint32_t hi)
+{
+    uint32_t w0 = w * 32u, w1 = w0 + 32u;
+    uint32_t a = lo > w0 ? lo : w0, b = hi < w1 ? hi : w1;
+    if (a >= b)
+        return 0u;
+    uint32_t n = b - a, s = a - w0;
+    uint32_t m = n >= 32u ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    return m << s;
+}
+
+// Segment s of d+1 for a key of len bases: [len*s/(d+1), len*(s+1)/(d+1))  
+__device__ __forceinline__ void fqd_segment(uint32_t len, uint32_t s, uint32_t nseg, uint32_t &lo, uint32_t &hi)
+{
+    lo = (uint32_t)(((uint64_t)len * s) / nseg);
+    hi = (uint32_t)(((uint64_t)len * (s + 1)) / nseg);
+}
+
+__device__ __forceinline__ uint32_t fqd_lane() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint64_t fqd_lanemask_lt()
+{
+    return (1ull << fqd_lane()) - 1ull;
+}
+
+#endif  // __HIPCC__
+
+// ---- launchers (one per translation unit; all asynchronous on `st`) ---------
+namespace fqd {
+
+// prims.hip -- rocPRIM device-wide primitives
+size_t sort_pairs_u64_u32_temp(uint64_t n, int begin_bit, int end_bit);
+hipError_t sort_pairs_u64_u32(void *tmp, size_t tmp_bytes, const uint64_t *kin, uint64_t *kout,
+                              const uint32_t *vin, uint32_t *vout, uint64_t n, int begin_bit,
+                              int end_bit, hipStream_t st);
+size_t sort_pairs_u32_u32_temp(uint64_t n, int begin_bit, int end_bit);
+hipError_t sort_pairs_u32_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout,
+                              const uint32_t *vin, uint32_t *vout, uint64_t n, int begin_bit,
+                              int end_bit, hipStream_t st);
+size_t sort_keys_u64_temp(uint64_t n);
+hipError_t sort_keys_u64(void *tmp, size_t tmp_bytes, const uint64_t *kin, uint64_t *kout, uint64_t n,
+                         hipStream_t st);
+size_t scan_u32_temp(uint64_t n);
+hipError_t inclusive_scan_u32(void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, uint64_t n,
+                              hipStream_t st);
+
+// pack.hip
+hipError_t launch_scan_bytes(const uint8_t *bytes, uint64_t n_bytes, uint32_t *present128_dev,
+                             hipStream_t st);
+hipError_t launch_scan_lens(const uint64_t *offsets, uint64_t n, uint32_t *minmax_dev, hipStream_t st);
+hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
+                       uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, uint32_t *recs,
+                       uint32_t *lens, uint64_t *hashes, uint32_t *bad_flag, hipStream_t st);
+hipError_t launch_hash_records(const uint32_t *recs, const uint32_t *lens, uint64_t n, KeyShape sh,
+                               uint64_t *hashes, hipStream_t st);
+
+// collapse.hip
+hipError_t launch_iota_u32(uint32_t *out, uint64_t n, hipStream_t st);
+hipError_t launch_head_flags(const uint64_t *hs, const uint32_t *ids, const uint32_t *recs,
+                             const uint32_t *lens, uint64_t n, KeyShape sh, uint64_t hash_mask,
+                             uint32_t *flags, uint32_t *n_collision_runs, uint32_t *collision_runs,
+                             uint32_t cap, hipStream_t st);
+hipError_t launch_fix_collision_runs(const uint64_t *hs, uint32_t *ids, const uint32_t *recs,
+                                     const uint32_t *lens, uint64_t n, KeyShape sh, uint64_t hash_mask,
+                                     uint32_t *flags, const uint32_t *collision_runs, uint32_t n_runs,
+                                     hipStream_t st);
+hipError_t launch_run_starts(const uint32_t *flags, const uint32_t *run_idx, uint64_t n,
+                             uint32_t *run_start, hipStream_t st);
+hipError_t launch_run_weights(const uint32_t *run_start, uint32_t n_runs, uint64_t n, const uint32_t *ids,
+                              const uint32_t *weights, uint32_t *run_weight, uint32_t *live_flag,
+                              hipStream_t st);
+hipError_t launch_write_unique(const uint32_t *run_start, const uint32_t *run_weight,
+                               const uint32_t *live_flag, const uint32_t *live_idx, uint32_t n_runs,
+                               const uint32_t *ids, const uint32_t *recs, const uint32_t *lens,
+                               const uint64_t *read_ids, KeyShape sh, uint32_t *urecs, uint32_t *ulens,
+                               uint32_t *ucounts, uint64_t *ufirst, hipStream_t st);
+hipError_t launch_sum_u32(const uint32_t *in, uint64_t n, unsigned long long *out, hipStream_t st);
+
+// edges.hip
+hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh,
+                                 uint32_t nseg, uint32_t *seg_hashes /* nseg * U */, hipStream_t st);
+struct PairStats {
+    unsigned long long keys_gathered, pairs_compared, edges;
+};
+hipError_t launch_bucket_pairs(const uint32_t *sorted_hash, const uint32_t *sorted_uid, uint64_t U,
+                               const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d,
+                               uint32_t seg, uint32_t nseg, uint32_t shard, uint32_t n_shards,
+                               uint32_t *edges, unsigned long long *edge_count, uint64_t edge_cap,
+                               PairStats *stats, hipStream_t st);
+hipError_t launch_pairs_within(const uint8_t *a, const uint64_t *ao, const uint8_t *b, const uint64_t *bo,
+                               uint64_t n, int d, int metric, uint8_t *out, hipStream_t st);
+hipError_t launch_contains(const uint8_t *q, const uint64_t *qo, uint64_t nq, const uint32_t *urecs,
+                           const uint32_t *ulens, uint64_t U, KeyShape sh, const uint8_t *lut_dev, int d,
+                           int metric, uint32_t *hit_flags, hipStream_t st);
+
+// graph.hip -- union-find + dissection
+hipError_t launch_uf_init(uint32_t *parent, uint64_t U, hipStream_t st);
+hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, hipStream_t st);
+hipError_t launch_uf_flatten(uint32_t *parent, uint64_t U, unsigned long long *n_roots, hipStream_t st);
+hipError_t launch_dissect_init(uint32_t *best, uint8_t *state, uint64_t U, hipStream_t st);
+hipError_t launch_highest_count(const uint32_t *labels, const uint32_t *ucounts, const uint32_t *urecs,
+                                const uint32_t *ulens, KeyShape sh, uint64_t U, uint32_t *best,
+                                hipStream_t st);
+hipError_t launch_directional_round(const uint32_t *edges, uint64_t E, const uint32_t *ucounts,
+                                    const uint32_t *urecs, const uint32_t *ulens, KeyShape sh,
+                                    uint32_t *best, uint32_t *changed, hipStream_t st);
+hipError_t launch_adjacency_round(const uint32_t *edges, uint64_t E, const uint32_t *ucounts,
+                                  const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint64_t U,
+                                  uint8_t *state, uint32_t *blocked, uint32_t round, uint32_t *changed,
+                                  hipStream_t st);
+hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t *best, const uint8_t *state,
+                             uint64_t U, uint8_t *kept, uint32_t *kept_u32, hipStream_t st);
+hipError_t launch_gather_kept(const uint32_t *kept_u32, const uint32_t *kept_scan, const uint64_t *ufirst,
+                              uint64_t U, uint64_t *out, hipStream_t st);
+
+// synth.hip
+hipError_t launch_synth(uint8_t *out, uint64_t n_total, uint64_t start, uint64_t count, uint32_t length,
+                        uint32_t umi, uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub,
+                        hipStream_t st);
+
+}  // namespace fqd

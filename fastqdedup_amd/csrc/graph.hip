@@ -1,0 +1,303 @@
+// graph.hip -- stage 4 (components) and stage 5 (dissection).
+//
+// Stage 4 replaces the BFS of Trie.pop_cluster (reference _triemodule.c:865-895):
+// a popped cluster is exactly one connected component of the "within distance"
+// graph on unique keys, so a lock-free union-find over the
+// edge list gives the same partition. Hooks always point a larger root at a
+// smaller one, so the final label of a component is its smallest uid.
+//
+// Stage 5 replaces cluster_dissection_* (reference __init__.py:60-122). All
+// three start from sorted(cluster), i.e. the order "(count, key)" with Python
+// str comparison -- rank_greater() below. They are restated as order-free fixed
+// points over the edge list (derivations in DESIGN.md, checked against the
+// reference's own functions in tests/):
+//   highest_count  keep the rank-maximum of each component.
+//   directional    with arcs t->c for every edge where 2*count_c-1 <= count_t
+//                  (:84), key v is kept iff no key of higher rank reaches v along
+//                  arcs. best[v] = max rank over {u : u ~> v}; kept iff best[v]==v.
+//   adjacency      greedy "take the max, drop its neighbours, repeat" (:112-122) is
+//                  the lexicographically-first maximal independent set in rank
+//                  order: v is kept iff none of its higher-rank neighbours is kept.
+#include "fqd_internal.h"
+
+namespace {
+
+__device__ __forceinline__ bool rank_greater(uint32_t a, uint32_t b, const uint32_t *__restrict__ ucounts,
+                                             const uint32_t *__restrict__ urecs,
+                                             const uint32_t *__restrict__ ulens, const KeyShape &sh)
+{
+    const uint32_t ca = ucounts[a], cb = ucounts[b];
+    if (ca != cb)
+        return ca > cb;
+    return fqd_key_cmp(urecs + (uint64_t)a * sh.stride, fqd_key_len(sh, ulens, a),
+                       urecs + (uint64_t)b * sh.stride, fqd_key_len(sh, ulens, b), sh.planes, sh.words) > 0;
+}
+
+__device__ __forceinline__ uint32_t load_relaxed(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- union-find ------------------------------------------------------------------
+__global__ void uf_init_kernel(uint32_t *parent, uint64_t U)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < U)
+        parent[i] = (uint32_t)i;
+}
+
+__device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
+{
+    uint32_t p = load_relaxed(&parent[x]);
+    while (p != x) {
+        const uint32_t g = load_relaxed(&parent[p]);
+        if (g != p)
+            atomicMin(&parent[x], g);  // path halving; parents only ever decrease
+        x = p;
+        p = g;
+    }
+    return x;
+}
+
+__global__ void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ edges, uint64_t E)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E)
+        return;
+    uint32_t a = edges[2 * e], b = edges[2 * e + 1];
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b)
+            return;
+        if (a > b) {
+            const uint32_t t = a;
+            a = b;
+            b = t;
+        }
+        // hook the larger root under the smaller one
+        if (atomicCAS(&parent[b], b, a) == b)
+            return;
+    }
+}
+
+__global__ void uf_flatten_kernel(uint32_t *parent, uint64_t U, unsigned long long *n_roots)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool root = false;
+    if (i < U) {
+        uint32_t x = (uint32_t)i, p = load_relaxed(&parent[x]);
+        while (p != x) {
+            x = p;
+            p = load_relaxed(&parent[x]);
+        }
+        // writing the root early is harmless: it is a valid ancestor for every reader
+        __hip_atomic_store(&parent[i], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        root = x == (uint32_t)i;
+    }
+    const unsigned long long m = __ballot(root);
+    if (fqd_lane() == 0 && m)
+        atomicAdd(n_roots, (unsigned long long)__popcll(m));
+}
+
+// ---- dissection ------------------------------------------------------------------
+__global__ void dissect_init_kernel(uint32_t *best, uint8_t *state, uint64_t U)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < U) {
+        best[i] = (uint32_t)i;
+        state[i] = 0;
+    }
+}
+
+// best[dst] = max_rank(best[dst], cand)
+__device__ __forceinline__ bool raise_best(uint32_t *best, uint32_t dst, uint32_t cand,
+                                           const uint32_t *__restrict__ ucounts, const uint32_t *__restrict__ urecs,
+                                           const uint32_t *__restrict__ ulens, const KeyShape &sh)
+{
+    for (;;) {
+        const uint32_t old = load_relaxed(&best[dst]);
+        if (old == cand || !rank_greater(cand, old, ucounts, urecs, ulens, sh))
+            return false;
+        if (atomicCAS(&best[dst], old, cand) == old)
+            return true;
+    }
+}
+
+__global__ void highest_count_kernel(const uint32_t *__restrict__ labels, const uint32_t *__restrict__ ucounts,
+                                     const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens,
+                                     KeyShape sh, uint64_t U, uint32_t *best)
+{
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= U)
+        return;
+    const uint32_t r = labels[v];
+    if (r != (uint32_t)v)
+        raise_best(best, r, (uint32_t)v, ucounts, urecs, ulens, sh);
+}
+
+__global__ void directional_round_kernel(const uint32_t *__restrict__ edges, uint64_t E,
+                                         const uint32_t *__restrict__ ucounts, const uint32_t *__restrict__ urecs,
+                                         const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t *best,
+                                         uint32_t *changed)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E)
+        return;
+    const uint32_t u = edges[2 * e], v = edges[2 * e + 1];
+    const long long cu = ucounts[u], cv = ucounts[v];
+    bool moved = false;
+    if (2 * cv - 1 <= cu)  // arc u -> v
+        moved |= raise_best(best, v, load_relaxed(&best[u]), ucounts, urecs, ulens, sh);
+    if (2 * cu - 1 <= cv)  // arc v -> u
+        moved |= raise_best(best, u, load_relaxed(&best[v]), ucounts, urecs, ulens, sh);
+    if (moved)
+        *changed = 1;
+}
+
+// state: 0 undecided, 1 kept, 2 dropped. blocked[v] == round: v still has an
+// undecided neighbour of higher rank.
+__global__ void adjacency_edges_kernel(const uint32_t *__restrict__ edges, uint64_t E,
+                                       const uint32_t *__restrict__ ucounts, const uint32_t *__restrict__ urecs,
+                                       const uint32_t *__restrict__ ulens, KeyShape sh, uint8_t *state,
+                                       uint32_t *blocked, uint32_t round, uint32_t *changed)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E)
+        return;
+    uint32_t hi = edges[2 * e], lo = edges[2 * e + 1];
+    if (state[lo] && state[hi])
+        return;
+    if (!rank_greater(hi, lo, ucounts, urecs, ulens, sh)) {
+        const uint32_t t = hi;
+        hi = lo;
+        lo = t;
+    }
+    if (state[lo])
+        return;
+    const uint8_t sh_hi = state[hi];
+    if (sh_hi == 1) {
+        state[lo] = 2;
+        *changed = 1;
+    } else if (sh_hi == 0) {
+        blocked[lo] = round;
+    }
+}
+
+__global__ void adjacency_nodes_kernel(uint64_t U, uint8_t *state, const uint32_t *__restrict__ blocked,
+                                       uint32_t round, uint32_t *changed)
+{
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= U)
+        return;
+    if (state[v] == 0 && blocked[v] != round) {
+        state[v] = 1;
+        *changed = 1;
+    }
+}
+
+__global__ void kept_flags_kernel(int method, const uint32_t *__restrict__ labels, const uint32_t *__restrict__ best,
+                                  const uint8_t *__restrict__ state, uint64_t U, uint8_t *kept, uint32_t *kept_u32)
+{
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= U)
+        return;
+    bool k;
+    if (method == 0)
+        k = best[labels[v]] == (uint32_t)v;
+    else if (method == 2)
+        k = best[v] == (uint32_t)v;
+    else
+        k = state[v] == 1;
+    kept[v] = k ? 1 : 0;
+    kept_u32[v] = k ? 1u : 0u;
+}
+
+__global__ void gather_kept_kernel(const uint32_t *__restrict__ kept_u32, const uint32_t *__restrict__ kept_scan,
+                                   const uint64_t *__restrict__ ufirst, uint64_t U, uint64_t *out)
+{
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < U && kept_u32[v])
+        out[kept_scan[v] - 1] = ufirst[v];
+}
+
+inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+namespace fqd {
+
+hipError_t launch_uf_init(uint32_t *parent, uint64_t U, hipStream_t st)
+{
+    if (U)
+        uf_init_kernel<<<grid_for(U), 256, 0, st>>>(parent, U);
+    return hipGetLastError();
+}
+
+hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, hipStream_t st)
+{
+    if (E)
+        uf_union_kernel<<<grid_for(E), 256, 0, st>>>(parent, edges, E);
+    return hipGetLastError();
+}
+
+hipError_t launch_uf_flatten(uint32_t *parent, uint64_t U, unsigned long long *n_roots, hipStream_t st)
+{
+    if (U)
+        uf_flatten_kernel<<<grid_for(U), 256, 0, st>>>(parent, U, n_roots);
+    return hipGetLastError();
+}
+
+hipError_t launch_dissect_init(uint32_t *best, uint8_t *state, uint64_t U, hipStream_t st)
+{
+    if (U)
+        dissect_init_kernel<<<grid_for(U), 256, 0, st>>>(best, state, U);
+    return hipGetLastError();
+}
+
+hipError_t launch_highest_count(const uint32_t *labels, const uint32_t *ucounts, const uint32_t *urecs,
+                                const uint32_t *ulens, KeyShape sh, uint64_t U, uint32_t *best, hipStream_t st)
+{
+    if (U)
+        highest_count_kernel<<<grid_for(U), 256, 0, st>>>(labels, ucounts, urecs, ulens, sh, U, best);
+    return hipGetLastError();
+}
+
+hipError_t launch_directional_round(const uint32_t *edges, uint64_t E, const uint32_t *ucounts,
+                                    const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t *best,
+                                    uint32_t *changed, hipStream_t st)
+{
+    if (E)
+        directional_round_kernel<<<grid_for(E), 256, 0, st>>>(edges, E, ucounts, urecs, ulens, sh, best, changed);
+    return hipGetLastError();
+}
+
+hipError_t launch_adjacency_round(const uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
+                                  const uint32_t *ulens, KeyShape sh, uint64_t U, uint8_t *state, uint32_t *blocked,
+                                  uint32_t round, uint32_t *changed, hipStream_t st)
+{
+    if (E)
+        adjacency_edges_kernel<<<grid_for(E), 256, 0, st>>>(edges, E, ucounts, urecs, ulens, sh, state, blocked,
+                                                            round, changed);
+    if (U)
+        adjacency_nodes_kernel<<<grid_for(U), 256, 0, st>>>(U, state, blocked, round, changed);
+    return hipGetLastError();
+}
+
+hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t *best, const uint8_t *state,
+                             uint64_t U, uint8_t *kept, uint32_t *kept_u32, hipStream_t st)
+{
+    if (U)
+        kept_flags_kernel<<<grid_for(U), 256, 0, st>>>(method, labels, best, state, U, kept, kept_u32);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_kept(const uint32_t *kept_u32, const uint32_t *kept_scan, const uint64_t *ufirst, uint64_t U,
+                              uint64_t *out, hipStream_t st)
+{
+    if (U)
+        gather_kept_kernel<<<grid_for(U), 256, 0, st>>>(kept_u32, kept_scan, ufirst, U, out);
+    return hipGetLastError();
+}
+
+}  // namespace fqd

@@ -1,0 +1,287 @@
+// pack.hip -- stage 1: ASCII keys -> bit-plane records + 64-bit key hashes.
+//
+// Replaces the storage half of TrieNode_AddSequence (reference
+// _triemodule.c:222-288): instead of one trie node per base, a key becomes K
+// bit planes of ceil(len/32) words (fqd_internal.h).
+//
+// Kernel shape (HBM-bound: reads every input byte exactly once with coalesced
+// dword loads, writes each record once with 16-byte stores):
+//   phase A  each wave streams 256-byte chunks of the block's contiguous byte
+//            range: dword load -> wave-private LDS -> 4 x (ds_read_u8, LUT,
+//            K x __ballot). A wave64 ballot IS 64 consecutive bases of one bit
+//            plane, so no per-base shifting is needed. Result: the block's byte
+//            range as K bit streams in LDS.
+//   phase B  one thread per (key, 32-base word): funnel-shift the key's bits
+//            out of the streams into the record tile in LDS.
+//   phase C  one thread per key hashes its record from LDS; the tile is then
+//            copied to HBM with uint4 stores.
+#include "fqd_internal.h"
+
+namespace {
+
+constexpr int PACK_THREADS = 256;
+constexpr int PACK_WAVES = PACK_THREADS / FQD_WAVE;
+
+__global__ __launch_bounds__(256) void scan_bytes_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes,
+                                                         uint32_t *__restrict__ present)
+{
+    __shared__ uint32_t seen[256];
+    seen[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t n16 = n_bytes / 16;
+    const uint4 *v = reinterpret_cast<const uint4 *>(bytes);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint4 q = v[i];
+        uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            seen[w[j] & 0xFF] = 1;
+            seen[(w[j] >> 8) & 0xFF] = 1;
+            seen[(w[j] >> 16) & 0xFF] = 1;
+            seen[w[j] >> 24] = 1;
+        }
+    }
+    if (blockIdx.x == 0)
+        for (uint64_t i = n16 * 16 + threadIdx.x; i < n_bytes; i += blockDim.x)
+            seen[bytes[i]] = 1;
+    __syncthreads();
+    if (seen[threadIdx.x])
+        present[threadIdx.x] = 1;
+}
+
+__global__ void scan_lens_kernel(const uint64_t *__restrict__ offsets, uint64_t n, uint32_t *__restrict__ minmax)
+{
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t l = offsets[i + 1] - offsets[i];
+        uint32_t l32 = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+        lo = min(lo, l32);
+        hi = max(hi, l32);
+    }
+    for (int o = 32; o; o >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+    }
+    if (fqd_lane() == 0) {
+        atomicMin(&minmax[0], lo);
+        atomicMax(&minmax[1], hi);
+    }
+}
+
+// LDS carve (u32 words): lut[64] | scratch[PACK_WAVES][64] | planes[K][plane_words] | tile[kpb*stride]
+template <int K>
+__global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
+    const uint8_t *__restrict__ bytes, uint64_t n_bytes, const uint64_t *__restrict__ offsets, uint64_t n,
+    uint32_t fixed_len, KeyShape sh, uint32_t kpb, uint32_t plane_words, const uint8_t *__restrict__ lut_g,
+    uint32_t *__restrict__ recs, uint32_t *__restrict__ lens, uint64_t *__restrict__ hashes,
+    uint32_t *__restrict__ bad_flag)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *lut32 = smem;                                   // 256 bytes
+    uint32_t *scratch = smem + 64;                            // PACK_WAVES * 64 words
+    uint32_t *planes = scratch + PACK_WAVES * 64;             // K * plane_words
+    uint32_t *tile = planes + K * plane_words;                // kpb * stride (16-byte aligned by host)
+    const uint8_t *lut = reinterpret_cast<const uint8_t *>(lut32);
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t key0 = (uint64_t)blockIdx.x * kpb;
+    const uint32_t nk = (uint32_t)min((uint64_t)kpb, n - key0);
+    const uint64_t b0 = offsets ? offsets[key0] : key0 * fixed_len;
+    const uint64_t b1 = offsets ? offsets[key0 + nk] : (key0 + nk) * fixed_len;
+    const uint64_t a0 = b0 & ~3ull;
+    const uint32_t span = (uint32_t)(b1 - a0);
+    const uint32_t lead = (uint32_t)(b0 - a0);
+    const uint32_t n_chunks = (span + 255u) / 256u;
+
+    if (tid < 64)
+        lut32[tid] = reinterpret_cast<const uint32_t *>(lut_g)[tid];
+    __syncthreads();
+
+    // ---- phase A: byte range -> K bit streams in LDS ------------------------
+    uint32_t bad = 0;
+    uint32_t *my_scratch = scratch + wave * 64;
+    const uint8_t *my_scratch8 = reinterpret_cast<const uint8_t *>(my_scratch);
+    for (uint32_t chunk = wave; chunk < n_chunks; chunk += PACK_WAVES) {
+        const uint64_t at = a0 + (uint64_t)chunk * 256u + lane * 4u;
+        uint32_t v = 0;
+        if (at + 4 <= n_bytes) {
+            v = *reinterpret_cast<const uint32_t *>(bytes + at);
+        } else {
+            for (uint32_t j = 0; j < 4; j++)
+                if (at + j < n_bytes)
+                    v |= (uint32_t)bytes[at + j] << (8 * j);
+        }
+        my_scratch[lane] = v;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t pos = chunk * 256u + j * 64u + lane;
+            const bool in = pos >= lead && pos < span;
+            const uint32_t c = my_scratch8[j * 64u + lane];
+            const uint32_t code = lut[c];
+            bad |= (in && code == 0xFFu) ? 1u : 0u;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const unsigned long long bits = __ballot(in && ((code >> k) & 1u));
+                if (lane == 0) {
+                    uint32_t *dst = planes + k * plane_words + (chunk * 8u + j * 2u);
+                    dst[0] = (uint32_t)bits;
+                    dst[1] = (uint32_t)(bits >> 32);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // two guard words behind each stream so the funnel shift may read one word ahead
+    if (tid < K * 2)
+        planes[(tid >> 1) * plane_words + n_chunks * 8u + (tid & 1u)] = 0;
+    if (__ballot(bad) && lane == 0)
+        atomicOr(bad_flag, 1u);
+    __syncthreads();
+
+    // ---- phase B: bit streams -> record tile ---------------------------------
+    const uint32_t W = sh.words, stride = sh.stride;
+    for (uint32_t item = tid; item < nk * W; item += PACK_THREADS) {
+        const uint32_t k = item / W, w = item - k * W;
+        uint64_t kb, ke;
+        if (offsets) {
+            kb = offsets[key0 + k];
+            ke = offsets[key0 + k + 1];
+        } else {
+            kb = (key0 + k) * fixed_len;
+            ke = kb + fixed_len;
+        }
+        const uint32_t len = (uint32_t)(ke - kb);
+        const uint32_t bitpos = (uint32_t)(kb - a0) + w * 32u;
+        const uint32_t q = bitpos >> 5, sft = bitpos & 31u;
+        const uint32_t done = w * 32u;
+        const uint32_t rem = len > done ? len - done : 0u;
+        const uint32_t mask = rem >= 32u ? 0xFFFFFFFFu : ((1u << rem) - 1u);
+#pragma unroll
+        for (int p = 0; p < K; p++) {
+            uint32_t val = 0;
+            if (rem) {
+                const uint32_t lo = planes[p * plane_words + q], hi = planes[p * plane_words + q + 1];
+                val = (uint32_t)((((uint64_t)hi << 32) | lo) >> sft) & mask;
+            }
+            tile[k * stride + w * K + p] = val;
+        }
+    }
+    for (uint32_t item = tid; item < nk * (stride - W * K); item += PACK_THREADS) {
+        const uint32_t pad = stride - W * K;
+        const uint32_t k = item / pad, j = item - k * pad;
+        tile[k * stride + W * K + j] = 0;
+    }
+    __syncthreads();
+
+    // ---- phase C: hash per key, then stream the tile out ---------------------
+    for (uint32_t k = tid; k < nk; k += PACK_THREADS) {
+        const uint32_t len = offsets ? (uint32_t)(offsets[key0 + k + 1] - offsets[key0 + k]) : fixed_len;
+        hashes[key0 + k] = fqd_hash_record(tile + k * stride, W * K, len);
+        if (lens)
+            lens[key0 + k] = len;
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(recs + key0 * stride);
+    const uint4 *src = reinterpret_cast<const uint4 *>(tile);
+    for (uint32_t i = tid; i < nk * stride / 4u; i += PACK_THREADS)
+        dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void hash_records_kernel(const uint32_t *__restrict__ recs,
+                                                           const uint32_t *__restrict__ lens, uint64_t n,
+                                                           KeyShape sh, uint64_t *__restrict__ hashes)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    hashes[i] = fqd_hash_record(recs + i * sh.stride, sh.words * sh.planes, fqd_key_len(sh, lens, i));
+}
+
+}  // namespace
+
+namespace fqd {
+
+hipError_t launch_scan_bytes(const uint8_t *bytes, uint64_t n_bytes, uint32_t *present256_dev, hipStream_t st)
+{
+    if (!n_bytes)
+        return hipSuccess;
+    uint64_t blocks = (n_bytes / 16 + 255) / 256;
+    if (blocks > 2048)
+        blocks = 2048;
+    if (blocks < 1)
+        blocks = 1;
+    scan_bytes_kernel<<<(unsigned)blocks, 256, 0, st>>>(bytes, n_bytes, present256_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_lens(const uint64_t *offsets, uint64_t n, uint32_t *minmax_dev, hipStream_t st)
+{
+    if (!n)
+        return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 2048)
+        blocks = 2048;
+    scan_lens_kernel<<<(unsigned)blocks, 256, 0, st>>>(offsets, n, minmax_dev);
+    return hipGetLastError();
+}
+
+static uint32_t pack_lds_bytes(uint32_t kpb, const KeyShape &sh, uint32_t &plane_words)
+{
+    // worst-case byte span of kpb keys, plus 3 bytes of alignment lead
+    uint64_t span = (uint64_t)kpb * sh.max_len + 3;
+    uint64_t chunks = (span + 255) / 256;
+    plane_words = (uint32_t)(chunks * 8 + 2);
+    plane_words = (plane_words + 3u) & ~3u;  // keeps the tile 16-byte aligned
+    uint64_t words = 64 + PACK_WAVES * 64 + (uint64_t)sh.planes * plane_words + (uint64_t)kpb * sh.stride;
+    return words * 4 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(words * 4);
+}
+
+hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
+                       uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, uint32_t *recs, uint32_t *lens,
+                       uint64_t *hashes, uint32_t *bad_flag, hipStream_t st)
+{
+    if (!n)
+        return hipSuccess;
+    const uint32_t budget = 60 * 1024;
+    uint32_t kpb = 256, plane_words = 0;
+    while (kpb > 1 && pack_lds_bytes(kpb, sh, plane_words) > budget)
+        kpb >>= 1;
+    uint32_t lds = pack_lds_bytes(kpb, sh, plane_words);
+    if (lds > budget)
+        return hipErrorInvalidValue;  // a single key does not fit the LDS tile
+    const uint64_t blocks = (n + kpb - 1) / kpb;
+    if (blocks > 0x7FFFFFFFull)
+        return hipErrorInvalidValue;
+#define FQD_PACK_CASE(KK)                                                                               \
+    case KK:                                                                                            \
+        pack_kernel<KK><<<(unsigned)blocks, PACK_THREADS, lds, st>>>(bytes, n_bytes, offsets, n, fixed_len, \
+                                                                      sh, kpb, plane_words, lut_dev, recs,  \
+                                                                      lens, hashes, bad_flag);              \
+        break;
+    switch (sh.planes) {
+        FQD_PACK_CASE(1)
+        FQD_PACK_CASE(2)
+        FQD_PACK_CASE(3)
+        FQD_PACK_CASE(4)
+        FQD_PACK_CASE(5)
+        FQD_PACK_CASE(6)
+        FQD_PACK_CASE(7)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef FQD_PACK_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_hash_records(const uint32_t *recs, const uint32_t *lens, uint64_t n, KeyShape sh,
+                               uint64_t *hashes, hipStream_t st)
+{
+    if (!n)
+        return hipSuccess;
+    hash_records_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(recs, lens, n, sh, hashes);
+    return hipGetLastError();
+}
+
+}  // namespace fqd

@@ -1,0 +1,183 @@
+/*
+ * fqdedup_hip.h -- C ABI of libfqdedup_hip.so: the MI355X (gfx950) clustering
+ * hot path of fastqdedup. Plain pointers and sizes only; no CPython, no torch.
+ *
+ * What each entry point replaces in the reference (/root/reference):
+ *
+ *   fqd_pack_keys        storage half of TrieNode_AddSequence / Trie.add_sequence
+ *                        (src/fastqdedup/_triemodule.c:222-288, :677-706), driven by
+ *                        the insert loop of deduplicate_cluster (__init__.py:242-252)
+ *   fqd_collapse         duplicate-count half of TrieNode_AddSequence
+ *                        (_triemodule.c:235-239, :261-264) + Trie.number_of_sequences
+ *   fqd_find_edges       TrieNode_FindNearest + within_hamming_distance /
+ *                        within_edit_distance (_triemodule.c:380-495, distances.h:8-88)
+ *   fqd_components       the BFS of Trie.pop_cluster (_triemodule.c:778-897):
+ *                        one popped cluster == one connected component
+ *   fqd_dissect          cluster_dissection_{highest_count,adjacency,directional}
+ *                        (__init__.py:60-130) and deduplicated_set.add (:276)
+ *   fqd_cluster          the caller loop __init__.py:266-281 in one call
+ *   fqd_get_kept_read_ids  first holder of every kept key in input order, i.e. what
+ *                        filter_fastq_files_on_set selects (__init__.py:189-206)
+ *   fqd_within_distance  _distance.within_distance (_distancemodule.c:46-93)
+ *   fqd_contains         Trie.contains_sequence (_triemodule.c:730-758)
+ *
+ * Threading: one fqd_ctx = one device + one HIP stream; calls on one context
+ * must be serialised (the reference holds the GIL for every call,
+ * SURVEY.md section 8b). Every function returns FQD_OK or a negative code;
+ * fqd_last_error() gives the message. There is NO CPU fallback: without a
+ * usable gfx950 device fqd_create fails with FQD_E_DEVICE.
+ *
+ * Memory: `mem` says where caller buffers live (FQD_HOST or FQD_DEVICE).
+ * Device buffers must be 16-byte aligned and stay valid until the call returns.
+ * Results are copied into caller-provided buffers.
+ */
+#ifndef FQDEDUP_HIP_H
+#define FQDEDUP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FQD_OK             0
+#define FQD_E_NOMEM       -1  /* MemoryError  */
+#define FQD_E_VALUE       -2  /* ValueError   */
+#define FQD_E_LOOKUP      -3  /* LookupError  */
+#define FQD_E_RUNTIME     -4  /* RuntimeError */
+#define FQD_E_DEVICE      -5  /* RuntimeError: HIP error / no device */
+#define FQD_E_STATE       -6  /* RuntimeError: stage called out of order */
+
+#define FQD_HOST   0
+#define FQD_DEVICE 1
+
+#define FQD_METRIC_HAMMING 0
+#define FQD_METRIC_EDIT    1
+
+#define FQD_METHOD_HIGHEST_COUNT 0
+#define FQD_METHOD_ADJACENCY     1
+#define FQD_METHOD_DIRECTIONAL   2
+
+typedef struct fqd_ctx fqd_ctx;
+
+typedef struct fqd_summary {
+    uint64_t n_reads;      /* keys handed in                                  */
+    uint64_t n_counted;    /* sum of weights == Trie.number_of_sequences      */
+    uint64_t n_unique;     /* distinct keys with weight > 0                   */
+    uint64_t n_edges;      /* unordered key pairs within distance             */
+    uint64_t n_clusters;   /* == number of pop_cluster calls in the reference */
+    uint64_t n_kept;       /* == len(deduplicated_set)                        */
+} fqd_summary;
+
+/* Packed-key geometry chosen by fqd_pack_keys (DESIGN.md "data layout"). */
+typedef struct fqd_shape {
+    uint32_t planes;       /* bit planes per base: ceil(log2(alphabet size))  */
+    uint32_t words;        /* 32-base words per plane: ceil(max_len/32)       */
+    uint32_t stride_words; /* u32 words per record (multiple of 4)            */
+    uint32_t max_len;      /* longest key, bases                              */
+    uint32_t ragged;       /* 1 when key lengths differ                       */
+    uint32_t alphabet_size;
+    uint8_t  alphabet[128];/* symbols in ASCII order; code = index            */
+} fqd_shape;
+
+int         fqd_device_count(void);
+const char *fqd_global_error(void);             /* message of a failed fqd_create */
+int         fqd_create(int device, fqd_ctx **out);
+void        fqd_destroy(fqd_ctx *ctx);
+const char *fqd_last_error(const fqd_ctx *ctx);
+int         fqd_synchronize(fqd_ctx *ctx);
+
+/* ---- stage 1: keys -> bit-plane records + 64-bit hashes --------------------
+ * bytes: concatenated ASCII keys. offsets: n+1 byte offsets, or NULL for n keys
+ * of fixed_len bytes each. Bytes >= 128 are a FQD_E_VALUE (the reference
+ * refuses non-ASCII keys, _triemodule.c:684-688). */
+int fqd_pack_keys(fqd_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n,
+                  uint32_t fixed_len, int mem);
+/* Force the alphabet (symbols present, as a 128-entry 0/1 table), longest key
+ * and raggedness before fqd_pack_keys, so that several contexts (ranks) share
+ * one record geometry. present == NULL restores auto-detection. */
+int fqd_configure(fqd_ctx *ctx, const uint8_t *present128, uint32_t max_len, int ragged);
+/* What a buffer of keys needs: symbols present, longest key, raggedness. */
+int fqd_scan_keys(fqd_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n,
+                  uint32_t fixed_len, int mem, uint8_t *present128, uint32_t *max_len, int *ragged);
+int fqd_get_shape(const fqd_ctx *ctx, fqd_shape *out);
+
+/* ---- stage 2: exact duplicates -> unique keys, counts, first holders -------
+ * weights: per key multiplicity (0 = present but not counted: a read that
+ * failed the quality filter still is a "first holder", __init__.py:201-206),
+ * NULL = 1 each. read_ids: caller's ids for the keys (NULL = 0..n-1). */
+int fqd_collapse(fqd_ctx *ctx, const uint32_t *weights, const uint64_t *read_ids, int mem,
+                 uint64_t *n_unique);
+
+/* ---- stage 3: all pairs of unique keys within max_distance -----------------
+ * Only buckets with (bucket_hash % n_shards) == shard are searched, so that the
+ * ranks of a multi-GPU job split the search; (0, 1) searches everything. */
+int fqd_find_edges(fqd_ctx *ctx, int max_distance, int metric, uint32_t shard, uint32_t n_shards,
+                   uint64_t *n_edges);
+
+/* ---- stage 4 / 5 ----------------------------------------------------------- */
+int fqd_components(fqd_ctx *ctx, uint64_t *n_clusters);
+int fqd_dissect(fqd_ctx *ctx, int method, uint64_t *n_kept);
+
+/* ---- all of 2..5 ----------------------------------------------------------- */
+int fqd_cluster(fqd_ctx *ctx, const uint32_t *weights, const uint64_t *read_ids, int mem,
+                int max_distance, int metric, int method, fqd_summary *out);
+
+/* ---- results --------------------------------------------------------------- */
+/* n_kept ids, ascending: the first holder of every kept key. */
+int fqd_get_kept_read_ids(fqd_ctx *ctx, uint64_t *out, int mem);
+/* Per unique key u in [0, n_unique): first holder, count, component label
+ * (= smallest u of the component), kept flag. Any pointer may be NULL. */
+int fqd_get_unique_table(fqd_ctx *ctx, uint64_t *first_ids, uint32_t *counts, uint32_t *labels,
+                         uint8_t *kept, int mem);
+
+/* ---- exchange (multi-GPU: the caller moves these buffers with RCCL) -------- */
+/* Packed reads of stage 1: recs n*stride_words u32, lens n u32, hashes n u64. */
+int fqd_export_packed(fqd_ctx *ctx, uint32_t *recs, uint32_t *lens, uint64_t *hashes, int mem);
+int fqd_import_packed(fqd_ctx *ctx, const uint32_t *recs, const uint32_t *lens, uint64_t n, int mem);
+/* Unique table of stage 2. */
+int fqd_export_unique(fqd_ctx *ctx, uint32_t *recs, uint32_t *lens, uint32_t *counts,
+                      uint64_t *first_ids, int mem);
+int fqd_import_unique(fqd_ctx *ctx, const uint32_t *recs, const uint32_t *lens,
+                      const uint32_t *counts, const uint64_t *first_ids, uint64_t n_unique, int mem);
+/* Edge list of stage 3: n_edges pairs (u, v), u < v. */
+int fqd_export_edges(fqd_ctx *ctx, uint32_t *uv, int mem);
+int fqd_import_edges(fqd_ctx *ctx, const uint32_t *uv, uint64_t n_edges, int mem);
+
+/* ---- single calls of the reference surface --------------------------------- */
+/* out[i] = within_distance(a_i, b_i) for n pairs (_distancemodule.c:46-93). */
+int fqd_within_distance(fqd_ctx *ctx, const uint8_t *a_bytes, const uint64_t *a_offsets,
+                        const uint8_t *b_bytes, const uint64_t *b_offsets, uint64_t n,
+                        int max_distance, int metric, uint8_t *out, int mem);
+/* out[i] = 1 when some unique key (after fqd_collapse) is within max_distance of
+ * query i (Trie.contains_sequence, _triemodule.c:730-758). */
+int fqd_contains(fqd_ctx *ctx, const uint8_t *q_bytes, const uint64_t *q_offsets, uint64_t n,
+                 int max_distance, int metric, uint8_t *out, int mem);
+
+/* ---- measurement ----------------------------------------------------------- */
+#define FQD_T_PACK       0
+#define FQD_T_COLLAPSE   1
+#define FQD_T_EDGES      2
+#define FQD_T_COMPONENTS 3
+#define FQD_T_DISSECT    4
+#define FQD_T_PAIRS_KERNEL 5   /* sum over launches of the bucket pair-compare kernel */
+#define FQD_T_COUNT      8
+/* HIP-event milliseconds of the last run of each stage, measured on the
+ * context's own stream; launches[k] = kernel launches summed into ms[k]. */
+int fqd_stage_times(fqd_ctx *ctx, float *ms /* FQD_T_COUNT */, uint32_t *launches /* FQD_T_COUNT */);
+/* Bucket statistics of the last fqd_find_edges (for the roofline's unit count):
+ * keys gathered by the pair kernel, pairs compared, edges emitted. */
+int fqd_edge_stats(fqd_ctx *ctx, uint64_t *keys_gathered, uint64_t *pairs_compared,
+                   uint64_t *edges_emitted);
+
+/* Synthetic keys (fastqdedup_amd/synth.py, byte-identical): writes count*length
+ * ASCII bytes for reads start..start+count of an n_total-read job into `out`
+ * (device memory). Bench/test utility. */
+int fqd_synth_keys(fqd_ctx *ctx, uint8_t *out_device, uint64_t n_total, uint64_t start,
+                   uint64_t count, uint32_t length, uint32_t umi, uint64_t seed, uint32_t copies,
+                   uint64_t thr_n, uint64_t thr_sub);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,237 @@
+"""Parity of the HIP path (through the C ABI) with the reference: golden vectors
+minted by the reference, the reference's own known answers, and the CPU oracle
+on seeded inputs. GPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import surface_checks as sc
+
+pytestmark = pytest.mark.gpu
+
+METHODS = ("highest_count", "adjacency", "directional")
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fastqdedup_amd
+    return fastqdedup_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(F):
+    return F.Context(0)
+
+
+def _pack(keys):
+    enc = [k.encode() for k in keys]
+    raw = np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8)[: sum(len(e) for e in enc)]
+    off = np.concatenate([[0], np.cumsum([len(e) for e in enc])]).astype(np.uint64)
+    return raw, off
+
+
+def _golden_cases():
+    import gzip, json
+    here = os.path.dirname(os.path.abspath(__file__))
+    with gzip.open(os.path.join(here, "golden", "ref_vectors.json.gz")) as fh:
+        return sorted(json.load(fh)["cases"])
+
+
+def _device_edit_ok(tag, keys):
+    """What the device edit path covers so far (api.hip: fqd_find_edges)."""
+    if tag[0] != "L":
+        return True
+    return int(tag[1]) <= 1 and len({len(k) for k in keys}) <= 1
+
+
+@pytest.mark.parametrize("name", _golden_cases())
+def test_golden_vectors(F, ctx, ref_vectors, name):
+    case = ref_vectors["cases"][name]
+    keys, weights = case["keys"], case["weights"]
+    raw, off = _pack(keys)
+    w = np.array(weights, dtype=np.uint32)
+    uniq = sorted({k for k, ww in zip(keys, weights) if ww})
+    first = {}
+    for i, k in enumerate(keys):
+        first.setdefault(k, i)
+    for tag, run in case["runs"].items():
+        if not _device_edit_ok(tag, keys):
+            continue
+        edit, d = tag[0] == "L", int(tag[1])
+        for m in METHODS:
+            got = F.cluster_keys(raw, off, weights=w, max_distance=d, use_edit_distance=edit,
+                                 method=m, context=ctx)
+            want = sorted(first[uniq[i]] for i in run["kept"][m])
+            assert got.n_unique == len(uniq), (name, tag)
+            assert got.n_clusters == run["n_clusters"], (name, tag)
+            assert got.kept_read_ids.tolist() == want, (name, tag, m)
+        # component partition, key for key
+        fid, cnt, lab, _ = ctx.unique_table(got.n_unique, labels=True, kept=False)
+        dev_keys = [keys[int(i)] for i in fid]
+        assert sorted(dev_keys) == uniq
+        ref_label = dict(zip(uniq, run["labels"]))
+        ref_count = dict(zip(uniq, run["counts"]))
+        seen = {}
+        for k, c, l in zip(dev_keys, cnt, lab):
+            assert int(c) == ref_count[k]
+            assert seen.setdefault(int(l), ref_label[k]) == ref_label[k], "component split/merged"
+        assert len(seen) == run["n_clusters"]
+
+
+def test_known_answers_within_distance(F, known_answers):
+    sc.check_within_distance(F, known_answers)
+
+
+def test_known_answers_dissection(F, known_answers):
+    sc.check_dissection(F, known_answers)
+
+
+def test_known_answers_pop_cluster(F, known_answers):
+    for case in known_answers["trie_pop_cluster"]:
+        if case["edit"]:
+            continue  # mixed lengths under the edit metric: not on device yet
+        sc.check_trie_pop_cluster(F, {"trie_pop_cluster": [case]})
+
+
+def test_known_answers_trie_bookkeeping(F, known_answers):
+    sc.check_trie_bookkeeping(F, known_answers)
+
+
+def test_pass2_rule(F, ctx, known_answers):
+    ka = known_answers["pass2_rule"]
+    raw, off = _pack(ka["keys"])
+    w = np.array(ka["passes_quality"], dtype=np.uint32)
+    got = F.cluster_keys(raw, off, weights=w, max_distance=ka["d"], method=ka["method"], context=ctx)
+    assert got.kept_read_ids.tolist() == ka["kept_read_ids"]
+    assert got.n_clusters == ka["n_clusters"]
+    assert got.n_counted == ka["processed"]
+
+
+@pytest.mark.parametrize("n,L,umi,d,sub,nr", [
+    (10000, 50, 8, 1, 1e-3, 1e-4),      # BASELINE config 1
+    (200000, 100, 12, 1, 2e-3, 2e-4),   # config 2 shape
+    (300000, 32, 32, 1, 2e-3, 2e-4),    # config 3 shape (key = R1[:16] + R2[:16])
+    (60000, 300, 300, 2, 1e-3, 1e-4),   # config 4 shape, d=2
+    (50000, 24, 6, 2, 5e-3, 1e-3),
+    (40000, 12, 4, 3, 5e-3, 1e-3),      # low complexity, larger buckets, d=3
+])
+def test_against_oracle_synthetic(F, ctx, oracle, n, L, umi, d, sub, nr):
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    keys = synth_keys(n, L, umi, 4242 + L, sub_rate=sub, n_rate=nr).reshape(-1)
+    off = fixed_offsets(n, L)
+    for m in METHODS:
+        got = F.cluster_keys(keys, key_len=L, max_distance=d, method=m, context=ctx)
+        want = oracle.dedup(keys, off, max_distance=d, method=m)
+        assert got.n_unique == want["n_unique"]
+        assert got.n_clusters == want["n_clusters"]
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), (m, n, L, d)
+
+
+def test_edit_d1_equal_length_matches_oracle(F, ctx, oracle):
+    """Levenshtein <= 1 on equal-length keys == Hamming <= 1 (BASELINE config 5 shape)."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    n, L = 40000, 300
+    keys = synth_keys(n, L, L, 77, sub_rate=1e-3).reshape(-1)
+    got = F.cluster_keys(keys, key_len=L, max_distance=1, use_edit_distance=True, method="adjacency",
+                         context=ctx)
+    want = oracle.dedup(keys, fixed_offsets(n, L), max_distance=1, use_edit_distance=True,
+                        method="adjacency")
+    assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+
+
+def test_ragged_and_foreign_alphabet(F, ctx, oracle):
+    import random
+    rng = random.Random(3)
+    mols = ["".join(rng.choice("acgtXN-") for _ in range(rng.randint(0, 40))) for _ in range(400)]
+    keys = []
+    for _ in range(5000):
+        s = list(rng.choice(mols))
+        if s and rng.random() < 0.3:
+            s[rng.randrange(len(s))] = rng.choice("acgtXN-")
+        keys.append("".join(s))
+    raw, off = _pack(keys)
+    w = np.array([rng.choice([0, 1, 1, 1, 3]) for _ in keys], dtype=np.uint32)
+    for d in (0, 1, 2):
+        for m in METHODS:
+            got = F.cluster_keys(raw, off, weights=w, max_distance=d, method=m, context=ctx)
+            want = oracle.dedup(raw, off, w, max_distance=d, method=m)
+            assert got.n_unique == want["n_unique"]
+            assert got.n_clusters == want["n_clusters"]
+            assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), (d, m)
+    sh = ctx.shape()
+    assert bytes(sh.alphabet[: sh.alphabet_size]).decode() == "".join(sorted(set("".join(keys))))
+
+
+def test_hash_collisions_do_not_merge_keys(F, oracle, monkeypatch):
+    """Narrow the collapse hash to 5 bits: thousands of distinct keys share a hash
+    and must still come out as distinct keys."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_HASH_BITS", "5")
+    n, L = 6000, 20
+    keys = synth_keys(n, L, 6, 9, sub_rate=0.01, n_rate=0.002).reshape(-1)
+    ctx = F.Context(0)
+    got = F.cluster_keys(keys, key_len=L, max_distance=1, method="directional", context=ctx)
+    want = oracle.dedup(keys, fixed_offsets(n, L), max_distance=1, method="directional")
+    assert got.n_unique == want["n_unique"]
+    assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+
+
+def test_edge_cases(F, ctx):
+    empty = F.cluster_keys(np.zeros(0, np.uint8), np.zeros(1, np.uint64), context=ctx)
+    assert (empty.n_reads, empty.n_unique, empty.n_clusters, empty.n_kept) == (0, 0, 0, 0)
+    one = F.cluster_keys(np.frombuffer(b"ACGT", np.uint8), key_len=4, context=ctx)
+    assert one.kept_read_ids.tolist() == [0] and one.n_clusters == 1
+    same = F.cluster_keys(np.frombuffer(b"ACGT" * 1000, np.uint8), key_len=4, context=ctx)
+    assert same.kept_read_ids.tolist() == [0] and same.n_unique == 1 and same.n_counted == 1000
+    raw, off = _pack(["", "", "A", ""])
+    e = F.cluster_keys(raw, off, max_distance=1, context=ctx)
+    assert e.n_unique == 2 and e.n_clusters == 2 and e.kept_read_ids.tolist() == [0, 2]
+    with pytest.raises(ValueError):
+        F.cluster_keys(np.array([65, 200, 67], np.uint8), key_len=3, context=ctx)
+    with pytest.raises(ValueError):
+        F.cluster_keys(np.frombuffer(b"ACGT", np.uint8), key_len=4, max_distance=-1, context=ctx)
+    # d larger than the key: every pair of equal-length keys is adjacent
+    raw, off = _pack(["AC", "GT", "TT", "ACG"])
+    big = F.cluster_keys(raw, off, max_distance=5, method="highest_count", context=ctx)
+    assert big.n_clusters == 2
+
+
+def test_device_resident_input_and_synth_twin(F, ctx):
+    import torch
+    from fastqdedup_amd.synth import synth_keys
+    n, L, umi, seed = 50000, 100, 12, 1002
+    host = synth_keys(n, L, umi, seed)
+    dev = torch.empty(n * L, dtype=torch.uint8, device="cuda:0")
+    ctx.synth_keys(dev, n, 0, n, L, umi, seed)
+    assert np.array_equal(dev.cpu().numpy().reshape(n, L), host), "HIP and numpy generators differ"
+    a = F.cluster_keys(dev, key_len=L, context=ctx)
+    b = F.cluster_keys(host.reshape(-1), key_len=L, context=ctx)
+    assert np.array_equal(a.kept_read_ids, b.kept_read_ids)
+
+
+def test_full_size_properties(F, ctx):
+    """BASELINE config 2 at full size (10 M x 100 nt, UMI 12, d=1): properties that
+    need no CPU-side answer."""
+    import torch
+    n, L, umi, seed = 10_000_000, 100, 12, 1002
+    dev = torch.empty(n * L, dtype=torch.uint8, device="cuda:0")
+    ctx.synth_keys(dev, n, 0, n, L, umi, seed)
+    d0 = F.cluster_keys(dev, key_len=L, max_distance=0, context=ctx)
+    assert d0.n_kept == d0.n_unique == d0.n_clusters           # d=0: one cluster per distinct key
+    ids0 = d0.kept_read_ids
+    assert (np.diff(ids0.astype(np.int64)) > 0).all()          # sorted, no read twice
+    hc = F.cluster_keys(dev, key_len=L, max_distance=1, method="highest_count", context=ctx)
+    dr = F.cluster_keys(dev, key_len=L, max_distance=1, method="directional", context=ctx)
+    ad = F.cluster_keys(dev, key_len=L, max_distance=1, method="adjacency", context=ctx)
+    assert hc.n_unique == d0.n_unique and hc.n_kept == hc.n_clusters
+    assert hc.n_clusters == dr.n_clusters == ad.n_clusters < d0.n_clusters
+    assert hc.n_kept <= dr.n_kept <= d0.n_kept and hc.n_kept <= ad.n_kept <= d0.n_kept
+    # every kept read is the first holder of a distinct key: subset of the d=0 answer
+    assert np.isin(dr.kept_read_ids, ids0).all() and np.isin(ad.kept_read_ids, ids0).all()
+    # idempotence: clustering only the kept reads again keeps them all under highest_count's
+    # complement -- no two kept keys of `adjacency` are adjacent
+    sel = torch.from_numpy(ad.kept_read_ids.astype(np.int64)).to("cuda:0")
+    sub = dev.view(n, L)[sel].contiguous().view(-1)
+    again = F.cluster_keys(sub, key_len=L, max_distance=1, method="adjacency", context=ctx)
+    assert again.n_edges == 0 and again.n_kept == ad.n_kept
