@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the clustering hot path on N MI355X (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3]
+
+A step = one pass of the hot path (pack -> collapse -> bucket pair search ->
+components -> dissection -> kept read ids) over one batch of synthetic keys that
+already sit in HBM. Prints ONE JSON line (rank 0). See DESIGN.md "measurement".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# BASELINE.json configs. n = reads PER GPU (weak scaling), key = what enters the trie.
+WORKLOADS = {
+    # configs[2]: the configuration BASELINE.json's metric ("Hamming<=1, 150 bp") and target are quoted on
+    "config3": dict(n=50_000_000, L=32, umi=32, d=1, edit=False, method="directional", seed=1003,
+                    name="50M paired 2x150-bp reads, --check-lengths 16,16 (key = R1[:16]+R2[:16], 32 nt), "
+                         "Hamming d=1, directional"),
+    "config2": dict(n=10_000_000, L=100, umi=12, d=1, edit=False, method="directional", seed=1002,
+                    name="10M single-end 100-bp reads, UMI=12, Hamming d=1, directional"),
+    "config1": dict(n=10_000, L=50, umi=8, d=1, edit=False, method="directional", seed=1001,
+                    name="10k single-end 50-bp reads, UMI=8, Hamming d=1, directional"),
+    "config4": dict(n=25_000_000, L=300, umi=300, d=2, edit=False, method="directional", seed=1004,
+                    name="200M paired 2x150-bp reads over 8 GPUs (25M per GPU), key = R1+R2 (300 nt), "
+                         "Hamming d=2, directional"),
+    "config5": dict(n=50_000_000, L=300, umi=300, d=1, edit=True, method="adjacency", seed=1005,
+                    name="50M paired 2x150-bp reads, key = R1+R2 (300 nt), --edit d=1, adjacency"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(ctx, wl, sample_reads: int):
+    """The reference CPU path (oracle/_ref: the reference's own trie + distance
+    extensions, driven as deduplicate_cluster drives them) on a bounded sample of
+    the same workload; falls back to the oracle's C port when _ref is absent."""
+    from oracle import oracle as O
+    n = min(sample_reads, wl["n"])
+    dev = torch.empty(n * wl["L"], dtype=torch.uint8, device="cuda:0")
+    ctx.synth_keys(dev, n, 0, n, wl["L"], wl["umi"], wl["seed"])
+    host = dev.cpu().numpy()
+    del dev
+    sample = (f"first {n} reads of the same generator (n_total={n}, L={wl['L']}, umi={wl['umi']}, "
+              f"seed={wl['seed']}), d={wl['d']}, {'edit' if wl['edit'] else 'hamming'}, {wl['method']}")
+    cores = 1
+    if O.reference_available():
+        from oracle import ref_driver
+        strs = [s.decode() for s in host.view(f"S{wl['L']}")]
+        out = ref_driver.run_reference_path(strs, wl["d"], wl["edit"], wl["method"])
+        secs = out["seconds"]
+        return {"value": n / secs["total"], "unit": "reads/s", "cores": cores, "kind": "reference",
+                "sample": sample, "seconds": {k: round(v, 3) for k, v in secs.items()},
+                "n_unique": out["n_unique"], "n_clusters": out["n_clusters"], "n_kept": len(out["kept_keys"]),
+                "cpu_count": os.cpu_count(),
+                "note": "reference C extensions (Trie, within_distance) built from the reference sources; "
+                        "its Python dissection loops restated in oracle/ref_driver.py"}
+    from fastqdedup_amd.synth import fixed_offsets
+    out = O.dedup(host, fixed_offsets(n, wl["L"]), max_distance=wl["d"], use_edit_distance=wl["edit"],
+                  method=wl["method"])
+    total = sum(out["stage_seconds"].values())
+    return {"value": n / total, "unit": "reads/s", "cores": cores, "kind": "port", "sample": sample,
+            "seconds": {k: round(v, 3) for k, v in out["stage_seconds"].items()},
+            "n_unique": out["n_unique"], "n_clusters": out["n_clusters"],
+            "n_kept": int(len(out["kept_read_ids"])), "cpu_count": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--reads-per-gpu", type=int, default=0, help="override the workload's n (testing)")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import fastqdedup_amd as F
+    from fastqdedup_amd import _lib
+    from fastqdedup_amd.sharded import HipBackend, cluster_keys_sharded
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.reads_per_gpu:
+        wl["n"] = args.reads_per_gpu
+    n, L = wl["n"], wl["L"]
+    n_total = n * world
+    ctx = F.Context(local_rank)
+
+    # synthetic input, generated in HBM before the timed region
+    keys = torch.empty(n * L, dtype=torch.uint8, device=device)
+    ctx.synth_keys(keys, n_total, rank * n, n, L, wl["umi"], wl["seed"])
+    kept_buf = torch.empty(n, dtype=torch.int64, device=device)
+    backend = HipBackend(ctx, device) if world > 1 else None
+
+    def step():
+        if world == 1:
+            return F.cluster_keys(keys, key_len=L, max_distance=wl["d"], use_edit_distance=wl["edit"],
+                                  method=wl["method"], context=ctx, kept_out=kept_buf)
+        return cluster_keys_sharded(backend, keys, None, L, max_distance=wl["d"],
+                                    use_edit_distance=wl["edit"], method=wl["method"])
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    stage_sum, pairs_ms, pairs_launches = {}, 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        ms, launches = ctx.stage_times()
+        for k, v in ms.items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+        pairs_ms += ms["pairs_kernel"]
+        pairs_launches += launches["pairs_kernel"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_total * args.steps / elapsed
+
+    # ---- roofline of the bucket pair-compare kernel (DESIGN.md "kernels") -------
+    sh = ctx.shape()
+    st = ctx.edge_stats()          # of the last step: all d+1 launches
+    nseg = wl["d"] + 1
+    u_table = res.n_unique
+    b_key = sh.planes * sh.words * 4
+    # algorithmic bytes of ONE launch: (bucket hash, uid) of every unique key, the record of
+    # every key that sits in a bucket of >= 2 (read once), 8 B per emitted edge
+    alg_bytes = u_table * 8 + st["keys_gathered"] / nseg * b_key + st["edges"] / nseg * 8
+    avg_ms = pairs_ms / max(pairs_launches, 1)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"kernel": "bucket_pairs_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None, "alg_bytes_per_launch": int(alg_bytes),
+                "avg_launch_ms": round(avg_ms, 4), "launches_timed": pairs_launches}
+
+    out = {
+        "metric": "reads/sec clustered (Hamming<=1, 150 bp)", "value": round(value, 1), "unit": "reads/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+        "data": "synthetic keys generated in HBM (fqd_synth_keys, fastqdedup_amd/synth.py)",
+        "config": {"workload": wl["name"], "reads_per_gpu": n, "reads_total": n_total, "key_len": L,
+                   "max_distance": wl["d"], "metric": "edit" if wl["edit"] else "hamming",
+                   "dissection": wl["method"], "seed": wl["seed"],
+                   "parallelism": "1 process/GPU, key-hash all-to-all + bucket-sharded search" if world > 1
+                   else "single GPU"},
+        "result": {"n_unique": res.n_unique, "n_edges": res.n_edges, "n_clusters": res.n_clusters,
+                   "n_kept": res.n_kept},
+        "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_sum.items()},
+        "record_bytes": sh.stride_words * 4, "planes": sh.planes,
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(ctx, wl, args.cpu_sample)
+        except Exception as exc:  # the GPU numbers stand on their own
+            out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -142,7 +142,7 @@ def _dissect_on_device(cluster, method: int, max_distance: int, use_edit_distanc
     shape = ctx.shape()
     recs = np.empty(n * shape.stride_words, dtype=np.uint32)
     lens = np.empty(n, dtype=np.uint32)
-    hashes = np.empty(n, dtype=np.uint64)
+    hashes = np.empty(n, dtype=np.uint32)
     ctx.export_packed(recs, lens, hashes)
     # every list item is its own node, even if a key repeats (the reference
     # compares items pairwise and never merges them)

@@ -270,20 +270,12 @@ uint64_t total_bytes_of(const uint64_t *offsets_host_or_null, uint64_t n, uint32
     return offsets_host_or_null ? offsets_host_or_null[n] : n * (uint64_t)fixed_len;
 }
 
-int sort_u64_pairs(fqd_ctx *c, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n,
-                   int bits)
+int sort_u32_pairs(fqd_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n,
+                   int bits = 32)
 {
-    const size_t need = fqd::sort_pairs_u64_u32_temp(n, 0, bits);
+    const size_t need = fqd::sort_pairs_u32_u32_temp(n, 0, bits);
     HIP_TRY(c, c->tmp.reserve(need + 16));
-    HIP_TRY(c, fqd::sort_pairs_u64_u32(c->tmp.p, need, kin, kout, vin, vout, n, 0, bits, c->st));
-    return FQD_OK;
-}
-
-int sort_u32_pairs(fqd_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n)
-{
-    const size_t need = fqd::sort_pairs_u32_u32_temp(n, 0, 32);
-    HIP_TRY(c, c->tmp.reserve(need + 16));
-    HIP_TRY(c, fqd::sort_pairs_u32_u32(c->tmp.p, need, kin, kout, vin, vout, n, 0, 32, c->st));
+    HIP_TRY(c, fqd::sort_pairs_u32_u32(c->tmp.p, need, kin, kout, vin, vout, n, 0, bits, c->st));
     return FQD_OK;
 }
 
@@ -299,9 +291,9 @@ int hash_bits_from_env()
 {
     const char *e = getenv("FQD_HASH_BITS");  // tests narrow the hash to force collisions
     if (!e)
-        return 64;
+        return 32;
     int b = atoi(e);
-    return b < 1 ? 1 : (b > 64 ? 64 : b);
+    return b < 1 ? 1 : (b > 32 ? 32 : b);
 }
 
 }  // namespace
@@ -483,13 +475,13 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
 
     const KeyShape sh = c->ks;
     HIP_TRY(c, c->recs.reserve((size_t)n * sh.stride * 4 + 16));
-    HIP_TRY(c, c->hashes.reserve((size_t)n * 8 + 16));
+    HIP_TRY(c, c->hashes.reserve((size_t)n * 4 + 16));
     if (sh.ragged)
         HIP_TRY(c, c->lens.reserve((size_t)n * 4 + 16));
     FQD_TRY(zero_ctr32(c, C_BAD));
     HIP_TRY(c, fqd::launch_pack(d_bytes, n_bytes, d_off, n, fixed_len, sh, c->d_lut.as<uint8_t>(),
                                 c->recs.as<uint32_t>(), sh.ragged ? c->lens.as<uint32_t>() : nullptr,
-                                c->hashes.as<uint64_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+                                c->hashes.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
     uint32_t bad = 0;
     FQD_TRY(read_ctr32(c, C_BAD, &bad));
     timer.stop();
@@ -526,21 +518,21 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
     FQD_TRY(to_device(c, read_ids, (size_t)n, mem, c->in_read_ids, &d_ids));
 
     const int bits = hash_bits_from_env();
-    const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
-    HIP_TRY(c, c->hs_sorted.reserve(n * 8 + 16));
+    const uint32_t mask = bits >= 32 ? ~0u : ((1u << bits) - 1u);
+    HIP_TRY(c, c->hs_sorted.reserve(n * 4 + 16));
     HIP_TRY(c, c->ids.reserve(n * 4 + 16));
     HIP_TRY(c, c->ids_sorted.reserve(n * 4 + 16));
     HIP_TRY(c, c->flags.reserve(n * 4 + 16));
     HIP_TRY(c, c->run_idx.reserve(n * 4 + 16));
     HIP_TRY(c, fqd::launch_iota_u32(c->ids.as<uint32_t>(), n, c->st));
-    FQD_TRY(sort_u64_pairs(c, c->hashes.as<uint64_t>(), c->hs_sorted.as<uint64_t>(), c->ids.as<uint32_t>(),
+    FQD_TRY(sort_u32_pairs(c, c->hashes.as<uint32_t>(), c->hs_sorted.as<uint32_t>(), c->ids.as<uint32_t>(),
                            c->ids_sorted.as<uint32_t>(), n, bits));
 
     uint32_t cap = (uint32_t)std::max<size_t>(1024, c->collision_runs.cap / 4);
     for (;;) {
         HIP_TRY(c, c->collision_runs.reserve((size_t)cap * 4));
         FQD_TRY(zero_ctr32(c, C_COLLISIONS));
-        HIP_TRY(c, fqd::launch_head_flags(c->hs_sorted.as<uint64_t>(), c->ids_sorted.as<uint32_t>(),
+        HIP_TRY(c, fqd::launch_head_flags(c->hs_sorted.as<uint32_t>(), c->ids_sorted.as<uint32_t>(),
                                           c->recs.as<uint32_t>(), c->lens.as<uint32_t>(), n, sh, mask,
                                           c->flags.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_COLLISIONS,
                                           c->collision_runs.as<uint32_t>(), cap, c->st));
@@ -550,7 +542,7 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
             cap = n_coll + 1024;
             continue;
         }
-        HIP_TRY(c, fqd::launch_fix_collision_runs(c->hs_sorted.as<uint64_t>(), c->ids_sorted.as<uint32_t>(),
+        HIP_TRY(c, fqd::launch_fix_collision_runs(c->hs_sorted.as<uint32_t>(), c->ids_sorted.as<uint32_t>(),
                                                   c->recs.as<uint32_t>(), c->lens.as<uint32_t>(), n, sh, mask,
                                                   c->flags.as<uint32_t>(), c->collision_runs.as<uint32_t>(), n_coll,
                                                   c->st));
@@ -839,7 +831,7 @@ int fqd_get_unique_table(fqd_ctx *c, uint64_t *first_ids, uint32_t *counts, uint
 }
 
 // ---- exchange -------------------------------------------------------------------
-int fqd_export_packed(fqd_ctx *c, uint32_t *recs, uint32_t *lens, uint64_t *hashes, int mem)
+int fqd_export_packed(fqd_ctx *c, uint32_t *recs, uint32_t *lens, uint32_t *hashes, int mem)
 {
     FQD_TRY(bind(c));
     if (c->stage < ST_PACKED)
@@ -870,7 +862,7 @@ int fqd_import_packed(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, ui
     const KeyShape sh = c->ks;
     const hipMemcpyKind kind = mem == FQD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     HIP_TRY(c, c->recs.reserve((size_t)n * sh.stride * 4 + 16));
-    HIP_TRY(c, c->hashes.reserve((size_t)n * 8 + 16));
+    HIP_TRY(c, c->hashes.reserve((size_t)n * 4 + 16));
     if (n)
         HIP_TRY(c, hipMemcpyAsync(c->recs.p, recs, (size_t)n * sh.stride * 4, kind, c->st));
     if (sh.ragged) {
@@ -881,7 +873,7 @@ int fqd_import_packed(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, ui
             HIP_TRY(c, hipMemcpyAsync(c->lens.p, lens, (size_t)n * 4, kind, c->st));
     }
     HIP_TRY(c, fqd::launch_hash_records(c->recs.as<uint32_t>(), c->lens.as<uint32_t>(), n, sh,
-                                        c->hashes.as<uint64_t>(), c->st));
+                                        c->hashes.as<uint32_t>(), c->st));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     c->n = n;
     c->stage = ST_PACKED;

@@ -3,7 +3,7 @@
 // Replaces the duplicate-count half of TrieNode_AddSequence (reference
 // _triemodule.c:235-239, :261-264: "identical key => count += n").
 //
-// Reads are radix-sorted by (a prefix of) their 64-bit key hash (prims.hip);
+// Reads are radix-sorted by (a prefix of) their 32-bit key hash (prims.hip);
 // the kernels here turn the sorted order into runs of IDENTICAL KEYS. A hash
 // only proposes: a read opens a new run unless its full record equals its
 // predecessor's, and runs of equal hash that hold more than one distinct key
@@ -49,10 +49,10 @@ __global__ void iota_kernel(uint32_t *out, uint64_t n)
         out[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(256) void head_flags_kernel(const uint64_t *__restrict__ hs, const uint32_t *__restrict__ ids,
+__global__ __launch_bounds__(256) void head_flags_kernel(const uint32_t *__restrict__ hs, const uint32_t *__restrict__ ids,
                                                          const uint32_t *__restrict__ recs,
                                                          const uint32_t *__restrict__ lens, uint64_t n, KeyShape sh,
-                                                         uint64_t hash_mask, uint32_t *__restrict__ flags,
+                                                         uint32_t hash_mask, uint32_t *__restrict__ flags,
                                                          uint32_t *__restrict__ n_collision_runs,
                                                          uint32_t *__restrict__ collision_runs, uint32_t cap)
 {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void head_flags_kernel(const uint64_t *__restr
             head = 0;
         } else {
             // equal hash, different key: report the run once (by its first such position)
-            const uint64_t h = hs[i] & hash_mask;
+            const uint32_t h = hs[i] & hash_mask;
             uint64_t a = i - 1;
             bool first = true;
             while (a > 0 && (hs[a - 1] & hash_mask) == h) {
@@ -88,16 +88,16 @@ __global__ __launch_bounds__(256) void head_flags_kernel(const uint64_t *__restr
 // One thread per reported run [a, b): insertion sort of ids by (record, id), then
 // rewrite the head flags of the run. Runs are a handful of reads unless the hash
 // has been narrowed on purpose (FQD_HASH_BITS, tests).
-__global__ void fix_collision_runs_kernel(const uint64_t *__restrict__ hs, uint32_t *__restrict__ ids,
+__global__ void fix_collision_runs_kernel(const uint32_t *__restrict__ hs, uint32_t *__restrict__ ids,
                                           const uint32_t *__restrict__ recs, const uint32_t *__restrict__ lens,
-                                          uint64_t n, KeyShape sh, uint64_t hash_mask, uint32_t *__restrict__ flags,
+                                          uint64_t n, KeyShape sh, uint32_t hash_mask, uint32_t *__restrict__ flags,
                                           const uint32_t *__restrict__ collision_runs, uint32_t n_runs)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_runs)
         return;
     const uint64_t a = collision_runs[r];
-    const uint64_t h = hs[a] & hash_mask;
+    const uint32_t h = hs[a] & hash_mask;
     uint64_t b = a + 1;
     while (b < n && (hs[b] & hash_mask) == h)
         b++;
@@ -198,8 +198,8 @@ hipError_t launch_iota_u32(uint32_t *out, uint64_t n, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_head_flags(const uint64_t *hs, const uint32_t *ids, const uint32_t *recs, const uint32_t *lens,
-                             uint64_t n, KeyShape sh, uint64_t hash_mask, uint32_t *flags,
+hipError_t launch_head_flags(const uint32_t *hs, const uint32_t *ids, const uint32_t *recs, const uint32_t *lens,
+                             uint64_t n, KeyShape sh, uint32_t hash_mask, uint32_t *flags,
                              uint32_t *n_collision_runs, uint32_t *collision_runs, uint32_t cap, hipStream_t st)
 {
     if (n)
@@ -208,8 +208,8 @@ hipError_t launch_head_flags(const uint64_t *hs, const uint32_t *ids, const uint
     return hipGetLastError();
 }
 
-hipError_t launch_fix_collision_runs(const uint64_t *hs, uint32_t *ids, const uint32_t *recs, const uint32_t *lens,
-                                     uint64_t n, KeyShape sh, uint64_t hash_mask, uint32_t *flags,
+hipError_t launch_fix_collision_runs(const uint32_t *hs, uint32_t *ids, const uint32_t *recs, const uint32_t *lens,
+                                     uint64_t n, KeyShape sh, uint32_t hash_mask, uint32_t *flags,
                                      const uint32_t *collision_runs, uint32_t n_runs, hipStream_t st)
 {
     if (n_runs)

@@ -43,13 +43,18 @@ __global__ __launch_bounds__(256) void segment_hashes_kernel(const uint32_t *__r
 }
 
 // ---- the pair kernel -----------------------------------------------------------
-// One block = T consecutive positions of the bucket-sorted order. Keys that sit
-// in a bucket of >= 2 are gathered ONCE from HBM (one aligned record each) into
-// a word-major LDS tile (word j of key t at tile[j*T + t]: lanes t, t+1, ... hit
-// consecutive banks). Lane t then walks forward over the rest of its bucket,
-// XOR/OR/popcount per 32-base word with early exit; partners beyond the tile are
-// read from HBM. Hits are appended with one atomic per wave (ballot + popcount
-// of the lanes below).
+// Persistent blocks walk tiles of T consecutive positions of the bucket-sorted
+// order. Keys that sit in a bucket of >= 2 are gathered ONCE from HBM (one
+// aligned record each) into a word-major LDS tile (word j of key t at
+// tile[j*T + t]: lanes t, t+1, ... hit consecutive banks). Lane t then walks
+// forward over the rest of its bucket, XOR/OR/popcount per 32-base word with
+// early exit; partners beyond the tile are read from HBM. Hits go to an LDS
+// edge buffer (wave ballot + popcount of the lanes below, one LDS atomic per
+// wave); the buffer is flushed to HBM with ONE global atomic per flush, so the
+// single edge counter is touched a few thousand times per launch instead of
+// once per hit.
+constexpr uint32_t PAIR_ECAP = 1024;  // edges buffered per block
+
 template <int K, bool USE_LDS>
 __global__ __launch_bounds__(256) void bucket_pairs_kernel(
     const uint32_t *__restrict__ sorted_hash, const uint32_t *__restrict__ sorted_uid, uint64_t U,
@@ -59,125 +64,169 @@ __global__ __launch_bounds__(256) void bucket_pairs_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t T = blockDim.x;
-    uint32_t *s_hash = smem;          // T
-    uint32_t *s_uid = smem + T;       // T
-    uint32_t *s_len = smem + 2 * T;   // T
-    uint32_t *tile = smem + 3 * T;    // KW * T when USE_LDS
+    uint32_t *s_hash = smem;                    // T
+    uint32_t *s_uid = smem + T;                 // T
+    uint32_t *s_len = smem + 2 * T;             // T
+    uint32_t *s_edges = smem + 3 * T;           // 2 * PAIR_ECAP
+    uint32_t *s_ctl = s_edges + 2 * PAIR_ECAP;  // [0] buffered edges, [1..2] flush base (lo, hi)
+    uint32_t *tile = s_ctl + 4;                 // KW * T when USE_LDS
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint64_t base = (uint64_t)blockIdx.x * T;
-    const uint64_t i = base + tid;
-    const bool valid = i < U;
     const uint32_t W = sh.words, KW = W * K, stride = sh.stride;
+    const uint64_t n_tiles = (U + T - 1) / T;
+    unsigned long long n_pairs = 0, n_hits = 0, n_gathered = 0;
 
-    const uint32_t h = valid ? sorted_hash[i] : 0u;
-    const uint32_t uid = valid ? sorted_uid[i] : 0u;
-    s_hash[tid] = h;
-    s_uid[tid] = uid;
+    if (tid == 0)
+        s_ctl[0] = 0;
     __syncthreads();
-    bool prev_same = false, next_same = false;
-    if (valid) {
-        if (i > 0)
-            prev_same = (tid > 0 ? s_hash[tid - 1] : sorted_hash[i - 1]) == h;
-        if (i + 1 < U)
-            next_same = (tid + 1 < T ? s_hash[tid + 1] : sorted_hash[i + 1]) == h;
-    }
-    const bool mine = n_shards <= 1 || (h % n_shards) == shard;
-    const bool multi = valid && mine && (prev_same || next_same);
-    const uint32_t len = valid ? fqd_key_len(sh, ulens, uid) : 0u;
-    s_len[tid] = len;
-    const uint32_t *my_rec = urecs + (uint64_t)uid * stride;
-    if (USE_LDS && multi) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(my_rec);
-        for (uint32_t q = 0; q < stride / 4; q++) {
-            const uint4 v = src[q];
-            const uint32_t j = q * 4;
-            if (j + 0 < KW) tile[(j + 0) * T + tid] = v.x;
-            if (j + 1 < KW) tile[(j + 1) * T + tid] = v.y;
-            if (j + 2 < KW) tile[(j + 2) * T + tid] = v.z;
-            if (j + 3 < KW) tile[(j + 3) * T + tid] = v.w;
+
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t base = t * T;
+        const uint64_t i = base + tid;
+        const bool valid = i < U;
+        const uint32_t h = valid ? sorted_hash[i] : 0u;
+        const uint32_t uid = valid ? sorted_uid[i] : 0u;
+        s_hash[tid] = h;
+        s_uid[tid] = uid;
+        __syncthreads();
+        bool prev_same = false, next_same = false;
+        if (valid) {
+            if (i > 0)
+                prev_same = (tid > 0 ? s_hash[tid - 1] : sorted_hash[i - 1]) == h;
+            if (i + 1 < U)
+                next_same = (tid + 1 < T ? s_hash[tid + 1] : sorted_hash[i + 1]) == h;
         }
-    }
-    __syncthreads();
-
-    unsigned long long n_pairs = 0, n_hits = 0;
-    if (multi && next_same) {
-        for (uint64_t gj = i + 1; gj < U; gj++) {
-            const uint32_t j = (uint32_t)(gj - base);
-            const bool in_tile = j < T;
-            const uint32_t hj = in_tile ? s_hash[j] : sorted_hash[gj];
-            if (hj != h)
-                break;
-            const uint32_t uj = in_tile ? s_uid[j] : sorted_uid[gj];
-            const uint32_t lj = in_tile ? s_len[j] : fqd_key_len(sh, ulens, uj);
-            n_pairs++;
-            bool hit = false;
-            if (lj == len) {
-                const uint32_t *other = urecs + (uint64_t)uj * stride;
-                uint32_t dist = 0;
-                for (uint32_t w = 0; w < W && dist <= d; w++) {
-                    uint32_t dw = 0;
-#pragma unroll
-                    for (int k = 0; k < K; k++) {
-                        const uint32_t a = USE_LDS ? tile[(w * K + k) * T + tid] : my_rec[w * K + k];
-                        const uint32_t b = (USE_LDS && in_tile) ? tile[(w * K + k) * T + j] : other[w * K + k];
-                        dw |= a ^ b;
-                    }
-                    dist += __popc(dw);
+        const bool mine = n_shards <= 1 || (h % n_shards) == shard;
+        const bool multi = valid && mine && (prev_same || next_same);
+        const uint32_t *my_rec = urecs + (uint64_t)uid * stride;
+        uint32_t len = sh.max_len;
+        if (multi) {
+            n_gathered++;
+            if (sh.ragged)
+                len = ulens[uid];
+            if (USE_LDS) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(my_rec);
+                for (uint32_t q = 0; q < stride / 4; q++) {
+                    const uint4 v = src[q];
+                    const uint32_t j = q * 4;
+                    if (j + 0 < KW) tile[(j + 0) * T + tid] = v.x;
+                    if (j + 1 < KW) tile[(j + 1) * T + tid] = v.y;
+                    if (j + 2 < KW) tile[(j + 2) * T + tid] = v.z;
+                    if (j + 3 < KW) tile[(j + 3) * T + tid] = v.w;
                 }
-                if (dist <= d) {
-                    // emit only in the pass of the first truly agreeing segment
-                    hit = true;
-                    for (uint32_t s2 = 0; s2 < seg && hit; s2++) {
-                        uint32_t lo, hi;
-                        fqd_segment(len, s2, nseg, lo, hi);
-                        bool agree = true;
-                        if (hi > lo) {
-                            for (uint32_t w = lo >> 5; w <= ((hi - 1) >> 5) && agree; w++) {
-                                uint32_t dw = 0;
+            }
+        }
+        s_len[tid] = len;
+        __syncthreads();
+
+        if (multi && next_same) {
+            for (uint64_t gj = i + 1; gj < U; gj++) {
+                const uint32_t j = (uint32_t)(gj - base);
+                const bool in_tile = j < T;
+                const uint32_t hj = in_tile ? s_hash[j] : sorted_hash[gj];
+                if (hj != h)
+                    break;
+                const uint32_t uj = in_tile ? s_uid[j] : sorted_uid[gj];
+                const uint32_t lj = in_tile ? s_len[j] : fqd_key_len(sh, ulens, uj);
+                n_pairs++;
+                bool hit = false;
+                if (lj == len) {
+                    const uint32_t *other = urecs + (uint64_t)uj * stride;
+                    uint32_t dist = 0;
+                    for (uint32_t w = 0; w < W && dist <= d; w++) {
+                        uint32_t dw = 0;
 #pragma unroll
-                                for (int k = 0; k < K; k++) {
-                                    const uint32_t a = USE_LDS ? tile[(w * K + k) * T + tid] : my_rec[w * K + k];
-                                    const uint32_t b =
-                                        (USE_LDS && in_tile) ? tile[(w * K + k) * T + j] : other[w * K + k];
-                                    dw |= a ^ b;
+                        for (int k = 0; k < K; k++) {
+                            const uint32_t a = USE_LDS ? tile[(w * K + k) * T + tid] : my_rec[w * K + k];
+                            const uint32_t b = (USE_LDS && in_tile) ? tile[(w * K + k) * T + j] : other[w * K + k];
+                            dw |= a ^ b;
+                        }
+                        dist += __popc(dw);
+                    }
+                    if (dist <= d) {
+                        // emit only in the pass of the first truly agreeing segment
+                        hit = true;
+                        for (uint32_t s2 = 0; s2 < seg && hit; s2++) {
+                            uint32_t lo, hi;
+                            fqd_segment(len, s2, nseg, lo, hi);
+                            bool agree = true;
+                            if (hi > lo) {
+                                for (uint32_t w = lo >> 5; w <= ((hi - 1) >> 5) && agree; w++) {
+                                    uint32_t dw = 0;
+#pragma unroll
+                                    for (int k = 0; k < K; k++) {
+                                        const uint32_t a = USE_LDS ? tile[(w * K + k) * T + tid] : my_rec[w * K + k];
+                                        const uint32_t b =
+                                            (USE_LDS && in_tile) ? tile[(w * K + k) * T + j] : other[w * K + k];
+                                        dw |= a ^ b;
+                                    }
+                                    if (dw & fqd_range_mask(w, lo, hi))
+                                        agree = false;
                                 }
-                                if (dw & fqd_range_mask(w, lo, hi))
-                                    agree = false;
+                            }
+                            if (agree)
+                                hit = false;
+                        }
+                    }
+                }
+                const unsigned long long m = __ballot(hit);
+                if (m) {
+                    const int leader = __ffsll((long long)m) - 1;
+                    uint32_t at = 0;
+                    if ((int)lane == leader)
+                        at = atomicAdd(&s_ctl[0], (uint32_t)__popcll(m));
+                    at = __shfl(at, leader);
+                    if (hit) {
+                        at += __popcll(m & fqd_lanemask_lt());
+                        const uint32_t eu = uid < uj ? uid : uj, ev = uid < uj ? uj : uid;
+                        if (at < PAIR_ECAP) {
+                            s_edges[2 * at] = eu;
+                            s_edges[2 * at + 1] = ev;
+                        } else {
+                            // buffer full inside one tile (a very large bucket): straight to HBM
+                            const unsigned long long g = atomicAdd(edge_count, 1ull);
+                            if (g < edge_cap) {
+                                edges[2 * g] = eu;
+                                edges[2 * g + 1] = ev;
                             }
                         }
-                        if (agree)
-                            hit = false;
+                        n_hits++;
                     }
                 }
             }
-            const unsigned long long m = __ballot(hit);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                unsigned long long at = 0;
-                if ((int)lane == leader)
-                    at = atomicAdd(edge_count, (unsigned long long)__popcll(m));
-                at = __shfl(at, leader);
-                if (hit) {
-                    at += __popcll(m & fqd_lanemask_lt());
-                    if (at < edge_cap) {
-                        edges[2 * at] = uid < uj ? uid : uj;
-                        edges[2 * at + 1] = uid < uj ? uj : uid;
-                    }
-                    n_hits++;
-                }
+        }
+        __syncthreads();
+        // flush when more than half full, and after the block's last tile
+        const uint32_t buffered = s_ctl[0];
+        const bool last = t + gridDim.x >= n_tiles;
+        if (buffered >= PAIR_ECAP / 2 || (last && buffered)) {
+            const uint32_t cnt = buffered < PAIR_ECAP ? buffered : PAIR_ECAP;
+            if (tid == 0) {
+                const unsigned long long g = atomicAdd(edge_count, (unsigned long long)cnt);
+                s_ctl[1] = (uint32_t)g;
+                s_ctl[2] = (uint32_t)(g >> 32);
             }
+            __syncthreads();
+            const unsigned long long g = ((unsigned long long)s_ctl[2] << 32) | s_ctl[1];
+            for (uint32_t e = tid; e < cnt; e += T)
+                if (g + e < edge_cap) {
+                    edges[2 * (g + e)] = s_edges[2 * e];
+                    edges[2 * (g + e) + 1] = s_edges[2 * e + 1];
+                }
+            __syncthreads();
+            if (tid == 0)
+                s_ctl[0] = 0;
+            __syncthreads();
         }
     }
     if (stats) {
-        unsigned long long g = multi ? 1ull : 0ull;
         for (int o = 32; o; o >>= 1) {
-            g += __shfl_xor(g, o);
+            n_gathered += __shfl_xor(n_gathered, o);
             n_pairs += __shfl_xor(n_pairs, o);
             n_hits += __shfl_xor(n_hits, o);
         }
         if (lane == 0) {
-            if (g) atomicAdd(&stats->keys_gathered, g);
+            if (n_gathered) atomicAdd(&stats->keys_gathered, n_gathered);
             if (n_pairs) atomicAdd(&stats->pairs_compared, n_pairs);
             if (n_hits) atomicAdd(&stats->edges, n_hits);
         }
@@ -278,15 +327,19 @@ hipError_t launch_bucket_pairs(const uint32_t *sorted_hash, const uint32_t *sort
     const uint32_t KW = sh.planes * sh.words;
     uint32_t T = 256;
     const uint32_t budget = 60 * 1024;
+    const uint32_t fixed_words = 2 * PAIR_ECAP + 4;
     bool use_lds = true;
-    while (T > 64 && (3 + KW) * T * 4 > budget)
+    while (T > 64 && ((3 + KW) * T + fixed_words) * 4 > budget)
         T >>= 1;
-    if ((3 + KW) * T * 4 > budget) {
+    if (((3 + KW) * T + fixed_words) * 4 > budget) {
         use_lds = false;
         T = 256;
     }
-    const uint32_t lds = (3 + (use_lds ? KW : 0)) * T * 4;
-    const unsigned grid = (unsigned)((U + T - 1) / T);
+    const uint32_t lds = ((3 + (use_lds ? KW : 0)) * T + fixed_words) * 4;
+    const uint64_t n_tiles = (U + T - 1) / T;
+    // persistent grid: enough blocks to fill 256 CUs several times over, few enough that the
+    // per-block flush/stat atomics stay in the thousands
+    const unsigned grid = (unsigned)(n_tiles < 4096 ? n_tiles : 4096);
 #define FQD_PAIRS_CASE(KK)                                                                                   \
     case KK:                                                                                                 \
         if (use_lds)                                                                                         \

@@ -47,8 +47,8 @@ __device__ __forceinline__ uint32_t fqd_key_len(const KeyShape &sh, const uint32
     return sh.ragged ? lens[i] : sh.max_len;
 }
 
-// 64-bit hash of a whole record (all K*W words) and its length.
-__device__ __forceinline__ uint64_t fqd_hash_record(const uint32_t *rec, uint32_t n_words, uint32_t len)
+// 64-bit mix of a whole record (all K*W words) and its length.
+__device__ __forceinline__ uint64_t fqd_hash_record64(const uint32_t *rec, uint32_t n_words, uint32_t len)
 {
     uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)len * 0xD1B54A32D192ED03ull);
     for (uint32_t j = 0; j + 1 < n_words; j += 2) {
@@ -61,6 +61,15 @@ __device__ __forceinline__ uint64_t fqd_hash_record(const uint32_t *rec, uint32_
         h ^= h >> 32;
     }
     return fqd_mix64(h);
+}
+
+// The 32-bit key hash the collapse sorts by. It only PROPOSES equality: runs of equal hash
+// are verified record by record (collapse.hip), so its width trades radix passes against
+// collision-run fix-ups, never exactness.
+__device__ __forceinline__ uint32_t fqd_hash_record(const uint32_t *rec, uint32_t n_words, uint32_t len)
+{
+    const uint64_t h = fqd_hash_record64(rec, n_words, len);
+    return (uint32_t)(h ^ (h >> 32));
 }
 
 // Mismatching positions of word w between records a and b (one bit per base).
@@ -163,18 +172,18 @@ hipError_t launch_scan_bytes(const uint8_t *bytes, uint64_t n_bytes, uint32_t *p
 hipError_t launch_scan_lens(const uint64_t *offsets, uint64_t n, uint32_t *minmax_dev, hipStream_t st);
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
                        uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, uint32_t *recs,
-                       uint32_t *lens, uint64_t *hashes, uint32_t *bad_flag, hipStream_t st);
+                       uint32_t *lens, uint32_t *hashes, uint32_t *bad_flag, hipStream_t st);
 hipError_t launch_hash_records(const uint32_t *recs, const uint32_t *lens, uint64_t n, KeyShape sh,
-                               uint64_t *hashes, hipStream_t st);
+                               uint32_t *hashes, hipStream_t st);
 
 // collapse.hip
 hipError_t launch_iota_u32(uint32_t *out, uint64_t n, hipStream_t st);
-hipError_t launch_head_flags(const uint64_t *hs, const uint32_t *ids, const uint32_t *recs,
-                             const uint32_t *lens, uint64_t n, KeyShape sh, uint64_t hash_mask,
+hipError_t launch_head_flags(const uint32_t *hs, const uint32_t *ids, const uint32_t *recs,
+                             const uint32_t *lens, uint64_t n, KeyShape sh, uint32_t hash_mask,
                              uint32_t *flags, uint32_t *n_collision_runs, uint32_t *collision_runs,
                              uint32_t cap, hipStream_t st);
-hipError_t launch_fix_collision_runs(const uint64_t *hs, uint32_t *ids, const uint32_t *recs,
-                                     const uint32_t *lens, uint64_t n, KeyShape sh, uint64_t hash_mask,
+hipError_t launch_fix_collision_runs(const uint32_t *hs, uint32_t *ids, const uint32_t *recs,
+                                     const uint32_t *lens, uint64_t n, KeyShape sh, uint32_t hash_mask,
                                      uint32_t *flags, const uint32_t *collision_runs, uint32_t n_runs,
                                      hipStream_t st);
 hipError_t launch_run_starts(const uint32_t *flags, const uint32_t *run_idx, uint64_t n,

@@ -81,11 +81,12 @@ __global__ void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ e
     }
 }
 
-__global__ void uf_flatten_kernel(uint32_t *parent, uint64_t U, unsigned long long *n_roots)
+__global__ __launch_bounds__(256) void uf_flatten_kernel(uint32_t *parent, uint64_t U, unsigned long long *n_roots)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool root = false;
-    if (i < U) {
+    // grid-stride so that the single root counter sees one atomic per wave of a capped grid
+    unsigned long long roots = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < U;
+         i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t x = (uint32_t)i, p = load_relaxed(&parent[x]);
         while (p != x) {
             x = p;
@@ -93,11 +94,12 @@ __global__ void uf_flatten_kernel(uint32_t *parent, uint64_t U, unsigned long lo
         }
         // writing the root early is harmless: it is a valid ancestor for every reader
         __hip_atomic_store(&parent[i], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        root = x == (uint32_t)i;
+        roots += x == (uint32_t)i ? 1ull : 0ull;
     }
-    const unsigned long long m = __ballot(root);
-    if (fqd_lane() == 0 && m)
-        atomicAdd(n_roots, (unsigned long long)__popcll(m));
+    for (int o = 32; o; o >>= 1)
+        roots += __shfl_xor(roots, o);
+    if (fqd_lane() == 0 && roots)
+        atomicAdd(n_roots, roots);
 }
 
 // ---- dissection ------------------------------------------------------------------
@@ -243,8 +245,12 @@ hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, 
 
 hipError_t launch_uf_flatten(uint32_t *parent, uint64_t U, unsigned long long *n_roots, hipStream_t st)
 {
-    if (U)
-        uf_flatten_kernel<<<grid_for(U), 256, 0, st>>>(parent, U, n_roots);
+    if (U) {
+        unsigned g = grid_for(U);
+        if (g > 2048)
+            g = 2048;
+        uf_flatten_kernel<<<g, 256, 0, st>>>(parent, U, n_roots);
+    }
     return hipGetLastError();
 }
 

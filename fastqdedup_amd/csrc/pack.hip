@@ -1,4 +1,4 @@
-// pack.hip -- stage 1: ASCII keys -> bit-plane records + 64-bit key hashes.
+// pack.hip -- stage 1: ASCII keys -> bit-plane records + 32-bit key hashes.
 //
 // Replaces the storage half of TrieNode_AddSequence (reference
 // _triemodule.c:222-288): instead of one trie node per base, a key becomes K
@@ -75,7 +75,7 @@ template <int K>
 __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     const uint8_t *__restrict__ bytes, uint64_t n_bytes, const uint64_t *__restrict__ offsets, uint64_t n,
     uint32_t fixed_len, KeyShape sh, uint32_t kpb, uint32_t plane_words, const uint8_t *__restrict__ lut_g,
-    uint32_t *__restrict__ recs, uint32_t *__restrict__ lens, uint64_t *__restrict__ hashes,
+    uint32_t *__restrict__ recs, uint32_t *__restrict__ lens, uint32_t *__restrict__ hashes,
     uint32_t *__restrict__ bad_flag)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
 
 __global__ __launch_bounds__(256) void hash_records_kernel(const uint32_t *__restrict__ recs,
                                                            const uint32_t *__restrict__ lens, uint64_t n,
-                                                           KeyShape sh, uint64_t *__restrict__ hashes)
+                                                           KeyShape sh, uint32_t *__restrict__ hashes)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -240,7 +240,7 @@ static uint32_t pack_lds_bytes(uint32_t kpb, const KeyShape &sh, uint32_t &plane
 
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
                        uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, uint32_t *recs, uint32_t *lens,
-                       uint64_t *hashes, uint32_t *bad_flag, hipStream_t st)
+                       uint32_t *hashes, uint32_t *bad_flag, hipStream_t st)
 {
     if (!n)
         return hipSuccess;
@@ -276,7 +276,7 @@ hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *o
 }
 
 hipError_t launch_hash_records(const uint32_t *recs, const uint32_t *lens, uint64_t n, KeyShape sh,
-                               uint64_t *hashes, hipStream_t st)
+                               uint32_t *hashes, hipStream_t st)
 {
     if (!n)
         return hipSuccess;

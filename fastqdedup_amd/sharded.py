@@ -1,0 +1,188 @@
+"""Multi-GPU clustering: one process per MI355X, ``torch.distributed`` (backend
+"nccl" == RCCL over xGMI) for the exchange steps, the HIP library for all the
+arithmetic. The reference has no counterpart (it is single-threaded,
+SURVEY.md section 2); this is how the hot path of ONE job spreads over the 8
+GPUs of a node (DESIGN.md "multi-GPU").
+
+Exchange steps (everything else is rank-local):
+
+  1. all-gather of 3 small words/rank + all-reduce(MAX) of the 128-entry
+     symbol table  -> every rank packs with the SAME record geometry.
+  2. all-to-all(v) of packed reads by ``owner = key_hash mod G``: all copies of a
+     key meet on one rank, which collapses them (count, first holder).
+  3. all-gather of the per-rank unique tables: with 288 GB of HBM every rank
+     holds the whole unique-key table (config 4: 1e8 keys x 128 B = 12.8 GB),
+     so the bucket pair search needs no further key movement -- rank r searches
+     the buckets with ``bucket_hash mod G == r`` (the k-mer-bucket shard).
+  4. all-gather of the edge shards; components and dissection then run on the
+     full edge list on every rank (they are a few percent of the job).
+
+The ``backend`` object does the arithmetic: ``HipBackend`` in production; tests
+inject a numpy stand-in to exercise the exchange logic on CPU with gloo.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ._lib import METHODS, METRIC_EDIT, METRIC_HAMMING, Context
+
+
+@dataclass
+class ShardedResult:
+    kept_read_ids: torch.Tensor   # int64, ascending, global read ids (same on every rank)
+    n_reads: int                  # whole job
+    n_unique: int
+    n_edges: int
+    n_clusters: int
+    n_kept: int
+
+
+class HipBackend:
+    """Arithmetic of the sharded job on one MI355X through libfqdedup_hip.so."""
+
+    def __init__(self, ctx: Context, device: torch.device):
+        self.ctx = ctx
+        self.device = device
+
+    def scan(self, keys, offsets, key_len):
+        present, max_len, ragged = self.ctx.scan_keys(keys, offsets, key_len)
+        return present, max_len, ragged
+
+    def configure(self, present, max_len, ragged):
+        self.ctx.configure(present, max_len, ragged)
+
+    def pack(self, keys, offsets, key_len):
+        n = self.ctx.pack_keys(keys, offsets, key_len)
+        sh = self.ctx.shape()
+        self.stride = int(sh.stride_words)
+        recs = torch.empty((n, self.stride), dtype=torch.int32, device=self.device)
+        lens = torch.empty(n, dtype=torch.int32, device=self.device)
+        hashes = torch.empty(n, dtype=torch.int32, device=self.device)
+        self.ctx.export_packed(recs, lens, hashes)
+        return recs, lens, hashes
+
+    def collapse_packed(self, recs, lens, weights, read_ids):
+        n = recs.shape[0]
+        self.ctx.import_packed(recs, lens, n)
+        nu = self.ctx.collapse(weights, read_ids)
+        urecs = torch.empty((nu, self.stride), dtype=torch.int32, device=self.device)
+        ulens = torch.empty(nu, dtype=torch.int32, device=self.device)
+        ucounts = torch.empty(nu, dtype=torch.int32, device=self.device)
+        ufirst = torch.empty(nu, dtype=torch.int64, device=self.device)
+        self.ctx.export_unique(urecs, ulens, ucounts, ufirst)
+        return urecs, ulens, ucounts, ufirst
+
+    def find_edges(self, urecs, ulens, ucounts, ufirst, max_distance, metric, shard, n_shards):
+        self.ctx.import_unique(urecs, ulens, ucounts, ufirst, urecs.shape[0])
+        ne = self.ctx.find_edges(max_distance, metric, shard, n_shards)
+        edges = torch.empty((ne, 2), dtype=torch.int32, device=self.device)
+        self.ctx.export_edges(edges)
+        return edges
+
+    def finish(self, edges, method):
+        self.ctx.import_edges(edges, edges.shape[0])
+        n_clusters = self.ctx.components()
+        n_kept = self.ctx.dissect(method)
+        kept = torch.empty(n_kept, dtype=torch.int64, device=self.device)
+        self.ctx.kept_read_ids(n_kept, kept)
+        return kept, n_clusters
+
+
+def _all_gather_rows(x: torch.Tensor, group) -> torch.Tensor:
+    """Concatenation over ranks (rank-major) of tensors that differ in dim 0."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    pad = torch.zeros((cap,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    pad[: x.shape[0]] = x
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+
+def _all_to_all_rows(x: torch.Tensor, send_counts: torch.Tensor, recv_counts, group) -> torch.Tensor:
+    """all-to-all(v) of the rows of x, already grouped by destination rank."""
+    out = torch.empty((int(sum(recv_counts)),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_to_all_single(out, x.contiguous(), output_split_sizes=list(recv_counts),
+                           input_split_sizes=[int(c) for c in send_counts.tolist()], group=group)
+    return out
+
+
+def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=None, *,
+                         max_distance: int = 1, use_edit_distance: bool = False,
+                         method="directional", group=None) -> ShardedResult:
+    """Cluster the union of every rank's keys as ONE job. ``keys`` is this rank's
+    shard (device tensor or numpy array, as ``cluster_keys``). Read ids are global:
+    rank r's reads follow rank r-1's. Every rank returns the same result."""
+    if max_distance < 0:
+        raise ValueError("max_distance should be non-negative")
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = backend.device
+    method_id = METHODS[method] if isinstance(method, str) else int(method)
+    metric = METRIC_EDIT if use_edit_distance else METRIC_HAMMING
+
+    # ---- 1. common geometry --------------------------------------------------
+    present, max_len, ragged = backend.scan(keys, offsets, key_len)
+    if offsets is None:
+        nbytes = keys.numel() if hasattr(keys, "numel") else keys.size
+        n_local = nbytes // key_len if key_len else 0
+    else:
+        n_local = (offsets.numel() if hasattr(offsets, "numel") else offsets.size) - 1
+    mine = torch.tensor([n_local, max_len, int(ragged)], dtype=torch.int64, device=dev)
+    everyone = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine, group=group)
+    everyone = torch.stack(everyone).cpu().numpy()
+    n_per_rank = everyone[:, 0]
+    lens_seen = {int(m) for n, m, _ in everyone if n > 0}
+    g_ragged = bool(everyone[:, 2].any()) or len(lens_seen) > 1
+    g_max_len = int(everyone[:, 1].max()) if len(everyone) else 0
+    p = torch.from_numpy(np.ascontiguousarray(present, dtype=np.uint8)).to(dev).to(torch.int32)
+    dist.all_reduce(p, op=dist.ReduceOp.MAX, group=group)
+    g_present = p.to(torch.uint8).cpu().numpy()
+    backend.configure(g_present, g_max_len, g_ragged)
+    id0 = int(n_per_rank[:rank].sum())
+    n_total = int(n_per_rank.sum())
+
+    # ---- 2. all copies of a key to its owner rank ------------------------------
+    recs, lens, hashes = backend.pack(keys, offsets, key_len)
+    owner = (hashes.to(torch.int64) & 0xFFFFFFFF) % world      # the u32 hash travels as int32
+    order = torch.argsort(owner, stable=True)
+    send_counts = torch.bincount(owner, minlength=world)
+    counts_in = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(counts_in, send_counts.to(torch.int64), group=group)
+    recv_counts = [int(c) for c in counts_in.tolist()]
+    ids = torch.arange(id0, id0 + n_local, dtype=torch.int64, device=dev)
+    if weights is None:
+        w = torch.ones(n_local, dtype=torch.int32, device=dev)
+    else:
+        w = torch.as_tensor(weights).to(dev).to(torch.int32)
+    r_recs = _all_to_all_rows(recs[order], send_counts, recv_counts, group)
+    r_lens = _all_to_all_rows(lens[order], send_counts, recv_counts, group)
+    r_ids = _all_to_all_rows(ids[order], send_counts, recv_counts, group)
+    r_w = _all_to_all_rows(w[order], send_counts, recv_counts, group)
+    # first holder = smallest global id: present the copies in id order
+    by_id = torch.argsort(r_ids, stable=True)
+    urecs, ulens, ucounts, ufirst = backend.collapse_packed(
+        r_recs[by_id].contiguous(), r_lens[by_id].contiguous(), r_w[by_id].contiguous(),
+        r_ids[by_id].contiguous())
+
+    # ---- 3. whole unique table on every rank; search this rank's bucket shard ---
+    g_recs = _all_gather_rows(urecs, group)
+    g_lens = _all_gather_rows(ulens, group)
+    g_counts = _all_gather_rows(ucounts, group)
+    g_first = _all_gather_rows(ufirst, group)
+    edges = backend.find_edges(g_recs, g_lens, g_counts, g_first, max_distance, metric, rank, world)
+
+    # ---- 4. all edges everywhere; components + dissection ------------------------
+    g_edges = _all_gather_rows(edges, group)
+    kept, n_clusters = backend.finish(g_edges.contiguous(), method_id)
+    return ShardedResult(kept, n_total, int(g_recs.shape[0]), int(g_edges.shape[0]), int(n_clusters),
+                         int(kept.shape[0]))

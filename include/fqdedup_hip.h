@@ -87,7 +87,7 @@ void        fqd_destroy(fqd_ctx *ctx);
 const char *fqd_last_error(const fqd_ctx *ctx);
 int         fqd_synchronize(fqd_ctx *ctx);
 
-/* ---- stage 1: keys -> bit-plane records + 64-bit hashes --------------------
+/* ---- stage 1: keys -> bit-plane records + 32-bit hashes --------------------
  * bytes: concatenated ASCII keys. offsets: n+1 byte offsets, or NULL for n keys
  * of fixed_len bytes each. Bytes >= 128 are a FQD_E_VALUE (the reference
  * refuses non-ASCII keys, _triemodule.c:684-688). */
@@ -132,8 +132,8 @@ int fqd_get_unique_table(fqd_ctx *ctx, uint64_t *first_ids, uint32_t *counts, ui
                          uint8_t *kept, int mem);
 
 /* ---- exchange (multi-GPU: the caller moves these buffers with RCCL) -------- */
-/* Packed reads of stage 1: recs n*stride_words u32, lens n u32, hashes n u64. */
-int fqd_export_packed(fqd_ctx *ctx, uint32_t *recs, uint32_t *lens, uint64_t *hashes, int mem);
+/* Packed reads of stage 1: recs n*stride_words u32, lens n u32, hashes n u32. */
+int fqd_export_packed(fqd_ctx *ctx, uint32_t *recs, uint32_t *lens, uint32_t *hashes, int mem);
 int fqd_import_packed(fqd_ctx *ctx, const uint32_t *recs, const uint32_t *lens, uint64_t n, int mem);
 /* Unique table of stage 2. */
 int fqd_export_unique(fqd_ctx *ctx, uint32_t *recs, uint32_t *lens, uint32_t *counts,
