@@ -152,21 +152,31 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed
 
-    # ---- roofline of the bucket pair-compare kernel (DESIGN.md "kernels") -------
+    # ---- roofline of the dominant hand-written kernel (DESIGN.md "kernels") --------
+    # Both candidates are timed live with HIP events on the context's stream
+    # (fqd_stage_times); the one with the longer average launch is reported as `roofline`.
     sh = ctx.shape()
     st = ctx.edge_stats()          # of the last step: all d+1 launches
     nseg = wl["d"] + 1
-    u_table = res.n_unique
     b_key = sh.planes * sh.words * 4
-    # algorithmic bytes of ONE launch: (bucket hash, uid) of every unique key, the record of
+    # bucket pair kernel, ONE launch: (bucket hash, uid) of every unique key, the record of
     # every key that sits in a bucket of >= 2 (read once), 8 B per emitted edge
-    alg_bytes = u_table * 8 + st["keys_gathered"] / nseg * b_key + st["edges"] / nseg * 8
-    avg_ms = pairs_ms / max(pairs_launches, 1)
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roofline = {"kernel": "bucket_pairs_kernel", "bound": "hbm", "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None, "alg_bytes_per_launch": int(alg_bytes),
-                "avg_launch_ms": round(avg_ms, 4), "launches_timed": pairs_launches}
+    pairs_bytes = res.n_unique * 8 + st["keys_gathered"] / nseg * b_key + st["edges"] / nseg * 8
+    pairs_avg = pairs_ms / max(pairs_launches, 1)
+    # pack kernel, one launch: every key byte in, one record + one 32-bit hash out
+    pack_bytes = n * (L + b_key + 4)
+    pack_avg = stage_sum.get("pack_kernel", 0.0) / args.steps
+
+    def roof(name, nbytes, avg_ms, launches):
+        gbs = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_launch": int(nbytes),
+                "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
+
+    cands = [roof("pack_kernel", pack_bytes, pack_avg, args.steps),
+             roof("bucket_pairs_kernel", pairs_bytes, pairs_avg, pairs_launches)]
+    cands.sort(key=lambda r: -r["avg_launch_ms"])
+    roofline, roofline_other = cands[0], cands[1]
 
     out = {
         "metric": "reads/sec clustered (Hamming<=1, 150 bp)", "value": round(value, 1), "unit": "reads/s",
@@ -183,6 +193,7 @@ def main():
         "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_sum.items()},
         "record_bytes": sh.stride_words * 4, "planes": sh.planes,
         "roofline": roofline,
+        "roofline_other": roofline_other,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -63,7 +63,7 @@ struct fqd_ctx {
 
     fqd_shape shape{};
     KeyShape ks{};
-    DevBuf d_lut, d_ctr32, d_ctr64, d_present;
+    DevBuf d_lut, d_ctr32, d_ctr64, d_present, d_stats;
 
     // stage 1
     uint64_t n = 0;
@@ -344,7 +344,8 @@ int fqd_create(int device, fqd_ctx **out)
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
               hipEventCreate(&c->evk0) == hipSuccess && hipEventCreate(&c->evk1) == hipSuccess &&
               c->d_ctr32.reserve(C_N32 * 4) == hipSuccess && c->d_ctr64.reserve(C64_N * 8) == hipSuccess &&
-              c->d_lut.reserve(256) == hipSuccess;
+              c->d_lut.reserve(256) == hipSuccess &&
+              c->d_stats.reserve(FQD_STAT_SLOTS * sizeof(fqd::PairStats)) == hipSuccess;
     if (!ok) {
         g_global_error = "could not create stream/events/buffers on the device";
         fqd_destroy(c);
@@ -361,7 +362,7 @@ void fqd_destroy(fqd_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->st)
         (void)hipStreamSynchronize(c->st);
-    DevBuf *bufs[] = {&c->d_lut, &c->d_ctr32, &c->d_ctr64, &c->d_present, &c->in_bytes, &c->in_offsets, &c->recs,
+    DevBuf *bufs[] = {&c->d_lut, &c->d_ctr32, &c->d_ctr64, &c->d_present, &c->d_stats, &c->in_bytes, &c->in_offsets, &c->recs,
                       &c->lens, &c->hashes, &c->in_weights, &c->in_read_ids, &c->hs_sorted, &c->ids, &c->ids_sorted,
                       &c->flags, &c->run_idx, &c->run_start, &c->run_weight, &c->live_flag, &c->live_idx,
                       &c->collision_runs, &c->urecs, &c->ulens, &c->ucounts, &c->ufirst, &c->seg_hashes,
@@ -437,8 +438,8 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
     c->stage = ST_EMPTY;
     if (n >= 0xFFFFFFF0ull)
         return fail(c, FQD_E_VALUE, "at most 2^32-16 keys per context");
-    if (mem == FQD_DEVICE && ((uintptr_t)bytes & 3u))
-        return fail(c, FQD_E_VALUE, "device key buffer must be 4-byte aligned");
+    if (mem == FQD_DEVICE && ((uintptr_t)bytes & 15u))
+        return fail(c, FQD_E_VALUE, "device key buffer must be 16-byte aligned");
     uint64_t n_bytes;
     if (offsets) {
         if (mem == FQD_HOST) {
@@ -460,6 +461,10 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
     uint8_t present[128], lut[256];
     uint32_t max_len = fixed_len;
     int ragged = 0;
+    // Auto mode is optimistic: pack with the DNA alphabet "ACGNT" first (no pass over the
+    // bytes just to learn the alphabet); only if the pack kernel meets a byte outside it
+    // are the bytes scanned and the keys packed again with the exact alphabet.
+    bool optimistic = !c->forced;
     if (c->forced) {
         memcpy(present, c->forced_present, 128);
         max_len = c->forced_max_len;
@@ -467,28 +472,55 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
         if (!offsets && fixed_len != max_len)
             ragged = 1;
     } else {
+        memset(present, 0, sizeof present);
+        for (const char *p = "ACGNT"; *p; p++)
+            present[(int)*p] = 1;
+        if (offsets && n) {
+            uint32_t mm[2] = {0xFFFFFFFFu, 0u};
+            HIP_TRY(c, hipMemcpyAsync(c->d_ctr32.as<uint32_t>() + C_MINLEN, mm, 8, hipMemcpyHostToDevice, c->st));
+            HIP_TRY(c, fqd::launch_scan_lens(d_off, n, c->d_ctr32.as<uint32_t>() + C_MINLEN, c->st));
+            HIP_TRY(c, hipMemcpyAsync(mm, c->d_ctr32.as<uint32_t>() + C_MINLEN, 8, hipMemcpyDeviceToHost, c->st));
+            HIP_TRY(c, hipStreamSynchronize(c->st));
+            max_len = mm[1];
+            ragged = mm[0] != mm[1];
+        } else if (!n) {
+            max_len = 0;
+        }
+    }
+    for (int attempt = 0;; attempt++) {
+        build_alphabet(c, present, lut);
+        FQD_TRY(set_geometry(c, max_len, ragged));
+        HIP_TRY(c, hipMemcpyAsync(c->d_lut.p, lut, 256, hipMemcpyHostToDevice, c->st));
+        const KeyShape sh = c->ks;
+        HIP_TRY(c, c->recs.reserve((size_t)n * sh.stride * 4 + 16));
+        HIP_TRY(c, c->hashes.reserve((size_t)n * 4 + 16));
+        if (sh.ragged)
+            HIP_TRY(c, c->lens.reserve((size_t)n * 4 + 16));
+        FQD_TRY(zero_ctr32(c, C_BAD));
+        (void)hipEventRecord(c->evk0, c->st);
+        HIP_TRY(c, fqd::launch_pack(d_bytes, n_bytes, d_off, n, fixed_len, sh, c->d_lut.as<uint8_t>(), lut,
+                                    c->recs.as<uint32_t>(), sh.ragged ? c->lens.as<uint32_t>() : nullptr,
+                                    c->hashes.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+        (void)hipEventRecord(c->evk1, c->st);
+        uint32_t bad = 0;
+        FQD_TRY(read_ctr32(c, C_BAD, &bad));
+        float kms = 0;
+        if (hipEventElapsedTime(&kms, c->evk0, c->evk1) == hipSuccess) {
+            c->ms[FQD_T_PACK_KERNEL] = kms;
+            c->launches[FQD_T_PACK_KERNEL] = 1;
+        }
+        if (!bad)
+            break;
+        if (!optimistic || attempt > 0) {
+            timer.stop();
+            return fail(c, FQD_E_VALUE,
+                        c->forced ? "a key holds a byte outside the configured alphabet"
+                                  : "Sequence must consist only of ASCII characters");
+        }
+        // a byte outside "ACGNT": learn the real alphabet (and refuse non-ASCII there)
         FQD_TRY(scan_keys_device(c, d_bytes, d_off, n, n_bytes, fixed_len, present, &max_len, &ragged));
     }
-    build_alphabet(c, present, lut);
-    FQD_TRY(set_geometry(c, max_len, ragged));
-    HIP_TRY(c, hipMemcpyAsync(c->d_lut.p, lut, 256, hipMemcpyHostToDevice, c->st));
-
-    const KeyShape sh = c->ks;
-    HIP_TRY(c, c->recs.reserve((size_t)n * sh.stride * 4 + 16));
-    HIP_TRY(c, c->hashes.reserve((size_t)n * 4 + 16));
-    if (sh.ragged)
-        HIP_TRY(c, c->lens.reserve((size_t)n * 4 + 16));
-    FQD_TRY(zero_ctr32(c, C_BAD));
-    HIP_TRY(c, fqd::launch_pack(d_bytes, n_bytes, d_off, n, fixed_len, sh, c->d_lut.as<uint8_t>(),
-                                c->recs.as<uint32_t>(), sh.ragged ? c->lens.as<uint32_t>() : nullptr,
-                                c->hashes.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
-    uint32_t bad = 0;
-    FQD_TRY(read_ctr32(c, C_BAD, &bad));
     timer.stop();
-    if (bad)
-        return fail(c, FQD_E_VALUE,
-                    c->forced ? "a key holds a byte outside the configured alphabet"
-                              : "Sequence must consist only of ASCII characters");
     c->n = n;
     c->stage = ST_PACKED;
     return FQD_OK;
@@ -613,7 +645,7 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
     c->launches[FQD_T_PAIRS_KERNEL] = 0;
     c->last_stats = fqd::PairStats{0, 0, 0};
     FQD_TRY(zero_ctr64(c, C64_EDGES));
-    FQD_TRY(zero_ctr64(c, C64_STATS, 3));
+    HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
     if (U >= 2 && (max_distance > 0 || !c->collapsed)) {
         // with d >= max_len every segment split has empty segments: still correct (all keys of a
         // length share the empty segment's bucket), just quadratic.
@@ -641,7 +673,7 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
                                c->sorted_hash.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), U,
                                c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, s, nseg, shard, n_shards,
                                c->edges.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_EDGES, c->edge_cap,
-                               reinterpret_cast<fqd::PairStats *>(c->d_ctr64.as<unsigned long long>() + C64_STATS),
+                               c->d_stats.as<fqd::PairStats>(),
                                c->st));
                 (void)hipEventRecord(c->evk1, c->st);
                 unsigned long long now = 0;
@@ -671,9 +703,14 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
             }
         }
         c->E = have;
-        unsigned long long st3[3];
-        FQD_TRY(read_ctr64(c, C64_STATS, st3, 3));
-        c->last_stats = fqd::PairStats{st3[0], st3[1], st3[2]};
+        fqd::PairStats slots[FQD_STAT_SLOTS];
+        HIP_TRY(c, hipMemcpyAsync(slots, c->d_stats.p, sizeof slots, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(c, hipStreamSynchronize(c->st));
+        for (const fqd::PairStats &p : slots) {
+            c->last_stats.keys_gathered += p.keys_gathered;
+            c->last_stats.pairs_compared += p.pairs_compared;
+            c->last_stats.edges += p.edges;
+        }
     }
     timer.stop();
     c->stage = ST_EDGES;

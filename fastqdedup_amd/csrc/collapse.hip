@@ -49,6 +49,10 @@ __global__ void iota_kernel(uint32_t *out, uint64_t n)
         out[i] = (uint32_t)i;
 }
 
+// A read opens a new run unless its hash AND its full record equal its predecessor's.
+// Every read of a multi-read hash run gathers its own record once; the predecessor's
+// record then comes from the lane below (__shfl_up), only lane 0 of a wave gathers
+// a second record. Reads whose hash is unique among their neighbours gather nothing.
 __global__ __launch_bounds__(256) void head_flags_kernel(const uint32_t *__restrict__ hs, const uint32_t *__restrict__ ids,
                                                          const uint32_t *__restrict__ recs,
                                                          const uint32_t *__restrict__ lens, uint64_t n, KeyShape sh,
@@ -57,15 +61,46 @@ __global__ __launch_bounds__(256) void head_flags_kernel(const uint32_t *__restr
                                                          uint32_t *__restrict__ collision_runs, uint32_t cap)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
+    const bool valid = i < n;
+    const uint32_t lane = fqd_lane();
+    const uint32_t h = valid ? (hs[i] & hash_mask) : 0u;
+    const uint32_t id = valid ? ids[i] : 0u;
+    const bool same_prev = valid && i > 0 && (hs[i - 1] & hash_mask) == h;
+    const bool same_next = valid && i + 1 < n && (hs[i + 1] & hash_mask) == h;
+    const bool need = same_prev || same_next;
+    const bool fetch_prev = same_prev && lane == 0;   // the lane below is in another wave
+    const uint32_t prev_id = fetch_prev ? ids[i - 1] : 0u;
+    bool eq = true;
+    if (sh.ragged) {
+        const uint32_t mine = need ? lens[id] : 0u;
+        uint32_t prev = __shfl_up(mine, 1);
+        if (fetch_prev)
+            prev = lens[prev_id];
+        eq = mine == prev;
+    }
+    const uint4 *src = reinterpret_cast<const uint4 *>(recs + (uint64_t)id * sh.stride);
+    const uint4 *psrc = reinterpret_cast<const uint4 *>(recs + (uint64_t)prev_id * sh.stride);
+    for (uint32_t q = 0; q < sh.stride / 4; q++) {
+        uint4 m = make_uint4(0, 0, 0, 0);
+        if (need)
+            m = src[q];
+        uint4 p;
+        p.x = __shfl_up(m.x, 1);
+        p.y = __shfl_up(m.y, 1);
+        p.z = __shfl_up(m.z, 1);
+        p.w = __shfl_up(m.w, 1);
+        if (fetch_prev)
+            p = psrc[q];
+        eq = eq && m.x == p.x && m.y == p.y && m.z == p.z && m.w == p.w;
+    }
+    if (!valid)
         return;
     uint32_t head = 1;
-    if (i > 0 && ((hs[i] ^ hs[i - 1]) & hash_mask) == 0) {
-        if (records_equal(recs, lens, sh, ids[i], ids[i - 1])) {
+    if (same_prev) {
+        if (eq) {
             head = 0;
         } else {
             // equal hash, different key: report the run once (by its first such position)
-            const uint32_t h = hs[i] & hash_mask;
             uint64_t a = i - 1;
             bool first = true;
             while (a > 0 && (hs[a - 1] & hash_mask) == h) {

@@ -220,15 +220,28 @@ __global__ __launch_bounds__(256) void bucket_pairs_kernel(
         }
     }
     if (stats) {
+        // block totals land in one of FQD_STAT_SLOTS slots: no hot counter
         for (int o = 32; o; o >>= 1) {
             n_gathered += __shfl_xor(n_gathered, o);
             n_pairs += __shfl_xor(n_pairs, o);
             n_hits += __shfl_xor(n_hits, o);
         }
+        __syncthreads();
+        unsigned long long *red = reinterpret_cast<unsigned long long *>(s_edges);
         if (lane == 0) {
-            if (n_gathered) atomicAdd(&stats->keys_gathered, n_gathered);
-            if (n_pairs) atomicAdd(&stats->pairs_compared, n_pairs);
-            if (n_hits) atomicAdd(&stats->edges, n_hits);
+            red[(tid >> 6) * 3 + 0] = n_gathered;
+            red[(tid >> 6) * 3 + 1] = n_pairs;
+            red[(tid >> 6) * 3 + 2] = n_hits;
+        }
+        __syncthreads();
+        if (tid < 3) {
+            unsigned long long tot = 0;
+            for (uint32_t wv = 0; wv < T / 64; wv++)
+                tot += red[wv * 3 + tid];
+            fqd::PairStats *slot = stats + (blockIdx.x % FQD_STAT_SLOTS);
+            unsigned long long *dst = tid == 0 ? &slot->keys_gathered : (tid == 1 ? &slot->pairs_compared : &slot->edges);
+            if (tot)
+                atomicAdd(dst, tot);
         }
     }
 }

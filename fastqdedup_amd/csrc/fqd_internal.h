@@ -47,29 +47,17 @@ __device__ __forceinline__ uint32_t fqd_key_len(const KeyShape &sh, const uint32
     return sh.ragged ? lens[i] : sh.max_len;
 }
 
-// 64-bit mix of a whole record (all K*W words) and its length.
-__device__ __forceinline__ uint64_t fqd_hash_record64(const uint32_t *rec, uint32_t n_words, uint32_t len)
-{
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)len * 0xD1B54A32D192ED03ull);
-    for (uint32_t j = 0; j + 1 < n_words; j += 2) {
-        uint64_t v = (uint64_t)rec[j] | ((uint64_t)rec[j + 1] << 32);
-        h = (h ^ v) * 0xFF51AFD7ED558CCDull;
-        h ^= h >> 32;
-    }
-    if (n_words & 1) {
-        h = (h ^ rec[n_words - 1]) * 0xFF51AFD7ED558CCDull;
-        h ^= h >> 32;
-    }
-    return fqd_mix64(h);
-}
-
-// The 32-bit key hash the collapse sorts by. It only PROPOSES equality: runs of equal hash
-// are verified record by record (collapse.hip), so its width trades radix passes against
-// collision-run fix-ups, never exactness.
+// The 32-bit key hash the collapse sorts by (and that picks a key's owner rank). It only
+// PROPOSES equality: runs of equal hash are verified record by record (collapse.hip), so
+// its quality trades collision-run fix-ups against cycles, never exactness.
 __device__ __forceinline__ uint32_t fqd_hash_record(const uint32_t *rec, uint32_t n_words, uint32_t len)
 {
-    const uint64_t h = fqd_hash_record64(rec, n_words, len);
-    return (uint32_t)(h ^ (h >> 32));
+    uint32_t h = 0x9E3779B9u ^ (len * 0x85EBCA6Bu);
+    for (uint32_t j = 0; j < n_words; j++) {
+        h = (h ^ rec[j]) * 0x9E3779B1u;
+        h ^= h >> 15;
+    }
+    return fqd_mix32(h);
 }
 
 // Mismatching positions of word w between records a and b (one bit per base).
@@ -171,8 +159,8 @@ hipError_t launch_scan_bytes(const uint8_t *bytes, uint64_t n_bytes, uint32_t *p
                              hipStream_t st);
 hipError_t launch_scan_lens(const uint64_t *offsets, uint64_t n, uint32_t *minmax_dev, hipStream_t st);
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
-                       uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, uint32_t *recs,
-                       uint32_t *lens, uint32_t *hashes, uint32_t *bad_flag, hipStream_t st);
+                       uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, const uint8_t *lut_host,
+                       uint32_t *recs, uint32_t *lens, uint32_t *hashes, uint32_t *bad_flag, hipStream_t st);
 hipError_t launch_hash_records(const uint32_t *recs, const uint32_t *lens, uint64_t n, KeyShape sh,
                                uint32_t *hashes, hipStream_t st);
 
@@ -204,6 +192,7 @@ hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, u
 struct PairStats {
     unsigned long long keys_gathered, pairs_compared, edges;
 };
+#define FQD_STAT_SLOTS 64  // the pair kernel spreads its block totals over this many PairStats
 hipError_t launch_bucket_pairs(const uint32_t *sorted_hash, const uint32_t *sorted_uid, uint64_t U,
                                const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d,
                                uint32_t seg, uint32_t nseg, uint32_t shard, uint32_t n_shards,

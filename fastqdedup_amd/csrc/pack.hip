@@ -5,12 +5,13 @@
 // bit planes of ceil(len/32) words (fqd_internal.h).
 //
 // Kernel shape (HBM-bound: reads every input byte exactly once with coalesced
-// dword loads, writes each record once with 16-byte stores):
-//   phase A  each wave streams 256-byte chunks of the block's contiguous byte
-//            range: dword load -> wave-private LDS -> 4 x (ds_read_u8, LUT,
-//            K x __ballot). A wave64 ballot IS 64 consecutive bases of one bit
-//            plane, so no per-base shifting is needed. Result: the block's byte
-//            range as K bit streams in LDS.
+// 16-byte loads, writes each record once with 16-byte stores):
+//   phase A  bytes -> K bit streams of the block's contiguous byte range in LDS.
+//            Alphabets of <= 8 symbols (all DNA input) take the SWAR path: every
+//            lane turns its own 2 x 16 bytes into 2 x 16 stream bits per plane with
+//            no cross-lane traffic (v_perm_b32 as an 8-entry byte table, two
+//            delta-swaps as the bit transpose). Larger alphabets take the table
+//            path: 256-entry code table in LDS, one wave64 ballot per plane and row.
 //   phase B  one thread per (key, 32-base word): funnel-shift the key's bits
 //            out of the streams into the record tile in LDS.
 //   phase C  one thread per key hashes its record from LDS; the tile is then
@@ -70,12 +71,24 @@ __global__ void scan_lens_kernel(const uint64_t *__restrict__ offsets, uint64_t 
     }
 }
 
+// Perfect hash of the alphabet into 8 slots, found on the host: slot(c) =
+// ((c >> s1) ^ (c >> s2)) & 7 (s2 == PACK_NO_SHIFT: one shift only). code_tbl / char_tbl
+// hold, per slot, the code of its symbol and the symbol itself (0x80 for an empty slot,
+// which no ASCII byte equals).
+constexpr uint32_t PACK_NO_SHIFT = 0xFFFFFFFFu;
+struct PackHash {
+    uint32_t s1, s2;
+    uint64_t code_tbl, char_tbl;
+    uint32_t fill;  // a valid symbol in all 4 bytes: stands in for bytes past the buffer end
+};
+
 // LDS carve (u32 words): lut[64] | scratch[PACK_WAVES][64] | planes[K][plane_words] | tile[kpb*stride]
-template <int K>
+// A "row" is 2048 bytes (64 lanes x 2 groups x 16 bytes) = 64 stream dwords per plane.
+template <int K, bool SWAR>
 __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     const uint8_t *__restrict__ bytes, uint64_t n_bytes, const uint64_t *__restrict__ offsets, uint64_t n,
     uint32_t fixed_len, KeyShape sh, uint32_t kpb, uint32_t plane_words, const uint8_t *__restrict__ lut_g,
-    uint32_t *__restrict__ recs, uint32_t *__restrict__ lens, uint32_t *__restrict__ hashes,
+    PackHash ph, uint32_t *__restrict__ recs, uint32_t *__restrict__ lens, uint32_t *__restrict__ hashes,
     uint32_t *__restrict__ bad_flag)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -83,61 +96,128 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     uint32_t *scratch = smem + 64;                            // PACK_WAVES * 64 words
     uint32_t *planes = scratch + PACK_WAVES * 64;             // K * plane_words
     uint32_t *tile = planes + K * plane_words;                // kpb * stride (16-byte aligned by host)
-    const uint8_t *lut = reinterpret_cast<const uint8_t *>(lut32);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t key0 = (uint64_t)blockIdx.x * kpb;
     const uint32_t nk = (uint32_t)min((uint64_t)kpb, n - key0);
     const uint64_t b0 = offsets ? offsets[key0] : key0 * fixed_len;
     const uint64_t b1 = offsets ? offsets[key0 + nk] : (key0 + nk) * fixed_len;
-    const uint64_t a0 = b0 & ~3ull;
+    const uint64_t a0 = b0 & ~15ull;
     const uint32_t span = (uint32_t)(b1 - a0);
-    const uint32_t lead = (uint32_t)(b0 - a0);
-    const uint32_t n_chunks = (span + 255u) / 256u;
-
-    if (tid < 64)
-        lut32[tid] = reinterpret_cast<const uint32_t *>(lut_g)[tid];
-    __syncthreads();
+    const uint32_t n_rows = (span + 2047u) / 2048u;
+    uint32_t bad = 0;
 
     // ---- phase A: byte range -> K bit streams in LDS ------------------------
-    uint32_t bad = 0;
-    uint32_t *my_scratch = scratch + wave * 64;
-    const uint8_t *my_scratch8 = reinterpret_cast<const uint8_t *>(my_scratch);
-    for (uint32_t chunk = wave; chunk < n_chunks; chunk += PACK_WAVES) {
-        const uint64_t at = a0 + (uint64_t)chunk * 256u + lane * 4u;
-        uint32_t v = 0;
-        if (at + 4 <= n_bytes) {
-            v = *reinterpret_cast<const uint32_t *>(bytes + at);
-        } else {
-            for (uint32_t j = 0; j < 4; j++)
-                if (at + j < n_bytes)
-                    v |= (uint32_t)bytes[at + j] << (8 * j);
-        }
-        my_scratch[lane] = v;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
-            const uint32_t pos = chunk * 256u + j * 64u + lane;
-            const bool in = pos >= lead && pos < span;
-            const uint32_t c = my_scratch8[j * 64u + lane];
-            const uint32_t code = lut[c];
-            bad |= (in && code == 0xFFu) ? 1u : 0u;
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                const unsigned long long bits = __ballot(in && ((code >> k) & 1u));
-                if (lane == 0) {
-                    uint32_t *dst = planes + k * plane_words + (chunk * 8u + j * 2u);
-                    dst[0] = (uint32_t)bits;
-                    dst[1] = (uint32_t)(bits >> 32);
+    // Bits of bytes outside [b0, b1) are never read by phase B; bytes past the END OF THE
+    // BUFFER are replaced by a valid symbol so that they cannot raise the foreign-byte flag.
+    if (SWAR) {
+        const uint32_t code_lo = (uint32_t)ph.code_tbl, code_hi = (uint32_t)(ph.code_tbl >> 32);
+        const uint32_t char_lo = (uint32_t)ph.char_tbl, char_hi = (uint32_t)(ph.char_tbl >> 32);
+        auto load_group = [&](uint32_t row, uint32_t g) -> uint4 {
+            const uint64_t at = a0 + (uint64_t)row * 2048u + g * 1024u + lane * 16u;
+            uint4 v = make_uint4(ph.fill, ph.fill, ph.fill, ph.fill);
+            if (row < n_rows) {
+                if (at + 16 <= n_bytes) {
+                    v = *reinterpret_cast<const uint4 *>(bytes + at);
+                } else if (at < n_bytes) {
+                    uint32_t w[4] = {ph.fill, ph.fill, ph.fill, ph.fill};
+                    for (uint32_t j = 0; j < 16; j++)
+                        if (at + j < n_bytes) {
+                            w[j >> 2] &= ~(0xFFu << (8 * (j & 3)));
+                            w[j >> 2] |= (uint32_t)bytes[at + j] << (8 * (j & 3));
+                        }
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             }
+            return v;
+        };
+        uint16_t *planes16 = reinterpret_cast<uint16_t *>(planes);
+        auto convert_row = [&](uint32_t row, const uint4 &g0, const uint4 &g1) {
+            const uint32_t x[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            uint32_t acc[K];
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                acc[k] = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int g = q >> 2, i = q & 3;
+                // flag of (group g, dword i, byte b) goes to bit 8b + sigma, sigma = (i0, g, i1)
+                const int sigma = ((i & 1) << 2) | (g << 1) | (i >> 1);
+                uint32_t t = x[q] >> ph.s1;
+                if (ph.s2 != PACK_NO_SHIFT)
+                    t ^= x[q] >> ph.s2;
+                const uint32_t sel = t & 0x07070707u;
+                const uint32_t codes = __builtin_amdgcn_perm(code_hi, code_lo, sel);
+                const uint32_t expect = __builtin_amdgcn_perm(char_hi, char_lo, sel);
+                bad |= (expect ^ x[q]) | (x[q] & 0x80808080u);
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const uint32_t f = codes & (0x01010101u << k);   // flag at bit 8b + k
+                    acc[k] |= sigma >= k ? (f << (sigma - k)) : (f >> (k - sigma));
+                }
+            }
+            // bit index (b1 b0 i0 g i1) -> (g i1 i0 b1 b0): swap index bits 4<->1 and 3<->0
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                uint32_t a = acc[k];
+                uint32_t d = ((a >> 14) ^ a) & 0x0000CCCCu;
+                a ^= d ^ (d << 14);
+                d = ((a >> 7) ^ a) & 0x00AA00AAu;
+                a ^= d ^ (d << 7);
+                uint16_t *dst = planes16 + (size_t)k * plane_words * 2u + row * 128u;
+                dst[lane] = (uint16_t)a;               // stream bits of bytes [16*lane, +16)
+                dst[64u + lane] = (uint16_t)(a >> 16); // ... of bytes [1024 + 16*lane, +16)
+            }
+        };
+        uint4 c0 = load_group(wave, 0), c1 = load_group(wave, 1);
+        for (uint32_t row = wave; row < n_rows; row += PACK_WAVES) {
+            const uint4 n0 = load_group(row + PACK_WAVES, 0), n1 = load_group(row + PACK_WAVES, 1);
+            convert_row(row, c0, c1);
+            c0 = n0;
+            c1 = n1;
         }
-        __builtin_amdgcn_wave_barrier();
+    } else {
+        const uint8_t *lut = reinterpret_cast<const uint8_t *>(lut32);
+        uint32_t *my_scratch = scratch + wave * 64;
+        const uint8_t *my_scratch8 = reinterpret_cast<const uint8_t *>(my_scratch);
+        if (tid < 64)
+            lut32[tid] = reinterpret_cast<const uint32_t *>(lut_g)[tid];
+        __syncthreads();
+        const uint32_t n_chunks = n_rows * 8u;  // 256-byte chunks
+        for (uint32_t chunk = wave; chunk < n_chunks; chunk += PACK_WAVES) {
+            const uint64_t at = a0 + (uint64_t)chunk * 256u + lane * 4u;
+            uint32_t v = 0;
+            if (at + 4 <= n_bytes) {
+                v = *reinterpret_cast<const uint32_t *>(bytes + at);
+            } else {
+                for (uint32_t j = 0; j < 4; j++)
+                    if (at + j < n_bytes)
+                        v |= (uint32_t)bytes[at + j] << (8 * j);
+            }
+            my_scratch[lane] = v;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint64_t pos = a0 + (uint64_t)chunk * 256u + j * 64u + lane;
+                const uint32_t code = lut[my_scratch8[j * 64u + lane]];
+                bad |= (pos < n_bytes && code == 0xFFu) ? 1u : 0u;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const unsigned long long bits = __builtin_amdgcn_ballot_w64(((code >> k) & 1u) != 0u);
+                    if (lane == 0) {
+                        uint32_t *dst = planes + k * plane_words + (chunk * 8u + j * 2u);
+                        dst[0] = (uint32_t)bits;
+                        dst[1] = (uint32_t)(bits >> 32);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     // two guard words behind each stream so the funnel shift may read one word ahead
     if (tid < K * 2)
-        planes[(tid >> 1) * plane_words + n_chunks * 8u + (tid & 1u)] = 0;
-    if (__ballot(bad) && lane == 0)
+        planes[(tid >> 1) * plane_words + n_rows * 64u + (tid & 1u)] = 0;
+    if (bad)
         atomicOr(bad_flag, 1u);
     __syncthreads();
 
@@ -229,21 +309,63 @@ hipError_t launch_scan_lens(const uint64_t *offsets, uint64_t n, uint32_t *minma
 
 static uint32_t pack_lds_bytes(uint32_t kpb, const KeyShape &sh, uint32_t &plane_words)
 {
-    // worst-case byte span of kpb keys, plus 3 bytes of alignment lead
-    uint64_t span = (uint64_t)kpb * sh.max_len + 3;
-    uint64_t chunks = (span + 255) / 256;
-    plane_words = (uint32_t)(chunks * 8 + 2);
+    // worst-case byte span of kpb keys, plus 15 bytes of alignment lead, in 2048-byte rows
+    uint64_t span = (uint64_t)kpb * sh.max_len + 15;
+    uint64_t rows = (span + 2047) / 2048;
+    plane_words = (uint32_t)(rows * 64 + 2);
     plane_words = (plane_words + 3u) & ~3u;  // keeps the tile 16-byte aligned
     uint64_t words = 64 + PACK_WAVES * 64 + (uint64_t)sh.planes * plane_words + (uint64_t)kpb * sh.stride;
     return words * 4 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(words * 4);
 }
 
+// slot(c) = ((c >> s1) ^ (c >> s2)) & 7 must be injective on the alphabet
+static bool find_pack_hash(const uint8_t *lut_host, PackHash &ph)
+{
+    uint8_t syms[8];
+    uint32_t nsym = 0;
+    for (int b = 0; b < 128; b++)
+        if (lut_host[b] != 0xFF) {
+            if (nsym == 8)
+                return false;
+            syms[nsym++] = (uint8_t)b;
+        }
+    for (uint32_t s1 = 0; s1 <= 5; s1++)
+        for (uint32_t s2 = s1; s2 <= 5; s2++) {
+            const bool two = s2 != s1;
+            uint32_t used = 0;
+            bool ok = true;
+            for (uint32_t i = 0; i < nsym && ok; i++) {
+                const uint32_t slot = ((syms[i] >> s1) ^ (two ? (syms[i] >> s2) : 0)) & 7u;
+                ok = !(used & (1u << slot));
+                used |= 1u << slot;
+            }
+            if (!ok)
+                continue;
+            ph.s1 = s1;
+            ph.s2 = two ? s2 : PACK_NO_SHIFT;
+            ph.code_tbl = 0;
+            ph.char_tbl = 0x8080808080808080ull;
+            for (uint32_t i = 0; i < nsym; i++) {
+                const uint32_t slot = ((syms[i] >> s1) ^ (two ? (syms[i] >> s2) : 0)) & 7u;
+                ph.code_tbl |= (uint64_t)lut_host[syms[i]] << (8 * slot);
+                ph.char_tbl &= ~(0xFFull << (8 * slot));
+                ph.char_tbl |= (uint64_t)syms[i] << (8 * slot);
+            }
+            const uint32_t f = nsym ? syms[0] : 0x80u;
+            ph.fill = f * 0x01010101u;
+            return nsym > 0;
+        }
+    return false;
+}
+
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
-                       uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, uint32_t *recs, uint32_t *lens,
-                       uint32_t *hashes, uint32_t *bad_flag, hipStream_t st)
+                       uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, const uint8_t *lut_host,
+                       uint32_t *recs, uint32_t *lens, uint32_t *hashes, uint32_t *bad_flag, hipStream_t st)
 {
     if (!n)
         return hipSuccess;
+    if ((uintptr_t)bytes & 15u)
+        return hipErrorInvalidValue;  // 16-byte loads
     const uint32_t budget = 60 * 1024;
     uint32_t kpb = 256, plane_words = 0;
     while (kpb > 1 && pack_lds_bytes(kpb, sh, plane_words) > budget)
@@ -254,22 +376,29 @@ hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *o
     const uint64_t blocks = (n + kpb - 1) / kpb;
     if (blocks > 0x7FFFFFFFull)
         return hipErrorInvalidValue;
-#define FQD_PACK_CASE(KK)                                                                               \
-    case KK:                                                                                            \
-        pack_kernel<KK><<<(unsigned)blocks, PACK_THREADS, lds, st>>>(bytes, n_bytes, offsets, n, fixed_len, \
-                                                                      sh, kpb, plane_words, lut_dev, recs,  \
-                                                                      lens, hashes, bad_flag);              \
-        break;
-    switch (sh.planes) {
-        FQD_PACK_CASE(1)
-        FQD_PACK_CASE(2)
-        FQD_PACK_CASE(3)
-        FQD_PACK_CASE(4)
-        FQD_PACK_CASE(5)
-        FQD_PACK_CASE(6)
-        FQD_PACK_CASE(7)
-    default:
-        return hipErrorInvalidValue;
+    PackHash ph{};
+    const bool swar = sh.planes <= 3 && find_pack_hash(lut_host, ph);
+#define FQD_PACK_CASE(KK, SW)                                                                              \
+    pack_kernel<KK, SW><<<(unsigned)blocks, PACK_THREADS, lds, st>>>(bytes, n_bytes, offsets, n, fixed_len, sh, \
+                                                                     kpb, plane_words, lut_dev, ph, recs, lens, \
+                                                                     hashes, bad_flag)
+    if (swar) {
+        switch (sh.planes) {
+        case 1: FQD_PACK_CASE(1, true); break;
+        case 2: FQD_PACK_CASE(2, true); break;
+        default: FQD_PACK_CASE(3, true); break;
+        }
+    } else {
+        switch (sh.planes) {
+        case 1: FQD_PACK_CASE(1, false); break;
+        case 2: FQD_PACK_CASE(2, false); break;
+        case 3: FQD_PACK_CASE(3, false); break;
+        case 4: FQD_PACK_CASE(4, false); break;
+        case 5: FQD_PACK_CASE(5, false); break;
+        case 6: FQD_PACK_CASE(6, false); break;
+        case 7: FQD_PACK_CASE(7, false); break;
+        default: return hipErrorInvalidValue;
+        }
     }
 #undef FQD_PACK_CASE
     return hipGetLastError();

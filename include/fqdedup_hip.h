@@ -161,6 +161,7 @@ int fqd_contains(fqd_ctx *ctx, const uint8_t *q_bytes, const uint64_t *q_offsets
 #define FQD_T_COMPONENTS 3
 #define FQD_T_DISSECT    4
 #define FQD_T_PAIRS_KERNEL 5   /* sum over launches of the bucket pair-compare kernel */
+#define FQD_T_PACK_KERNEL  6   /* the pack kernel alone (stage FQD_T_PACK also holds copies/scans) */
 #define FQD_T_COUNT      8
 /* HIP-event milliseconds of the last run of each stage, measured on the
  * context's own stream; launches[k] = kernel launches summed into ms[k]. */
