@@ -75,6 +75,47 @@ def cpu_baseline(ctx, wl, sample_reads: int):
             "n_kept": int(len(out["kept_read_ids"])), "cpu_count": os.cpu_count()}
 
 
+def pmc_traffic(kernel_substr: str, workload: str, reads_per_gpu: int):
+    """HBM bytes per launch of one kernel from the PMC counters, collected the way
+    MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3
+    passes (kernel-trace only), KB -> bytes, and FETCH_SIZE doubled (on gfx950 it reports
+    half the bytes of a wide coalesced stream; exact for 16-B/lane reads like the pack
+    kernel's, uncalibrated for gathers)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix=f"fqd_pmc_{counter}_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1",
+               "--workload", workload, "--no-cpu-baseline", "--no-pmc", "--no-host-input"]
+        if reads_per_gpu:
+            cmd += ["--reads-per-gpu", str(reads_per_gpu)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, check=True, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            got = [float(r["Counter_Value"]) for f in files for r in csv.DictReader(open(f))
+                   if r["Counter_Name"] == counter and kernel_substr in r["Kernel_Name"]]
+            if not got:
+                return None, f"no {counter} rows for {kernel_substr}"
+            vals[counter] = sum(got) / len(got)
+        except Exception as exc:
+            return None, f"{counter} pass failed: {type(exc).__name__}"
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    traffic = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return traffic, {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
+                     "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +125,8 @@ def main():
     ap.add_argument("--reads-per-gpu", type=int, default=0, help="override the workload's n (testing)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two child rocprofv3 --pmc passes (traffic=null)")
+    ap.add_argument("--no-host-input", action="store_true", help="skip the PCIe-inclusive extra step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -177,6 +220,24 @@ def main():
              roof("bucket_pairs_kernel", pairs_bytes, pairs_avg, pairs_launches)]
     cands.sort(key=lambda r: -r["avg_launch_ms"])
     roofline, roofline_other = cands[0], cands[1]
+    if rank == 0 and world == 1 and not args.no_pmc:
+        traffic, how = pmc_traffic(roofline["kernel"], args.workload, args.reads_per_gpu)
+        roofline["traffic"] = None if traffic is None else int(traffic)
+        roofline["traffic_source"] = how
+
+    # the same step with the keys in (pageable) host memory: PCIe-inclusive, never `value`
+    pcie = None
+    if rank == 0 and world == 1 and not args.no_host_input:
+        host_keys = keys.cpu().numpy()
+        F.cluster_keys(host_keys, key_len=L, max_distance=wl["d"], use_edit_distance=wl["edit"],
+                       method=wl["method"], context=ctx)
+        t1 = time.perf_counter()
+        F.cluster_keys(host_keys, key_len=L, max_distance=wl["d"], use_edit_distance=wl["edit"],
+                       method=wl["method"], context=ctx)
+        dt = time.perf_counter() - t1
+        pcie = {"reads_per_s": round(n / dt, 1), "ms": round(dt * 1e3, 3),
+                "note": "keys start in pageable host memory, kept ids end in host memory"}
+        del host_keys
 
     out = {
         "metric": "reads/sec clustered (Hamming<=1, 150 bp)", "value": round(value, 1), "unit": "reads/s",
@@ -194,6 +255,7 @@ def main():
         "record_bytes": sh.stride_words * 4, "planes": sh.planes,
         "roofline": roofline,
         "roofline_other": roofline_other,
+        "host_input": pcie,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

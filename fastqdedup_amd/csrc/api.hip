@@ -70,6 +70,7 @@ struct fqd_ctx {
     DevBuf in_bytes, in_offsets, recs, lens, hashes;
     // stage 2
     uint64_t U = 0, n_counted = 0;
+    int id_bits = 64;  // bits needed to sort first-holder ids (read ids 0..n-1 need few)
     bool collapsed = false;  // unique table came from fqd_collapse (keys are pairwise distinct)
     DevBuf in_weights, in_read_ids, hs_sorted, ids, ids_sorted, flags, run_idx, run_start, run_weight, live_flag,
         live_idx, collision_runs;
@@ -617,6 +618,12 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
     c->U = U;
     c->n_counted = counted;
     c->collapsed = true;
+    c->id_bits = 64;
+    if (!read_ids) {  // ids are 0..n-1
+        c->id_bits = 1;
+        while (c->id_bits < 64 && (n >> c->id_bits))
+            c->id_bits++;
+    }
     c->stage = ST_UNIQUE;
     if (n_unique)
         *n_unique = U;
@@ -809,7 +816,7 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
             const size_t need = fqd::sort_keys_u64_temp(nk);
             HIP_TRY(c, c->tmp.reserve(need + 16));
             HIP_TRY(c, fqd::sort_keys_u64(c->tmp.p, need, c->kept_ids.as<uint64_t>(),
-                                          c->kept_ids_sorted.as<uint64_t>(), nk, c->st));
+                                          c->kept_ids_sorted.as<uint64_t>(), nk, c->id_bits, c->st));
         }
     }
     timer.stop();
@@ -966,6 +973,7 @@ int fqd_import_unique(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, co
     HIP_TRY(c, hipStreamSynchronize(c->st));
     c->U = U;
     c->collapsed = false;  // imported rows may repeat a key (dissection of a caller's list)
+    c->id_bits = 64;
     c->stage = ST_UNIQUE;
     return FQD_OK;
 }

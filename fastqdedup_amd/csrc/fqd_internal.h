@@ -149,7 +149,7 @@ hipError_t sort_pairs_u32_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, 
                               int end_bit, hipStream_t st);
 size_t sort_keys_u64_temp(uint64_t n);
 hipError_t sort_keys_u64(void *tmp, size_t tmp_bytes, const uint64_t *kin, uint64_t *kout, uint64_t n,
-                         hipStream_t st);
+                         int end_bit, hipStream_t st);
 size_t scan_u32_temp(uint64_t n);
 hipError_t inclusive_scan_u32(void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, uint64_t n,
                               hipStream_t st);

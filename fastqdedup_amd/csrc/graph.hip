@@ -144,16 +144,17 @@ __global__ void directional_round_kernel(const uint32_t *__restrict__ edges, uin
                                          uint32_t *changed)
 {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E)
-        return;
-    const uint32_t u = edges[2 * e], v = edges[2 * e + 1];
-    const long long cu = ucounts[u], cv = ucounts[v];
     bool moved = false;
-    if (2 * cv - 1 <= cu)  // arc u -> v
-        moved |= raise_best(best, v, load_relaxed(&best[u]), ucounts, urecs, ulens, sh);
-    if (2 * cu - 1 <= cv)  // arc v -> u
-        moved |= raise_best(best, u, load_relaxed(&best[v]), ucounts, urecs, ulens, sh);
-    if (moved)
+    if (e < E) {
+        const uint32_t u = edges[2 * e], v = edges[2 * e + 1];
+        const long long cu = ucounts[u], cv = ucounts[v];
+        if (2 * cv - 1 <= cu)  // arc u -> v
+            moved |= raise_best(best, v, load_relaxed(&best[u]), ucounts, urecs, ulens, sh);
+        if (2 * cu - 1 <= cv)  // arc v -> u
+            moved |= raise_best(best, u, load_relaxed(&best[v]), ucounts, urecs, ulens, sh);
+    }
+    // one store per wave, not one per lane, on the round's single flag word
+    if (__ballot(moved) && fqd_lane() == 0)
         *changed = 1;
 }
 

@@ -48,9 +48,9 @@ size_t sort_keys_u64_temp(uint64_t n)
 }
 
 hipError_t sort_keys_u64(void *tmp, size_t tmp_bytes, const uint64_t *kin, uint64_t *kout, uint64_t n,
-                         hipStream_t st)
+                         int end_bit, hipStream_t st)
 {
-    return rocprim::radix_sort_keys(tmp, tmp_bytes, kin, kout, n, 0, 64, st);
+    return rocprim::radix_sort_keys(tmp, tmp_bytes, kin, kout, n, 0, end_bit, st);
 }
 
 size_t scan_u32_temp(uint64_t n)
