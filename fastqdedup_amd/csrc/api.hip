@@ -78,6 +78,7 @@ struct fqd_ctx {
     // stage 3
     uint64_t E = 0, edge_cap = 0;
     DevBuf seg_hashes, sorted_hash, sorted_uid, uid_iota, edges;
+    DevBuf len_present, ed_hash, ed_payload, ed_hash_sorted, ed_payload_sorted, ed_cands, ed_cands_sorted, d_alphabet;
     fqd::PairStats last_stats{};
     // stage 4
     uint64_t n_clusters = 0;
@@ -297,6 +298,71 @@ int hash_bits_from_env()
     return b < 1 ? 1 : (b > 32 ? 32 : b);
 }
 
+// Levenshtein neighbour search for the general case (edit.hip): index/probe records ->
+// sort -> candidate pairs -> sort/unique -> banded-DP verification.
+int find_edges_edit(fqd_ctx *c, uint32_t d, uint32_t shard, uint32_t n_shards)
+{
+    const uint64_t U = c->U;
+    const KeyShape sh = c->ks;
+    if (d > 64)
+        return fail(c, FQD_E_VALUE, "edit distance bound above 64 is not supported on device");
+    HIP_TRY(c, c->len_present.reserve((size_t)sh.max_len + 16));
+    HIP_TRY(c, hipMemsetAsync(c->len_present.p, 0, (size_t)sh.max_len + 1, c->st));
+    HIP_TRY(c, fqd::launch_len_present(c->ulens.as<uint32_t>(), U, sh, c->len_present.as<uint8_t>(), c->st));
+    std::vector<uint8_t> present((size_t)sh.max_len + 1);
+    HIP_TRY(c, hipMemcpyAsync(present.data(), c->len_present.p, present.size(), hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    uint32_t n_lengths = 0;
+    for (uint8_t f : present)
+        n_lengths += f ? 1 : 0;
+    const uint32_t classes = std::min<uint32_t>(2 * d + 1, std::max<uint32_t>(n_lengths, 1));
+    const uint32_t slots = (d + 1) * (1 + classes * (2 * d + 1));
+    const uint64_t R = U * slots;
+    HIP_TRY(c, c->ed_hash.reserve(R * 4 + 16));
+    HIP_TRY(c, c->ed_payload.reserve(R * 4 + 16));
+    HIP_TRY(c, c->ed_hash_sorted.reserve(R * 4 + 16));
+    HIP_TRY(c, c->ed_payload_sorted.reserve(R * 4 + 16));
+    HIP_TRY(c, fqd::launch_edit_records(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, sh, d,
+                                        c->len_present.as<uint8_t>(), slots, c->ed_hash.as<uint32_t>(),
+                                        c->ed_payload.as<uint32_t>(), c->st));
+    FQD_TRY(sort_u32_pairs(c, c->ed_hash.as<uint32_t>(), c->ed_hash_sorted.as<uint32_t>(),
+                           c->ed_payload.as<uint32_t>(), c->ed_payload_sorted.as<uint32_t>(), R));
+    uint64_t cap = std::max<uint64_t>(c->ed_cands.cap / 8, std::max<uint64_t>(4096, 4 * U));
+    unsigned long long n_cand = 0;
+    for (;;) {
+        HIP_TRY(c, c->ed_cands.reserve(cap * 8));
+        FQD_TRY(zero_ctr64(c, C64_SUM));
+        HIP_TRY(c, fqd::launch_edit_candidates(c->ed_hash_sorted.as<uint32_t>(), c->ed_payload_sorted.as<uint32_t>(), R,
+                                               c->ulens.as<uint32_t>(), sh, d, shard, n_shards,
+                                               c->ed_cands.as<uint64_t>(), c->d_ctr64.as<unsigned long long>() + C64_SUM,
+                                               cap, c->st));
+        FQD_TRY(read_ctr64(c, C64_SUM, &n_cand));
+        if (n_cand <= cap)
+            break;
+        cap = n_cand + n_cand / 8 + 1024;
+    }
+    c->last_stats.pairs_compared = n_cand;
+    if (!n_cand)
+        return FQD_OK;
+    HIP_TRY(c, c->ed_cands_sorted.reserve(n_cand * 8 + 16));
+    {
+        const size_t need = fqd::sort_keys_u64_temp(n_cand);
+        HIP_TRY(c, c->tmp.reserve(need + 16));
+        HIP_TRY(c, fqd::sort_keys_u64(c->tmp.p, need, c->ed_cands.as<uint64_t>(), c->ed_cands_sorted.as<uint64_t>(),
+                                      n_cand, 64, c->st));
+    }
+    HIP_TRY(c, c->edges.reserve(n_cand * 8 + 16));  // every unique candidate yields at most one edge
+    c->edge_cap = c->edges.cap / 8;
+    HIP_TRY(c, fqd::launch_edit_verify(c->ed_cands_sorted.as<uint64_t>(), n_cand, c->urecs.as<uint32_t>(),
+                                       c->ulens.as<uint32_t>(), sh, d, c->edges.as<uint32_t>(),
+                                       c->d_ctr64.as<unsigned long long>() + C64_EDGES, c->edge_cap, c->st));
+    unsigned long long ne = 0;
+    FQD_TRY(read_ctr64(c, C64_EDGES, &ne));
+    c->E = ne;
+    c->last_stats.edges = ne;
+    return FQD_OK;
+}
+
 }  // namespace
 
 // =============================================================================
@@ -367,7 +433,9 @@ void fqd_destroy(fqd_ctx *c)
                       &c->lens, &c->hashes, &c->in_weights, &c->in_read_ids, &c->hs_sorted, &c->ids, &c->ids_sorted,
                       &c->flags, &c->run_idx, &c->run_start, &c->run_weight, &c->live_flag, &c->live_idx,
                       &c->collision_runs, &c->urecs, &c->ulens, &c->ucounts, &c->ufirst, &c->seg_hashes,
-                      &c->sorted_hash, &c->sorted_uid, &c->uid_iota, &c->edges, &c->labels, &c->best, &c->state,
+                      &c->sorted_hash, &c->sorted_uid, &c->uid_iota, &c->edges, &c->len_present, &c->ed_hash,
+                      &c->ed_payload, &c->ed_hash_sorted, &c->ed_payload_sorted, &c->ed_cands, &c->ed_cands_sorted,
+                      &c->d_alphabet, &c->labels, &c->best, &c->state,
                       &c->blocked, &c->kept, &c->kept_u32, &c->kept_scan, &c->kept_ids, &c->kept_ids_sorted, &c->tmp,
                       &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d};
     for (DevBuf *b : bufs)
@@ -640,10 +708,9 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
     if (n_shards == 0 || shard >= n_shards)
         return fail(c, FQD_E_VALUE, "bad shard");
     const KeyShape sh = c->ks;
-    if (metric == FQD_METRIC_EDIT && !(max_distance <= 1 && !sh.ragged))
-        return fail(c, FQD_E_VALUE,
-                    "edit metric on device: only max_distance <= 1 with equal-length keys so far "
-                    "(there Levenshtein <= 1 equals Hamming <= 1)");
+    // Levenshtein <= 1 between keys of ONE length is Hamming <= 1 (an indel changes the length):
+    // that case shares the Hamming search; everything else takes the bucketed edit search.
+    const bool edit_general = metric == FQD_METRIC_EDIT && !(max_distance <= 1 && !sh.ragged);
     c->stage = ST_UNIQUE;
     const uint64_t U = c->U;
     StageTimer timer(c, FQD_T_EDGES);
@@ -653,7 +720,9 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
     c->last_stats = fqd::PairStats{0, 0, 0};
     FQD_TRY(zero_ctr64(c, C64_EDGES));
     HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
-    if (U >= 2 && (max_distance > 0 || !c->collapsed)) {
+    if (edit_general && U >= 2 && (max_distance > 0 || !c->collapsed)) {
+        FQD_TRY(find_edges_edit(c, (uint32_t)max_distance, shard, n_shards));
+    } else if (U >= 2 && (max_distance > 0 || !c->collapsed)) {
         // with d >= max_len every segment split has empty segments: still correct (all keys of a
         // length share the empty segment's bucket), just quadratic.
         const uint32_t d = (uint32_t)max_distance;
@@ -1030,9 +1099,41 @@ int fqd_within_distance(fqd_ctx *c, const uint8_t *a_bytes, const uint64_t *a_of
     return from_device(c, out, c->tmp.p, (size_t)n, FQD_HOST);
 }
 
-int fqd_contains(fqd_ctx *c, const uint8_t *, const uint64_t *, uint64_t, int, int, uint8_t *, int)
+int fqd_contains(fqd_ctx *c, const uint8_t *q_bytes, const uint64_t *q_offsets, uint64_t n, int max_distance,
+                 int metric, uint8_t *out, int mem)
 {
-    return fail(c, FQD_E_RUNTIME, "fqd_contains: not built yet");
+    FQD_TRY(bind(c));
+    if (c->stage < ST_UNIQUE)
+        return fail(c, FQD_E_STATE, "fqd_contains before fqd_collapse/fqd_import_unique");
+    if (mem != FQD_HOST)
+        return fail(c, FQD_E_VALUE, "fqd_contains takes host buffers");
+    if (!n)
+        return FQD_OK;
+    if (n > 65535)
+        return fail(c, FQD_E_VALUE, "at most 65535 queries per call");
+    if (metric == FQD_METRIC_EDIT && max_distance > 64 && (uint32_t)max_distance < c->ks.max_len)
+        return fail(c, FQD_E_VALUE, "edit distance bound above 64 is not supported on device");
+    for (uint64_t i = 0; i < n; i++)
+        out[i] = 0;
+    if (!c->U || max_distance < 0)
+        return FQD_OK;
+    const uint8_t *dq;
+    const uint64_t *dqo;
+    FQD_TRY(to_device(c, q_bytes, (size_t)q_offsets[n] + 1, FQD_HOST, c->stage_a, &dq));
+    FQD_TRY(to_device(c, q_offsets, (size_t)n + 1, FQD_HOST, c->stage_b, &dqo));
+    HIP_TRY(c, c->d_alphabet.reserve(128));
+    HIP_TRY(c, hipMemcpyAsync(c->d_alphabet.p, c->shape.alphabet, 128, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, c->stage_c.reserve(n * 4 + 16));
+    HIP_TRY(c, hipMemsetAsync(c->stage_c.p, 0, n * 4, c->st));
+    HIP_TRY(c, fqd::launch_contains(dq, dqo, n, c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), c->U, c->ks,
+                                    c->d_alphabet.as<uint8_t>(), max_distance, metric, c->stage_c.as<uint32_t>(),
+                                    c->st));
+    std::vector<uint32_t> flags((size_t)n);
+    HIP_TRY(c, hipMemcpyAsync(flags.data(), c->stage_c.p, n * 4, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    for (uint64_t i = 0; i < n; i++)
+        out[i] = flags[i] ? 1 : 0;
+    return FQD_OK;
 }
 
 // ---- measurement ----------------------------------------------------------------

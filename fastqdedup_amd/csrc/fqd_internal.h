@@ -200,8 +200,20 @@ hipError_t launch_bucket_pairs(const uint32_t *sorted_hash, const uint32_t *sort
                                PairStats *stats, hipStream_t st);
 hipError_t launch_pairs_within(const uint8_t *a, const uint64_t *ao, const uint8_t *b, const uint64_t *bo,
                                uint64_t n, int d, int metric, uint8_t *out, hipStream_t st);
+
+// edit.hip -- Levenshtein neighbour search + contains
+hipError_t launch_len_present(const uint32_t *ulens, uint64_t U, KeyShape sh, uint8_t *len_present, hipStream_t st);
+hipError_t launch_edit_records(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t d,
+                               const uint8_t *len_present, uint32_t slots_per_key, uint32_t *out_hash,
+                               uint32_t *out_payload, hipStream_t st);
+hipError_t launch_edit_candidates(const uint32_t *sorted_hash, const uint32_t *sorted_payload, uint64_t R,
+                                  const uint32_t *ulens, KeyShape sh, uint32_t d, uint32_t shard, uint32_t n_shards,
+                                  uint64_t *cands, unsigned long long *cand_count, uint64_t cand_cap, hipStream_t st);
+hipError_t launch_edit_verify(const uint64_t *cands, uint64_t C, const uint32_t *urecs, const uint32_t *ulens,
+                              KeyShape sh, uint32_t d, uint32_t *edges, unsigned long long *edge_count,
+                              uint64_t edge_cap, hipStream_t st);
 hipError_t launch_contains(const uint8_t *q, const uint64_t *qo, uint64_t nq, const uint32_t *urecs,
-                           const uint32_t *ulens, uint64_t U, KeyShape sh, const uint8_t *lut_dev, int d,
+                           const uint32_t *ulens, uint64_t U, KeyShape sh, const uint8_t *alphabet_dev, int d,
                            int metric, uint32_t *hit_flags, hipStream_t st);
 
 // graph.hip -- union-find + dissection

@@ -38,13 +38,6 @@ def _golden_cases():
         return sorted(json.load(fh)["cases"])
 
 
-def _device_edit_ok(tag, keys):
-    """What the device edit path covers so far (api.hip: fqd_find_edges)."""
-    if tag[0] != "L":
-        return True
-    return int(tag[1]) <= 1 and len({len(k) for k in keys}) <= 1
-
-
 @pytest.mark.parametrize("name", _golden_cases())
 def test_golden_vectors(F, ctx, ref_vectors, name):
     case = ref_vectors["cases"][name]
@@ -56,8 +49,6 @@ def test_golden_vectors(F, ctx, ref_vectors, name):
     for i, k in enumerate(keys):
         first.setdefault(k, i)
     for tag, run in case["runs"].items():
-        if not _device_edit_ok(tag, keys):
-            continue
         edit, d = tag[0] == "L", int(tag[1])
         for m in METHODS:
             got = F.cluster_keys(raw, off, weights=w, max_distance=d, use_edit_distance=edit,
@@ -88,10 +79,11 @@ def test_known_answers_dissection(F, known_answers):
 
 
 def test_known_answers_pop_cluster(F, known_answers):
-    for case in known_answers["trie_pop_cluster"]:
-        if case["edit"]:
-            continue  # mixed lengths under the edit metric: not on device yet
-        sc.check_trie_pop_cluster(F, {"trie_pop_cluster": [case]})
+    sc.check_trie_pop_cluster(F, known_answers)
+
+
+def test_known_answers_contains(F, known_answers):
+    sc.check_trie_contains(F, known_answers)
 
 
 def test_known_answers_trie_bookkeeping(F, known_answers):
@@ -138,6 +130,67 @@ def test_edit_d1_equal_length_matches_oracle(F, ctx, oracle):
     want = oracle.dedup(keys, fixed_offsets(n, L), max_distance=1, use_edit_distance=True,
                         method="adjacency")
     assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+
+
+def test_edit_metric_mixed_lengths_matches_oracle(F, ctx, oracle):
+    """The bucketed Levenshtein search: indels, several length classes, d up to 3."""
+    import random
+    rng = random.Random(11)
+    mols = ["".join(rng.choice("ACGT") for _ in range(rng.randint(14, 40))) for _ in range(600)]
+    keys = []
+    for _ in range(6000):
+        s = list(rng.choice(mols))
+        for _ in range(rng.choice([0, 0, 1, 1, 2])):
+            op = rng.random()
+            pos = rng.randrange(len(s) + 1)
+            if op < 0.4 and s:
+                s[min(pos, len(s) - 1)] = rng.choice("ACGTN")
+            elif op < 0.7 and len(s) > 1:
+                del s[min(pos, len(s) - 1)]
+            else:
+                s.insert(pos, rng.choice("ACGT"))
+        keys.append("".join(s))
+    raw, off = _pack(keys)
+    for d in (1, 2, 3):
+        for m in METHODS:
+            got = F.cluster_keys(raw, off, max_distance=d, use_edit_distance=True, method=m, context=ctx)
+            want = oracle.dedup(raw, off, max_distance=d, use_edit_distance=True, method=m)
+            assert got.n_unique == want["n_unique"]
+            assert got.n_clusters == want["n_clusters"], (d, m)
+            assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), (d, m)
+
+
+def test_edit_d2_equal_length_matches_oracle(F, ctx, oracle):
+    """Equal lengths but d=2: one insertion + one deletion is not a Hamming neighbour."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    n, L = 20000, 40
+    keys = synth_keys(n, L, 8, 5, sub_rate=4e-3, n_rate=1e-3)
+    shifted = np.roll(keys[:2000], 1, axis=1)          # rotate: 1 ins + 1 del away from the original
+    keys = np.concatenate([keys, shifted]).reshape(-1)
+    n += 2000
+    got = F.cluster_keys(keys, key_len=L, max_distance=2, use_edit_distance=True, method="directional",
+                         context=ctx)
+    want = oracle.dedup(keys, fixed_offsets(n, L), max_distance=2, use_edit_distance=True,
+                        method="directional")
+    ham = F.cluster_keys(keys, key_len=L, max_distance=2, method="directional", context=ctx)
+    assert got.n_clusters == want["n_clusters"] < ham.n_clusters
+    assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+
+
+def test_contains_sequence_fuzz(F, oracle):
+    import random
+    rng = random.Random(2)
+    for _ in range(40):
+        syms = rng.choice(["AC", "ACGT", "ACGTN", "abcXN"])
+        a, b = F.Trie(), oracle.Trie()
+        for _ in range(rng.randint(1, 30)):
+            s = "".join(rng.choice(syms) for _ in range(rng.randint(0, 7)))
+            a.add_sequence(s)
+            b.add_sequence(s)
+        for _ in range(8):
+            q = "".join(rng.choice(syms + "U") for _ in range(rng.randint(0, 8)))
+            d, edit = rng.randint(0, 3), rng.random() < 0.5
+            assert a.contains_sequence(q, d, edit) == b.contains_sequence(q, d, edit), (q, d, edit)
 
 
 def test_ragged_and_foreign_alphabet(F, ctx, oracle):
