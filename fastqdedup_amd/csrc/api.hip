@@ -318,6 +318,8 @@ int find_edges_edit(fqd_ctx *c, uint32_t d, uint32_t shard, uint32_t n_shards)
     const uint32_t classes = std::min<uint32_t>(2 * d + 1, std::max<uint32_t>(n_lengths, 1));
     const uint32_t slots = (d + 1) * (1 + classes * (2 * d + 1));
     const uint64_t R = U * slots;
+    if (R >= 0xFFFFFF00ull)
+        return fail(c, FQD_E_VALUE, "edit search: more than 2^32 index/probe records; lower max_distance or shard the job");
     HIP_TRY(c, c->ed_hash.reserve(R * 4 + 16));
     HIP_TRY(c, c->ed_payload.reserve(R * 4 + 16));
     HIP_TRY(c, c->ed_hash_sorted.reserve(R * 4 + 16));
@@ -578,6 +580,10 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
             c->ms[FQD_T_PACK_KERNEL] = kms;
             c->launches[FQD_T_PACK_KERNEL] = 1;
         }
+        if (getenv("FQD_DEBUG"))
+            fprintf(stderr, "[fqd] pack attempt %d: n=%llu len=%u K=%u W=%u stride=%u alphabet=%.*s bad=%u kernel=%.3f ms\n",
+                    attempt, (unsigned long long)n, max_len, sh.planes, sh.words, sh.stride, (int)c->shape.alphabet_size,
+                    (const char *)c->shape.alphabet, bad, kms);
         if (!bad)
             break;
         if (!optimistic || attempt > 0) {

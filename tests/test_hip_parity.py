@@ -263,6 +263,20 @@ def test_device_resident_input_and_synth_twin(F, ctx):
     assert np.array_equal(a.kept_read_ids, b.kept_read_ids)
 
 
+def test_synth_twin_beyond_4gib(ctx):
+    """A launch is capped at 2^32 threads: the generator must still fill a 4.5 GB buffer."""
+    import torch
+    from fastqdedup_amd.synth import synth_keys_range
+    n, L, umi, seed = 15_000_000, 300, 300, 1005
+    dev = torch.empty(n * L, dtype=torch.uint8, device="cuda:0")
+    ctx.synth_keys(dev, n, 0, n, L, umi, seed)
+    for start in (0, (1 << 32) // L - 3, n - 50):
+        want = synth_keys_range(n, start, 50, L, umi, seed)
+        got = dev[start * L:(start + 50) * L].cpu().numpy().reshape(50, L)
+        assert np.array_equal(got, want), start
+    del dev
+
+
 def test_full_size_properties(F, ctx):
     """BASELINE config 2 at full size (10 M x 100 nt, UMI 12, d=1): properties that
     need no CPU-side answer."""
