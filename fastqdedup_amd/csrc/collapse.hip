@@ -185,7 +185,8 @@ __global__ void run_weights_kernel(const uint32_t *__restrict__ run_start, uint3
     live_flag[r] = w ? 1u : 0u;
 }
 
-__global__ void write_unique_kernel(const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ run_weight,
+// Q = stride/4 lanes copy one record, one uint4 each: coalesced for any record size.
+__global__ __launch_bounds__(256) void write_unique_kernel(const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ run_weight,
                                     const uint32_t *__restrict__ live_flag, const uint32_t *__restrict__ live_idx,
                                     uint32_t n_runs, const uint32_t *__restrict__ ids,
                                     const uint32_t *__restrict__ recs, const uint32_t *__restrict__ lens,
@@ -193,19 +194,22 @@ __global__ void write_unique_kernel(const uint32_t *__restrict__ run_start, cons
                                     uint32_t *__restrict__ urecs, uint32_t *__restrict__ ulens,
                                     uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t Q = sh.stride / 4;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r = t / Q;
+    const uint32_t q = (uint32_t)(t - r * Q);
     if (r >= n_runs || !live_flag[r])
         return;
     const uint32_t u = live_idx[r] - 1;  // inclusive scan of live flags
     const uint32_t id = ids[run_start[r]];
-    const uint4 *src = reinterpret_cast<const uint4 *>(recs + (uint64_t)id * sh.stride);
-    uint4 *dst = reinterpret_cast<uint4 *>(urecs + (uint64_t)u * sh.stride);
-    for (uint32_t j = 0; j < sh.stride / 4; j++)
-        dst[j] = src[j];
-    if (sh.ragged)
-        ulens[u] = lens[id];
-    ucounts[u] = run_weight[r];
-    ufirst[u] = read_ids ? read_ids[id] : (uint64_t)id;
+    reinterpret_cast<uint4 *>(urecs + (uint64_t)u * sh.stride)[q] =
+        reinterpret_cast<const uint4 *>(recs + (uint64_t)id * sh.stride)[q];
+    if (q == 0) {
+        if (sh.ragged)
+            ulens[u] = lens[id];
+        ucounts[u] = run_weight[r];
+        ufirst[u] = read_ids ? read_ids[id] : (uint64_t)id;
+    }
 }
 
 __global__ void sum_u32_kernel(const uint32_t *__restrict__ in, uint64_t n, unsigned long long *__restrict__ out)
@@ -277,7 +281,7 @@ hipError_t launch_write_unique(const uint32_t *run_start, const uint32_t *run_we
                                hipStream_t st)
 {
     if (n_runs)
-        write_unique_kernel<<<grid_for(n_runs), 256, 0, st>>>(run_start, run_weight, live_flag, live_idx, n_runs,
+        write_unique_kernel<<<grid_for((uint64_t)n_runs * (sh.stride / 4)), 256, 0, st>>>(run_start, run_weight, live_flag, live_idx, n_runs,
                                                               ids, recs, lens, read_ids, sh, urecs, ulens,
                                                               ucounts, ufirst);
     return hipGetLastError();

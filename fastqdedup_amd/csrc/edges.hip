@@ -14,31 +14,49 @@
 
 namespace {
 
+// Q = stride/4 lanes share one record, one uint4 (4 words) each, so a wave reads whole records
+// with fully coalesced 16-byte loads whatever the record size. A segment's hash is
+// fmix(len, s, SUM over its words of mix(word & segment mask, word index)): the sum is
+// order-free, so the Q lanes add up their partial sums with shuffles.
 __global__ __launch_bounds__(256) void segment_hashes_kernel(const uint32_t *__restrict__ urecs,
                                                              const uint32_t *__restrict__ ulens, uint64_t U,
                                                              KeyShape sh, uint32_t nseg,
                                                              uint32_t *__restrict__ seg_hashes)
 {
-    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= U)
-        return;
-    const uint32_t len = fqd_key_len(sh, ulens, u);
-    const uint32_t *rec = urecs + u * sh.stride;
-    const uint32_t K = sh.planes;
+    const uint32_t Q = sh.stride / 4, K = sh.planes, KW = sh.planes * sh.words;
+    const uint32_t rpw = 64u / Q;                       // records per wave (Q <= 64 checked by the host)
+    const uint32_t lane = fqd_lane();
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t rl = lane / Q, q = lane - rl * Q;
+    const uint64_t u = wave * rpw + rl;
+    const bool active = rl < rpw && u < U;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    uint32_t len = 0;
+    if (active) {
+        v = reinterpret_cast<const uint4 *>(urecs + u * sh.stride)[q];
+        len = fqd_key_len(sh, ulens, u);
+    }
+    const uint32_t word[4] = {v.x, v.y, v.z, v.w};
     for (uint32_t s = 0; s < nseg; s++) {
         uint32_t lo, hi;
         fqd_segment(len, s, nseg, lo, hi);
-        uint32_t h = fqd_mix32(len * 0x9E3779B1u + s * 0x85EBCA77u + 0x165667B1u);
-        if (hi > lo) {
-            for (uint32_t w = lo >> 5; w <= ((hi - 1) >> 5); w++) {
-                const uint32_t m = fqd_range_mask(w, lo, hi);
-                for (uint32_t k = 0; k < K; k++) {
-                    h = (h + (rec[w * K + k] & m)) * 0x9E3779B1u;
-                    h ^= h >> 15;
-                }
+        uint32_t part = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < 4; e++) {
+            const uint32_t j = q * 4 + e;               // word index in the record
+            if (j < KW) {
+                const uint32_t m = fqd_range_mask(j / K, lo, hi);
+                if (m)
+                    part += fqd_mix32((word[e] & m) + (j + 1u) * 0x9E3779B1u);
             }
         }
-        seg_hashes[(uint64_t)s * U + u] = fqd_mix32(h);
+        for (uint32_t off = 1; off < Q; off <<= 1) {    // segmented sum over the record's Q lanes
+            const uint32_t other = __shfl_down(part, off);
+            if (q + off < Q)
+                part += other;
+        }
+        if (active && q == 0)
+            seg_hashes[(uint64_t)s * U + u] = fqd_mix32(part + fqd_mix32(len * 0x9E3779B1u + s * 0x85EBCA77u + 0x165667B1u));
     }
 }
 
@@ -325,8 +343,15 @@ namespace fqd {
 hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh,
                                  uint32_t nseg, uint32_t *seg_hashes, hipStream_t st)
 {
-    if (U)
-        segment_hashes_kernel<<<(unsigned)((U + 255) / 256), 256, 0, st>>>(urecs, ulens, U, sh, nseg, seg_hashes);
+    if (!U)
+        return hipSuccess;
+    const uint32_t Q = sh.stride / 4;
+    if (Q > 64)
+        return hipErrorInvalidValue;  // records above 1 KiB: not reachable within the pack tile limit
+    const uint64_t rpw = 64 / Q, waves = (U + rpw - 1) / rpw, blocks = (waves + 3) / 4;
+    if (blocks > 0x7FFFFFull * 256)
+        return hipErrorInvalidValue;
+    segment_hashes_kernel<<<(unsigned)blocks, 256, 0, st>>>(urecs, ulens, U, sh, nseg, seg_hashes);
     return hipGetLastError();
 }
 
