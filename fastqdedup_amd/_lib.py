@@ -41,7 +41,7 @@ EXPORTS = [
     "fqd_device_count", "fqd_global_error", "fqd_create", "fqd_destroy", "fqd_last_error",
     "fqd_synchronize", "fqd_pack_keys", "fqd_configure", "fqd_scan_keys", "fqd_get_shape",
     "fqd_collapse", "fqd_find_edges", "fqd_components", "fqd_dissect", "fqd_cluster",
-    "fqd_get_kept_read_ids", "fqd_get_unique_table", "fqd_export_packed", "fqd_import_packed",
+    "fqd_set_id_window", "fqd_get_kept_count", "fqd_get_kept_read_ids", "fqd_get_unique_table", "fqd_export_packed", "fqd_import_packed",
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
     "fqd_within_distance", "fqd_contains", "fqd_stage_times", "fqd_edge_stats", "fqd_synth_keys",
 ]
@@ -86,6 +86,8 @@ def load() -> C.CDLL:
     L.fqd_dissect.argtypes = [vp, C.c_int, u64p]
     L.fqd_cluster.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Summary)]
     L.fqd_get_kept_read_ids.argtypes = [vp, vp, C.c_int]
+    L.fqd_set_id_window.argtypes = [vp, C.c_uint64, C.c_uint64]
+    L.fqd_get_kept_count.argtypes = [vp, u64p, u64p]
     L.fqd_get_unique_table.argtypes = [vp, vp, vp, vp, vp, C.c_int]
     L.fqd_export_packed.argtypes = [vp, vp, vp, vp, C.c_int]
     L.fqd_import_packed.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
@@ -251,6 +253,14 @@ class Context:
         return s.as_dict()
 
     # ---- results --------------------------------------------------------------
+    def set_id_window(self, lo: int = 0, hi: int = 0xFFFFFFFFFFFFFFFF):
+        self._ck(self._L.fqd_set_id_window(self._h, int(lo), int(hi)))
+
+    def kept_count(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._L.fqd_get_kept_count(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def kept_read_ids(self, n_kept: int, out=None):
         if out is None:
             out = np.empty(n_kept, dtype=np.uint64)

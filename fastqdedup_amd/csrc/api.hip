@@ -77,14 +77,15 @@ struct fqd_ctx {
     DevBuf urecs, ulens, ucounts, ufirst;
     // stage 3
     uint64_t E = 0, edge_cap = 0;
-    DevBuf seg_hashes, sorted_hash, sorted_uid, uid_iota, edges;
+    DevBuf seg_hashes, sorted_hash, sorted_uid, uid_iota, edges, sel_hash, sel_uid;
     DevBuf len_present, ed_hash, ed_payload, ed_hash_sorted, ed_payload_sorted, ed_cands, ed_cands_sorted, d_alphabet;
     fqd::PairStats last_stats{};
     // stage 4
     uint64_t n_clusters = 0;
     DevBuf labels;
     // stage 5
-    uint64_t n_kept = 0;
+    uint64_t n_kept = 0, n_listed = 0;          // kept keys; kept keys whose first holder is in the id window
+    uint64_t id_lo = 0, id_hi = ~0ull;
     DevBuf best, state, blocked, kept, kept_u32, kept_scan, kept_ids, kept_ids_sorted;
     // scratch
     DevBuf tmp, stage_a, stage_b, stage_c, stage_d;
@@ -275,6 +276,8 @@ uint64_t total_bytes_of(const uint64_t *offsets_host_or_null, uint64_t n, uint32
 int sort_u32_pairs(fqd_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n,
                    int bits = 32)
 {
+    if (!n)
+        return FQD_OK;
     const size_t need = fqd::sort_pairs_u32_u32_temp(n, 0, bits);
     HIP_TRY(c, c->tmp.reserve(need + 16));
     HIP_TRY(c, fqd::sort_pairs_u32_u32(c->tmp.p, need, kin, kout, vin, vout, n, 0, bits, c->st));
@@ -435,7 +438,7 @@ void fqd_destroy(fqd_ctx *c)
                       &c->lens, &c->hashes, &c->in_weights, &c->in_read_ids, &c->hs_sorted, &c->ids, &c->ids_sorted,
                       &c->flags, &c->run_idx, &c->run_start, &c->run_weight, &c->live_flag, &c->live_idx,
                       &c->collision_runs, &c->urecs, &c->ulens, &c->ucounts, &c->ufirst, &c->seg_hashes,
-                      &c->sorted_hash, &c->sorted_uid, &c->uid_iota, &c->edges, &c->len_present, &c->ed_hash,
+                      &c->sorted_hash, &c->sorted_uid, &c->uid_iota, &c->edges, &c->sel_hash, &c->sel_uid, &c->len_present, &c->ed_hash,
                       &c->ed_payload, &c->ed_hash_sorted, &c->ed_payload_sorted, &c->ed_cands, &c->ed_cands_sorted,
                       &c->d_alphabet, &c->labels, &c->best, &c->state,
                       &c->blocked, &c->kept, &c->kept_u32, &c->kept_scan, &c->kept_ids, &c->kept_ids_sorted, &c->tmp,
@@ -746,14 +749,33 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
         }
         c->edge_cap = c->edges.cap / 8;
         unsigned long long have = 0;
+        if (n_shards > 1) {
+            HIP_TRY(c, c->sel_hash.reserve(U * 4 + 16));
+            HIP_TRY(c, c->sel_uid.reserve(U * 4 + 16));
+        }
         for (uint32_t s = 0; s < nseg; s++) {
-            FQD_TRY(sort_u32_pairs(c, c->seg_hashes.as<uint32_t>() + (size_t)s * U, c->sorted_hash.as<uint32_t>(),
-                                   c->uid_iota.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), U));
+            uint64_t m = U;  // entries this rank sorts and searches in this pass
+            if (n_shards > 1) {
+                // only this rank's buckets go through the sort and the pair kernel
+                FQD_TRY(zero_ctr64(c, C64_SUM));
+                HIP_TRY(c, fqd::launch_select_shard(c->seg_hashes.as<uint32_t>() + (size_t)s * U, U, shard, n_shards,
+                                                    c->sel_hash.as<uint32_t>(), c->sel_uid.as<uint32_t>(),
+                                                    c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+                unsigned long long got = 0;
+                FQD_TRY(read_ctr64(c, C64_SUM, &got));
+                m = got;
+                FQD_TRY(sort_u32_pairs(c, c->sel_hash.as<uint32_t>(), c->sorted_hash.as<uint32_t>(),
+                                       c->sel_uid.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), m));
+            } else {
+                FQD_TRY(sort_u32_pairs(c, c->seg_hashes.as<uint32_t>() + (size_t)s * U,
+                                       c->sorted_hash.as<uint32_t>(), c->uid_iota.as<uint32_t>(),
+                                       c->sorted_uid.as<uint32_t>(), U));
+            }
             for (;;) {
                 (void)hipEventRecord(c->evk0, c->st);
                 HIP_TRY(c, fqd::launch_bucket_pairs(
-                               c->sorted_hash.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), U,
-                               c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, s, nseg, shard, n_shards,
+                               c->sorted_hash.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), m,
+                               c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, s, nseg, 0, 1,
                                c->edges.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_EDGES, c->edge_cap,
                                c->d_stats.as<fqd::PairStats>(),
                                c->st));
@@ -874,15 +896,20 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
         }
     }
     c->n_kept = 0;
+    c->n_listed = 0;
     if (U) {
+        FQD_TRY(zero_ctr64(c, C64_SUM));
         HIP_TRY(c, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
-                                          c->state.as<uint8_t>(), U, c->kept.as<uint8_t>(), c->kept_u32.as<uint32_t>(),
-                                          c->st));
+                                          c->state.as<uint8_t>(), c->ufirst.as<uint64_t>(), c->id_lo, c->id_hi, U,
+                                          c->kept.as<uint8_t>(), c->kept_u32.as<uint32_t>(),
+                                          c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
         FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), U));
         uint32_t nk = 0;
         HIP_TRY(c, hipMemcpyAsync(&nk, c->kept_scan.as<uint32_t>() + (U - 1), 4, hipMemcpyDeviceToHost, c->st));
-        HIP_TRY(c, hipStreamSynchronize(c->st));
-        c->n_kept = nk;
+        unsigned long long total = 0;
+        FQD_TRY(read_ctr64(c, C64_SUM, &total));
+        c->n_kept = total;
+        c->n_listed = nk;
         HIP_TRY(c, c->kept_ids.reserve((size_t)nk * 8 + 16));
         HIP_TRY(c, c->kept_ids_sorted.reserve((size_t)nk * 8 + 16));
         HIP_TRY(c, fqd::launch_gather_kept(c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(),
@@ -921,12 +948,30 @@ int fqd_cluster(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, i
     return FQD_OK;
 }
 
+int fqd_set_id_window(fqd_ctx *c, uint64_t lo, uint64_t hi)
+{
+    c->id_lo = lo;
+    c->id_hi = hi;
+    return FQD_OK;
+}
+
+int fqd_get_kept_count(fqd_ctx *c, uint64_t *n_kept, uint64_t *n_listed)
+{
+    if (c->stage < ST_KEPT)
+        return fail(c, FQD_E_STATE, "no dissection result yet");
+    if (n_kept)
+        *n_kept = c->n_kept;
+    if (n_listed)
+        *n_listed = c->n_listed;
+    return FQD_OK;
+}
+
 int fqd_get_kept_read_ids(fqd_ctx *c, uint64_t *out, int mem)
 {
     FQD_TRY(bind(c));
     if (c->stage < ST_KEPT)
         return fail(c, FQD_E_STATE, "no dissection result yet");
-    return from_device(c, out, c->kept_ids_sorted.p, (size_t)c->n_kept, mem);
+    return from_device(c, out, c->kept_ids_sorted.p, (size_t)c->n_listed, mem);
 }
 
 int fqd_get_unique_table(fqd_ctx *c, uint64_t *first_ids, uint32_t *counts, uint32_t *labels, uint8_t *kept, int mem)
@@ -1048,7 +1093,15 @@ int fqd_import_unique(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, co
     HIP_TRY(c, hipStreamSynchronize(c->st));
     c->U = U;
     c->collapsed = false;  // imported rows may repeat a key (dissection of a caller's list)
-    c->id_bits = 64;
+    {   // width of the largest first-holder id: the kept-id sort runs over that many bits only
+        unsigned long long mx = 0;
+        FQD_TRY(zero_ctr64(c, C64_SUM));
+        HIP_TRY(c, fqd::launch_max_u64(c->ufirst.as<uint64_t>(), U, c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+        FQD_TRY(read_ctr64(c, C64_SUM, &mx));
+        c->id_bits = 1;
+        while (c->id_bits < 64 && (mx >> c->id_bits))
+            c->id_bits++;
+    }
     c->stage = ST_UNIQUE;
     return FQD_OK;
 }

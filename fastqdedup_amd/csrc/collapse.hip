@@ -224,6 +224,20 @@ __global__ void sum_u32_kernel(const uint32_t *__restrict__ in, uint64_t n, unsi
         atomicAdd(out, s);
 }
 
+__global__ void max_u64_kernel(const uint64_t *__restrict__ in, uint64_t n, unsigned long long *__restrict__ out)
+{
+    unsigned long long m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        m = in[i] > m ? in[i] : m;
+    for (int o = 32; o; o >>= 1) {
+        const unsigned long long other = __shfl_xor(m, o);
+        m = other > m ? other : m;
+    }
+    if (fqd_lane() == 0)
+        atomicMax(out, m);
+}
+
 inline unsigned grid_for(uint64_t n, unsigned block = 256) { return (unsigned)((n + block - 1) / block); }
 
 }  // namespace
@@ -284,6 +298,17 @@ hipError_t launch_write_unique(const uint32_t *run_start, const uint32_t *run_we
         write_unique_kernel<<<grid_for((uint64_t)n_runs * (sh.stride / 4)), 256, 0, st>>>(run_start, run_weight, live_flag, live_idx, n_runs,
                                                               ids, recs, lens, read_ids, sh, urecs, ulens,
                                                               ucounts, ufirst);
+    return hipGetLastError();
+}
+
+hipError_t launch_max_u64(const uint64_t *in, uint64_t n, unsigned long long *out, hipStream_t st)
+{
+    if (n) {
+        unsigned g = grid_for(n);
+        if (g > 1024)
+            g = 1024;
+        max_u64_kernel<<<g, 256, 0, st>>>(in, n, out);
+    }
     return hipGetLastError();
 }
 

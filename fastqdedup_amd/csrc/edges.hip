@@ -60,6 +60,32 @@ __global__ __launch_bounds__(256) void segment_hashes_kernel(const uint32_t *__r
     }
 }
 
+// Multi-GPU: keep only this rank's share of the buckets (bucket_hash % n_shards == shard)
+// BEFORE the sort, so a rank sorts and searches 1/G of the unique table. One atomic per wave.
+__global__ __launch_bounds__(256) void select_shard_kernel(const uint32_t *__restrict__ hashes, uint64_t U,
+                                                           uint32_t shard, uint32_t n_shards,
+                                                           uint32_t *__restrict__ out_hash,
+                                                           uint32_t *__restrict__ out_uid,
+                                                           unsigned long long *__restrict__ counter)
+{
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t h = u < U ? hashes[u] : 0u;
+    const bool mine = u < U && (h % n_shards) == shard;
+    const unsigned long long m = __ballot(mine);
+    if (!m)
+        return;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long at = 0;
+    if ((int)fqd_lane() == leader)
+        at = atomicAdd(counter, (unsigned long long)__popcll(m));
+    at = __shfl(at, leader);
+    if (mine) {
+        at += __popcll(m & fqd_lanemask_lt());
+        out_hash[at] = h;
+        out_uid[at] = (uint32_t)u;
+    }
+}
+
 // ---- the pair kernel -----------------------------------------------------------
 // Persistent blocks walk tiles of T consecutive positions of the bucket-sorted
 // order. Keys that sit in a bucket of >= 2 are gathered ONCE from HBM (one
@@ -401,6 +427,15 @@ hipError_t launch_bucket_pairs(const uint32_t *sorted_hash, const uint32_t *sort
         return hipErrorInvalidValue;
     }
 #undef FQD_PAIRS_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_select_shard(const uint32_t *hashes, uint64_t U, uint32_t shard, uint32_t n_shards,
+                               uint32_t *out_hash, uint32_t *out_uid, unsigned long long *counter, hipStream_t st)
+{
+    if (U)
+        select_shard_kernel<<<(unsigned)((U + 255) / 256), 256, 0, st>>>(hashes, U, shard, n_shards, out_hash,
+                                                                         out_uid, counter);
     return hipGetLastError();
 }
 

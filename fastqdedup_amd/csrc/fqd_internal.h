@@ -185,6 +185,7 @@ hipError_t launch_write_unique(const uint32_t *run_start, const uint32_t *run_we
                                const uint64_t *read_ids, KeyShape sh, uint32_t *urecs, uint32_t *ulens,
                                uint32_t *ucounts, uint64_t *ufirst, hipStream_t st);
 hipError_t launch_sum_u32(const uint32_t *in, uint64_t n, unsigned long long *out, hipStream_t st);
+hipError_t launch_max_u64(const uint64_t *in, uint64_t n, unsigned long long *out, hipStream_t st);
 
 // edges.hip
 hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh,
@@ -198,6 +199,8 @@ hipError_t launch_bucket_pairs(const uint32_t *sorted_hash, const uint32_t *sort
                                uint32_t seg, uint32_t nseg, uint32_t shard, uint32_t n_shards,
                                uint32_t *edges, unsigned long long *edge_count, uint64_t edge_cap,
                                PairStats *stats, hipStream_t st);
+hipError_t launch_select_shard(const uint32_t *hashes, uint64_t U, uint32_t shard, uint32_t n_shards,
+                               uint32_t *out_hash, uint32_t *out_uid, unsigned long long *counter, hipStream_t st);
 hipError_t launch_pairs_within(const uint8_t *a, const uint64_t *ao, const uint8_t *b, const uint64_t *bo,
                                uint64_t n, int d, int metric, uint8_t *out, hipStream_t st);
 
@@ -232,7 +235,8 @@ hipError_t launch_adjacency_round(const uint32_t *edges, uint64_t E, const uint3
                                   uint8_t *state, uint32_t *blocked, uint32_t round, uint32_t *changed,
                                   hipStream_t st);
 hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t *best, const uint8_t *state,
-                             uint64_t U, uint8_t *kept, uint32_t *kept_u32, hipStream_t st);
+                             const uint64_t *ufirst, uint64_t id_lo, uint64_t id_hi, uint64_t U, uint8_t *kept,
+                             uint32_t *kept_u32, unsigned long long *n_kept_total, hipStream_t st);
 hipError_t launch_gather_kept(const uint32_t *kept_u32, const uint32_t *kept_scan, const uint64_t *ufirst,
                               uint64_t U, uint64_t *out, hipStream_t st);
 

@@ -199,21 +199,34 @@ __global__ void adjacency_nodes_kernel(uint64_t U, uint8_t *state, const uint32_
     }
 }
 
-__global__ void kept_flags_kernel(int method, const uint32_t *__restrict__ labels, const uint32_t *__restrict__ best,
-                                  const uint8_t *__restrict__ state, uint64_t U, uint8_t *kept, uint32_t *kept_u32)
+// kept[v]: the dissection's verdict. kept_u32[v]: 1 when v is kept AND its first holder lies in
+// the id window [id_lo, id_hi) -- the ids this context lists (a rank lists its own reads).
+__global__ __launch_bounds__(256) void kept_flags_kernel(int method, const uint32_t *__restrict__ labels,
+                                                         const uint32_t *__restrict__ best,
+                                                         const uint8_t *__restrict__ state,
+                                                         const uint64_t *__restrict__ ufirst, uint64_t id_lo,
+                                                         uint64_t id_hi, uint64_t U, uint8_t *kept, uint32_t *kept_u32,
+                                                         unsigned long long *n_kept_total)
 {
-    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= U)
-        return;
-    bool k;
-    if (method == 0)
-        k = best[labels[v]] == (uint32_t)v;
-    else if (method == 2)
-        k = best[v] == (uint32_t)v;
-    else
-        k = state[v] == 1;
-    kept[v] = k ? 1 : 0;
-    kept_u32[v] = k ? 1u : 0u;
+    unsigned long long total = 0;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < U;
+         v += (uint64_t)gridDim.x * blockDim.x) {
+        bool k;
+        if (method == 0)
+            k = best[labels[v]] == (uint32_t)v;
+        else if (method == 2)
+            k = best[v] == (uint32_t)v;
+        else
+            k = state[v] == 1;
+        kept[v] = k ? 1 : 0;
+        const uint64_t id = ufirst[v];
+        kept_u32[v] = (k && id >= id_lo && id < id_hi) ? 1u : 0u;
+        total += k ? 1ull : 0ull;
+    }
+    for (int o = 32; o; o >>= 1)
+        total += __shfl_xor(total, o);
+    if (fqd_lane() == 0 && total)
+        atomicAdd(n_kept_total, total);
 }
 
 __global__ void gather_kept_kernel(const uint32_t *__restrict__ kept_u32, const uint32_t *__restrict__ kept_scan,
@@ -292,10 +305,16 @@ hipError_t launch_adjacency_round(const uint32_t *edges, uint64_t E, const uint3
 }
 
 hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t *best, const uint8_t *state,
-                             uint64_t U, uint8_t *kept, uint32_t *kept_u32, hipStream_t st)
+                             const uint64_t *ufirst, uint64_t id_lo, uint64_t id_hi, uint64_t U, uint8_t *kept,
+                             uint32_t *kept_u32, unsigned long long *n_kept_total, hipStream_t st)
 {
-    if (U)
-        kept_flags_kernel<<<grid_for(U), 256, 0, st>>>(method, labels, best, state, U, kept, kept_u32);
+    if (U) {
+        unsigned g = grid_for(U);
+        if (g > 2048)
+            g = 2048;
+        kept_flags_kernel<<<g, 256, 0, st>>>(method, labels, best, state, ufirst, id_lo, id_hi, U, kept, kept_u32,
+                                             n_kept_total);
+    }
     return hipGetLastError();
 }
 

@@ -34,7 +34,7 @@ from ._lib import METHODS, METRIC_EDIT, METRIC_HAMMING, Context
 
 @dataclass
 class ShardedResult:
-    kept_read_ids: torch.Tensor   # int64, ascending, global read ids (same on every rank)
+    kept_read_ids: torch.Tensor   # int64, ascending: the kept global read ids among THIS rank's reads
     n_reads: int                  # whole job
     n_unique: int
     n_edges: int
@@ -69,7 +69,7 @@ class HipBackend:
     def collapse_packed(self, recs, lens, weights, read_ids):
         n = recs.shape[0]
         self.ctx.import_packed(recs, lens, n)
-        nu = self.ctx.collapse(weights, read_ids)
+        nu = self.ctx.collapse(weights, read_ids) if weights is not None else self.ctx.collapse(None, read_ids)
         urecs = torch.empty((nu, self.stride), dtype=torch.int32, device=self.device)
         ulens = torch.empty(nu, dtype=torch.int32, device=self.device)
         ucounts = torch.empty(nu, dtype=torch.int32, device=self.device)
@@ -84,13 +84,18 @@ class HipBackend:
         self.ctx.export_edges(edges)
         return edges
 
-    def finish(self, edges, method):
+    def finish(self, edges, method, id_lo, id_hi):
         self.ctx.import_edges(edges, edges.shape[0])
         n_clusters = self.ctx.components()
-        n_kept = self.ctx.dissect(method)
-        kept = torch.empty(n_kept, dtype=torch.int64, device=self.device)
-        self.ctx.kept_read_ids(n_kept, kept)
-        return kept, n_clusters
+        self.ctx.set_id_window(id_lo, id_hi)     # list only the kept ids among this rank's own reads
+        try:
+            self.ctx.dissect(method)
+        finally:
+            self.ctx.set_id_window()
+        n_kept, n_listed = self.ctx.kept_count()
+        kept = torch.empty(n_listed, dtype=torch.int64, device=self.device)
+        self.ctx.kept_read_ids(n_listed, kept)
+        return kept, n_clusters, n_kept
 
 
 def _all_gather_rows(x: torch.Tensor, group) -> torch.Tensor:
@@ -121,7 +126,7 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
                          method="directional", group=None) -> ShardedResult:
     """Cluster the union of every rank's keys as ONE job. ``keys`` is this rank's
     shard (device tensor or numpy array, as ``cluster_keys``). Read ids are global:
-    rank r's reads follow rank r-1's. Every rank returns the same result."""
+    rank r's reads follow rank r-1's. Counters are global; the id list is this rank's share."""
     if max_distance < 0:
         raise ValueError("max_distance should be non-negative")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -153,26 +158,29 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
 
     # ---- 2. all copies of a key to its owner rank ------------------------------
     recs, lens, hashes = backend.pack(keys, offsets, key_len)
-    owner = (hashes.to(torch.int64) & 0xFFFFFFFF) % world      # the u32 hash travels as int32
-    order = torch.argsort(owner, stable=True)
-    send_counts = torch.bincount(owner, minlength=world)
+    owner = ((hashes.to(torch.int64) & 0xFFFFFFFF) % world).to(torch.uint8)   # the u32 hash travels as int32
+    order = torch.sort(owner, stable=True).indices       # one radix pass; keeps each destination in id order
+    send_counts = torch.bincount(owner.to(torch.int64), minlength=world)
     counts_in = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(counts_in, send_counts.to(torch.int64), group=group)
     recv_counts = [int(c) for c in counts_in.tolist()]
     ids = torch.arange(id0, id0 + n_local, dtype=torch.int64, device=dev)
+    r_recs = _all_to_all_rows(recs[order], send_counts, recv_counts, group)
+    r_ids = _all_to_all_rows(ids[order], send_counts, recv_counts, group)
+    n_recv = r_recs.shape[0]
+    if g_ragged:
+        r_lens = _all_to_all_rows(lens[order], send_counts, recv_counts, group)
+    else:
+        r_lens = torch.full((n_recv,), g_max_len, dtype=torch.int32, device=dev)
     if weights is None:
-        w = torch.ones(n_local, dtype=torch.int32, device=dev)
+        r_w = None
     else:
         w = torch.as_tensor(weights).to(dev).to(torch.int32)
-    r_recs = _all_to_all_rows(recs[order], send_counts, recv_counts, group)
-    r_lens = _all_to_all_rows(lens[order], send_counts, recv_counts, group)
-    r_ids = _all_to_all_rows(ids[order], send_counts, recv_counts, group)
-    r_w = _all_to_all_rows(w[order], send_counts, recv_counts, group)
-    # first holder = smallest global id: present the copies in id order
-    by_id = torch.argsort(r_ids, stable=True)
-    urecs, ulens, ucounts, ufirst = backend.collapse_packed(
-        r_recs[by_id].contiguous(), r_lens[by_id].contiguous(), r_w[by_id].contiguous(),
-        r_ids[by_id].contiguous())
+        r_w = _all_to_all_rows(w[order], send_counts, recv_counts, group)
+    # The received rows are ALREADY in global id order: all-to-all delivers source ranks in rank
+    # order, rank r's ids precede rank r+1's, and every source sent its rows in id order. The
+    # collapse's stable sort therefore makes the smallest global id the head of each run.
+    urecs, ulens, ucounts, ufirst = backend.collapse_packed(r_recs, r_lens, r_w, r_ids)
 
     # ---- 3. whole unique table on every rank; search this rank's bucket shard ---
     g_recs = _all_gather_rows(urecs, group)
@@ -182,7 +190,9 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
     edges = backend.find_edges(g_recs, g_lens, g_counts, g_first, max_distance, metric, rank, world)
 
     # ---- 4. all edges everywhere; components + dissection ------------------------
+    # Every rank labels and dissects the whole graph (a few percent of the job) but LISTS only
+    # the kept ids among its own reads [id0, id0 + n_local): what its pass 2 would need.
     g_edges = _all_gather_rows(edges, group)
-    kept, n_clusters = backend.finish(g_edges.contiguous(), method_id)
+    kept, n_clusters, n_kept = backend.finish(g_edges.contiguous(), method_id, id0, id0 + n_local)
     return ShardedResult(kept, n_total, int(g_recs.shape[0]), int(g_edges.shape[0]), int(n_clusters),
-                         int(kept.shape[0]))
+                         int(n_kept))

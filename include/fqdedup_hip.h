@@ -124,7 +124,12 @@ int fqd_cluster(fqd_ctx *ctx, const uint32_t *weights, const uint64_t *read_ids,
                 int max_distance, int metric, int method, fqd_summary *out);
 
 /* ---- results --------------------------------------------------------------- */
-/* n_kept ids, ascending: the first holder of every kept key. */
+/* The ids this context LISTS are the first holders that fall into [lo, hi) (default: all).
+ * A rank of a multi-GPU job lists the ids of its own reads -- what its pass 2 needs.
+ * n_kept counts every kept key, n_listed those inside the window. */
+int fqd_set_id_window(fqd_ctx *ctx, uint64_t lo, uint64_t hi);
+int fqd_get_kept_count(fqd_ctx *ctx, uint64_t *n_kept, uint64_t *n_listed);
+/* n_listed ids, ascending: the first holder of every kept key (inside the id window). */
 int fqd_get_kept_read_ids(fqd_ctx *ctx, uint64_t *out, int mem);
 /* Per unique key u in [0, n_unique): first holder, count, component label
  * (= smallest u of the component), kept flag. Any pointer may be NULL. */

@@ -263,6 +263,45 @@ def test_device_resident_input_and_synth_twin(F, ctx):
     assert np.array_equal(a.kept_read_ids, b.kept_read_ids)
 
 
+def test_sharded_path_on_rccl_world1(F, oracle):
+    """The production multi-GPU code path (HipBackend + torch.distributed 'nccl' = RCCL) with a
+    one-rank group: every collective, every export/import of the C ABI, against the oracle."""
+    import torch
+    import torch.distributed as dist
+    from fastqdedup_amd.sharded import HipBackend, cluster_keys_sharded
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ctx = F.Context(0)
+        backend = HipBackend(ctx, dev)
+        n, L = 120000, 50
+        host = synth_keys(n, L, 8, 21, sub_rate=3e-3, n_rate=5e-4).reshape(-1)
+        keys = torch.from_numpy(host).to(dev)
+        w = np.ones(n, dtype=np.int32)
+        w[::7] = 0
+        for d, m in ((1, "directional"), (2, "adjacency"), (1, "highest_count")):
+            got = cluster_keys_sharded(backend, keys, None, L, torch.from_numpy(w).to(dev),
+                                       max_distance=d, method=m)
+            want = oracle.dedup(host, fixed_offsets(n, L), w.astype(np.uint32), max_distance=d, method=m)
+            assert got.n_unique == want["n_unique"] and got.n_clusters == want["n_clusters"]
+            assert np.array_equal(got.kept_read_ids.cpu().numpy().astype(np.uint64), want["kept_read_ids"]), (d, m)
+            assert got.n_kept == len(want["kept_read_ids"])
+        # ragged + edit metric through the same path
+        rag = ["ACGTACGTAC", "ACGTACGTA", "ACGTACGTACG", "TTTTTTTTTT", "TTTTTTTTT", "GGGGG"] * 50
+        raw, off = _pack(rag)
+        got = cluster_keys_sharded(backend, torch.from_numpy(raw.copy()).to(dev),
+                                   torch.from_numpy(off.astype(np.int64)).to(dev), 0,
+                                   max_distance=1, use_edit_distance=True, method="directional")
+        want = oracle.dedup(raw, off, max_distance=1, use_edit_distance=True, method="directional")
+        assert np.array_equal(got.kept_read_ids.cpu().numpy().astype(np.uint64), want["kept_read_ids"])
+    finally:
+        dist.destroy_process_group()
+
+
 def test_synth_twin_beyond_4gib(ctx):
     """A launch is capped at 2^32 threads: the generator must still fill a 4.5 GB buffer."""
     import torch

@@ -61,7 +61,8 @@ class NumpyBackend:
     def collapse_packed(self, recs, lens, weights, read_ids):
         ks = self._decode(recs, lens)
         first, count = {}, {}
-        for k, w, i in zip(ks, weights.tolist(), read_ids.tolist()):
+        wl = [1] * len(ks) if weights is None else weights.tolist()
+        for k, w, i in zip(ks, wl, read_ids.tolist()):
             first[k] = min(first.get(k, i), i)
             count[k] = count.get(k, 0) + w
         uniq = [k for k in first if count[k] > 0]
@@ -84,7 +85,7 @@ class NumpyBackend:
         self.d, self.edit = max_distance, bool(metric)
         return torch.tensor(edges, dtype=torch.int32).reshape(-1, 2)
 
-    def finish(self, edges, method):
+    def finish(self, edges, method, id_lo, id_hi):
         parent = list(range(len(self.keys)))
 
         def find(x):
@@ -106,7 +107,8 @@ class NumpyBackend:
         for members in comps.values():
             cluster = [(self.counts[i], self.keys[i]) for i in members]
             kept.extend(first_of[k] for k in fn(cluster, self.d, self.edit))
-        return torch.tensor(sorted(kept), dtype=torch.int64), len(comps)
+        mine = sorted(i for i in kept if id_lo <= i < id_hi)
+        return torch.tensor(mine, dtype=torch.int64), len(comps), len(kept)
 
 
 def _free_port():
@@ -128,7 +130,7 @@ def _worker(rank, world, port, shards, d, method, weights, q):
         off = np.concatenate([[0], np.cumsum([len(k) for k in keys])]).astype(np.uint64)
         w = None if weights is None else np.asarray(weights[rank], dtype=np.int32)
         res = cluster_keys_sharded(NumpyBackend(O), raw, off, 0, w, max_distance=d, method=method)
-        q.put((rank, res.kept_read_ids.tolist(), res.n_clusters, res.n_unique, res.n_reads))
+        q.put((rank, res.kept_read_ids.tolist(), res.n_clusters, res.n_unique, res.n_reads, res.n_kept))
     finally:
         dist.destroy_process_group()
 
@@ -162,8 +164,14 @@ def test_sharded_job_equals_single_job(oracle, world, d, method):
     raw = np.frombuffer(b"".join(allk), dtype=np.uint8)
     off = np.concatenate([[0], np.cumsum([len(k) for k in allk])]).astype(np.uint64)
     want = oracle.dedup(raw, off, np.array(weights, dtype=np.uint32), max_distance=d, method=method)
-    for rank, kept, n_clusters, n_unique, n_reads in got:
-        assert kept == want["kept_read_ids"].tolist(), rank
+    want_ids = want["kept_read_ids"].tolist()
+    union = []
+    for rank, kept, n_clusters, n_unique, n_reads, n_kept in got:
+        lo, hi = cuts[rank], cuts[rank + 1]
+        assert kept == [i for i in want_ids if lo <= i < hi], rank      # each rank lists its own reads
+        union += kept
+        assert n_kept == len(want_ids)
         assert n_clusters == want["n_clusters"]
         assert n_unique == want["n_unique"]
         assert n_reads == n
+    assert sorted(union) == want_ids
