@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--reads-per-gpu", type=int, default=0, help="override the workload's n (testing)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path even with one rank (diagnostic)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two child rocprofv3 --pmc passes (traffic=null)")
     ap.add_argument("--no-host-input", action="store_true", help="skip the PCIe-inclusive extra step")
     args = ap.parse_args()
@@ -139,8 +141,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import fastqdedup_amd as F
@@ -158,10 +162,10 @@ def main():
     keys = torch.empty(n * L, dtype=torch.uint8, device=device)
     ctx.synth_keys(keys, n_total, rank * n, n, L, wl["umi"], wl["seed"])
     kept_buf = torch.empty(n, dtype=torch.int64, device=device)
-    backend = HipBackend(ctx, device) if world > 1 else None
+    backend = HipBackend(ctx, device) if sharded else None
 
     def step():
-        if world == 1:
+        if not sharded:
             return F.cluster_keys(keys, key_len=L, max_distance=wl["d"], use_edit_distance=wl["edit"],
                                   method=wl["method"], context=ctx, kept_out=kept_buf)
         return cluster_keys_sharded(backend, keys, None, L, max_distance=wl["d"],
@@ -170,7 +174,7 @@ def main():
     def fence():
         ctx.synchronize()
         torch.cuda.synchronize(device)
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -264,7 +268,7 @@ def main():
             out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

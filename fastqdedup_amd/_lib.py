@@ -41,7 +41,7 @@ EXPORTS = [
     "fqd_device_count", "fqd_global_error", "fqd_create", "fqd_destroy", "fqd_last_error",
     "fqd_synchronize", "fqd_pack_keys", "fqd_configure", "fqd_scan_keys", "fqd_get_shape",
     "fqd_collapse", "fqd_find_edges", "fqd_components", "fqd_dissect", "fqd_cluster",
-    "fqd_set_id_window", "fqd_get_kept_count", "fqd_get_kept_read_ids", "fqd_get_unique_table", "fqd_export_packed", "fqd_import_packed",
+    "fqd_set_id_window", "fqd_get_kept_count", "fqd_get_kept_read_ids", "fqd_get_unique_table", "fqd_export_packed", "fqd_export_packed_by_owner", "fqd_import_packed",
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
     "fqd_within_distance", "fqd_contains", "fqd_stage_times", "fqd_edge_stats", "fqd_synth_keys",
 ]
@@ -91,6 +91,7 @@ def load() -> C.CDLL:
     L.fqd_get_unique_table.argtypes = [vp, vp, vp, vp, vp, C.c_int]
     L.fqd_export_packed.argtypes = [vp, vp, vp, vp, C.c_int]
     L.fqd_import_packed.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
+    L.fqd_export_packed_by_owner.argtypes = [vp, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_int]
     L.fqd_export_unique.argtypes = [vp, vp, vp, vp, vp, C.c_int]
     L.fqd_import_unique.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_int]
     L.fqd_export_edges.argtypes = [vp, vp, C.c_int]
@@ -284,6 +285,17 @@ class Context:
         lp, lm, _2 = _ptr_mem(lens)
         hp, hm, _3 = _ptr_mem(hashes)
         self._ck(self._L.fqd_export_packed(self._h, rp, lp, hp, rm))
+
+    def export_packed_by_owner(self, n_parts: int, id0: int, weights, recs, lens, ids, weights_out):
+        wp, _m, _0 = _ptr_mem(weights)
+        rp, rm, _1 = _ptr_mem(recs)
+        lp, _m, _2 = _ptr_mem(lens)
+        ip, _m, _3 = _ptr_mem(ids)
+        op, _m, _4 = _ptr_mem(weights_out)
+        counts = np.zeros(n_parts, dtype=np.uint64)
+        self._ck(self._L.fqd_export_packed_by_owner(self._h, int(n_parts), int(id0), wp, rp, lp, ip, op,
+                                                    counts.ctypes.data, rm))
+        return counts
 
     def import_packed(self, recs, lens, n: int):
         rp, rm, _1 = _ptr_mem(recs)

@@ -1004,15 +1004,47 @@ int fqd_export_packed(fqd_ctx *c, uint32_t *recs, uint32_t *lens, uint32_t *hash
     if (lens) {
         if (c->ks.ragged) {
             FQD_TRY(from_device(c, lens, c->lens.p, (size_t)c->n, mem));
-        } else {
-            std::vector<uint32_t> fill((size_t)c->n, c->ks.max_len);
-            if (mem == FQD_HOST)
-                memcpy(lens, fill.data(), fill.size() * 4);
-            else
-                HIP_TRY(c, hipMemcpy(lens, fill.data(), fill.size() * 4, hipMemcpyHostToDevice));
+        } else if (mem == FQD_HOST) {
+            std::fill(lens, lens + c->n, c->ks.max_len);
+        } else if (c->n) {
+            HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)lens, (int)c->ks.max_len, (size_t)c->n, c->st));
         }
     }
     FQD_TRY(from_device(c, hashes, c->hashes.p, (size_t)c->n, mem));
+    return FQD_OK;
+}
+
+int fqd_export_packed_by_owner(fqd_ctx *c, uint32_t n_parts, uint64_t id0, const uint32_t *weights, uint32_t *recs,
+                               uint32_t *lens, uint64_t *ids, uint32_t *weights_out, uint64_t *counts, int mem)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_PACKED)
+        return fail(c, FQD_E_STATE, "nothing packed");
+    if (mem != FQD_DEVICE)
+        return fail(c, FQD_E_VALUE, "fqd_export_packed_by_owner works on device buffers (counts: host)");
+    if (n_parts == 0 || n_parts > 65536)
+        return fail(c, FQD_E_VALUE, "1..65536 parts");
+    const uint64_t n = c->n;
+    const KeyShape sh = c->ks;
+    int bits = 1;
+    while ((1u << bits) < n_parts)
+        bits++;
+    HIP_TRY(c, c->ids.reserve(n * 4 + 16));
+    HIP_TRY(c, c->ids_sorted.reserve(n * 4 + 16));
+    HIP_TRY(c, c->flags.reserve(n * 4 + 16));
+    HIP_TRY(c, c->run_idx.reserve(n * 4 + 16));
+    uint32_t *owner = c->flags.as<uint32_t>(), *owner_sorted = c->run_idx.as<uint32_t>();
+    HIP_TRY(c, fqd::launch_owner(c->hashes.as<uint32_t>(), n, n_parts, owner, c->st));
+    HIP_TRY(c, fqd::launch_iota_u32(c->ids.as<uint32_t>(), n, c->st));
+    FQD_TRY(sort_u32_pairs(c, owner, owner_sorted, c->ids.as<uint32_t>(), c->ids_sorted.as<uint32_t>(), n, bits));
+    if (!n)
+        HIP_TRY(c, c->run_idx.reserve(16));
+    HIP_TRY(c, fqd::launch_gather_by_owner(c->ids_sorted.as<uint32_t>(), n, sh, c->recs.as<uint32_t>(),
+                                           c->lens.as<uint32_t>(), weights, id0, recs, lens, ids, weights_out, c->st));
+    HIP_TRY(c, c->stage_d.reserve((size_t)n_parts * 8 + 16));
+    HIP_TRY(c, fqd::launch_owner_counts(c->run_idx.as<uint32_t>(), n, n_parts, c->stage_d.as<uint64_t>(), c->st));
+    HIP_TRY(c, hipMemcpyAsync(counts, c->stage_d.p, (size_t)n_parts * 8, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
     return FQD_OK;
 }
 
@@ -1053,12 +1085,10 @@ int fqd_export_unique(fqd_ctx *c, uint32_t *recs, uint32_t *lens, uint32_t *coun
     if (lens) {
         if (c->ks.ragged) {
             FQD_TRY(from_device(c, lens, c->ulens.p, (size_t)c->U, mem));
-        } else {
-            std::vector<uint32_t> fill((size_t)c->U, c->ks.max_len);
-            if (mem == FQD_HOST)
-                memcpy(lens, fill.data(), fill.size() * 4);
-            else
-                HIP_TRY(c, hipMemcpy(lens, fill.data(), fill.size() * 4, hipMemcpyHostToDevice));
+        } else if (mem == FQD_HOST) {
+            std::fill(lens, lens + c->U, c->ks.max_len);
+        } else if (c->U) {
+            HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)lens, (int)c->ks.max_len, (size_t)c->U, c->st));
         }
     }
     FQD_TRY(from_device(c, counts, c->ucounts.p, (size_t)c->U, mem));

@@ -219,6 +219,14 @@ hipError_t launch_contains(const uint8_t *q, const uint64_t *qo, uint64_t nq, co
                            const uint32_t *ulens, uint64_t U, KeyShape sh, const uint8_t *alphabet_dev, int d,
                            int metric, uint32_t *hit_flags, hipStream_t st);
 
+// exchange.hip -- group packed reads by owner rank
+hipError_t launch_owner(const uint32_t *hashes, uint64_t n, uint32_t parts, uint32_t *owner, hipStream_t st);
+hipError_t launch_gather_by_owner(const uint32_t *order, uint64_t n, KeyShape sh, const uint32_t *recs,
+                                  const uint32_t *lens, const uint32_t *weights, uint64_t id0, uint32_t *recs_out,
+                                  uint32_t *lens_out, uint64_t *ids_out, uint32_t *weights_out, hipStream_t st);
+hipError_t launch_owner_counts(const uint32_t *owner_sorted, uint64_t n, uint32_t parts, uint64_t *counts,
+                               hipStream_t st);
+
 // graph.hip -- union-find + dissection
 hipError_t launch_uf_init(uint32_t *parent, uint64_t U, hipStream_t st);
 hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, hipStream_t st);

@@ -25,6 +25,9 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -56,22 +59,28 @@ class HipBackend:
     def configure(self, present, max_len, ragged):
         self.ctx.configure(present, max_len, ragged)
 
-    def pack(self, keys, offsets, key_len):
+    def pack_by_owner(self, keys, offsets, key_len, n_parts, id0, weights):
+        """Pack this rank's keys and return them grouped by owner rank (part 0 first, every
+        part in read order): rows, lengths (None unless ragged), global ids, weights (None if
+        not given), rows per part."""
         n = self.ctx.pack_keys(keys, offsets, key_len)
         sh = self.ctx.shape()
         self.stride = int(sh.stride_words)
+        self.ragged = bool(sh.ragged)
         recs = torch.empty((n, self.stride), dtype=torch.int32, device=self.device)
-        lens = torch.empty(n, dtype=torch.int32, device=self.device)
-        hashes = torch.empty(n, dtype=torch.int32, device=self.device)
-        self.ctx.export_packed(recs, lens, hashes)
-        return recs, lens, hashes
+        lens = torch.empty(n, dtype=torch.int32, device=self.device) if self.ragged else None
+        ids = torch.empty(n, dtype=torch.int64, device=self.device)
+        w_in = None if weights is None else torch.as_tensor(weights).to(self.device).to(torch.int32).contiguous()
+        w_out = None if weights is None else torch.empty(n, dtype=torch.int32, device=self.device)
+        counts = self.ctx.export_packed_by_owner(n_parts, id0, w_in, recs, lens, ids, w_out)
+        return recs, lens, ids, w_out, [int(c) for c in counts]
 
     def collapse_packed(self, recs, lens, weights, read_ids):
         n = recs.shape[0]
-        self.ctx.import_packed(recs, lens, n)
-        nu = self.ctx.collapse(weights, read_ids) if weights is not None else self.ctx.collapse(None, read_ids)
+        self.ctx.import_packed(recs, lens if self.ragged else None, n)
+        nu = self.ctx.collapse(weights, read_ids)
         urecs = torch.empty((nu, self.stride), dtype=torch.int32, device=self.device)
-        ulens = torch.empty(nu, dtype=torch.int32, device=self.device)
+        ulens = torch.empty(nu, dtype=torch.int32, device=self.device) if self.ragged else None
         ucounts = torch.empty(nu, dtype=torch.int32, device=self.device)
         ufirst = torch.empty(nu, dtype=torch.int64, device=self.device)
         self.ctx.export_unique(urecs, ulens, ucounts, ufirst)
@@ -96,6 +105,24 @@ class HipBackend:
         kept = torch.empty(n_listed, dtype=torch.int64, device=self.device)
         self.ctx.kept_read_ids(n_listed, kept)
         return kept, n_clusters, n_kept
+
+
+class _PhaseTimer:
+    """FQD_SHARD_TIMING=1: wall time per phase (with a device sync at each mark) on stderr."""
+
+    def __init__(self, dev):
+        self.dev, self.t, self.out = dev, time.perf_counter(), []
+
+    def mark(self, name):
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        now = time.perf_counter()
+        self.out.append(f"{name}={1e3 * (now - self.t):.2f}")
+        self.t = now
+
+    def done(self):
+        import sys
+        print("[fqd shard ms] " + " ".join(self.out), file=sys.stderr, flush=True)
 
 
 def _all_gather_rows(x: torch.Tensor, group) -> torch.Tensor:
@@ -131,6 +158,7 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
         raise ValueError("max_distance should be non-negative")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = backend.device
+    tick = _PhaseTimer(dev) if os.environ.get("FQD_SHARD_TIMING") else None
     method_id = METHODS[method] if isinstance(method, str) else int(method)
     metric = METRIC_EDIT if use_edit_distance else METRIC_HAMMING
 
@@ -153,46 +181,50 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
     dist.all_reduce(p, op=dist.ReduceOp.MAX, group=group)
     g_present = p.to(torch.uint8).cpu().numpy()
     backend.configure(g_present, g_max_len, g_ragged)
+    if tick:
+        tick.mark("geometry")
     id0 = int(n_per_rank[:rank].sum())
     n_total = int(n_per_rank.sum())
 
     # ---- 2. all copies of a key to its owner rank ------------------------------
-    recs, lens, hashes = backend.pack(keys, offsets, key_len)
-    owner = ((hashes.to(torch.int64) & 0xFFFFFFFF) % world).to(torch.uint8)   # the u32 hash travels as int32
-    order = torch.sort(owner, stable=True).indices       # one radix pass; keeps each destination in id order
-    send_counts = torch.bincount(owner.to(torch.int64), minlength=world)
+    s_recs, s_lens, s_ids, s_w, send_counts = backend.pack_by_owner(keys, offsets, key_len, world, id0, weights)
+    if tick:
+        tick.mark("pack+group-by-owner")
+    send_counts = torch.tensor(send_counts, dtype=torch.int64, device=dev)
     counts_in = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_to_all_single(counts_in, send_counts.to(torch.int64), group=group)
+    dist.all_to_all_single(counts_in, send_counts, group=group)
     recv_counts = [int(c) for c in counts_in.tolist()]
-    ids = torch.arange(id0, id0 + n_local, dtype=torch.int64, device=dev)
-    r_recs = _all_to_all_rows(recs[order], send_counts, recv_counts, group)
-    r_ids = _all_to_all_rows(ids[order], send_counts, recv_counts, group)
-    n_recv = r_recs.shape[0]
-    if g_ragged:
-        r_lens = _all_to_all_rows(lens[order], send_counts, recv_counts, group)
-    else:
-        r_lens = torch.full((n_recv,), g_max_len, dtype=torch.int32, device=dev)
-    if weights is None:
-        r_w = None
-    else:
-        w = torch.as_tensor(weights).to(dev).to(torch.int32)
-        r_w = _all_to_all_rows(w[order], send_counts, recv_counts, group)
+    r_recs = _all_to_all_rows(s_recs, send_counts, recv_counts, group)
+    r_ids = _all_to_all_rows(s_ids, send_counts, recv_counts, group)
+    r_lens = _all_to_all_rows(s_lens, send_counts, recv_counts, group) if g_ragged else None
+    r_w = None if s_w is None else _all_to_all_rows(s_w, send_counts, recv_counts, group)
     # The received rows are ALREADY in global id order: all-to-all delivers source ranks in rank
     # order, rank r's ids precede rank r+1's, and every source sent its rows in id order. The
     # collapse's stable sort therefore makes the smallest global id the head of each run.
+    if tick:
+        tick.mark("all-to-all")
     urecs, ulens, ucounts, ufirst = backend.collapse_packed(r_recs, r_lens, r_w, r_ids)
+    if tick:
+        tick.mark("collapse")
 
     # ---- 3. whole unique table on every rank; search this rank's bucket shard ---
     g_recs = _all_gather_rows(urecs, group)
-    g_lens = _all_gather_rows(ulens, group)
+    g_lens = _all_gather_rows(ulens, group) if g_ragged else None
     g_counts = _all_gather_rows(ucounts, group)
     g_first = _all_gather_rows(ufirst, group)
+    if tick:
+        tick.mark("all-gather-unique")
     edges = backend.find_edges(g_recs, g_lens, g_counts, g_first, max_distance, metric, rank, world)
+    if tick:
+        tick.mark("find-edges")
 
     # ---- 4. all edges everywhere; components + dissection ------------------------
     # Every rank labels and dissects the whole graph (a few percent of the job) but LISTS only
     # the kept ids among its own reads [id0, id0 + n_local): what its pass 2 would need.
     g_edges = _all_gather_rows(edges, group)
     kept, n_clusters, n_kept = backend.finish(g_edges.contiguous(), method_id, id0, id0 + n_local)
+    if tick:
+        tick.mark("gather-edges+finish")
+        tick.done()
     return ShardedResult(kept, n_total, int(g_recs.shape[0]), int(g_edges.shape[0]), int(n_clusters),
                          int(n_kept))

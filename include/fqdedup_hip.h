@@ -140,6 +140,13 @@ int fqd_get_unique_table(fqd_ctx *ctx, uint64_t *first_ids, uint32_t *counts, ui
 /* Packed reads of stage 1: recs n*stride_words u32, lens n u32, hashes n u32. */
 int fqd_export_packed(fqd_ctx *ctx, uint32_t *recs, uint32_t *lens, uint32_t *hashes, int mem);
 int fqd_import_packed(fqd_ctx *ctx, const uint32_t *recs, const uint32_t *lens, uint64_t n, int mem);
+/* The same reads grouped by owner = key_hash % n_parts (part 0 first), each part in read order:
+ * the send buffers of the all-to-all. ids[i] = id0 + read index. recs/lens/ids/weights_out are
+ * DEVICE buffers of n rows (lens, weights_out may be NULL); weights (device, NULL = 1 each) are
+ * carried along; counts is a HOST array of n_parts row counts. */
+int fqd_export_packed_by_owner(fqd_ctx *ctx, uint32_t n_parts, uint64_t id0, const uint32_t *weights,
+                               uint32_t *recs, uint32_t *lens, uint64_t *ids, uint32_t *weights_out,
+                               uint64_t *counts, int mem);
 /* Unique table of stage 2. */
 int fqd_export_unique(fqd_ctx *ctx, uint32_t *recs, uint32_t *lens, uint32_t *counts,
                       uint64_t *first_ids, int mem);

@@ -32,6 +32,8 @@ class NumpyBackend:
         return [bytes(keys[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
 
     def _decode(self, recs, lens):
+        if lens is None:        # not ragged: the orchestration does not move lengths
+            lens = [self.max_len] * recs.shape[0]
         raw = recs.numpy().view(np.uint8).reshape(recs.shape[0], -1)
         return [bytes(raw[i, :int(lens[i])]) for i in range(recs.shape[0])]
 
@@ -45,18 +47,23 @@ class NumpyBackend:
         return present, (max(lens) if lens else 0), (len(set(lens)) > 1)
 
     def configure(self, present, max_len, ragged):
+        self.ragged = bool(ragged)
         self.max_len = int(max_len)
         self.stride = max(1, (self.max_len + 3) // 4)
 
-    def pack(self, keys, offsets, key_len):
+    def pack_by_owner(self, keys, offsets, key_len, n_parts, id0, weights):
         ks = self._split(keys, offsets, key_len)
+        owner = np.array([zlib.crc32(k) % n_parts for k in ks], dtype=np.int64)
+        order = np.argsort(owner, kind="stable")
         recs = np.zeros((len(ks), self.stride * 4), dtype=np.uint8)
-        for i, k in enumerate(ks):
-            recs[i, :len(k)] = np.frombuffer(k, dtype=np.uint8)
-        lens = np.array([len(k) for k in ks], dtype=np.int32)
-        hashes = np.array([zlib.crc32(k) for k in ks], dtype=np.uint32).view(np.int32)
+        for row, i in enumerate(order):
+            recs[row, :len(ks[i])] = np.frombuffer(ks[i], dtype=np.uint8)
+        lens = np.array([len(ks[i]) for i in order], dtype=np.int32)
+        ids = torch.from_numpy((id0 + order).astype(np.int64))
+        w = None if weights is None else torch.from_numpy(np.asarray(weights, dtype=np.int32)[order].copy())
+        counts = np.bincount(owner, minlength=n_parts).tolist()
         return (torch.from_numpy(recs.view(np.int32).reshape(len(ks), self.stride).copy()),
-                torch.from_numpy(lens), torch.from_numpy(hashes.copy()))
+                torch.from_numpy(lens) if self.ragged else None, ids, w, counts)
 
     def collapse_packed(self, recs, lens, weights, read_ids):
         ks = self._decode(recs, lens)
@@ -69,7 +76,7 @@ class NumpyBackend:
         idx = {k: j for j, k in enumerate(ks)}
         rows = [idx[k] for k in uniq]
         sel = torch.tensor(rows, dtype=torch.long)
-        return (recs[sel].contiguous(), lens[sel].contiguous(),
+        return (recs[sel].contiguous(), None if lens is None else lens[sel].contiguous(),
                 torch.tensor([count[k] for k in uniq], dtype=torch.int32),
                 torch.tensor([first[k] for k in uniq], dtype=torch.int64))
 
@@ -135,14 +142,17 @@ def _worker(rank, world, port, shards, d, method, weights, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,d,method", [(2, 1, "directional"), (2, 2, "adjacency"),
-                                            (3, 1, "highest_count")])
-def test_sharded_job_equals_single_job(oracle, world, d, method):
+@pytest.mark.parametrize("world,d,method,ragged", [(2, 1, "directional", True), (2, 2, "adjacency", False),
+                                                   (3, 1, "highest_count", True)])
+def test_sharded_job_equals_single_job(oracle, world, d, method, ragged):
     from fastqdedup_amd.synth import synth_keys
     n, L = 240, 12
     allk = [bytes(r) for r in synth_keys(n, L, 4, 5 + world, sub_rate=0.02, n_rate=0.01)]
-    allk[7] = allk[7][:-2]            # ragged on one rank only
-    allk[200] = b"ACGTacgt"           # a symbol set the other ranks do not have
+    if ragged:
+        allk[7] = allk[7][:-2]        # ragged on one rank only
+        allk[200] = b"ACGTacgt"       # a symbol set the other ranks do not have
+    else:
+        allk[200] = b"ACGTacgtACGT"
     rng = np.random.default_rng(world)
     weights = rng.integers(0, 3, size=n).tolist()
     cuts = [0, 90, 240] if world == 2 else [0, 90, 90, 240]     # rank 1 of 3 is empty
