@@ -11,10 +11,13 @@ from .core import (CLUSTER_DISSECTION_METHODS, DEFAULT_MAX_DISTANCE, ClusterResu
                    cluster_dissection_highest_count, cluster_keys, default_context,
                    pack_strings, within_distance)
 from ._lib import Context
+from .cli import (DEFAULT_CLUSTER_DISSECTION, DEFAULT_MAX_AVERAGE_ERROR_RATE, DEFAULT_PREFIX, argument_parser,
+                  average_error_rate, deduplicate_cluster, length_string_to_slices, main)
 
 __all__ = [
     "CLUSTER_DISSECTION_METHODS", "ClusterResult", "Context", "DEFAULT_MAX_DISTANCE", "Trie",
     "cluster_dissection_adjacency", "cluster_dissection_directional",
     "cluster_dissection_highest_count", "cluster_keys", "default_context", "pack_strings",
-    "within_distance",
+    "within_distance", "argument_parser", "average_error_rate", "deduplicate_cluster",
+    "length_string_to_slices", "main",
 ]

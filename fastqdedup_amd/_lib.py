@@ -43,7 +43,7 @@ EXPORTS = [
     "fqd_collapse", "fqd_find_edges", "fqd_components", "fqd_dissect", "fqd_cluster",
     "fqd_set_id_window", "fqd_get_kept_count", "fqd_get_kept_read_ids", "fqd_get_unique_table", "fqd_export_packed", "fqd_export_packed_by_owner", "fqd_import_packed",
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
-    "fqd_within_distance", "fqd_contains", "fqd_stage_times", "fqd_edge_stats", "fqd_synth_keys",
+    "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_edge_stats", "fqd_synth_keys",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -98,6 +98,8 @@ def load() -> C.CDLL:
     L.fqd_import_edges.argtypes = [vp, vp, C.c_uint64, C.c_int]
     L.fqd_within_distance.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, C.c_int]
     L.fqd_contains.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, C.c_int]
+    L.fqd_quality_filter.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp,
+                                     u64p, C.c_int]
     L.fqd_stage_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.fqd_edge_stats.argtypes = [vp, u64p, u64p, u64p]
     L.fqd_synth_keys.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
@@ -339,6 +341,35 @@ class Context:
         self._ck(self._L.fqd_contains(self._h, q_bytes.ctypes.data, q_off.ctypes.data, n,
                                       int(max_distance), int(metric), out.ctypes.data, HOST))
         return out[:n]
+
+    # ---- quality gate -----------------------------------------------------------
+    def quality_filter(self, quals, offsets=None, qual_len: int = 0, *, threshold: float = 0.001,
+                       phred_offset: int = 33, want_means: bool = False, table=None):
+        """pass flags (uint32, 1 = keep) [, means], number discarded."""
+        qp, qm, _q = _ptr_mem(quals)
+        op, om, _o = _ptr_mem(offsets)
+        if offsets is None:
+            nbytes = quals.numel() if hasattr(quals, "numel") else quals.size
+            n = nbytes // qual_len if qual_len else 0
+        else:
+            n = (offsets.numel() if hasattr(offsets, "numel") else offsets.size) - 1
+        mem = self._same_mem((qm, True), (om, offsets is not None))
+        if mem == DEVICE:
+            import torch
+            dev = quals.device
+            flags = torch.empty(n, dtype=torch.int32, device=dev)
+            means = torch.empty(n, dtype=torch.float64, device=dev) if want_means else None
+        else:
+            flags = np.empty(n, dtype=np.uint32)
+            means = np.empty(n, dtype=np.float64) if want_means else None
+        fp, _m, _f = _ptr_mem(flags)
+        mp_, _m, _mm = _ptr_mem(means)
+        tb = None if table is None else np.ascontiguousarray(table, dtype=np.float64)
+        nd = C.c_uint64(0)
+        self._ck(self._L.fqd_quality_filter(self._h, qp, op, n, int(qual_len), int(phred_offset),
+                                            float(threshold), None if tb is None else tb.ctypes.data,
+                                            fp, mp_, C.byref(nd), mem))
+        return flags, means, int(nd.value)
 
     # ---- measurement ------------------------------------------------------------
     def stage_times(self):

@@ -1,6 +1,7 @@
 // api.hip -- the C ABI of libfqdedup_hip.so (include/fqdedup_hip.h): context,
 // device buffers, stage orchestration, HIP-event timing. No kernels here.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -78,6 +79,7 @@ struct fqd_ctx {
     // stage 3
     uint64_t E = 0, edge_cap = 0;
     DevBuf seg_hashes, sorted_hash, sorted_uid, uid_iota, edges, sel_hash, sel_uid;
+    DevBuf q_table, q_pass, q_means, q_bytes, q_offsets;
     DevBuf len_present, ed_hash, ed_payload, ed_hash_sorted, ed_payload_sorted, ed_cands, ed_cands_sorted, d_alphabet;
     fqd::PairStats last_stats{};
     // stage 4
@@ -438,7 +440,8 @@ void fqd_destroy(fqd_ctx *c)
                       &c->lens, &c->hashes, &c->in_weights, &c->in_read_ids, &c->hs_sorted, &c->ids, &c->ids_sorted,
                       &c->flags, &c->run_idx, &c->run_start, &c->run_weight, &c->live_flag, &c->live_idx,
                       &c->collision_runs, &c->urecs, &c->ulens, &c->ucounts, &c->ufirst, &c->seg_hashes,
-                      &c->sorted_hash, &c->sorted_uid, &c->uid_iota, &c->edges, &c->sel_hash, &c->sel_uid, &c->len_present, &c->ed_hash,
+                      &c->sorted_hash, &c->sorted_uid, &c->uid_iota, &c->edges, &c->sel_hash, &c->sel_uid, &c->q_table, &c->q_pass, &c->q_means, &c->q_bytes, &c->q_offsets,
+                      &c->len_present, &c->ed_hash,
                       &c->ed_payload, &c->ed_hash_sorted, &c->ed_payload_sorted, &c->ed_cands, &c->ed_cands_sorted,
                       &c->d_alphabet, &c->labels, &c->best, &c->state,
                       &c->blocked, &c->kept, &c->kept_u32, &c->kept_scan, &c->kept_ids, &c->kept_ids_sorted, &c->tmp,
@@ -1222,6 +1225,84 @@ int fqd_contains(fqd_ctx *c, const uint8_t *q_bytes, const uint64_t *q_offsets, 
     HIP_TRY(c, hipStreamSynchronize(c->st));
     for (uint64_t i = 0; i < n; i++)
         out[i] = flags[i] ? 1 : 0;
+    return FQD_OK;
+}
+
+// ---- quality gate -----------------------------------------------------------------
+int fqd_quality_filter(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, uint32_t fixed_len,
+                       uint32_t phred_offset, double threshold, const double *table128, uint32_t *pass_out,
+                       double *means_out, uint64_t *n_discarded, int mem)
+{
+    FQD_TRY(bind(c));
+    if (phred_offset > 126)
+        return fail(c, FQD_E_VALUE, "phred_offset out of range");
+    if (n_discarded)
+        *n_discarded = 0;
+    if (!n)
+        return FQD_OK;
+    if (n >= 0xFFFFFFF0ull)
+        return fail(c, FQD_E_VALUE, "at most 2^32-16 reads per call");
+    if (mem == FQD_DEVICE && ((uintptr_t)bytes & 15u))
+        return fail(c, FQD_E_VALUE, "device buffer must be 16-byte aligned");
+    uint64_t n_bytes;
+    if (offsets) {
+        if (mem == FQD_HOST) {
+            n_bytes = offsets[n];
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(&n_bytes, offsets + n, 8, hipMemcpyDeviceToHost, c->st));
+            HIP_TRY(c, hipStreamSynchronize(c->st));
+        }
+    } else {
+        n_bytes = n * (uint64_t)fixed_len;
+    }
+    const uint8_t *d_bytes;
+    const uint64_t *d_off = nullptr;
+    FQD_TRY(to_device(c, bytes, (size_t)n_bytes, mem, c->q_bytes, &d_bytes));
+    if (offsets)
+        FQD_TRY(to_device(c, offsets, (size_t)n + 1, mem, c->q_offsets, &d_off));
+    uint32_t max_len = fixed_len;
+    if (offsets) {
+        uint32_t mm[2] = {0xFFFFFFFFu, 0u};
+        HIP_TRY(c, hipMemcpyAsync(c->d_ctr32.as<uint32_t>() + C_MINLEN, mm, 8, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(c, fqd::launch_scan_lens(d_off, n, c->d_ctr32.as<uint32_t>() + C_MINLEN, c->st));
+        HIP_TRY(c, hipMemcpyAsync(mm, c->d_ctr32.as<uint32_t>() + C_MINLEN, 8, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(c, hipStreamSynchronize(c->st));
+        max_len = mm[1];
+    }
+    double table[128];
+    for (int i = 0; i < 128; i++)
+        table[i] = table128 ? table128[i] : std::pow(10.0, -((double)i / 10.0));  // score_to_error_rate.py
+    HIP_TRY(c, c->q_table.reserve(sizeof table));
+    HIP_TRY(c, hipMemcpyAsync(c->q_table.p, table, sizeof table, hipMemcpyHostToDevice, c->st));
+    uint32_t *d_pass = pass_out;
+    double *d_means = means_out;
+    if (mem == FQD_HOST) {
+        HIP_TRY(c, c->q_pass.reserve(n * 4 + 16));
+        d_pass = c->q_pass.as<uint32_t>();
+        if (means_out) {
+            HIP_TRY(c, c->q_means.reserve(n * 8 + 16));
+            d_means = c->q_means.as<double>();
+        }
+    }
+    FQD_TRY(zero_ctr32(c, C_BAD));
+    HIP_TRY(c, fqd::launch_quality(d_bytes, n_bytes, d_off, n, fixed_len, max_len, c->q_table.as<double>(),
+                                   phred_offset, 126u - phred_offset, threshold, d_pass, d_means,
+                                   c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+    uint32_t bad = 0;
+    FQD_TRY(read_ctr32(c, C_BAD, &bad));
+    if (bad)
+        return fail(c, FQD_E_VALUE, "a phred string holds a character outside the valid phred range");
+    FQD_TRY(zero_ctr64(c, C64_SUM));
+    HIP_TRY(c, fqd::launch_sum_u32(d_pass, n, c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+    unsigned long long passed = 0;
+    FQD_TRY(read_ctr64(c, C64_SUM, &passed));
+    if (n_discarded)
+        *n_discarded = n - passed;
+    if (mem == FQD_HOST) {
+        FQD_TRY(from_device(c, pass_out, d_pass, (size_t)n, FQD_HOST));
+        if (means_out)
+            FQD_TRY(from_device(c, means_out, d_means, (size_t)n, FQD_HOST));
+    }
     return FQD_OK;
 }
 

@@ -227,6 +227,12 @@ hipError_t launch_gather_by_owner(const uint32_t *order, uint64_t n, KeyShape sh
 hipError_t launch_owner_counts(const uint32_t *owner_sorted, uint64_t n, uint32_t parts, uint64_t *counts,
                                hipStream_t st);
 
+// quality.hip -- per-read mean error rate gate
+hipError_t launch_quality(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
+                          uint32_t fixed_len, uint32_t max_len, const double *table_dev, uint32_t phred_offset,
+                          uint32_t max_score, double threshold, uint32_t *pass, double *means, uint32_t *bad_flag,
+                          hipStream_t st);
+
 // graph.hip -- union-find + dissection
 hipError_t launch_uf_init(uint32_t *parent, uint64_t U, hipStream_t st);
 hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, hipStream_t st);

@@ -166,6 +166,19 @@ int fqd_within_distance(fqd_ctx *ctx, const uint8_t *a_bytes, const uint64_t *a_
 int fqd_contains(fqd_ctx *ctx, const uint8_t *q_bytes, const uint64_t *q_offsets, uint64_t n,
                  int max_distance, int metric, uint8_t *out, int mem);
 
+/* ---- the quality gate in front of the path ---------------------------------
+ * _fastq.average_error_rate (reference _fastqmodule.c:38-76) over n phred strings as
+ * deduplicate_cluster uses it (__init__.py:243-250): pass_out[i] = 0 when the mean of
+ * 10**-(q/10) over string i exceeds `threshold`, else 1 (an empty string gives NaN and
+ * passes). The sum runs in string order in double precision, like the reference, so the
+ * means are bit-identical. table128: the 128 error rates (NULL: computed as the
+ * reference's generator does). means_out may be NULL. A character outside
+ * ['!' + 0 .. '~'] relative to phred_offset is a FQD_E_VALUE. */
+int fqd_quality_filter(fqd_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n,
+                       uint32_t fixed_len, uint32_t phred_offset, double threshold,
+                       const double *table128, uint32_t *pass_out, double *means_out,
+                       uint64_t *n_discarded, int mem);
+
 /* ---- measurement ----------------------------------------------------------- */
 #define FQD_T_PACK       0
 #define FQD_T_COLLAPSE   1

@@ -13,6 +13,7 @@
 #define _POSIX_C_SOURCE 200809L
 #include "fqd_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -825,4 +826,33 @@ done:
     fqo_trie_free(t);
     free(first);
     return err;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Quality gate (_fastqmodule.c:38-76, score_to_error_rate.py)              */
+/* ------------------------------------------------------------------------ */
+
+int fqo_average_error_rate(const uint8_t *phred, size_t len, uint8_t phred_offset, double *out,
+                           uint8_t *bad_char)
+{
+    static double table[128];
+    static int ready = 0;
+    if (!ready) { /* score_to_error_rate.py: 10 ** -(i / 10) */
+        for (int i = 0; i < 128; i++)
+            table[i] = pow(10.0, -((double)i / 10.0));
+        ready = 1;
+    }
+    const uint8_t max_score = (uint8_t)(126 - phred_offset); /* :20, :65 */
+    double total = 0.0;
+    for (size_t i = 0; i < len; i++) {
+        const uint8_t score = (uint8_t)(phred[i] - phred_offset);
+        if (score > max_score) { /* :68-74 */
+            if (bad_char)
+                *bad_char = phred[i];
+            return FQO_E_VALUE;
+        }
+        total += table[score];
+    }
+    *out = total / (double)len; /* :76 */
+    return FQO_OK;
 }

@@ -81,6 +81,12 @@ int fqo_dedup(const uint8_t *bytes, const uint64_t *offsets, uint64_t n,
               uint64_t *kept_first_ids, uint64_t *n_kept, uint64_t *n_clusters,
               uint64_t *n_unique, double *stage_seconds);
 
+/* _fastqmodule.c:38-76: mean of 10**-(q/10) over the phred string, summed in order in a
+ * double; *bad_char receives the first character outside [phred_offset, 126] (then
+ * FQO_E_VALUE). An empty string gives NaN (0.0/0). */
+int fqo_average_error_rate(const uint8_t *phred, size_t len, uint8_t phred_offset, double *out,
+                           uint8_t *bad_char);
+
 #ifdef __cplusplus
 }
 #endif

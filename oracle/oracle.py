@@ -77,6 +77,7 @@ def lib() -> C.CDLL:
                               C.c_int, C.c_int, C.c_void_p]
     L.fqo_dedup.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int,
                             C.c_int, C.c_void_p, u64p, u64p, u64p, C.POINTER(C.c_double)]
+    L.fqo_average_error_rate.argtypes = [C.c_char_p, C.c_size_t, C.c_uint8, C.POINTER(C.c_double), u8p]
     _lib = L
     return L
 
@@ -110,6 +111,21 @@ def within_distance(s1: str, s2: str, /, max_distance: int, use_edit_distance: b
         raise ValueError("strings must be ASCII or latin-1 encoded.") from None
     f = lib().fqo_within_edit if use_edit_distance else lib().fqo_within_hamming
     return bool(f(b1, len(b1), b2, len(b2), int(max_distance)))
+
+
+def average_error_rate(phred_scores: str, *, phred_offset: int = 33) -> float:
+    """_fastqmodule.c:38-76"""
+    if not isinstance(phred_scores, str):
+        raise TypeError("phred_scores must be str")
+    if not phred_scores.isascii():
+        raise ValueError("phred_scores must be ASCII encoded.")
+    b = phred_scores.encode("ascii")
+    out, bad = C.c_double(0.0), C.c_uint8(0)
+    rc = lib().fqo_average_error_rate(b, len(b), phred_offset, C.byref(out), C.byref(bad))
+    if rc:
+        raise ValueError(f"Character {chr(bad.value)} outside of valid phred range "
+                         f"('{chr(phred_offset)}' to '{chr(126)}')")
+    return out.value
 
 
 class Trie:
