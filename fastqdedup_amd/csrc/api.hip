@@ -76,6 +76,10 @@ struct fqd_ctx {
     DevBuf in_weights, in_read_ids, hs_sorted, ids, ids_sorted, flags, run_idx, run_start, run_weight, live_flag,
         live_idx, collision_runs;
     DevBuf urecs, ulens, ucounts, ufirst;
+    DevBuf ld_small, ld_part2;
+    DevBuf ld_hist, ld_hist_incl, ld_start, ld_cursor, ld_part, ld_tmp_rec, ld_tmp_count, ld_tmp_first, ld_unique,
+        ld_unique_incl;
+    int collapse_path = 0;  // 1: LDS bucket dedupe, 2: sort + verify (last fqd_collapse)
     // stage 3
     uint64_t E = 0, edge_cap = 0;
     DevBuf seg_hashes, sorted_hash, sorted_uid, uid_iota, edges, sel_hash, sel_uid;
@@ -303,6 +307,107 @@ int hash_bits_from_env()
     return b < 1 ? 1 : (b > 32 ? 32 : b);
 }
 
+// Sort-free collapse for records of one uint4 (collapse_lds.hip). Returns FQD_OK with
+// *done = false when it does not apply or a bucket's table overflowed (caller falls back).
+int collapse_lds(fqd_ctx *c, const uint32_t *d_w, const uint64_t *d_ids, bool *done)
+{
+    *done = false;
+    const uint64_t n = c->n;
+    const KeyShape sh = c->ks;
+    const char *force = getenv("FQD_COLLAPSE");  // "sort" / "lds": tests pin a path
+    if (force && !strcmp(force, "sort"))
+        return FQD_OK;
+    if (sh.ragged || sh.stride != 4 || sh.planes * sh.words > 3 || n >= 0xFFFFFF00ull)
+        return FQD_OK;
+    if (n < 32768 && !(force && !strcmp(force, "lds")))
+        return FQD_OK;
+    uint32_t B = 8;
+    while (B < 18 && (n >> B) > 400)
+        B++;
+    if (const char *e = getenv("FQD_LDS_BUCKET_BITS"))  // tests: few buckets => table overflow => fallback
+        B = (uint32_t)std::max(1, std::min(18, atoi(e)));
+    const uint32_t B1 = std::min<uint32_t>(B, 8), B2 = B - B1;
+    const uint32_t bins1 = 1u << B1, bins2 = 1u << B2, n_buckets = 1u << B;
+    const uint32_t kw = sh.planes * sh.words, tile = fqd::part_tile_size();
+    const uint32_t tiles1 = (uint32_t)((n + tile - 1) / tile), max_tiles2 = tiles1 + bins1;
+    HIP_TRY(c, c->ld_hist.reserve((size_t)n_buckets * 4 + 1024 * 4));
+    HIP_TRY(c, c->ld_hist_incl.reserve((size_t)n_buckets * 4 + 1024 * 4));
+    HIP_TRY(c, c->ld_start.reserve(((size_t)n_buckets + 1) * 4 + 16));
+    HIP_TRY(c, c->ld_cursor.reserve((size_t)n_buckets * 4 + 1024 * 4));
+    HIP_TRY(c, c->ld_unique.reserve((size_t)n_buckets * 4 + 16));
+    HIP_TRY(c, c->ld_unique_incl.reserve((size_t)n_buckets * 4 + 16));
+    HIP_TRY(c, c->ld_small.reserve(4096 * 4));
+    HIP_TRY(c, c->ld_part.reserve(n * 16 + 16));
+    HIP_TRY(c, c->ld_tmp_rec.reserve(n * 16 + 16));   // level-2 output first, then the dedupe's tmp
+    HIP_TRY(c, c->ld_part2.reserve(n * 16 + 16));
+    HIP_TRY(c, c->ld_tmp_count.reserve(n * 4 + 16));
+    HIP_TRY(c, c->ld_tmp_first.reserve(n * 4 + 16));
+    // small device tables: [0] seg_start1 (2) | [8] tile_start1 (2) | [16] start1 (257) | [512] tile_start2 (257)
+    uint32_t *small = c->ld_small.as<uint32_t>();
+    uint32_t *seg1 = small, *tiles1_d = small + 8, *start1 = small + 16, *tiles2_d = small + 512;
+    const uint32_t seg1_h[2] = {0u, (uint32_t)n}, tiles1_h[2] = {0u, tiles1};
+    HIP_TRY(c, hipMemcpyAsync(seg1, seg1_h, 8, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, hipMemcpyAsync(tiles1_d, tiles1_h, 8, hipMemcpyHostToDevice, c->st));
+    // ---- level 1: 2^B1 parts by the top B1 hash bits
+    HIP_TRY(c, hipMemsetAsync(c->ld_hist.p, 0, (size_t)bins1 * 4, c->st));
+    HIP_TRY(c, fqd::launch_part_hist(true, c->hashes.as<uint32_t>(), c->recs.as<uint32_t>(), seg1, tiles1_d, 1, tiles1,
+                                     32 - B1, bins1, kw, sh.max_len, c->ld_hist.as<uint32_t>(), c->st));
+    FQD_TRY(scan_u32(c, c->ld_hist.as<uint32_t>(), c->ld_hist_incl.as<uint32_t>(), bins1));
+    HIP_TRY(c, fqd::launch_bucket_starts(c->ld_hist_incl.as<uint32_t>(), bins1, start1, c->ld_cursor.as<uint32_t>(),
+                                         c->st));
+    HIP_TRY(c, fqd::launch_part_scatter(true, c->hashes.as<uint32_t>(), c->recs.as<uint32_t>(), seg1, tiles1_d, 1,
+                                        tiles1, 32 - B1, bins1, kw, sh.max_len, c->ld_cursor.as<uint32_t>(),
+                                        c->ld_part.as<uint32_t>(), c->st));
+    const uint32_t *parted = c->ld_part.as<uint32_t>();
+    if (B2 == 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->ld_start.p, start1, ((size_t)bins1 + 1) * 4, hipMemcpyDeviceToDevice, c->st));
+    } else {
+        // ---- level 2: every part into 2^B2 buckets by the next B2 hash bits
+        HIP_TRY(c, fqd::launch_tile_starts(start1, bins1, tiles2_d, c->st));
+        HIP_TRY(c, hipMemsetAsync(c->ld_hist.p, 0, (size_t)n_buckets * 4, c->st));
+        HIP_TRY(c, fqd::launch_part_hist(false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1, max_tiles2,
+                                         32 - B, bins2, kw, sh.max_len, c->ld_hist.as<uint32_t>(), c->st));
+        FQD_TRY(scan_u32(c, c->ld_hist.as<uint32_t>(), c->ld_hist_incl.as<uint32_t>(), n_buckets));
+        HIP_TRY(c, fqd::launch_bucket_starts(c->ld_hist_incl.as<uint32_t>(), n_buckets, c->ld_start.as<uint32_t>(),
+                                             c->ld_cursor.as<uint32_t>(), c->st));
+        HIP_TRY(c, fqd::launch_part_scatter(false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1,
+                                            max_tiles2, 32 - B, bins2, kw, sh.max_len, c->ld_cursor.as<uint32_t>(),
+                                            c->ld_part2.as<uint32_t>(), c->st));
+        parted = c->ld_part2.as<uint32_t>();
+    }
+    FQD_TRY(zero_ctr32(c, C_BAD));
+    HIP_TRY(c, fqd::launch_bucket_dedupe(parted, c->ld_start.as<uint32_t>(), n_buckets, d_w,
+                                         c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(),
+                                         c->ld_tmp_first.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
+                                         c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+    FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
+    uint32_t U32 = 0, overflow = 0;
+    HIP_TRY(c, hipMemcpyAsync(&U32, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 4, hipMemcpyDeviceToHost,
+                              c->st));
+    FQD_TRY(read_ctr32(c, C_BAD, &overflow));
+    if (overflow)
+        return FQD_OK;  // some bucket held more distinct keys than the LDS table: sort-based path
+    const uint64_t U = U32;
+    HIP_TRY(c, c->urecs.reserve(U * 16 + 16));
+    HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
+    HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
+    HIP_TRY(c, c->ufirst.reserve(U * 8 + 16));
+    HIP_TRY(c, fqd::launch_bucket_compact(c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets,
+                                          c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(),
+                                          c->ld_tmp_first.as<uint32_t>(), d_ids, c->urecs.as<uint32_t>(),
+                                          c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st));
+    unsigned long long counted = n;
+    if (d_w) {
+        FQD_TRY(zero_ctr64(c, C64_SUM));
+        HIP_TRY(c, fqd::launch_sum_u32(d_w, n, c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+        FQD_TRY(read_ctr64(c, C64_SUM, &counted));
+    }
+    c->U = U;
+    c->n_counted = counted;
+    *done = true;
+    return FQD_OK;
+}
+
 // Levenshtein neighbour search for the general case (edit.hip): index/probe records ->
 // sort -> candidate pairs -> sort/unique -> banded-DP verification.
 int find_edges_edit(fqd_ctx *c, uint32_t d, uint32_t shard, uint32_t n_shards)
@@ -439,7 +544,9 @@ void fqd_destroy(fqd_ctx *c)
     DevBuf *bufs[] = {&c->d_lut, &c->d_ctr32, &c->d_ctr64, &c->d_present, &c->d_stats, &c->in_bytes, &c->in_offsets, &c->recs,
                       &c->lens, &c->hashes, &c->in_weights, &c->in_read_ids, &c->hs_sorted, &c->ids, &c->ids_sorted,
                       &c->flags, &c->run_idx, &c->run_start, &c->run_weight, &c->live_flag, &c->live_idx,
-                      &c->collision_runs, &c->urecs, &c->ulens, &c->ucounts, &c->ufirst, &c->seg_hashes,
+                      &c->collision_runs, &c->urecs, &c->ulens, &c->ucounts, &c->ufirst, &c->ld_hist, &c->ld_hist_incl, &c->ld_start,
+                      &c->ld_cursor, &c->ld_part, &c->ld_part2, &c->ld_small, &c->ld_tmp_rec, &c->ld_tmp_count, &c->ld_tmp_first, &c->ld_unique,
+                      &c->ld_unique_incl, &c->seg_hashes,
                       &c->sorted_hash, &c->sorted_uid, &c->uid_iota, &c->edges, &c->sel_hash, &c->sel_uid, &c->q_table, &c->q_pass, &c->q_means, &c->q_bytes, &c->q_offsets,
                       &c->len_present, &c->ed_hash,
                       &c->ed_payload, &c->ed_hash_sorted, &c->ed_payload_sorted, &c->ed_cands, &c->ed_cands_sorted,
@@ -630,6 +737,24 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
     FQD_TRY(to_device(c, weights, (size_t)n, mem, c->in_weights, &d_w));
     FQD_TRY(to_device(c, read_ids, (size_t)n, mem, c->in_read_ids, &d_ids));
 
+    bool lds_done = false;
+    FQD_TRY(collapse_lds(c, weights ? d_w : nullptr, read_ids ? d_ids : nullptr, &lds_done));
+    if (lds_done) {
+        timer.stop();
+        c->collapse_path = 1;
+        c->collapsed = true;
+        c->id_bits = 64;
+        if (!read_ids) {
+            c->id_bits = 1;
+            while (c->id_bits < 64 && (n >> c->id_bits))
+                c->id_bits++;
+        }
+        c->stage = ST_UNIQUE;
+        if (n_unique)
+            *n_unique = c->U;
+        return FQD_OK;
+    }
+    c->collapse_path = 2;
     const int bits = hash_bits_from_env();
     const uint32_t mask = bits >= 32 ? ~0u : ((1u << bits) - 1u);
     HIP_TRY(c, c->hs_sorted.reserve(n * 4 + 16));

@@ -1,0 +1,394 @@
+// collapse_lds.hip -- stage 2 for short keys (a record is one uint4: <= 3 plane words + a
+// spare word): exact-duplicate collapse WITHOUT a device-wide sort and WITHOUT gathers.
+// Same contract as collapse.hip (reference _triemodule.c:235-239, :261-264: an identical
+// key bumps a count; pass-2 rule __init__.py:201-206: the first holder is remembered).
+//
+//   1+2. two-level partition by the top B = 8 + B2 bits of the 32-bit key hash: level 1
+//      splits all reads into 256 parts, level 2 splits every part into 2^B2 buckets. Each
+//      level is a histogram pass and a scatter pass over TILES of 2048 reads; bin counts
+//      and the ranks inside a bin are LDS atomics, so the global cursor table sees ONE
+//      atomic per (tile, bin) instead of one per read (a one-level scatter with one global
+//      atomic per read took 5.3 ms for 50 M reads; this takes ~1 ms). The record travels
+//      as a uint4 whose spare word carries the read index; level 2 re-derives the hash.
+//   3. one workgroup per bucket (~400 reads) streams the bucket through an LDS hash
+//      table keyed by the full record: a slot's tag is claimed with ds_cmpswap, the
+//      claimer parks its record, later copies are VERIFIED word by word against the
+//      parked record (a tag only proposes), then bump the slot's count / min index with
+//      LDS atomics. Equal keys meet because they share a hash, hence a bucket.
+//   4. per-bucket unique counts are scanned and the parked records are copied out.
+//
+// Every read is moved twice, always as a 16-byte store; nothing is gathered. Buckets hold whatever falls into them: a key with a
+// million copies makes one long bucket (slow for that workgroup, still exact); a bucket
+// with more distinct keys than the table holds raises `overflow` and the caller falls
+// back to the sort-based collapse.
+#include "fqd_internal.h"
+
+namespace {
+
+constexpr uint32_t DD_SLOTS = 1024;        // LDS table slots per bucket (power of two)
+constexpr uint32_t DD_THREADS = 256;
+constexpr uint32_t DD_EMPTY = 0xFFFFFFFFu;
+
+constexpr uint32_t PT_THREADS = 256;
+constexpr uint32_t PT_EPT = 8;                      // reads per thread
+constexpr uint32_t PT_TILE = PT_THREADS * PT_EPT;   // reads per tile
+constexpr uint32_t PT_MAX_BINS = 1024;
+
+// Tiles never straddle a segment (level 1: one segment = all reads; level 2: the 256
+// level-1 parts). tile_start[s] = first tile of segment s, tile_start[n_seg] = tile count.
+__device__ __forceinline__ bool tile_of_block(const uint32_t *__restrict__ seg_start,
+                                              const uint32_t *__restrict__ tile_start, uint32_t n_seg,
+                                              uint32_t &seg, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t t = blockIdx.x;
+    if (t >= tile_start[n_seg])
+        return false;
+    uint32_t a = 0, b = n_seg;  // last segment with tile_start <= t
+    while (b - a > 1) {
+        const uint32_t m = (a + b) >> 1;
+        if (tile_start[m] <= t)
+            a = m;
+        else
+            b = m;
+    }
+    seg = a;
+    lo = seg_start[a] + (t - tile_start[a]) * PT_TILE;
+    hi = min(lo + PT_TILE, seg_start[a + 1]);
+    return true;
+}
+
+// LEVEL 1 reads (hash, record) of the packed reads and stamps the read index into the spare
+// word; LEVEL 2 reads level-1 output and recomputes the hash from the record.
+template <bool LEVEL1>
+__device__ __forceinline__ uint32_t load_item(const uint32_t *__restrict__ hashes, const uint4 *__restrict__ in,
+                                              uint32_t i, uint32_t kw, uint32_t len, uint4 &v)
+{
+    v = in[i];
+    if (LEVEL1) {
+        v.w = i;
+        return hashes[i];
+    }
+    const uint32_t rec[3] = {v.x, v.y, v.z};
+    return fqd_hash_record(rec, kw, len);
+}
+
+template <bool LEVEL1>
+__global__ __launch_bounds__(PT_THREADS) void part_hist_kernel(const uint32_t *__restrict__ hashes,
+                                                               const uint4 *__restrict__ in,
+                                                               const uint32_t *__restrict__ seg_start,
+                                                               const uint32_t *__restrict__ tile_start, uint32_t n_seg,
+                                                               uint32_t shift, uint32_t n_bins, uint32_t kw,
+                                                               uint32_t len, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t s_hist[PT_MAX_BINS];
+    uint32_t seg, lo, hi;
+    if (!tile_of_block(seg_start, tile_start, n_seg, seg, lo, hi))
+        return;
+    for (uint32_t b = threadIdx.x; b < n_bins; b += PT_THREADS)
+        s_hist[b] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += PT_THREADS) {
+        uint32_t h;
+        if (LEVEL1) {
+            h = hashes[i];
+        } else {
+            uint4 v;
+            h = load_item<false>(hashes, in, i, kw, len, v);
+        }
+        atomicAdd(&s_hist[(h >> shift) & (n_bins - 1)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_bins; b += PT_THREADS)
+        if (s_hist[b])
+            atomicAdd(&hist[seg * n_bins + b], s_hist[b]);
+}
+
+template <bool LEVEL1>
+__global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const uint32_t *__restrict__ hashes,
+                                                                  const uint4 *__restrict__ in,
+                                                                  const uint32_t *__restrict__ seg_start,
+                                                                  const uint32_t *__restrict__ tile_start,
+                                                                  uint32_t n_seg, uint32_t shift, uint32_t n_bins,
+                                                                  uint32_t kw, uint32_t len,
+                                                                  uint32_t *__restrict__ cursor,
+                                                                  uint4 *__restrict__ out)
+{
+    __shared__ uint32_t s_hist[PT_MAX_BINS];   // count per bin, then the bin's global base
+    uint32_t seg, lo, hi;
+    if (!tile_of_block(seg_start, tile_start, n_seg, seg, lo, hi))
+        return;
+    for (uint32_t b = threadIdx.x; b < n_bins; b += PT_THREADS)
+        s_hist[b] = 0;
+    __syncthreads();
+    uint4 v[PT_EPT];
+    uint32_t bin[PT_EPT], rank[PT_EPT];
+#pragma unroll
+    for (uint32_t e = 0; e < PT_EPT; e++) {
+        const uint32_t i = lo + e * PT_THREADS + threadIdx.x;
+        bin[e] = 0xFFFFFFFFu;
+        if (i < hi) {
+            const uint32_t h = load_item<LEVEL1>(hashes, in, i, kw, len, v[e]);
+            bin[e] = (h >> shift) & (n_bins - 1);
+            rank[e] = atomicAdd(&s_hist[bin[e]], 1u);   // position inside the tile's share of the bin
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_bins; b += PT_THREADS) {
+        const uint32_t c = s_hist[b];
+        s_hist[b] = c ? atomicAdd(&cursor[seg * n_bins + b], c) : 0u;  // ONE global atomic per (tile, bin)
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < PT_EPT; e++)
+        if (bin[e] != 0xFFFFFFFFu)
+            out[s_hist[bin[e]] + rank[e]] = v[e];
+}
+
+// tile_start[] for segments given by seg_start[0..n_seg] (single block; n_seg <= 256)
+__global__ void tile_starts_kernel(const uint32_t *__restrict__ seg_start, uint32_t n_seg,
+                                   uint32_t *__restrict__ tile_start)
+{
+    __shared__ uint32_t s[257];
+    const uint32_t t = threadIdx.x;
+    uint32_t tiles = 0;
+    if (t < n_seg)
+        tiles = (seg_start[t + 1] - seg_start[t] + PT_TILE - 1) / PT_TILE;
+    s[t] = tiles;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < n_seg; i++) {
+            const uint32_t c = s[i];
+            s[i] = acc;
+            acc += c;
+        }
+        s[n_seg] = acc;
+    }
+    __syncthreads();
+    if (t <= n_seg)
+        tile_start[t] = s[t];
+    if (t == 0 && n_seg < 256)
+        tile_start[n_seg] = s[n_seg];
+}
+
+__device__ __forceinline__ uint32_t rec_tag(const uint4 &v)
+{
+    uint32_t h = (v.x ^ 0x9E3779B9u) * 0x85EBCA6Bu;
+    h = (h ^ (h >> 15) ^ v.y) * 0xC2B2AE35u;
+    h = (h ^ (h >> 13) ^ v.z) * 0x27D4EB2Fu;
+    h ^= h >> 16;
+    return h == DD_EMPTY ? 0u : h;
+}
+
+__global__ __launch_bounds__(DD_THREADS) void bucket_dedupe_kernel(
+    const uint4 *__restrict__ part, const uint32_t *__restrict__ bucket_start /* n_buckets + 1 */,
+    const uint32_t *__restrict__ weights, uint4 *__restrict__ tmp_rec, uint32_t *__restrict__ tmp_count,
+    uint32_t *__restrict__ tmp_first, uint32_t *__restrict__ bucket_unique, uint32_t *__restrict__ overflow)
+{
+    __shared__ uint32_t s_tag[DD_SLOTS], s_x[DD_SLOTS], s_y[DD_SLOTS], s_z[DD_SLOTS], s_cnt[DD_SLOTS], s_min[DD_SLOTS];
+    __shared__ uint32_t s_wave_tot[DD_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t lo = bucket_start[b], hi = bucket_start[b + 1];
+    for (uint32_t s = tid; s < DD_SLOTS; s += DD_THREADS)
+        s_tag[s] = DD_EMPTY;
+    __syncthreads();
+
+    bool full = false;
+    for (uint32_t base = lo; base < hi; base += DD_THREADS) {
+        const uint32_t i = base + tid;
+        const bool active = i < hi;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (active)
+            v = part[i];
+        const uint32_t tag = rec_tag(v);
+        const uint32_t w = active ? (weights ? weights[v.w] : 1u) : 0u;
+        uint32_t slot = (tag * 0x9E3779B1u) >> 22;  // top 10 bits of a re-mix: DD_SLOTS == 1024
+        uint32_t probes = 0;
+        bool pending = active;
+        do {
+            // claim an empty slot, or stop at a slot whose tag matches (to be verified below)
+            if (pending) {
+                for (;;) {
+                    const uint32_t old = atomicCAS(&s_tag[slot], DD_EMPTY, tag);
+                    if (old == DD_EMPTY) {
+                        s_x[slot] = v.x;
+                        s_y[slot] = v.y;
+                        s_z[slot] = v.z;
+                        s_cnt[slot] = w;
+                        s_min[slot] = v.w;
+                        pending = false;
+                        break;
+                    }
+                    if (old == tag)
+                        break;
+                    slot = (slot + 1) & (DD_SLOTS - 1);
+                    if (++probes >= DD_SLOTS) {
+                        full = true;
+                        pending = false;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();  // parked records of this round are visible
+            if (pending) {
+                if (s_x[slot] == v.x && s_y[slot] == v.y && s_z[slot] == v.z) {
+                    atomicAdd(&s_cnt[slot], w);
+                    atomicMin(&s_min[slot], v.w);
+                    pending = false;
+                } else {  // same tag, different key: keep probing
+                    slot = (slot + 1) & (DD_SLOTS - 1);
+                    if (++probes >= DD_SLOTS) {
+                        full = true;
+                        pending = false;
+                    }
+                }
+            }
+        } while (__syncthreads_or(pending));
+    }
+    if (full)
+        atomicOr(overflow, 1u);
+    __syncthreads();
+
+    // compact the live slots (count > 0: a key all of whose holders have weight 0 is not
+    // in the trie) to tmp[lo ...): unique keys <= reads of the bucket, so they fit
+    uint32_t mine = 0;
+    for (uint32_t s = tid; s < DD_SLOTS; s += DD_THREADS)
+        mine += (s_tag[s] != DD_EMPTY && s_cnt[s] > 0) ? 1u : 0u;
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if ((int)lane >= o)
+            incl += up;
+    }
+    if (lane == 63)
+        s_wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine;
+    for (uint32_t wv = 0; wv < wave; wv++)
+        before += s_wave_tot[wv];
+    uint32_t total = 0;
+    for (uint32_t wv = 0; wv < DD_THREADS / 64; wv++)
+        total += s_wave_tot[wv];
+    uint32_t out = lo + before;
+    for (uint32_t s = tid; s < DD_SLOTS; s += DD_THREADS)
+        if (s_tag[s] != DD_EMPTY && s_cnt[s] > 0) {
+            tmp_rec[out] = make_uint4(s_x[s], s_y[s], s_z[s], 0u);
+            tmp_count[out] = s_cnt[s];
+            tmp_first[out] = s_min[s];
+            out++;
+        }
+    if (tid == 0)
+        bucket_unique[b] = total;
+}
+
+// one wave per bucket: tmp[bucket_start[b] + j] -> out[uoff[b] + j], j < unique count
+__global__ __launch_bounds__(256) void bucket_compact_kernel(
+    const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ unique_incl /* inclusive scan */,
+    uint32_t n_buckets, const uint4 *__restrict__ tmp_rec, const uint32_t *__restrict__ tmp_count,
+    const uint32_t *__restrict__ tmp_first, const uint64_t *__restrict__ read_ids, uint4 *__restrict__ urecs,
+    uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst)
+{
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= n_buckets)
+        return;
+    const uint32_t end = unique_incl[b], begin = b ? unique_incl[b - 1] : 0u;
+    const uint32_t src = bucket_start[b];
+    for (uint32_t j = fqd_lane(); j < end - begin; j += 64) {
+        urecs[begin + j] = tmp_rec[src + j];
+        ucounts[begin + j] = tmp_count[src + j];
+        const uint32_t f = tmp_first[src + j];
+        ufirst[begin + j] = read_ids ? read_ids[f] : (uint64_t)f;
+    }
+}
+
+// bucket_start[b] = number of reads in buckets < b, from the inclusive scan of the histogram
+__global__ void bucket_starts_kernel(const uint32_t *__restrict__ hist_incl, uint32_t n_buckets,
+                                     uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ cursor)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_buckets)
+        return;
+    const uint32_t v = b ? hist_incl[b - 1] : 0u;
+    bucket_start[b] = v;
+    if (b < n_buckets)
+        cursor[b] = v;
+}
+
+}  // namespace
+
+namespace fqd {
+
+hipError_t launch_tile_starts(const uint32_t *seg_start, uint32_t n_seg, uint32_t *tile_start, hipStream_t st)
+{
+    tile_starts_kernel<<<1, 257, 0, st>>>(seg_start, n_seg, tile_start);
+    return hipGetLastError();
+}
+
+// max_tiles bounds the tile count (n / TILE + n_seg); surplus blocks exit at once
+hipError_t launch_part_hist(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
+                            const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
+                            uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *hist, hipStream_t st)
+{
+    if (n_bins > PT_MAX_BINS)
+        return hipErrorInvalidValue;
+    const uint4 *in4 = reinterpret_cast<const uint4 *>(in);
+    if (level1)
+        part_hist_kernel<true><<<max_tiles, PT_THREADS, 0, st>>>(hashes, in4, seg_start, tile_start, n_seg, shift,
+                                                                 n_bins, kw, len, hist);
+    else
+        part_hist_kernel<false><<<max_tiles, PT_THREADS, 0, st>>>(hashes, in4, seg_start, tile_start, n_seg, shift,
+                                                                  n_bins, kw, len, hist);
+    return hipGetLastError();
+}
+
+hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
+                               const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
+                               uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
+                               hipStream_t st)
+{
+    if (n_bins > PT_MAX_BINS)
+        return hipErrorInvalidValue;
+    const uint4 *in4 = reinterpret_cast<const uint4 *>(in);
+    uint4 *out4 = reinterpret_cast<uint4 *>(out);
+    if (level1)
+        part_scatter_kernel<true><<<max_tiles, PT_THREADS, 0, st>>>(hashes, in4, seg_start, tile_start, n_seg, shift,
+                                                                    n_bins, kw, len, cursor, out4);
+    else
+        part_scatter_kernel<false><<<max_tiles, PT_THREADS, 0, st>>>(hashes, in4, seg_start, tile_start, n_seg, shift,
+                                                                     n_bins, kw, len, cursor, out4);
+    return hipGetLastError();
+}
+
+uint32_t part_tile_size() { return PT_TILE; }
+
+hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
+                                uint32_t *cursor, hipStream_t st)
+{
+    bucket_starts_kernel<<<(n_buckets + 1 + 255) / 256, 256, 0, st>>>(hist_incl, n_buckets, bucket_start, cursor);
+    return hipGetLastError();
+}
+
+hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, uint32_t n_buckets,
+                                const uint32_t *weights, uint32_t *tmp_rec, uint32_t *tmp_count, uint32_t *tmp_first,
+                                uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st)
+{
+    bucket_dedupe_kernel<<<n_buckets, DD_THREADS, 0, st>>>(reinterpret_cast<const uint4 *>(part), bucket_start, weights,
+                                                           reinterpret_cast<uint4 *>(tmp_rec), tmp_count, tmp_first,
+                                                           bucket_unique, overflow);
+    return hipGetLastError();
+}
+
+hipError_t launch_bucket_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
+                                 const uint32_t *tmp_rec, const uint32_t *tmp_count, const uint32_t *tmp_first,
+                                 const uint64_t *read_ids, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
+                                 hipStream_t st)
+{
+    const uint64_t threads = (uint64_t)n_buckets * 64;
+    bucket_compact_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
+        bucket_start, unique_incl, n_buckets, reinterpret_cast<const uint4 *>(tmp_rec), tmp_count, tmp_first, read_ids,
+        reinterpret_cast<uint4 *>(urecs), ucounts, ufirst);
+    return hipGetLastError();
+}
+
+}  // namespace fqd

@@ -187,6 +187,26 @@ hipError_t launch_write_unique(const uint32_t *run_start, const uint32_t *run_we
 hipError_t launch_sum_u32(const uint32_t *in, uint64_t n, unsigned long long *out, hipStream_t st);
 hipError_t launch_max_u64(const uint64_t *in, uint64_t n, unsigned long long *out, hipStream_t st);
 
+// collapse_lds.hip -- sort-free collapse for one-uint4 records
+hipError_t launch_tile_starts(const uint32_t *seg_start, uint32_t n_seg, uint32_t *tile_start, hipStream_t st);
+hipError_t launch_part_hist(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
+                            const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
+                            uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *hist, hipStream_t st);
+hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
+                               const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
+                               uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
+                               hipStream_t st);
+uint32_t part_tile_size();
+hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
+                                uint32_t *cursor, hipStream_t st);
+hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, uint32_t n_buckets,
+                                const uint32_t *weights, uint32_t *tmp_rec, uint32_t *tmp_count, uint32_t *tmp_first,
+                                uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);
+hipError_t launch_bucket_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
+                                 const uint32_t *tmp_rec, const uint32_t *tmp_count, const uint32_t *tmp_first,
+                                 const uint64_t *read_ids, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
+                                 hipStream_t st);
+
 // edges.hip
 hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh,
                                  uint32_t nseg, uint32_t *seg_hashes /* nseg * U */, hipStream_t st);

@@ -230,6 +230,38 @@ def test_hash_collisions_do_not_merge_keys(F, oracle, monkeypatch):
     assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
 
 
+@pytest.mark.parametrize("path,bucket_bits", [("lds", None), ("sort", None), ("lds", "1")])
+def test_collapse_paths_agree_with_oracle(F, oracle, monkeypatch, path, bucket_bits):
+    """Both collapse implementations (LDS bucket dedupe / sort + verify), and the overflow
+    fallback from the first to the second, give the oracle's answer: weights incl. 0, caller
+    read ids, one key with 150 k copies, many singletons."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_COLLAPSE", path)
+    if bucket_bits:
+        monkeypatch.setenv("FQD_LDS_BUCKET_BITS", bucket_bits)
+    rng = np.random.default_rng(12)
+    L = 32
+    a = synth_keys(120_000, L, L, 77, sub_rate=2e-3, n_rate=2e-4)
+    heavy = np.tile(np.frombuffer(b"ACGTTGCAACGTTGCAACGTTGCAACGTTGCA", dtype=np.uint8), (150_000, 1))
+    singles = np.frombuffer(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=80_000 * L).tobytes(),
+                            dtype=np.uint8).reshape(-1, L)
+    keys = np.concatenate([a, heavy, singles])
+    keys = keys[rng.permutation(len(keys))].reshape(-1)
+    n = len(keys) // L
+    w = rng.choice(np.array([0, 1, 1, 1, 3], dtype=np.uint32), size=n)
+    ctx = F.Context(0)
+    got = F.cluster_keys(keys, key_len=L, weights=w, max_distance=1, method="directional", context=ctx)
+    want = oracle.dedup(keys, fixed_offsets(n, L), w, max_distance=1, method="directional")
+    assert got.n_unique == want["n_unique"] and got.n_clusters == want["n_clusters"]
+    assert got.n_counted == int(w.sum())
+    assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+    ids = (np.arange(n, dtype=np.uint64) * 3 + 11)
+    got2 = F.cluster_keys(keys, key_len=L, weights=w, read_ids=ids, max_distance=1, method="adjacency",
+                          context=ctx)
+    want2 = oracle.dedup(keys, fixed_offsets(n, L), w, max_distance=1, method="adjacency")
+    assert np.array_equal(got2.kept_read_ids, want2["kept_read_ids"] * 3 + 11)
+
+
 def test_edge_cases(F, ctx):
     empty = F.cluster_keys(np.zeros(0, np.uint8), np.zeros(1, np.uint64), context=ctx)
     assert (empty.n_reads, empty.n_unique, empty.n_clusters, empty.n_kept) == (0, 0, 0, 0)
