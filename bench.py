@@ -181,15 +181,18 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    stage_sum, pairs_ms, pairs_launches = {}, 0.0, 0
+    stage_sum, kern = {}, {}
+    ctx.kernel_times(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
-        ms, launches = ctx.stage_times()
+        ms, _launches = ctx.stage_times()
         for k, v in ms.items():
             stage_sum[k] = stage_sum.get(k, 0.0) + v
-        pairs_ms += ms["pairs_kernel"]
-        pairs_launches += launches["pairs_kernel"]
+        for k, (kms, kl) in ctx.kernel_times(reset=True).items():   # HIP events on the context's stream
+            a = kern.setdefault(k, [0.0, 0])
+            a[0] += kms
+            a[1] += kl
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -200,32 +203,51 @@ def main():
     value = n_total * args.steps / elapsed
 
     # ---- roofline of the dominant hand-written kernel (DESIGN.md "kernels") --------
-    # Both candidates are timed live with HIP events on the context's stream
-    # (fqd_stage_times); the one with the longer average launch is reported as `roofline`.
+    # Every hand-written kernel of the step is timed live with HIP events on the context's stream
+    # (fqd_kernel_times). `roofline` is the one with the longest average launch; `kernels` lists all.
     sh = ctx.shape()
     st = ctx.edge_stats()          # of the last step: all d+1 launches
     nseg = wl["d"] + 1
     b_key = sh.planes * sh.words * 4
-    # bucket pair kernel, ONE launch: (bucket hash, uid) of every unique key, the record of
-    # every key that sits in a bucket of >= 2 (read once), 8 B per emitted edge
-    pairs_bytes = res.n_unique * 8 + st["keys_gathered"] / nseg * b_key + st["edges"] / nseg * 8
-    pairs_avg = pairs_ms / max(pairs_launches, 1)
-    # pack kernel, one launch: every key byte in, one record + one 32-bit hash out
-    pack_bytes = n * (L + b_key + 4)
-    pack_avg = stage_sum.get("pack_kernel", 0.0) / args.steps
-
-    def roof(name, nbytes, avg_ms, launches):
-        gbs = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_launch": int(nbytes),
-                "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
-
-    cands = [roof("pack_kernel", pack_bytes, pack_avg, args.steps),
-             roof("bucket_pairs_kernel", pairs_bytes, pairs_avg, pairs_launches)]
-    cands.sort(key=lambda r: -r["avg_launch_ms"])
-    roofline, roofline_other = cands[0], cands[1]
+    U, E = res.n_unique, res.n_edges
+    n_in = n if world == 1 else U  # reads this rank collapses (multi-GPU: about n, after the exchange)
+    alg = {  # algorithmic bytes of ONE launch
+        "pack_kernel": n * (L + b_key + 4),                          # key bytes in, record + hash out
+        "part_hist_kernel<1>": n_in * 4,                             # hash
+        "part_scatter_kernel<1>": n_in * (4 + 16 + 16),              # hash + record in, record out
+        "part_hist_kernel<2>": n_in * 16,
+        "part_scatter_kernel<2>": n_in * (16 + 16),
+        "bucket_dedupe_kernel": n_in * 16 + U * 24,                  # reads in, unique (record, count, first) out
+        "bucket_compact_kernel": U * (24 + 28),
+        "head_flags_kernel": n_in * (4 + 4 + b_key + 4),             # (hash, id), the record once, a flag
+        "write_unique_kernel": U * (2 * b_key + 16),
+        "segment_hashes_kernel": U * (b_key + 4 * nseg),
+        # (bucket hash, uid) of every unique key, the record of every key in a bucket >= 2, 8 B per edge
+        "bucket_pairs_kernel": U * 8 + st["keys_gathered"] / nseg * b_key + st["edges"] / nseg * 8,
+        "uf_union_kernel": E * 8,
+        "uf_flatten_kernel": U * 8,
+        "dissect_round_kernel": E * 8,
+    }
+    rocprof_name = {"part_hist_kernel<1>": "part_hist_kernel<true>", "part_hist_kernel<2>": "part_hist_kernel<false>",
+                    "part_scatter_kernel<1>": "part_scatter_kernel<true>",
+                    "part_scatter_kernel<2>": "part_scatter_kernel<false>",
+                    "dissect_round_kernel": "_round_kernel" if wl["method"] == "directional" else "adjacency_edges"}
+    table = []
+    for name, (kms, kl) in kern.items():
+        if not kl:
+            continue
+        avg = kms / kl
+        gbs = alg[name] / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        table.append({"kernel": name, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                      "alg_bytes_per_launch": int(alg[name]), "avg_launch_ms": round(avg, 4),
+                      "launches_timed": kl, "ms_per_step": round(kms / args.steps, 4)})
+    table.sort(key=lambda r: -r["avg_launch_ms"])
+    roofline = dict(table[0])
+    kernels = [{k: r[k] for k in ("kernel", "avg_launch_ms", "ms_per_step", "achieved", "frac")} for r in table]
     if rank == 0 and world == 1 and not args.no_pmc:
-        traffic, how = pmc_traffic(roofline["kernel"], args.workload, args.reads_per_gpu)
+        traffic, how = pmc_traffic(rocprof_name.get(roofline["kernel"], roofline["kernel"]), args.workload,
+                                   args.reads_per_gpu)
         roofline["traffic"] = None if traffic is None else int(traffic)
         roofline["traffic_source"] = how
 
@@ -258,7 +280,7 @@ def main():
         "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_sum.items()},
         "record_bytes": sh.stride_words * 4, "planes": sh.planes,
         "roofline": roofline,
-        "roofline_other": roofline_other,
+        "kernels": kernels,
         "host_input": pcie,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -43,7 +43,7 @@ EXPORTS = [
     "fqd_collapse", "fqd_find_edges", "fqd_components", "fqd_dissect", "fqd_cluster",
     "fqd_set_id_window", "fqd_get_kept_count", "fqd_get_kept_read_ids", "fqd_get_unique_table", "fqd_export_packed", "fqd_export_packed_by_owner", "fqd_import_packed",
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
-    "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_edge_stats", "fqd_synth_keys",
+    "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_edge_stats", "fqd_synth_keys",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -101,6 +101,7 @@ def load() -> C.CDLL:
     L.fqd_quality_filter.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp,
                                      u64p, C.c_int]
     L.fqd_stage_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.fqd_kernel_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_int]
     L.fqd_edge_stats.argtypes = [vp, u64p, u64p, u64p]
     L.fqd_synth_keys.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                  C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]
@@ -379,6 +380,18 @@ class Context:
         names = ["pack", "collapse", "edges", "components", "dissect", "pairs_kernel", "pack_kernel"]
         return ({k: float(ms[i]) for i, k in enumerate(names)},
                 {k: int(ln[i]) for i, k in enumerate(names)})
+
+    KERNELS = ["pack_kernel", "part_hist_kernel<1>", "part_scatter_kernel<1>", "part_hist_kernel<2>",
+               "part_scatter_kernel<2>", "bucket_dedupe_kernel", "bucket_compact_kernel", "head_flags_kernel",
+               "write_unique_kernel", "segment_hashes_kernel", "bucket_pairs_kernel", "uf_union_kernel",
+               "uf_flatten_kernel", "dissect_round_kernel"]
+
+    def kernel_times(self, reset: bool = True):
+        """{kernel: (ms summed over launches, launches)} since the last reset."""
+        ms = (C.c_float * 16)()
+        ln = (C.c_uint32 * 16)()
+        self._ck(self._L.fqd_kernel_times(self._h, ms, ln, int(reset)))
+        return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(self.KERNELS)}
 
     def edge_stats(self):
         a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)

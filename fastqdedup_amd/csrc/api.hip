@@ -76,7 +76,7 @@ struct fqd_ctx {
     DevBuf in_weights, in_read_ids, hs_sorted, ids, ids_sorted, flags, run_idx, run_start, run_weight, live_flag,
         live_idx, collision_runs;
     DevBuf urecs, ulens, ucounts, ufirst;
-    DevBuf ld_small, ld_part2;
+    DevBuf ld_small, ld_part2, ld_matrix, ld_matrix_incl;
     DevBuf ld_hist, ld_hist_incl, ld_start, ld_cursor, ld_part, ld_tmp_rec, ld_tmp_count, ld_tmp_first, ld_unique,
         ld_unique_incl;
     int collapse_path = 0;  // 1: LDS bucket dedupe, 2: sort + verify (last fqd_collapse)
@@ -97,6 +97,13 @@ struct fqd_ctx {
     DevBuf tmp, stage_a, stage_b, stage_c, stage_d;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+    // per-kernel timing (fqd_kernel_times): a pool of event pairs, drained at every stage end
+    static constexpr int KPOOL = 96;
+    hipEvent_t kev[2 * KPOOL] = {nullptr};
+    int kslot[KPOOL] = {0};
+    int kused = 0;
+    float kms[FQD_K_COUNT] = {0};
+    uint32_t klaunches[FQD_K_COUNT] = {0};
     float ms[FQD_T_COUNT] = {0};
     uint32_t launches[FQD_T_COUNT] = {0};
 };
@@ -196,6 +203,8 @@ int zero_ctr64(fqd_ctx *c, int idx, int count = 1)
     return FQD_OK;
 }
 
+void ktime_collect(fqd_ctx *c);
+
 struct StageTimer {
     fqd_ctx *c;
     int slot;
@@ -208,8 +217,49 @@ struct StageTimer {
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess)
             c->ms[slot] = ms;
         c->launches[slot] = 1;
+        ktime_collect(c);
     }
 };
+
+int ktime_begin(fqd_ctx *c, int slot)
+{
+    if (c->kused >= fqd_ctx::KPOOL)
+        return -1;
+    const int i = c->kused++;
+    c->kslot[i] = slot;
+    (void)hipEventRecord(c->kev[2 * i], c->st);
+    return i;
+}
+
+void ktime_end(fqd_ctx *c, int i)
+{
+    if (i >= 0)
+        (void)hipEventRecord(c->kev[2 * i + 1], c->st);
+}
+
+// after the stage's final synchronisation: fold the recorded pairs into the per-kernel sums
+void ktime_collect(fqd_ctx *c)
+{
+    if (!c->kused)
+        return;
+    (void)hipStreamSynchronize(c->st);
+    for (int i = 0; i < c->kused; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->kev[2 * i], c->kev[2 * i + 1]) == hipSuccess) {
+            c->kms[c->kslot[i]] += ms;
+            c->klaunches[c->kslot[i]] += 1;
+        }
+    }
+    c->kused = 0;
+}
+
+// time one kernel launch with HIP events on the context's stream
+#define KTIME(c, slot, call)                 \
+    do {                                     \
+        const int kt_ = ktime_begin((c), (slot)); \
+        HIP_TRY((c), call);                  \
+        ktime_end((c), kt_);                 \
+    } while (0)
 
 void build_alphabet(fqd_ctx *c, const uint8_t *present128, uint8_t *lut256)
 {
@@ -348,15 +398,17 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, const uint64_t *d_ids, bool *d
     const uint32_t seg1_h[2] = {0u, (uint32_t)n}, tiles1_h[2] = {0u, tiles1};
     HIP_TRY(c, hipMemcpyAsync(seg1, seg1_h, 8, hipMemcpyHostToDevice, c->st));
     HIP_TRY(c, hipMemcpyAsync(tiles1_d, tiles1_h, 8, hipMemcpyHostToDevice, c->st));
-    // ---- level 1: 2^B1 parts by the top B1 hash bits
-    HIP_TRY(c, hipMemsetAsync(c->ld_hist.p, 0, (size_t)bins1 * 4, c->st));
-    HIP_TRY(c, fqd::launch_part_hist(true, c->hashes.as<uint32_t>(), c->recs.as<uint32_t>(), seg1, tiles1_d, 1, tiles1,
-                                     32 - B1, bins1, kw, sh.max_len, c->ld_hist.as<uint32_t>(), c->st));
-    FQD_TRY(scan_u32(c, c->ld_hist.as<uint32_t>(), c->ld_hist_incl.as<uint32_t>(), bins1));
-    HIP_TRY(c, fqd::launch_bucket_starts(c->ld_hist_incl.as<uint32_t>(), bins1, start1, c->ld_cursor.as<uint32_t>(),
-                                         c->st));
-    HIP_TRY(c, fqd::launch_part_scatter(true, c->hashes.as<uint32_t>(), c->recs.as<uint32_t>(), seg1, tiles1_d, 1,
-                                        tiles1, 32 - B1, bins1, kw, sh.max_len, c->ld_cursor.as<uint32_t>(),
+    // ---- level 1: 2^B1 parts by the top B1 hash bits. Counts go to a (bin x tile) matrix whose
+    // scan gives every (tile, bin) its output position (no atomics on 2^B1 hot counters).
+    const size_t matrix = (size_t)bins1 * tiles1;
+    HIP_TRY(c, c->ld_matrix.reserve(matrix * 4 + 16));
+    HIP_TRY(c, c->ld_matrix_incl.reserve(matrix * 4 + 16));
+    KTIME(c, FQD_K_PART_HIST1, fqd::launch_part_hist(true, c->hashes.as<uint32_t>(), c->recs.as<uint32_t>(), seg1, tiles1_d, 1, tiles1,
+                                     32 - B1, bins1, kw, sh.max_len, c->ld_matrix.as<uint32_t>(), c->st));
+    FQD_TRY(scan_u32(c, c->ld_matrix.as<uint32_t>(), c->ld_matrix_incl.as<uint32_t>(), matrix));
+    HIP_TRY(c, fqd::launch_matrix_starts(c->ld_matrix_incl.as<uint32_t>(), bins1, tiles1, start1, c->st));
+    KTIME(c, FQD_K_PART_SCATTER1, fqd::launch_part_scatter(true, c->hashes.as<uint32_t>(), c->recs.as<uint32_t>(), seg1, tiles1_d, 1,
+                                        tiles1, 32 - B1, bins1, kw, sh.max_len, c->ld_matrix_incl.as<uint32_t>(),
                                         c->ld_part.as<uint32_t>(), c->st));
     const uint32_t *parted = c->ld_part.as<uint32_t>();
     if (B2 == 0) {
@@ -365,18 +417,18 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, const uint64_t *d_ids, bool *d
         // ---- level 2: every part into 2^B2 buckets by the next B2 hash bits
         HIP_TRY(c, fqd::launch_tile_starts(start1, bins1, tiles2_d, c->st));
         HIP_TRY(c, hipMemsetAsync(c->ld_hist.p, 0, (size_t)n_buckets * 4, c->st));
-        HIP_TRY(c, fqd::launch_part_hist(false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1, max_tiles2,
+        KTIME(c, FQD_K_PART_HIST2, fqd::launch_part_hist(false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1, max_tiles2,
                                          32 - B, bins2, kw, sh.max_len, c->ld_hist.as<uint32_t>(), c->st));
         FQD_TRY(scan_u32(c, c->ld_hist.as<uint32_t>(), c->ld_hist_incl.as<uint32_t>(), n_buckets));
         HIP_TRY(c, fqd::launch_bucket_starts(c->ld_hist_incl.as<uint32_t>(), n_buckets, c->ld_start.as<uint32_t>(),
                                              c->ld_cursor.as<uint32_t>(), c->st));
-        HIP_TRY(c, fqd::launch_part_scatter(false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1,
+        KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1,
                                             max_tiles2, 32 - B, bins2, kw, sh.max_len, c->ld_cursor.as<uint32_t>(),
                                             c->ld_part2.as<uint32_t>(), c->st));
         parted = c->ld_part2.as<uint32_t>();
     }
     FQD_TRY(zero_ctr32(c, C_BAD));
-    HIP_TRY(c, fqd::launch_bucket_dedupe(parted, c->ld_start.as<uint32_t>(), n_buckets, d_w,
+    KTIME(c, FQD_K_DEDUPE, fqd::launch_bucket_dedupe(parted, c->ld_start.as<uint32_t>(), n_buckets, d_w,
                                          c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(),
                                          c->ld_tmp_first.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
                                          c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
@@ -392,7 +444,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, const uint64_t *d_ids, bool *d
     HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
     HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
     HIP_TRY(c, c->ufirst.reserve(U * 8 + 16));
-    HIP_TRY(c, fqd::launch_bucket_compact(c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets,
+    KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_compact(c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets,
                                           c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(),
                                           c->ld_tmp_first.as<uint32_t>(), d_ids, c->urecs.as<uint32_t>(),
                                           c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st));
@@ -522,6 +574,7 @@ int fqd_create(int device, fqd_ctx **out)
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&c->st) == hipSuccess &&
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
               hipEventCreate(&c->evk0) == hipSuccess && hipEventCreate(&c->evk1) == hipSuccess &&
+              [&] { for (hipEvent_t &e : c->kev) if (hipEventCreate(&e) != hipSuccess) return false; return true; }() &&
               c->d_ctr32.reserve(C_N32 * 4) == hipSuccess && c->d_ctr64.reserve(C64_N * 8) == hipSuccess &&
               c->d_lut.reserve(256) == hipSuccess &&
               c->d_stats.reserve(FQD_STAT_SLOTS * sizeof(fqd::PairStats)) == hipSuccess;
@@ -545,7 +598,7 @@ void fqd_destroy(fqd_ctx *c)
                       &c->lens, &c->hashes, &c->in_weights, &c->in_read_ids, &c->hs_sorted, &c->ids, &c->ids_sorted,
                       &c->flags, &c->run_idx, &c->run_start, &c->run_weight, &c->live_flag, &c->live_idx,
                       &c->collision_runs, &c->urecs, &c->ulens, &c->ucounts, &c->ufirst, &c->ld_hist, &c->ld_hist_incl, &c->ld_start,
-                      &c->ld_cursor, &c->ld_part, &c->ld_part2, &c->ld_small, &c->ld_tmp_rec, &c->ld_tmp_count, &c->ld_tmp_first, &c->ld_unique,
+                      &c->ld_cursor, &c->ld_part, &c->ld_part2, &c->ld_small, &c->ld_matrix, &c->ld_matrix_incl, &c->ld_tmp_rec, &c->ld_tmp_count, &c->ld_tmp_first, &c->ld_unique,
                       &c->ld_unique_incl, &c->seg_hashes,
                       &c->sorted_hash, &c->sorted_uid, &c->uid_iota, &c->edges, &c->sel_hash, &c->sel_uid, &c->q_table, &c->q_pass, &c->q_means, &c->q_bytes, &c->q_offsets,
                       &c->len_present, &c->ed_hash,
@@ -559,6 +612,8 @@ void fqd_destroy(fqd_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->evk0) (void)hipEventDestroy(c->evk0);
     if (c->evk1) (void)hipEventDestroy(c->evk1);
+    for (hipEvent_t e : c->kev)
+        if (e) (void)hipEventDestroy(e);
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
 }
@@ -682,7 +737,7 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
             HIP_TRY(c, c->lens.reserve((size_t)n * 4 + 16));
         FQD_TRY(zero_ctr32(c, C_BAD));
         (void)hipEventRecord(c->evk0, c->st);
-        HIP_TRY(c, fqd::launch_pack(d_bytes, n_bytes, d_off, n, fixed_len, sh, c->d_lut.as<uint8_t>(), lut,
+        KTIME(c, FQD_K_PACK, fqd::launch_pack(d_bytes, n_bytes, d_off, n, fixed_len, sh, c->d_lut.as<uint8_t>(), lut,
                                     c->recs.as<uint32_t>(), sh.ragged ? c->lens.as<uint32_t>() : nullptr,
                                     c->hashes.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
         (void)hipEventRecord(c->evk1, c->st);
@@ -770,7 +825,7 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
     for (;;) {
         HIP_TRY(c, c->collision_runs.reserve((size_t)cap * 4));
         FQD_TRY(zero_ctr32(c, C_COLLISIONS));
-        HIP_TRY(c, fqd::launch_head_flags(c->hs_sorted.as<uint32_t>(), c->ids_sorted.as<uint32_t>(),
+        KTIME(c, FQD_K_HEAD_FLAGS, fqd::launch_head_flags(c->hs_sorted.as<uint32_t>(), c->ids_sorted.as<uint32_t>(),
                                           c->recs.as<uint32_t>(), c->lens.as<uint32_t>(), n, sh, mask,
                                           c->flags.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_COLLISIONS,
                                           c->collision_runs.as<uint32_t>(), cap, c->st));
@@ -813,7 +868,7 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
     HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
     HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
     HIP_TRY(c, c->ufirst.reserve(U * 8 + 16));
-    HIP_TRY(c, fqd::launch_write_unique(c->run_start.as<uint32_t>(), c->run_weight.as<uint32_t>(),
+    KTIME(c, FQD_K_WRITE_UNIQUE, fqd::launch_write_unique(c->run_start.as<uint32_t>(), c->run_weight.as<uint32_t>(),
                                         c->live_flag.as<uint32_t>(), c->live_idx.as<uint32_t>(), n_runs,
                                         c->ids_sorted.as<uint32_t>(), c->recs.as<uint32_t>(), c->lens.as<uint32_t>(),
                                         read_ids ? d_ids : nullptr, sh, c->urecs.as<uint32_t>(),
@@ -869,7 +924,7 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
         HIP_TRY(c, c->sorted_uid.reserve(U * 4 + 16));
         HIP_TRY(c, c->uid_iota.reserve(U * 4 + 16));
         HIP_TRY(c, fqd::launch_iota_u32(c->uid_iota.as<uint32_t>(), U, c->st));
-        HIP_TRY(c, fqd::launch_segment_hashes(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, sh, nseg,
+        KTIME(c, FQD_K_SEG_HASH, fqd::launch_segment_hashes(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, sh, nseg,
                                               c->seg_hashes.as<uint32_t>(), c->st));
         if (c->edge_cap < 1024 || !c->edges.p) {
             c->edge_cap = std::max<uint64_t>(1024, U);
@@ -901,7 +956,7 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
             }
             for (;;) {
                 (void)hipEventRecord(c->evk0, c->st);
-                HIP_TRY(c, fqd::launch_bucket_pairs(
+                KTIME(c, FQD_K_PAIRS, fqd::launch_bucket_pairs(
                                c->sorted_hash.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), m,
                                c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, s, nseg, 0, 1,
                                c->edges.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_EDGES, c->edge_cap,
@@ -962,8 +1017,8 @@ int fqd_components(fqd_ctx *c, uint64_t *n_clusters)
     HIP_TRY(c, c->labels.reserve(U * 4 + 16));
     FQD_TRY(zero_ctr64(c, C64_ROOTS));
     HIP_TRY(c, fqd::launch_uf_init(c->labels.as<uint32_t>(), U, c->st));
-    HIP_TRY(c, fqd::launch_uf_union(c->labels.as<uint32_t>(), c->edges.as<uint32_t>(), c->E, c->st));
-    HIP_TRY(c, fqd::launch_uf_flatten(c->labels.as<uint32_t>(), U, c->d_ctr64.as<unsigned long long>() + C64_ROOTS,
+    KTIME(c, FQD_K_UF_UNION, fqd::launch_uf_union(c->labels.as<uint32_t>(), c->edges.as<uint32_t>(), c->E, c->st));
+    KTIME(c, FQD_K_UF_FLATTEN, fqd::launch_uf_flatten(c->labels.as<uint32_t>(), U, c->d_ctr64.as<unsigned long long>() + C64_ROOTS,
                                       c->st));
     unsigned long long roots = 0;
     FQD_TRY(read_ctr64(c, C64_ROOTS, &roots));
@@ -1000,7 +1055,7 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
     } else if (method == FQD_METHOD_DIRECTIONAL) {
         for (uint64_t round = 0; E && round <= U; round++) {
             FQD_TRY(zero_ctr32(c, C_CHANGED));
-            HIP_TRY(c, fqd::launch_directional_round(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
+            KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_directional_round(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
                                                      c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh,
                                                      c->best.as<uint32_t>(), d_changed, c->st));
             uint32_t changed = 0;
@@ -1013,7 +1068,7 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
         HIP_TRY(c, hipMemsetAsync(c->blocked.p, 0, U * 4, c->st));
         for (uint64_t round = 1; round <= U + 1; round++) {
             FQD_TRY(zero_ctr32(c, C_CHANGED));
-            HIP_TRY(c, fqd::launch_adjacency_round(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
+            KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_adjacency_round(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
                                                    c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, U,
                                                    c->state.as<uint8_t>(), c->blocked.as<uint32_t>(), (uint32_t)round,
                                                    d_changed, c->st));
@@ -1438,6 +1493,20 @@ int fqd_stage_times(fqd_ctx *c, float *ms, uint32_t *launches)
         memcpy(ms, c->ms, sizeof c->ms);
     if (launches)
         memcpy(launches, c->launches, sizeof c->launches);
+    return FQD_OK;
+}
+
+int fqd_kernel_times(fqd_ctx *c, float *ms, uint32_t *launches, int reset)
+{
+    ktime_collect(c);
+    if (ms)
+        memcpy(ms, c->kms, sizeof c->kms);
+    if (launches)
+        memcpy(launches, c->klaunches, sizeof c->klaunches);
+    if (reset) {
+        memset(c->kms, 0, sizeof c->kms);
+        memset(c->klaunches, 0, sizeof c->klaunches);
+    }
     return FQD_OK;
 }
 

@@ -86,23 +86,44 @@ __global__ __launch_bounds__(PT_THREADS) void part_hist_kernel(const uint32_t *_
         return;
     for (uint32_t b = threadIdx.x; b < n_bins; b += PT_THREADS)
         s_hist[b] = 0;
-    __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += PT_THREADS) {
-        uint32_t h;
-        if (LEVEL1) {
-            h = hashes[i];
-        } else {
-            uint4 v;
-            h = load_item<false>(hashes, in, i, kw, len, v);
+    uint32_t h[PT_EPT];
+#pragma unroll
+    for (uint32_t e = 0; e < PT_EPT; e++) {   // all loads in flight before the first LDS atomic
+        const uint32_t i = lo + e * PT_THREADS + threadIdx.x;
+        h[e] = 0;
+        if (i < hi) {
+            if (LEVEL1) {
+                h[e] = hashes[i];
+            } else {
+                uint4 v;
+                h[e] = load_item<false>(hashes, in, i, kw, len, v);
+            }
         }
-        atomicAdd(&s_hist[(h >> shift) & (n_bins - 1)], 1u);
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < n_bins; b += PT_THREADS)
-        if (s_hist[b])
-            atomicAdd(&hist[seg * n_bins + b], s_hist[b]);
+#pragma unroll
+    for (uint32_t e = 0; e < PT_EPT; e++)
+        if (lo + e * PT_THREADS + threadIdx.x < hi)
+            atomicAdd(&s_hist[(h[e] >> shift) & (n_bins - 1)], 1u);
+    __syncthreads();
+    if (LEVEL1) {
+        // level 1 has ONE segment: thousands of tiles would hammer the same 2^B1 counters, so
+        // each tile stores its counts in a (bin x tile) matrix; one scan of the matrix in
+        // bin-major order then IS every (tile, bin)'s output position -- no atomics, and the
+        // level-1 placement is deterministic
+        const uint32_t n_tiles = tile_start[n_seg];
+        for (uint32_t b = threadIdx.x; b < n_bins; b += PT_THREADS)
+            hist[(size_t)b * n_tiles + blockIdx.x] = s_hist[b];
+    } else {
+        for (uint32_t b = threadIdx.x; b < n_bins; b += PT_THREADS)
+            if (s_hist[b])
+                atomicAdd(&hist[seg * n_bins + b], s_hist[b]);
+    }
 }
 
+// The tile is counting-sorted by bin in LDS before it leaves: every bin's share of the tile
+// goes out as ONE contiguous run of 16-byte stores (a lone 16-byte store costs a whole
+// 64-byte HBM burst), and the global cursor sees one atomic per (tile, bin).
 template <bool LEVEL1>
 __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const uint32_t *__restrict__ hashes,
                                                                   const uint4 *__restrict__ in,
@@ -113,35 +134,86 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const uint32_t
                                                                   uint32_t *__restrict__ cursor,
                                                                   uint4 *__restrict__ out)
 {
-    __shared__ uint32_t s_hist[PT_MAX_BINS];   // count per bin, then the bin's global base
+    __shared__ uint32_t s_hist[PT_MAX_BINS];   // tile count per bin
+    __shared__ uint32_t s_off[PT_MAX_BINS];    // first tile-local position of the bin
+    __shared__ uint32_t s_base[PT_MAX_BINS];   // global position of the bin's run, minus s_off
+    __shared__ uint32_t s_wave[PT_THREADS / 64];
+    __shared__ uint4 s_stage[PT_TILE];
+    __shared__ uint16_t s_stage_bin[PT_TILE];
     uint32_t seg, lo, hi;
     if (!tile_of_block(seg_start, tile_start, n_seg, seg, lo, hi))
         return;
-    for (uint32_t b = threadIdx.x; b < n_bins; b += PT_THREADS)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t b = tid; b < n_bins; b += PT_THREADS)
         s_hist[b] = 0;
-    __syncthreads();
     uint4 v[PT_EPT];
-    uint32_t bin[PT_EPT], rank[PT_EPT];
+    uint32_t h[PT_EPT], bin[PT_EPT], rank[PT_EPT];
 #pragma unroll
     for (uint32_t e = 0; e < PT_EPT; e++) {
-        const uint32_t i = lo + e * PT_THREADS + threadIdx.x;
+        const uint32_t i = lo + e * PT_THREADS + tid;
+        h[e] = 0;
+        if (i < hi)
+            h[e] = load_item<LEVEL1>(hashes, in, i, kw, len, v[e]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < PT_EPT; e++) {
         bin[e] = 0xFFFFFFFFu;
-        if (i < hi) {
-            const uint32_t h = load_item<LEVEL1>(hashes, in, i, kw, len, v[e]);
-            bin[e] = (h >> shift) & (n_bins - 1);
+        if (lo + e * PT_THREADS + tid < hi) {
+            bin[e] = (h[e] >> shift) & (n_bins - 1);
             rank[e] = atomicAdd(&s_hist[bin[e]], 1u);   // position inside the tile's share of the bin
         }
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < n_bins; b += PT_THREADS) {
-        const uint32_t c = s_hist[b];
-        s_hist[b] = c ? atomicAdd(&cursor[seg * n_bins + b], c) : 0u;  // ONE global atomic per (tile, bin)
+    // exclusive scan of the bin counts (each thread owns bpt consecutive bins) + global bases
+    const uint32_t bpt = (n_bins + PT_THREADS - 1) / PT_THREADS;
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < bpt; k++) {
+        const uint32_t b = tid * bpt + k;
+        mine += b < n_bins ? s_hist[b] : 0u;
+    }
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if ((int)lane >= o)
+            incl += up;
+    }
+    if (lane == 63)
+        s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (uint32_t wv = 0; wv < wave; wv++)
+        run += s_wave[wv];
+    for (uint32_t k = 0; k < bpt; k++) {
+        const uint32_t b = tid * bpt + k;
+        if (b < n_bins) {
+            const uint32_t c = s_hist[b];
+            s_off[b] = run;
+            uint32_t g;
+            if (LEVEL1)   // cursor = inclusive scan of the (bin x tile) count matrix
+                g = cursor[(size_t)b * tile_start[n_seg] + blockIdx.x] - c;
+            else          // ONE atomic per (tile, bin)
+                g = c ? atomicAdd(&cursor[seg * n_bins + b], c) : 0u;
+            s_base[b] = g - run;
+            run += c;
+        }
     }
     __syncthreads();
 #pragma unroll
     for (uint32_t e = 0; e < PT_EPT; e++)
-        if (bin[e] != 0xFFFFFFFFu)
-            out[s_hist[bin[e]] + rank[e]] = v[e];
+        if (bin[e] != 0xFFFFFFFFu) {
+            const uint32_t p = s_off[bin[e]] + rank[e];
+            s_stage[p] = v[e];
+            s_stage_bin[p] = (uint16_t)bin[e];
+        }
+    __syncthreads();
+    const uint32_t count = hi - lo;
+#pragma unroll
+    for (uint32_t e = 0; e < PT_EPT; e++) {
+        const uint32_t p = e * PT_THREADS + tid;
+        if (p < count)
+            out[s_base[s_stage_bin[p]] + p] = s_stage[p];   // consecutive p of one bin: consecutive addresses
+    }
 }
 
 // tile_start[] for segments given by seg_start[0..n_seg] (single block; n_seg <= 256)
@@ -302,6 +374,16 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(
     }
 }
 
+// level 1: part p starts where the scan of the (bin x tile) matrix stood before row p
+__global__ void matrix_starts_kernel(const uint32_t *__restrict__ matrix_incl, uint32_t n_bins, uint32_t n_tiles,
+                                     uint32_t *__restrict__ start)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_bins)
+        return;
+    start[b] = b ? matrix_incl[(size_t)b * n_tiles - 1] : 0u;
+}
+
 // bucket_start[b] = number of reads in buckets < b, from the inclusive scan of the histogram
 __global__ void bucket_starts_kernel(const uint32_t *__restrict__ hist_incl, uint32_t n_buckets,
                                      uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ cursor)
@@ -361,6 +443,13 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
 }
 
 uint32_t part_tile_size() { return PT_TILE; }
+
+hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
+                                hipStream_t st)
+{
+    matrix_starts_kernel<<<(n_bins + 1 + 255) / 256, 256, 0, st>>>(matrix_incl, n_bins, n_tiles, start);
+    return hipGetLastError();
+}
 
 hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
                                 uint32_t *cursor, hipStream_t st)

@@ -197,6 +197,8 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
                                hipStream_t st);
 uint32_t part_tile_size();
+hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
+                                hipStream_t st);
 hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
                                 uint32_t *cursor, hipStream_t st);
 hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, uint32_t n_buckets,

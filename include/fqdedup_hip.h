@@ -191,6 +191,25 @@ int fqd_quality_filter(fqd_ctx *ctx, const uint8_t *bytes, const uint64_t *offse
 /* HIP-event milliseconds of the last run of each stage, measured on the
  * context's own stream; launches[k] = kernel launches summed into ms[k]. */
 int fqd_stage_times(fqd_ctx *ctx, float *ms /* FQD_T_COUNT */, uint32_t *launches /* FQD_T_COUNT */);
+/* Per-kernel HIP-event time (ms, summed over launches) and launch counts of the hand-written
+ * kernels since the last reset, measured on the context's own stream. */
+#define FQD_K_PACK           0
+#define FQD_K_PART_HIST1     1
+#define FQD_K_PART_SCATTER1  2
+#define FQD_K_PART_HIST2     3
+#define FQD_K_PART_SCATTER2  4
+#define FQD_K_DEDUPE         5
+#define FQD_K_COMPACT        6
+#define FQD_K_HEAD_FLAGS     7
+#define FQD_K_WRITE_UNIQUE   8
+#define FQD_K_SEG_HASH       9
+#define FQD_K_PAIRS         10
+#define FQD_K_UF_UNION      11
+#define FQD_K_UF_FLATTEN    12
+#define FQD_K_DISSECT_ROUND 13
+#define FQD_K_COUNT         16
+int fqd_kernel_times(fqd_ctx *ctx, float *ms /* FQD_K_COUNT */, uint32_t *launches /* FQD_K_COUNT */,
+                     int reset);
 /* Bucket statistics of the last fqd_find_edges (for the roofline's unit count):
  * keys gathered by the pair kernel, pairs compared, edges emitted. */
 int fqd_edge_stats(fqd_ctx *ctx, uint64_t *keys_gathered, uint64_t *pairs_compared,
