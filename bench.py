@@ -210,17 +210,18 @@ def main():
     nseg = wl["d"] + 1
     b_key = sh.planes * sh.words * 4
     U, E = res.n_unique, res.n_edges
-    n_in = n if world == 1 else U  # reads this rank collapses (multi-GPU: about n, after the exchange)
+    n_in = n                # reads this rank collapses (multi-GPU: about n again after the all-to-all)
+    U_own = U // world      # unique keys this rank's collapse produces (multi-GPU: its owner share)
     alg = {  # algorithmic bytes of ONE launch
         "pack_kernel": n * (L + b_key + 4),                          # key bytes in, record + hash out
         "part_hist_kernel<1>": n_in * 4,                             # hash
         "part_scatter_kernel<1>": n_in * (4 + 16 + 16),              # hash + record in, record out
         "part_hist_kernel<2>": n_in * 16,
         "part_scatter_kernel<2>": n_in * (16 + 16),
-        "bucket_dedupe_kernel": n_in * 16 + U * 24,                  # reads in, unique (record, count, first) out
-        "bucket_compact_kernel": U * (24 + 28),
+        "bucket_dedupe_kernel": n_in * 16 + U_own * 24,                  # reads in, unique (record, count, first) out
+        "bucket_compact_kernel": U_own * (24 + 28),
         "head_flags_kernel": n_in * (4 + 4 + b_key + 4),             # (hash, id), the record once, a flag
-        "write_unique_kernel": U * (2 * b_key + 16),
+        "write_unique_kernel": U_own * (2 * b_key + 16),
         "segment_hashes_kernel": U * (b_key + 4 * nseg),
         # (bucket hash, uid) of every unique key, the record of every key in a bucket >= 2, 8 B per edge
         "bucket_pairs_kernel": U * 8 + st["keys_gathered"] / nseg * b_key + st["edges"] / nseg * 8,

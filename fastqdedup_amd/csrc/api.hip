@@ -372,7 +372,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, const uint64_t *d_ids, bool *d
     if (n < 32768 && !(force && !strcmp(force, "lds")))
         return FQD_OK;
     uint32_t B = 8;
-    while (B < 18 && (n >> B) > 400)
+    while (B < 18 && (n >> B) > 800)   // ~400-800 reads per bucket: 2x fewer workgroups than at 200-400, longer runs
         B++;
     if (const char *e = getenv("FQD_LDS_BUCKET_BITS"))  // tests: few buckets => table overflow => fallback
         B = (uint32_t)std::max(1, std::min(18, atoi(e)));
@@ -1053,11 +1053,15 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
                                              c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, U,
                                              c->best.as<uint32_t>(), c->st));
     } else if (method == FQD_METHOD_DIRECTIONAL) {
-        for (uint64_t round = 0; E && round <= U; round++) {
+        HIP_TRY(c, c->blocked.reserve(U * 4 + 16));   // here: round stamps of the nodes
+        if (E)
+            HIP_TRY(c, hipMemsetAsync(c->blocked.p, 0, U * 4, c->st));
+        for (uint64_t round = 1; E && round <= U + 1; round++) {
             FQD_TRY(zero_ctr32(c, C_CHANGED));
             KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_directional_round(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
                                                      c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh,
-                                                     c->best.as<uint32_t>(), d_changed, c->st));
+                                                     c->best.as<uint32_t>(), c->blocked.as<uint32_t>(), (uint32_t)round,
+                                                     d_changed, c->st));
             uint32_t changed = 0;
             FQD_TRY(read_ctr32(c, C_CHANGED, &changed));
             if (!changed)

@@ -265,7 +265,8 @@ hipError_t launch_highest_count(const uint32_t *labels, const uint32_t *ucounts,
                                 hipStream_t st);
 hipError_t launch_directional_round(const uint32_t *edges, uint64_t E, const uint32_t *ucounts,
                                     const uint32_t *urecs, const uint32_t *ulens, KeyShape sh,
-                                    uint32_t *best, uint32_t *changed, hipStream_t st);
+                                    uint32_t *best, uint32_t *stamp, uint32_t round, uint32_t *changed,
+                                    hipStream_t st);
 hipError_t launch_adjacency_round(const uint32_t *edges, uint64_t E, const uint32_t *ucounts,
                                   const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint64_t U,
                                   uint8_t *state, uint32_t *blocked, uint32_t round, uint32_t *changed,

@@ -138,20 +138,29 @@ __global__ void highest_count_kernel(const uint32_t *__restrict__ labels, const 
         raise_best(best, r, (uint32_t)v, ucounts, urecs, ulens, sh);
 }
 
+// One relaxation sweep over the edges. stamp[v] = last round in which best[v] rose; from the
+// second round on, an edge is revisited only if one of its ends rose in the previous round
+// (anything that rises during this round is stamped with it and revisited in the next).
 __global__ void directional_round_kernel(const uint32_t *__restrict__ edges, uint64_t E,
                                          const uint32_t *__restrict__ ucounts, const uint32_t *__restrict__ urecs,
                                          const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t *best,
-                                         uint32_t *changed)
+                                         uint32_t *stamp, uint32_t round, uint32_t *changed)
 {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool moved = false;
     if (e < E) {
         const uint32_t u = edges[2 * e], v = edges[2 * e + 1];
-        const long long cu = ucounts[u], cv = ucounts[v];
-        if (2 * cv - 1 <= cu)  // arc u -> v
-            moved |= raise_best(best, v, load_relaxed(&best[u]), ucounts, urecs, ulens, sh);
-        if (2 * cu - 1 <= cv)  // arc v -> u
-            moved |= raise_best(best, u, load_relaxed(&best[v]), ucounts, urecs, ulens, sh);
+        if (round == 1 || load_relaxed(&stamp[u]) + 1 == round || load_relaxed(&stamp[v]) + 1 == round) {
+            const long long cu = ucounts[u], cv = ucounts[v];
+            if (2 * cv - 1 <= cu && raise_best(best, v, load_relaxed(&best[u]), ucounts, urecs, ulens, sh)) {  // arc u -> v
+                stamp[v] = round;
+                moved = true;
+            }
+            if (2 * cu - 1 <= cv && raise_best(best, u, load_relaxed(&best[v]), ucounts, urecs, ulens, sh)) {  // arc v -> u
+                stamp[u] = round;
+                moved = true;
+            }
+        }
     }
     // one store per wave, not one per lane, on the round's single flag word
     if (__ballot(moved) && fqd_lane() == 0)
@@ -285,10 +294,11 @@ hipError_t launch_highest_count(const uint32_t *labels, const uint32_t *ucounts,
 
 hipError_t launch_directional_round(const uint32_t *edges, uint64_t E, const uint32_t *ucounts,
                                     const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t *best,
-                                    uint32_t *changed, hipStream_t st)
+                                    uint32_t *stamp, uint32_t round, uint32_t *changed, hipStream_t st)
 {
     if (E)
-        directional_round_kernel<<<grid_for(E), 256, 0, st>>>(edges, E, ucounts, urecs, ulens, sh, best, changed);
+        directional_round_kernel<<<grid_for(E), 256, 0, st>>>(edges, E, ucounts, urecs, ulens, sh, best, stamp, round,
+                                                              changed);
     return hipGetLastError();
 }
 
