@@ -295,6 +295,59 @@ def test_device_resident_input_and_synth_twin(F, ctx):
     assert np.array_equal(a.kept_read_ids, b.kept_read_ids)
 
 
+@pytest.mark.parametrize("edit,d", [(False, 1), (False, 2), (True, 2)])
+def test_bucket_shards_union_to_the_whole_search(F, oracle, edit, d):
+    """What rank r of a G-rank job does in stage 3 (search only the buckets with hash % G == r),
+    done here for r = 0..2 on one GPU: the union of the edge shards must give the oracle's result."""
+    import random
+    rng = random.Random(31)
+    if edit:
+        mols = ["".join(rng.choice("ACGT") for _ in range(rng.randint(18, 30))) for _ in range(500)]
+        keys = []
+        for _ in range(5000):
+            s = list(rng.choice(mols))
+            for _ in range(rng.choice([0, 1, 1, 2])):
+                pos = rng.randrange(len(s))
+                r = rng.random()
+                if r < 0.4:
+                    s[pos] = rng.choice("ACGTN")
+                elif r < 0.7 and len(s) > 2:
+                    del s[pos]
+                else:
+                    s.insert(pos, rng.choice("ACGT"))
+            keys.append("".join(s))
+        raw, off = _pack(keys)
+        key_len = 0
+    else:
+        from fastqdedup_amd.synth import fixed_offsets, synth_keys
+        n, key_len = 150_000, 36
+        raw = synth_keys(n, key_len, 8, 17, sub_rate=4e-3, n_rate=5e-4).reshape(-1)
+        off = fixed_offsets(n, key_len)
+    ctx = F.Context(0)
+    metric = 1 if edit else 0
+    ctx.pack_keys(raw, None if key_len else off, key_len)
+    nu = ctx.collapse()
+    shards = []
+    for r in range(3):
+        ne = ctx.find_edges(d, metric, r, 3)
+        e = np.empty((ne, 2), dtype=np.uint32)
+        ctx.export_edges(e)
+        shards.append(e)
+    whole = ctx.find_edges(d, metric, 0, 1)
+    union = np.concatenate(shards)
+    uniq = {(int(a), int(b)) for a, b in union}
+    assert len(uniq) == whole                      # nothing lost; Hamming shards are disjoint
+    if not edit:
+        assert len(union) == whole
+    ctx.import_edges(np.ascontiguousarray(union), len(union))
+    n_clusters = ctx.components()
+    n_kept = ctx.dissect(2)
+    kept = ctx.kept_read_ids(n_kept)
+    want = oracle.dedup(raw, off, max_distance=d, use_edit_distance=edit, method="directional")
+    assert nu == want["n_unique"] and n_clusters == want["n_clusters"]
+    assert np.array_equal(kept, want["kept_read_ids"])
+
+
 def test_sharded_path_on_rccl_world1(F, oracle):
     """The production multi-GPU code path (HipBackend + torch.distributed 'nccl' = RCCL) with a
     one-rank group: every collective, every export/import of the C ABI, against the oracle."""
