@@ -1070,12 +1070,13 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
     } else {
         HIP_TRY(c, c->blocked.reserve(U * 4 + 16));
         HIP_TRY(c, hipMemsetAsync(c->blocked.p, 0, U * 4, c->st));
+        // edges become (higher rank, lower rank); union-find and the other methods do not care
+        HIP_TRY(c, fqd::launch_orient_edges(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
+                                            c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, c->st));
         for (uint64_t round = 1; round <= U + 1; round++) {
             FQD_TRY(zero_ctr32(c, C_CHANGED));
-            KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_adjacency_round(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
-                                                   c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, U,
-                                                   c->state.as<uint8_t>(), c->blocked.as<uint32_t>(), (uint32_t)round,
-                                                   d_changed, c->st));
+            KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_adjacency_round(c->edges.as<uint32_t>(), E, U, c->state.as<uint8_t>(),
+                                                   c->blocked.as<uint32_t>(), (uint32_t)round, d_changed, c->st));
             uint32_t changed = 0;
             FQD_TRY(read_ctr32(c, C_CHANGED, &changed));
             if (!changed)

@@ -50,9 +50,10 @@ __global__ void iota_kernel(uint32_t *out, uint64_t n)
 }
 
 // A read opens a new run unless its hash AND its full record equal its predecessor's.
-// Every read of a multi-read hash run gathers its own record once; the predecessor's
-// record then comes from the lane below (__shfl_up), only lane 0 of a wave gathers
-// a second record. Reads whose hash is unique among their neighbours gather nothing.
+// Q = stride/4 lanes serve one read (one uint4 of its record each, so the gather of a record is
+// one coalesced request); a wave holds 64/Q reads. The predecessor's chunk comes from the lane
+// Q below (__shfl_up); only the first read of a wave fetches its predecessor's record itself.
+// Reads whose hash is unique among their neighbours gather nothing.
 __global__ __launch_bounds__(256) void head_flags_kernel(const uint32_t *__restrict__ hs, const uint32_t *__restrict__ ids,
                                                          const uint32_t *__restrict__ recs,
                                                          const uint32_t *__restrict__ lens, uint64_t n, KeyShape sh,
@@ -60,40 +61,42 @@ __global__ __launch_bounds__(256) void head_flags_kernel(const uint32_t *__restr
                                                          uint32_t *__restrict__ n_collision_runs,
                                                          uint32_t *__restrict__ collision_runs, uint32_t cap)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = i < n;
-    const uint32_t lane = fqd_lane();
+    const uint32_t Q = sh.stride / 4, rpw = 64u / Q, lane = fqd_lane();
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t rl = lane / Q, q = lane - rl * Q;
+    const uint64_t i = wave * rpw + rl;
+    const bool valid = rl < rpw && i < n;
     const uint32_t h = valid ? (hs[i] & hash_mask) : 0u;
     const uint32_t id = valid ? ids[i] : 0u;
     const bool same_prev = valid && i > 0 && (hs[i - 1] & hash_mask) == h;
     const bool same_next = valid && i + 1 < n && (hs[i + 1] & hash_mask) == h;
     const bool need = same_prev || same_next;
-    const bool fetch_prev = same_prev && lane == 0;   // the lane below is in another wave
+    const bool fetch_prev = same_prev && rl == 0;       // the read below lives in another wave
     const uint32_t prev_id = fetch_prev ? ids[i - 1] : 0u;
-    bool eq = true;
+    bool neq = false;
     if (sh.ragged) {
         const uint32_t mine = need ? lens[id] : 0u;
-        uint32_t prev = __shfl_up(mine, 1);
+        uint32_t prev = __shfl_up(mine, Q);
         if (fetch_prev)
             prev = lens[prev_id];
-        eq = mine == prev;
+        neq = mine != prev;
     }
-    const uint4 *src = reinterpret_cast<const uint4 *>(recs + (uint64_t)id * sh.stride);
-    const uint4 *psrc = reinterpret_cast<const uint4 *>(recs + (uint64_t)prev_id * sh.stride);
-    for (uint32_t q = 0; q < sh.stride / 4; q++) {
-        uint4 m = make_uint4(0, 0, 0, 0);
-        if (need)
-            m = src[q];
-        uint4 p;
-        p.x = __shfl_up(m.x, 1);
-        p.y = __shfl_up(m.y, 1);
-        p.z = __shfl_up(m.z, 1);
-        p.w = __shfl_up(m.w, 1);
-        if (fetch_prev)
-            p = psrc[q];
-        eq = eq && m.x == p.x && m.y == p.y && m.z == p.z && m.w == p.w;
-    }
-    if (!valid)
+    uint4 m = make_uint4(0, 0, 0, 0);
+    if (need)
+        m = reinterpret_cast<const uint4 *>(recs + (uint64_t)id * sh.stride)[q];
+    uint4 p;
+    p.x = __shfl_up(m.x, Q);
+    p.y = __shfl_up(m.y, Q);
+    p.z = __shfl_up(m.z, Q);
+    p.w = __shfl_up(m.w, Q);
+    if (fetch_prev)
+        p = reinterpret_cast<const uint4 *>(recs + (uint64_t)prev_id * sh.stride)[q];
+    neq = neq || m.x != p.x || m.y != p.y || m.z != p.z || m.w != p.w;
+    // a read differs from its predecessor when any of its Q lanes saw a difference
+    const unsigned long long diff = __ballot(same_prev && neq);
+    const unsigned long long group = Q >= 64 ? ~0ull : (((1ull << Q) - 1ull) << (rl * Q));
+    const bool eq = (diff & group) == 0;
+    if (!valid || q != 0)
         return;
     uint32_t head = 1;
     if (same_prev) {
@@ -255,9 +258,13 @@ hipError_t launch_head_flags(const uint32_t *hs, const uint32_t *ids, const uint
                              uint64_t n, KeyShape sh, uint32_t hash_mask, uint32_t *flags,
                              uint32_t *n_collision_runs, uint32_t *collision_runs, uint32_t cap, hipStream_t st)
 {
-    if (n)
-        head_flags_kernel<<<grid_for(n), 256, 0, st>>>(hs, ids, recs, lens, n, sh, hash_mask, flags,
-                                                       n_collision_runs, collision_runs, cap);
+    if (n) {
+        if (sh.stride / 4 > 64)
+            return hipErrorInvalidValue;
+        const uint64_t rpw = 64 / (sh.stride / 4), waves = (n + rpw - 1) / rpw;
+        head_flags_kernel<<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(hs, ids, recs, lens, n, sh, hash_mask, flags,
+                                                                     n_collision_runs, collision_runs, cap);
+    }
     return hipGetLastError();
 }
 

@@ -148,16 +148,18 @@ __global__ __launch_bounds__(256) void bucket_pairs_kernel(
             n_gathered++;
             if (sh.ragged)
                 len = ulens[uid];
-            if (USE_LDS) {
-                const uint4 *src = reinterpret_cast<const uint4 *>(my_rec);
-                for (uint32_t q = 0; q < stride / 4; q++) {
-                    const uint4 v = src[q];
-                    const uint32_t j = q * 4;
-                    if (j + 0 < KW) tile[(j + 0) * T + tid] = v.x;
-                    if (j + 1 < KW) tile[(j + 1) * T + tid] = v.y;
-                    if (j + 2 < KW) tile[(j + 2) * T + tid] = v.z;
-                    if (j + 3 < KW) tile[(j + 3) * T + tid] = v.w;
-                }
+        }
+        if (USE_LDS && multi) {
+            // only keys in a bucket of >= 2 (typically 10-40 %) fetch their record; a per-lane
+            // fetch beats a cooperative one here because the idle lanes have nothing to loop over
+            const uint4 *src = reinterpret_cast<const uint4 *>(my_rec);
+            for (uint32_t q = 0; q < stride / 4; q++) {
+                const uint4 v = src[q];
+                const uint32_t j = q * 4;
+                if (j + 0 < KW) tile[(j + 0) * T + tid] = v.x;
+                if (j + 1 < KW) tile[(j + 1) * T + tid] = v.y;
+                if (j + 2 < KW) tile[(j + 2) * T + tid] = v.z;
+                if (j + 3 < KW) tile[(j + 3) * T + tid] = v.w;
             }
         }
         s_len[tid] = len;

@@ -267,10 +267,10 @@ hipError_t launch_directional_round(const uint32_t *edges, uint64_t E, const uin
                                     const uint32_t *urecs, const uint32_t *ulens, KeyShape sh,
                                     uint32_t *best, uint32_t *stamp, uint32_t round, uint32_t *changed,
                                     hipStream_t st);
-hipError_t launch_adjacency_round(const uint32_t *edges, uint64_t E, const uint32_t *ucounts,
-                                  const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint64_t U,
-                                  uint8_t *state, uint32_t *blocked, uint32_t round, uint32_t *changed,
-                                  hipStream_t st);
+hipError_t launch_orient_edges(uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
+                               const uint32_t *ulens, KeyShape sh, hipStream_t st);
+hipError_t launch_adjacency_round(const uint32_t *edges, uint64_t E, uint64_t U, uint8_t *state, uint32_t *blocked,
+                                  uint32_t round, uint32_t *changed, hipStream_t st);
 hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t *best, const uint8_t *state,
                              const uint64_t *ufirst, uint64_t id_lo, uint64_t id_hi, uint64_t U, uint8_t *kept,
                              uint32_t *kept_u32, unsigned long long *n_kept_total, hipStream_t st);

@@ -167,33 +167,42 @@ __global__ void directional_round_kernel(const uint32_t *__restrict__ edges, uin
         *changed = 1;
 }
 
-// state: 0 undecided, 1 kept, 2 dropped. blocked[v] == round: v still has an
-// undecided neighbour of higher rank.
-__global__ void adjacency_edges_kernel(const uint32_t *__restrict__ edges, uint64_t E,
-                                       const uint32_t *__restrict__ ucounts, const uint32_t *__restrict__ urecs,
-                                       const uint32_t *__restrict__ ulens, KeyShape sh, uint8_t *state,
-                                       uint32_t *blocked, uint32_t round, uint32_t *changed)
+// Put the endpoint of higher rank first, once: the adjacency rounds then never compare keys.
+__global__ void orient_edges_kernel(uint32_t *__restrict__ edges, uint64_t E, const uint32_t *__restrict__ ucounts,
+                                    const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens,
+                                    KeyShape sh)
 {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E)
         return;
-    uint32_t hi = edges[2 * e], lo = edges[2 * e + 1];
-    if (state[lo] && state[hi])
-        return;
-    if (!rank_greater(hi, lo, ucounts, urecs, ulens, sh)) {
-        const uint32_t t = hi;
-        hi = lo;
-        lo = t;
+    const uint32_t a = edges[2 * e], b = edges[2 * e + 1];
+    if (a != b && !rank_greater(a, b, ucounts, urecs, ulens, sh)) {
+        edges[2 * e] = b;
+        edges[2 * e + 1] = a;
     }
-    if (state[lo])
-        return;
-    const uint8_t sh_hi = state[hi];
-    if (sh_hi == 1) {
-        state[lo] = 2;
+}
+
+// state: 0 undecided, 1 kept, 2 dropped. blocked[v] == round: v still has an
+// undecided neighbour of higher rank. Edges are (higher rank, lower rank).
+__global__ void adjacency_edges_kernel(const uint32_t *__restrict__ edges, uint64_t E, uint8_t *state,
+                                       uint32_t *blocked, uint32_t round, uint32_t *changed)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool moved = false;
+    if (e < E) {
+        const uint32_t hi = edges[2 * e], lo = edges[2 * e + 1];
+        if (hi != lo && state[lo] == 0) {
+            const uint8_t s_hi = state[hi];
+            if (s_hi == 1) {
+                state[lo] = 2;
+                moved = true;
+            } else if (s_hi == 0) {
+                blocked[lo] = round;
+            }
+        }
+    }
+    if (__ballot(moved) && fqd_lane() == 0)
         *changed = 1;
-    } else if (sh_hi == 0) {
-        blocked[lo] = round;
-    }
 }
 
 __global__ void adjacency_nodes_kernel(uint64_t U, uint8_t *state, const uint32_t *__restrict__ blocked,
@@ -302,13 +311,19 @@ hipError_t launch_directional_round(const uint32_t *edges, uint64_t E, const uin
     return hipGetLastError();
 }
 
-hipError_t launch_adjacency_round(const uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
-                                  const uint32_t *ulens, KeyShape sh, uint64_t U, uint8_t *state, uint32_t *blocked,
+hipError_t launch_orient_edges(uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
+                               const uint32_t *ulens, KeyShape sh, hipStream_t st)
+{
+    if (E)
+        orient_edges_kernel<<<grid_for(E), 256, 0, st>>>(edges, E, ucounts, urecs, ulens, sh);
+    return hipGetLastError();
+}
+
+hipError_t launch_adjacency_round(const uint32_t *edges, uint64_t E, uint64_t U, uint8_t *state, uint32_t *blocked,
                                   uint32_t round, uint32_t *changed, hipStream_t st)
 {
     if (E)
-        adjacency_edges_kernel<<<grid_for(E), 256, 0, st>>>(edges, E, ucounts, urecs, ulens, sh, state, blocked,
-                                                            round, changed);
+        adjacency_edges_kernel<<<grid_for(E), 256, 0, st>>>(edges, E, state, blocked, round, changed);
     if (U)
         adjacency_nodes_kernel<<<grid_for(U), 256, 0, st>>>(U, state, blocked, round, changed);
     return hipGetLastError();
