@@ -37,6 +37,10 @@ __global__ __launch_bounds__(256) void segment_hashes_kernel(const uint32_t *__r
         len = fqd_key_len(sh, ulens, u);
     }
     const uint32_t word[4] = {v.x, v.y, v.z, v.w};
+    uint32_t wi[4];   // 32-base word index of each of this lane's 4 record words
+#pragma unroll
+    for (uint32_t e = 0; e < 4; e++)
+        wi[e] = (q * 4 + e) / K;
     for (uint32_t s = 0; s < nseg; s++) {
         uint32_t lo, hi;
         fqd_segment(len, s, nseg, lo, hi);
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256) void segment_hashes_kernel(const uint32_t *__r
         for (uint32_t e = 0; e < 4; e++) {
             const uint32_t j = q * 4 + e;               // word index in the record
             if (j < KW) {
-                const uint32_t m = fqd_range_mask(j / K, lo, hi);
+                const uint32_t m = fqd_range_mask(wi[e], lo, hi);
                 if (m)
                     part += fqd_mix32((word[e] & m) + (j + 1u) * 0x9E3779B1u);
             }

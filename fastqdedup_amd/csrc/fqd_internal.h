@@ -122,8 +122,10 @@ __device__ __forceinline__ uint32_t fqd_range_mask(uint32_t w, uint32_t lo, uint
 // Segment s of d+1 for a key of len bases: [len*s/(d+1), len*(s+1)/(d+1))  
 __device__ __forceinline__ void fqd_segment(uint32_t len, uint32_t s, uint32_t nseg, uint32_t &lo, uint32_t &hi)
 {
-    lo = (uint32_t)(((uint64_t)len * s) / nseg);
-    hi = (uint32_t)(((uint64_t)len * (s + 1)) / nseg);
+    // 32-bit on purpose (a 64-bit divide is a long software routine): len <= ~150 k bases
+    // (pack tile limit) and nseg <= 65, so len * (s + 1) < 2^32
+    lo = len * s / nseg;
+    hi = len * (s + 1) / nseg;
 }
 
 __device__ __forceinline__ uint32_t fqd_lane() { return threadIdx.x & 63u; }
