@@ -262,6 +262,66 @@ def test_collapse_paths_agree_with_oracle(F, oracle, monkeypatch, path, bucket_b
     assert np.array_equal(got2.kept_read_ids, want2["kept_read_ids"] * 3 + 11)
 
 
+def test_random_small_inputs_sweep(F, ctx, oracle):
+    """600 tiny random jobs: alphabets of 1-6 symbols, key lengths 0-12 (ragged or fixed),
+    weights incl. 0, d 0-3, both metrics, all methods -- kept ids, cluster and unique counts."""
+    import random
+    rng = random.Random(2026)
+    for trial in range(600):
+        syms = rng.choice(["A", "AC", "ACG", "ACGT", "ACGTN", "ACGTNX", "acgt#-"])
+        lo, hi = rng.choice([(0, 4), (3, 3), (5, 9), (12, 12), (0, 12)])
+        n = rng.randint(1, 60)
+        pool = ["".join(rng.choice(syms) for _ in range(rng.randint(lo, hi))) for _ in range(rng.randint(1, 12))]
+        keys = []
+        for _ in range(n):
+            s = list(rng.choice(pool))
+            if s and rng.random() < 0.5:
+                s[rng.randrange(len(s))] = rng.choice(syms)
+            if rng.random() < 0.15 and lo != hi:
+                s = s[:-1] if s and rng.random() < 0.5 else s + [rng.choice(syms)]
+            keys.append("".join(s))
+        raw, off = _pack(keys)
+        w = np.array([rng.choice([0, 1, 1, 2, 5]) for _ in keys], dtype=np.uint32)
+        d, edit, m = rng.randint(0, 3), rng.random() < 0.5, rng.choice(METHODS)
+        got = F.cluster_keys(raw, off, weights=w, max_distance=d, use_edit_distance=edit, method=m, context=ctx)
+        want = oracle.dedup(raw, off, w, max_distance=d, use_edit_distance=edit, method=m)
+        ctxt = (trial, keys, w.tolist(), d, edit, m)
+        assert got.n_unique == want["n_unique"], ctxt
+        assert got.n_clusters == want["n_clusters"], ctxt
+        assert got.kept_read_ids.tolist() == want["kept_read_ids"].tolist(), ctxt
+
+
+def test_trie_interleaved_add_pop_matches_oracle_trie(F, oracle):
+    """The drop-in Trie against the oracle's trie (which equals the reference's call for call):
+    interleaved add_sequence / pop_cluster, both metrics; clusters compared as sets AND in
+    emission order (ascending seed in trie-alphabet order, longer key before its prefix)."""
+    import random
+    rng = random.Random(77)
+    for trial in range(60):
+        a, b = F.Trie("ACGTN"), oracle.Trie("ACGTN")
+        d, edit = rng.randint(0, 2), rng.random() < 0.5
+        pool = ["".join(rng.choice("ACGTN") for _ in range(rng.randint(2, 7))) for _ in range(10)]
+        for _ in range(rng.randint(1, 40)):
+            s = list(rng.choice(pool))
+            if rng.random() < 0.4:
+                s[rng.randrange(len(s))] = rng.choice("ACGT")
+            s = "".join(s)
+            a.add_sequence(s)
+            b.add_sequence(s)
+        assert a.number_of_sequences == b.number_of_sequences
+        while b.number_of_sequences:
+            ca, cb = a.pop_cluster(d, edit), b.pop_cluster(d, edit)
+            assert sorted(ca) == sorted(cb), (trial, d, edit)
+            assert ca[0] == cb[0]                       # same seed first
+            assert a.number_of_sequences == b.number_of_sequences
+            if rng.random() < 0.25:                     # add between pops: re-clustered on the device
+                s = "".join(rng.choice("ACGT") for _ in range(rng.randint(2, 7)))
+                a.add_sequence(s)
+                b.add_sequence(s)
+        with pytest.raises(LookupError):
+            a.pop_cluster(d, edit)
+
+
 def test_edge_cases(F, ctx):
     empty = F.cluster_keys(np.zeros(0, np.uint8), np.zeros(1, np.uint64), context=ctx)
     assert (empty.n_reads, empty.n_unique, empty.n_clusters, empty.n_kept) == (0, 0, 0, 0)
