@@ -18,7 +18,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -148,7 +147,6 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import fastqdedup_amd as F
-    from fastqdedup_amd import _lib
     from fastqdedup_amd.sharded import HipBackend, cluster_keys_sharded
 
     wl = dict(WORKLOADS[args.workload])

@@ -12,7 +12,7 @@ import datetime
 import logging
 import resource
 import time
-from typing import Callable, Dict, Iterator, List, Optional, Tuple
+from typing import Callable, Iterator, List, Optional, Tuple
 
 import numpy as np
 

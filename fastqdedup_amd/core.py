@@ -15,7 +15,6 @@ from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import _lib
 from ._lib import METHODS, METRIC_EDIT, METRIC_HAMMING, Context
 
 DEFAULT_MAX_DISTANCE = 1

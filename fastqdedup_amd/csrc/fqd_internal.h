@@ -61,16 +61,6 @@ __device__ __forceinline__ uint32_t fqd_hash_record(const uint32_t *rec, uint32_
 }
 
 // Mismatching positions of word w between records a and b (one bit per base).
-template <int K>
-__device__ __forceinline__ uint32_t fqd_diff_word(const uint32_t *a, const uint32_t *b, uint32_t w)
-{
-    uint32_t d = 0;
-#pragma unroll
-    for (int k = 0; k < K; k++)
-        d |= a[w * K + k] ^ b[w * K + k];
-    return d;
-}
-
 __device__ __forceinline__ uint32_t fqd_diff_word_dyn(const uint32_t *a, const uint32_t *b, uint32_t w,
                                                       uint32_t K)
 {
@@ -141,10 +131,6 @@ __device__ __forceinline__ uint64_t fqd_lanemask_lt()
 namespace fqd {
 
 // prims.hip -- rocPRIM device-wide primitives
-size_t sort_pairs_u64_u32_temp(uint64_t n, int begin_bit, int end_bit);
-hipError_t sort_pairs_u64_u32(void *tmp, size_t tmp_bytes, const uint64_t *kin, uint64_t *kout,
-                              const uint32_t *vin, uint32_t *vout, uint64_t n, int begin_bit,
-                              int end_bit, hipStream_t st);
 size_t sort_pairs_u32_u32_temp(uint64_t n, int begin_bit, int end_bit);
 hipError_t sort_pairs_u32_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout,
                               const uint32_t *vin, uint32_t *vout, uint64_t n, int begin_bit,

@@ -10,21 +10,6 @@
 
 namespace fqd {
 
-size_t sort_pairs_u64_u32_temp(uint64_t n, int begin_bit, int end_bit)
-{
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
-                                    (const uint32_t *)nullptr, (uint32_t *)nullptr, n, begin_bit, end_bit);
-    return bytes;
-}
-
-hipError_t sort_pairs_u64_u32(void *tmp, size_t tmp_bytes, const uint64_t *kin, uint64_t *kout,
-                              const uint32_t *vin, uint32_t *vout, uint64_t n, int begin_bit, int end_bit,
-                              hipStream_t st)
-{
-    return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);
-}
-
 size_t sort_pairs_u32_u32_temp(uint64_t n, int begin_bit, int end_bit)
 {
     size_t bytes = 0;

@@ -23,7 +23,6 @@ inject a numpy stand-in to exercise the exchange logic on CPU with gloo.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional
 
 import os
 import time

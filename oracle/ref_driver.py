@@ -15,7 +15,7 @@ Only bench.py's cpu_baseline leg and tests/ may import this.
 from __future__ import annotations
 
 import time
-from typing import Dict, Iterable, Iterator, List, Tuple
+from typing import Dict, Iterable, Iterator, List
 
 
 def make_dissectors(within_distance):

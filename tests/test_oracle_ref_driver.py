@@ -1,6 +1,5 @@
 """oracle/ref_driver.py (the CPU-baseline driver around the real reference
 extensions) against the golden vectors and against the C oracle. CPU only."""
-import numpy as np
 import pytest
 
 
