@@ -377,7 +377,7 @@ class Context:
         ms = (C.c_float * T_COUNT)()
         ln = (C.c_uint32 * T_COUNT)()
         self._ck(self._L.fqd_stage_times(self._h, ms, ln))
-        names = ["pack", "collapse", "edges", "components", "dissect", "pairs_kernel", "pack_kernel"]
+        names = ["pack", "collapse", "edges", "components", "dissect"]   # per kernel: kernel_times()
         return ({k: float(ms[i]) for i, k in enumerate(names)},
                 {k: int(ln[i]) for i, k in enumerate(names)})
 

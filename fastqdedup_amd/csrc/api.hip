@@ -936,58 +936,48 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
             HIP_TRY(c, c->sel_hash.reserve(U * 4 + 16));
             HIP_TRY(c, c->sel_uid.reserve(U * 4 + 16));
         }
-        for (uint32_t s = 0; s < nseg; s++) {
-            uint64_t m = U;  // entries this rank sorts and searches in this pass
-            if (n_shards > 1) {
-                // only this rank's buckets go through the sort and the pair kernel
-                FQD_TRY(zero_ctr64(c, C64_SUM));
-                HIP_TRY(c, fqd::launch_select_shard(c->seg_hashes.as<uint32_t>() + (size_t)s * U, U, shard, n_shards,
-                                                    c->sel_hash.as<uint32_t>(), c->sel_uid.as<uint32_t>(),
-                                                    c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
-                unsigned long long got = 0;
-                FQD_TRY(read_ctr64(c, C64_SUM, &got));
-                m = got;
-                FQD_TRY(sort_u32_pairs(c, c->sel_hash.as<uint32_t>(), c->sorted_hash.as<uint32_t>(),
-                                       c->sel_uid.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), m));
-            } else {
-                FQD_TRY(sort_u32_pairs(c, c->seg_hashes.as<uint32_t>() + (size_t)s * U,
-                                       c->sorted_hash.as<uint32_t>(), c->uid_iota.as<uint32_t>(),
-                                       c->sorted_uid.as<uint32_t>(), U));
-            }
-            for (;;) {
-                (void)hipEventRecord(c->evk0, c->st);
+        // All d+1 passes are queued without a host round trip; the edge count is read ONCE at the
+        // end. If the passes overflowed the edge buffer (the count still says how many edges there
+        // are), the buffer is grown to the known need and the whole search runs again.
+        for (int attempt = 0;; attempt++) {
+            for (uint32_t s = 0; s < nseg; s++) {
+                uint64_t m = U;  // entries this rank sorts and searches in this pass
+                if (n_shards > 1) {
+                    // only this rank's buckets go through the sort and the pair kernel
+                    FQD_TRY(zero_ctr64(c, C64_SUM));
+                    HIP_TRY(c, fqd::launch_select_shard(c->seg_hashes.as<uint32_t>() + (size_t)s * U, U, shard,
+                                                        n_shards, c->sel_hash.as<uint32_t>(),
+                                                        c->sel_uid.as<uint32_t>(),
+                                                        c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+                    unsigned long long got = 0;
+                    FQD_TRY(read_ctr64(c, C64_SUM, &got));
+                    m = got;
+                    FQD_TRY(sort_u32_pairs(c, c->sel_hash.as<uint32_t>(), c->sorted_hash.as<uint32_t>(),
+                                           c->sel_uid.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), m));
+                } else {
+                    FQD_TRY(sort_u32_pairs(c, c->seg_hashes.as<uint32_t>() + (size_t)s * U,
+                                           c->sorted_hash.as<uint32_t>(), c->uid_iota.as<uint32_t>(),
+                                           c->sorted_uid.as<uint32_t>(), U));
+                }
                 KTIME(c, FQD_K_PAIRS, fqd::launch_bucket_pairs(
                                c->sorted_hash.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), m,
                                c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, s, nseg, 0, 1,
                                c->edges.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_EDGES, c->edge_cap,
-                               c->d_stats.as<fqd::PairStats>(),
-                               c->st));
-                (void)hipEventRecord(c->evk1, c->st);
-                unsigned long long now = 0;
-                FQD_TRY(read_ctr64(c, C64_EDGES, &now));
-                float kms = 0;
-                if (hipEventElapsedTime(&kms, c->evk0, c->evk1) == hipSuccess) {
-                    c->ms[FQD_T_PAIRS_KERNEL] += kms;
-                    c->launches[FQD_T_PAIRS_KERNEL] += 1;
-                }
-                if (now <= c->edge_cap) {
-                    have = now;
-                    break;
-                }
-                // the pass overflowed the edge buffer: grow to the known need, keep the
-                // earlier passes' edges, redo this pass
-                DevBuf bigger;
-                HIP_TRY(c, bigger.reserve((size_t)(now + now / 2 + 1024) * 8));
-                if (have)
-                    HIP_TRY(c, hipMemcpyAsync(bigger.p, c->edges.p, (size_t)have * 8, hipMemcpyDeviceToDevice, c->st));
-                HIP_TRY(c, hipStreamSynchronize(c->st));
-                c->edges.release();
-                c->edges = bigger;
-                c->edge_cap = c->edges.cap / 8;
-                HIP_TRY(c, hipMemcpyAsync(c->d_ctr64.as<unsigned long long>() + C64_EDGES, &have, 8,
-                                          hipMemcpyHostToDevice, c->st));
-                HIP_TRY(c, hipStreamSynchronize(c->st));
+                               c->d_stats.as<fqd::PairStats>(), c->st));
             }
+            unsigned long long now = 0;
+            FQD_TRY(read_ctr64(c, C64_EDGES, &now));
+            if (now <= c->edge_cap) {
+                have = now;
+                break;
+            }
+            if (attempt > 2)
+                return fail(c, FQD_E_RUNTIME, "edge buffer kept overflowing");
+            c->edges.release();
+            HIP_TRY(c, c->edges.reserve((size_t)(now + now / 8 + 1024) * 8));
+            c->edge_cap = c->edges.cap / 8;
+            FQD_TRY(zero_ctr64(c, C64_EDGES));
+            HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
         }
         c->E = have;
         fqd::PairStats slots[FQD_STAT_SLOTS];
@@ -1006,20 +996,28 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
     return FQD_OK;
 }
 
+// Queue the union-find kernels; the root count stays on the device until somebody asks for it
+// (fqd_cluster asks after the dissection, so the GPU never waits for the host in between).
+static int components_queue(fqd_ctx *c)
+{
+    const uint64_t U = c->U;
+    HIP_TRY(c, c->labels.reserve(U * 4 + 16));
+    FQD_TRY(zero_ctr64(c, C64_ROOTS));
+    HIP_TRY(c, fqd::launch_uf_init(c->labels.as<uint32_t>(), U, c->st));
+    KTIME(c, FQD_K_UF_UNION, fqd::launch_uf_union(c->labels.as<uint32_t>(), c->edges.as<uint32_t>(), c->E, c->st));
+    KTIME(c, FQD_K_UF_FLATTEN, fqd::launch_uf_flatten(c->labels.as<uint32_t>(), U,
+                                                      c->d_ctr64.as<unsigned long long>() + C64_ROOTS, c->st));
+    return FQD_OK;
+}
+
 int fqd_components(fqd_ctx *c, uint64_t *n_clusters)
 {
     FQD_TRY(bind(c));
     if (c->stage < ST_EDGES)
         return fail(c, FQD_E_STATE, "fqd_components before fqd_find_edges/fqd_import_edges");
     c->stage = ST_EDGES;
-    const uint64_t U = c->U;
     StageTimer timer(c, FQD_T_COMPONENTS);
-    HIP_TRY(c, c->labels.reserve(U * 4 + 16));
-    FQD_TRY(zero_ctr64(c, C64_ROOTS));
-    HIP_TRY(c, fqd::launch_uf_init(c->labels.as<uint32_t>(), U, c->st));
-    KTIME(c, FQD_K_UF_UNION, fqd::launch_uf_union(c->labels.as<uint32_t>(), c->edges.as<uint32_t>(), c->E, c->st));
-    KTIME(c, FQD_K_UF_FLATTEN, fqd::launch_uf_flatten(c->labels.as<uint32_t>(), U, c->d_ctr64.as<unsigned long long>() + C64_ROOTS,
-                                      c->st));
+    FQD_TRY(components_queue(c));
     unsigned long long roots = 0;
     FQD_TRY(read_ctr64(c, C64_ROOTS, &roots));
     timer.stop();
@@ -1056,12 +1054,15 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
         HIP_TRY(c, c->blocked.reserve(U * 4 + 16));   // here: round stamps of the nodes
         if (E)
             HIP_TRY(c, hipMemsetAsync(c->blocked.p, 0, U * 4, c->st));
-        for (uint64_t round = 1; E && round <= U + 1; round++) {
+        // two sweeps per host check: the flag is read back half as often, and a sweep over edges
+        // whose ends did not move is cheap (stamps)
+        for (uint64_t round = 1; E && round <= U + 2; round += 2) {
             FQD_TRY(zero_ctr32(c, C_CHANGED));
-            KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_directional_round(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
+            for (uint32_t k = 0; k < 2; k++)
+                KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_directional_round(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
                                                      c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh,
-                                                     c->best.as<uint32_t>(), c->blocked.as<uint32_t>(), (uint32_t)round,
-                                                     d_changed, c->st));
+                                                     c->best.as<uint32_t>(), c->blocked.as<uint32_t>(),
+                                                     (uint32_t)(round + k), d_changed, c->st));
             uint32_t changed = 0;
             FQD_TRY(read_ctr32(c, C_CHANGED, &changed));
             if (!changed)
@@ -1073,10 +1074,11 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
         // edges become (higher rank, lower rank); union-find and the other methods do not care
         HIP_TRY(c, fqd::launch_orient_edges(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
                                             c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, c->st));
-        for (uint64_t round = 1; round <= U + 1; round++) {
+        for (uint64_t round = 1; round <= U + 2; round += 2) {
             FQD_TRY(zero_ctr32(c, C_CHANGED));
-            KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_adjacency_round(c->edges.as<uint32_t>(), E, U, c->state.as<uint8_t>(),
-                                                   c->blocked.as<uint32_t>(), (uint32_t)round, d_changed, c->st));
+            for (uint32_t k = 0; k < 2; k++)
+                KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_adjacency_round(c->edges.as<uint32_t>(), E, U, c->state.as<uint8_t>(),
+                                                   c->blocked.as<uint32_t>(), (uint32_t)(round + k), d_changed, c->st));
             uint32_t changed = 0;
             FQD_TRY(read_ctr32(c, C_CHANGED, &changed));
             if (!changed)
@@ -1123,8 +1125,15 @@ int fqd_cluster(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, i
         return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
     FQD_TRY(fqd_collapse(c, weights, read_ids, mem, nullptr));
     FQD_TRY(fqd_find_edges(c, max_distance, metric, 0, 1, nullptr));
-    FQD_TRY(fqd_components(c, nullptr));
+    FQD_TRY(components_queue(c));      // no host round trip between components and dissection
+    c->stage = ST_LABELS;
+    c->ms[FQD_T_COMPONENTS] = 0;
     FQD_TRY(fqd_dissect(c, method, nullptr));
+    {
+        unsigned long long roots = 0;
+        FQD_TRY(read_ctr64(c, C64_ROOTS, &roots));
+        c->n_clusters = roots;
+    }
     if (out) {
         out->n_reads = c->n;
         out->n_counted = c->n_counted;
