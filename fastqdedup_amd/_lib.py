@@ -42,6 +42,8 @@ EXPORTS = [
     "fqd_synchronize", "fqd_pack_keys", "fqd_configure", "fqd_scan_keys", "fqd_get_shape",
     "fqd_collapse", "fqd_find_edges", "fqd_components", "fqd_dissect", "fqd_cluster",
     "fqd_set_id_window", "fqd_get_kept_count", "fqd_get_kept_read_ids", "fqd_get_unique_table", "fqd_export_packed", "fqd_export_packed_by_owner", "fqd_import_packed",
+    "fqd_export_packed_by_segment", "fqd_export_unique_by_segment", "fqd_gather_unique",
+    "fqd_find_edges_segments", "fqd_edge_labels", "fqd_list_kept_except",
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
     "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_edge_stats", "fqd_synth_keys",
 ]
@@ -92,6 +94,14 @@ def load() -> C.CDLL:
     L.fqd_export_packed.argtypes = [vp, vp, vp, vp, C.c_int]
     L.fqd_import_packed.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
     L.fqd_export_packed_by_owner.argtypes = [vp, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_int]
+    L.fqd_export_packed_by_segment.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp, vp,
+                                               vp, vp, C.c_int]
+    L.fqd_export_unique_by_segment.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp,
+                                               C.c_int]
+    L.fqd_gather_unique.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_int]
+    L.fqd_find_edges_segments.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, u64p]
+    L.fqd_edge_labels.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, u64p, C.c_int]
+    L.fqd_list_kept_except.argtypes = [vp, vp, C.c_uint64, C.c_int, u64p]
     L.fqd_export_unique.argtypes = [vp, vp, vp, vp, vp, C.c_int]
     L.fqd_import_unique.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_int]
     L.fqd_export_edges.argtypes = [vp, vp, C.c_int]
@@ -282,6 +292,11 @@ class Context:
             lab.ctypes.data if labels else None, kp.ctypes.data if kept else None, HOST))
         return first, counts, lab, kp
 
+    def kept_flags_into(self, kept):
+        """The dissection's verdict per unique key (uint8) into a caller's buffer."""
+        kp, km, _0 = _ptr_mem(kept)
+        self._ck(self._L.fqd_get_unique_table(self._h, None, None, None, kp, km))
+
     # ---- exchange (raw pointers; the caller owns the buffers) ----------------------
     def export_packed(self, recs, lens, hashes):
         rp, rm, _1 = _ptr_mem(recs)
@@ -299,6 +314,53 @@ class Context:
         self._ck(self._L.fqd_export_packed_by_owner(self._h, int(n_parts), int(id0), wp, rp, lp, ip, op,
                                                     counts.ctypes.data, rm))
         return counts
+
+    def export_packed_by_segment(self, n_parts: int, n_segments: int, segment: int, id0: int, weights, recs, lens,
+                                 ids, weights_out):
+        wp, _m, _0 = _ptr_mem(weights)
+        rp, rm, _1 = _ptr_mem(recs)
+        lp, _m, _2 = _ptr_mem(lens)
+        ip, _m, _3 = _ptr_mem(ids)
+        op, _m, _4 = _ptr_mem(weights_out)
+        counts = np.zeros(n_parts, dtype=np.uint64)
+        self._ck(self._L.fqd_export_packed_by_segment(self._h, int(n_parts), int(n_segments), int(segment), int(id0),
+                                                      wp, rp, lp, ip, op, counts.ctypes.data, rm))
+        return counts
+
+    def export_unique_by_segment(self, n_parts: int, n_segments: int, segment: int, uid_base: int, recs, lens, uids):
+        rp, rm, _1 = _ptr_mem(recs)
+        lp, _m, _2 = _ptr_mem(lens)
+        up, _m, _3 = _ptr_mem(uids)
+        counts = np.zeros(n_parts, dtype=np.uint64)
+        self._ck(self._L.fqd_export_unique_by_segment(self._h, int(n_parts), int(n_segments), int(segment),
+                                                      int(uid_base), rp, lp, up, counts.ctypes.data, rm))
+        return counts
+
+    def gather_unique(self, idx, n: int, recs, lens, counts):
+        ip, im, _0 = _ptr_mem(idx)
+        rp, rm, _1 = _ptr_mem(recs)
+        lp, _m, _2 = _ptr_mem(lens)
+        cp, _m, _3 = _ptr_mem(counts)
+        self._ck(self._L.fqd_gather_unique(self._h, ip, int(n), rp, lp, cp, rm))
+
+    def find_edges_segments(self, max_distance: int, seg_lo: int, seg_hi: int) -> int:
+        ne = C.c_uint64(0)
+        self._ck(self._L.fqd_find_edges_segments(self._h, int(max_distance), int(seg_lo), int(seg_hi), C.byref(ne)))
+        return ne.value
+
+    def edge_labels(self, uv, n_edges: int, n_nodes: int, roots) -> int:
+        """roots[e] = smallest node of edge e's component; returns the number of components."""
+        ep, em, _0 = _ptr_mem(uv)
+        rp, rm, _1 = _ptr_mem(roots)
+        nc = C.c_uint64(0)
+        self._ck(self._L.fqd_edge_labels(self._h, ep, int(n_edges), int(n_nodes), rp, C.byref(nc), DEVICE))
+        return nc.value
+
+    def list_kept_except(self, dropped, n_dropped: int) -> int:
+        dp, dm, _0 = _ptr_mem(dropped)
+        nk = C.c_uint64(0)
+        self._ck(self._L.fqd_list_kept_except(self._h, dp, int(n_dropped), DEVICE, C.byref(nk)))
+        return nk.value
 
     def import_packed(self, recs, lens, n: int):
         rp, rm, _1 = _ptr_mem(recs)

@@ -638,6 +638,15 @@ int fqd_configure(fqd_ctx *c, const uint8_t *present128, uint32_t max_len, int r
     c->forced = true;
     c->forced_max_len = max_len;
     c->forced_ragged = ragged;
+    // The geometry applies at once, so a context that only IMPORTS records (a routed search
+    // pass, a cluster dissected away from its owner) needs no pack call first.
+    FQD_TRY(bind(c));
+    uint8_t lut[256];
+    build_alphabet(c, c->forced_present, lut);
+    FQD_TRY(set_geometry(c, max_len, ragged));
+    HIP_TRY(c, hipMemcpyAsync(c->d_lut.p, lut, 256, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    c->stage = ST_EMPTY;
     return FQD_OK;
 }
 
@@ -890,7 +899,10 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
     return FQD_OK;
 }
 
-int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uint32_t n_shards, uint64_t *n_edges)
+// Shared body of fqd_find_edges / fqd_find_edges_segments: passes [seg_lo, seg_hi) of the
+// (max_distance+1)-way pigeonhole split (the whole range for a plain search).
+static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uint32_t n_shards,
+                           uint32_t seg_lo, uint32_t seg_hi, uint64_t *n_edges)
 {
     FQD_TRY(bind(c));
     if (c->stage < ST_UNIQUE)
@@ -903,6 +915,10 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
     // Levenshtein <= 1 between keys of ONE length is Hamming <= 1 (an indel changes the length):
     // that case shares the Hamming search; everything else takes the bucketed edit search.
     const bool edit_general = metric == FQD_METRIC_EDIT && !(max_distance <= 1 && !sh.ragged);
+    if (seg_hi > (uint32_t)max_distance + 1 || seg_lo > seg_hi)
+        return fail(c, FQD_E_VALUE, "segment range outside [0, max_distance + 1]");
+    if (edit_general && (seg_lo != 0 || seg_hi != (uint32_t)max_distance + 1))
+        return fail(c, FQD_E_VALUE, "the bucketed edit search has no per-segment passes");
     c->stage = ST_UNIQUE;
     const uint64_t U = c->U;
     StageTimer timer(c, FQD_T_EDGES);
@@ -919,13 +935,13 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
         // length share the empty segment's bucket), just quadratic.
         const uint32_t d = (uint32_t)max_distance;
         const uint32_t nseg = d + 1;
-        HIP_TRY(c, c->seg_hashes.reserve((size_t)nseg * U * 4 + 16));
+        HIP_TRY(c, c->seg_hashes.reserve((size_t)(seg_hi - seg_lo) * U * 4 + 16));
         HIP_TRY(c, c->sorted_hash.reserve(U * 4 + 16));
         HIP_TRY(c, c->sorted_uid.reserve(U * 4 + 16));
         HIP_TRY(c, c->uid_iota.reserve(U * 4 + 16));
         HIP_TRY(c, fqd::launch_iota_u32(c->uid_iota.as<uint32_t>(), U, c->st));
         KTIME(c, FQD_K_SEG_HASH, fqd::launch_segment_hashes(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, sh, nseg,
-                                              c->seg_hashes.as<uint32_t>(), c->st));
+                                              seg_lo, seg_hi, 0, c->seg_hashes.as<uint32_t>(), c->st));
         if (c->edge_cap < 1024 || !c->edges.p) {
             c->edge_cap = std::max<uint64_t>(1024, U);
             HIP_TRY(c, c->edges.reserve(c->edge_cap * 8));
@@ -940,12 +956,13 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
         // end. If the passes overflowed the edge buffer (the count still says how many edges there
         // are), the buffer is grown to the known need and the whole search runs again.
         for (int attempt = 0;; attempt++) {
-            for (uint32_t s = 0; s < nseg; s++) {
+            for (uint32_t s = seg_lo; s < seg_hi; s++) {
+                const uint32_t *pass_hashes = c->seg_hashes.as<uint32_t>() + (size_t)(s - seg_lo) * U;
                 uint64_t m = U;  // entries this rank sorts and searches in this pass
                 if (n_shards > 1) {
                     // only this rank's buckets go through the sort and the pair kernel
                     FQD_TRY(zero_ctr64(c, C64_SUM));
-                    HIP_TRY(c, fqd::launch_select_shard(c->seg_hashes.as<uint32_t>() + (size_t)s * U, U, shard,
+                    HIP_TRY(c, fqd::launch_select_shard(pass_hashes, U, shard,
                                                         n_shards, c->sel_hash.as<uint32_t>(),
                                                         c->sel_uid.as<uint32_t>(),
                                                         c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
@@ -955,7 +972,7 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
                     FQD_TRY(sort_u32_pairs(c, c->sel_hash.as<uint32_t>(), c->sorted_hash.as<uint32_t>(),
                                            c->sel_uid.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), m));
                 } else {
-                    FQD_TRY(sort_u32_pairs(c, c->seg_hashes.as<uint32_t>() + (size_t)s * U,
+                    FQD_TRY(sort_u32_pairs(c, pass_hashes,
                                            c->sorted_hash.as<uint32_t>(), c->uid_iota.as<uint32_t>(),
                                            c->sorted_uid.as<uint32_t>(), U));
                 }
@@ -996,6 +1013,20 @@ int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uin
     return FQD_OK;
 }
 
+int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uint32_t n_shards, uint64_t *n_edges)
+{
+    if (max_distance < 0)
+        return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
+    return find_edges_impl(c, max_distance, metric, shard, n_shards, 0, (uint32_t)max_distance + 1, n_edges);
+}
+
+int fqd_find_edges_segments(fqd_ctx *c, int max_distance, uint32_t seg_lo, uint32_t seg_hi, uint64_t *n_edges)
+{
+    if (max_distance < 0)
+        return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
+    return find_edges_impl(c, max_distance, FQD_METRIC_HAMMING, 0, 1, seg_lo, seg_hi, n_edges);
+}
+
 // Queue the union-find kernels; the root count stays on the device until somebody asks for it
 // (fqd_cluster asks after the dissection, so the GPU never waits for the host in between).
 static int components_queue(fqd_ctx *c)
@@ -1004,7 +1035,7 @@ static int components_queue(fqd_ctx *c)
     HIP_TRY(c, c->labels.reserve(U * 4 + 16));
     FQD_TRY(zero_ctr64(c, C64_ROOTS));
     HIP_TRY(c, fqd::launch_uf_init(c->labels.as<uint32_t>(), U, c->st));
-    KTIME(c, FQD_K_UF_UNION, fqd::launch_uf_union(c->labels.as<uint32_t>(), c->edges.as<uint32_t>(), c->E, c->st));
+    KTIME(c, FQD_K_UF_UNION, fqd::launch_uf_union(c->labels.as<uint32_t>(), c->edges.as<uint32_t>(), c->E, nullptr, c->st));
     KTIME(c, FQD_K_UF_FLATTEN, fqd::launch_uf_flatten(c->labels.as<uint32_t>(), U,
                                                       c->d_ctr64.as<unsigned long long>() + C64_ROOTS, c->st));
     return FQD_OK;
@@ -1025,6 +1056,47 @@ int fqd_components(fqd_ctx *c, uint64_t *n_clusters)
     c->stage = ST_LABELS;
     if (n_clusters)
         *n_clusters = roots;
+    return FQD_OK;
+}
+
+// Verdicts (best / state) -> kept flags, the counters and the ascending list of kept first-holder
+// ids inside the id window.
+static int list_kept(fqd_ctx *c, int method)
+{
+    const uint64_t U = c->U;
+    c->n_kept = 0;
+    c->n_listed = 0;
+    if (U) {
+        FQD_TRY(zero_ctr64(c, C64_SUM));
+        HIP_TRY(c, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
+                                          c->state.as<uint8_t>(), c->ufirst.as<uint64_t>(), c->id_lo, c->id_hi, U,
+                                          c->kept.as<uint8_t>(), c->kept_u32.as<uint32_t>(),
+                                          c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+        FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), U));
+        uint32_t nk = 0;
+        HIP_TRY(c, hipMemcpyAsync(&nk, c->kept_scan.as<uint32_t>() + (U - 1), 4, hipMemcpyDeviceToHost, c->st));
+        unsigned long long total = 0;
+        FQD_TRY(read_ctr64(c, C64_SUM, &total));
+        c->n_kept = total;
+        c->n_listed = nk;
+        HIP_TRY(c, c->kept_ids.reserve((size_t)nk * 8 + 16));
+        HIP_TRY(c, c->kept_ids_sorted.reserve((size_t)nk * 8 + 16));
+        HIP_TRY(c, fqd::launch_gather_kept(c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(),
+                                           c->ufirst.as<uint64_t>(), U, c->kept_ids.as<uint64_t>(), c->st));
+        if (nk) {
+            int sort_bits = c->id_bits;   // listed ids lie below id_hi: fewer radix passes
+            if (c->id_hi != ~0ull) {
+                int wb = 1;
+                while (wb < 64 && (c->id_hi >> wb))
+                    wb++;
+                sort_bits = std::min(sort_bits, wb);
+            }
+            const size_t need = fqd::sort_keys_u64_temp(nk);
+            HIP_TRY(c, c->tmp.reserve(need + 16));
+            HIP_TRY(c, fqd::sort_keys_u64(c->tmp.p, need, c->kept_ids.as<uint64_t>(),
+                                          c->kept_ids_sorted.as<uint64_t>(), nk, sort_bits, c->st));
+        }
+    }
     return FQD_OK;
 }
 
@@ -1085,32 +1157,7 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
                 break;
         }
     }
-    c->n_kept = 0;
-    c->n_listed = 0;
-    if (U) {
-        FQD_TRY(zero_ctr64(c, C64_SUM));
-        HIP_TRY(c, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
-                                          c->state.as<uint8_t>(), c->ufirst.as<uint64_t>(), c->id_lo, c->id_hi, U,
-                                          c->kept.as<uint8_t>(), c->kept_u32.as<uint32_t>(),
-                                          c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
-        FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), U));
-        uint32_t nk = 0;
-        HIP_TRY(c, hipMemcpyAsync(&nk, c->kept_scan.as<uint32_t>() + (U - 1), 4, hipMemcpyDeviceToHost, c->st));
-        unsigned long long total = 0;
-        FQD_TRY(read_ctr64(c, C64_SUM, &total));
-        c->n_kept = total;
-        c->n_listed = nk;
-        HIP_TRY(c, c->kept_ids.reserve((size_t)nk * 8 + 16));
-        HIP_TRY(c, c->kept_ids_sorted.reserve((size_t)nk * 8 + 16));
-        HIP_TRY(c, fqd::launch_gather_kept(c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(),
-                                           c->ufirst.as<uint64_t>(), U, c->kept_ids.as<uint64_t>(), c->st));
-        if (nk) {
-            const size_t need = fqd::sort_keys_u64_temp(nk);
-            HIP_TRY(c, c->tmp.reserve(need + 16));
-            HIP_TRY(c, fqd::sort_keys_u64(c->tmp.p, need, c->kept_ids.as<uint64_t>(),
-                                          c->kept_ids_sorted.as<uint64_t>(), nk, c->id_bits, c->st));
-        }
-    }
+    FQD_TRY(list_kept(c, method));
     timer.stop();
     c->stage = ST_KEPT;
     if (n_kept)
@@ -1211,37 +1258,174 @@ int fqd_export_packed(fqd_ctx *c, uint32_t *recs, uint32_t *lens, uint32_t *hash
     return FQD_OK;
 }
 
-int fqd_export_packed_by_owner(fqd_ctx *c, uint32_t n_parts, uint64_t id0, const uint32_t *weights, uint32_t *recs,
-                               uint32_t *lens, uint64_t *ids, uint32_t *weights_out, uint64_t *counts, int mem)
+// Rows 0..n-1 of a record table grouped by owner[] (values < n_parts; part 0 first, stable):
+// one radix pass over ceil(log2 parts) bits, one coalesced gather, the part sizes to the host.
+static int export_grouped(fqd_ctx *c, uint64_t n, uint32_t n_parts, const uint32_t *owner, const uint32_t *src_recs,
+                          const uint32_t *src_lens, const uint32_t *weights, uint64_t id0, uint32_t *recs,
+                          uint32_t *lens, uint64_t *ids, uint32_t *ids32, uint32_t *weights_out, uint64_t *counts)
 {
-    FQD_TRY(bind(c));
-    if (c->stage < ST_PACKED)
-        return fail(c, FQD_E_STATE, "nothing packed");
-    if (mem != FQD_DEVICE)
-        return fail(c, FQD_E_VALUE, "fqd_export_packed_by_owner works on device buffers (counts: host)");
-    if (n_parts == 0 || n_parts > 65536)
-        return fail(c, FQD_E_VALUE, "1..65536 parts");
-    const uint64_t n = c->n;
     const KeyShape sh = c->ks;
     int bits = 1;
     while ((1u << bits) < n_parts)
         bits++;
     HIP_TRY(c, c->ids.reserve(n * 4 + 16));
     HIP_TRY(c, c->ids_sorted.reserve(n * 4 + 16));
-    HIP_TRY(c, c->flags.reserve(n * 4 + 16));
     HIP_TRY(c, c->run_idx.reserve(n * 4 + 16));
-    uint32_t *owner = c->flags.as<uint32_t>(), *owner_sorted = c->run_idx.as<uint32_t>();
-    HIP_TRY(c, fqd::launch_owner(c->hashes.as<uint32_t>(), n, n_parts, owner, c->st));
+    uint32_t *owner_sorted = c->run_idx.as<uint32_t>();
     HIP_TRY(c, fqd::launch_iota_u32(c->ids.as<uint32_t>(), n, c->st));
     FQD_TRY(sort_u32_pairs(c, owner, owner_sorted, c->ids.as<uint32_t>(), c->ids_sorted.as<uint32_t>(), n, bits));
-    if (!n)
-        HIP_TRY(c, c->run_idx.reserve(16));
-    HIP_TRY(c, fqd::launch_gather_by_owner(c->ids_sorted.as<uint32_t>(), n, sh, c->recs.as<uint32_t>(),
-                                           c->lens.as<uint32_t>(), weights, id0, recs, lens, ids, weights_out, c->st));
+    HIP_TRY(c, fqd::launch_gather_by_owner(c->ids_sorted.as<uint32_t>(), n, sh, src_recs, src_lens, weights, id0, recs,
+                                           lens, ids, ids32, weights_out, c->st));
     HIP_TRY(c, c->stage_d.reserve((size_t)n_parts * 8 + 16));
-    HIP_TRY(c, fqd::launch_owner_counts(c->run_idx.as<uint32_t>(), n, n_parts, c->stage_d.as<uint64_t>(), c->st));
+    HIP_TRY(c, fqd::launch_owner_counts(owner_sorted, n, n_parts, c->stage_d.as<uint64_t>(), c->st));
     HIP_TRY(c, hipMemcpyAsync(counts, c->stage_d.p, (size_t)n_parts * 8, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(c, hipStreamSynchronize(c->st));
+    return FQD_OK;
+}
+
+static int check_parts(fqd_ctx *c, uint32_t n_parts, int mem, const char *who)
+{
+    if (mem != FQD_DEVICE)
+        return fail(c, FQD_E_VALUE, std::string(who) + " works on device buffers (counts: host)");
+    if (n_parts == 0 || n_parts > 65536)
+        return fail(c, FQD_E_VALUE, "1..65536 parts");
+    return FQD_OK;
+}
+
+int fqd_export_packed_by_owner(fqd_ctx *c, uint32_t n_parts, uint64_t id0, const uint32_t *weights, uint32_t *recs,
+                               uint32_t *lens, uint64_t *ids, uint32_t *weights_out, uint64_t *counts, int mem)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_PACKED)
+        return fail(c, FQD_E_STATE, "nothing packed");
+    FQD_TRY(check_parts(c, n_parts, mem, "fqd_export_packed_by_owner"));
+    const uint64_t n = c->n;
+    HIP_TRY(c, c->flags.reserve(n * 4 + 16));
+    HIP_TRY(c, fqd::launch_owner(c->hashes.as<uint32_t>(), n, n_parts, c->flags.as<uint32_t>(), c->st));
+    return export_grouped(c, n, n_parts, c->flags.as<uint32_t>(), c->recs.as<uint32_t>(), c->lens.as<uint32_t>(),
+                          weights, id0, recs, lens, ids, nullptr, weights_out, counts);
+}
+
+int fqd_export_packed_by_segment(fqd_ctx *c, uint32_t n_parts, uint32_t n_segments, uint32_t segment, uint64_t id0,
+                                 const uint32_t *weights, uint32_t *recs, uint32_t *lens, uint64_t *ids,
+                                 uint32_t *weights_out, uint64_t *counts, int mem)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_PACKED)
+        return fail(c, FQD_E_STATE, "nothing packed");
+    FQD_TRY(check_parts(c, n_parts, mem, "fqd_export_packed_by_segment"));
+    if (n_segments == 0 || segment >= n_segments)
+        return fail(c, FQD_E_VALUE, "bad segment");
+    const uint64_t n = c->n;
+    HIP_TRY(c, c->flags.reserve(n * 4 + 16));
+    HIP_TRY(c, fqd::launch_segment_hashes(c->recs.as<uint32_t>(), c->lens.as<uint32_t>(), n, c->ks, n_segments, segment,
+                                          segment + 1, n_parts, c->flags.as<uint32_t>(), c->st));
+    return export_grouped(c, n, n_parts, c->flags.as<uint32_t>(), c->recs.as<uint32_t>(), c->lens.as<uint32_t>(),
+                          weights, id0, recs, lens, ids, nullptr, weights_out, counts);
+}
+
+int fqd_export_unique_by_segment(fqd_ctx *c, uint32_t n_parts, uint32_t n_segments, uint32_t segment,
+                                 uint32_t uid_base, uint32_t *recs, uint32_t *lens, uint32_t *uids, uint64_t *counts,
+                                 int mem)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_UNIQUE)
+        return fail(c, FQD_E_STATE, "no unique table yet");
+    FQD_TRY(check_parts(c, n_parts, mem, "fqd_export_unique_by_segment"));
+    if (n_segments == 0 || segment >= n_segments)
+        return fail(c, FQD_E_VALUE, "bad segment");
+    const uint64_t U = c->U;
+    if ((uint64_t)uid_base + U > 0xFFFFFFF0ull)
+        return fail(c, FQD_E_VALUE, "global unique ids must stay below 2^32-16");
+    HIP_TRY(c, c->flags.reserve(U * 4 + 16));
+    HIP_TRY(c, fqd::launch_segment_hashes(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, c->ks, n_segments,
+                                          segment, segment + 1, n_parts, c->flags.as<uint32_t>(), c->st));
+    return export_grouped(c, U, n_parts, c->flags.as<uint32_t>(), c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(),
+                          nullptr, uid_base, recs, lens, nullptr, uids, nullptr, counts);
+}
+
+// Rows idx[0..n) of the unique table (an owner answering another rank's request for key data).
+int fqd_gather_unique(fqd_ctx *c, const uint32_t *idx, uint64_t n, uint32_t *recs, uint32_t *lens, uint32_t *counts,
+                      int mem)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_UNIQUE)
+        return fail(c, FQD_E_STATE, "no unique table yet");
+    if (mem != FQD_DEVICE)
+        return fail(c, FQD_E_VALUE, "fqd_gather_unique works on device buffers");
+    if (n >= 0xFFFFFFF0ull)
+        return fail(c, FQD_E_VALUE, "too many rows");
+    // an index past the table would be a wild read: check on the device first
+    FQD_TRY(zero_ctr32(c, C_BAD));
+    HIP_TRY(c, fqd::launch_check_indices(idx, n, c->U, c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+    uint32_t bad = 0;
+    FQD_TRY(read_ctr32(c, C_BAD, &bad));
+    if (bad)
+        return fail(c, FQD_E_VALUE, "row index outside the unique table");
+    HIP_TRY(c, fqd::launch_gather_by_owner(idx, n, c->ks, c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(),
+                                           c->ucounts.as<uint32_t>(), 0, recs, lens, nullptr, nullptr, counts, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    return FQD_OK;
+}
+
+// Union-find over n_nodes nodes and a caller's edge list (device): roots[e] = smallest node of
+// edge e's component; *n_components = n_nodes - successful hooks.
+int fqd_edge_labels(fqd_ctx *c, const uint32_t *uv, uint64_t E, uint64_t n_nodes, uint32_t *roots,
+                    uint64_t *n_components, int mem)
+{
+    FQD_TRY(bind(c));
+    if (mem != FQD_DEVICE)
+        return fail(c, FQD_E_VALUE, "fqd_edge_labels works on device buffers");
+    if (n_nodes >= 0xFFFFFFF0ull)
+        return fail(c, FQD_E_VALUE, "at most 2^32-16 nodes");
+    FQD_TRY(zero_ctr32(c, C_BAD));
+    HIP_TRY(c, fqd::launch_check_indices(uv, 2 * E, n_nodes, c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+    uint32_t bad = 0;
+    FQD_TRY(read_ctr32(c, C_BAD, &bad));
+    if (bad)
+        return fail(c, FQD_E_VALUE, "edge end outside [0, n_nodes)");
+    HIP_TRY(c, c->stage_a.reserve(n_nodes * 4 + 16));
+    uint32_t *parent = c->stage_a.as<uint32_t>();
+    FQD_TRY(zero_ctr64(c, C64_SUM));
+    HIP_TRY(c, fqd::launch_uf_init(parent, n_nodes, c->st));
+    HIP_TRY(c, fqd::launch_uf_union(parent, uv, E, c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+    HIP_TRY(c, fqd::launch_edge_roots(parent, uv, E, roots, c->st));
+    unsigned long long hooks = 0;
+    FQD_TRY(read_ctr64(c, C64_SUM, &hooks));
+    if (n_components)
+        *n_components = n_nodes - hooks;
+    return FQD_OK;
+}
+
+// The dissection's verdicts came from elsewhere (the rank that held the cluster): every key of
+// the unique table is kept except the listed rows. Fills the kept list like fqd_dissect.
+int fqd_list_kept_except(fqd_ctx *c, const uint32_t *dropped, uint64_t n_dropped, int mem, uint64_t *n_kept)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_UNIQUE)
+        return fail(c, FQD_E_STATE, "no unique table yet");
+    if (mem != FQD_DEVICE && n_dropped)
+        return fail(c, FQD_E_VALUE, "fqd_list_kept_except works on device buffers");
+    const uint64_t U = c->U;
+    StageTimer timer(c, FQD_T_DISSECT);
+    HIP_TRY(c, c->state.reserve(U + 16));
+    HIP_TRY(c, c->kept.reserve(U + 16));
+    HIP_TRY(c, c->kept_u32.reserve(U * 4 + 16));
+    HIP_TRY(c, c->kept_scan.reserve(U * 4 + 16));
+    if (U)
+        HIP_TRY(c, hipMemsetAsync(c->state.p, 1, U, c->st));
+    FQD_TRY(zero_ctr32(c, C_BAD));
+    HIP_TRY(c, fqd::launch_mark_dropped(c->state.as<uint8_t>(), U, dropped, n_dropped,
+                                        c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+    uint32_t bad = 0;
+    FQD_TRY(read_ctr32(c, C_BAD, &bad));
+    if (bad)
+        return fail(c, FQD_E_VALUE, "dropped row outside the unique table");
+    FQD_TRY(list_kept(c, FQD_METHOD_ADJACENCY));   // "state == 1" is the verdict
+    timer.stop();
+    c->stage = ST_KEPT;
+    if (n_kept)
+        *n_kept = c->n_kept;
     return FQD_OK;
 }
 
@@ -1314,13 +1498,21 @@ int fqd_import_unique(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, co
                 return fail(c, FQD_E_VALUE, "ragged geometry needs lens");
             HIP_TRY(c, hipMemcpyAsync(c->ulens.p, lens, U * 4, kind, c->st));
         }
-        HIP_TRY(c, hipMemcpyAsync(c->ucounts.p, counts, U * 4, kind, c->st));
-        HIP_TRY(c, hipMemcpyAsync(c->ufirst.p, first_ids, U * 8, kind, c->st));
+        // a table used only for a neighbour search (a routed pass) needs neither column
+        if (counts)
+            HIP_TRY(c, hipMemcpyAsync(c->ucounts.p, counts, U * 4, kind, c->st));
+        else
+            HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->ucounts.p, 1, U, c->st));
+        if (first_ids)
+            HIP_TRY(c, hipMemcpyAsync(c->ufirst.p, first_ids, U * 8, kind, c->st));
+        else
+            HIP_TRY(c, hipMemsetAsync(c->ufirst.p, 0, U * 8, c->st));
     }
     HIP_TRY(c, hipStreamSynchronize(c->st));
     c->U = U;
     c->collapsed = false;  // imported rows may repeat a key (dissection of a caller's list)
-    {   // width of the largest first-holder id: the kept-id sort runs over that many bits only
+    c->id_bits = 1;
+    if (first_ids) {   // width of the largest first-holder id: the kept-id sort runs over that many bits only
         unsigned long long mx = 0;
         FQD_TRY(zero_ctr64(c, C64_SUM));
         HIP_TRY(c, fqd::launch_max_u64(c->ufirst.as<uint64_t>(), U, c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));

@@ -20,7 +20,8 @@ namespace {
 // order-free, so the Q lanes add up their partial sums with shuffles.
 __global__ __launch_bounds__(256) void segment_hashes_kernel(const uint32_t *__restrict__ urecs,
                                                              const uint32_t *__restrict__ ulens, uint64_t U,
-                                                             KeyShape sh, uint32_t nseg,
+                                                             KeyShape sh, uint32_t nseg, uint32_t s_begin,
+                                                             uint32_t s_end, uint32_t mod,
                                                              uint32_t *__restrict__ seg_hashes)
 {
     const uint32_t Q = sh.stride / 4, K = sh.planes, KW = sh.planes * sh.words;
@@ -41,7 +42,9 @@ __global__ __launch_bounds__(256) void segment_hashes_kernel(const uint32_t *__r
 #pragma unroll
     for (uint32_t e = 0; e < 4; e++)
         wi[e] = (q * 4 + e) / K;
-    for (uint32_t s = 0; s < nseg; s++) {
+    // segments [s_begin, s_end) of the nseg-way split; row (s - s_begin) of the output. mod != 0
+    // stores hash % mod (the owner rank of a segment-routed exchange).
+    for (uint32_t s = s_begin; s < s_end; s++) {
         uint32_t lo, hi;
         fqd_segment(len, s, nseg, lo, hi);
         uint32_t part = 0;
@@ -59,8 +62,10 @@ __global__ __launch_bounds__(256) void segment_hashes_kernel(const uint32_t *__r
             if (q + off < Q)
                 part += other;
         }
-        if (active && q == 0)
-            seg_hashes[(uint64_t)s * U + u] = fqd_mix32(part + fqd_mix32(len * 0x9E3779B1u + s * 0x85EBCA77u + 0x165667B1u));
+        if (active && q == 0) {
+            const uint32_t h = fqd_mix32(part + fqd_mix32(len * 0x9E3779B1u + s * 0x85EBCA77u + 0x165667B1u));
+            seg_hashes[(uint64_t)(s - s_begin) * U + u] = mod ? h % mod : h;
+        }
     }
 }
 
@@ -372,8 +377,9 @@ __global__ void pairs_within_kernel(const uint8_t *__restrict__ a, const uint64_
 
 namespace fqd {
 
-hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh,
-                                 uint32_t nseg, uint32_t *seg_hashes, hipStream_t st)
+hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t nseg,
+                                 uint32_t s_begin, uint32_t s_end, uint32_t mod, uint32_t *seg_hashes,
+                                 hipStream_t st)
 {
     if (!U)
         return hipSuccess;
@@ -383,7 +389,7 @@ hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, u
     const uint64_t rpw = 64 / Q, waves = (U + rpw - 1) / rpw, blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFull * 256)
         return hipErrorInvalidValue;
-    segment_hashes_kernel<<<(unsigned)blocks, 256, 0, st>>>(urecs, ulens, U, sh, nseg, seg_hashes);
+    segment_hashes_kernel<<<(unsigned)blocks, 256, 0, st>>>(urecs, ulens, U, sh, nseg, s_begin, s_end, mod, seg_hashes);
     return hipGetLastError();
 }
 

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void gather_by_owner_kernel(const uint32_t *__
                                                               uint32_t *__restrict__ recs_out,
                                                               uint32_t *__restrict__ lens_out,
                                                               uint64_t *__restrict__ ids_out,
+                                                              uint32_t *__restrict__ ids32_out,
                                                               uint32_t *__restrict__ weights_out)
 {
     const uint32_t Q = sh.stride / 4;
@@ -37,7 +38,10 @@ __global__ __launch_bounds__(256) void gather_by_owner_kernel(const uint32_t *__
     reinterpret_cast<uint4 *>(recs_out + i * sh.stride)[q] =
         reinterpret_cast<const uint4 *>(recs + (uint64_t)src * sh.stride)[q];
     if (q == 0) {
-        ids_out[i] = id0 + src;
+        if (ids_out)
+            ids_out[i] = id0 + src;
+        if (ids32_out)
+            ids32_out[i] = (uint32_t)id0 + src;
         if (lens_out)
             lens_out[i] = sh.ragged ? lens[src] : sh.max_len;
         if (weights_out)
@@ -79,13 +83,14 @@ hipError_t launch_owner(const uint32_t *hashes, uint64_t n, uint32_t parts, uint
 
 hipError_t launch_gather_by_owner(const uint32_t *order, uint64_t n, KeyShape sh, const uint32_t *recs,
                                   const uint32_t *lens, const uint32_t *weights, uint64_t id0, uint32_t *recs_out,
-                                  uint32_t *lens_out, uint64_t *ids_out, uint32_t *weights_out, hipStream_t st)
+                                  uint32_t *lens_out, uint64_t *ids_out, uint32_t *ids32_out, uint32_t *weights_out,
+                                  hipStream_t st)
 {
     if (n) {
         const uint64_t threads = n * (sh.stride / 4);
         gather_by_owner_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(order, n, sh, recs, lens, weights, id0,
                                                                                 recs_out, lens_out, ids_out,
-                                                                                weights_out);
+                                                                                ids32_out, weights_out);
     }
     return hipGetLastError();
 }

@@ -198,8 +198,9 @@ hipError_t launch_bucket_compact(const uint32_t *bucket_start, const uint32_t *u
                                  hipStream_t st);
 
 // edges.hip
-hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh,
-                                 uint32_t nseg, uint32_t *seg_hashes /* nseg * U */, hipStream_t st);
+hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t nseg,
+                                 uint32_t s_begin, uint32_t s_end, uint32_t mod, uint32_t *seg_hashes,
+                                 hipStream_t st);
 struct PairStats {
     unsigned long long keys_gathered, pairs_compared, edges;
 };
@@ -233,7 +234,8 @@ hipError_t launch_contains(const uint8_t *q, const uint64_t *qo, uint64_t nq, co
 hipError_t launch_owner(const uint32_t *hashes, uint64_t n, uint32_t parts, uint32_t *owner, hipStream_t st);
 hipError_t launch_gather_by_owner(const uint32_t *order, uint64_t n, KeyShape sh, const uint32_t *recs,
                                   const uint32_t *lens, const uint32_t *weights, uint64_t id0, uint32_t *recs_out,
-                                  uint32_t *lens_out, uint64_t *ids_out, uint32_t *weights_out, hipStream_t st);
+                                  uint32_t *lens_out, uint64_t *ids_out, uint32_t *ids32_out, uint32_t *weights_out,
+                                  hipStream_t st);
 hipError_t launch_owner_counts(const uint32_t *owner_sorted, uint64_t n, uint32_t parts, uint64_t *counts,
                                hipStream_t st);
 
@@ -245,7 +247,12 @@ hipError_t launch_quality(const uint8_t *bytes, uint64_t n_bytes, const uint64_t
 
 // graph.hip -- union-find + dissection
 hipError_t launch_uf_init(uint32_t *parent, uint64_t U, hipStream_t st);
-hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, hipStream_t st);
+hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, unsigned long long *n_hooks,
+                           hipStream_t st);
+hipError_t launch_edge_roots(uint32_t *parent, const uint32_t *edges, uint64_t E, uint32_t *roots, hipStream_t st);
+hipError_t launch_check_indices(const uint32_t *idx, uint64_t n, uint64_t limit, uint32_t *bad, hipStream_t st);
+hipError_t launch_mark_dropped(uint8_t *state, uint64_t U, const uint32_t *dropped, uint64_t n, uint32_t *bad,
+                               hipStream_t st);
 hipError_t launch_uf_flatten(uint32_t *parent, uint64_t U, unsigned long long *n_roots, hipStream_t st);
 hipError_t launch_dissect_init(uint32_t *best, uint8_t *state, uint64_t U, hipStream_t st);
 hipError_t launch_highest_count(const uint32_t *labels, const uint32_t *ucounts, const uint32_t *urecs,

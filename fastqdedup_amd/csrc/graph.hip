@@ -59,26 +59,68 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
     return x;
 }
 
-__global__ void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ edges, uint64_t E)
+// n_hooks (may be NULL) += successful hooks: every hook merges two components, so
+// components = nodes - hooks without a sweep over the nodes.
+__global__ void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ edges, uint64_t E,
+                                unsigned long long *n_hooks)
 {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E)
-        return;
-    uint32_t a = edges[2 * e], b = edges[2 * e + 1];
-    for (;;) {
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
-        if (a == b)
-            return;
-        if (a > b) {
-            const uint32_t t = a;
-            a = b;
-            b = t;
+    bool hooked = false;
+    if (e < E) {
+        uint32_t a = edges[2 * e], b = edges[2 * e + 1];
+        for (;;) {
+            a = uf_find(parent, a);
+            b = uf_find(parent, b);
+            if (a == b)
+                break;
+            if (a > b) {
+                const uint32_t t = a;
+                a = b;
+                b = t;
+            }
+            // hook the larger root under the smaller one
+            if (atomicCAS(&parent[b], b, a) == b) {
+                hooked = true;
+                break;
+            }
         }
-        // hook the larger root under the smaller one
-        if (atomicCAS(&parent[b], b, a) == b)
-            return;
     }
+    if (n_hooks) {
+        const unsigned long long m = __ballot(hooked);
+        if (m && fqd_lane() == (uint32_t)(__ffsll((long long)m) - 1))
+            atomicAdd(n_hooks, (unsigned long long)__popcll(m));
+    }
+}
+
+// roots[e] = component label (smallest node) of edge e's first end, after all unions are done
+__global__ void edge_roots_kernel(uint32_t *parent, const uint32_t *__restrict__ edges, uint64_t E,
+                                  uint32_t *__restrict__ roots)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E)
+        roots[e] = uf_find(parent, edges[2 * e]);
+}
+
+// *bad = 1 when some idx[i] >= limit (checked before a gather trusts a caller's indices)
+__global__ void check_indices_kernel(const uint32_t *__restrict__ idx, uint64_t n, uint64_t limit, uint32_t *bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && idx[i] >= limit)
+        *bad = 1;
+}
+
+// state[v] = 2 for every listed v (the dissection's verdict for v, computed elsewhere: "dropped")
+__global__ void mark_dropped_kernel(uint8_t *state, uint64_t U, const uint32_t *__restrict__ dropped, uint64_t n,
+                                    uint32_t *bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t v = dropped[i];
+    if (v < U)
+        state[v] = 2;
+    else
+        *bad = 1;
 }
 
 __global__ __launch_bounds__(256) void uf_flatten_kernel(uint32_t *parent, uint64_t U, unsigned long long *n_roots)
@@ -268,10 +310,33 @@ hipError_t launch_uf_init(uint32_t *parent, uint64_t U, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, hipStream_t st)
+hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, unsigned long long *n_hooks,
+                           hipStream_t st)
 {
     if (E)
-        uf_union_kernel<<<grid_for(E), 256, 0, st>>>(parent, edges, E);
+        uf_union_kernel<<<grid_for(E), 256, 0, st>>>(parent, edges, E, n_hooks);
+    return hipGetLastError();
+}
+
+hipError_t launch_edge_roots(uint32_t *parent, const uint32_t *edges, uint64_t E, uint32_t *roots, hipStream_t st)
+{
+    if (E)
+        edge_roots_kernel<<<grid_for(E), 256, 0, st>>>(parent, edges, E, roots);
+    return hipGetLastError();
+}
+
+hipError_t launch_check_indices(const uint32_t *idx, uint64_t n, uint64_t limit, uint32_t *bad, hipStream_t st)
+{
+    if (n)
+        check_indices_kernel<<<grid_for(n), 256, 0, st>>>(idx, n, limit, bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_dropped(uint8_t *state, uint64_t U, const uint32_t *dropped, uint64_t n, uint32_t *bad,
+                               hipStream_t st)
+{
+    if (n)
+        mark_dropped_kernel<<<grid_for(n), 256, 0, st>>>(state, U, dropped, n, bad);
     return hipGetLastError();
 }
 

@@ -4,18 +4,31 @@ arithmetic. The reference has no counterpart (it is single-threaded,
 SURVEY.md section 2); this is how the hot path of ONE job spreads over the 8
 GPUs of a node (DESIGN.md "multi-GPU").
 
-Exchange steps (everything else is rank-local):
+Two plans:
 
-  1. all-gather of 3 small words/rank + all-reduce(MAX) of the 128-entry
-     symbol table  -> every rank packs with the SAME record geometry.
-  2. all-to-all(v) of packed reads by ``owner = key_hash mod G``: all copies of a
-     key meet on one rank, which collapses them (count, first holder).
-  3. all-gather of the per-rank unique tables: with 288 GB of HBM every rank
-     holds the whole unique-key table (config 4: 1e8 keys x 128 B = 12.8 GB),
-     so the bucket pair search needs no further key movement -- rank r searches
-     the buckets with ``bucket_hash mod G == r`` (the k-mer-bucket shard).
-  4. all-gather of the edge shards; components and dissection then run on the
-     full edge list on every rank (they are a few percent of the job).
+``segment-routed`` (Hamming; the default). Per-rank work and traffic stay constant as
+ranks are added (weak scaling), except one all-gather of the edge list (8 B/edge):
+
+  1. geometry: 3 words/rank all-gather + all-reduce(MAX) of the symbol table.
+  2. all-to-all(v) of packed reads by ``owner = hash(segment 0 of the key) mod G``
+     (pigeonhole segments of the d+1 split). All copies of a key meet on one rank, which
+     collapses them into ITS rows of the job-wide unique table (uid = rank base + row) --
+     and every pair of keys agreeing on segment 0 is already together, so search pass 0
+     is rank-local.
+  3. for each further segment s: all-to-all(v) of (record, uid) by
+     ``hash(segment s) mod G``; search pass s runs on the received rows. A pair is
+     emitted in the first segment it agrees on, so every edge appears once, somewhere.
+  4. all-gather of the edges (uid pairs); a union-find over them on every rank labels
+     each edge with its component; rank r takes the clusters with ``label mod G == r``.
+  5. the rank fetches (record, count) of its clusters' keys from their owners
+     (request/response all-to-all), dissects, and returns the DROPPED uids to their
+     owners; an owner keeps every other row. Keys without neighbours never move.
+  6. kept first-holder ids go to the rank that read them (all-to-all by id window).
+
+``gathered`` (edit metric, or FQD_SHARD_PLAN=gathered): all-to-all by key hash,
+all-gather of the whole unique table (it fits: 288 GB/GPU), bucket-sharded search,
+all-gather of edges, components + dissection replicated. Simple, but per-rank work
+grows with G.
 
 The ``backend`` object does the arithmetic: ``HipBackend`` in production; tests
 inject a numpy stand-in to exercise the exchange logic on CPU with gloo.
@@ -42,6 +55,8 @@ class ShardedResult:
     n_edges: int
     n_clusters: int
     n_kept: int
+    plan: str = "segment-routed"
+    phases_ms: dict | None = None
 
 
 class HipBackend:
@@ -50,41 +65,130 @@ class HipBackend:
     def __init__(self, ctx: Context, device: torch.device):
         self.ctx = ctx
         self.device = device
+        self._aux = None      # second context: routed search passes and the clusters dissected here
+        self._geometry = None
 
+    # ---- geometry -------------------------------------------------------------------
     def scan(self, keys, offsets, key_len):
         present, max_len, ragged = self.ctx.scan_keys(keys, offsets, key_len)
         return present, max_len, ragged
 
     def configure(self, present, max_len, ragged):
-        self.ctx.configure(present, max_len, ragged)
+        self._geometry = (np.ascontiguousarray(present, dtype=np.uint8), int(max_len), bool(ragged))
+        self.ctx.configure(*self._geometry)
+        if self._aux is not None:
+            self._aux.configure(*self._geometry)
+        sh = self.ctx.shape()
+        self.stride = int(sh.stride_words)
+        self.ragged = bool(sh.ragged)
 
-    def pack_by_owner(self, keys, offsets, key_len, n_parts, id0, weights):
+    @property
+    def aux(self) -> Context:
+        if self._aux is None:
+            self._aux = Context(self.ctx.device)
+            self._aux.configure(*self._geometry)
+        return self._aux
+
+    def _rows(self, n):
+        recs = torch.empty((n, self.stride), dtype=torch.int32, device=self.device)
+        lens = torch.empty(n, dtype=torch.int32, device=self.device) if self.ragged else None
+        return recs, lens
+
+    # ---- reads -> owner ----------------------------------------------------------------
+    def pack_by_owner(self, keys, offsets, key_len, n_parts, id0, weights, n_segments=0):
         """Pack this rank's keys and return them grouped by owner rank (part 0 first, every
         part in read order): rows, lengths (None unless ragged), global ids, weights (None if
-        not given), rows per part."""
+        not given), rows per part. n_segments == 0: owner = key hash; else owner = hash of
+        segment 0 of the n_segments-way split."""
         n = self.ctx.pack_keys(keys, offsets, key_len)
         sh = self.ctx.shape()
         self.stride = int(sh.stride_words)
         self.ragged = bool(sh.ragged)
-        recs = torch.empty((n, self.stride), dtype=torch.int32, device=self.device)
-        lens = torch.empty(n, dtype=torch.int32, device=self.device) if self.ragged else None
+        recs, lens = self._rows(n)
         ids = torch.empty(n, dtype=torch.int64, device=self.device)
         w_in = None if weights is None else torch.as_tensor(weights).to(self.device).to(torch.int32).contiguous()
         w_out = None if weights is None else torch.empty(n, dtype=torch.int32, device=self.device)
-        counts = self.ctx.export_packed_by_owner(n_parts, id0, w_in, recs, lens, ids, w_out)
+        if n_segments:
+            counts = self.ctx.export_packed_by_segment(n_parts, n_segments, 0, id0, w_in, recs, lens, ids, w_out)
+        else:
+            counts = self.ctx.export_packed_by_owner(n_parts, id0, w_in, recs, lens, ids, w_out)
         return recs, lens, ids, w_out, [int(c) for c in counts]
 
+    def collapse_resident(self, recs, lens, weights, read_ids) -> int:
+        """Collapse the received reads; the unique table stays in the context."""
+        self.ctx.import_packed(recs, lens if self.ragged else None, recs.shape[0])
+        self.n_unique_local = self.ctx.collapse(weights, read_ids)
+        return self.n_unique_local
+
     def collapse_packed(self, recs, lens, weights, read_ids):
-        n = recs.shape[0]
-        self.ctx.import_packed(recs, lens if self.ragged else None, n)
-        nu = self.ctx.collapse(weights, read_ids)
-        urecs = torch.empty((nu, self.stride), dtype=torch.int32, device=self.device)
-        ulens = torch.empty(nu, dtype=torch.int32, device=self.device) if self.ragged else None
+        nu = self.collapse_resident(recs, lens, weights, read_ids)
+        urecs, ulens = self._rows(nu)
         ucounts = torch.empty(nu, dtype=torch.int32, device=self.device)
         ufirst = torch.empty(nu, dtype=torch.int64, device=self.device)
         self.ctx.export_unique(urecs, ulens, ucounts, ufirst)
         return urecs, ulens, ucounts, ufirst
 
+    # ---- segment-routed plan --------------------------------------------------------------
+    def local_edges(self, max_distance, seg_lo, seg_hi):
+        """Edges (row pairs of this rank's unique table) of search passes [seg_lo, seg_hi)."""
+        ne = self.ctx.find_edges_segments(max_distance, seg_lo, seg_hi)
+        edges = torch.empty((ne, 2), dtype=torch.int32, device=self.device)
+        self.ctx.export_edges(edges)
+        return edges
+
+    def unique_by_segment(self, n_parts, n_segments, segment, uid_base):
+        nu = self.n_unique_local
+        recs, lens = self._rows(nu)
+        uids = torch.empty(nu, dtype=torch.int32, device=self.device)
+        counts = self.ctx.export_unique_by_segment(n_parts, n_segments, segment, uid_base, recs, lens, uids)
+        return recs, lens, uids, [int(c) for c in counts]
+
+    def routed_edges(self, recs, lens, uids, max_distance, segment):
+        """Search pass `segment` over rows received from every rank; edges as uid pairs."""
+        n = recs.shape[0]
+        self.aux.import_unique(recs, lens if self.ragged else None, None, None, n)
+        ne = self.aux.find_edges_segments(max_distance, segment, segment + 1)
+        edges = torch.empty((ne, 2), dtype=torch.int32, device=self.device)
+        self.aux.export_edges(edges)
+        return uids[edges.long()] if ne else edges
+
+    def edge_labels(self, edges, n_nodes):
+        """(component label of every edge, number of components over all n_nodes nodes)."""
+        roots = torch.empty(edges.shape[0], dtype=torch.int32, device=self.device)
+        n_components = self.ctx.edge_labels(edges, edges.shape[0], n_nodes, roots)
+        return roots, n_components
+
+    def gather_unique(self, rows):
+        n = rows.shape[0]
+        recs, lens = self._rows(n)
+        counts = torch.empty(n, dtype=torch.int32, device=self.device)
+        self.ctx.gather_unique(rows.to(torch.int32).contiguous(), n, recs, lens, counts)
+        return recs, lens, counts
+
+    def dissect_subgraph(self, recs, lens, counts, edges, method):
+        """Verdict (uint8, 1 = kept) for every row of a table of whole clusters."""
+        n = recs.shape[0]
+        self.aux.import_unique(recs, lens if self.ragged else None, counts, None, n)
+        self.aux.import_edges(edges.contiguous(), edges.shape[0])
+        self.aux.components()
+        self.aux.dissect(method)
+        kept = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self.aux.kept_flags_into(kept)
+        return kept
+
+    def finish_owner(self, dropped_rows, id_hi):
+        """Every row is kept except the dropped ones -> (ascending kept first-holder ids, count)."""
+        self.ctx.set_id_window(0, id_hi)
+        try:
+            self.ctx.list_kept_except(dropped_rows.to(torch.int32).contiguous(), dropped_rows.shape[0])
+        finally:
+            self.ctx.set_id_window()
+        n_kept, n_listed = self.ctx.kept_count()
+        kept = torch.empty(n_listed, dtype=torch.int64, device=self.device)
+        self.ctx.kept_read_ids(n_listed, kept)
+        return kept, n_kept
+
+    # ---- gathered plan ----------------------------------------------------------------------
     def find_edges(self, urecs, ulens, ucounts, ufirst, max_distance, metric, shard, n_shards):
         self.ctx.import_unique(urecs, ulens, ucounts, ufirst, urecs.shape[0])
         ne = self.ctx.find_edges(max_distance, metric, shard, n_shards)
@@ -107,57 +211,114 @@ class HipBackend:
 
 
 class _PhaseTimer:
-    """FQD_SHARD_TIMING=1: wall time per phase (with a device sync at each mark) on stderr."""
+    """Wall time per phase, with a device sync at each mark (FQD_SHARD_TIMING=1 prints it;
+    bench.py runs one extra, untimed step with it for the per-phase table)."""
 
     def __init__(self, dev):
-        self.dev, self.t, self.out = dev, time.perf_counter(), []
+        self.dev, self.t, self.out = dev, time.perf_counter(), {}
 
     def mark(self, name):
         if self.dev.type == "cuda":
             torch.cuda.synchronize(self.dev)
         now = time.perf_counter()
-        self.out.append(f"{name}={1e3 * (now - self.t):.2f}")
+        self.out[name] = self.out.get(name, 0.0) + 1e3 * (now - self.t)
         self.t = now
 
     def done(self):
-        import sys
-        print("[fqd shard ms] " + " ".join(self.out), file=sys.stderr, flush=True)
+        if os.environ.get("FQD_SHARD_TIMING"):
+            import sys
+            print("[fqd shard ms] " + " ".join(f"{k}={v:.2f}" for k, v in self.out.items()), file=sys.stderr,
+                  flush=True)
+        return {k: round(v, 3) for k, v in self.out.items()}
 
 
-def _all_gather_rows(x: torch.Tensor, group) -> torch.Tensor:
-    """Concatenation over ranks (rank-major) of tensors that differ in dim 0."""
-    world = dist.get_world_size(group)
-    n = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    cap = max(max(sizes), 1)
-    pad = torch.zeros((cap,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    pad[: x.shape[0]] = x
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+class _Comm:
+    """The collectives of the job. ``via_host`` stages every buffer through host memory: the
+    two-ranks-on-one-GPU test runs the production arithmetic with gloo in between (RCCL refuses
+    two ranks on one device)."""
+
+    def __init__(self, group, device, via_host=False):
+        self.group, self.device, self.via_host = group, device, via_host
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def _wire(self, x):
+        return x.cpu() if self.via_host else x
+
+    def _back(self, x):
+        return x.to(self.device) if self.via_host else x
+
+    def all_gather_ints(self, values) -> np.ndarray:
+        """(world, len(values)) int64 on the host."""
+        wire_dev = torch.device("cpu") if self.via_host else self.device
+        mine = torch.tensor(list(values), dtype=torch.int64, device=wire_dev)
+        everyone = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(everyone, mine, group=self.group)
+        return torch.stack(everyone).cpu().numpy()
+
+    def all_reduce_max(self, x: torch.Tensor) -> torch.Tensor:
+        w = self._wire(x)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX, group=self.group)
+        return self._back(w)
+
+    def exchange_counts(self, send_counts) -> list:
+        wire_dev = torch.device("cpu") if self.via_host else self.device
+        s = torch.tensor([int(c) for c in send_counts], dtype=torch.int64, device=wire_dev)
+        r = torch.empty(self.world, dtype=torch.int64, device=wire_dev)
+        dist.all_to_all_single(r, s, group=self.group)
+        return [int(c) for c in r.tolist()]
+
+    def all_to_all_rows(self, x, send_counts, recv_counts):
+        """all-to-all(v) of the rows of x, already grouped by destination rank."""
+        if x is None:
+            return None
+        w = self._wire(x.contiguous())
+        out = torch.empty((int(sum(recv_counts)),) + tuple(x.shape[1:]), dtype=x.dtype, device=w.device)
+        dist.all_to_all_single(out, w, output_split_sizes=[int(c) for c in recv_counts],
+                               input_split_sizes=[int(c) for c in send_counts], group=self.group)
+        return self._back(out)
+
+    def all_gather_rows(self, x):
+        """Concatenation over ranks (rank-major) of tensors that differ in dim 0."""
+        if x is None:
+            return None
+        sizes = [int(s) for s in self.all_gather_ints([x.shape[0]])[:, 0]]
+        cap = max(max(sizes), 1)
+        w = self._wire(x)
+        pad = torch.zeros((cap,) + tuple(x.shape[1:]), dtype=x.dtype, device=w.device)
+        pad[: x.shape[0]] = w
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad, group=self.group)
+        return self._back(torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0))
 
 
-def _all_to_all_rows(x: torch.Tensor, send_counts: torch.Tensor, recv_counts, group) -> torch.Tensor:
-    """all-to-all(v) of the rows of x, already grouped by destination rank."""
-    out = torch.empty((int(sum(recv_counts)),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_to_all_single(out, x.contiguous(), output_split_sizes=list(recv_counts),
-                           input_split_sizes=[int(c) for c in send_counts.tolist()], group=group)
-    return out
+def _split_by_bounds(sorted_values: torch.Tensor, bounds) -> list:
+    """Rows per part of an ascending tensor cut at bounds[1:-1] (part p = [bounds[p], bounds[p+1]))."""
+    if len(bounds) <= 2:
+        return [int(sorted_values.shape[0])]
+    cuts = torch.searchsorted(sorted_values, torch.tensor(list(bounds[1:-1]), dtype=sorted_values.dtype,
+                                                          device=sorted_values.device)).tolist()
+    edges = [0] + [int(c) for c in cuts] + [int(sorted_values.shape[0])]
+    return [edges[i + 1] - edges[i] for i in range(len(edges) - 1)]
 
 
 def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=None, *,
                          max_distance: int = 1, use_edit_distance: bool = False,
-                         method="directional", group=None) -> ShardedResult:
+                         method="directional", group=None, plan: str | None = None,
+                         comm_via_host: bool = False, timing: bool = False) -> ShardedResult:
     """Cluster the union of every rank's keys as ONE job. ``keys`` is this rank's
     shard (device tensor or numpy array, as ``cluster_keys``). Read ids are global:
     rank r's reads follow rank r-1's. Counters are global; the id list is this rank's share."""
     if max_distance < 0:
         raise ValueError("max_distance should be non-negative")
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    plan = plan or os.environ.get("FQD_SHARD_PLAN") or "segment-routed"
+    if plan not in ("segment-routed", "gathered"):
+        raise ValueError(f"unknown plan {plan!r}")
+    if use_edit_distance:
+        plan = "gathered"      # the edit search buckets keys across lengths and shifts: no per-segment routing
+    comm = _Comm(group, backend.device, comm_via_host)
+    rank, world = comm.rank, comm.world
     dev = backend.device
-    tick = _PhaseTimer(dev) if os.environ.get("FQD_SHARD_TIMING") else None
+    tick = _PhaseTimer(dev) if (timing or os.environ.get("FQD_SHARD_TIMING")) else None
     method_id = METHODS[method] if isinstance(method, str) else int(method)
     metric = METRIC_EDIT if use_edit_distance else METRIC_HAMMING
 
@@ -168,49 +329,142 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
         n_local = nbytes // key_len if key_len else 0
     else:
         n_local = (offsets.numel() if hasattr(offsets, "numel") else offsets.size) - 1
-    mine = torch.tensor([n_local, max_len, int(ragged)], dtype=torch.int64, device=dev)
-    everyone = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(everyone, mine, group=group)
-    everyone = torch.stack(everyone).cpu().numpy()
+    everyone = comm.all_gather_ints([n_local, max_len, int(ragged)])
     n_per_rank = everyone[:, 0]
     lens_seen = {int(m) for n, m, _ in everyone if n > 0}
     g_ragged = bool(everyone[:, 2].any()) or len(lens_seen) > 1
     g_max_len = int(everyone[:, 1].max()) if len(everyone) else 0
     p = torch.from_numpy(np.ascontiguousarray(present, dtype=np.uint8)).to(dev).to(torch.int32)
-    dist.all_reduce(p, op=dist.ReduceOp.MAX, group=group)
-    g_present = p.to(torch.uint8).cpu().numpy()
+    g_present = comm.all_reduce_max(p).to(torch.uint8).cpu().numpy()
     backend.configure(g_present, g_max_len, g_ragged)
     if tick:
         tick.mark("geometry")
-    id0 = int(n_per_rank[:rank].sum())
-    n_total = int(n_per_rank.sum())
+    id_bounds = [0] + [int(x) for x in np.cumsum(n_per_rank)]
+    id0, n_total = id_bounds[rank], id_bounds[-1]
 
+    if plan == "gathered":
+        return _gathered(backend, comm, tick, keys, offsets, key_len, weights, max_distance, metric, method_id,
+                         g_ragged, id0, n_local, n_total)
+
+    # ---- 2. reads to the owner of their segment 0; collapse -------------------------
+    n_seg = max_distance + 1
+    s_recs, s_lens, s_ids, s_w, send_counts = backend.pack_by_owner(keys, offsets, key_len, world, id0, weights,
+                                                                    n_segments=n_seg)
+    if tick:
+        tick.mark("pack+group-by-owner")
+    recv_counts = comm.exchange_counts(send_counts)
+    r_recs = comm.all_to_all_rows(s_recs, send_counts, recv_counts)
+    r_ids = comm.all_to_all_rows(s_ids, send_counts, recv_counts)
+    r_lens = comm.all_to_all_rows(s_lens, send_counts, recv_counts) if g_ragged else None
+    r_w = comm.all_to_all_rows(s_w, send_counts, recv_counts)
+    del s_recs, s_ids, s_lens, s_w
+    # The received rows are ALREADY in global id order: all-to-all delivers source ranks in rank
+    # order, rank r's ids precede rank r+1's, and every source sent its rows in id order.
+    if tick:
+        tick.mark("all-to-all-reads")
+    n_unique_local = backend.collapse_resident(r_recs, r_lens, r_w, r_ids)
+    del r_recs, r_ids, r_lens, r_w
+    if tick:
+        tick.mark("collapse")
+    uid_bounds = [0] + [int(x) for x in np.cumsum(comm.all_gather_ints([n_unique_local])[:, 0])]
+    uid0, n_unique = uid_bounds[rank], uid_bounds[-1]
+    if n_unique >= 2**31 - 16:
+        raise ValueError("more than 2^31 unique keys in one job")
+
+    # ---- 3. search: pass 0 at home, pass s on the owner of segment s -----------------
+    found = []
+    if n_seg >= 1 and max_distance > 0:
+        e0 = backend.local_edges(max_distance, 0, 1)
+        found.append(e0 + uid0 if e0.shape[0] else e0)
+        if tick:
+            tick.mark("search-pass-0")
+        for s in range(1, n_seg):
+            q_recs, q_lens, q_uids, q_counts = backend.unique_by_segment(world, n_seg, s, uid0)
+            back_counts = comm.exchange_counts(q_counts)
+            x_recs = comm.all_to_all_rows(q_recs, q_counts, back_counts)
+            x_uids = comm.all_to_all_rows(q_uids, q_counts, back_counts)
+            x_lens = comm.all_to_all_rows(q_lens, q_counts, back_counts) if g_ragged else None
+            del q_recs, q_lens, q_uids
+            if tick:
+                tick.mark("route-unique")
+            found.append(backend.routed_edges(x_recs, x_lens, x_uids, max_distance, s))
+            del x_recs, x_lens, x_uids
+            if tick:
+                tick.mark("search-routed")
+    mine = torch.cat(found, dim=0) if found else torch.empty((0, 2), dtype=torch.int32, device=dev)
+
+    # ---- 4. all edges everywhere (8 B each); label; take this rank's clusters ----------
+    g_edges = comm.all_gather_rows(mine).contiguous()
+    n_edges = int(g_edges.shape[0])
+    labels, n_clusters = backend.edge_labels(g_edges, n_unique)
+    my_edges = g_edges[(labels % world) == rank]
+    touched, inverse = torch.unique(my_edges.reshape(-1), return_inverse=True)     # ascending uids
+    sub_edges = inverse.reshape(-1, 2).to(torch.int32)
+    del g_edges, labels, my_edges
+    if tick:
+        tick.mark("gather-edges+label")
+
+    # ---- 5. key data of my clusters from their owners; dissect; verdicts back ----------
+    ask_counts = _split_by_bounds(touched, uid_bounds)            # ascending uids are grouped by owner
+    asked_counts = comm.exchange_counts(ask_counts)
+    asked = comm.all_to_all_rows(touched, ask_counts, asked_counts)
+    a_recs, a_lens, a_counts = backend.gather_unique(asked - uid0)
+    t_recs = comm.all_to_all_rows(a_recs, asked_counts, ask_counts)
+    t_counts = comm.all_to_all_rows(a_counts, asked_counts, ask_counts)
+    t_lens = comm.all_to_all_rows(a_lens, asked_counts, ask_counts) if g_ragged else None
+    del a_recs, a_lens, a_counts, asked
+    if tick:
+        tick.mark("fetch-cluster-keys")
+    verdict = backend.dissect_subgraph(t_recs, t_lens, t_counts, sub_edges, method_id)
+    dropped = touched[verdict == 0]
+    del t_recs, t_lens, t_counts, sub_edges
+    if tick:
+        tick.mark("dissect")
+    drop_counts = _split_by_bounds(dropped, uid_bounds)
+    dropped_counts = comm.exchange_counts(drop_counts)
+    dropped_here = comm.all_to_all_rows(dropped, drop_counts, dropped_counts)
+    kept_owned, n_kept_owned = backend.finish_owner(dropped_here - uid0, max(n_total, 1))
+    if tick:
+        tick.mark("verdicts-home")
+
+    # ---- 6. kept ids to the rank that read them ------------------------------------------
+    out_counts = _split_by_bounds(kept_owned, id_bounds)
+    in_counts = comm.exchange_counts(out_counts)
+    kept_mine = comm.all_to_all_rows(kept_owned, out_counts, in_counts)
+    kept_mine = torch.sort(kept_mine).values if world > 1 else kept_mine
+    n_kept = int(comm.all_gather_ints([n_kept_owned])[:, 0].sum())
+    phases = None
+    if tick:
+        tick.mark("kept-ids-home")
+        phases = tick.done()
+    return ShardedResult(kept_mine, n_total, n_unique, n_edges, int(n_clusters), n_kept, "segment-routed", phases)
+
+
+def _gathered(backend, comm, tick, keys, offsets, key_len, weights, max_distance, metric, method_id, g_ragged,
+              id0, n_local, n_total) -> ShardedResult:
+    rank, world = comm.rank, comm.world
     # ---- 2. all copies of a key to its owner rank ------------------------------
     s_recs, s_lens, s_ids, s_w, send_counts = backend.pack_by_owner(keys, offsets, key_len, world, id0, weights)
     if tick:
         tick.mark("pack+group-by-owner")
-    send_counts = torch.tensor(send_counts, dtype=torch.int64, device=dev)
-    counts_in = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_to_all_single(counts_in, send_counts, group=group)
-    recv_counts = [int(c) for c in counts_in.tolist()]
-    r_recs = _all_to_all_rows(s_recs, send_counts, recv_counts, group)
-    r_ids = _all_to_all_rows(s_ids, send_counts, recv_counts, group)
-    r_lens = _all_to_all_rows(s_lens, send_counts, recv_counts, group) if g_ragged else None
-    r_w = None if s_w is None else _all_to_all_rows(s_w, send_counts, recv_counts, group)
-    # The received rows are ALREADY in global id order: all-to-all delivers source ranks in rank
-    # order, rank r's ids precede rank r+1's, and every source sent its rows in id order. The
-    # collapse's stable sort therefore makes the smallest global id the head of each run.
+    recv_counts = comm.exchange_counts(send_counts)
+    r_recs = comm.all_to_all_rows(s_recs, send_counts, recv_counts)
+    r_ids = comm.all_to_all_rows(s_ids, send_counts, recv_counts)
+    r_lens = comm.all_to_all_rows(s_lens, send_counts, recv_counts) if g_ragged else None
+    r_w = comm.all_to_all_rows(s_w, send_counts, recv_counts)
+    # Received rows are in global id order (see the segment-routed plan): the collapse's stable
+    # grouping makes the smallest global id the head of each run.
     if tick:
-        tick.mark("all-to-all")
+        tick.mark("all-to-all-reads")
     urecs, ulens, ucounts, ufirst = backend.collapse_packed(r_recs, r_lens, r_w, r_ids)
     if tick:
         tick.mark("collapse")
 
     # ---- 3. whole unique table on every rank; search this rank's bucket shard ---
-    g_recs = _all_gather_rows(urecs, group)
-    g_lens = _all_gather_rows(ulens, group) if g_ragged else None
-    g_counts = _all_gather_rows(ucounts, group)
-    g_first = _all_gather_rows(ufirst, group)
+    g_recs = comm.all_gather_rows(urecs)
+    g_lens = comm.all_gather_rows(ulens) if g_ragged else None
+    g_counts = comm.all_gather_rows(ucounts)
+    g_first = comm.all_gather_rows(ufirst)
     if tick:
         tick.mark("all-gather-unique")
     edges = backend.find_edges(g_recs, g_lens, g_counts, g_first, max_distance, metric, rank, world)
@@ -218,12 +472,13 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
         tick.mark("find-edges")
 
     # ---- 4. all edges everywhere; components + dissection ------------------------
-    # Every rank labels and dissects the whole graph (a few percent of the job) but LISTS only
-    # the kept ids among its own reads [id0, id0 + n_local): what its pass 2 would need.
-    g_edges = _all_gather_rows(edges, group)
+    # Every rank labels and dissects the whole graph but LISTS only the kept ids among its own
+    # reads [id0, id0 + n_local): what its pass 2 would need.
+    g_edges = comm.all_gather_rows(edges)
     kept, n_clusters, n_kept = backend.finish(g_edges.contiguous(), method_id, id0, id0 + n_local)
+    phases = None
     if tick:
         tick.mark("gather-edges+finish")
-        tick.done()
+        phases = tick.done()
     return ShardedResult(kept, n_total, int(g_recs.shape[0]), int(g_edges.shape[0]), int(n_clusters),
-                         int(n_kept))
+                         int(n_kept), "gathered", phases)

@@ -147,14 +147,48 @@ int fqd_import_packed(fqd_ctx *ctx, const uint32_t *recs, const uint32_t *lens, 
 int fqd_export_packed_by_owner(fqd_ctx *ctx, uint32_t n_parts, uint64_t id0, const uint32_t *weights,
                                uint32_t *recs, uint32_t *lens, uint64_t *ids, uint32_t *weights_out,
                                uint64_t *counts, int mem);
+/* Same, with owner = hash(segment `segment` of the n_segments-way pigeonhole split, key length)
+ * % n_parts. Every copy of a key and every pair of keys that agree on that segment meet on one
+ * rank: the receiving rank collapses its reads AND runs search pass `segment` with no further key
+ * movement (sharded.py, "segment-routed" plan). */
+int fqd_export_packed_by_segment(fqd_ctx *ctx, uint32_t n_parts, uint32_t n_segments, uint32_t segment,
+                                 uint64_t id0, const uint32_t *weights, uint32_t *recs, uint32_t *lens,
+                                 uint64_t *ids, uint32_t *weights_out, uint64_t *counts, int mem);
+/* The UNIQUE table grouped the same way for a later pass: uids[i] = uid_base + row (the job-wide
+ * id of a unique key: owner rank's base + its row). recs/lens/uids DEVICE, counts HOST. */
+int fqd_export_unique_by_segment(fqd_ctx *ctx, uint32_t n_parts, uint32_t n_segments, uint32_t segment,
+                                 uint32_t uid_base, uint32_t *recs, uint32_t *lens, uint32_t *uids,
+                                 uint64_t *counts, int mem);
+/* Rows idx[0..n) of the unique table: records, lengths (may be NULL), counts. DEVICE buffers.
+ * FQD_E_VALUE when an index lies outside the table. */
+int fqd_gather_unique(fqd_ctx *ctx, const uint32_t *idx, uint64_t n, uint32_t *recs, uint32_t *lens,
+                      uint32_t *counts, int mem);
 /* Unique table of stage 2. */
 int fqd_export_unique(fqd_ctx *ctx, uint32_t *recs, uint32_t *lens, uint32_t *counts,
                       uint64_t *first_ids, int mem);
+/* counts NULL = 1 each, first_ids NULL = 0 each (a table that is only searched). */
 int fqd_import_unique(fqd_ctx *ctx, const uint32_t *recs, const uint32_t *lens,
                       const uint32_t *counts, const uint64_t *first_ids, uint64_t n_unique, int mem);
 /* Edge list of stage 3: n_edges pairs (u, v), u < v. */
 int fqd_export_edges(fqd_ctx *ctx, uint32_t *uv, int mem);
 int fqd_import_edges(fqd_ctx *ctx, const uint32_t *uv, uint64_t n_edges, int mem);
+
+/* Search passes [seg_lo, seg_hi) only of the Hamming search with max_distance (a pair is still
+ * reported in the FIRST segment it agrees on, so disjoint ranges over any placement of the keys
+ * give every edge exactly once). Same role as fqd_find_edges: Trie.pop_cluster's neighbour
+ * search, reference _triemodule.c:807-895. */
+int fqd_find_edges_segments(fqd_ctx *ctx, int max_distance, uint32_t seg_lo, uint32_t seg_hi,
+                            uint64_t *n_edges);
+/* Components of a caller's edge list over n_nodes nodes (DEVICE buffers): roots[e] = smallest
+ * node of edge e's component; *n_components = n_nodes - merges. The job-wide pop_cluster
+ * partition when the nodes are global unique ids. */
+int fqd_edge_labels(fqd_ctx *ctx, const uint32_t *uv, uint64_t n_edges, uint64_t n_nodes, uint32_t *roots,
+                    uint64_t *n_components, int mem);
+/* Kept list when the verdicts were computed on other ranks: every key of the unique table is
+ * kept except rows dropped[0..n_dropped) (DEVICE). Afterwards fqd_get_kept_count /
+ * fqd_get_kept_read_ids / fqd_get_unique_table(kept) answer as after fqd_dissect. */
+int fqd_list_kept_except(fqd_ctx *ctx, const uint32_t *dropped, uint64_t n_dropped, int mem,
+                         uint64_t *n_kept);
 
 /* ---- single calls of the reference surface --------------------------------- */
 /* out[i] = within_distance(a_i, b_i) for n pairs (_distancemodule.c:46-93). */

@@ -428,12 +428,15 @@ def test_sharded_path_on_rccl_world1(F, oracle):
         keys = torch.from_numpy(host).to(dev)
         w = np.ones(n, dtype=np.int32)
         w[::7] = 0
-        for d, m in ((1, "directional"), (2, "adjacency"), (1, "highest_count")):
+        for d, m, plan in ((1, "directional", "segment-routed"), (2, "adjacency", "segment-routed"),
+                           (1, "highest_count", "segment-routed"), (0, "directional", "segment-routed"),
+                           (1, "directional", "gathered"), (2, "adjacency", "gathered")):
             got = cluster_keys_sharded(backend, keys, None, L, torch.from_numpy(w).to(dev),
-                                       max_distance=d, method=m)
+                                       max_distance=d, method=m, plan=plan)
             want = oracle.dedup(host, fixed_offsets(n, L), w.astype(np.uint32), max_distance=d, method=m)
-            assert got.n_unique == want["n_unique"] and got.n_clusters == want["n_clusters"]
-            assert np.array_equal(got.kept_read_ids.cpu().numpy().astype(np.uint64), want["kept_read_ids"]), (d, m)
+            assert got.plan == plan
+            assert got.n_unique == want["n_unique"] and got.n_clusters == want["n_clusters"], (d, m, plan)
+            assert np.array_equal(got.kept_read_ids.cpu().numpy().astype(np.uint64), want["kept_read_ids"]), (d, m, plan)
             assert got.n_kept == len(want["kept_read_ids"])
         # ragged + edit metric through the same path
         rag = ["ACGTACGTAC", "ACGTACGTA", "ACGTACGTACG", "TTTTTTTTTT", "TTTTTTTTT", "GGGGG"] * 50

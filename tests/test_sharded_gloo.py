@@ -1,6 +1,7 @@
 """The multi-GPU orchestration (fastqdedup_amd/sharded.py) on 2 and 3 CPU ranks
-over gloo: geometry agreement, all-to-all by key owner, all-gather of the unique
-table and of the edge shards, global read ids. The arithmetic is a numpy stand-in
+over gloo, both plans: geometry agreement, all-to-all by owner, segment-routed search
+passes / all-gather of the unique table, edge all-gather, clusters dissected away from
+their owners, verdicts and kept ids sent home, global read ids. The arithmetic is a numpy stand-in
 (tests only; production uses HipBackend); the answer is checked against the CPU
 oracle run on the concatenation of every rank's reads."""
 import os
@@ -51,19 +52,108 @@ class NumpyBackend:
         self.max_len = int(max_len)
         self.stride = max(1, (self.max_len + 3) // 4)
 
-    def pack_by_owner(self, keys, offsets, key_len, n_parts, id0, weights):
-        ks = self._split(keys, offsets, key_len)
-        owner = np.array([zlib.crc32(k) % n_parts for k in ks], dtype=np.int64)
-        order = np.argsort(owner, kind="stable")
+    @staticmethod
+    def _segment(key, s, nseg):
+        return key[s * len(key) // nseg:(s + 1) * len(key) // nseg]
+
+    def _seg_owner(self, key, s, nseg, n_parts):
+        return zlib.crc32(bytes([len(key) & 255, s]) + self._segment(key, s, nseg)) % n_parts
+
+    def _first_agreeing(self, a, b, nseg):
+        if len(a) != len(b):
+            return None
+        for s in range(nseg):
+            if self._segment(a, s, nseg) == self._segment(b, s, nseg):
+                return s
+        return None
+
+    def _rows_of(self, ks):
         recs = np.zeros((len(ks), self.stride * 4), dtype=np.uint8)
-        for row, i in enumerate(order):
-            recs[row, :len(ks[i])] = np.frombuffer(ks[i], dtype=np.uint8)
-        lens = np.array([len(ks[i]) for i in order], dtype=np.int32)
+        for row, k in enumerate(ks):
+            recs[row, :len(k)] = np.frombuffer(k, dtype=np.uint8)
+        lens = torch.tensor([len(k) for k in ks], dtype=torch.int32)
+        return (torch.from_numpy(recs.view(np.int32).reshape(len(ks), self.stride).copy()),
+                lens if self.ragged else None)
+
+    def pack_by_owner(self, keys, offsets, key_len, n_parts, id0, weights, n_segments=0):
+        ks = self._split(keys, offsets, key_len)
+        if n_segments:
+            self.max_distance = n_segments - 1
+            owner = np.array([self._seg_owner(k, 0, n_segments, n_parts) for k in ks], dtype=np.int64)
+        else:
+            owner = np.array([zlib.crc32(k) % n_parts for k in ks], dtype=np.int64)
+        order = np.argsort(owner, kind="stable")
+        recs, lens = self._rows_of([ks[i] for i in order])
         ids = torch.from_numpy((id0 + order).astype(np.int64))
         w = None if weights is None else torch.from_numpy(np.asarray(weights, dtype=np.int32)[order].copy())
         counts = np.bincount(owner, minlength=n_parts).tolist()
-        return (torch.from_numpy(recs.view(np.int32).reshape(len(ks), self.stride).copy()),
-                torch.from_numpy(lens) if self.ragged else None, ids, w, counts)
+        return recs, lens, ids, w, counts
+
+    # -- segment-routed plan ---------------------------------------------------
+    def collapse_resident(self, recs, lens, weights, read_ids):
+        urecs, ulens, ucounts, ufirst = self.collapse_packed(recs, lens, weights, read_ids)
+        self.table = self._decode(urecs, ulens)
+        self.table_counts, self.table_first = ucounts.tolist(), ufirst.tolist()
+        return len(self.table)
+
+    def _pass_edges(self, ks, d, s):
+        out = []
+        for u in range(len(ks)):
+            for v in range(u + 1, len(ks)):
+                if self._first_agreeing(ks[u], ks[v], d + 1) == s and self.O.within_distance(
+                        ks[u].decode("latin-1"), ks[v].decode("latin-1"), d, False):
+                    out.append((u, v))
+        return torch.tensor(out, dtype=torch.int32).reshape(-1, 2)
+
+    def local_edges(self, d, seg_lo, seg_hi):
+        parts = [self._pass_edges(self.table, d, s) for s in range(seg_lo, seg_hi)]
+        return torch.cat(parts) if parts else torch.empty((0, 2), dtype=torch.int32)
+
+    def unique_by_segment(self, n_parts, n_segments, segment, uid_base):
+        owner = np.array([self._seg_owner(k, segment, n_segments, n_parts) for k in self.table], dtype=np.int64)
+        order = np.argsort(owner, kind="stable")
+        recs, lens = self._rows_of([self.table[i] for i in order])
+        uids = torch.from_numpy((uid_base + order).astype(np.int32))
+        return recs, lens, uids, np.bincount(owner, minlength=n_parts).tolist()
+
+    def routed_edges(self, recs, lens, uids, d, segment):
+        e = self._pass_edges(self._decode(recs, lens), d, segment)
+        return uids[e.long()] if e.shape[0] else e
+
+    def edge_labels(self, edges, n_nodes):
+        parent = list(range(n_nodes))
+
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        hooks = 0
+        for u, v in edges.tolist():
+            ru, rv = find(u), find(v)
+            if ru != rv:
+                parent[max(ru, rv)] = min(ru, rv)
+                hooks += 1
+        return torch.tensor([find(u) for u, _ in edges.tolist()], dtype=torch.int32), n_nodes - hooks
+
+    def gather_unique(self, rows):
+        sel = rows.tolist()
+        recs, lens = self._rows_of([self.table[i] for i in sel])
+        return recs, lens, torch.tensor([self.table_counts[i] for i in sel], dtype=torch.int32)
+
+    def dissect_subgraph(self, recs, lens, counts, edges, method):
+        self.keys = [k.decode("latin-1") for k in self._decode(recs, lens)]
+        self.counts, self.first = counts.tolist(), list(range(len(self.keys)))
+        self.d, self.edit = self.max_distance, False
+        kept, _, _ = self.finish(edges, method, 0, len(self.keys))
+        flags = torch.zeros(len(self.keys), dtype=torch.uint8)
+        flags[kept] = 1
+        return flags
+
+    def finish_owner(self, dropped_rows, id_hi):
+        gone = set(dropped_rows.tolist())
+        kept = sorted(f for i, f in enumerate(self.table_first) if i not in gone)
+        return torch.tensor(kept, dtype=torch.int64), len(kept)
 
     def collapse_packed(self, recs, lens, weights, read_ids):
         ks = self._decode(recs, lens)
@@ -124,7 +214,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, shards, d, method, weights, q):
+def _worker(rank, world, port, shards, d, method, weights, plan, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -136,15 +226,17 @@ def _worker(rank, world, port, shards, d, method, weights, q):
         raw = np.frombuffer(b"".join(keys) or b"", dtype=np.uint8)
         off = np.concatenate([[0], np.cumsum([len(k) for k in keys])]).astype(np.uint64)
         w = None if weights is None else np.asarray(weights[rank], dtype=np.int32)
-        res = cluster_keys_sharded(NumpyBackend(O), raw, off, 0, w, max_distance=d, method=method)
+        res = cluster_keys_sharded(NumpyBackend(O), raw, off, 0, w, max_distance=d, method=method, plan=plan)
+        assert res.plan == plan
         q.put((rank, res.kept_read_ids.tolist(), res.n_clusters, res.n_unique, res.n_reads, res.n_kept))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("plan", ["segment-routed", "gathered"])
 @pytest.mark.parametrize("world,d,method,ragged", [(2, 1, "directional", True), (2, 2, "adjacency", False),
                                                    (3, 1, "highest_count", True)])
-def test_sharded_job_equals_single_job(oracle, world, d, method, ragged):
+def test_sharded_job_equals_single_job(oracle, world, d, method, ragged, plan):
     from fastqdedup_amd.synth import synth_keys
     n, L = 240, 12
     allk = [bytes(r) for r in synth_keys(n, L, 4, 5 + world, sub_rate=0.02, n_rate=0.01)]
@@ -162,7 +254,7 @@ def test_sharded_job_equals_single_job(oracle, world, d, method, ragged):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shards, d, method, wshards, q))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shards, d, method, wshards, plan, q))
              for r in range(world)]
     for p in procs:
         p.start()

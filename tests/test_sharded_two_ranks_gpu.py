@@ -1,7 +1,8 @@
-"""Two ranks of the production multi-GPU path on ONE MI355X: both processes run the
-arithmetic on GPU 0 through HipBackend (every C-ABI export/import, owner grouping with 2
-parts, 2-shard bucket search, id windows) while the collectives go over gloo on host copies
-(RCCL refuses two ranks on one device). Checked against the CPU oracle. GPU only."""
+"""Two and three ranks of the production multi-GPU path on ONE MI355X, both plans: every
+process runs the arithmetic on GPU 0 through HipBackend (every C-ABI export/import, owner
+grouping, segment-routed search passes, clusters dissected away from their owners, id
+windows) while the collectives go over gloo on host copies (RCCL refuses two ranks on one
+device; ``comm_via_host``). Checked against the CPU oracle. GPU only."""
 import os
 import socket
 
@@ -20,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, q):
+def _worker(rank, world, port, case, plan, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -30,73 +31,23 @@ def _worker(rank, world, port, case, q):
         from fastqdedup_amd.sharded import HipBackend, cluster_keys_sharded
 
         gpu = torch.device("cuda", 0)
-
-        class HostComm(HipBackend):
-            """HipBackend whose results are handed to the orchestrator as host tensors."""
-
-            def __init__(self, ctx):
-                super().__init__(ctx, gpu)
-                self.device = torch.device("cpu")
-
-            @staticmethod
-            def _up(x):
-                return None if x is None else (x.to(gpu) if torch.is_tensor(x) else x)
-
-            @staticmethod
-            def _down(xs):
-                return tuple(x.cpu() if torch.is_tensor(x) else x for x in xs)
-
-            def pack_by_owner(self, keys, offsets, key_len, n_parts, id0, weights):
-                self.device = gpu
-                try:
-                    out = super().pack_by_owner(self._up(keys), self._up(offsets), key_len, n_parts, id0,
-                                                self._up(weights))
-                finally:
-                    self.device = torch.device("cpu")
-                return self._down(out)
-
-            def scan(self, keys, offsets, key_len):
-                return super().scan(self._up(keys), self._up(offsets), key_len)
-
-            def collapse_packed(self, recs, lens, weights, read_ids):
-                self.device = gpu
-                try:
-                    out = super().collapse_packed(self._up(recs), self._up(lens), self._up(weights),
-                                                  self._up(read_ids))
-                finally:
-                    self.device = torch.device("cpu")
-                return self._down(out)
-
-            def find_edges(self, urecs, ulens, ucounts, ufirst, d, metric, shard, n_shards):
-                self.device = gpu
-                try:
-                    out = super().find_edges(self._up(urecs), self._up(ulens), self._up(ucounts),
-                                             self._up(ufirst), d, metric, shard, n_shards)
-                finally:
-                    self.device = torch.device("cpu")
-                return out.cpu()
-
-            def finish(self, edges, method, id_lo, id_hi):
-                self.device = gpu
-                try:
-                    kept, ncl, nk = super().finish(self._up(edges), method, id_lo, id_hi)
-                finally:
-                    self.device = torch.device("cpu")
-                return kept.cpu(), ncl, nk
-
         keys, offsets, key_len, weights, d, edit, method = case[rank]
-        k = torch.from_numpy(keys)
-        o = None if offsets is None else torch.from_numpy(offsets.astype(np.int64))
-        w = None if weights is None else torch.from_numpy(weights.astype(np.int32))
-        res = cluster_keys_sharded(HostComm(F.Context(0)), k, o, key_len, w, max_distance=d,
-                                   use_edit_distance=edit, method=method)
+        k = torch.from_numpy(keys).to(gpu)
+        o = None if offsets is None else torch.from_numpy(offsets.astype(np.int64)).to(gpu)
+        w = None if weights is None else torch.from_numpy(weights.astype(np.int32)).to(gpu)
+        # the production backend on the GPU; only the collectives detour through host memory
+        res = cluster_keys_sharded(HipBackend(F.Context(0), gpu), k, o, key_len, w, max_distance=d,
+                                   use_edit_distance=edit, method=method, plan=plan, comm_via_host=True)
+        assert res.plan == ("gathered" if edit else plan)
         q.put((rank, res.kept_read_ids.tolist(), res.n_clusters, res.n_unique, res.n_kept, res.n_reads))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shape", ["fixed32", "fixed100_weights", "ragged_edit"])
-def test_two_ranks_on_one_gpu(oracle, shape):
+@pytest.mark.parametrize("shape,plan", [("fixed32", "segment-routed"), ("fixed32", "gathered"),
+                                        ("fixed100_weights", "segment-routed"), ("fixed100_weights", "gathered"),
+                                        ("ragged_hamming3", "segment-routed"), ("ragged_edit", "gathered")])
+def test_ranks_on_one_gpu(oracle, shape, plan):
     from fastqdedup_amd.synth import fixed_offsets, synth_keys
     world = 2
     if shape == "fixed32":
@@ -116,6 +67,26 @@ def test_two_ranks_on_one_gpu(oracle, shape):
                 (allk[cut:].reshape(-1), None, L, w[cut:], d, edit, method)]
         raw, off = allk.reshape(-1), fixed_offsets(n, L)
         cuts = [0, cut, n]
+    elif shape == "ragged_hamming3":
+        # three ranks (one of them empty), two key lengths, weights with zeros, d = 2
+        world = 3
+        a = synth_keys(30_000, 24, 8, 8, sub_rate=4e-3, n_rate=3e-4)
+        b = synth_keys(20_000, 20, 8, 9, sub_rate=4e-3, n_rate=3e-4)
+        enc = [bytes(r) for r in a] + [bytes(r) for r in b]
+        np.random.default_rng(3).shuffle(enc)
+        n, d, edit, method = len(enc), 2, False, "directional"
+        w = np.random.default_rng(2).choice(np.array([0, 1, 1, 3], dtype=np.uint32), size=n)
+        cuts = [0, 21_000, 21_000, n]
+
+        def pk(part):
+            r = np.frombuffer(b"".join(part), dtype=np.uint8).copy()
+            o = np.concatenate([[0], np.cumsum([len(e) for e in part])]).astype(np.uint64)
+            return r, o
+        case = []
+        for r in range(world):
+            rr, oo = pk(enc[cuts[r]:cuts[r + 1]])
+            case.append((rr, oo, 0, w[cuts[r]:cuts[r + 1]], d, edit, method))
+        raw, off = pk(enc)
     else:
         import random
         rng = random.Random(4)
@@ -145,7 +116,7 @@ def test_two_ranks_on_one_gpu(oracle, shape):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, plan, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(world)]
