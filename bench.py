@@ -199,6 +199,12 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed
+    # one more, UNTIMED step with a device sync after every phase: where a sharded step spends its time
+    phases = None
+    if sharded:
+        phases = cluster_keys_sharded(backend, keys, None, L, max_distance=wl["d"], use_edit_distance=wl["edit"],
+                                      method=wl["method"], timing=True).phases_ms
+        fence()
 
     # ---- roofline of the dominant hand-written kernel (DESIGN.md "kernels") --------
     # Every hand-written kernel of the step is timed live with HIP events on the context's stream
@@ -272,8 +278,8 @@ def main():
         "config": {"workload": wl["name"], "reads_per_gpu": n, "reads_total": n_total, "key_len": L,
                    "max_distance": wl["d"], "metric": "edit" if wl["edit"] else "hamming",
                    "dissection": wl["method"], "seed": wl["seed"],
-                   "parallelism": "1 process/GPU, key-hash all-to-all + bucket-sharded search" if world > 1
-                   else "single GPU"},
+                   "parallelism": (f"1 process/GPU over RCCL, plan {res.plan} (fastqdedup_amd/sharded.py)"
+                                   if sharded else "single GPU")},
         "result": {"n_unique": res.n_unique, "n_edges": res.n_edges, "n_clusters": res.n_clusters,
                    "n_kept": res.n_kept},
         "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_sum.items()},
@@ -282,6 +288,8 @@ def main():
         "kernels": kernels,
         "host_input": pcie,
     }
+    if phases is not None:
+        out["sharded_phases_ms_rank0"] = phases
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(ctx, wl, args.cpu_sample)

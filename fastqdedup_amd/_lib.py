@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfqdedup_hip.so")
 
-HOST, DEVICE = 0, 1
+HOST, DEVICE, DEVICE_BORROW = 0, 1, 2
 METRIC_HAMMING, METRIC_EDIT = 0, 1
 METHODS = {"highest_count": 0, "adjacency": 1, "directional": 2}
 T_PACK, T_COLLAPSE, T_EDGES, T_COMPONENTS, T_DISSECT, T_PAIRS_KERNEL, T_COUNT = 0, 1, 2, 3, 4, 5, 8
@@ -127,6 +127,15 @@ def _raise(code: int, msg: str):
     if code == E_LOOKUP:
         raise LookupError(msg)
     raise RuntimeError(msg)
+
+
+def _contiguous(x) -> bool:
+    """True when _ptr_mem(x) points into x itself (not into a temporary contiguous copy)."""
+    if x is None:
+        return True
+    if isinstance(x, np.ndarray):
+        return bool(x.flags["C_CONTIGUOUS"])
+    return bool(x.is_contiguous())
 
 
 def _ptr_mem(x):
@@ -362,10 +371,12 @@ class Context:
         self._ck(self._L.fqd_list_kept_except(self._h, dp, int(n_dropped), DEVICE, C.byref(nk)))
         return nk.value
 
-    def import_packed(self, recs, lens, n: int):
+    def import_packed(self, recs, lens, n: int, borrow: bool = False):
+        """borrow: read the (device) buffers in place; keep them alive until collapse() returned."""
+        borrow = borrow and _contiguous(recs) and _contiguous(lens)
         rp, rm, _1 = _ptr_mem(recs)
         lp, lm, _2 = _ptr_mem(lens)
-        self._ck(self._L.fqd_import_packed(self._h, rp, lp, int(n), rm))
+        self._ck(self._L.fqd_import_packed(self._h, rp, lp, int(n), DEVICE_BORROW if borrow and rm == DEVICE else rm))
 
     def export_unique(self, recs, lens, counts, first_ids):
         rp, rm, _1 = _ptr_mem(recs)
@@ -374,12 +385,15 @@ class Context:
         fp, _m, _4 = _ptr_mem(first_ids)
         self._ck(self._L.fqd_export_unique(self._h, rp, lp, cp, fp, rm))
 
-    def import_unique(self, recs, lens, counts, first_ids, n_unique: int):
+    def import_unique(self, recs, lens, counts, first_ids, n_unique: int, borrow: bool = False):
+        """borrow: records/lengths are read in place; keep them alive while this table is in use."""
+        borrow = borrow and _contiguous(recs) and _contiguous(lens)
         rp, rm, _1 = _ptr_mem(recs)
         lp, _m, _2 = _ptr_mem(lens)
         cp, _m, _3 = _ptr_mem(counts)
         fp, _m, _4 = _ptr_mem(first_ids)
-        self._ck(self._L.fqd_import_unique(self._h, rp, lp, cp, fp, int(n_unique), rm))
+        self._ck(self._L.fqd_import_unique(self._h, rp, lp, cp, fp, int(n_unique),
+                                           DEVICE_BORROW if borrow and rm == DEVICE else rm))
 
     def export_edges(self, uv):
         p, m, _ = _ptr_mem(uv)

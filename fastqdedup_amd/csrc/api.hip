@@ -18,8 +18,14 @@ std::string g_global_error;
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool borrowed = false;   // p belongs to the caller (FQD_DEVICE_BORROW): never freed, never reused
     hipError_t reserve(size_t bytes)
     {
+        if (borrowed) {
+            p = nullptr;
+            cap = 0;
+            borrowed = false;
+        }
         if (bytes <= cap)
             return hipSuccess;
         if (p)
@@ -34,10 +40,19 @@ struct DevBuf {
     }
     void release()
     {
-        if (p)
+        if (p && !borrowed)
             (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        borrowed = false;
+    }
+    // Use the caller's device buffer in place (no copy); the next reserve() lets go of it.
+    void borrow(const void *ptr, size_t bytes)
+    {
+        release();
+        p = const_cast<void *>(ptr);
+        cap = bytes;
+        borrowed = true;
     }
     template <typename T>
     T *as() const { return reinterpret_cast<T *>(p); }
@@ -1265,19 +1280,35 @@ static int export_grouped(fqd_ctx *c, uint64_t n, uint32_t n_parts, const uint32
                           uint32_t *lens, uint64_t *ids, uint32_t *ids32, uint32_t *weights_out, uint64_t *counts)
 {
     const KeyShape sh = c->ks;
-    int bits = 1;
-    while ((1u << bits) < n_parts)
-        bits++;
-    HIP_TRY(c, c->ids.reserve(n * 4 + 16));
     HIP_TRY(c, c->ids_sorted.reserve(n * 4 + 16));
-    HIP_TRY(c, c->run_idx.reserve(n * 4 + 16));
-    uint32_t *owner_sorted = c->run_idx.as<uint32_t>();
-    HIP_TRY(c, fqd::launch_iota_u32(c->ids.as<uint32_t>(), n, c->st));
-    FQD_TRY(sort_u32_pairs(c, owner, owner_sorted, c->ids.as<uint32_t>(), c->ids_sorted.as<uint32_t>(), n, bits));
-    HIP_TRY(c, fqd::launch_gather_by_owner(c->ids_sorted.as<uint32_t>(), n, sh, src_recs, src_lens, weights, id0, recs,
-                                           lens, ids, ids32, weights_out, c->st));
     HIP_TRY(c, c->stage_d.reserve((size_t)n_parts * 8 + 16));
-    HIP_TRY(c, fqd::launch_owner_counts(owner_sorted, n, n_parts, c->stage_d.as<uint64_t>(), c->st));
+    uint32_t *order = c->ids_sorted.as<uint32_t>();
+    if (n == 0) {
+        std::fill(counts, counts + n_parts, 0ull);
+        return FQD_OK;
+    }
+    if (n_parts <= fqd::split_max_parts() && !getenv("FQD_GROUP_BY_SORT")) {
+        // stable multi-split: count per (part, tile), scan, place
+        const size_t cells = (size_t)n_parts * fqd::split_tiles(n);
+        HIP_TRY(c, c->ld_matrix.reserve(cells * 4 + 16));
+        HIP_TRY(c, c->ld_matrix_incl.reserve(cells * 4 + 16));
+        HIP_TRY(c, fqd::launch_split_count(owner, n, n_parts, c->ld_matrix.as<uint32_t>(), c->st));
+        FQD_TRY(scan_u32(c, c->ld_matrix.as<uint32_t>(), c->ld_matrix_incl.as<uint32_t>(), cells));
+        HIP_TRY(c, fqd::launch_split_order(owner, n, n_parts, c->ld_matrix.as<uint32_t>(),
+                                           c->ld_matrix_incl.as<uint32_t>(), order, c->stage_d.as<uint64_t>(), c->st));
+    } else {
+        int bits = 1;
+        while ((1u << bits) < n_parts)
+            bits++;
+        HIP_TRY(c, c->ids.reserve(n * 4 + 16));
+        HIP_TRY(c, c->run_idx.reserve(n * 4 + 16));
+        uint32_t *owner_sorted = c->run_idx.as<uint32_t>();
+        HIP_TRY(c, fqd::launch_iota_u32(c->ids.as<uint32_t>(), n, c->st));
+        FQD_TRY(sort_u32_pairs(c, owner, owner_sorted, c->ids.as<uint32_t>(), order, n, bits));
+        HIP_TRY(c, fqd::launch_owner_counts(owner_sorted, n, n_parts, c->stage_d.as<uint64_t>(), c->st));
+    }
+    HIP_TRY(c, fqd::launch_gather_by_owner(order, n, sh, src_recs, src_lens, weights, id0, recs, lens, ids, ids32,
+                                           weights_out, c->st));
     HIP_TRY(c, hipMemcpyAsync(counts, c->stage_d.p, (size_t)n_parts * 8, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     return FQD_OK;
@@ -1385,13 +1416,18 @@ int fqd_edge_labels(fqd_ctx *c, const uint32_t *uv, uint64_t E, uint64_t n_nodes
     if (bad)
         return fail(c, FQD_E_VALUE, "edge end outside [0, n_nodes)");
     HIP_TRY(c, c->stage_a.reserve(n_nodes * 4 + 16));
+    HIP_TRY(c, c->stage_b.reserve(FQD_HOOK_SLOTS * 64));
     uint32_t *parent = c->stage_a.as<uint32_t>();
-    FQD_TRY(zero_ctr64(c, C64_SUM));
+    HIP_TRY(c, hipMemsetAsync(c->stage_b.p, 0, FQD_HOOK_SLOTS * 64, c->st));
     HIP_TRY(c, fqd::launch_uf_init(parent, n_nodes, c->st));
-    HIP_TRY(c, fqd::launch_uf_union(parent, uv, E, c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+    HIP_TRY(c, fqd::launch_uf_union(parent, uv, E, c->stage_b.as<unsigned long long>(), c->st));
     HIP_TRY(c, fqd::launch_edge_roots(parent, uv, E, roots, c->st));
+    std::vector<unsigned long long> slots((size_t)FQD_HOOK_SLOTS * 8);
+    HIP_TRY(c, hipMemcpyAsync(slots.data(), c->stage_b.p, FQD_HOOK_SLOTS * 64, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
     unsigned long long hooks = 0;
-    FQD_TRY(read_ctr64(c, C64_SUM, &hooks));
+    for (size_t i = 0; i < slots.size(); i += 8)
+        hooks += slots[i];
     if (n_components)
         *n_components = n_nodes - hooks;
     return FQD_OK;
@@ -1437,17 +1473,26 @@ int fqd_import_packed(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, ui
     if (n >= 0xFFFFFFF0ull)
         return fail(c, FQD_E_VALUE, "at most 2^32-16 keys per context");
     const KeyShape sh = c->ks;
-    const hipMemcpyKind kind = mem == FQD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    HIP_TRY(c, c->recs.reserve((size_t)n * sh.stride * 4 + 16));
+    const hipMemcpyKind kind = mem == FQD_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    const bool borrow = mem == FQD_DEVICE_BORROW && n > 0;
+    if (sh.ragged && !lens)
+        return fail(c, FQD_E_VALUE, "ragged geometry needs lens");
     HIP_TRY(c, c->hashes.reserve((size_t)n * 4 + 16));
-    if (n)
-        HIP_TRY(c, hipMemcpyAsync(c->recs.p, recs, (size_t)n * sh.stride * 4, kind, c->st));
-    if (sh.ragged) {
-        if (!lens)
-            return fail(c, FQD_E_VALUE, "ragged geometry needs lens");
-        HIP_TRY(c, c->lens.reserve((size_t)n * 4 + 16));
+    if (borrow) {
+        if ((uintptr_t)recs & 15u)
+            return fail(c, FQD_E_VALUE, "borrowed record buffer must be 16-byte aligned");
+        c->recs.borrow(recs, (size_t)n * sh.stride * 4);
+        if (sh.ragged)
+            c->lens.borrow(lens, (size_t)n * 4);
+    } else {
+        HIP_TRY(c, c->recs.reserve((size_t)n * sh.stride * 4 + 16));
         if (n)
-            HIP_TRY(c, hipMemcpyAsync(c->lens.p, lens, (size_t)n * 4, kind, c->st));
+            HIP_TRY(c, hipMemcpyAsync(c->recs.p, recs, (size_t)n * sh.stride * 4, kind, c->st));
+        if (sh.ragged) {
+            HIP_TRY(c, c->lens.reserve((size_t)n * 4 + 16));
+            if (n)
+                HIP_TRY(c, hipMemcpyAsync(c->lens.p, lens, (size_t)n * 4, kind, c->st));
+        }
     }
     HIP_TRY(c, fqd::launch_hash_records(c->recs.as<uint32_t>(), c->lens.as<uint32_t>(), n, sh,
                                         c->hashes.as<uint32_t>(), c->st));
@@ -1486,17 +1531,29 @@ int fqd_import_unique(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, co
     if (U >= 0xFFFFFFF0ull)
         return fail(c, FQD_E_VALUE, "at most 2^32-16 unique keys per context");
     const KeyShape sh = c->ks;
-    const hipMemcpyKind kind = mem == FQD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    HIP_TRY(c, c->urecs.reserve(U * sh.stride * 4 + 16));
-    HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
+    const hipMemcpyKind kind = mem == FQD_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    const bool borrow = mem == FQD_DEVICE_BORROW && U > 0;   // records and lengths stay where they are
+    if (sh.ragged && !lens && U)
+        return fail(c, FQD_E_VALUE, "ragged geometry needs lens");
+    if (borrow) {
+        if ((uintptr_t)recs & 15u)
+            return fail(c, FQD_E_VALUE, "borrowed record buffer must be 16-byte aligned");
+        c->urecs.borrow(recs, U * sh.stride * 4);
+        if (sh.ragged)
+            c->ulens.borrow(lens, U * 4);
+        else
+            HIP_TRY(c, c->ulens.reserve(16));
+    } else {
+        HIP_TRY(c, c->urecs.reserve(U * sh.stride * 4 + 16));
+        HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
+    }
     HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
     HIP_TRY(c, c->ufirst.reserve(U * 8 + 16));
     if (U) {
-        HIP_TRY(c, hipMemcpyAsync(c->urecs.p, recs, U * sh.stride * 4, kind, c->st));
-        if (sh.ragged) {
-            if (!lens)
-                return fail(c, FQD_E_VALUE, "ragged geometry needs lens");
-            HIP_TRY(c, hipMemcpyAsync(c->ulens.p, lens, U * 4, kind, c->st));
+        if (!borrow) {
+            HIP_TRY(c, hipMemcpyAsync(c->urecs.p, recs, U * sh.stride * 4, kind, c->st));
+            if (sh.ragged)
+                HIP_TRY(c, hipMemcpyAsync(c->ulens.p, lens, U * 4, kind, c->st));
         }
         // a table used only for a neighbour search (a routed pass) needs neither column
         if (counts)

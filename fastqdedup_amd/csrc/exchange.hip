@@ -49,6 +49,99 @@ __global__ __launch_bounds__(256) void gather_by_owner_kernel(const uint32_t *__
     }
 }
 
+// ---- stable multi-split (parts <= SPLIT_MAX_PARTS): two light passes instead of a radix sort ----
+// A tile is SPLIT_TILE consecutive rows; matrix[p * n_tiles + t] = rows of tile t owned by p. An
+// inclusive scan of the flat matrix (part-major) turns it into destination offsets.
+constexpr uint32_t SPLIT_TILE = 2048, SPLIT_THREADS = 256, SPLIT_MAX_PARTS = 256;
+
+__global__ __launch_bounds__(SPLIT_THREADS) void split_count_kernel(const uint32_t *__restrict__ owner, uint64_t n,
+                                                                    uint32_t parts, uint32_t n_tiles,
+                                                                    uint32_t *__restrict__ matrix)
+{
+    __shared__ uint32_t cnt[SPLIT_MAX_PARTS];
+    for (uint32_t p = threadIdx.x; p < parts; p += SPLIT_THREADS)
+        cnt[p] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * SPLIT_TILE;
+    for (uint32_t k = 0; k < SPLIT_TILE; k += SPLIT_THREADS) {
+        const uint64_t i = base + k + threadIdx.x;
+        if (i < n)
+            atomicAdd(&cnt[owner[i]], 1u);
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < parts; p += SPLIT_THREADS)
+        matrix[(size_t)p * n_tiles + blockIdx.x] = cnt[p];
+}
+
+// order[dst] = source row, dst = rows of smaller parts + rows of this part in earlier tiles +
+// rows of this part earlier in the tile (stable: every part keeps its rows in input order).
+__global__ __launch_bounds__(SPLIT_THREADS) void split_order_kernel(const uint32_t *__restrict__ owner, uint64_t n,
+                                                                    uint32_t parts, uint32_t n_tiles,
+                                                                    const uint32_t *__restrict__ matrix,
+                                                                    const uint32_t *__restrict__ matrix_incl,
+                                                                    uint32_t *__restrict__ order)
+{
+    constexpr uint32_t WAVES = SPLIT_THREADS / 64;
+    __shared__ uint32_t running[SPLIT_MAX_PARTS];          // next free slot of part p for this tile
+    __shared__ uint32_t wave_cnt[WAVES][SPLIT_MAX_PARTS];  // rows of part p in wave w, this round
+    for (uint32_t p = threadIdx.x; p < parts; p += SPLIT_THREADS) {
+        const size_t m = (size_t)p * n_tiles + blockIdx.x;
+        running[p] = matrix_incl[m] - matrix[m];
+        for (uint32_t w = 0; w < WAVES; w++)
+            wave_cnt[w][p] = 0;
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * SPLIT_TILE;
+    for (uint32_t k = 0; k < SPLIT_TILE; k += SPLIT_THREADS) {
+        const uint64_t i = base + k + threadIdx.x;
+        const bool live = i < n;
+        const uint32_t o = live ? owner[i] : 0xFFFFFFFFu;
+        // rank among the wave's earlier lanes with the same owner: one ballot per distinct owner
+        uint32_t rank = 0;
+        unsigned long long todo = __ballot(live);
+        while (todo) {
+            const uint32_t lead = __shfl(o, __ffsll((long long)todo) - 1);
+            const unsigned long long same = __ballot(live && o == lead);
+            if (o == lead) {
+                rank = (uint32_t)__popcll(same & fqd_lanemask_lt());
+                if (rank == 0)
+                    wave_cnt[wave][lead] = (uint32_t)__popcll(same);
+            }
+            todo &= ~same;
+        }
+        __syncthreads();
+        if (live) {
+            uint32_t before = running[o];
+            for (uint32_t w = 0; w < wave; w++)
+                before += wave_cnt[w][o];
+            order[before + rank] = (uint32_t)i;
+        }
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < parts; p += SPLIT_THREADS) {
+            uint32_t add = 0;
+            for (uint32_t w = 0; w < WAVES; w++) {
+                add += wave_cnt[w][p];
+                wave_cnt[w][p] = 0;
+            }
+            running[p] += add;
+        }
+        __syncthreads();
+    }
+}
+
+// counts[p] = rows of part p, from the scanned matrix
+__global__ void split_totals_kernel(const uint32_t *__restrict__ matrix_incl, uint32_t parts, uint32_t n_tiles,
+                                    uint64_t *__restrict__ counts)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= parts)
+        return;
+    const uint32_t hi = matrix_incl[(size_t)(p + 1) * n_tiles - 1];
+    const uint32_t lo = p ? matrix_incl[(size_t)p * n_tiles - 1] : 0u;
+    counts[p] = hi - lo;
+}
+
 // counts[p] = number of sorted owners equal to p (binary search, one thread per part)
 __global__ void owner_counts_kernel(const uint32_t *__restrict__ owner_sorted, uint64_t n, uint32_t parts,
                                     uint64_t *__restrict__ counts)
@@ -91,6 +184,28 @@ hipError_t launch_gather_by_owner(const uint32_t *order, uint64_t n, KeyShape sh
         gather_by_owner_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(order, n, sh, recs, lens, weights, id0,
                                                                                 recs_out, lens_out, ids_out,
                                                                                 ids32_out, weights_out);
+    }
+    return hipGetLastError();
+}
+
+uint32_t split_tiles(uint64_t n) { return (uint32_t)((n + SPLIT_TILE - 1) / SPLIT_TILE); }
+uint32_t split_max_parts() { return SPLIT_MAX_PARTS; }
+
+hipError_t launch_split_count(const uint32_t *owner, uint64_t n, uint32_t parts, uint32_t *matrix, hipStream_t st)
+{
+    const uint32_t tiles = split_tiles(n);
+    if (tiles)
+        split_count_kernel<<<tiles, SPLIT_THREADS, 0, st>>>(owner, n, parts, tiles, matrix);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_order(const uint32_t *owner, uint64_t n, uint32_t parts, const uint32_t *matrix,
+                              const uint32_t *matrix_incl, uint32_t *order, uint64_t *counts, hipStream_t st)
+{
+    const uint32_t tiles = split_tiles(n);
+    if (tiles) {
+        split_order_kernel<<<tiles, SPLIT_THREADS, 0, st>>>(owner, n, parts, tiles, matrix, matrix_incl, order);
+        split_totals_kernel<<<(parts + 63) / 64, 64, 0, st>>>(matrix_incl, parts, tiles, counts);
     }
     return hipGetLastError();
 }

@@ -204,7 +204,8 @@ hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, u
 struct PairStats {
     unsigned long long keys_gathered, pairs_compared, edges;
 };
-#define FQD_STAT_SLOTS 64  // the pair kernel spreads its block totals over this many PairStats
+#define FQD_STAT_SLOTS 64
+#define FQD_HOOK_SLOTS 256   // uf_union_kernel's hook counters (one 64-byte line each)  // the pair kernel spreads its block totals over this many PairStats
 hipError_t launch_bucket_pairs(const uint32_t *sorted_hash, const uint32_t *sorted_uid, uint64_t U,
                                const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d,
                                uint32_t seg, uint32_t nseg, uint32_t shard, uint32_t n_shards,
@@ -236,6 +237,11 @@ hipError_t launch_gather_by_owner(const uint32_t *order, uint64_t n, KeyShape sh
                                   const uint32_t *lens, const uint32_t *weights, uint64_t id0, uint32_t *recs_out,
                                   uint32_t *lens_out, uint64_t *ids_out, uint32_t *ids32_out, uint32_t *weights_out,
                                   hipStream_t st);
+uint32_t split_tiles(uint64_t n);
+uint32_t split_max_parts();
+hipError_t launch_split_count(const uint32_t *owner, uint64_t n, uint32_t parts, uint32_t *matrix, hipStream_t st);
+hipError_t launch_split_order(const uint32_t *owner, uint64_t n, uint32_t parts, const uint32_t *matrix,
+                              const uint32_t *matrix_incl, uint32_t *order, uint64_t *counts, hipStream_t st);
 hipError_t launch_owner_counts(const uint32_t *owner_sorted, uint64_t n, uint32_t parts, uint64_t *counts,
                                hipStream_t st);
 

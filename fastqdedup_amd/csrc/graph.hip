@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
     return x;
 }
 
-// n_hooks (may be NULL) += successful hooks: every hook merges two components, so
+// n_hooks (may be NULL; FQD_HOOK_SLOTS x 8 words, summed by the host) += successful hooks: every hook merges two components, so
 // components = nodes - hooks without a sweep over the nodes.
 __global__ void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ edges, uint64_t E,
                                 unsigned long long *n_hooks)
@@ -86,9 +86,11 @@ __global__ void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ e
         }
     }
     if (n_hooks) {
+        // FQD_HOOK_SLOTS counters one cache line apart: tens of thousands of waves adding to ONE
+        // word serialise in the L2 (measured: 350 us against 98 us for the unions themselves)
         const unsigned long long m = __ballot(hooked);
         if (m && fqd_lane() == (uint32_t)(__ffsll((long long)m) - 1))
-            atomicAdd(n_hooks, (unsigned long long)__popcll(m));
+            atomicAdd(n_hooks + (size_t)(blockIdx.x % FQD_HOOK_SLOTS) * 8, (unsigned long long)__popcll(m));
     }
 }
 

@@ -116,7 +116,7 @@ class HipBackend:
 
     def collapse_resident(self, recs, lens, weights, read_ids) -> int:
         """Collapse the received reads; the unique table stays in the context."""
-        self.ctx.import_packed(recs, lens if self.ragged else None, recs.shape[0])
+        self.ctx.import_packed(recs, lens if self.ragged else None, recs.shape[0], borrow=True)
         self.n_unique_local = self.ctx.collapse(weights, read_ids)
         return self.n_unique_local
 
@@ -146,7 +146,7 @@ class HipBackend:
     def routed_edges(self, recs, lens, uids, max_distance, segment):
         """Search pass `segment` over rows received from every rank; edges as uid pairs."""
         n = recs.shape[0]
-        self.aux.import_unique(recs, lens if self.ragged else None, None, None, n)
+        self.aux.import_unique(recs, lens if self.ragged else None, None, None, n, borrow=True)
         ne = self.aux.find_edges_segments(max_distance, segment, segment + 1)
         edges = torch.empty((ne, 2), dtype=torch.int32, device=self.device)
         self.aux.export_edges(edges)
@@ -168,7 +168,7 @@ class HipBackend:
     def dissect_subgraph(self, recs, lens, counts, edges, method):
         """Verdict (uint8, 1 = kept) for every row of a table of whole clusters."""
         n = recs.shape[0]
-        self.aux.import_unique(recs, lens if self.ragged else None, counts, None, n)
+        self.aux.import_unique(recs, lens if self.ragged else None, counts, None, n, borrow=True)
         self.aux.import_edges(edges.contiguous(), edges.shape[0])
         self.aux.components()
         self.aux.dissect(method)
@@ -323,33 +323,55 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
     metric = METRIC_EDIT if use_edit_distance else METRIC_HAMMING
 
     # ---- 1. common geometry --------------------------------------------------
-    present, max_len, ragged = backend.scan(keys, offsets, key_len)
     if offsets is None:
         nbytes = keys.numel() if hasattr(keys, "numel") else keys.size
         n_local = nbytes // key_len if key_len else 0
     else:
         n_local = (offsets.numel() if hasattr(offsets, "numel") else offsets.size) - 1
-    everyone = comm.all_gather_ints([n_local, max_len, int(ragged)])
+    n_seg = max_distance + 1
+    owner_segments = n_seg if plan == "segment-routed" else 0
+    packed = None
+    # Fixed-length keys: pack at once with the DNA alphabet "ACGNT" (no pass over the bytes just
+    # to learn the symbols); one flag tells every rank whether somebody met another byte, and
+    # only then are the keys scanned and the symbol tables merged.
+    everyone = comm.all_gather_ints([n_local, key_len if offsets is None else -1])
     n_per_rank = everyone[:, 0]
-    lens_seen = {int(m) for n, m, _ in everyone if n > 0}
-    g_ragged = bool(everyone[:, 2].any()) or len(lens_seen) > 1
-    g_max_len = int(everyone[:, 1].max()) if len(everyone) else 0
-    p = torch.from_numpy(np.ascontiguousarray(present, dtype=np.uint8)).to(dev).to(torch.int32)
-    g_present = comm.all_reduce_max(p).to(torch.uint8).cpu().numpy()
-    backend.configure(g_present, g_max_len, g_ragged)
-    if tick:
-        tick.mark("geometry")
     id_bounds = [0] + [int(x) for x in np.cumsum(n_per_rank)]
     id0, n_total = id_bounds[rank], id_bounds[-1]
+    lens_seen = {int(m) for n, m in everyone if n > 0}
+    if len(lens_seen) == 1 and min(lens_seen) > 0 and not os.environ.get("FQD_SHARD_SCAN"):
+        dna = np.zeros(128, dtype=np.uint8)
+        dna[[ord(ch) for ch in "ACGNT"]] = 1
+        backend.configure(dna, lens_seen.pop(), False)
+        foreign = 0
+        try:
+            packed = backend.pack_by_owner(keys, offsets, key_len, world, id0, weights, n_segments=owner_segments)
+        except ValueError:
+            foreign = 1
+        if int(comm.all_reduce_max(torch.tensor([foreign], dtype=torch.int32, device=dev)).item()):
+            packed = None
+        g_ragged = False
+    if packed is None:
+        present, max_len, ragged = backend.scan(keys, offsets, key_len)
+        everyone = comm.all_gather_ints([n_local, max_len, int(ragged)])
+        lens_seen = {int(m) for n, m, _ in everyone if n > 0}
+        g_ragged = bool(everyone[:, 2].any()) or len(lens_seen) > 1
+        g_max_len = int(everyone[:, 1].max()) if len(everyone) else 0
+        p = torch.from_numpy(np.ascontiguousarray(present, dtype=np.uint8)).to(dev).to(torch.int32)
+        g_present = comm.all_reduce_max(p).to(torch.uint8).cpu().numpy()
+        backend.configure(g_present, g_max_len, g_ragged)
+    if tick:
+        tick.mark("geometry")
 
     if plan == "gathered":
-        return _gathered(backend, comm, tick, keys, offsets, key_len, weights, max_distance, metric, method_id,
-                         g_ragged, id0, n_local, n_total)
+        return _gathered(backend, comm, tick, packed, keys, offsets, key_len, weights, max_distance, metric,
+                         method_id, g_ragged, id0, n_local, n_total)
 
     # ---- 2. reads to the owner of their segment 0; collapse -------------------------
-    n_seg = max_distance + 1
-    s_recs, s_lens, s_ids, s_w, send_counts = backend.pack_by_owner(keys, offsets, key_len, world, id0, weights,
-                                                                    n_segments=n_seg)
+    if packed is None:
+        packed = backend.pack_by_owner(keys, offsets, key_len, world, id0, weights, n_segments=n_seg)
+    s_recs, s_lens, s_ids, s_w, send_counts = packed
+    del packed
     if tick:
         tick.mark("pack+group-by-owner")
     recv_counts = comm.exchange_counts(send_counts)
@@ -431,7 +453,11 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
     out_counts = _split_by_bounds(kept_owned, id_bounds)
     in_counts = comm.exchange_counts(out_counts)
     kept_mine = comm.all_to_all_rows(kept_owned, out_counts, in_counts)
-    kept_mine = torch.sort(kept_mine).values if world > 1 else kept_mine
+    if world > 1:
+        # G ascending runs -> one ascending list: mark the window's reads, list the marked ones
+        window = torch.zeros(max(n_local, 1), dtype=torch.bool, device=kept_mine.device)
+        window[kept_mine - id0] = True
+        kept_mine = window.nonzero().reshape(-1)[: kept_mine.shape[0]] + id0
     n_kept = int(comm.all_gather_ints([n_kept_owned])[:, 0].sum())
     phases = None
     if tick:
@@ -440,11 +466,14 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
     return ShardedResult(kept_mine, n_total, n_unique, n_edges, int(n_clusters), n_kept, "segment-routed", phases)
 
 
-def _gathered(backend, comm, tick, keys, offsets, key_len, weights, max_distance, metric, method_id, g_ragged,
-              id0, n_local, n_total) -> ShardedResult:
+def _gathered(backend, comm, tick, packed, keys, offsets, key_len, weights, max_distance, metric, method_id,
+              g_ragged, id0, n_local, n_total) -> ShardedResult:
     rank, world = comm.rank, comm.world
     # ---- 2. all copies of a key to its owner rank ------------------------------
-    s_recs, s_lens, s_ids, s_w, send_counts = backend.pack_by_owner(keys, offsets, key_len, world, id0, weights)
+    if packed is None:
+        packed = backend.pack_by_owner(keys, offsets, key_len, world, id0, weights)
+    s_recs, s_lens, s_ids, s_w, send_counts = packed
+    del packed
     if tick:
         tick.mark("pack+group-by-owner")
     recv_counts = comm.exchange_counts(send_counts)

@@ -50,6 +50,11 @@ extern "C" {
 
 #define FQD_HOST   0
 #define FQD_DEVICE 1
+/* fqd_import_packed / fqd_import_unique only: a device buffer the context READS IN PLACE (records
+ * and lengths are not copied). The caller keeps it alive and unchanged until the stage that
+ * consumes it has returned (fqd_collapse; fqd_find_edges* / fqd_dissect); the context lets go of
+ * it the next time it needs that buffer. Records must be 16-byte aligned. */
+#define FQD_DEVICE_BORROW 2
 
 #define FQD_METRIC_HAMMING 0
 #define FQD_METRIC_EDIT    1

@@ -45,15 +45,21 @@ def _worker(rank, world, port, case, plan, q):
 
 
 @pytest.mark.parametrize("shape,plan", [("fixed32", "segment-routed"), ("fixed32", "gathered"),
+                                        ("fixed32_foreign", "segment-routed"),
                                         ("fixed100_weights", "segment-routed"), ("fixed100_weights", "gathered"),
                                         ("ragged_hamming3", "segment-routed"), ("ragged_edit", "gathered")])
 def test_ranks_on_one_gpu(oracle, shape, plan):
     from fastqdedup_amd.synth import fixed_offsets, synth_keys
     world = 2
-    if shape == "fixed32":
+    if shape in ("fixed32", "fixed32_foreign"):
         n, L, d, edit, method = 120_000, 32, 1, False, "directional"
         allk = synth_keys(n, L, L, 5, sub_rate=3e-3, n_rate=3e-4)
         cut = 70_000
+        if shape == "fixed32_foreign":
+            # a symbol outside "ACGNT" on rank 1 only: the optimistic pack fails there, every
+            # rank must fall back to the scanned, merged symbol table
+            allk[cut + 11] = np.frombuffer(bytes(allk[cut + 11]).lower(), dtype=np.uint8)
+            allk[cut + 12] = allk[cut + 11]
         case = [(allk[:cut].reshape(-1), None, L, None, d, edit, method),
                 (allk[cut:].reshape(-1), None, L, None, d, edit, method)]
         raw, off, w = allk.reshape(-1), fixed_offsets(n, L), None
