@@ -43,7 +43,7 @@ EXPORTS = [
     "fqd_collapse", "fqd_find_edges", "fqd_components", "fqd_dissect", "fqd_cluster",
     "fqd_set_id_window", "fqd_get_kept_count", "fqd_get_kept_read_ids", "fqd_get_unique_table", "fqd_export_packed", "fqd_export_packed_by_owner", "fqd_import_packed",
     "fqd_export_packed_by_segment", "fqd_export_unique_by_segment", "fqd_gather_unique",
-    "fqd_find_edges_segments", "fqd_edge_labels", "fqd_list_kept_except",
+    "fqd_find_edges_segments", "fqd_edge_labels", "fqd_list_kept_except", "fqd_set_owner_rule",
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
     "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_edge_stats", "fqd_synth_keys",
 ]
@@ -98,6 +98,7 @@ def load() -> C.CDLL:
                                                vp, vp, C.c_int]
     L.fqd_export_unique_by_segment.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp,
                                                C.c_int]
+    L.fqd_set_owner_rule.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.fqd_gather_unique.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_int]
     L.fqd_find_edges_segments.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, u64p]
     L.fqd_edge_labels.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, u64p, C.c_int]
@@ -335,6 +336,10 @@ class Context:
         self._ck(self._L.fqd_export_packed_by_segment(self._h, int(n_parts), int(n_segments), int(segment), int(id0),
                                                       wp, rp, lp, ip, op, counts.ctypes.data, rm))
         return counts
+
+    def set_owner_rule(self, n_parts: int, n_segments: int = 1, segment: int = 0):
+        """pack_keys also computes every read's owner rank (0 parts: off)."""
+        self._ck(self._L.fqd_set_owner_rule(self._h, int(n_parts), int(n_segments), int(segment)))
 
     def export_unique_by_segment(self, n_parts: int, n_segments: int, segment: int, uid_base: int, recs, lens, uids):
         rp, rm, _1 = _ptr_mem(recs)

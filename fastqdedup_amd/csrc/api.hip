@@ -83,7 +83,9 @@ struct fqd_ctx {
 
     // stage 1
     uint64_t n = 0;
-    DevBuf in_bytes, in_offsets, recs, lens, hashes;
+    DevBuf in_bytes, in_offsets, recs, lens, hashes, owners;
+    fqd::OwnerRule owner_rule;     // fqd_set_owner_rule: fqd_pack_keys also writes each read's owner rank
+    fqd::OwnerRule owners_done;    // the rule `owners` was filled with (parts == 0: not filled)
     // stage 2
     uint64_t U = 0, n_counted = 0;
     int id_bits = 64;  // bits needed to sort first-holder ids (read ids 0..n-1 need few)
@@ -759,11 +761,15 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
         HIP_TRY(c, c->hashes.reserve((size_t)n * 4 + 16));
         if (sh.ragged)
             HIP_TRY(c, c->lens.reserve((size_t)n * 4 + 16));
+        if (c->owner_rule.parts)
+            HIP_TRY(c, c->owners.reserve((size_t)n * 4 + 16));
+        c->owners_done = fqd::OwnerRule{};
         FQD_TRY(zero_ctr32(c, C_BAD));
         (void)hipEventRecord(c->evk0, c->st);
         KTIME(c, FQD_K_PACK, fqd::launch_pack(d_bytes, n_bytes, d_off, n, fixed_len, sh, c->d_lut.as<uint8_t>(), lut,
                                     c->recs.as<uint32_t>(), sh.ragged ? c->lens.as<uint32_t>() : nullptr,
-                                    c->hashes.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+                                    c->hashes.as<uint32_t>(), c->owner_rule.parts ? c->owners.as<uint32_t>() : nullptr,
+                                    c->owner_rule, c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
         (void)hipEventRecord(c->evk1, c->st);
         uint32_t bad = 0;
         FQD_TRY(read_ctr32(c, C_BAD, &bad));
@@ -789,7 +795,18 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
     }
     timer.stop();
     c->n = n;
+    c->owners_done = c->owner_rule;
     c->stage = ST_PACKED;
+    return FQD_OK;
+}
+
+int fqd_set_owner_rule(fqd_ctx *c, uint32_t n_parts, uint32_t n_segments, uint32_t segment)
+{
+    if (n_parts > 65536 || (n_parts && (n_segments == 0 || segment >= n_segments)))
+        return fail(c, FQD_E_VALUE, "bad owner rule");
+    c->owner_rule.parts = n_parts;
+    c->owner_rule.nseg = n_parts ? n_segments : 1;
+    c->owner_rule.seg = n_parts ? segment : 0;
     return FQD_OK;
 }
 
@@ -1348,10 +1365,16 @@ int fqd_export_packed_by_segment(fqd_ctx *c, uint32_t n_parts, uint32_t n_segmen
     if (n_segments == 0 || segment >= n_segments)
         return fail(c, FQD_E_VALUE, "bad segment");
     const uint64_t n = c->n;
-    HIP_TRY(c, c->flags.reserve(n * 4 + 16));
-    HIP_TRY(c, fqd::launch_segment_hashes(c->recs.as<uint32_t>(), c->lens.as<uint32_t>(), n, c->ks, n_segments, segment,
-                                          segment + 1, n_parts, c->flags.as<uint32_t>(), c->st));
-    return export_grouped(c, n, n_parts, c->flags.as<uint32_t>(), c->recs.as<uint32_t>(), c->lens.as<uint32_t>(),
+    const uint32_t *owner;
+    if (c->owners_done.parts == n_parts && c->owners_done.nseg == n_segments && c->owners_done.seg == segment) {
+        owner = c->owners.as<uint32_t>();      // fqd_pack_keys already worked them out
+    } else {
+        HIP_TRY(c, c->flags.reserve(n * 4 + 16));
+        HIP_TRY(c, fqd::launch_segment_hashes(c->recs.as<uint32_t>(), c->lens.as<uint32_t>(), n, c->ks, n_segments,
+                                              segment, segment + 1, n_parts, c->flags.as<uint32_t>(), c->st));
+        owner = c->flags.as<uint32_t>();
+    }
+    return export_grouped(c, n, n_parts, owner, c->recs.as<uint32_t>(), c->lens.as<uint32_t>(),
                           weights, id0, recs, lens, ids, nullptr, weights_out, counts);
 }
 
@@ -1498,6 +1521,7 @@ int fqd_import_packed(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, ui
                                         c->hashes.as<uint32_t>(), c->st));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     c->n = n;
+    c->owners_done = fqd::OwnerRule{};
     c->stage = ST_PACKED;
     return FQD_OK;
 }

@@ -65,8 +65,18 @@ __global__ __launch_bounds__(SPLIT_THREADS) void split_count_kernel(const uint32
     const uint64_t base = (uint64_t)blockIdx.x * SPLIT_TILE;
     for (uint32_t k = 0; k < SPLIT_TILE; k += SPLIT_THREADS) {
         const uint64_t i = base + k + threadIdx.x;
-        if (i < n)
-            atomicAdd(&cnt[owner[i]], 1u);
+        const bool live = i < n;
+        const uint32_t o = live ? owner[i] : 0xFFFFFFFFu;
+        // one LDS add per (wave, distinct owner): with a handful of parts, per-row adds would all
+        // hit the same few LDS words
+        unsigned long long todo = __ballot(live);
+        while (todo) {
+            const uint32_t lead = __shfl(o, __ffsll((long long)todo) - 1);
+            const unsigned long long same = __ballot(live && o == lead);
+            if (o == lead && (same & fqd_lanemask_lt()) == 0)
+                atomicAdd(&cnt[lead], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
     }
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < parts; p += SPLIT_THREADS)

@@ -118,6 +118,23 @@ __device__ __forceinline__ void fqd_segment(uint32_t len, uint32_t s, uint32_t n
     hi = len * (s + 1) / nseg;
 }
 
+// Hash of segment s of the nseg-way split of one record, by ONE thread; the same value as
+// segment_hashes_kernel's cooperative sum (edges.hip): fmix(len, s, SUM over the record's words
+// of mix(word & segment mask, word index)).
+__device__ __forceinline__ uint32_t fqd_segment_hash(const uint32_t *rec, uint32_t K, uint32_t KW, uint32_t len,
+                                                     uint32_t s, uint32_t nseg)
+{
+    uint32_t lo, hi;
+    fqd_segment(len, s, nseg, lo, hi);
+    uint32_t part = 0;
+    for (uint32_t j = 0; j < KW; j++) {
+        const uint32_t m = fqd_range_mask(j / K, lo, hi);
+        if (m)
+            part += fqd_mix32((rec[j] & m) + (j + 1u) * 0x9E3779B1u);
+    }
+    return fqd_mix32(part + fqd_mix32(len * 0x9E3779B1u + s * 0x85EBCA77u + 0x165667B1u));
+}
+
 __device__ __forceinline__ uint32_t fqd_lane() { return threadIdx.x & 63u; }
 
 __device__ __forceinline__ uint64_t fqd_lanemask_lt()
@@ -146,9 +163,15 @@ hipError_t inclusive_scan_u32(void *tmp, size_t tmp_bytes, const uint32_t *in, u
 hipError_t launch_scan_bytes(const uint8_t *bytes, uint64_t n_bytes, uint32_t *present128_dev,
                              hipStream_t st);
 hipError_t launch_scan_lens(const uint64_t *offsets, uint64_t n, uint32_t *minmax_dev, hipStream_t st);
+// owner rule (own_parts != 0): owners[i] = hash(segment own_seg of own_nseg) % own_parts, in the
+// same pass (the record is in LDS anyway); owners may be NULL.
+struct OwnerRule {
+    uint32_t parts = 0, nseg = 1, seg = 0;
+};
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
                        uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, const uint8_t *lut_host,
-                       uint32_t *recs, uint32_t *lens, uint32_t *hashes, uint32_t *bad_flag, hipStream_t st);
+                       uint32_t *recs, uint32_t *lens, uint32_t *hashes, uint32_t *owners, OwnerRule rule,
+                       uint32_t *bad_flag, hipStream_t st);
 hipError_t launch_hash_records(const uint32_t *recs, const uint32_t *lens, uint64_t n, KeyShape sh,
                                uint32_t *hashes, hipStream_t st);
 

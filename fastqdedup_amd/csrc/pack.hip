@@ -89,7 +89,7 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     const uint8_t *__restrict__ bytes, uint64_t n_bytes, const uint64_t *__restrict__ offsets, uint64_t n,
     uint32_t fixed_len, KeyShape sh, uint32_t kpb, uint32_t plane_words, const uint8_t *__restrict__ lut_g,
     PackHash ph, uint32_t *__restrict__ recs, uint32_t *__restrict__ lens, uint32_t *__restrict__ hashes,
-    uint32_t *__restrict__ bad_flag)
+    uint32_t *__restrict__ owners, fqd::OwnerRule rule, uint32_t *__restrict__ bad_flag)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *lut32 = smem;                                   // 256 bytes
@@ -262,6 +262,8 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
         hashes[key0 + k] = fqd_hash_record(tile + k * stride, W * K, len);
         if (lens)
             lens[key0 + k] = len;
+        if (owners)   // multi-GPU: the rank this read goes to
+            owners[key0 + k] = fqd_segment_hash(tile + k * stride, K, W * K, len, rule.seg, rule.nseg) % rule.parts;
     }
     uint4 *dst = reinterpret_cast<uint4 *>(recs + key0 * stride);
     const uint4 *src = reinterpret_cast<const uint4 *>(tile);
@@ -360,8 +362,11 @@ static bool find_pack_hash(const uint8_t *lut_host, PackHash &ph)
 
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
                        uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, const uint8_t *lut_host,
-                       uint32_t *recs, uint32_t *lens, uint32_t *hashes, uint32_t *bad_flag, hipStream_t st)
+                       uint32_t *recs, uint32_t *lens, uint32_t *hashes, uint32_t *owners, OwnerRule rule,
+                       uint32_t *bad_flag, hipStream_t st)
 {
+    if (!rule.parts)
+        owners = nullptr;
     if (!n)
         return hipSuccess;
     if ((uintptr_t)bytes & 15u)
@@ -381,7 +386,7 @@ hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *o
 #define FQD_PACK_CASE(KK, SW)                                                                              \
     pack_kernel<KK, SW><<<(unsigned)blocks, PACK_THREADS, lds, st>>>(bytes, n_bytes, offsets, n, fixed_len, sh, \
                                                                      kpb, plane_words, lut_dev, ph, recs, lens, \
-                                                                     hashes, bad_flag)
+                                                                     hashes, owners, rule, bad_flag)
     if (swar) {
         switch (sh.planes) {
         case 1: FQD_PACK_CASE(1, true); break;

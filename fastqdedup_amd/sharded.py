@@ -100,7 +100,11 @@ class HipBackend:
         part in read order): rows, lengths (None unless ragged), global ids, weights (None if
         not given), rows per part. n_segments == 0: owner = key hash; else owner = hash of
         segment 0 of the n_segments-way split."""
-        n = self.ctx.pack_keys(keys, offsets, key_len)
+        self.ctx.set_owner_rule(n_parts if n_segments else 0, max(n_segments, 1), 0)   # owners in the pack pass
+        try:
+            n = self.ctx.pack_keys(keys, offsets, key_len)
+        finally:
+            self.ctx.set_owner_rule(0)
         sh = self.ctx.shape()
         self.stride = int(sh.stride_words)
         self.ragged = bool(sh.ragged)

@@ -159,6 +159,10 @@ int fqd_export_packed_by_owner(fqd_ctx *ctx, uint32_t n_parts, uint64_t id0, con
 int fqd_export_packed_by_segment(fqd_ctx *ctx, uint32_t n_parts, uint32_t n_segments, uint32_t segment,
                                  uint64_t id0, const uint32_t *weights, uint32_t *recs, uint32_t *lens,
                                  uint64_t *ids, uint32_t *weights_out, uint64_t *counts, int mem);
+/* Optional: announce the owner rule BEFORE fqd_pack_keys, which then works out every read's owner
+ * in the same pass; a matching fqd_export_packed_by_segment skips its own pass over the records.
+ * n_parts = 0 switches it off. */
+int fqd_set_owner_rule(fqd_ctx *ctx, uint32_t n_parts, uint32_t n_segments, uint32_t segment);
 /* The UNIQUE table grouped the same way for a later pass: uids[i] = uid_base + row (the job-wide
  * id of a unique key: owner rank's base + its row). recs/lens/uids DEVICE, counts HOST. */
 int fqd_export_unique_by_segment(fqd_ctx *ctx, uint32_t n_parts, uint32_t n_segments, uint32_t segment,
