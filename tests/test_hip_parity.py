@@ -408,6 +408,123 @@ def test_bucket_shards_union_to_the_whole_search(F, oracle, edit, d):
     assert np.array_equal(kept, want["kept_read_ids"])
 
 
+def test_segment_passes_partition_the_search(F, oracle):
+    """fqd_find_edges_segments: disjoint pass ranges give every edge of the whole search exactly
+    once (a pair is reported in the first segment it agrees on)."""
+    from fastqdedup_amd.synth import synth_keys
+    n, L, d = 120_000, 40, 2
+    raw = synth_keys(n, L, 8, 23, sub_rate=5e-3, n_rate=5e-4).reshape(-1)
+    ctx = F.Context(0)
+    ctx.pack_keys(raw, None, L)
+    ctx.collapse()
+    whole_n = ctx.find_edges(d, 0, 0, 1)
+    whole = np.empty((whole_n, 2), dtype=np.uint32)
+    ctx.export_edges(whole)
+    parts = []
+    for lo, hi in ((0, 1), (1, 3)):
+        ne = ctx.find_edges_segments(d, lo, hi)
+        e = np.empty((ne, 2), dtype=np.uint32)
+        ctx.export_edges(e)
+        parts.append(e)
+    union = np.concatenate(parts)
+    assert len(union) == whole_n
+    assert {(int(a), int(b)) for a, b in union} == {(int(a), int(b)) for a, b in whole}
+    with pytest.raises(ValueError):
+        ctx.find_edges_segments(d, 2, 4)
+
+
+def test_grouping_by_segment_owner(F):
+    """fqd_export_packed_by_segment / fqd_export_unique_by_segment: a stable split into parts; keys
+    that agree on the segment (and all copies of a key) land in the same part; the owners worked
+    out inside the pack pass (fqd_set_owner_rule) equal the ones worked out afterwards."""
+    import torch
+    from fastqdedup_amd.synth import synth_keys
+    dev = torch.device("cuda", 0)
+    n, L, parts, nseg = 70_001, 32, 5, 2
+    host = synth_keys(n, L, 8, 29, sub_rate=5e-3, n_rate=5e-4)
+    keys = torch.from_numpy(host.reshape(-1).copy()).to(dev)
+    ctx = F.Context(0)
+
+    def grouped(rule_in_pack):
+        ctx.set_owner_rule(parts if rule_in_pack else 0, nseg, 0)
+        ctx.pack_keys(keys, None, L)
+        ctx.set_owner_rule(0)
+        stride = ctx.shape().stride_words
+        recs = torch.empty((n, stride), dtype=torch.int32, device=dev)
+        ids = torch.empty(n, dtype=torch.int64, device=dev)
+        counts = ctx.export_packed_by_segment(parts, nseg, 0, 1000, None, recs, None, ids, None)
+        return recs.cpu().numpy(), ids.cpu().numpy(), [int(c) for c in counts]
+
+    recs_a, ids_a, counts_a = grouped(True)
+    recs_b, ids_b, counts_b = grouped(False)
+    assert counts_a == counts_b and sum(counts_a) == n
+    assert np.array_equal(ids_a, ids_b) and np.array_equal(recs_a, recs_b)
+    bounds = np.concatenate([[0], np.cumsum(counts_a)])
+    seen = {}
+    for p in range(parts):
+        part_ids = ids_a[bounds[p]:bounds[p + 1]] - 1000
+        assert np.all(np.diff(part_ids) > 0)                     # stable: read order kept
+        for half in {bytes(host[i, :L // nseg]) for i in part_ids[:2000]}:
+            assert seen.setdefault(half, p) == p                 # one owner per segment-0 content
+    assert sorted(ids_a - 1000) == list(range(n))
+
+    # the unique table, by segment 1, with job-wide ids
+    nu = ctx.collapse()
+    stride = ctx.shape().stride_words
+    urecs = torch.empty((nu, stride), dtype=torch.int32, device=dev)
+    uids = torch.empty(nu, dtype=torch.int32, device=dev)
+    ucounts = ctx.export_unique_by_segment(parts, nseg, 1, 500, urecs, None, uids)
+    assert sum(int(c) for c in ucounts) == nu
+    assert sorted(uids.cpu().tolist()) == list(range(500, 500 + nu))
+    # rows fetched back by index are the rows that were exported
+    rows = (uids - 500).contiguous()
+    g_recs = torch.empty_like(urecs)
+    g_counts = torch.empty(nu, dtype=torch.int32, device=dev)
+    ctx.gather_unique(rows, nu, g_recs, None, g_counts)
+    assert torch.equal(g_recs, urecs)
+    _first, counts_tbl, _l, _k = ctx.unique_table(nu, labels=False, kept=False)
+    assert np.array_equal(g_counts.cpu().numpy().astype(np.uint32), counts_tbl[rows.cpu().numpy()])
+    with pytest.raises(ValueError):
+        ctx.gather_unique(torch.tensor([nu], dtype=torch.int32, device=dev), 1, g_recs, None, g_counts)
+
+
+def test_edge_labels_and_kept_except(F, oracle):
+    """fqd_edge_labels (components of a caller's edge list) and fqd_list_kept_except (verdicts
+    computed elsewhere) against the plain single-context path."""
+    import torch
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    dev = torch.device("cuda", 0)
+    n, L, d = 90_000, 32, 1
+    raw = synth_keys(n, L, 8, 31, sub_rate=5e-3, n_rate=5e-4).reshape(-1)
+    ctx = F.Context(0)
+    ctx.pack_keys(raw, None, L)
+    nu = ctx.collapse()
+    ne = ctx.find_edges(d, 0, 0, 1)
+    edges = torch.empty((ne, 2), dtype=torch.int32, device=dev)
+    ctx.export_edges(edges)
+    n_clusters = ctx.components()
+    n_kept = ctx.dissect(2)
+    kept_ids = ctx.kept_read_ids(n_kept)
+    _first, _counts, labels, kept = ctx.unique_table(nu)
+
+    other = F.Context(0)
+    roots = torch.empty(ne, dtype=torch.int32, device=dev)
+    assert other.edge_labels(edges, ne, nu, roots) == n_clusters
+    e = edges.cpu().numpy()
+    assert np.array_equal(roots.cpu().numpy().astype(np.uint32), labels[e[:, 0]])
+    with pytest.raises(ValueError):
+        other.edge_labels(edges, ne, int(e.max()), roots)          # an end outside [0, n_nodes)
+
+    dropped = torch.from_numpy(np.flatnonzero(kept == 0).astype(np.int32)).to(dev)
+    assert ctx.list_kept_except(dropped, dropped.shape[0]) == n_kept
+    assert np.array_equal(ctx.kept_read_ids(n_kept), kept_ids)
+    flags = torch.empty(nu, dtype=torch.uint8, device=dev)
+    ctx.kept_flags_into(flags)
+    assert np.array_equal(flags.cpu().numpy(), kept)
+    want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=d, method="directional")
+    assert np.array_equal(kept_ids, want["kept_read_ids"])
+
+
 def test_sharded_path_on_rccl_world1(F, oracle):
     """The production multi-GPU code path (HipBackend + torch.distributed 'nccl' = RCCL) with a
     one-rank group: every collective, every export/import of the C ABI, against the oracle."""
