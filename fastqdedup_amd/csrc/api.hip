@@ -89,7 +89,9 @@ struct fqd_ctx {
     // stage 2
     uint64_t U = 0, n_counted = 0;
     int id_bits = 64;  // bits needed to sort first-holder ids (read ids 0..n-1 need few)
+    uint64_t id_limit = ~0ull;  // every first-holder id is below this (~0: unknown)
     bool collapsed = false;  // unique table came from fqd_collapse (keys are pairwise distinct)
+    bool first_distinct = true;  // first-holder ids are pairwise distinct (false: imported without ids)
     DevBuf in_weights, in_read_ids, hs_sorted, ids, ids_sorted, flags, run_idx, run_start, run_weight, live_flag,
         live_idx, collision_runs;
     DevBuf urecs, ulens, ucounts, ufirst;
@@ -105,7 +107,8 @@ struct fqd_ctx {
     fqd::PairStats last_stats{};
     // stage 4
     uint64_t n_clusters = 0;
-    DevBuf labels;
+    DevBuf labels, hook_slots;
+    bool labels_flat = false;
     // stage 5
     uint64_t n_kept = 0, n_listed = 0;          // kept keys; kept keys whose first holder is in the id window
     uint64_t id_lo = 0, id_hi = ~0ull;
@@ -622,7 +625,7 @@ void fqd_destroy(fqd_ctx *c)
                       &c->ed_payload, &c->ed_hash_sorted, &c->ed_payload_sorted, &c->ed_cands, &c->ed_cands_sorted,
                       &c->d_alphabet, &c->labels, &c->best, &c->state,
                       &c->blocked, &c->kept, &c->kept_u32, &c->kept_scan, &c->kept_ids, &c->kept_ids_sorted, &c->tmp,
-                      &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d};
+                      &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners};
     for (DevBuf *b : bufs)
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -839,7 +842,9 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
         timer.stop();
         c->collapse_path = 1;
         c->collapsed = true;
+        c->first_distinct = true;
         c->id_bits = 64;
+        c->id_limit = read_ids ? ~0ull : n;
         if (!read_ids) {
             c->id_bits = 1;
             while (c->id_bits < 64 && (n >> c->id_bits))
@@ -919,7 +924,9 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
     c->U = U;
     c->n_counted = counted;
     c->collapsed = true;
+    c->first_distinct = true;
     c->id_bits = 64;
+    c->id_limit = read_ids ? ~0ull : n;
     if (!read_ids) {  // ids are 0..n-1
         c->id_bits = 1;
         while (c->id_bits < 64 && (n >> c->id_bits))
@@ -1059,17 +1066,36 @@ int fqd_find_edges_segments(fqd_ctx *c, int max_distance, uint32_t seg_lo, uint3
     return find_edges_impl(c, max_distance, FQD_METRIC_HAMMING, 0, 1, seg_lo, seg_hi, n_edges);
 }
 
-// Queue the union-find kernels; the root count stays on the device until somebody asks for it
-// (fqd_cluster asks after the dissection, so the GPU never waits for the host in between).
-static int components_queue(fqd_ctx *c)
+static int ensure_flat_labels(fqd_ctx *c)
+{
+    if (c->labels_flat)
+        return FQD_OK;
+    HIP_TRY(c, c->tmp.reserve(64));
+    KTIME(c, FQD_K_UF_FLATTEN, fqd::launch_uf_flatten(c->labels.as<uint32_t>(), c->U,
+                                                      c->tmp.as<unsigned long long>(), c->st));
+    c->labels_flat = true;
+    return FQD_OK;
+}
+
+// Queue the union-find kernels; the component count stays on the device (C64_ROOTS) until
+// somebody asks for it (fqd_cluster asks after the dissection, so the GPU never waits for the
+// host in between). flatten = false leaves the parent forest unflattened: components = nodes -
+// hooks needs no sweep over the nodes, and only highest_count and the label export read labels
+// (ensure_flat_labels does the sweep then).
+static int components_queue(fqd_ctx *c, bool flatten)
 {
     const uint64_t U = c->U;
     HIP_TRY(c, c->labels.reserve(U * 4 + 16));
-    FQD_TRY(zero_ctr64(c, C64_ROOTS));
+    HIP_TRY(c, c->hook_slots.reserve(FQD_HOOK_SLOTS * 64));
+    HIP_TRY(c, hipMemsetAsync(c->hook_slots.p, 0, FQD_HOOK_SLOTS * 64, c->st));
     HIP_TRY(c, fqd::launch_uf_init(c->labels.as<uint32_t>(), U, c->st));
-    KTIME(c, FQD_K_UF_UNION, fqd::launch_uf_union(c->labels.as<uint32_t>(), c->edges.as<uint32_t>(), c->E, nullptr, c->st));
-    KTIME(c, FQD_K_UF_FLATTEN, fqd::launch_uf_flatten(c->labels.as<uint32_t>(), U,
-                                                      c->d_ctr64.as<unsigned long long>() + C64_ROOTS, c->st));
+    KTIME(c, FQD_K_UF_UNION, fqd::launch_uf_union(c->labels.as<uint32_t>(), c->edges.as<uint32_t>(), c->E,
+                                                  c->hook_slots.as<unsigned long long>(), c->st));
+    HIP_TRY(c, fqd::launch_hook_total(c->hook_slots.as<unsigned long long>(), U,
+                                      c->d_ctr64.as<unsigned long long>() + C64_ROOTS, c->st));
+    c->labels_flat = false;
+    if (flatten)
+        FQD_TRY(ensure_flat_labels(c));
     return FQD_OK;
 }
 
@@ -1080,7 +1106,7 @@ int fqd_components(fqd_ctx *c, uint64_t *n_clusters)
         return fail(c, FQD_E_STATE, "fqd_components before fqd_find_edges/fqd_import_edges");
     c->stage = ST_EDGES;
     StageTimer timer(c, FQD_T_COMPONENTS);
-    FQD_TRY(components_queue(c));
+    FQD_TRY(components_queue(c, true));
     unsigned long long roots = 0;
     FQD_TRY(read_ctr64(c, C64_ROOTS, &roots));
     timer.stop();
@@ -1098,36 +1124,77 @@ static int list_kept(fqd_ctx *c, int method)
     const uint64_t U = c->U;
     c->n_kept = 0;
     c->n_listed = 0;
-    if (U) {
-        FQD_TRY(zero_ctr64(c, C64_SUM));
+    if (!U)
+        return FQD_OK;
+    // First-holder ids are distinct and bounded (by the id window, or by id_limit): when that
+    // range is not much larger than the table, the ascending list is a compaction of a byte map of
+    // the range -- cheaper than scan + gather + a radix sort of the ids.
+    uint64_t base = 0, window = c->id_limit;
+    if (c->id_hi != ~0ull) {
+        base = c->id_lo;
+        window = std::min(window > base ? window - base : 0, c->id_hi - c->id_lo);
+    }
+    const bool by_map = c->first_distinct && window <= 32 * U && window < 0xFFFFFFF0ull &&
+                        !getenv("FQD_KEPT_BY_SORT");
+    FQD_TRY(zero_ctr64(c, C64_SUM));
+    if (by_map) {
+        HIP_TRY(c, c->stage_c.reserve(window + 16));
+        if (window)
+            HIP_TRY(c, hipMemsetAsync(c->stage_c.p, 0, window, c->st));
         HIP_TRY(c, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
                                           c->state.as<uint8_t>(), c->ufirst.as<uint64_t>(), c->id_lo, c->id_hi, U,
-                                          c->kept.as<uint8_t>(), c->kept_u32.as<uint32_t>(),
+                                          c->kept.as<uint8_t>(), nullptr, c->stage_c.as<uint8_t>(), window,
                                           c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
-        FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), U));
-        uint32_t nk = 0;
-        HIP_TRY(c, hipMemcpyAsync(&nk, c->kept_scan.as<uint32_t>() + (U - 1), 4, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(c, c->kept_ids_sorted.reserve(std::min(window, U) * 8 + 16));
+        const uint32_t blocks = fqd::window_blocks(window);
+        uint32_t listed = 0;
+        if (blocks) {
+            HIP_TRY(c, c->kept_u32.reserve((size_t)blocks * 4 + 16));
+            HIP_TRY(c, c->kept_scan.reserve((size_t)blocks * 4 + 16));
+            HIP_TRY(c, fqd::launch_window_count(c->stage_c.as<uint8_t>(), window, c->kept_u32.as<uint32_t>(), c->st));
+            FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), blocks));
+            HIP_TRY(c, fqd::launch_window_emit(c->stage_c.as<uint8_t>(), window, c->kept_scan.as<uint32_t>(), base,
+                                               c->kept_ids_sorted.as<uint64_t>(), c->st));
+            HIP_TRY(c, hipMemcpyAsync(&listed, c->kept_scan.as<uint32_t>() + (blocks - 1), 4, hipMemcpyDeviceToHost,
+                                      c->st));
+        }
         unsigned long long total = 0;
         FQD_TRY(read_ctr64(c, C64_SUM, &total));
         c->n_kept = total;
-        c->n_listed = nk;
-        HIP_TRY(c, c->kept_ids.reserve((size_t)nk * 8 + 16));
-        HIP_TRY(c, c->kept_ids_sorted.reserve((size_t)nk * 8 + 16));
-        HIP_TRY(c, fqd::launch_gather_kept(c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(),
-                                           c->ufirst.as<uint64_t>(), U, c->kept_ids.as<uint64_t>(), c->st));
-        if (nk) {
-            int sort_bits = c->id_bits;   // listed ids lie below id_hi: fewer radix passes
-            if (c->id_hi != ~0ull) {
-                int wb = 1;
-                while (wb < 64 && (c->id_hi >> wb))
-                    wb++;
-                sort_bits = std::min(sort_bits, wb);
-            }
-            const size_t need = fqd::sort_keys_u64_temp(nk);
-            HIP_TRY(c, c->tmp.reserve(need + 16));
-            HIP_TRY(c, fqd::sort_keys_u64(c->tmp.p, need, c->kept_ids.as<uint64_t>(),
-                                          c->kept_ids_sorted.as<uint64_t>(), nk, sort_bits, c->st));
+        c->n_listed = listed;
+        if (getenv("FQD_DEBUG"))
+            fprintf(stderr, "[fqd] kept list by map: U=%llu base=%llu window=%llu id_limit=%llu kept=%llu listed=%u\n",
+                    (unsigned long long)U, (unsigned long long)base, (unsigned long long)window,
+                    (unsigned long long)c->id_limit, total, listed);
+        return FQD_OK;
+    }
+    HIP_TRY(c, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
+                                      c->state.as<uint8_t>(), c->ufirst.as<uint64_t>(), c->id_lo, c->id_hi, U,
+                                      c->kept.as<uint8_t>(), c->kept_u32.as<uint32_t>(), nullptr, 0,
+                                      c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+    FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), U));
+    uint32_t nk = 0;
+    HIP_TRY(c, hipMemcpyAsync(&nk, c->kept_scan.as<uint32_t>() + (U - 1), 4, hipMemcpyDeviceToHost, c->st));
+    unsigned long long total = 0;
+    FQD_TRY(read_ctr64(c, C64_SUM, &total));
+    c->n_kept = total;
+    c->n_listed = nk;
+    HIP_TRY(c, c->kept_ids.reserve((size_t)nk * 8 + 16));
+    HIP_TRY(c, c->kept_ids_sorted.reserve((size_t)nk * 8 + 16));
+    HIP_TRY(c, fqd::launch_gather_kept(c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(),
+                                       c->ufirst.as<uint64_t>(), U, c->kept_ids.as<uint64_t>(), c->st));
+    if (nk) {
+        int sort_bits = c->id_bits;   // listed ids lie below id_hi: fewer radix passes
+        if (c->id_hi != ~0ull) {
+            int wb = 1;
+            while (wb < 64 && (c->id_hi >> wb))
+                wb++;
+            sort_bits = std::min(sort_bits, wb);
         }
+        const size_t need = fqd::sort_keys_u64_temp(nk);
+        HIP_TRY(c, c->tmp.reserve(need + 16));
+        HIP_TRY(c, fqd::sort_keys_u64(c->tmp.p, need, c->kept_ids.as<uint64_t>(),
+                                      c->kept_ids_sorted.as<uint64_t>(), nk, sort_bits, c->st));
     }
     return FQD_OK;
 }
@@ -1151,6 +1218,7 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
     HIP_TRY(c, fqd::launch_dissect_init(c->best.as<uint32_t>(), c->state.as<uint8_t>(), U, c->st));
     uint32_t *d_changed = c->d_ctr32.as<uint32_t>() + C_CHANGED;
     if (method == FQD_METHOD_HIGHEST_COUNT) {
+        FQD_TRY(ensure_flat_labels(c));
         HIP_TRY(c, fqd::launch_highest_count(c->labels.as<uint32_t>(), c->ucounts.as<uint32_t>(),
                                              c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, U,
                                              c->best.as<uint32_t>(), c->st));
@@ -1204,7 +1272,8 @@ int fqd_cluster(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, i
         return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
     FQD_TRY(fqd_collapse(c, weights, read_ids, mem, nullptr));
     FQD_TRY(fqd_find_edges(c, max_distance, metric, 0, 1, nullptr));
-    FQD_TRY(components_queue(c));      // no host round trip between components and dissection
+    // no host round trip between components and dissection; labels are flattened only if read
+    FQD_TRY(components_queue(c, method == FQD_METHOD_HIGHEST_COUNT));
     c->stage = ST_LABELS;
     c->ms[FQD_T_COMPONENTS] = 0;
     FQD_TRY(fqd_dissect(c, method, nullptr));
@@ -1260,6 +1329,7 @@ int fqd_get_unique_table(fqd_ctx *c, uint64_t *first_ids, uint32_t *counts, uint
     if (labels) {
         if (c->stage < ST_LABELS)
             return fail(c, FQD_E_STATE, "no component labels yet");
+        FQD_TRY(ensure_flat_labels(c));
         FQD_TRY(from_device(c, labels, c->labels.p, (size_t)c->U, mem));
     }
     if (kept) {
@@ -1592,13 +1662,16 @@ int fqd_import_unique(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, co
     HIP_TRY(c, hipStreamSynchronize(c->st));
     c->U = U;
     c->collapsed = false;  // imported rows may repeat a key (dissection of a caller's list)
+    c->first_distinct = first_ids != nullptr;
     c->id_bits = 1;
+    c->id_limit = 1;
     if (first_ids) {   // width of the largest first-holder id: the kept-id sort runs over that many bits only
         unsigned long long mx = 0;
         FQD_TRY(zero_ctr64(c, C64_SUM));
         HIP_TRY(c, fqd::launch_max_u64(c->ufirst.as<uint64_t>(), U, c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
         FQD_TRY(read_ctr64(c, C64_SUM, &mx));
         c->id_bits = 1;
+        c->id_limit = mx + 1;
         while (c->id_bits < 64 && (mx >> c->id_bits))
             c->id_bits++;
     }

@@ -278,6 +278,12 @@ hipError_t launch_quality(const uint8_t *bytes, uint64_t n_bytes, const uint64_t
 hipError_t launch_uf_init(uint32_t *parent, uint64_t U, hipStream_t st);
 hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, unsigned long long *n_hooks,
                            hipStream_t st);
+uint32_t window_blocks(uint64_t n);
+hipError_t launch_window_count(const uint8_t *flags, uint64_t n, uint32_t *block_counts, hipStream_t st);
+hipError_t launch_window_emit(const uint8_t *flags, uint64_t n, const uint32_t *block_incl, uint64_t id_base,
+                              uint64_t *out, hipStream_t st);
+hipError_t launch_hook_total(const unsigned long long *slots, uint64_t n_nodes, unsigned long long *n_components,
+                             hipStream_t st);
 hipError_t launch_edge_roots(uint32_t *parent, const uint32_t *edges, uint64_t E, uint32_t *roots, hipStream_t st);
 hipError_t launch_check_indices(const uint32_t *idx, uint64_t n, uint64_t limit, uint32_t *bad, hipStream_t st);
 hipError_t launch_mark_dropped(uint8_t *state, uint64_t U, const uint32_t *dropped, uint64_t n, uint32_t *bad,
@@ -297,7 +303,8 @@ hipError_t launch_adjacency_round(const uint32_t *edges, uint64_t E, uint64_t U,
                                   uint32_t round, uint32_t *changed, hipStream_t st);
 hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t *best, const uint8_t *state,
                              const uint64_t *ufirst, uint64_t id_lo, uint64_t id_hi, uint64_t U, uint8_t *kept,
-                             uint32_t *kept_u32, unsigned long long *n_kept_total, hipStream_t st);
+                             uint32_t *kept_u32, uint8_t *window_flags, uint64_t window_size,
+                             unsigned long long *n_kept_total, hipStream_t st);
 hipError_t launch_gather_kept(const uint32_t *kept_u32, const uint32_t *kept_scan, const uint64_t *ufirst,
                               uint64_t U, uint64_t *out, hipStream_t st);
 

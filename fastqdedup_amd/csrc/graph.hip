@@ -94,6 +94,19 @@ __global__ void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ e
     }
 }
 
+// *n_components = n_nodes - sum of the hook slots (one wave)
+__global__ void hook_total_kernel(const unsigned long long *__restrict__ slots, uint64_t n_nodes,
+                                  unsigned long long *n_components)
+{
+    unsigned long long sum = 0;
+    for (uint32_t i = threadIdx.x; i < FQD_HOOK_SLOTS; i += 64)
+        sum += slots[(size_t)i * 8];
+    for (int o = 32; o; o >>= 1)
+        sum += __shfl_xor(sum, o);
+    if (threadIdx.x == 0)
+        *n_components = n_nodes - sum;
+}
+
 // roots[e] = component label (smallest node) of edge e's first end, after all unions are done
 __global__ void edge_roots_kernel(uint32_t *parent, const uint32_t *__restrict__ edges, uint64_t E,
                                   uint32_t *__restrict__ roots)
@@ -261,13 +274,15 @@ __global__ void adjacency_nodes_kernel(uint64_t U, uint8_t *state, const uint32_
     }
 }
 
-// kept[v]: the dissection's verdict. kept_u32[v]: 1 when v is kept AND its first holder lies in
-// the id window [id_lo, id_hi) -- the ids this context lists (a rank lists its own reads).
+// kept[v]: the dissection's verdict. A key is LISTED when it is kept AND its first holder lies in
+// the id window [id_lo, id_hi) -- the ids this context lists (a rank lists its own reads):
+// kept_u32[v] = 1 (scan + gather + sort path) or window_flags[id - id_lo] = 1 (compaction path).
 __global__ __launch_bounds__(256) void kept_flags_kernel(int method, const uint32_t *__restrict__ labels,
                                                          const uint32_t *__restrict__ best,
                                                          const uint8_t *__restrict__ state,
                                                          const uint64_t *__restrict__ ufirst, uint64_t id_lo,
                                                          uint64_t id_hi, uint64_t U, uint8_t *kept, uint32_t *kept_u32,
+                                                         uint8_t *window_flags, uint64_t window_size,
                                                          unsigned long long *n_kept_total)
 {
     unsigned long long total = 0;
@@ -282,13 +297,90 @@ __global__ __launch_bounds__(256) void kept_flags_kernel(int method, const uint3
             k = state[v] == 1;
         kept[v] = k ? 1 : 0;
         const uint64_t id = ufirst[v];
-        kept_u32[v] = (k && id >= id_lo && id < id_hi) ? 1u : 0u;
+        const bool listed = k && id >= id_lo && id < id_hi;
+        if (window_flags) {
+            // ids are distinct: one byte per id of the window, set for the listed ones; the
+            // ascending id list is then a stream compaction of the window (no sort)
+            if (listed && id - id_lo < window_size)
+                window_flags[id - id_lo] = 1;
+        } else {
+            kept_u32[v] = listed ? 1u : 0u;
+        }
         total += k ? 1ull : 0ull;
     }
     for (int o = 32; o; o >>= 1)
         total += __shfl_xor(total, o);
     if (fqd_lane() == 0 && total)
         atomicAdd(n_kept_total, total);
+}
+
+// ---- ascending id list = compaction of the window's byte map (bytes are 0 or 1) -------------
+// A block covers WIN_BLOCK flags, 16 per thread (one uint4): counts per block, a scan of the
+// block counts, then every thread writes the ids of its set bytes behind its block's offset.
+constexpr uint32_t WIN_BLOCK = 256 * 16;
+
+__device__ __forceinline__ uint4 window_load16(const uint8_t *__restrict__ flags, uint64_t at, uint64_t n)
+{
+    if (at + 16 <= n)
+        return *reinterpret_cast<const uint4 *>(flags + at);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t j = 0; j < 16 && at + j < n; j++)
+        w[j >> 2] |= (uint32_t)flags[at + j] << (8 * (j & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ __launch_bounds__(256) void window_count_kernel(const uint8_t *__restrict__ flags, uint64_t n,
+                                                           uint32_t *__restrict__ block_counts)
+{
+    __shared__ uint32_t wave_sum[4];
+    const uint64_t at = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    uint32_t c = 0;
+    if (at < n) {
+        const uint4 v = window_load16(flags, at, n);
+        c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    for (int o = 32; o; o >>= 1)
+        c += __shfl_xor(c, o);
+    if (fqd_lane() == 0)
+        wave_sum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        block_counts[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+
+__global__ __launch_bounds__(256) void window_emit_kernel(const uint8_t *__restrict__ flags, uint64_t n,
+                                                          const uint32_t *__restrict__ block_incl, uint64_t id_base,
+                                                          uint64_t *__restrict__ out)
+{
+    __shared__ uint32_t wave_sum[4];
+    const uint64_t at = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (at < n)
+        v = window_load16(flags, at, n);
+    const uint32_t mine = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    uint32_t incl = mine;                       // inclusive scan over the wave
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if (fqd_lane() >= (uint32_t)o)
+            incl += up;
+    }
+    if (fqd_lane() == 63)
+        wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t pos = blockIdx.x ? block_incl[blockIdx.x - 1] : 0u;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
+        pos += wave_sum[w];
+    pos += incl - mine;
+    const uint32_t word[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        uint32_t m = word[j];
+        while (m) {
+            const uint32_t b = __ffs((int)m) - 1;          // bit 8k of the word = byte k
+            out[pos++] = id_base + at + j * 4 + (b >> 3);
+            m &= m - 1;
+        }
+    }
 }
 
 __global__ void gather_kept_kernel(const uint32_t *__restrict__ kept_u32, const uint32_t *__restrict__ kept_scan,
@@ -317,6 +409,13 @@ hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, 
 {
     if (E)
         uf_union_kernel<<<grid_for(E), 256, 0, st>>>(parent, edges, E, n_hooks);
+    return hipGetLastError();
+}
+
+hipError_t launch_hook_total(const unsigned long long *slots, uint64_t n_nodes, unsigned long long *n_components,
+                             hipStream_t st)
+{
+    hook_total_kernel<<<1, 64, 0, st>>>(slots, n_nodes, n_components);
     return hipGetLastError();
 }
 
@@ -398,15 +497,33 @@ hipError_t launch_adjacency_round(const uint32_t *edges, uint64_t E, uint64_t U,
 
 hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t *best, const uint8_t *state,
                              const uint64_t *ufirst, uint64_t id_lo, uint64_t id_hi, uint64_t U, uint8_t *kept,
-                             uint32_t *kept_u32, unsigned long long *n_kept_total, hipStream_t st)
+                             uint32_t *kept_u32, uint8_t *window_flags, uint64_t window_size,
+                             unsigned long long *n_kept_total, hipStream_t st)
 {
     if (U) {
         unsigned g = grid_for(U);
         if (g > 2048)
             g = 2048;
         kept_flags_kernel<<<g, 256, 0, st>>>(method, labels, best, state, ufirst, id_lo, id_hi, U, kept, kept_u32,
-                                             n_kept_total);
+                                             window_flags, window_size, n_kept_total);
     }
+    return hipGetLastError();
+}
+
+uint32_t window_blocks(uint64_t n) { return (uint32_t)((n + WIN_BLOCK - 1) / WIN_BLOCK); }
+
+hipError_t launch_window_count(const uint8_t *flags, uint64_t n, uint32_t *block_counts, hipStream_t st)
+{
+    if (n)
+        window_count_kernel<<<window_blocks(n), 256, 0, st>>>(flags, n, block_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_window_emit(const uint8_t *flags, uint64_t n, const uint32_t *block_incl, uint64_t id_base,
+                              uint64_t *out, hipStream_t st)
+{
+    if (n)
+        window_emit_kernel<<<window_blocks(n), 256, 0, st>>>(flags, n, block_incl, id_base, out);
     return hipGetLastError();
 }
 

@@ -175,7 +175,8 @@ int fqd_gather_unique(fqd_ctx *ctx, const uint32_t *idx, uint64_t n, uint32_t *r
 /* Unique table of stage 2. */
 int fqd_export_unique(fqd_ctx *ctx, uint32_t *recs, uint32_t *lens, uint32_t *counts,
                       uint64_t *first_ids, int mem);
-/* counts NULL = 1 each, first_ids NULL = 0 each (a table that is only searched). */
+/* counts NULL = 1 each, first_ids NULL = 0 each (a table that is only searched). first_ids, when
+ * given, are pairwise distinct (they are read ids). */
 int fqd_import_unique(fqd_ctx *ctx, const uint32_t *recs, const uint32_t *lens,
                       const uint32_t *counts, const uint64_t *first_ids, uint64_t n_unique, int mem);
 /* Edge list of stage 3: n_edges pairs (u, v), u < v. */
