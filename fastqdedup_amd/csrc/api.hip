@@ -112,7 +112,7 @@ struct fqd_ctx {
     // stage 5
     uint64_t n_kept = 0, n_listed = 0;          // kept keys; kept keys whose first holder is in the id window
     uint64_t id_lo = 0, id_hi = ~0ull;
-    DevBuf best, state, blocked, kept, kept_u32, kept_scan, kept_ids, kept_ids_sorted;
+    DevBuf best, state, blocked, taint, root_taint, kept, kept_u32, kept_scan, kept_ids, kept_ids_sorted;
     // scratch
     DevBuf tmp, stage_a, stage_b, stage_c, stage_d;
 
@@ -625,7 +625,7 @@ void fqd_destroy(fqd_ctx *c)
                       &c->ed_payload, &c->ed_hash_sorted, &c->ed_payload_sorted, &c->ed_cands, &c->ed_cands_sorted,
                       &c->d_alphabet, &c->labels, &c->best, &c->state,
                       &c->blocked, &c->kept, &c->kept_u32, &c->kept_scan, &c->kept_ids, &c->kept_ids_sorted, &c->tmp,
-                      &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners};
+                      &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners, &c->taint, &c->root_taint};
     for (DevBuf *b : bufs)
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1144,6 +1144,8 @@ static int list_kept(fqd_ctx *c, int method)
         HIP_TRY(c, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
                                           c->state.as<uint8_t>(), c->ufirst.as<uint64_t>(), c->id_lo, c->id_hi, U,
                                           c->kept.as<uint8_t>(), nullptr, c->stage_c.as<uint8_t>(), window,
+                                          c->ucounts.as<uint32_t>(), c->blocked.as<uint32_t>(),
+                                          c->root_taint.as<uint8_t>(),
                                           c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
         HIP_TRY(c, c->kept_ids_sorted.reserve(std::min(window, U) * 8 + 16));
         const uint32_t blocks = fqd::window_blocks(window);
@@ -1171,6 +1173,7 @@ static int list_kept(fqd_ctx *c, int method)
     HIP_TRY(c, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
                                       c->state.as<uint8_t>(), c->ufirst.as<uint64_t>(), c->id_lo, c->id_hi, U,
                                       c->kept.as<uint8_t>(), c->kept_u32.as<uint32_t>(), nullptr, 0,
+                                      c->ucounts.as<uint32_t>(), c->blocked.as<uint32_t>(), c->root_taint.as<uint8_t>(),
                                       c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
     FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), U));
     uint32_t nk = 0;
@@ -1217,11 +1220,30 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
     HIP_TRY(c, c->kept_scan.reserve(U * 4 + 16));
     HIP_TRY(c, fqd::launch_dissect_init(c->best.as<uint32_t>(), c->state.as<uint8_t>(), U, c->st));
     uint32_t *d_changed = c->d_ctr32.as<uint32_t>() + C_CHANGED;
+    int list_method = method;      // how list_kept reads the verdicts
     if (method == FQD_METHOD_HIGHEST_COUNT) {
         FQD_TRY(ensure_flat_labels(c));
         HIP_TRY(c, fqd::launch_highest_count(c->labels.as<uint32_t>(), c->ucounts.as<uint32_t>(),
                                              c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, U,
                                              c->best.as<uint32_t>(), c->st));
+    } else if (method == FQD_METHOD_DIRECTIONAL && c->collapsed && !getenv("FQD_DIRECTIONAL_ROUNDS")) {
+        // closed form (graph.hip): two passes over the edges, no rounds, no host round trips. It
+        // relies on a strict order of the keys, so a caller's list with repeated keys
+        // (fqd_import_unique) takes the relaxation rounds below.
+        HIP_TRY(c, c->blocked.reserve(U * 4 + 16));   // here: union-find over the count-1 keys
+        HIP_TRY(c, c->taint.reserve(U + 16));
+        HIP_TRY(c, c->root_taint.reserve(U + 16));
+        if (E) {
+            HIP_TRY(c, hipMemsetAsync(c->taint.p, 0, U, c->st));
+            HIP_TRY(c, hipMemsetAsync(c->root_taint.p, 0, U, c->st));
+            HIP_TRY(c, fqd::launch_uf_init(c->blocked.as<uint32_t>(), U, c->st));
+            for (int pass = 1; pass <= 2; pass++)
+                KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_directional_closed(
+                          c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(), c->urecs.as<uint32_t>(),
+                          c->ulens.as<uint32_t>(), sh, c->blocked.as<uint32_t>(), c->state.as<uint8_t>(),
+                          c->taint.as<uint8_t>(), c->root_taint.as<uint8_t>(), c->best.as<uint32_t>(), pass, c->st));
+            list_method = 3;
+        }
     } else if (method == FQD_METHOD_DIRECTIONAL) {
         HIP_TRY(c, c->blocked.reserve(U * 4 + 16));   // here: round stamps of the nodes
         if (E)
@@ -1257,7 +1279,7 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
                 break;
         }
     }
-    FQD_TRY(list_kept(c, method));
+    FQD_TRY(list_kept(c, list_method));
     timer.stop();
     c->stage = ST_KEPT;
     if (n_kept)
@@ -1676,6 +1698,14 @@ int fqd_import_unique(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, co
             c->id_bits++;
     }
     c->stage = ST_UNIQUE;
+    return FQD_OK;
+}
+
+int fqd_declare_distinct_keys(fqd_ctx *c)
+{
+    if (c->stage < ST_UNIQUE)
+        return fail(c, FQD_E_STATE, "no unique table yet");
+    c->collapsed = true;
     return FQD_OK;
 }
 

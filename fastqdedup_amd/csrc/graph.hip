@@ -15,6 +15,12 @@
 //   directional    with arcs t->c for every edge where 2*count_c-1 <= count_t
 //                  (:84), key v is kept iff no key of higher rank reaches v along
 //                  arcs. best[v] = max rank over {u : u ~> v}; kept iff best[v]==v.
+//                  Closed form (no rounds): a key with count >= 2
+//                  is reached only from keys of strictly larger count, so it is kept iff
+//                  it has NO in-arc; keys of count 1 take an arc from every neighbour and
+//                  reach each other, so a connected set S of count-1 keys is dropped
+//                  entirely when it touches a key of count >= 2, and otherwise (S is a
+//                  whole component) keeps exactly its largest key.
 //   adjacency      greedy "take the max, drop its neighbours, repeat" (:112-122) is
 //                  the lexicographically-first maximal independent set in rank
 //                  order: v is kept iff none of its higher-rank neighbours is kept.
@@ -224,6 +230,72 @@ __global__ void directional_round_kernel(const uint32_t *__restrict__ edges, uin
         *changed = 1;
 }
 
+// ---- directional, closed form -------------------------------------------------------
+// Pass 1 over the edges: in-arcs of keys with count >= 2 (state = 2: dropped), count-1 keys that
+// touch a bigger key (taint), and a union-find over the edges between count-1 keys.
+__global__ void directional_edges_kernel(const uint32_t *__restrict__ edges, uint64_t E,
+                                         const uint32_t *__restrict__ ucounts, uint32_t *parent1, uint8_t *state,
+                                         uint8_t *taint)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E)
+        return;
+    const uint32_t u = edges[2 * e], v = edges[2 * e + 1];
+    if (u == v)
+        return;
+    const long long cu = ucounts[u], cv = ucounts[v];
+    if (cu == 1 && cv == 1) {
+        uint32_t a = u, b = v;
+        for (;;) {
+            a = uf_find(parent1, a);
+            b = uf_find(parent1, b);
+            if (a == b)
+                break;
+            if (a > b) {
+                const uint32_t t = a;
+                a = b;
+                b = t;
+            }
+            if (atomicCAS(&parent1[b], b, a) == b)
+                break;
+        }
+        return;
+    }
+    if (cv >= 2 && 2 * cv - 1 <= cu)
+        state[v] = 2;          // arc u -> v from a key of larger count
+    if (cu >= 2 && 2 * cu - 1 <= cv)
+        state[u] = 2;
+    if (cu == 1)
+        taint[u] = 1;          // here cv >= 2: v reaches u and outranks all of u's count-1 set
+    if (cv == 1)
+        taint[v] = 1;
+}
+
+// Pass 2 (after every union of pass 1): each count-1 key reports to the root of its set.
+__global__ void directional_roots_kernel(const uint32_t *__restrict__ edges, uint64_t E,
+                                         const uint32_t *__restrict__ ucounts, const uint32_t *__restrict__ urecs,
+                                         const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t *parent1,
+                                         const uint8_t *__restrict__ taint, uint8_t *root_taint, uint32_t *best)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E)
+        return;
+    const uint32_t ends[2] = {edges[2 * e], edges[2 * e + 1]};
+    if (ends[0] == ends[1])
+        return;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const uint32_t x = ends[k];
+        if (ucounts[x] != 1)
+            continue;
+        const uint32_t r = uf_find(parent1, x);
+        if (taint[x])
+            root_taint[r] = 1;
+        if (r != x)
+            raise_best(best, r, x, ucounts, urecs, ulens, sh);
+    }
+}
+
 // Put the endpoint of higher rank first, once: the adjacency rounds then never compare keys.
 __global__ void orient_edges_kernel(uint32_t *__restrict__ edges, uint64_t E, const uint32_t *__restrict__ ucounts,
                                     const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens,
@@ -283,6 +355,9 @@ __global__ __launch_bounds__(256) void kept_flags_kernel(int method, const uint3
                                                          const uint64_t *__restrict__ ufirst, uint64_t id_lo,
                                                          uint64_t id_hi, uint64_t U, uint8_t *kept, uint32_t *kept_u32,
                                                          uint8_t *window_flags, uint64_t window_size,
+                                                         const uint32_t *__restrict__ ucounts,
+                                                         const uint32_t *__restrict__ parent1,
+                                                         const uint8_t *__restrict__ root_taint,
                                                          unsigned long long *n_kept_total)
 {
     unsigned long long total = 0;
@@ -293,7 +368,18 @@ __global__ __launch_bounds__(256) void kept_flags_kernel(int method, const uint3
             k = best[labels[v]] == (uint32_t)v;
         else if (method == 2)
             k = best[v] == (uint32_t)v;
-        else
+        else if (method == 3) {    // directional, closed form
+            if (ucounts[v] != 1) {
+                k = state[v] != 2;
+            } else {
+                uint32_t r = (uint32_t)v, p = parent1[r];
+                while (p != r) {
+                    r = p;
+                    p = parent1[r];
+                }
+                k = !root_taint[r] && best[r] == (uint32_t)v;
+            }
+        } else
             k = state[v] == 1;
         kept[v] = k ? 1 : 0;
         const uint64_t id = ufirst[v];
@@ -477,6 +563,20 @@ hipError_t launch_directional_round(const uint32_t *edges, uint64_t E, const uin
     return hipGetLastError();
 }
 
+hipError_t launch_directional_closed(const uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
+                                     const uint32_t *ulens, KeyShape sh, uint32_t *parent1, uint8_t *state,
+                                     uint8_t *taint, uint8_t *root_taint, uint32_t *best, int pass, hipStream_t st)
+{
+    if (!E)
+        return hipSuccess;
+    if (pass == 1)
+        directional_edges_kernel<<<grid_for(E), 256, 0, st>>>(edges, E, ucounts, parent1, state, taint);
+    else
+        directional_roots_kernel<<<grid_for(E), 256, 0, st>>>(edges, E, ucounts, urecs, ulens, sh, parent1, taint,
+                                                              root_taint, best);
+    return hipGetLastError();
+}
+
 hipError_t launch_orient_edges(uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
                                const uint32_t *ulens, KeyShape sh, hipStream_t st)
 {
@@ -498,6 +598,7 @@ hipError_t launch_adjacency_round(const uint32_t *edges, uint64_t E, uint64_t U,
 hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t *best, const uint8_t *state,
                              const uint64_t *ufirst, uint64_t id_lo, uint64_t id_hi, uint64_t U, uint8_t *kept,
                              uint32_t *kept_u32, uint8_t *window_flags, uint64_t window_size,
+                             const uint32_t *ucounts, const uint32_t *parent1, const uint8_t *root_taint,
                              unsigned long long *n_kept_total, hipStream_t st)
 {
     if (U) {
@@ -505,7 +606,7 @@ hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t 
         if (g > 2048)
             g = 2048;
         kept_flags_kernel<<<g, 256, 0, st>>>(method, labels, best, state, ufirst, id_lo, id_hi, U, kept, kept_u32,
-                                             window_flags, window_size, n_kept_total);
+                                             window_flags, window_size, ucounts, parent1, root_taint, n_kept_total);
     }
     return hipGetLastError();
 }

@@ -151,6 +151,7 @@ class HipBackend:
         """Search pass `segment` over rows received from every rank; edges as uid pairs."""
         n = recs.shape[0]
         self.aux.import_unique(recs, lens if self.ragged else None, None, None, n, borrow=True)
+        self.aux.declare_distinct_keys()
         ne = self.aux.find_edges_segments(max_distance, segment, segment + 1)
         edges = torch.empty((ne, 2), dtype=torch.int32, device=self.device)
         self.aux.export_edges(edges)
@@ -173,6 +174,7 @@ class HipBackend:
         """Verdict (uint8, 1 = kept) for every row of a table of whole clusters."""
         n = recs.shape[0]
         self.aux.import_unique(recs, lens if self.ragged else None, counts, None, n, borrow=True)
+        self.aux.declare_distinct_keys()      # rows of collapsed tables: no key twice
         self.aux.import_edges(edges.contiguous(), edges.shape[0])
         self.aux.components()
         self.aux.dissect(method)
@@ -195,6 +197,7 @@ class HipBackend:
     # ---- gathered plan ----------------------------------------------------------------------
     def find_edges(self, urecs, ulens, ucounts, ufirst, max_distance, metric, shard, n_shards):
         self.ctx.import_unique(urecs, ulens, ucounts, ufirst, urecs.shape[0])
+        self.ctx.declare_distinct_keys()      # every key was collapsed on its owner rank
         ne = self.ctx.find_edges(max_distance, metric, shard, n_shards)
         edges = torch.empty((ne, 2), dtype=torch.int32, device=self.device)
         self.ctx.export_edges(edges)

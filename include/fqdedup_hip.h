@@ -179,6 +179,10 @@ int fqd_export_unique(fqd_ctx *ctx, uint32_t *recs, uint32_t *lens, uint32_t *co
  * given, are pairwise distinct (they are read ids). */
 int fqd_import_unique(fqd_ctx *ctx, const uint32_t *recs, const uint32_t *lens,
                       const uint32_t *counts, const uint64_t *first_ids, uint64_t n_unique, int mem);
+/* The caller vouches that the imported rows hold pairwise DISTINCT keys (rows of collapsed tables
+ * of other ranks): the table is then treated like one fqd_collapse made (no distance-0 search,
+ * closed-form directional dissection). */
+int fqd_declare_distinct_keys(fqd_ctx *ctx);
 /* Edge list of stage 3: n_edges pairs (u, v), u < v. */
 int fqd_export_edges(fqd_ctx *ctx, uint32_t *uv, int mem);
 int fqd_import_edges(fqd_ctx *ctx, const uint32_t *uv, uint64_t n_edges, int mem);

@@ -408,6 +408,36 @@ def test_bucket_shards_union_to_the_whole_search(F, oracle, edit, d):
     assert np.array_equal(kept, want["kept_read_ids"])
 
 
+@pytest.mark.parametrize("edit", [False, True])
+def test_directional_closed_form_equals_rounds(F, oracle, monkeypatch, edit):
+    """The directional dissection has a closed form on collapsed tables (two passes over the edges)
+    and a relaxation-round form (lists with repeated keys): same verdicts, and the oracle's."""
+    import random
+    rng = random.Random(77)
+    mols = ["".join(rng.choice("ACGT") for _ in range(rng.choice([14, 15, 16]) if edit else 16)) for _ in range(700)]
+    keys, weights = [], []
+    for _ in range(30_000):
+        s = list(rng.choice(mols))
+        for _ in range(rng.choice([0, 0, 0, 1, 1, 2])):
+            pos = rng.randrange(len(s))
+            s[pos] = rng.choice("ACGTN")
+        keys.append("".join(s))
+        weights.append(rng.choice([0, 1, 1, 1, 2, 5]))
+    raw, off = _pack(keys)
+    w = np.array(weights, dtype=np.uint32)
+    want = oracle.dedup(raw, off, w, max_distance=2 if not edit else 1, use_edit_distance=edit, method="directional")
+    got = {}
+    for mode in ("closed", "rounds"):
+        if mode == "rounds":
+            monkeypatch.setenv("FQD_DIRECTIONAL_ROUNDS", "1")
+        res = F.cluster_keys(raw, off, weights=w, max_distance=2 if not edit else 1, use_edit_distance=edit,
+                             method="directional", context=F.Context(0))
+        got[mode] = res.kept_read_ids
+        assert res.n_clusters == want["n_clusters"]
+    assert np.array_equal(got["closed"], got["rounds"])
+    assert np.array_equal(got["closed"], want["kept_read_ids"])
+
+
 def test_segment_passes_partition_the_search(F, oracle):
     """fqd_find_edges_segments: disjoint pass ranges give every edge of the whole search exactly
     once (a pair is reported in the first segment it agrees on)."""
