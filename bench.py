@@ -229,6 +229,9 @@ def main():
         "segment_hashes_kernel": U * (b_key + 4 * nseg),
         # (bucket hash, uid) of every unique key, the record of every key in a bucket >= 2, 8 B per edge
         "bucket_pairs_kernel": U * 8 + st["keys_gathered"] / nseg * b_key + st["edges"] / nseg * 8,
+        "gp_hist_kernel": U * 6,                                     # level 1 reads the hash, level 2 the (hash, uid) item
+        "gp_scatter_kernel": U * 14,                                 # 4 + 8 at level 1, 8 + 8 at level 2
+        "verify_candidates_kernel": st["pairs_compared"] / nseg * (8 + 2 * b_key) + st["edges"] / nseg * 8,
         "uf_union_kernel": E * 8,
         "uf_flatten_kernel": U * 8,
         "dissect_round_kernel": E * 8,

@@ -62,7 +62,7 @@ enum Stage { ST_EMPTY = 0, ST_PACKED = 1, ST_UNIQUE = 2, ST_EDGES = 3, ST_LABELS
 
 // small device-side words read back by the host
 enum Ctr { C_BAD = 0, C_COLLISIONS = 1, C_CHANGED = 2, C_MINLEN = 3, C_MAXLEN = 4, C_N32 = 8 };
-enum Ctr64 { C64_EDGES = 0, C64_ROOTS = 1, C64_SUM = 2, C64_STATS = 3 /* 3,4,5 */, C64_N = 8 };
+enum Ctr64 { C64_EDGES = 0, C64_ROOTS = 1, C64_SUM = 2, C64_STATS = 3, C64_CANDS = 4, C64_CAND_NEED = 5, C64_N = 8 };
 
 }  // namespace
 
@@ -102,6 +102,8 @@ struct fqd_ctx {
     // stage 3
     uint64_t E = 0, edge_cap = 0;
     DevBuf seg_hashes, sorted_hash, sorted_uid, uid_iota, edges, sel_hash, sel_uid;
+    DevBuf gp_a, gp_b, gp_small, gp_cands;   // grouped search pass: items after level 1 / level 2, small tables, candidate pairs
+    uint64_t gp_cand_cap = 0;
     DevBuf q_table, q_pass, q_means, q_bytes, q_offsets;
     DevBuf len_present, ed_hash, ed_payload, ed_hash_sorted, ed_payload_sorted, ed_cands, ed_cands_sorted, d_alphabet;
     fqd::PairStats last_stats{};
@@ -625,7 +627,7 @@ void fqd_destroy(fqd_ctx *c)
                       &c->ed_payload, &c->ed_hash_sorted, &c->ed_payload_sorted, &c->ed_cands, &c->ed_cands_sorted,
                       &c->d_alphabet, &c->labels, &c->best, &c->state,
                       &c->blocked, &c->kept, &c->kept_u32, &c->kept_scan, &c->kept_ids, &c->kept_ids_sorted, &c->tmp,
-                      &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners, &c->taint, &c->root_taint};
+                      &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners, &c->taint, &c->root_taint, &c->gp_a, &c->gp_b, &c->gp_small, &c->gp_cands};
     for (DevBuf *b : bufs)
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -938,6 +940,82 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
     return FQD_OK;
 }
 
+// One Hamming search pass without a device-wide sort (group.hip): the (segment hash, uid) pairs
+// are partitioned into 2^B buckets of ~50-100 keys by the top hash bits, then one wave per bucket
+// compares hashes all against all out of LDS. Queues work only (no host round trip).
+static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t d, uint32_t s, uint32_t nseg)
+{
+    const KeyShape sh = c->ks;
+    uint32_t B = 8;
+    while (B < 20 && (U >> B) > 96)
+        B++;
+    if (const char *e = getenv("FQD_GROUP_BUCKET_BITS"))   // tests: few, crowded buckets
+        B = (uint32_t)std::max(1, std::min(20, atoi(e)));
+    const uint32_t B1 = B <= 18 ? std::min<uint32_t>(B, 8) : B - 10, B2 = B - B1;
+    const uint32_t bins1 = 1u << B1, bins2 = 1u << B2, n_buckets = 1u << B;
+    const uint32_t tile = fqd::group_tile_size();
+    const uint32_t tiles1 = (uint32_t)((U + tile - 1) / tile), max_tiles2 = tiles1 + bins1;
+    HIP_TRY(c, c->gp_a.reserve(U * 8 + 16));
+    HIP_TRY(c, c->gp_small.reserve(4096 * 4 + (size_t)fqd::group_cand_lists() * 64));
+    HIP_TRY(c, c->ld_start.reserve(((size_t)n_buckets + 1) * 4 + 16));
+    uint32_t *small = c->gp_small.as<uint32_t>();
+    uint32_t *seg1 = small, *tiles1_d = small + 8, *start1 = small + 16, *tiles2_d = small + 2048;
+    const uint32_t seg1_h[2] = {0u, (uint32_t)U}, tiles1_h[2] = {0u, tiles1};
+    HIP_TRY(c, hipMemcpyAsync(seg1, seg1_h, 8, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, hipMemcpyAsync(tiles1_d, tiles1_h, 8, hipMemcpyHostToDevice, c->st));
+    // ---- level 1: (bin x tile) count matrix, scan, placement without atomics
+    const size_t matrix = (size_t)bins1 * tiles1;
+    HIP_TRY(c, c->ld_matrix.reserve(matrix * 4 + 16));
+    HIP_TRY(c, c->ld_matrix_incl.reserve(matrix * 4 + 16));
+    KTIME(c, FQD_K_GROUP_HIST, fqd::launch_group_hist(true, hashes, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1, bins1,
+                                                      c->ld_matrix.as<uint32_t>(), c->st));
+    FQD_TRY(scan_u32(c, c->ld_matrix.as<uint32_t>(), c->ld_matrix_incl.as<uint32_t>(), matrix));
+    HIP_TRY(c, fqd::launch_group_matrix_starts(c->ld_matrix_incl.as<uint32_t>(), bins1, tiles1, start1, c->st));
+    KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(true, hashes, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1,
+                                                            bins1, c->ld_matrix_incl.as<uint32_t>(),
+                                                            c->gp_a.as<uint32_t>(), c->st));
+    const uint32_t *items = c->gp_a.as<uint32_t>();
+    if (B2 == 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->ld_start.p, start1, ((size_t)bins1 + 1) * 4, hipMemcpyDeviceToDevice, c->st));
+    } else {
+        // ---- level 2: every part into 2^B2 buckets by the next hash bits
+        HIP_TRY(c, c->gp_b.reserve(U * 8 + 16));
+        HIP_TRY(c, c->ld_hist.reserve((size_t)n_buckets * 4 + 16));
+        HIP_TRY(c, c->ld_hist_incl.reserve((size_t)n_buckets * 4 + 16));
+        HIP_TRY(c, c->ld_cursor.reserve((size_t)n_buckets * 4 + 16));
+        HIP_TRY(c, fqd::launch_group_tile_starts(start1, bins1, tiles2_d, c->st));
+        HIP_TRY(c, hipMemsetAsync(c->ld_hist.p, 0, (size_t)n_buckets * 4, c->st));
+        KTIME(c, FQD_K_GROUP_HIST, fqd::launch_group_hist(false, nullptr, c->gp_a.as<uint32_t>(), start1, tiles2_d, bins1,
+                                                          max_tiles2, 32 - B, bins2, c->ld_hist.as<uint32_t>(), c->st));
+        FQD_TRY(scan_u32(c, c->ld_hist.as<uint32_t>(), c->ld_hist_incl.as<uint32_t>(), n_buckets));
+        HIP_TRY(c, fqd::launch_group_bucket_starts(c->ld_hist_incl.as<uint32_t>(), n_buckets,
+                                                   c->ld_start.as<uint32_t>(), c->ld_cursor.as<uint32_t>(), c->st));
+        KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(false, nullptr, c->gp_a.as<uint32_t>(), start1, tiles2_d,
+                                                                bins1, max_tiles2, 32 - B, bins2,
+                                                                c->ld_cursor.as<uint32_t>(), c->gp_b.as<uint32_t>(),
+                                                                c->st));
+        items = c->gp_b.as<uint32_t>();
+    }
+    // candidates (pairs with equal segment hashes) -> device list -> verification, one thread per pair
+    if (c->gp_cand_cap < 1024 || !c->gp_cands.p) {
+        c->gp_cand_cap = std::max<uint64_t>(1u << 20, 2 * U);   // split evenly over the lists: leave slack
+        HIP_TRY(c, c->gp_cands.reserve(c->gp_cand_cap * 8));
+    }
+    c->gp_cand_cap = c->gp_cands.cap / 8;
+    // the candidate counters (one per list, a cache line apart) live behind the small tables
+    unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(small + 4096);
+    HIP_TRY(c, hipMemsetAsync(cand_ctr, 0, (size_t)fqd::group_cand_lists() * 64, c->st));
+    unsigned long long *ctr = c->d_ctr64.as<unsigned long long>();
+    KTIME(c, FQD_K_PAIRS, fqd::launch_grouped_candidates(items, c->ld_start.as<uint32_t>(), n_buckets, U,
+                                                         c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,
+                                                         c->st));
+    KTIME(c, FQD_K_VERIFY, fqd::launch_verify_candidates(c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,
+                                                         c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, s, nseg,
+                                                         c->edges.as<uint32_t>(), ctr + C64_EDGES, c->edge_cap,
+                                                         ctr + C64_CAND_NEED, c->d_stats.as<fqd::PairStats>(), c->st));
+    return FQD_OK;
+}
+
 // Shared body of fqd_find_edges / fqd_find_edges_segments: passes [seg_lo, seg_hi) of the
 // (max_distance+1)-way pigeonhole split (the whole range for a plain search).
 static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uint32_t n_shards,
@@ -978,7 +1056,6 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         HIP_TRY(c, c->sorted_hash.reserve(U * 4 + 16));
         HIP_TRY(c, c->sorted_uid.reserve(U * 4 + 16));
         HIP_TRY(c, c->uid_iota.reserve(U * 4 + 16));
-        HIP_TRY(c, fqd::launch_iota_u32(c->uid_iota.as<uint32_t>(), U, c->st));
         KTIME(c, FQD_K_SEG_HASH, fqd::launch_segment_hashes(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, sh, nseg,
                                               seg_lo, seg_hi, 0, c->seg_hashes.as<uint32_t>(), c->st));
         if (c->edge_cap < 1024 || !c->edges.p) {
@@ -991,6 +1068,13 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
             HIP_TRY(c, c->sel_hash.reserve(U * 4 + 16));
             HIP_TRY(c, c->sel_uid.reserve(U * 4 + 16));
         }
+        // Grouping by partition (group.hip) unless a bucket shard was asked for or the table is small
+        // (FQD_EDGES=sort|grouped pins the path for tests).
+        const char *pin = getenv("FQD_EDGES");
+        const bool grouped = n_shards == 1 && U < 0xFFFFFF00ull &&
+                             (pin ? !strcmp(pin, "grouped") : U >= 65536);
+        bool iota_ready = false;
+        FQD_TRY(zero_ctr64(c, C64_CAND_NEED));
         // All d+1 passes are queued without a host round trip; the edge count is read ONCE at the
         // end. If the passes overflowed the edge buffer (the count still says how many edges there
         // are), the buffer is grown to the known need and the whole search runs again.
@@ -1010,7 +1094,14 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
                     m = got;
                     FQD_TRY(sort_u32_pairs(c, c->sel_hash.as<uint32_t>(), c->sorted_hash.as<uint32_t>(),
                                            c->sel_uid.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), m));
+                } else if (grouped) {
+                    FQD_TRY(grouped_pass(c, pass_hashes, U, d, s, nseg));
+                    continue;
                 } else {
+                    if (!iota_ready) {
+                        HIP_TRY(c, fqd::launch_iota_u32(c->uid_iota.as<uint32_t>(), U, c->st));
+                        iota_ready = true;
+                    }
                     FQD_TRY(sort_u32_pairs(c, pass_hashes,
                                            c->sorted_hash.as<uint32_t>(), c->uid_iota.as<uint32_t>(),
                                            c->sorted_uid.as<uint32_t>(), U));
@@ -1021,17 +1112,26 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
                                c->edges.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_EDGES, c->edge_cap,
                                c->d_stats.as<fqd::PairStats>(), c->st));
             }
-            unsigned long long now = 0;
-            FQD_TRY(read_ctr64(c, C64_EDGES, &now));
-            if (now <= c->edge_cap) {
+            unsigned long long ctrs[C64_CAND_NEED + 1] = {0};
+            FQD_TRY(read_ctr64(c, 0, ctrs, C64_CAND_NEED + 1));
+            const unsigned long long now = ctrs[C64_EDGES], cand_need = grouped ? ctrs[C64_CAND_NEED] : 0;
+            if (now <= c->edge_cap && cand_need <= c->gp_cand_cap) {
                 have = now;
                 break;
             }
             if (attempt > 2)
                 return fail(c, FQD_E_RUNTIME, "edge buffer kept overflowing");
-            c->edges.release();
-            HIP_TRY(c, c->edges.reserve((size_t)(now + now / 8 + 1024) * 8));
-            c->edge_cap = c->edges.cap / 8;
+            if (now > c->edge_cap) {
+                c->edges.release();
+                HIP_TRY(c, c->edges.reserve((size_t)(now + now / 8 + 1024) * 8));
+                c->edge_cap = c->edges.cap / 8;
+            }
+            if (cand_need > c->gp_cand_cap) {
+                c->gp_cands.release();
+                HIP_TRY(c, c->gp_cands.reserve((size_t)(cand_need + cand_need / 8 + 1024) * 8));
+                c->gp_cand_cap = c->gp_cands.cap / 8;
+            }
+            FQD_TRY(zero_ctr64(c, C64_CAND_NEED));
             FQD_TRY(zero_ctr64(c, C64_EDGES));
             HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
         }

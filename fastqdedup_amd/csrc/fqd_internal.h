@@ -254,6 +254,29 @@ hipError_t launch_contains(const uint8_t *q, const uint64_t *qo, uint64_t nq, co
                            const uint32_t *ulens, uint64_t U, KeyShape sh, const uint8_t *alphabet_dev, int d,
                            int metric, uint32_t *hit_flags, hipStream_t st);
 
+// group.hip -- one search pass without a sort: two-level partition of (segment hash, uid) + one wave per bucket
+uint32_t group_tile_size();
+uint32_t group_max_bins();
+uint32_t group_cand_lists();   // cand_count of the two launchers below: this many counters, 8 words apart
+hipError_t launch_group_hist(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
+                             const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
+                             uint32_t n_bins, uint32_t *hist, hipStream_t st);
+hipError_t launch_group_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
+                                const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
+                                uint32_t n_bins, uint32_t *cursor, uint32_t *out, hipStream_t st);
+hipError_t launch_group_tile_starts(const uint32_t *seg_start, uint32_t n_seg, uint32_t *tile_start, hipStream_t st);
+hipError_t launch_group_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
+                                      hipStream_t st);
+hipError_t launch_group_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
+                                      uint32_t *cursor, hipStream_t st);
+hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, uint32_t n_buckets,
+                                     uint64_t n_items, uint64_t *cands, unsigned long long *cand_count,
+                                     uint64_t cand_cap, hipStream_t st);
+hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
+                                    const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d, uint32_t seg,
+                                    uint32_t nseg, uint32_t *edges, unsigned long long *edge_count, uint64_t edge_cap,
+                                    unsigned long long *cand_need, PairStats *stats, hipStream_t st);
+
 // exchange.hip -- group packed reads by owner rank
 hipError_t launch_owner(const uint32_t *hashes, uint64_t n, uint32_t parts, uint32_t *owner, hipStream_t st);
 hipError_t launch_gather_by_owner(const uint32_t *order, uint64_t n, KeyShape sh, const uint32_t *recs,

@@ -1,0 +1,636 @@
+// group.hip -- stage 3 without a device-wide sort: the (segment hash, uid) pairs of one search
+// pass are PARTITIONED into ~2^B buckets by the top B hash bits (two levels, LDS-aggregated,
+// the scheme of collapse_lds.hip applied to 8-byte items); one wave per group of buckets then
+// compares the hashes of each bucket's ~50-100 keys all against all out of LDS and lists the pairs
+// whose full 32-bit segment hashes agree; a second kernel verifies those candidates, one thread
+// per pair (record fetches, mismatch count, first-agreeing-segment rule). Same contract as
+// bucket_pairs_kernel (edges.hip; reference _triemodule.c:807-895, the neighbour search of
+// Trie.pop_cluster): every pair within max_distance is reported in the pass of the FIRST
+// segment it agrees on.
+//
+// Against the radix sort it replaces (3 onesweep passes + histogram, 0.47 ms for 14 M pairs):
+// two histogram passes and two scatter passes, every store part of a contiguous run (0.2 ms).
+// What the sort gave for free -- equal hashes adjacent -- costs lambda/2 LDS hash compares per
+// key here (lambda = keys per bucket), cheap next to a fourth pass over HBM.
+#include "fqd_internal.h"
+
+namespace {
+
+constexpr uint32_t GP_THREADS = 256;
+constexpr uint32_t GP_EPT = 8;
+constexpr uint32_t GP_TILE = GP_THREADS * GP_EPT;
+constexpr uint32_t GP_MAX_BINS = 1024;
+constexpr uint32_t GP_SLICE = 512;      // hashes of one bucket held in LDS per wave
+constexpr uint32_t GP_ECAP = 1024;      // edges buffered per block of the verify kernel
+
+// Tiles never straddle a segment (level 1: one segment = everything; level 2: the level-1 parts).
+__device__ __forceinline__ bool gp_tile_of_block(const uint32_t *__restrict__ seg_start,
+                                                 const uint32_t *__restrict__ tile_start, uint32_t n_seg,
+                                                 uint32_t &seg, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t t = blockIdx.x;
+    if (t >= tile_start[n_seg])
+        return false;
+    uint32_t a = 0, b = n_seg;
+    while (b - a > 1) {
+        const uint32_t m = (a + b) >> 1;
+        if (tile_start[m] <= t)
+            a = m;
+        else
+            b = m;
+    }
+    seg = a;
+    lo = seg_start[a] + (t - tile_start[a]) * GP_TILE;
+    hi = min(lo + GP_TILE, seg_start[a + 1]);
+    return true;
+}
+
+// LEVEL 1 reads the hash array (uid = position); LEVEL 2 reads level-1's (hash, uid) items.
+template <bool LEVEL1>
+__device__ __forceinline__ uint2 gp_load(const uint32_t *__restrict__ hashes, const uint2 *__restrict__ in, uint32_t i)
+{
+    if (LEVEL1)
+        return make_uint2(hashes[i], i);
+    return in[i];
+}
+
+template <bool LEVEL1>
+__global__ __launch_bounds__(GP_THREADS) void gp_hist_kernel(const uint32_t *__restrict__ hashes,
+                                                             const uint2 *__restrict__ in,
+                                                             const uint32_t *__restrict__ seg_start,
+                                                             const uint32_t *__restrict__ tile_start, uint32_t n_seg,
+                                                             uint32_t shift, uint32_t n_bins,
+                                                             uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t s_hist[GP_MAX_BINS];
+    uint32_t seg, lo, hi;
+    if (!gp_tile_of_block(seg_start, tile_start, n_seg, seg, lo, hi))
+        return;
+    for (uint32_t b = threadIdx.x; b < n_bins; b += GP_THREADS)
+        s_hist[b] = 0;
+    uint32_t h[GP_EPT];
+#pragma unroll
+    for (uint32_t e = 0; e < GP_EPT; e++) {
+        const uint32_t i = lo + e * GP_THREADS + threadIdx.x;
+        h[e] = i < hi ? gp_load<LEVEL1>(hashes, in, i).x : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < GP_EPT; e++)
+        if (lo + e * GP_THREADS + threadIdx.x < hi)
+            atomicAdd(&s_hist[(h[e] >> shift) & (n_bins - 1)], 1u);
+    __syncthreads();
+    if (LEVEL1) {
+        // (bin x tile) count matrix: its scan in bin-major order is every (tile, bin)'s position
+        const uint32_t n_tiles = tile_start[n_seg];
+        for (uint32_t b = threadIdx.x; b < n_bins; b += GP_THREADS)
+            hist[(size_t)b * n_tiles + blockIdx.x] = s_hist[b];
+    } else {
+        for (uint32_t b = threadIdx.x; b < n_bins; b += GP_THREADS)
+            if (s_hist[b])
+                atomicAdd(&hist[seg * n_bins + b], s_hist[b]);
+    }
+}
+
+// The tile is counting-sorted by bin in LDS before it leaves: every bin's share goes out as one
+// contiguous run of 8-byte stores; the global cursor sees one atomic per (tile, bin).
+template <bool LEVEL1>
+__global__ __launch_bounds__(GP_THREADS) void gp_scatter_kernel(const uint32_t *__restrict__ hashes,
+                                                                const uint2 *__restrict__ in,
+                                                                const uint32_t *__restrict__ seg_start,
+                                                                const uint32_t *__restrict__ tile_start,
+                                                                uint32_t n_seg, uint32_t shift, uint32_t n_bins,
+                                                                uint32_t *__restrict__ cursor,
+                                                                uint2 *__restrict__ out)
+{
+    __shared__ uint32_t s_hist[GP_MAX_BINS], s_off[GP_MAX_BINS], s_base[GP_MAX_BINS];
+    __shared__ uint32_t s_wave[GP_THREADS / 64];
+    __shared__ uint2 s_stage[GP_TILE];
+    __shared__ uint16_t s_stage_bin[GP_TILE];
+    uint32_t seg, lo, hi;
+    if (!gp_tile_of_block(seg_start, tile_start, n_seg, seg, lo, hi))
+        return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t b = tid; b < n_bins; b += GP_THREADS)
+        s_hist[b] = 0;
+    uint2 v[GP_EPT];
+    uint32_t bin[GP_EPT], rank[GP_EPT];
+#pragma unroll
+    for (uint32_t e = 0; e < GP_EPT; e++) {
+        const uint32_t i = lo + e * GP_THREADS + tid;
+        v[e] = make_uint2(0, 0);
+        if (i < hi)
+            v[e] = gp_load<LEVEL1>(hashes, in, i);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < GP_EPT; e++) {
+        bin[e] = 0xFFFFFFFFu;
+        if (lo + e * GP_THREADS + tid < hi) {
+            bin[e] = (v[e].x >> shift) & (n_bins - 1);
+            rank[e] = atomicAdd(&s_hist[bin[e]], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t bpt = (n_bins + GP_THREADS - 1) / GP_THREADS;
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < bpt; k++) {
+        const uint32_t b = tid * bpt + k;
+        mine += b < n_bins ? s_hist[b] : 0u;
+    }
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if ((int)lane >= o)
+            incl += up;
+    }
+    if (lane == 63)
+        s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (uint32_t wv = 0; wv < wave; wv++)
+        run += s_wave[wv];
+    for (uint32_t k = 0; k < bpt; k++) {
+        const uint32_t b = tid * bpt + k;
+        if (b < n_bins) {
+            const uint32_t c = s_hist[b];
+            s_off[b] = run;
+            uint32_t g;
+            if (LEVEL1)
+                g = cursor[(size_t)b * tile_start[n_seg] + blockIdx.x] - c;   // inclusive scan of the matrix
+            else
+                g = c ? atomicAdd(&cursor[seg * n_bins + b], c) : 0u;
+            s_base[b] = g - run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < GP_EPT; e++)
+        if (bin[e] != 0xFFFFFFFFu) {
+            const uint32_t p = s_off[bin[e]] + rank[e];
+            s_stage[p] = v[e];
+            s_stage_bin[p] = (uint16_t)bin[e];
+        }
+    __syncthreads();
+    const uint32_t count = hi - lo;
+#pragma unroll
+    for (uint32_t e = 0; e < GP_EPT; e++) {
+        const uint32_t p = e * GP_THREADS + tid;
+        if (p < count)
+            out[s_base[s_stage_bin[p]] + p] = s_stage[p];
+    }
+}
+
+__global__ void gp_tile_starts_kernel(const uint32_t *__restrict__ seg_start, uint32_t n_seg,
+                                      uint32_t *__restrict__ tile_start)
+{
+    // single block, n_seg <= 1024
+    __shared__ uint32_t s[GP_MAX_BINS + 1];
+    for (uint32_t t = threadIdx.x; t < n_seg; t += blockDim.x)
+        s[t] = (seg_start[t + 1] - seg_start[t] + GP_TILE - 1) / GP_TILE;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < n_seg; i++) {
+            const uint32_t c = s[i];
+            s[i] = acc;
+            acc += c;
+        }
+        s[n_seg] = acc;
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t <= n_seg; t += blockDim.x)
+        tile_start[t] = s[t];
+}
+
+__global__ void gp_matrix_starts_kernel(const uint32_t *__restrict__ matrix_incl, uint32_t n_bins, uint32_t n_tiles,
+                                        uint32_t *__restrict__ start)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= n_bins)
+        start[b] = b ? matrix_incl[(size_t)b * n_tiles - 1] : 0u;
+}
+
+__global__ void gp_bucket_starts_kernel(const uint32_t *__restrict__ hist_incl, uint32_t n_buckets,
+                                        uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ cursor)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_buckets)
+        return;
+    const uint32_t v = b ? hist_incl[b - 1] : 0u;
+    bucket_start[b] = v;
+    if (b < n_buckets)
+        cursor[b] = v;
+}
+
+template <int K>
+__device__ __forceinline__ bool gp_verify(const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens,
+                                          const KeyShape &sh, uint32_t d, uint32_t seg, uint32_t nseg, uint32_t uid,
+                                          uint32_t uj)
+{
+    const uint32_t len = fqd_key_len(sh, ulens, uid);
+    if (fqd_key_len(sh, ulens, uj) != len)
+        return false;
+    const uint32_t W = sh.words;
+    const uint32_t *my_rec = urecs + (uint64_t)uid * sh.stride, *other = urecs + (uint64_t)uj * sh.stride;
+    uint32_t dist = 0;
+    for (uint32_t w = 0; w < W && dist <= d; w++) {
+        uint32_t dw = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            dw |= my_rec[w * K + k] ^ other[w * K + k];
+        dist += __popc(dw);
+    }
+    if (dist > d)
+        return false;
+    // emit only in the pass of the first truly agreeing segment
+    for (uint32_t s2 = 0; s2 < seg; s2++) {
+        uint32_t slo, shi;
+        fqd_segment(len, s2, nseg, slo, shi);
+        bool agree = true;
+        if (shi > slo) {
+            for (uint32_t w = slo >> 5; w <= ((shi - 1) >> 5) && agree; w++) {
+                uint32_t dw = 0;
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    dw |= my_rec[w * K + k] ^ other[w * K + k];
+                if (dw & fqd_range_mask(w, slo, shi))
+                    agree = false;
+            }
+        }
+        if (agree)
+            return false;
+    }
+    return true;
+}
+
+// Phase 1 -- one wave per GROUP of `gsz` consecutive buckets (a group is a contiguous range of
+// items, ~400 keys): lane i holds some keys of the group and walks the keys after each one in ITS
+// bucket, hashes out of LDS; pairs whose 32-bit hashes agree are CANDIDATES, appended (uid, uid)
+// to a device list through a per-wave LDS buffer that the wave flushes by itself (one global
+// atomic per flush). No record is touched here: verifying in place cost one HBM latency chain
+// per pair (17 us per bucket). Waves share nothing, so there is no workgroup barrier at all.
+constexpr uint32_t GP_WCAP = 128;   // candidates buffered per wave
+constexpr uint32_t GP_LISTS = 64;   // candidate lists (one counter each, a cache line apart): flush atomics spread out
+
+__global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
+    const uint2 *__restrict__ items, const uint32_t *__restrict__ bucket_start, uint32_t n_buckets, uint32_t gsz,
+    uint2 *__restrict__ cands_all, unsigned long long *__restrict__ cand_counts, uint64_t list_cap)
+{
+    constexpr uint32_t WAVES = GP_THREADS / 64;
+    // this wave's list: GP_LISTS lists of list_cap pairs each, counters 8 words apart
+    const uint32_t list = (blockIdx.x * WAVES + (threadIdx.x >> 6)) % GP_LISTS;
+    uint2 *__restrict__ cands = cands_all + (size_t)list * list_cap;
+    unsigned long long *__restrict__ cand_count = cand_counts + (size_t)list * 8;
+    const uint64_t cand_cap = list_cap;
+    __shared__ __attribute__((aligned(16))) uint32_t s_hash[WAVES][GP_SLICE];
+    __shared__ uint32_t s_uid[WAVES][GP_SLICE];
+    __shared__ uint32_t s_bnd[WAVES][65];        // item offsets (relative to the group) of its buckets' ends
+    __shared__ uint2 s_wbuf[WAVES][GP_WCAP];
+    __shared__ uint32_t s_wcnt[WAVES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_groups = (n_buckets + gsz - 1) / gsz;
+    uint32_t *hashes = s_hash[wave], *uids = s_uid[wave], *bnd = s_bnd[wave];
+    uint2 *wbuf = s_wbuf[wave];
+    volatile uint32_t *wcnt = &s_wcnt[wave];   // written by the leader lane, read by all: never cached in a register
+
+    // Called by whatever lanes are active at the call site (they are converged there): the active
+    // lanes take consecutive slots; a full buffer is written out first, by the same lanes.
+    auto note = [&](uint32_t a, uint32_t b) {
+        const unsigned long long act = __ballot(1);
+        const uint32_t n = (uint32_t)__popcll(act), rank = (uint32_t)__popcll(act & fqd_lanemask_lt());
+        const int leader = __ffsll((long long)act) - 1;
+        uint32_t have = *wcnt;
+        if (have + n > GP_WCAP) {
+            unsigned long long g = 0;
+            if ((int)lane == leader)
+                g = atomicAdd(cand_count, (unsigned long long)have);
+            g = __shfl(g, leader);
+            for (uint32_t e = rank; e < have; e += n)
+                if (g + e < cand_cap)
+                    cands[g + e] = wbuf[e];
+            have = 0;
+        }
+        wbuf[have + rank] = make_uint2(a, b);
+        if ((int)lane == leader)
+            *wcnt = have + n;
+    };
+
+    if (lane == 0)
+        *wcnt = 0;
+
+    for (uint32_t g = blockIdx.x * WAVES + wave; g < n_groups; g += gridDim.x * WAVES) {
+        const uint32_t b0 = g * gsz;
+        const uint32_t nb = b0 + gsz <= n_buckets ? gsz : n_buckets - b0;   // buckets of this group
+        // ONE coalesced load of the group's nb + 1 bucket offsets (lane l: bucket_start[b0 + l])
+        uint32_t mine_off = 0;
+        if (lane <= nb)
+            mine_off = bucket_start[b0 + lane];
+        const uint32_t lo = __shfl(mine_off, 0);
+        const uint32_t m = __shfl(mine_off, (int)nb) - lo;
+        if (lane >= 1 && lane <= nb)
+            bnd[lane - 1] = mine_off - lo;
+        const uint2 *grp = items + lo;
+        const uint32_t m_lds = m < GP_SLICE ? m : GP_SLICE;
+        {
+            // all of the lane's loads in flight before the first LDS store (a load-store loop
+            // pays one HBM latency per 64 items)
+            uint2 v[GP_SLICE / 64];
+#pragma unroll
+            for (uint32_t k = 0; k < GP_SLICE / 64; k++) {
+                const uint32_t t = lane + 64 * k;
+                v[k] = make_uint2(0, 0);
+                if (t < m_lds)
+                    v[k] = grp[t];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < GP_SLICE / 64; k++) {
+                const uint32_t t = lane + 64 * k;
+                if (t < m_lds) {
+                    hashes[t] = v[k].x;
+                    uids[t] = v[k].y;
+                }
+            }
+        }
+        // (same wave wrote what it now reads: the LDS keeps a wave's accesses in order)
+        for (uint32_t i = lane; i < m; i += 64) {
+            // end of i's bucket: first boundary above i (binary search over <= 64 boundaries)
+            uint32_t a = 0, bb = nb - 1;
+            while (a < bb) {
+                const uint32_t mid = (a + bb) >> 1;
+                if (bnd[mid] > i)
+                    bb = mid;
+                else
+                    a = mid + 1;
+            }
+            const uint32_t end = bnd[a];
+            if (i + 1 >= end)
+                continue;
+            if (i < GP_SLICE) {
+                const uint32_t h = hashes[i], ui = uids[i];
+                const uint32_t end_lds = end < GP_SLICE ? end : GP_SLICE;
+                // Windows of 32 hashes, 16-byte aligned, compared without a branch per read: the eight
+                // 128-bit LDS reads of a window are in flight together. (Measured: this loop is
+                // VALU/LDS-throughput bound -- ~45 compares per key at 53 keys per bucket are 0.10 ms
+                // of the kernel's 0.15 ms for 14 M keys.)
+                for (uint32_t jbase = (i + 1) & ~3u; jbase < end_lds; jbase += 32) {
+                    uint32_t match = 0;
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; q++) {
+                        const uint32_t jq = jbase + 4 * q;
+                        const uint32_t jr = jq < GP_SLICE ? jq : GP_SLICE - 4;   // stay inside the slice
+                        const uint4 v = *reinterpret_cast<const uint4 *>(hashes + jr);
+                        match |= ((v.x == h ? 1u : 0u) | (v.y == h ? 2u : 0u) | (v.z == h ? 4u : 0u) |
+                                  (v.w == h ? 8u : 0u))
+                                 << (4 * q);
+                    }
+                    // keep positions j with i < j < end_lds
+                    const uint32_t first = i + 1 > jbase ? i + 1 - jbase : 0u;      // < 32
+                    const uint32_t stop = end_lds - jbase;                           // >= 1
+                    match &= 0xFFFFFFFFu << first;
+                    if (stop < 32)
+                        match &= (1u << stop) - 1u;
+                    while (match) {
+                        const uint32_t b = __ffs((int)match) - 1;
+                        match &= match - 1;
+                        note(ui, uids[jbase + b]);
+                    }
+                }
+                // partners beyond the LDS slice (a group larger than the slice): from HBM
+                for (uint32_t jj = end_lds > i + 1 ? end_lds : i + 1; jj < end; jj++) {
+                    const uint2 it = grp[jj];
+                    if (it.x == h)
+                        note(ui, it.y);
+                }
+            } else {
+                const uint2 me = grp[i];
+                for (uint32_t jj = i + 1; jj < end; jj++) {
+                    const uint2 it = grp[jj];
+                    if (it.x == me.x)
+                        note(me.y, it.y);
+                }
+            }
+        }
+    }
+    // what is left in the wave's buffer (all lanes are back together here)
+    {
+        const uint32_t have = *wcnt;
+        unsigned long long gb = 0;
+        if (lane == 0 && have)
+            gb = atomicAdd(cand_count, (unsigned long long)have);
+        gb = __shfl(gb, 0);
+        for (uint32_t e = lane; e < have; e += 64)
+            if (gb + e < cand_cap)
+                cands[gb + e] = wbuf[e];
+    }
+}
+
+// Phase 2 -- one thread per candidate (persistent grid, gridDim.x a multiple of GP_LISTS; cand_cap
+// is the capacity of ONE list): fetch both records, count mismatches,
+// keep the pair only in the pass of the first segment it agrees on; hits leave through an LDS
+// edge buffer. Tens of thousands of independent record fetches are in flight at once.
+template <int K>
+__global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
+    const uint2 *__restrict__ cands, const unsigned long long *__restrict__ cand_count, uint64_t cand_cap,
+    const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t d, uint32_t seg,
+    uint32_t nseg, uint32_t *__restrict__ edges, unsigned long long *__restrict__ edge_count, uint64_t edge_cap,
+    unsigned long long *__restrict__ cand_need, fqd::PairStats *__restrict__ stats)
+{
+    __shared__ uint32_t s_edges[2 * GP_ECAP];
+    __shared__ uint32_t s_ctl[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    // blocks l, l + GP_LISTS, ... sweep list l
+    const uint32_t list = blockIdx.x % GP_LISTS, part = blockIdx.x / GP_LISTS, parts = gridDim.x / GP_LISTS;
+    const unsigned long long filled = cand_count[(size_t)list * 8];
+    const unsigned long long total = filled < cand_cap ? filled : cand_cap;
+    cands += (size_t)list * cand_cap;
+    if (part == 0 && tid == 0 && filled > cand_cap)
+        atomicMax(cand_need, filled * GP_LISTS);   // a list overflowed: the host grows them and searches again
+    unsigned long long n_pairs = 0, n_hits = 0;
+    if (tid == 0)
+        s_ctl[0] = 0;
+    __syncthreads();
+    const unsigned long long step = (unsigned long long)parts * GP_THREADS;
+    for (unsigned long long base = (unsigned long long)part * GP_THREADS; base < total; base += step) {
+        const unsigned long long idx = base + tid;
+        bool hit = false;
+        uint2 pr = make_uint2(0, 0);
+        if (idx < total) {
+            pr = cands[idx];
+            n_pairs++;
+            hit = gp_verify<K>(urecs, ulens, sh, d, seg, nseg, pr.x, pr.y);
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+            uint32_t at = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if ((int)lane == leader)
+                at = atomicAdd(&s_ctl[0], (uint32_t)__popcll(mask));
+            at = __shfl(at, leader);
+            if (hit) {
+                at += __popcll(mask & fqd_lanemask_lt());
+                const uint32_t eu = pr.x < pr.y ? pr.x : pr.y, ev = pr.x < pr.y ? pr.y : pr.x;
+                s_edges[2 * at] = eu;          // at < 256 hits per sweep + < GP_ECAP / 2 left over
+                s_edges[2 * at + 1] = ev;
+                n_hits++;
+            }
+        }
+        __syncthreads();
+        const uint32_t buffered = s_ctl[0];
+        const bool last = base + step >= total;
+        if (buffered >= GP_ECAP / 2 || (last && buffered)) {
+            if (tid == 0) {
+                const unsigned long long gb = atomicAdd(edge_count, (unsigned long long)buffered);
+                s_ctl[1] = (uint32_t)gb;
+                s_ctl[2] = (uint32_t)(gb >> 32);
+            }
+            __syncthreads();
+            const unsigned long long gb = ((unsigned long long)s_ctl[2] << 32) | s_ctl[1];
+            for (uint32_t e = tid; e < buffered; e += GP_THREADS)
+                if (gb + e < edge_cap) {
+                    edges[2 * (gb + e)] = s_edges[2 * e];
+                    edges[2 * (gb + e) + 1] = s_edges[2 * e + 1];
+                }
+            __syncthreads();
+            if (tid == 0)
+                s_ctl[0] = 0;
+            __syncthreads();
+        }
+    }
+    if (stats) {
+        for (int o = 32; o; o >>= 1) {
+            n_pairs += __shfl_xor(n_pairs, o);
+            n_hits += __shfl_xor(n_hits, o);
+        }
+        __syncthreads();
+        unsigned long long *red = reinterpret_cast<unsigned long long *>(s_edges);
+        if (lane == 0) {
+            red[(tid >> 6) * 2 + 0] = n_pairs;
+            red[(tid >> 6) * 2 + 1] = n_hits;
+        }
+        __syncthreads();
+        if (tid < 2) {
+            unsigned long long tot = 0;
+            for (uint32_t wv = 0; wv < GP_THREADS / 64; wv++)
+                tot += red[wv * 2 + tid];
+            fqd::PairStats *slot = stats + (blockIdx.x % FQD_STAT_SLOTS);
+            if (tot) {
+                if (tid == 0) {
+                    atomicAdd(&slot->pairs_compared, tot);
+                    atomicAdd(&slot->keys_gathered, 2 * tot);   // two records fetched per candidate
+                } else {
+                    atomicAdd(&slot->edges, tot);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+namespace fqd {
+
+uint32_t group_tile_size() { return GP_TILE; }
+uint32_t group_cand_lists() { return GP_LISTS; }
+uint32_t group_max_bins() { return GP_MAX_BINS; }
+
+hipError_t launch_group_hist(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
+                             const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
+                             uint32_t n_bins, uint32_t *hist, hipStream_t st)
+{
+    if (!max_tiles)
+        return hipSuccess;
+    if (level1)
+        gp_hist_kernel<true><<<max_tiles, GP_THREADS, 0, st>>>(hashes, reinterpret_cast<const uint2 *>(in), seg_start,
+                                                               tile_start, n_seg, shift, n_bins, hist);
+    else
+        gp_hist_kernel<false><<<max_tiles, GP_THREADS, 0, st>>>(hashes, reinterpret_cast<const uint2 *>(in), seg_start,
+                                                                tile_start, n_seg, shift, n_bins, hist);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
+                                const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
+                                uint32_t n_bins, uint32_t *cursor, uint32_t *out, hipStream_t st)
+{
+    if (!max_tiles)
+        return hipSuccess;
+    if (level1)
+        gp_scatter_kernel<true><<<max_tiles, GP_THREADS, 0, st>>>(hashes, reinterpret_cast<const uint2 *>(in),
+                                                                  seg_start, tile_start, n_seg, shift, n_bins, cursor,
+                                                                  reinterpret_cast<uint2 *>(out));
+    else
+        gp_scatter_kernel<false><<<max_tiles, GP_THREADS, 0, st>>>(hashes, reinterpret_cast<const uint2 *>(in),
+                                                                   seg_start, tile_start, n_seg, shift, n_bins, cursor,
+                                                                   reinterpret_cast<uint2 *>(out));
+    return hipGetLastError();
+}
+
+hipError_t launch_group_tile_starts(const uint32_t *seg_start, uint32_t n_seg, uint32_t *tile_start, hipStream_t st)
+{
+    gp_tile_starts_kernel<<<1, 256, 0, st>>>(seg_start, n_seg, tile_start);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
+                                      hipStream_t st)
+{
+    gp_matrix_starts_kernel<<<(n_bins + 1 + 255) / 256, 256, 0, st>>>(matrix_incl, n_bins, n_tiles, start);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
+                                      uint32_t *cursor, hipStream_t st)
+{
+    gp_bucket_starts_kernel<<<(n_buckets + 1 + 255) / 256, 256, 0, st>>>(hist_incl, n_buckets, bucket_start, cursor);
+    return hipGetLastError();
+}
+
+hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, uint32_t n_buckets,
+                                     uint64_t n_items, uint64_t *cands, unsigned long long *cand_count,
+                                     uint64_t cand_cap, hipStream_t st)
+{
+    if (!n_buckets)
+        return hipSuccess;
+    // buckets per wave: about 3/4 of the LDS slice on average (a group that outgrows the slice
+    // still works, its tail is read from HBM)
+    const uint64_t lambda = n_items / n_buckets + 1;
+    uint32_t gsz = (uint32_t)((GP_SLICE * 3 / 4) / lambda);
+    gsz = gsz < 1 ? 1 : (gsz > 64 ? 64 : gsz);
+    const uint32_t n_groups = (n_buckets + gsz - 1) / gsz;
+    const uint32_t blocks = (n_groups + 3) / 4;
+    const unsigned grid = blocks < 4096 ? blocks : 4096;
+    grouped_candidates_kernel<<<grid, GP_THREADS, 0, st>>>(reinterpret_cast<const uint2 *>(items), bucket_start,
+                                                           n_buckets, gsz, reinterpret_cast<uint2 *>(cands), cand_count,
+                                                           cand_cap / GP_LISTS);
+    return hipGetLastError();
+}
+
+hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
+                                    const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d, uint32_t seg,
+                                    uint32_t nseg, uint32_t *edges, unsigned long long *edge_count, uint64_t edge_cap,
+                                    unsigned long long *cand_need, PairStats *stats, hipStream_t st)
+{
+#define FQD_GP_CASE(KK)                                                                                              \
+    case KK:                                                                                                         \
+        verify_candidates_kernel<KK><<<2048, GP_THREADS, 0, st>>>(reinterpret_cast<const uint2 *>(cands), cand_count, \
+                                                                  cand_cap / GP_LISTS, urecs, ulens, sh, d, seg, nseg, edges, \
+                                                                  edge_count, edge_cap, cand_need, stats);           \
+        break;
+    switch (sh.planes) {
+        FQD_GP_CASE(1)
+        FQD_GP_CASE(2)
+        FQD_GP_CASE(3)
+        FQD_GP_CASE(4)
+        FQD_GP_CASE(5)
+        FQD_GP_CASE(6)
+        FQD_GP_CASE(7)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef FQD_GP_CASE
+    return hipGetLastError();
+}
+
+}  // namespace fqd

@@ -255,7 +255,10 @@ int fqd_stage_times(fqd_ctx *ctx, float *ms /* FQD_T_COUNT */, uint32_t *launche
 #define FQD_K_UF_UNION      11
 #define FQD_K_UF_FLATTEN    12
 #define FQD_K_DISSECT_ROUND 13
-#define FQD_K_COUNT         16
+#define FQD_K_GROUP_HIST    14   /* both levels of the (hash, uid) partition of a search pass */
+#define FQD_K_GROUP_SCATTER 15
+#define FQD_K_VERIFY        16   /* verification of the candidate pairs of a grouped search pass */
+#define FQD_K_COUNT         20
 int fqd_kernel_times(fqd_ctx *ctx, float *ms /* FQD_K_COUNT */, uint32_t *launches /* FQD_K_COUNT */,
                      int reset);
 /* Bucket statistics of the last fqd_find_edges (for the roofline's unit count):

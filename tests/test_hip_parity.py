@@ -408,6 +408,34 @@ def test_bucket_shards_union_to_the_whole_search(F, oracle, edit, d):
     assert np.array_equal(kept, want["kept_read_ids"])
 
 
+@pytest.mark.parametrize("bits,d,L", [(None, 1, 32), ("4", 2, 36), ("11", 1, 100), ("1", 3, 48)])
+def test_grouped_search_equals_sorted_search(F, oracle, monkeypatch, bits, d, L):
+    """The sort-free search pass (group.hip: partition + one wave per bucket) finds exactly the
+    edges of the radix-sort pass -- with roomy buckets, with buckets far larger than the LDS slice
+    (few bucket bits), single-level and two-level partitions -- and the oracle's clusters."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    n = 60_000
+    raw = synth_keys(n, L, 8, 41, sub_rate=6e-3, n_rate=5e-4).reshape(-1)
+    found = {}
+    ctx = F.Context(0)
+    ctx.pack_keys(raw, None, L)
+    ctx.collapse()             # ONE unique table (its row order is not reproducible across collapses)
+    for mode in ("sort", "grouped"):
+        monkeypatch.setenv("FQD_EDGES", mode)
+        if bits and mode == "grouped":
+            monkeypatch.setenv("FQD_GROUP_BUCKET_BITS", bits)
+        ne = ctx.find_edges(d, 0, 0, 1)
+        e = np.empty((ne, 2), dtype=np.uint32)
+        ctx.export_edges(e)
+        found[mode] = sorted(map(tuple, e.tolist()))
+        if mode == "grouped":
+            n_clusters = ctx.components()
+            kept = ctx.kept_read_ids(ctx.dissect(2))
+    assert found["sort"] == found["grouped"] and len(set(found["grouped"])) == len(found["grouped"])
+    want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=d, method="directional")
+    assert n_clusters == want["n_clusters"] and np.array_equal(kept, want["kept_read_ids"])
+
+
 @pytest.mark.parametrize("edit", [False, True])
 def test_directional_closed_form_equals_rounds(F, oracle, monkeypatch, edit):
     """The directional dissection has a closed form on collapsed tables (two passes over the edges)
