@@ -1206,7 +1206,7 @@ int fqd_components(fqd_ctx *c, uint64_t *n_clusters)
         return fail(c, FQD_E_STATE, "fqd_components before fqd_find_edges/fqd_import_edges");
     c->stage = ST_EDGES;
     StageTimer timer(c, FQD_T_COMPONENTS);
-    FQD_TRY(components_queue(c, true));
+    FQD_TRY(components_queue(c, false));   // labels are flattened when somebody reads them
     unsigned long long roots = 0;
     FQD_TRY(read_ctr64(c, C64_ROOTS, &roots));
     timer.stop();
