@@ -1071,8 +1071,13 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         // Grouping by partition (group.hip) unless a bucket shard was asked for or the table is small
         // (FQD_EDGES=sort|grouped pins the path for tests).
         const char *pin = getenv("FQD_EDGES");
-        const bool grouped = n_shards == 1 && U < 0xFFFFFF00ull &&
-                             (pin ? !strcmp(pin, "grouped") : U >= 65536);
+        bool grouped = n_shards == 1 && U < 0xFFFFFF00ull && (pin ? !strcmp(pin, "grouped") : U >= 65536);
+        // Candidate pairs are listed before they are verified; a segment value shared by very many
+        // keys (all of them pairwise candidates) would need a list beyond this budget: the search
+        // then runs again on the sort path, which verifies in place and needs no list.
+        uint64_t cand_budget = std::max<uint64_t>(8 * U, 1ull << 24);
+        if (const char *e = getenv("FQD_GROUP_CAND_BUDGET"))
+            cand_budget = strtoull(e, nullptr, 10);
         bool iota_ready = false;
         FQD_TRY(zero_ctr64(c, C64_CAND_NEED));
         // All d+1 passes are queued without a host round trip; the edge count is read ONCE at the
@@ -1127,9 +1132,13 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
                 c->edge_cap = c->edges.cap / 8;
             }
             if (cand_need > c->gp_cand_cap) {
-                c->gp_cands.release();
-                HIP_TRY(c, c->gp_cands.reserve((size_t)(cand_need + cand_need / 8 + 1024) * 8));
-                c->gp_cand_cap = c->gp_cands.cap / 8;
+                if (cand_need > cand_budget) {
+                    grouped = false;
+                } else {
+                    c->gp_cands.release();
+                    HIP_TRY(c, c->gp_cands.reserve((size_t)(cand_need + cand_need / 8 + 1024) * 8));
+                    c->gp_cand_cap = c->gp_cands.cap / 8;
+                }
             }
             FQD_TRY(zero_ctr64(c, C64_CAND_NEED));
             FQD_TRY(zero_ctr64(c, C64_EDGES));

@@ -279,21 +279,37 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
     uint2 *__restrict__ cands_all, unsigned long long *__restrict__ cand_counts, uint64_t list_cap)
 {
     constexpr uint32_t WAVES = GP_THREADS / 64;
-    // this wave's list: GP_LISTS lists of list_cap pairs each, counters 8 words apart
-    const uint32_t list = (blockIdx.x * WAVES + (threadIdx.x >> 6)) % GP_LISTS;
-    uint2 *__restrict__ cands = cands_all + (size_t)list * list_cap;
-    unsigned long long *__restrict__ cand_count = cand_counts + (size_t)list * 8;
+    // GP_LISTS lists of list_cap pairs each, counters 8 words apart. A wave starts at "its" list
+    // and moves to the next one after every flush, so one crowded bucket fills all lists evenly.
+    const uint32_t list0 = (blockIdx.x * WAVES + (threadIdx.x >> 6)) % GP_LISTS;
     const uint64_t cand_cap = list_cap;
     __shared__ __attribute__((aligned(16))) uint32_t s_hash[WAVES][GP_SLICE];
     __shared__ uint32_t s_uid[WAVES][GP_SLICE];
     __shared__ uint32_t s_bnd[WAVES][65];        // item offsets (relative to the group) of its buckets' ends
     __shared__ uint2 s_wbuf[WAVES][GP_WCAP];
-    __shared__ uint32_t s_wcnt[WAVES];
+    __shared__ uint32_t s_wcnt[WAVES], s_wflush[WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_groups = (n_buckets + gsz - 1) / gsz;
     uint32_t *hashes = s_hash[wave], *uids = s_uid[wave], *bnd = s_bnd[wave];
     uint2 *wbuf = s_wbuf[wave];
     volatile uint32_t *wcnt = &s_wcnt[wave];   // written by the leader lane, read by all: never cached in a register
+    volatile uint32_t *wflush = &s_wflush[wave];
+
+    // the wave's buffer -> the next list (called by converged lanes: `n` of them, ranks 0..n-1)
+    auto flush = [&](uint32_t have, uint32_t n, uint32_t rank, int leader) {
+        const uint32_t turn = *wflush;
+        const uint32_t list = (list0 + turn) % GP_LISTS;
+        unsigned long long g = 0;
+        if ((int)lane == leader) {
+            g = atomicAdd(cand_counts + (size_t)list * 8, (unsigned long long)have);
+            *wflush = turn + 1;
+        }
+        g = __shfl(g, leader);
+        uint2 *dst = cands_all + (size_t)list * list_cap;
+        for (uint32_t e = rank; e < have; e += n)
+            if (g + e < cand_cap)
+                dst[g + e] = wbuf[e];
+    };
 
     // Called by whatever lanes are active at the call site (they are converged there): the active
     // lanes take consecutive slots; a full buffer is written out first, by the same lanes.
@@ -303,13 +319,7 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
         const int leader = __ffsll((long long)act) - 1;
         uint32_t have = *wcnt;
         if (have + n > GP_WCAP) {
-            unsigned long long g = 0;
-            if ((int)lane == leader)
-                g = atomicAdd(cand_count, (unsigned long long)have);
-            g = __shfl(g, leader);
-            for (uint32_t e = rank; e < have; e += n)
-                if (g + e < cand_cap)
-                    cands[g + e] = wbuf[e];
+            flush(have, n, rank, leader);
             have = 0;
         }
         wbuf[have + rank] = make_uint2(a, b);
@@ -317,8 +327,10 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
             *wcnt = have + n;
     };
 
-    if (lane == 0)
+    if (lane == 0) {
         *wcnt = 0;
+        *wflush = 0;
+    }
 
     for (uint32_t g = blockIdx.x * WAVES + wave; g < n_groups; g += gridDim.x * WAVES) {
         const uint32_t b0 = g * gsz;
@@ -416,13 +428,8 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
     // what is left in the wave's buffer (all lanes are back together here)
     {
         const uint32_t have = *wcnt;
-        unsigned long long gb = 0;
-        if (lane == 0 && have)
-            gb = atomicAdd(cand_count, (unsigned long long)have);
-        gb = __shfl(gb, 0);
-        for (uint32_t e = lane; e < have; e += 64)
-            if (gb + e < cand_cap)
-                cands[gb + e] = wbuf[e];
+        if (have)
+            flush(have, 64, lane, 0);
     }
 }
 

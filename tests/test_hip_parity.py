@@ -436,6 +436,32 @@ def test_grouped_search_equals_sorted_search(F, oracle, monkeypatch, bits, d, L)
     assert n_clusters == want["n_clusters"] and np.array_equal(kept, want["kept_read_ids"])
 
 
+@pytest.mark.parametrize("budget", [None, "100000"])
+def test_grouped_search_with_a_crowded_segment(F, oracle, monkeypatch, budget):
+    """3000 keys share their first half: one bucket of the pass over segment 0 holds them all and
+    every pair of them is a candidate (4.5 M). The candidate lists grow to hold them; with a small
+    budget the search falls back to the sort path instead. Same answer as the oracle either way."""
+    from fastqdedup_amd.synth import synth_keys
+    rng = np.random.default_rng(5)
+    L = 32
+    base = synth_keys(40_000, L, L, 43, sub_rate=5e-3, n_rate=3e-4)
+    crowd = np.tile(base[0], (3000, 1))
+    crowd[:, L // 2:] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(3000, L // 2))
+    crowd[1::50, L // 2:] = crowd[0, L // 2:]             # some exact copies and near copies too
+    crowd[2::50, L - 1] = ord("N")
+    keys = np.concatenate([base, crowd])
+    rng.shuffle(keys)
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    monkeypatch.setenv("FQD_EDGES", "grouped")
+    if budget:
+        monkeypatch.setenv("FQD_GROUP_CAND_BUDGET", budget)
+    res = F.cluster_keys(raw, key_len=L, max_distance=1, method="directional", context=F.Context(0))
+    off = np.arange(len(keys) + 1, dtype=np.uint64) * L
+    want = oracle.dedup(raw, off, max_distance=1, method="directional")
+    assert res.n_unique == want["n_unique"] and res.n_clusters == want["n_clusters"]
+    assert np.array_equal(res.kept_read_ids, want["kept_read_ids"])
+
+
 @pytest.mark.parametrize("edit", [False, True])
 def test_directional_closed_form_equals_rounds(F, oracle, monkeypatch, edit):
     """The directional dissection has a closed form on collapsed tables (two passes over the edges)
