@@ -240,6 +240,12 @@ def main():
                     "part_scatter_kernel<1>": "part_scatter_kernel<true>",
                     "part_scatter_kernel<2>": "part_scatter_kernel<false>",
                     "dissect_round_kernel": "_round_kernel" if wl["method"] == "directional" else "adjacency_edges"}
+    if kern.get("gp_hist_kernel", (0, 0))[1]:
+        # the sort-free search pass ran: the FQD_K_PAIRS slot timed grouped_candidates_kernel
+        # ((hash, uid) items in, candidate pairs out), not bucket_pairs_kernel
+        kern["grouped_candidates_kernel"] = kern.pop("bucket_pairs_kernel")
+        alg["grouped_candidates_kernel"] = U * 8 + st["pairs_compared"] / nseg * 8
+        rocprof_name["grouped_candidates_kernel"] = "grouped_candidates_kernel"
     table = []
     for name, (kms, kl) in kern.items():
         if not kl:

@@ -941,13 +941,14 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
 }
 
 // One Hamming search pass without a device-wide sort (group.hip): the (segment hash, uid) pairs
-// are partitioned into 2^B buckets of ~50-100 keys by the top hash bits, then one wave per bucket
-// compares hashes all against all out of LDS. Queues work only (no host round trip).
+// are partitioned into 2^B buckets of ~200 keys by the top hash bits, then one wave per bucket
+// sub-sorts them in LDS and lists the pairs with equal hashes; a second kernel verifies those.
+// Queues work only (no host round trip).
 static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t d, uint32_t s, uint32_t nseg)
 {
     const KeyShape sh = c->ks;
     uint32_t B = 8;
-    while (B < 20 && (U >> B) > 96)
+    while (B < 20 && (U >> B) > 320)   // ~160-320 keys per bucket: a wave sorts them into 64 sub-bins in LDS
         B++;
     if (const char *e = getenv("FQD_GROUP_BUCKET_BITS"))   // tests: few, crowded buckets
         B = (uint32_t)std::max(1, std::min(20, atoi(e)));
@@ -1006,7 +1007,7 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
     unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(small + 4096);
     HIP_TRY(c, hipMemsetAsync(cand_ctr, 0, (size_t)fqd::group_cand_lists() * 64, c->st));
     unsigned long long *ctr = c->d_ctr64.as<unsigned long long>();
-    KTIME(c, FQD_K_PAIRS, fqd::launch_grouped_candidates(items, c->ld_start.as<uint32_t>(), n_buckets, U,
+    KTIME(c, FQD_K_PAIRS, fqd::launch_grouped_candidates(items, c->ld_start.as<uint32_t>(), n_buckets, B,
                                                          c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,
                                                          c->st));
     KTIME(c, FQD_K_VERIFY, fqd::launch_verify_candidates(c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,

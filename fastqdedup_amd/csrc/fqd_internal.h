@@ -270,7 +270,7 @@ hipError_t launch_group_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bi
 hipError_t launch_group_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
                                       uint32_t *cursor, hipStream_t st);
 hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, uint32_t n_buckets,
-                                     uint64_t n_items, uint64_t *cands, unsigned long long *cand_count,
+                                     uint32_t bucket_bits, uint64_t *cands, unsigned long long *cand_count,
                                      uint64_t cand_cap, hipStream_t st);
 hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
                                     const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d, uint32_t seg,

@@ -265,18 +265,20 @@ __device__ __forceinline__ bool gp_verify(const uint32_t *__restrict__ urecs, co
     return true;
 }
 
-// Phase 1 -- one wave per GROUP of `gsz` consecutive buckets (a group is a contiguous range of
-// items, ~400 keys): lane i holds some keys of the group and walks the keys after each one in ITS
-// bucket, hashes out of LDS; pairs whose 32-bit hashes agree are CANDIDATES, appended (uid, uid)
-// to a device list through a per-wave LDS buffer that the wave flushes by itself (one global
-// atomic per flush). No record is touched here: verifying in place cost one HBM latency chain
-// per pair (17 us per bucket). Waves share nothing, so there is no workgroup barrier at all.
+// Phase 1 -- one wave per bucket (~200 keys). The wave counting-sorts its bucket by the next 6
+// hash bits inside LDS (64 sub-bins of ~3 keys: LDS atomics for the ranks, one shuffle scan), so a
+// key is compared only with the few keys after it in its sub-bin -- one or two 128-bit LDS reads
+// instead of ~45 compares per key against the whole bucket (that loop was VALU/LDS-throughput
+// bound: 0.10 ms of the kernel's 0.15 ms for 14 M keys). Pairs whose 32-bit hashes agree are
+// CANDIDATES, appended (uid, uid) to a device list through a per-wave LDS buffer that the wave
+// flushes by itself. No record is touched here: verifying in place cost one HBM latency chain per
+// pair (17 us per bucket). Waves share nothing, so there is no workgroup barrier at all.
 constexpr uint32_t GP_WCAP = 128;   // candidates buffered per wave
 constexpr uint32_t GP_LISTS = 64;   // candidate lists (one counter each, a cache line apart): flush atomics spread out
 
 __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
-    const uint2 *__restrict__ items, const uint32_t *__restrict__ bucket_start, uint32_t n_buckets, uint32_t gsz,
-    uint2 *__restrict__ cands_all, unsigned long long *__restrict__ cand_counts, uint64_t list_cap)
+    const uint2 *__restrict__ items, const uint32_t *__restrict__ bucket_start, uint32_t n_buckets,
+    uint32_t sub_shift, uint2 *__restrict__ cands_all, unsigned long long *__restrict__ cand_counts, uint64_t list_cap)
 {
     constexpr uint32_t WAVES = GP_THREADS / 64;
     // GP_LISTS lists of list_cap pairs each, counters 8 words apart. A wave starts at "its" list
@@ -285,12 +287,11 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
     const uint64_t cand_cap = list_cap;
     __shared__ __attribute__((aligned(16))) uint32_t s_hash[WAVES][GP_SLICE];
     __shared__ uint32_t s_uid[WAVES][GP_SLICE];
-    __shared__ uint32_t s_bnd[WAVES][65];        // item offsets (relative to the group) of its buckets' ends
+    __shared__ uint32_t s_off[WAVES][66];        // sub-bin counts, then sub-bin starts (64 + end)
     __shared__ uint2 s_wbuf[WAVES][GP_WCAP];
     __shared__ uint32_t s_wcnt[WAVES], s_wflush[WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t n_groups = (n_buckets + gsz - 1) / gsz;
-    uint32_t *hashes = s_hash[wave], *uids = s_uid[wave], *bnd = s_bnd[wave];
+    uint32_t *hashes = s_hash[wave], *uids = s_uid[wave], *off = s_off[wave];
     uint2 *wbuf = s_wbuf[wave];
     volatile uint32_t *wcnt = &s_wcnt[wave];   // written by the leader lane, read by all: never cached in a register
     volatile uint32_t *wflush = &s_wflush[wave];
@@ -332,96 +333,88 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
         *wflush = 0;
     }
 
-    for (uint32_t g = blockIdx.x * WAVES + wave; g < n_groups; g += gridDim.x * WAVES) {
-        const uint32_t b0 = g * gsz;
-        const uint32_t nb = b0 + gsz <= n_buckets ? gsz : n_buckets - b0;   // buckets of this group
-        // ONE coalesced load of the group's nb + 1 bucket offsets (lane l: bucket_start[b0 + l])
-        uint32_t mine_off = 0;
-        if (lane <= nb)
-            mine_off = bucket_start[b0 + lane];
-        const uint32_t lo = __shfl(mine_off, 0);
-        const uint32_t m = __shfl(mine_off, (int)nb) - lo;
-        if (lane >= 1 && lane <= nb)
-            bnd[lane - 1] = mine_off - lo;
-        const uint2 *grp = items + lo;
+    for (uint32_t b = blockIdx.x * WAVES + wave; b < n_buckets; b += gridDim.x * WAVES) {
+        uint32_t two = 0;
+        if (lane < 2)
+            two = bucket_start[b + lane];
+        const uint32_t lo = __shfl(two, 0), m = __shfl(two, 1) - lo;
+        if (m < 2)
+            continue;
+        const uint2 *bucket = items + lo;
         const uint32_t m_lds = m < GP_SLICE ? m : GP_SLICE;
+        // ---- load (all of the lane's loads in flight before anything else), rank, scan, place
+        uint2 v[GP_SLICE / 64];
+        uint32_t rank[GP_SLICE / 64];
+#pragma unroll
+        for (uint32_t k = 0; k < GP_SLICE / 64; k++) {
+            const uint32_t t = lane + 64 * k;
+            v[k] = make_uint2(0, 0);
+            if (t < m_lds)
+                v[k] = bucket[t];
+        }
+        off[lane] = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < GP_SLICE / 64; k++)
+            if (lane + 64 * k < m_lds)
+                rank[k] = atomicAdd(&off[(v[k].x >> sub_shift) & 63u], 1u);
         {
-            // all of the lane's loads in flight before the first LDS store (a load-store loop
-            // pays one HBM latency per 64 items)
-            uint2 v[GP_SLICE / 64];
-#pragma unroll
-            for (uint32_t k = 0; k < GP_SLICE / 64; k++) {
-                const uint32_t t = lane + 64 * k;
-                v[k] = make_uint2(0, 0);
-                if (t < m_lds)
-                    v[k] = grp[t];
+            const uint32_t c = off[lane];
+            uint32_t incl = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o);
+                if ((int)lane >= o)
+                    incl += up;
             }
+            off[lane] = incl - c;          // start of sub-bin `lane`
+            if (lane == 63)
+                off[64] = incl;            // = m_lds
+        }
 #pragma unroll
-            for (uint32_t k = 0; k < GP_SLICE / 64; k++) {
-                const uint32_t t = lane + 64 * k;
-                if (t < m_lds) {
-                    hashes[t] = v[k].x;
-                    uids[t] = v[k].y;
+        for (uint32_t k = 0; k < GP_SLICE / 64; k++)
+            if (lane + 64 * k < m_lds) {
+                const uint32_t p = off[(v[k].x >> sub_shift) & 63u] + rank[k];
+                hashes[p] = v[k].x;
+                uids[p] = v[k].y;
+            }
+        // (same wave wrote what it now reads: the LDS keeps a wave's accesses in order)
+        // ---- every key against the keys after it in its sub-bin
+        for (uint32_t i = lane; i < m_lds; i += 64) {
+            const uint32_t h = hashes[i];
+            const uint32_t end = off[((h >> sub_shift) & 63u) + 1];
+            if (i + 1 >= end)
+                continue;
+            const uint32_t ui = uids[i];
+            // windows of 8 hashes, 16-byte aligned, no branch per read
+            for (uint32_t jbase = (i + 1) & ~3u; jbase < end; jbase += 8) {
+                const uint32_t j1 = jbase + 4 < GP_SLICE ? jbase + 4 : GP_SLICE - 4;   // stay inside the slice
+                const uint4 a = *reinterpret_cast<const uint4 *>(hashes + jbase);
+                const uint4 c4 = *reinterpret_cast<const uint4 *>(hashes + j1);
+                uint32_t match = (a.x == h ? 1u : 0u) | (a.y == h ? 2u : 0u) | (a.z == h ? 4u : 0u) |
+                                 (a.w == h ? 8u : 0u) | (c4.x == h ? 16u : 0u) | (c4.y == h ? 32u : 0u) |
+                                 (c4.z == h ? 64u : 0u) | (c4.w == h ? 128u : 0u);
+                const uint32_t first = i + 1 > jbase ? i + 1 - jbase : 0u;      // < 4
+                const uint32_t stop = end - jbase;                              // >= 1
+                match &= 0xFFu << first;
+                if (stop < 8)
+                    match &= (1u << stop) - 1u;
+                while (match) {
+                    const uint32_t bit = __ffs((int)match) - 1;
+                    match &= match - 1;
+                    note(ui, uids[jbase + bit]);
                 }
             }
         }
-        // (same wave wrote what it now reads: the LDS keeps a wave's accesses in order)
-        for (uint32_t i = lane; i < m; i += 64) {
-            // end of i's bucket: first boundary above i (binary search over <= 64 boundaries)
-            uint32_t a = 0, bb = nb - 1;
-            while (a < bb) {
-                const uint32_t mid = (a + bb) >> 1;
-                if (bnd[mid] > i)
-                    bb = mid;
-                else
-                    a = mid + 1;
-            }
-            const uint32_t end = bnd[a];
-            if (i + 1 >= end)
-                continue;
-            if (i < GP_SLICE) {
-                const uint32_t h = hashes[i], ui = uids[i];
-                const uint32_t end_lds = end < GP_SLICE ? end : GP_SLICE;
-                // Windows of 32 hashes, 16-byte aligned, compared without a branch per read: the eight
-                // 128-bit LDS reads of a window are in flight together. (Measured: this loop is
-                // VALU/LDS-throughput bound -- ~45 compares per key at 53 keys per bucket are 0.10 ms
-                // of the kernel's 0.15 ms for 14 M keys.)
-                for (uint32_t jbase = (i + 1) & ~3u; jbase < end_lds; jbase += 32) {
-                    uint32_t match = 0;
-#pragma unroll
-                    for (uint32_t q = 0; q < 8; q++) {
-                        const uint32_t jq = jbase + 4 * q;
-                        const uint32_t jr = jq < GP_SLICE ? jq : GP_SLICE - 4;   // stay inside the slice
-                        const uint4 v = *reinterpret_cast<const uint4 *>(hashes + jr);
-                        match |= ((v.x == h ? 1u : 0u) | (v.y == h ? 2u : 0u) | (v.z == h ? 4u : 0u) |
-                                  (v.w == h ? 8u : 0u))
-                                 << (4 * q);
-                    }
-                    // keep positions j with i < j < end_lds
-                    const uint32_t first = i + 1 > jbase ? i + 1 - jbase : 0u;      // < 32
-                    const uint32_t stop = end_lds - jbase;                           // >= 1
-                    match &= 0xFFFFFFFFu << first;
-                    if (stop < 32)
-                        match &= (1u << stop) - 1u;
-                    while (match) {
-                        const uint32_t b = __ffs((int)match) - 1;
-                        match &= match - 1;
-                        note(ui, uids[jbase + b]);
-                    }
-                }
-                // partners beyond the LDS slice (a group larger than the slice): from HBM
-                for (uint32_t jj = end_lds > i + 1 ? end_lds : i + 1; jj < end; jj++) {
-                    const uint2 it = grp[jj];
-                    if (it.x == h)
-                        note(ui, it.y);
-                }
-            } else {
-                const uint2 me = grp[i];
-                for (uint32_t jj = i + 1; jj < end; jj++) {
-                    const uint2 it = grp[jj];
-                    if (it.x == me.x)
-                        note(me.y, it.y);
-                }
+        // ---- a bucket larger than the slice: its tail against the sorted part and against itself
+        for (uint32_t t = GP_SLICE + lane; t < m; t += 64) {
+            const uint2 me = bucket[t];
+            const uint32_t sb = (me.x >> sub_shift) & 63u;
+            for (uint32_t j = off[sb]; j < off[sb + 1]; j++)
+                if (hashes[j] == me.x)
+                    note(uids[j], me.y);
+            for (uint32_t t2 = t + 1; t2 < m; t2++) {
+                const uint2 it = bucket[t2];
+                if (it.x == me.x)
+                    note(me.y, it.y);
             }
         }
     }
@@ -595,22 +588,18 @@ hipError_t launch_group_bucket_starts(const uint32_t *hist_incl, uint32_t n_buck
 }
 
 hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, uint32_t n_buckets,
-                                     uint64_t n_items, uint64_t *cands, unsigned long long *cand_count,
+                                     uint32_t bucket_bits, uint64_t *cands, unsigned long long *cand_count,
                                      uint64_t cand_cap, hipStream_t st)
 {
     if (!n_buckets)
         return hipSuccess;
-    // buckets per wave: about 3/4 of the LDS slice on average (a group that outgrows the slice
-    // still works, its tail is read from HBM)
-    const uint64_t lambda = n_items / n_buckets + 1;
-    uint32_t gsz = (uint32_t)((GP_SLICE * 3 / 4) / lambda);
-    gsz = gsz < 1 ? 1 : (gsz > 64 ? 64 : gsz);
-    const uint32_t n_groups = (n_buckets + gsz - 1) / gsz;
-    const uint32_t blocks = (n_groups + 3) / 4;
-    const unsigned grid = blocks < 4096 ? blocks : 4096;
+    // the 6 hash bits below the bucket bits pick the sub-bin (bucket_bits <= 26)
+    const uint32_t sub_shift = 32u - bucket_bits - 6u;
+    const uint32_t blocks = (n_buckets + 3) / 4;
+    const unsigned grid = blocks < 8192 ? blocks : 8192;
     grouped_candidates_kernel<<<grid, GP_THREADS, 0, st>>>(reinterpret_cast<const uint2 *>(items), bucket_start,
-                                                           n_buckets, gsz, reinterpret_cast<uint2 *>(cands), cand_count,
-                                                           cand_cap / GP_LISTS);
+                                                           n_buckets, sub_shift, reinterpret_cast<uint2 *>(cands),
+                                                           cand_count, cand_cap / GP_LISTS);
     return hipGetLastError();
 }
 
