@@ -107,8 +107,9 @@ struct fqd_ctx {
     DevBuf q_table, q_pass, q_means, q_bytes, q_offsets;
     DevBuf len_present, ed_hash, ed_payload, ed_hash_sorted, ed_payload_sorted, ed_cands, ed_cands_sorted, d_alphabet;
     fqd::PairStats last_stats{};
+    bool stats_pending = false;   // d_stats holds the slots of the last search, not yet summed into last_stats
     // stage 4
-    uint64_t n_clusters = 0;
+    uint64_t n_clusters = 0, roots_seen = 0;
     DevBuf labels, hook_slots;
     bool labels_flat = false;
     // stage 5
@@ -1044,6 +1045,7 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
     c->ms[FQD_T_PAIRS_KERNEL] = 0;
     c->launches[FQD_T_PAIRS_KERNEL] = 0;
     c->last_stats = fqd::PairStats{0, 0, 0};
+    c->stats_pending = false;
     FQD_TRY(zero_ctr64(c, C64_EDGES));
     HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
     if (edit_general && U >= 2 && (max_distance > 0 || !c->collapsed)) {
@@ -1146,14 +1148,7 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
             HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
         }
         c->E = have;
-        fqd::PairStats slots[FQD_STAT_SLOTS];
-        HIP_TRY(c, hipMemcpyAsync(slots, c->d_stats.p, sizeof slots, hipMemcpyDeviceToHost, c->st));
-        HIP_TRY(c, hipStreamSynchronize(c->st));
-        for (const fqd::PairStats &p : slots) {
-            c->last_stats.keys_gathered += p.keys_gathered;
-            c->last_stats.pairs_compared += p.pairs_compared;
-            c->last_stats.edges += p.edges;
-        }
+        c->stats_pending = true;     // the 64 stat slots are summed when fqd_edge_stats asks
     }
     timer.stop();
     c->stage = ST_EDGES;
@@ -1270,8 +1265,10 @@ static int list_kept(fqd_ctx *c, int method)
             HIP_TRY(c, hipMemcpyAsync(&listed, c->kept_scan.as<uint32_t>() + (blocks - 1), 4, hipMemcpyDeviceToHost,
                                       c->st));
         }
-        unsigned long long total = 0;
-        FQD_TRY(read_ctr64(c, C64_SUM, &total));
+        unsigned long long both[2] = {0, 0};      // C64_ROOTS, C64_SUM: one read for fqd_cluster
+        FQD_TRY(read_ctr64(c, C64_ROOTS, both, 2));
+        c->roots_seen = both[0];
+        const unsigned long long total = both[1];
         c->n_kept = total;
         c->n_listed = listed;
         if (getenv("FQD_DEBUG"))
@@ -1288,8 +1285,10 @@ static int list_kept(fqd_ctx *c, int method)
     FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), U));
     uint32_t nk = 0;
     HIP_TRY(c, hipMemcpyAsync(&nk, c->kept_scan.as<uint32_t>() + (U - 1), 4, hipMemcpyDeviceToHost, c->st));
-    unsigned long long total = 0;
-    FQD_TRY(read_ctr64(c, C64_SUM, &total));
+    unsigned long long both[2] = {0, 0};
+    FQD_TRY(read_ctr64(c, C64_ROOTS, both, 2));
+    c->roots_seen = both[0];
+    const unsigned long long total = both[1];
     c->n_kept = total;
     c->n_listed = nk;
     HIP_TRY(c, c->kept_ids.reserve((size_t)nk * 8 + 16));
@@ -1409,7 +1408,9 @@ int fqd_cluster(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, i
     c->stage = ST_LABELS;
     c->ms[FQD_T_COMPONENTS] = 0;
     FQD_TRY(fqd_dissect(c, method, nullptr));
-    {
+    if (c->U) {
+        c->n_clusters = c->roots_seen;   // read together with the kept counters
+    } else {
         unsigned long long roots = 0;
         FQD_TRY(read_ctr64(c, C64_ROOTS, &roots));
         c->n_clusters = roots;
@@ -2012,9 +2013,25 @@ int fqd_kernel_times(fqd_ctx *c, float *ms, uint32_t *launches, int reset)
 
 int fqd_edge_stats(fqd_ctx *c, uint64_t *keys_gathered, uint64_t *pairs_compared, uint64_t *edges_emitted)
 {
-    if (keys_gathered) *keys_gathered = c->last_stats.keys_gathered;
-    if (pairs_compared) *pairs_compared = c->last_stats.pairs_compared;
-    if (edges_emitted) *edges_emitted = c->last_stats.edges;
+    if (c->stats_pending) {
+        FQD_TRY(bind(c));
+        fqd::PairStats slots[FQD_STAT_SLOTS];
+        HIP_TRY(c, hipMemcpyAsync(slots, c->d_stats.p, sizeof slots, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(c, hipStreamSynchronize(c->st));
+        c->last_stats = fqd::PairStats{0, 0, 0};
+        for (const fqd::PairStats &p : slots) {
+            c->last_stats.keys_gathered += p.keys_gathered;
+            c->last_stats.pairs_compared += p.pairs_compared;
+            c->last_stats.edges += p.edges;
+        }
+        c->stats_pending = false;
+    }
+    if (keys_gathered)
+        *keys_gathered = c->last_stats.keys_gathered;
+    if (pairs_compared)
+        *pairs_compared = c->last_stats.pairs_compared;
+    if (edges_emitted)
+        *edges_emitted = c->last_stats.edges;
     return FQD_OK;
 }
 
