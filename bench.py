@@ -219,7 +219,7 @@ def main():
     alg = {  # algorithmic bytes of ONE launch
         "pack_kernel": n * (L + b_key + 4),                          # key bytes in, record + hash out
         "part_hist_kernel<1>": n_in * 4,                             # hash
-        "part_scatter_kernel<1>": n_in * (4 + 16 + 16),              # hash + record in, record out
+        "part_scatter_kernel<1>": n_in * (16 + 16),                  # record in (hash recomputed), record out
         "part_hist_kernel<2>": n_in * 16,
         "part_scatter_kernel<2>": n_in * (16 + 16),
         "bucket_dedupe_kernel": n_in * 16 + U_own * 24,                  # reads in, unique (record, count, first) out

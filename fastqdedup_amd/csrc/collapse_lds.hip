@@ -64,10 +64,11 @@ __device__ __forceinline__ uint32_t load_item(const uint32_t *__restrict__ hashe
                                               uint32_t i, uint32_t kw, uint32_t len, uint4 &v)
 {
     v = in[i];
-    if (LEVEL1) {
+    if (LEVEL1)
         v.w = i;
-        return hashes[i];
-    }
+    // the hash is recomputed from the record at both levels (a dozen VALU ops): reading the stored
+    // hash would add 4 B to the 32 B this kernel moves per read. Only the level-1 HISTOGRAM reads
+    // the hash array (4 B instead of the 16-B record).
     const uint32_t rec[3] = {v.x, v.y, v.z};
     return fqd_hash_record(rec, kw, len);
 }
