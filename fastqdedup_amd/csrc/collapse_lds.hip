@@ -268,14 +268,35 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe_kernel(
     __syncthreads();
 
     bool full = false;
-    for (uint32_t base = lo; base < hi; base += DD_THREADS) {
+    // Four 256-read chunks are fetched before the first one is hashed: a bucket (~760 reads) then
+    // pays ONE HBM latency instead of one per chunk (the kernel is latency bound: 42 buckets per
+    // resident workgroup, ~10 us each).
+    constexpr uint32_t DD_AHEAD = 4;
+    for (uint32_t base0 = lo; base0 < hi; base0 += DD_AHEAD * DD_THREADS) {
+      uint4 ahead[DD_AHEAD];
+      uint32_t ahead_w[DD_AHEAD];
+#pragma unroll
+      for (uint32_t k = 0; k < DD_AHEAD; k++) {
+          const uint32_t i = base0 + k * DD_THREADS + tid;
+          ahead[k] = make_uint4(0, 0, 0, 0);
+          if (i < hi)
+              ahead[k] = part[i];
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < DD_AHEAD; k++) {
+          const uint32_t i = base0 + k * DD_THREADS + tid;
+          ahead_w[k] = i < hi ? (weights ? weights[ahead[k].w] : 1u) : 0u;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < DD_AHEAD; k++) {
+        const uint32_t base = base0 + k * DD_THREADS;
+        if (base >= hi)
+            break;                      // uniform over the workgroup
         const uint32_t i = base + tid;
         const bool active = i < hi;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (active)
-            v = part[i];
+        const uint4 v = ahead[k];
         const uint32_t tag = rec_tag(v);
-        const uint32_t w = active ? (weights ? weights[v.w] : 1u) : 0u;
+        const uint32_t w = ahead_w[k];
         uint32_t slot = (tag * 0x9E3779B1u) >> 22;  // top 10 bits of a re-mix: DD_SLOTS == 1024
         uint32_t probes = 0;
         bool pending = active;
@@ -318,6 +339,7 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe_kernel(
                 }
             }
         } while (__syncthreads_or(pending));
+      }
     }
     if (full)
         atomicOr(overflow, 1u);
