@@ -43,7 +43,7 @@ EXPORTS = [
     "fqd_collapse", "fqd_find_edges", "fqd_components", "fqd_dissect", "fqd_cluster",
     "fqd_set_id_window", "fqd_get_kept_count", "fqd_get_kept_read_ids", "fqd_get_unique_table", "fqd_export_packed", "fqd_export_packed_by_owner", "fqd_import_packed",
     "fqd_export_packed_by_segment", "fqd_export_unique_by_segment", "fqd_gather_unique",
-    "fqd_find_edges_segments", "fqd_edge_labels", "fqd_list_kept_except", "fqd_set_owner_rule", "fqd_declare_distinct_keys",
+    "fqd_find_edges_segments", "fqd_edge_labels", "fqd_list_kept_except", "fqd_set_owner_rule", "fqd_declare_distinct_keys", "fqd_collapse_received",
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
     "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_edge_stats", "fqd_synth_keys",
 ]
@@ -100,6 +100,7 @@ def load() -> C.CDLL:
                                                C.c_int]
     L.fqd_set_owner_rule.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.fqd_declare_distinct_keys.argtypes = [vp]
+    L.fqd_collapse_received.argtypes = [vp, vp, u64p, u64p, C.c_uint32, C.c_uint64, C.c_int, u64p]
     L.fqd_gather_unique.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_int]
     L.fqd_find_edges_segments.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, u64p]
     L.fqd_edge_labels.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, u64p, C.c_int]
@@ -400,6 +401,19 @@ class Context:
         fp, _m, _4 = _ptr_mem(first_ids)
         self._ck(self._L.fqd_import_unique(self._h, rp, lp, cp, fp, int(n_unique),
                                            DEVICE_BORROW if borrow and rm == DEVICE else rm))
+
+    def collapse_received(self, weights, seg_rows, seg_id0, id_limit: int = 2**64 - 1) -> int:
+        """Collapse reads received from several ranks whose records carry the sender's local read
+        index in their padding word (export_packed_by_segment with ids=None): rows
+        seg_rows[s]..seg_rows[s+1] came from the rank whose first read has id seg_id0[s]."""
+        wp, wm, _0 = _ptr_mem(weights)
+        rows = np.ascontiguousarray(seg_rows, dtype=np.uint64)
+        id0 = np.ascontiguousarray(seg_id0, dtype=np.uint64)
+        nu = C.c_uint64(0)
+        self._ck(self._L.fqd_collapse_received(self._h, wp, rows.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                               id0.ctypes.data_as(C.POINTER(C.c_uint64)), len(id0),
+                                               int(id_limit), wm if weights is not None else DEVICE, C.byref(nu)))
+        return nu.value
 
     def declare_distinct_keys(self):
         """The imported rows hold pairwise distinct keys (rows of other ranks' collapsed tables)."""

@@ -19,13 +19,21 @@ struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     bool borrowed = false;   // p belongs to the caller (FQD_DEVICE_BORROW): never freed, never reused
-    hipError_t reserve(size_t bytes)
+    void *own_p = nullptr;   // the context's own allocation, parked while p is borrowed (no
+    size_t own_cap = 0;      // hipFree/hipMalloc per job: a job that borrows every time would churn)
+    void unborrow()
     {
         if (borrowed) {
-            p = nullptr;
-            cap = 0;
+            p = own_p;
+            cap = own_cap;
+            own_p = nullptr;
+            own_cap = 0;
             borrowed = false;
         }
+    }
+    hipError_t reserve(size_t bytes)
+    {
+        unborrow();
         if (bytes <= cap)
             return hipSuccess;
         if (p)
@@ -40,16 +48,19 @@ struct DevBuf {
     }
     void release()
     {
-        if (p && !borrowed)
+        unborrow();
+        if (p)
             (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        borrowed = false;
     }
     // Use the caller's device buffer in place (no copy); the next reserve() lets go of it.
     void borrow(const void *ptr, size_t bytes)
     {
-        release();
+        if (!borrowed) {
+            own_p = p;
+            own_cap = cap;
+        }
         p = const_cast<void *>(ptr);
         cap = bytes;
         borrowed = true;
@@ -92,6 +103,7 @@ struct fqd_ctx {
     uint64_t id_limit = ~0ull;  // every first-holder id is below this (~0: unknown)
     bool collapsed = false;  // unique table came from fqd_collapse (keys are pairwise distinct)
     bool first_distinct = true;  // first-holder ids are pairwise distinct (false: imported without ids)
+    DevBuf seg_tab;   // fqd_collapse_received: id bases and row offsets of the senders' segments
     DevBuf in_weights, in_read_ids, hs_sorted, ids, ids_sorted, flags, run_idx, run_start, run_weight, live_flag,
         live_idx, collision_runs;
     DevBuf urecs, ulens, ucounts, ufirst;
@@ -382,7 +394,7 @@ int hash_bits_from_env()
 
 // Sort-free collapse for records of one uint4 (collapse_lds.hip). Returns FQD_OK with
 // *done = false when it does not apply or a bucket's table overflowed (caller falls back).
-int collapse_lds(fqd_ctx *c, const uint32_t *d_w, const uint64_t *d_ids, bool *done)
+int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
 {
     *done = false;
     const uint64_t n = c->n;
@@ -628,7 +640,7 @@ void fqd_destroy(fqd_ctx *c)
                       &c->ed_payload, &c->ed_hash_sorted, &c->ed_payload_sorted, &c->ed_cands, &c->ed_cands_sorted,
                       &c->d_alphabet, &c->labels, &c->best, &c->state,
                       &c->blocked, &c->kept, &c->kept_u32, &c->kept_scan, &c->kept_ids, &c->kept_ids_sorted, &c->tmp,
-                      &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners, &c->taint, &c->root_taint, &c->gp_a, &c->gp_b, &c->gp_small, &c->gp_cands};
+                      &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners, &c->taint, &c->root_taint, &c->gp_a, &c->gp_b, &c->gp_small, &c->gp_cands, &c->seg_tab};
     for (DevBuf *b : bufs)
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -816,11 +828,23 @@ int fqd_set_owner_rule(fqd_ctx *c, uint32_t n_parts, uint32_t n_segments, uint32
     return FQD_OK;
 }
 
-int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, int mem, uint64_t *n_unique)
+static void set_id_range(fqd_ctx *c, uint64_t limit)
 {
-    FQD_TRY(bind(c));
-    if (c->stage < ST_PACKED)
-        return fail(c, FQD_E_STATE, "fqd_collapse before fqd_pack_keys/fqd_import_packed");
+    c->id_limit = limit;
+    c->id_bits = 64;
+    if (limit != ~0ull) {
+        c->id_bits = 1;
+        while (c->id_bits < 64 && ((limit ? limit - 1 : 0) >> c->id_bits))
+            c->id_bits++;
+    }
+}
+
+// Shared body of fqd_collapse / fqd_collapse_received. `ids` says where a read's id comes from
+// (device pointers); id_limit bounds every id (~0: unknown).
+static int collapse_impl(fqd_ctx *c, const uint32_t *weights, int mem, IdSource ids, uint64_t id_limit,
+                         uint64_t *n_unique)
+{
+    const bool read_ids = ids.ids64 || ids.stamped;   // false: a read's id is its position
     c->stage = ST_PACKED;
     const uint64_t n = c->n;
     const KeyShape sh = c->ks;
@@ -835,28 +859,30 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
         return FQD_OK;
     }
     const uint32_t *d_w;
-    const uint64_t *d_ids;
     FQD_TRY(to_device(c, weights, (size_t)n, mem, c->in_weights, &d_w));
-    FQD_TRY(to_device(c, read_ids, (size_t)n, mem, c->in_read_ids, &d_ids));
 
     bool lds_done = false;
-    FQD_TRY(collapse_lds(c, weights ? d_w : nullptr, read_ids ? d_ids : nullptr, &lds_done));
+    FQD_TRY(collapse_lds(c, weights ? d_w : nullptr, ids, &lds_done));
     if (lds_done) {
         timer.stop();
         c->collapse_path = 1;
         c->collapsed = true;
         c->first_distinct = true;
-        c->id_bits = 64;
-        c->id_limit = read_ids ? ~0ull : n;
-        if (!read_ids) {
-            c->id_bits = 1;
-            while (c->id_bits < 64 && (n >> c->id_bits))
-                c->id_bits++;
-        }
+        set_id_range(c, read_ids ? id_limit : n);
         c->stage = ST_UNIQUE;
         if (n_unique)
             *n_unique = c->U;
         return FQD_OK;
+    }
+    if (ids.stamped) {
+        // The sort-based path compares whole records, padding included: take the ids out of the
+        // padding word (explicit array from here on) and clear it. (The packed buffer may be one the
+        // caller lent with FQD_DEVICE_BORROW: its padding words are cleared in place.)
+        HIP_TRY(c, c->in_read_ids.reserve((size_t)n * 8 + 16));
+        HIP_TRY(c, fqd::launch_extract_ids(ids, c->recs.as<uint32_t>(), n, c->in_read_ids.as<uint64_t>(), c->st));
+        IdSource plain;
+        plain.ids64 = c->in_read_ids.as<uint64_t>();
+        ids = plain;
     }
     c->collapse_path = 2;
     const int bits = hash_bits_from_env();
@@ -920,7 +946,7 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
     KTIME(c, FQD_K_WRITE_UNIQUE, fqd::launch_write_unique(c->run_start.as<uint32_t>(), c->run_weight.as<uint32_t>(),
                                         c->live_flag.as<uint32_t>(), c->live_idx.as<uint32_t>(), n_runs,
                                         c->ids_sorted.as<uint32_t>(), c->recs.as<uint32_t>(), c->lens.as<uint32_t>(),
-                                        read_ids ? d_ids : nullptr, sh, c->urecs.as<uint32_t>(),
+                                        ids.ids64, sh, c->urecs.as<uint32_t>(),
                                         c->ulens.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(),
                                         c->st));
     timer.stop();
@@ -928,17 +954,56 @@ int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, 
     c->n_counted = counted;
     c->collapsed = true;
     c->first_distinct = true;
-    c->id_bits = 64;
-    c->id_limit = read_ids ? ~0ull : n;
-    if (!read_ids) {  // ids are 0..n-1
-        c->id_bits = 1;
-        while (c->id_bits < 64 && (n >> c->id_bits))
-            c->id_bits++;
-    }
+    set_id_range(c, read_ids ? id_limit : n);
     c->stage = ST_UNIQUE;
     if (n_unique)
         *n_unique = U;
     return FQD_OK;
+}
+
+int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, int mem, uint64_t *n_unique)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_PACKED)
+        return fail(c, FQD_E_STATE, "fqd_collapse before fqd_pack_keys/fqd_import_packed");
+    IdSource ids;
+    if (read_ids && c->n)
+        FQD_TRY(to_device(c, read_ids, (size_t)c->n, mem, c->in_read_ids, &ids.ids64));
+    return collapse_impl(c, weights, mem, ids, ~0ull, n_unique);
+}
+
+int fqd_collapse_received(fqd_ctx *c, const uint32_t *weights, const uint64_t *seg_rows, const uint64_t *seg_id0,
+                          uint32_t n_seg, uint64_t id_limit, int mem, uint64_t *n_unique)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_PACKED)
+        return fail(c, FQD_E_STATE, "fqd_collapse_received before fqd_import_packed");
+    const KeyShape sh = c->ks;
+    if (sh.stride <= sh.planes * sh.words)
+        return fail(c, FQD_E_VALUE, "records of this geometry have no padding word to carry an index");
+    if (n_seg == 0 || n_seg > 65536 || !seg_rows || !seg_id0 || seg_rows[0] != 0 || seg_rows[n_seg] != c->n)
+        return fail(c, FQD_E_VALUE, "segments must tile the packed reads");
+    for (uint32_t s = 0; s < n_seg; s++)
+        if (seg_rows[s] > seg_rows[s + 1])
+            return fail(c, FQD_E_VALUE, "segment offsets must not decrease");
+    // small tables on the device: n_seg + 1 row offsets (u32) behind n_seg id bases (u64)
+    HIP_TRY(c, c->seg_tab.reserve((size_t)n_seg * 8 + ((size_t)n_seg + 1) * 4 + 16));
+    std::vector<uint32_t> rows32((size_t)n_seg + 1);
+    for (uint32_t s = 0; s <= n_seg; s++)
+        rows32[s] = (uint32_t)seg_rows[s];
+    uint64_t *d_id0 = c->seg_tab.as<uint64_t>();
+    uint32_t *d_rows = reinterpret_cast<uint32_t *>(d_id0 + n_seg);
+    HIP_TRY(c, hipMemcpyAsync(d_id0, seg_id0, (size_t)n_seg * 8, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, hipMemcpyAsync(d_rows, rows32.data(), ((size_t)n_seg + 1) * 4, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));      // rows32 goes out of scope
+    IdSource ids;
+    ids.stamped = c->recs.as<uint32_t>();
+    ids.stride = sh.stride;
+    ids.spare_word = sh.planes * sh.words;
+    ids.seg_rows = d_rows;
+    ids.seg_id0 = d_id0;
+    ids.n_seg = n_seg;
+    return collapse_impl(c, weights, mem, ids, id_limit, n_unique);
 }
 
 // One Hamming search pass without a device-wide sort (group.hip): the (segment hash, uid) pairs
@@ -1497,7 +1562,8 @@ int fqd_export_packed(fqd_ctx *c, uint32_t *recs, uint32_t *lens, uint32_t *hash
 // one radix pass over ceil(log2 parts) bits, one coalesced gather, the part sizes to the host.
 static int export_grouped(fqd_ctx *c, uint64_t n, uint32_t n_parts, const uint32_t *owner, const uint32_t *src_recs,
                           const uint32_t *src_lens, const uint32_t *weights, uint64_t id0, uint32_t *recs,
-                          uint32_t *lens, uint64_t *ids, uint32_t *ids32, uint32_t *weights_out, uint64_t *counts)
+                          uint32_t *lens, uint64_t *ids, uint32_t *ids32, uint32_t *weights_out, uint64_t *counts,
+                          uint32_t stamp_word = 0)
 {
     const KeyShape sh = c->ks;
     HIP_TRY(c, c->ids_sorted.reserve(n * 4 + 16));
@@ -1528,7 +1594,7 @@ static int export_grouped(fqd_ctx *c, uint64_t n, uint32_t n_parts, const uint32
         HIP_TRY(c, fqd::launch_owner_counts(owner_sorted, n, n_parts, c->stage_d.as<uint64_t>(), c->st));
     }
     HIP_TRY(c, fqd::launch_gather_by_owner(order, n, sh, src_recs, src_lens, weights, id0, recs, lens, ids, ids32,
-                                           weights_out, c->st));
+                                           weights_out, c->st, stamp_word));
     HIP_TRY(c, hipMemcpyAsync(counts, c->stage_d.p, (size_t)n_parts * 8, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     return FQD_OK;
@@ -1577,8 +1643,15 @@ int fqd_export_packed_by_segment(fqd_ctx *c, uint32_t n_parts, uint32_t n_segmen
                                               segment, segment + 1, n_parts, c->flags.as<uint32_t>(), c->st));
         owner = c->flags.as<uint32_t>();
     }
+    // no id array asked for: the read's index on this rank rides in the record's first padding word
+    uint32_t stamp_word = 0;
+    if (!ids) {
+        stamp_word = c->ks.planes * c->ks.words;
+        if (stamp_word >= c->ks.stride)
+            return fail(c, FQD_E_VALUE, "records of this geometry have no padding word: pass an ids buffer");
+    }
     return export_grouped(c, n, n_parts, owner, c->recs.as<uint32_t>(), c->lens.as<uint32_t>(),
-                          weights, id0, recs, lens, ids, nullptr, weights_out, counts);
+                          weights, id0, recs, lens, ids, nullptr, weights_out, counts, stamp_word);
 }
 
 int fqd_export_unique_by_segment(fqd_ctx *c, uint32_t n_parts, uint32_t n_segments, uint32_t segment,

@@ -64,8 +64,15 @@ __device__ __forceinline__ uint32_t load_item(const uint32_t *__restrict__ hashe
                                               uint32_t i, uint32_t kw, uint32_t len, uint4 &v)
 {
     v = in[i];
-    if (LEVEL1)
+    if (LEVEL1) {
+        // words past the key are padding: zero on this rank's own packed reads, but a sender's local
+        // index on reads received from other ranks (fqd_collapse_received) -- never part of the key
+        if (kw < 3)
+            v.z = 0;
+        if (kw < 2)
+            v.y = 0;
         v.w = i;
+    }
     // the hash is recomputed from the record at both levels (a dozen VALU ops): reading the stored
     // hash would add 4 B to the 32 B this kernel moves per read. Only the level-1 HISTOGRAM reads
     // the hash array (4 B instead of the 16-B record).
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe_kernel(
 __global__ __launch_bounds__(256) void bucket_compact_kernel(
     const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ unique_incl /* inclusive scan */,
     uint32_t n_buckets, const uint4 *__restrict__ tmp_rec, const uint32_t *__restrict__ tmp_count,
-    const uint32_t *__restrict__ tmp_first, const uint64_t *__restrict__ read_ids, uint4 *__restrict__ urecs,
+    const uint32_t *__restrict__ tmp_first, IdSource read_ids, uint4 *__restrict__ urecs,
     uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst)
 {
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(
         urecs[begin + j] = tmp_rec[src + j];
         ucounts[begin + j] = tmp_count[src + j];
         const uint32_t f = tmp_first[src + j];
-        ufirst[begin + j] = read_ids ? read_ids[f] : (uint64_t)f;
+        ufirst[begin + j] = read_ids.at(f);
     }
 }
 
@@ -493,7 +500,7 @@ hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_sta
 
 hipError_t launch_bucket_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                  const uint32_t *tmp_rec, const uint32_t *tmp_count, const uint32_t *tmp_first,
-                                 const uint64_t *read_ids, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
+                                 IdSource read_ids, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
                                  hipStream_t st)
 {
     const uint64_t threads = (uint64_t)n_buckets * 64;

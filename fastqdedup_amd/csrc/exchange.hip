@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void gather_by_owner_kernel(const uint32_t *__
                                                               uint32_t *__restrict__ lens_out,
                                                               uint64_t *__restrict__ ids_out,
                                                               uint32_t *__restrict__ ids32_out,
-                                                              uint32_t *__restrict__ weights_out)
+                                                              uint32_t *__restrict__ weights_out, uint32_t stamp_word)
 {
     const uint32_t Q = sh.stride / 4;
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -35,8 +35,14 @@ __global__ __launch_bounds__(256) void gather_by_owner_kernel(const uint32_t *__
     if (i >= n)
         return;
     const uint32_t src = order[i];
-    reinterpret_cast<uint4 *>(recs_out + i * sh.stride)[q] =
-        reinterpret_cast<const uint4 *>(recs + (uint64_t)src * sh.stride)[q];
+    uint4 v = reinterpret_cast<const uint4 *>(recs + (uint64_t)src * sh.stride)[q];
+    if (stamp_word && q == stamp_word / 4) {
+        // the read's index on THIS rank travels in the record's first padding word (no id array
+        // on the wire); the receiver adds the rank's id base (IdSource)
+        const uint32_t e = stamp_word & 3u;
+        if (e == 0) v.x = src; else if (e == 1) v.y = src; else if (e == 2) v.z = src; else v.w = src;
+    }
+    reinterpret_cast<uint4 *>(recs_out + i * sh.stride)[q] = v;
     if (q == 0) {
         if (ids_out)
             ids_out[i] = id0 + src;
@@ -152,6 +158,15 @@ __global__ void split_totals_kernel(const uint32_t *__restrict__ matrix_incl, ui
     counts[p] = hi - lo;
 }
 
+__global__ void extract_ids_kernel(IdSource src, uint32_t *__restrict__ recs, uint64_t n, uint64_t *__restrict__ ids64)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    ids64[i] = src.at((uint32_t)i);
+    recs[i * src.stride + src.spare_word] = 0;
+}
+
 // counts[p] = number of sorted owners equal to p (binary search, one thread per part)
 __global__ void owner_counts_kernel(const uint32_t *__restrict__ owner_sorted, uint64_t n, uint32_t parts,
                                     uint64_t *__restrict__ counts)
@@ -187,13 +202,13 @@ hipError_t launch_owner(const uint32_t *hashes, uint64_t n, uint32_t parts, uint
 hipError_t launch_gather_by_owner(const uint32_t *order, uint64_t n, KeyShape sh, const uint32_t *recs,
                                   const uint32_t *lens, const uint32_t *weights, uint64_t id0, uint32_t *recs_out,
                                   uint32_t *lens_out, uint64_t *ids_out, uint32_t *ids32_out, uint32_t *weights_out,
-                                  hipStream_t st)
+                                  hipStream_t st, uint32_t stamp_word)
 {
     if (n) {
         const uint64_t threads = n * (sh.stride / 4);
         gather_by_owner_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(order, n, sh, recs, lens, weights, id0,
                                                                                 recs_out, lens_out, ids_out,
-                                                                                ids32_out, weights_out);
+                                                                                ids32_out, weights_out, stamp_word);
     }
     return hipGetLastError();
 }
@@ -217,6 +232,13 @@ hipError_t launch_split_order(const uint32_t *owner, uint64_t n, uint32_t parts,
         split_order_kernel<<<tiles, SPLIT_THREADS, 0, st>>>(owner, n, parts, tiles, matrix, matrix_incl, order);
         split_totals_kernel<<<(parts + 63) / 64, 64, 0, st>>>(matrix_incl, parts, tiles, counts);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_extract_ids(IdSource src, uint32_t *recs, uint64_t n, uint64_t *ids64, hipStream_t st)
+{
+    if (n)
+        extract_ids_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(src, recs, n, ids64);
     return hipGetLastError();
 }
 

@@ -137,6 +137,35 @@ __device__ __forceinline__ uint32_t fqd_segment_hash(const uint32_t *rec, uint32
 
 __device__ __forceinline__ uint32_t fqd_lane() { return threadIdx.x & 63u; }
 
+// Where the id of the read at position `pos` of the packed buffer comes from: an explicit id
+// array, or (reads received from several ranks, fqd_collapse_received) the local index that the
+// sender stamped into the record's first padding word plus the id base of the sender's segment,
+// or the position itself.
+struct IdSource {
+    const uint64_t *ids64 = nullptr;
+    const uint32_t *stamped = nullptr;    // packed records; word `spare_word` of each holds a local index
+    uint32_t stride = 0, spare_word = 0;
+    const uint32_t *seg_rows = nullptr;   // n_seg + 1 row offsets of the segments (device)
+    const uint64_t *seg_id0 = nullptr;    // n_seg id bases (device)
+    uint32_t n_seg = 0;
+    __device__ __forceinline__ uint64_t at(uint32_t pos) const
+    {
+        if (ids64)
+            return ids64[pos];
+        if (!stamped)
+            return pos;
+        uint32_t a = 0, b = n_seg;        // last segment with seg_rows[a] <= pos
+        while (b - a > 1) {
+            const uint32_t m = (a + b) >> 1;
+            if (seg_rows[m] <= pos)
+                a = m;
+            else
+                b = m;
+        }
+        return seg_id0[a] + stamped[(uint64_t)pos * stride + spare_word];
+    }
+};
+
 __device__ __forceinline__ uint64_t fqd_lanemask_lt()
 {
     return (1ull << fqd_lane()) - 1ull;
@@ -217,7 +246,7 @@ hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_sta
                                 uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);
 hipError_t launch_bucket_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                  const uint32_t *tmp_rec, const uint32_t *tmp_count, const uint32_t *tmp_first,
-                                 const uint64_t *read_ids, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
+                                 IdSource read_ids, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
                                  hipStream_t st);
 
 // edges.hip
@@ -282,7 +311,10 @@ hipError_t launch_owner(const uint32_t *hashes, uint64_t n, uint32_t parts, uint
 hipError_t launch_gather_by_owner(const uint32_t *order, uint64_t n, KeyShape sh, const uint32_t *recs,
                                   const uint32_t *lens, const uint32_t *weights, uint64_t id0, uint32_t *recs_out,
                                   uint32_t *lens_out, uint64_t *ids_out, uint32_t *ids32_out, uint32_t *weights_out,
-                                  hipStream_t st);
+                                  hipStream_t st, uint32_t stamp_word = 0);
+// ids64[pos] = src.at(pos) for every read, and the stamped word is cleared (the sort-based collapse
+// compares whole records, padding included)
+hipError_t launch_extract_ids(IdSource src, uint32_t *recs, uint64_t n, uint64_t *ids64, hipStream_t st);
 uint32_t split_tiles(uint64_t n);
 uint32_t split_max_parts();
 hipError_t launch_split_count(const uint32_t *owner, uint64_t n, uint32_t parts, uint32_t *matrix, hipStream_t st);

@@ -159,6 +159,16 @@ int fqd_export_packed_by_owner(fqd_ctx *ctx, uint32_t n_parts, uint64_t id0, con
 int fqd_export_packed_by_segment(fqd_ctx *ctx, uint32_t n_parts, uint32_t n_segments, uint32_t segment,
                                  uint64_t id0, const uint32_t *weights, uint32_t *recs, uint32_t *lens,
                                  uint64_t *ids, uint32_t *weights_out, uint64_t *counts, int mem);
+/* ids == NULL above: no id array is produced; instead every exported record carries the read's
+ * index on THIS rank in its first padding word (geometries with stride_words > planes * words:
+ * FQD_E_VALUE otherwise). The receiver collapses such reads with fqd_collapse_received, naming the
+ * row range each sender's reads occupy in its packed buffer (seg_rows, n_seg + 1 offsets, HOST)
+ * and the sender's id base (seg_id0, HOST): id = seg_id0[s] + carried index; id_limit bounds all
+ * ids (~0 = unknown). 16 instead of 24 bytes per read on the wire for keys of <= 32 nt. A buffer
+ * lent with FQD_DEVICE_BORROW may get its padding words cleared. Otherwise as fqd_collapse. */
+int fqd_collapse_received(fqd_ctx *ctx, const uint32_t *weights, const uint64_t *seg_rows,
+                          const uint64_t *seg_id0, uint32_t n_seg, uint64_t id_limit, int mem,
+                          uint64_t *n_unique);
 /* Optional: announce the owner rule BEFORE fqd_pack_keys, which then works out every read's owner
  * in the same pass; a matching fqd_export_packed_by_segment skips its own pass over the records.
  * n_parts = 0 switches it off. */

@@ -572,6 +572,49 @@ def test_grouping_by_segment_owner(F):
         ctx.gather_unique(torch.tensor([nu], dtype=torch.int32, device=dev), 1, g_recs, None, g_counts)
 
 
+@pytest.mark.parametrize("L,alphabet,path", [(32, "ACGTN", None), (32, "ACGTN", "sort"), (72, "ACGTN", None),
+                                             (20, "ACGT", "lds")])
+def test_collapse_of_received_reads(F, monkeypatch, L, alphabet, path):
+    """fqd_export_packed_by_segment(ids=NULL) + fqd_collapse_received: the sender's read index rides
+    in the record's padding word and the receiver adds the sender's id base. Same unique table
+    (first ids, counts) as a plain collapse with an explicit id array -- through the LDS collapse,
+    the sort-based one (ids extracted, padding cleared), long records, and a geometry whose padding
+    starts before the fourth word."""
+    import torch
+    from fastqdedup_amd.synth import synth_keys
+    dev = torch.device("cuda", 0)
+    if path:
+        monkeypatch.setenv("FQD_COLLAPSE", path)
+    nx, ny, base = 45_000, 30_000, 1000
+    allk = synth_keys(nx + ny, L, 8, 51, sub_rate=4e-3, n_rate=3e-4 if "N" in alphabet else 0.0)
+    ctx = F.Context(0)
+    sent = []
+    for part in (allk[:nx], allk[nx:]):
+        ctx.pack_keys(np.ascontiguousarray(part).reshape(-1), None, L)
+        sh = ctx.shape()
+        assert sh.stride_words > sh.planes * sh.words
+        recs = torch.empty((part.shape[0], sh.stride_words), dtype=torch.int32, device=dev)
+        counts = ctx.export_packed_by_segment(1, 2, 0, 0, None, recs, None, None, None)
+        assert [int(c) for c in counts] == [part.shape[0]]
+        sent.append(recs)
+    got_ctx = F.Context(0)
+    got_ctx.pack_keys(np.ascontiguousarray(allk[:1]).reshape(-1), None, L)      # same geometry
+    received = torch.cat(sent)
+    got_ctx.import_packed(received, None, nx + ny, borrow=True)
+    nu = got_ctx.collapse_received(None, [0, nx, nx + ny], [base, base + nx], base + nx + ny)
+    first, counts, _l, _k = got_ctx.unique_table(nu, labels=False, kept=False)
+
+    want_ctx = F.Context(0)
+    want_ctx.pack_keys(np.ascontiguousarray(allk).reshape(-1), None, L)
+    nu2 = want_ctx.collapse(None, np.arange(base, base + nx + ny, dtype=np.uint64))
+    first2, counts2, _l2, _k2 = want_ctx.unique_table(nu2, labels=False, kept=False)
+    assert nu == nu2
+    order, order2 = np.argsort(first), np.argsort(first2)
+    assert np.array_equal(first[order], first2[order2]) and np.array_equal(counts[order], counts2[order2])
+    # and the search still works on that table (padding never takes part in a key)
+    assert got_ctx.find_edges(1, 0, 0, 1) == want_ctx.find_edges(1, 0, 0, 1)
+
+
 def test_edge_labels_and_kept_except(F, oracle):
     """fqd_edge_labels (components of a caller's edge list) and fqd_list_kept_except (verdicts
     computed elsewhere) against the plain single-context path."""

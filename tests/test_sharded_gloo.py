@@ -90,7 +90,7 @@ class NumpyBackend:
         return recs, lens, ids, w, counts
 
     # -- segment-routed plan ---------------------------------------------------
-    def collapse_resident(self, recs, lens, weights, read_ids):
+    def collapse_resident(self, recs, lens, weights, read_ids, seg_rows=None, seg_id0=None, id_limit=None):
         urecs, ulens, ucounts, ufirst = self.collapse_packed(recs, lens, weights, read_ids)
         self.table = self._decode(urecs, ulens)
         self.table_counts, self.table_first = ucounts.tolist(), ufirst.tolist()
