@@ -95,6 +95,7 @@ struct fqd_ctx {
     // stage 1
     uint64_t n = 0;
     DevBuf in_bytes, in_offsets, recs, lens, hashes, owners;
+    bool hashes_valid = false;     // `hashes` holds the record hashes of the packed reads (lazy after an import)
     fqd::OwnerRule owner_rule;     // fqd_set_owner_rule: fqd_pack_keys also writes each read's owner rank
     fqd::OwnerRule owners_done;    // the rule `owners` was filled with (parts == 0: not filled)
     // stage 2
@@ -394,6 +395,19 @@ int hash_bits_from_env()
 
 // Sort-free collapse for records of one uint4 (collapse_lds.hip). Returns FQD_OK with
 // *done = false when it does not apply or a bucket's table overflowed (caller falls back).
+// Record hashes of the packed reads, computed on demand after an import (the LDS collapse works
+// from the records alone; the sort-based collapse and the exports need the array).
+int ensure_hashes(fqd_ctx *c)
+{
+    if (c->hashes_valid)
+        return FQD_OK;
+    HIP_TRY(c, c->hashes.reserve((size_t)c->n * 4 + 16));
+    HIP_TRY(c, fqd::launch_hash_records(c->recs.as<uint32_t>(), c->lens.as<uint32_t>(), c->n, c->ks,
+                                        c->hashes.as<uint32_t>(), c->st));
+    c->hashes_valid = true;
+    return FQD_OK;
+}
+
 int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
 {
     *done = false;
@@ -438,7 +452,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
     const size_t matrix = (size_t)bins1 * tiles1;
     HIP_TRY(c, c->ld_matrix.reserve(matrix * 4 + 16));
     HIP_TRY(c, c->ld_matrix_incl.reserve(matrix * 4 + 16));
-    KTIME(c, FQD_K_PART_HIST1, fqd::launch_part_hist(true, c->hashes.as<uint32_t>(), c->recs.as<uint32_t>(), seg1, tiles1_d, 1, tiles1,
+    KTIME(c, FQD_K_PART_HIST1, fqd::launch_part_hist(true, c->hashes_valid ? c->hashes.as<uint32_t>() : nullptr, c->recs.as<uint32_t>(), seg1, tiles1_d, 1, tiles1,
                                      32 - B1, bins1, kw, sh.max_len, c->ld_matrix.as<uint32_t>(), c->st));
     FQD_TRY(scan_u32(c, c->ld_matrix.as<uint32_t>(), c->ld_matrix_incl.as<uint32_t>(), matrix));
     HIP_TRY(c, fqd::launch_matrix_starts(c->ld_matrix_incl.as<uint32_t>(), bins1, tiles1, start1, c->st));
@@ -814,6 +828,7 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
     timer.stop();
     c->n = n;
     c->owners_done = c->owner_rule;
+    c->hashes_valid = true;
     c->stage = ST_PACKED;
     return FQD_OK;
 }
@@ -893,6 +908,7 @@ static int collapse_impl(fqd_ctx *c, const uint32_t *weights, int mem, IdSource 
     HIP_TRY(c, c->flags.reserve(n * 4 + 16));
     HIP_TRY(c, c->run_idx.reserve(n * 4 + 16));
     HIP_TRY(c, fqd::launch_iota_u32(c->ids.as<uint32_t>(), n, c->st));
+    FQD_TRY(ensure_hashes(c));
     FQD_TRY(sort_u32_pairs(c, c->hashes.as<uint32_t>(), c->hs_sorted.as<uint32_t>(), c->ids.as<uint32_t>(),
                            c->ids_sorted.as<uint32_t>(), n, bits));
 
@@ -1554,6 +1570,8 @@ int fqd_export_packed(fqd_ctx *c, uint32_t *recs, uint32_t *lens, uint32_t *hash
             HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)lens, (int)c->ks.max_len, (size_t)c->n, c->st));
         }
     }
+    if (hashes)
+        FQD_TRY(ensure_hashes(c));
     FQD_TRY(from_device(c, hashes, c->hashes.p, (size_t)c->n, mem));
     return FQD_OK;
 }
@@ -1618,6 +1636,7 @@ int fqd_export_packed_by_owner(fqd_ctx *c, uint32_t n_parts, uint64_t id0, const
     FQD_TRY(check_parts(c, n_parts, mem, "fqd_export_packed_by_owner"));
     const uint64_t n = c->n;
     HIP_TRY(c, c->flags.reserve(n * 4 + 16));
+    FQD_TRY(ensure_hashes(c));
     HIP_TRY(c, fqd::launch_owner(c->hashes.as<uint32_t>(), n, n_parts, c->flags.as<uint32_t>(), c->st));
     return export_grouped(c, n, n_parts, c->flags.as<uint32_t>(), c->recs.as<uint32_t>(), c->lens.as<uint32_t>(),
                           weights, id0, recs, lens, ids, nullptr, weights_out, counts);
@@ -1793,10 +1812,9 @@ int fqd_import_packed(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, ui
                 HIP_TRY(c, hipMemcpyAsync(c->lens.p, lens, (size_t)n * 4, kind, c->st));
         }
     }
-    HIP_TRY(c, fqd::launch_hash_records(c->recs.as<uint32_t>(), c->lens.as<uint32_t>(), n, sh,
-                                        c->hashes.as<uint32_t>(), c->st));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     c->n = n;
+    c->hashes_valid = false;       // computed when somebody needs them (ensure_hashes)
     c->owners_done = fqd::OwnerRule{};
     c->stage = ST_PACKED;
     return FQD_OK;

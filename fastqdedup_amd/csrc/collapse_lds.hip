@@ -100,7 +100,7 @@ __global__ __launch_bounds__(PT_THREADS) void part_hist_kernel(const uint32_t *_
         const uint32_t i = lo + e * PT_THREADS + threadIdx.x;
         h[e] = 0;
         if (i < hi) {
-            if (LEVEL1) {
+            if (LEVEL1 && hashes) {      // no hash array (reads imported from other ranks): recompute
                 h[e] = hashes[i];
             } else {
                 uint4 v;

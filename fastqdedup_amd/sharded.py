@@ -261,7 +261,15 @@ class _Comm:
         return x.cpu() if self.via_host else x
 
     def _back(self, x):
-        return x.to(self.device) if self.via_host else x
+        if self.via_host:
+            return x.to(self.device)
+        # The HIP library works on its own stream: what a collective produced on torch's stream must
+        # be complete before the next library call reads it. (The library's stream is a blocking
+        # stream, which already orders it behind torch's default stream; this makes the dependency
+        # explicit instead of relying on legacy default-stream semantics.)
+        if x.is_cuda:
+            torch.cuda.current_stream(x.device).synchronize()
+        return x
 
     def all_gather_ints(self, values) -> np.ndarray:
         """(world, len(values)) int64 on the host."""
