@@ -361,38 +361,56 @@ __global__ __launch_bounds__(256) void kept_flags_kernel(int method, const uint3
                                                          unsigned long long *n_kept_total)
 {
     unsigned long long total = 0;
-    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < U;
-         v += (uint64_t)gridDim.x * blockDim.x) {
-        bool k;
-        if (method == 0)
-            k = best[labels[v]] == (uint32_t)v;
-        else if (method == 2)
-            k = best[v] == (uint32_t)v;
-        else if (method == 3) {    // directional, closed form
-            if (ucounts[v] != 1) {
-                k = state[v] != 2;
-            } else {
-                uint32_t r = (uint32_t)v, p = parent1[r];
-                while (p != r) {
-                    r = p;
-                    p = parent1[r];
+    // Four keys per thread and step: their loads are issued together, the verdicts computed, then
+    // the stores go out (one key per step left every step waiting on its own chain of loads).
+    constexpr uint32_t KF = 4;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t v0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v0 < U; v0 += KF * stride) {
+        bool k[KF];
+        uint64_t id[KF];
+#pragma unroll
+        for (uint32_t t = 0; t < KF; t++) {
+            const uint64_t v = v0 + t * stride;
+            k[t] = false;
+            id[t] = 0;
+            if (v >= U)
+                continue;
+            id[t] = ufirst[v];
+            if (method == 0)
+                k[t] = best[labels[v]] == (uint32_t)v;
+            else if (method == 2)
+                k[t] = best[v] == (uint32_t)v;
+            else if (method == 3) {    // directional, closed form
+                if (ucounts[v] != 1) {
+                    k[t] = state[v] != 2;
+                } else {
+                    uint32_t r = (uint32_t)v, p = parent1[r];
+                    while (p != r) {
+                        r = p;
+                        p = parent1[r];
+                    }
+                    k[t] = !root_taint[r] && best[r] == (uint32_t)v;
                 }
-                k = !root_taint[r] && best[r] == (uint32_t)v;
-            }
-        } else
-            k = state[v] == 1;
-        kept[v] = k ? 1 : 0;
-        const uint64_t id = ufirst[v];
-        const bool listed = k && id >= id_lo && id < id_hi;
-        if (window_flags) {
-            // ids are distinct: one byte per id of the window, set for the listed ones; the
-            // ascending id list is then a stream compaction of the window (no sort)
-            if (listed && id - id_lo < window_size)
-                window_flags[id - id_lo] = 1;
-        } else {
-            kept_u32[v] = listed ? 1u : 0u;
+            } else
+                k[t] = state[v] == 1;
         }
-        total += k ? 1ull : 0ull;
+#pragma unroll
+        for (uint32_t t = 0; t < KF; t++) {
+            const uint64_t v = v0 + t * stride;
+            if (v >= U)
+                continue;
+            kept[v] = k[t] ? 1 : 0;
+            const bool listed = k[t] && id[t] >= id_lo && id[t] < id_hi;
+            if (window_flags) {
+                // ids are distinct: one byte per id of the window, set for the listed ones; the
+                // ascending id list is then a stream compaction of the window (no sort)
+                if (listed && id[t] - id_lo < window_size)
+                    window_flags[id[t] - id_lo] = 1;
+            } else {
+                kept_u32[v] = listed ? 1u : 0u;
+            }
+            total += k[t] ? 1ull : 0ull;
+        }
     }
     for (int o = 32; o; o >>= 1)
         total += __shfl_xor(total, o);
