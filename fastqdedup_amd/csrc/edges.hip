@@ -18,17 +18,26 @@ namespace {
 // with fully coalesced 16-byte loads whatever the record size. A segment's hash is
 // fmix(len, s, SUM over its words of mix(word & segment mask, word index)): the sum is
 // order-free, so the Q lanes add up their partial sums with shuffles.
+// Segment bounds of fixed-length keys, worked out once on the host (two integer divisions per
+// segment and thread otherwise: the kernel was ALU bound on them). n == 0: compute per key (ragged).
+struct SegBounds {
+    uint32_t n;
+    uint32_t lo[8], hi[8];
+};
+
 __global__ __launch_bounds__(256) void segment_hashes_kernel(const uint32_t *__restrict__ urecs,
                                                              const uint32_t *__restrict__ ulens, uint64_t U,
                                                              KeyShape sh, uint32_t nseg, uint32_t s_begin,
-                                                             uint32_t s_end, uint32_t mod,
+                                                             uint32_t s_end, uint32_t mod, SegBounds fixed,
+                                                             uint32_t inv_q, uint32_t inv_k,
                                                              uint32_t *__restrict__ seg_hashes)
 {
-    const uint32_t Q = sh.stride / 4, K = sh.planes, KW = sh.planes * sh.words;
+    const uint32_t Q = sh.stride / 4, KW = sh.planes * sh.words;
     const uint32_t rpw = 64u / Q;                       // records per wave (Q <= 64 checked by the host)
     const uint32_t lane = fqd_lane();
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t rl = lane / Q, q = lane - rl * Q;
+    // x / Q and x / K by multiplication (inv = ceil(2^20 / divisor), exact for x < 2^14)
+    const uint32_t rl = (lane * inv_q) >> 20, q = lane - rl * Q;
     const uint64_t u = wave * rpw + rl;
     const bool active = rl < rpw && u < U;
     uint4 v = make_uint4(0, 0, 0, 0);
@@ -41,12 +50,17 @@ __global__ __launch_bounds__(256) void segment_hashes_kernel(const uint32_t *__r
     uint32_t wi[4];   // 32-base word index of each of this lane's 4 record words
 #pragma unroll
     for (uint32_t e = 0; e < 4; e++)
-        wi[e] = (q * 4 + e) / K;
+        wi[e] = ((q * 4 + e) * inv_k) >> 20;
     // segments [s_begin, s_end) of the nseg-way split; row (s - s_begin) of the output. mod != 0
     // stores hash % mod (the owner rank of a segment-routed exchange).
     for (uint32_t s = s_begin; s < s_end; s++) {
         uint32_t lo, hi;
-        fqd_segment(len, s, nseg, lo, hi);
+        if (fixed.n) {
+            lo = fixed.lo[s - s_begin];
+            hi = fixed.hi[s - s_begin];
+        } else {
+            fqd_segment(len, s, nseg, lo, hi);
+        }
         uint32_t part = 0;
 #pragma unroll
         for (uint32_t e = 0; e < 4; e++) {
@@ -389,7 +403,17 @@ hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, u
     const uint64_t rpw = 64 / Q, waves = (U + rpw - 1) / rpw, blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFull * 256)
         return hipErrorInvalidValue;
-    segment_hashes_kernel<<<(unsigned)blocks, 256, 0, st>>>(urecs, ulens, U, sh, nseg, s_begin, s_end, mod, seg_hashes);
+    SegBounds fixed{};
+    if (!sh.ragged && s_end - s_begin <= 8) {
+        fixed.n = s_end - s_begin;
+        for (uint32_t s = s_begin; s < s_end; s++) {     // as fqd_segment
+            fixed.lo[s - s_begin] = sh.max_len * s / nseg;
+            fixed.hi[s - s_begin] = sh.max_len * (s + 1) / nseg;
+        }
+    }
+    const uint32_t inv_q = ((1u << 20) + (uint32_t)Q - 1) / (uint32_t)Q, inv_k = ((1u << 20) + sh.planes - 1) / sh.planes;
+    segment_hashes_kernel<<<(unsigned)blocks, 256, 0, st>>>(urecs, ulens, U, sh, nseg, s_begin, s_end, mod, fixed, inv_q,
+                                                            inv_k, seg_hashes);
     return hipGetLastError();
 }
 
