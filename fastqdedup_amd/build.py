@@ -23,7 +23,7 @@ def _stale(target: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    headers = [os.path.join(CSRC, "fqd_internal.h"),
+    headers = [os.path.join(CSRC, "fqd_internal.h"), os.path.join(CSRC, "partition.cuh"),
                os.path.join(os.path.dirname(HERE), "include", "fqdedup_hip.h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)

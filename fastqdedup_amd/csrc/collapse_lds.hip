@@ -22,6 +22,7 @@
 // with more distinct keys than the table holds raises `overflow` and the caller falls
 // back to the sort-based collapse.
 #include "fqd_internal.h"
+#include "partition.cuh"
 
 namespace {
 
@@ -29,226 +30,72 @@ constexpr uint32_t DD_SLOTS = 1024;        // LDS table slots per bucket (power 
 constexpr uint32_t DD_THREADS = 256;
 constexpr uint32_t DD_EMPTY = 0xFFFFFFFFu;
 
-constexpr uint32_t PT_THREADS = 256;
-constexpr uint32_t PT_EPT = 8;                      // reads per thread
-constexpr uint32_t PT_TILE = PT_THREADS * PT_EPT;   // reads per tile
-constexpr uint32_t PT_MAX_BINS = 1024;
-
-// Tiles never straddle a segment (level 1: one segment = all reads; level 2: the 256
-// level-1 parts). tile_start[s] = first tile of segment s, tile_start[n_seg] = tile count.
-__device__ __forceinline__ bool tile_of_block(const uint32_t *__restrict__ seg_start,
-                                              const uint32_t *__restrict__ tile_start, uint32_t n_seg,
-                                              uint32_t &seg, uint32_t &lo, uint32_t &hi)
-{
-    const uint32_t t = blockIdx.x;
-    if (t >= tile_start[n_seg])
-        return false;
-    uint32_t a = 0, b = n_seg;  // last segment with tile_start <= t
-    while (b - a > 1) {
-        const uint32_t m = (a + b) >> 1;
-        if (tile_start[m] <= t)
-            a = m;
-        else
-            b = m;
+// The partition itself (tiles, LDS counting sort, count matrix) is partition.cuh; here is what a
+// 16-byte record looks like to it. LEVEL 1 reads the packed reads and stamps the read index into
+// the spare word; level 2 reads level-1 output. The key is the record hash: recomputed from the
+// record (a dozen VALU ops) wherever the record is loaded anyway -- reading the stored hash would
+// add 4 B to the 32 B the scatter moves per read; only the level-1 HISTOGRAM reads the hash array
+// (4 B instead of the 16-B record), when there is one (reads imported from other ranks have none).
+struct RecordPolicy {
+    using Item = uint4;
+    struct Source {
+        const uint32_t *hashes;   // level 1 only, may be NULL
+        const uint4 *in;
+        uint32_t kw, len;
+    };
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint32_t load(const Source &s, uint32_t i, uint4 &v)
+    {
+        v = s.in[i];
+        if (LEVEL1) {
+            // words past the key are padding: zero on this rank's own packed reads, but a sender's
+            // local index on reads received from other ranks (fqd_collapse_received) -- never part
+            // of the key
+            if (s.kw < 3)
+                v.z = 0;
+            if (s.kw < 2)
+                v.y = 0;
+            v.w = i;
+        }
+        const uint32_t rec[3] = {v.x, v.y, v.z};
+        return fqd_hash_record(rec, s.kw, s.len);
     }
-    seg = a;
-    lo = seg_start[a] + (t - tile_start[a]) * PT_TILE;
-    hi = min(lo + PT_TILE, seg_start[a + 1]);
-    return true;
-}
-
-// LEVEL 1 reads (hash, record) of the packed reads and stamps the read index into the spare
-// word; LEVEL 2 reads level-1 output and recomputes the hash from the record.
-template <bool LEVEL1>
-__device__ __forceinline__ uint32_t load_item(const uint32_t *__restrict__ hashes, const uint4 *__restrict__ in,
-                                              uint32_t i, uint32_t kw, uint32_t len, uint4 &v)
-{
-    v = in[i];
-    if (LEVEL1) {
-        // words past the key are padding: zero on this rank's own packed reads, but a sender's local
-        // index on reads received from other ranks (fqd_collapse_received) -- never part of the key
-        if (kw < 3)
-            v.z = 0;
-        if (kw < 2)
-            v.y = 0;
-        v.w = i;
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint32_t key(const Source &s, uint32_t i)
+    {
+        if (LEVEL1 && s.hashes)
+            return s.hashes[i];
+        uint4 v;
+        return load<false>(s, i, v);
     }
-    // the hash is recomputed from the record at both levels (a dozen VALU ops): reading the stored
-    // hash would add 4 B to the 32 B this kernel moves per read. Only the level-1 HISTOGRAM reads
-    // the hash array (4 B instead of the 16-B record).
-    const uint32_t rec[3] = {v.x, v.y, v.z};
-    return fqd_hash_record(rec, kw, len);
-}
+};
 
 template <bool LEVEL1>
-__global__ __launch_bounds__(PT_THREADS) void part_hist_kernel(const uint32_t *__restrict__ hashes,
-                                                               const uint4 *__restrict__ in,
-                                                               const uint32_t *__restrict__ seg_start,
-                                                               const uint32_t *__restrict__ tile_start, uint32_t n_seg,
-                                                               uint32_t shift, uint32_t n_bins, uint32_t kw,
-                                                               uint32_t len, uint32_t *__restrict__ hist)
+__global__ __launch_bounds__(fqd_partition::THREADS) void part_hist_kernel(RecordPolicy::Source src,
+                                                                           const uint32_t *__restrict__ seg_start,
+                                                                           const uint32_t *__restrict__ tile_start,
+                                                                           uint32_t n_seg, uint32_t shift,
+                                                                           uint32_t n_bins, uint32_t *__restrict__ hist)
 {
-    __shared__ uint32_t s_hist[PT_MAX_BINS];
-    uint32_t seg, lo, hi;
-    if (!tile_of_block(seg_start, tile_start, n_seg, seg, lo, hi))
-        return;
-    for (uint32_t b = threadIdx.x; b < n_bins; b += PT_THREADS)
-        s_hist[b] = 0;
-    uint32_t h[PT_EPT];
-#pragma unroll
-    for (uint32_t e = 0; e < PT_EPT; e++) {   // all loads in flight before the first LDS atomic
-        const uint32_t i = lo + e * PT_THREADS + threadIdx.x;
-        h[e] = 0;
-        if (i < hi) {
-            if (LEVEL1 && hashes) {      // no hash array (reads imported from other ranks): recompute
-                h[e] = hashes[i];
-            } else {
-                uint4 v;
-                h[e] = load_item<false>(hashes, in, i, kw, len, v);
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t e = 0; e < PT_EPT; e++)
-        if (lo + e * PT_THREADS + threadIdx.x < hi)
-            atomicAdd(&s_hist[(h[e] >> shift) & (n_bins - 1)], 1u);
-    __syncthreads();
-    if (LEVEL1) {
-        // level 1 has ONE segment: thousands of tiles would hammer the same 2^B1 counters, so
-        // each tile stores its counts in a (bin x tile) matrix; one scan of the matrix in
-        // bin-major order then IS every (tile, bin)'s output position -- no atomics, and the
-        // level-1 placement is deterministic
-        const uint32_t n_tiles = tile_start[n_seg];
-        for (uint32_t b = threadIdx.x; b < n_bins; b += PT_THREADS)
-            hist[(size_t)b * n_tiles + blockIdx.x] = s_hist[b];
-    } else {
-        for (uint32_t b = threadIdx.x; b < n_bins; b += PT_THREADS)
-            if (s_hist[b])
-                atomicAdd(&hist[seg * n_bins + b], s_hist[b]);
-    }
+    fqd_partition::hist_body<RecordPolicy, LEVEL1>(src, seg_start, tile_start, n_seg, shift, n_bins, hist);
 }
 
-// The tile is counting-sorted by bin in LDS before it leaves: every bin's share of the tile
-// goes out as ONE contiguous run of 16-byte stores (a lone 16-byte store costs a whole
-// 64-byte HBM burst), and the global cursor sees one atomic per (tile, bin).
 template <bool LEVEL1>
-__global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const uint32_t *__restrict__ hashes,
-                                                                  const uint4 *__restrict__ in,
-                                                                  const uint32_t *__restrict__ seg_start,
-                                                                  const uint32_t *__restrict__ tile_start,
-                                                                  uint32_t n_seg, uint32_t shift, uint32_t n_bins,
-                                                                  uint32_t kw, uint32_t len,
-                                                                  uint32_t *__restrict__ cursor,
-                                                                  uint4 *__restrict__ out)
+__global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter_kernel(RecordPolicy::Source src,
+                                                                              const uint32_t *__restrict__ seg_start,
+                                                                              const uint32_t *__restrict__ tile_start,
+                                                                              uint32_t n_seg, uint32_t shift,
+                                                                              uint32_t n_bins,
+                                                                              uint32_t *__restrict__ cursor,
+                                                                              uint4 *__restrict__ out)
 {
-    __shared__ uint32_t s_hist[PT_MAX_BINS];   // tile count per bin
-    __shared__ uint32_t s_off[PT_MAX_BINS];    // first tile-local position of the bin
-    __shared__ uint32_t s_base[PT_MAX_BINS];   // global position of the bin's run, minus s_off
-    __shared__ uint32_t s_wave[PT_THREADS / 64];
-    __shared__ uint4 s_stage[PT_TILE];
-    __shared__ uint16_t s_stage_bin[PT_TILE];
-    uint32_t seg, lo, hi;
-    if (!tile_of_block(seg_start, tile_start, n_seg, seg, lo, hi))
-        return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t b = tid; b < n_bins; b += PT_THREADS)
-        s_hist[b] = 0;
-    uint4 v[PT_EPT];
-    uint32_t h[PT_EPT], bin[PT_EPT], rank[PT_EPT];
-#pragma unroll
-    for (uint32_t e = 0; e < PT_EPT; e++) {
-        const uint32_t i = lo + e * PT_THREADS + tid;
-        h[e] = 0;
-        if (i < hi)
-            h[e] = load_item<LEVEL1>(hashes, in, i, kw, len, v[e]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t e = 0; e < PT_EPT; e++) {
-        bin[e] = 0xFFFFFFFFu;
-        if (lo + e * PT_THREADS + tid < hi) {
-            bin[e] = (h[e] >> shift) & (n_bins - 1);
-            rank[e] = atomicAdd(&s_hist[bin[e]], 1u);   // position inside the tile's share of the bin
-        }
-    }
-    __syncthreads();
-    // exclusive scan of the bin counts (each thread owns bpt consecutive bins) + global bases
-    const uint32_t bpt = (n_bins + PT_THREADS - 1) / PT_THREADS;
-    uint32_t mine = 0;
-    for (uint32_t k = 0; k < bpt; k++) {
-        const uint32_t b = tid * bpt + k;
-        mine += b < n_bins ? s_hist[b] : 0u;
-    }
-    uint32_t incl = mine;
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o);
-        if ((int)lane >= o)
-            incl += up;
-    }
-    if (lane == 63)
-        s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - mine;
-    for (uint32_t wv = 0; wv < wave; wv++)
-        run += s_wave[wv];
-    for (uint32_t k = 0; k < bpt; k++) {
-        const uint32_t b = tid * bpt + k;
-        if (b < n_bins) {
-            const uint32_t c = s_hist[b];
-            s_off[b] = run;
-            uint32_t g;
-            if (LEVEL1)   // cursor = inclusive scan of the (bin x tile) count matrix
-                g = cursor[(size_t)b * tile_start[n_seg] + blockIdx.x] - c;
-            else          // ONE atomic per (tile, bin)
-                g = c ? atomicAdd(&cursor[seg * n_bins + b], c) : 0u;
-            s_base[b] = g - run;
-            run += c;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t e = 0; e < PT_EPT; e++)
-        if (bin[e] != 0xFFFFFFFFu) {
-            const uint32_t p = s_off[bin[e]] + rank[e];
-            s_stage[p] = v[e];
-            s_stage_bin[p] = (uint16_t)bin[e];
-        }
-    __syncthreads();
-    const uint32_t count = hi - lo;
-#pragma unroll
-    for (uint32_t e = 0; e < PT_EPT; e++) {
-        const uint32_t p = e * PT_THREADS + tid;
-        if (p < count)
-            out[s_base[s_stage_bin[p]] + p] = s_stage[p];   // consecutive p of one bin: consecutive addresses
-    }
+    fqd_partition::scatter_body<RecordPolicy, LEVEL1>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out);
 }
 
-// tile_start[] for segments given by seg_start[0..n_seg] (single block; n_seg <= 256)
 __global__ void tile_starts_kernel(const uint32_t *__restrict__ seg_start, uint32_t n_seg,
                                    uint32_t *__restrict__ tile_start)
 {
-    __shared__ uint32_t s[257];
-    const uint32_t t = threadIdx.x;
-    uint32_t tiles = 0;
-    if (t < n_seg)
-        tiles = (seg_start[t + 1] - seg_start[t] + PT_TILE - 1) / PT_TILE;
-    s[t] = tiles;
-    __syncthreads();
-    if (t == 0) {
-        uint32_t acc = 0;
-        for (uint32_t i = 0; i < n_seg; i++) {
-            const uint32_t c = s[i];
-            s[i] = acc;
-            acc += c;
-        }
-        s[n_seg] = acc;
-    }
-    __syncthreads();
-    if (t <= n_seg)
-        tile_start[t] = s[t];
-    if (t == 0 && n_seg < 256)
-        tile_start[n_seg] = s[n_seg];
+    fqd_partition::tile_starts_body(seg_start, n_seg, tile_start);
 }
 
 __device__ __forceinline__ uint32_t rec_tag(const uint4 &v)
@@ -404,27 +251,16 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(
     }
 }
 
-// level 1: part p starts where the scan of the (bin x tile) matrix stood before row p
 __global__ void matrix_starts_kernel(const uint32_t *__restrict__ matrix_incl, uint32_t n_bins, uint32_t n_tiles,
                                      uint32_t *__restrict__ start)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > n_bins)
-        return;
-    start[b] = b ? matrix_incl[(size_t)b * n_tiles - 1] : 0u;
+    fqd_partition::matrix_starts_body(matrix_incl, n_bins, n_tiles, start);
 }
 
-// bucket_start[b] = number of reads in buckets < b, from the inclusive scan of the histogram
 __global__ void bucket_starts_kernel(const uint32_t *__restrict__ hist_incl, uint32_t n_buckets,
                                      uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ cursor)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > n_buckets)
-        return;
-    const uint32_t v = b ? hist_incl[b - 1] : 0u;
-    bucket_start[b] = v;
-    if (b < n_buckets)
-        cursor[b] = v;
+    fqd_partition::bucket_starts_body(hist_incl, n_buckets, bucket_start, cursor);
 }
 
 }  // namespace
@@ -433,7 +269,7 @@ namespace fqd {
 
 hipError_t launch_tile_starts(const uint32_t *seg_start, uint32_t n_seg, uint32_t *tile_start, hipStream_t st)
 {
-    tile_starts_kernel<<<1, 257, 0, st>>>(seg_start, n_seg, tile_start);
+    tile_starts_kernel<<<1, 256, 0, st>>>(seg_start, n_seg, tile_start);
     return hipGetLastError();
 }
 
@@ -442,15 +278,15 @@ hipError_t launch_part_hist(bool level1, const uint32_t *hashes, const uint32_t 
                             const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                             uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *hist, hipStream_t st)
 {
-    if (n_bins > PT_MAX_BINS)
+    if (n_bins > fqd_partition::MAX_BINS)
         return hipErrorInvalidValue;
-    const uint4 *in4 = reinterpret_cast<const uint4 *>(in);
+    const RecordPolicy::Source src{hashes, reinterpret_cast<const uint4 *>(in), kw, len};
     if (level1)
-        part_hist_kernel<true><<<max_tiles, PT_THREADS, 0, st>>>(hashes, in4, seg_start, tile_start, n_seg, shift,
-                                                                 n_bins, kw, len, hist);
+        part_hist_kernel<true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, shift,
+                                                                             n_bins, hist);
     else
-        part_hist_kernel<false><<<max_tiles, PT_THREADS, 0, st>>>(hashes, in4, seg_start, tile_start, n_seg, shift,
-                                                                  n_bins, kw, len, hist);
+        part_hist_kernel<false><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, shift,
+                                                                              n_bins, hist);
     return hipGetLastError();
 }
 
@@ -459,20 +295,20 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
                                hipStream_t st)
 {
-    if (n_bins > PT_MAX_BINS)
+    if (n_bins > fqd_partition::MAX_BINS)
         return hipErrorInvalidValue;
-    const uint4 *in4 = reinterpret_cast<const uint4 *>(in);
+    const RecordPolicy::Source src{hashes, reinterpret_cast<const uint4 *>(in), kw, len};
     uint4 *out4 = reinterpret_cast<uint4 *>(out);
     if (level1)
-        part_scatter_kernel<true><<<max_tiles, PT_THREADS, 0, st>>>(hashes, in4, seg_start, tile_start, n_seg, shift,
-                                                                    n_bins, kw, len, cursor, out4);
+        part_scatter_kernel<true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg,
+                                                                                shift, n_bins, cursor, out4);
     else
-        part_scatter_kernel<false><<<max_tiles, PT_THREADS, 0, st>>>(hashes, in4, seg_start, tile_start, n_seg, shift,
-                                                                     n_bins, kw, len, cursor, out4);
+        part_scatter_kernel<false><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg,
+                                                                                 shift, n_bins, cursor, out4);
     return hipGetLastError();
 }
 
-uint32_t part_tile_size() { return PT_TILE; }
+uint32_t part_tile_size() { return fqd_partition::TILE; }
 
 hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                 hipStream_t st)

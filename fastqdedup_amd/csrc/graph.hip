@@ -274,7 +274,8 @@ __global__ void directional_edges_kernel(const uint32_t *__restrict__ edges, uin
 // Pass 2 (after every union of pass 1): each count-1 key reports to the root of its set.
 __global__ void directional_roots_kernel(const uint32_t *__restrict__ edges, uint64_t E,
                                          const uint32_t *__restrict__ ucounts, const uint32_t *__restrict__ urecs,
-                                         const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t *parent1,
+                                         const uint32_t *__restrict__ ulens, KeyShape sh,
+                                         const uint32_t *__restrict__ parent1,
                                          const uint8_t *__restrict__ taint, uint8_t *root_taint, uint32_t *best)
 {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -288,7 +289,13 @@ __global__ void directional_roots_kernel(const uint32_t *__restrict__ edges, uin
         const uint32_t x = ends[k];
         if (ucounts[x] != 1)
             continue;
-        const uint32_t r = uf_find(parent1, x);
+        // every union happened in pass 1 (an earlier launch): a plain read-only walk to the root,
+        // no path halving (those are device-scope atomics)
+        uint32_t r = x, pr = parent1[r];
+        while (pr != r) {
+            r = pr;
+            pr = parent1[r];
+        }
         if (taint[x])
             root_taint[r] = 1;
         if (r != x)

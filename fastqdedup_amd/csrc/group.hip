@@ -13,215 +13,72 @@
 // What the sort gave for free -- equal hashes adjacent -- costs lambda/2 LDS hash compares per
 // key here (lambda = keys per bucket), cheap next to a fourth pass over HBM.
 #include "fqd_internal.h"
+#include "partition.cuh"
 
 namespace {
 
 constexpr uint32_t GP_THREADS = 256;
-constexpr uint32_t GP_EPT = 8;
-constexpr uint32_t GP_TILE = GP_THREADS * GP_EPT;
-constexpr uint32_t GP_MAX_BINS = 1024;
 constexpr uint32_t GP_SLICE = 512;      // hashes of one bucket held in LDS per wave
 constexpr uint32_t GP_ECAP = 1024;      // edges buffered per block of the verify kernel
 
-// Tiles never straddle a segment (level 1: one segment = everything; level 2: the level-1 parts).
-__device__ __forceinline__ bool gp_tile_of_block(const uint32_t *__restrict__ seg_start,
-                                                 const uint32_t *__restrict__ tile_start, uint32_t n_seg,
-                                                 uint32_t &seg, uint32_t &lo, uint32_t &hi)
-{
-    const uint32_t t = blockIdx.x;
-    if (t >= tile_start[n_seg])
-        return false;
-    uint32_t a = 0, b = n_seg;
-    while (b - a > 1) {
-        const uint32_t m = (a + b) >> 1;
-        if (tile_start[m] <= t)
-            a = m;
-        else
-            b = m;
+// What a (segment hash, uid) item looks like to the partition (partition.cuh): LEVEL 1 reads the
+// hash array (uid = position); level 2 reads level-1's items. The key is the hash.
+struct PairPolicy {
+    using Item = uint2;
+    struct Source {
+        const uint32_t *hashes;   // level 1
+        const uint2 *in;          // level 2
+    };
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint32_t load(const Source &s, uint32_t i, uint2 &v)
+    {
+        v = LEVEL1 ? make_uint2(s.hashes[i], i) : s.in[i];
+        return v.x;
     }
-    seg = a;
-    lo = seg_start[a] + (t - tile_start[a]) * GP_TILE;
-    hi = min(lo + GP_TILE, seg_start[a + 1]);
-    return true;
-}
-
-// LEVEL 1 reads the hash array (uid = position); LEVEL 2 reads level-1's (hash, uid) items.
-template <bool LEVEL1>
-__device__ __forceinline__ uint2 gp_load(const uint32_t *__restrict__ hashes, const uint2 *__restrict__ in, uint32_t i)
-{
-    if (LEVEL1)
-        return make_uint2(hashes[i], i);
-    return in[i];
-}
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint32_t key(const Source &s, uint32_t i)
+    {
+        return LEVEL1 ? s.hashes[i] : s.in[i].x;
+    }
+};
 
 template <bool LEVEL1>
-__global__ __launch_bounds__(GP_THREADS) void gp_hist_kernel(const uint32_t *__restrict__ hashes,
-                                                             const uint2 *__restrict__ in,
-                                                             const uint32_t *__restrict__ seg_start,
-                                                             const uint32_t *__restrict__ tile_start, uint32_t n_seg,
-                                                             uint32_t shift, uint32_t n_bins,
-                                                             uint32_t *__restrict__ hist)
+__global__ __launch_bounds__(fqd_partition::THREADS) void gp_hist_kernel(PairPolicy::Source src,
+                                                                         const uint32_t *__restrict__ seg_start,
+                                                                         const uint32_t *__restrict__ tile_start,
+                                                                         uint32_t n_seg, uint32_t shift, uint32_t n_bins,
+                                                                         uint32_t *__restrict__ hist)
 {
-    __shared__ uint32_t s_hist[GP_MAX_BINS];
-    uint32_t seg, lo, hi;
-    if (!gp_tile_of_block(seg_start, tile_start, n_seg, seg, lo, hi))
-        return;
-    for (uint32_t b = threadIdx.x; b < n_bins; b += GP_THREADS)
-        s_hist[b] = 0;
-    uint32_t h[GP_EPT];
-#pragma unroll
-    for (uint32_t e = 0; e < GP_EPT; e++) {
-        const uint32_t i = lo + e * GP_THREADS + threadIdx.x;
-        h[e] = i < hi ? gp_load<LEVEL1>(hashes, in, i).x : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t e = 0; e < GP_EPT; e++)
-        if (lo + e * GP_THREADS + threadIdx.x < hi)
-            atomicAdd(&s_hist[(h[e] >> shift) & (n_bins - 1)], 1u);
-    __syncthreads();
-    if (LEVEL1) {
-        // (bin x tile) count matrix: its scan in bin-major order is every (tile, bin)'s position
-        const uint32_t n_tiles = tile_start[n_seg];
-        for (uint32_t b = threadIdx.x; b < n_bins; b += GP_THREADS)
-            hist[(size_t)b * n_tiles + blockIdx.x] = s_hist[b];
-    } else {
-        for (uint32_t b = threadIdx.x; b < n_bins; b += GP_THREADS)
-            if (s_hist[b])
-                atomicAdd(&hist[seg * n_bins + b], s_hist[b]);
-    }
+    fqd_partition::hist_body<PairPolicy, LEVEL1>(src, seg_start, tile_start, n_seg, shift, n_bins, hist);
 }
 
-// The tile is counting-sorted by bin in LDS before it leaves: every bin's share goes out as one
-// contiguous run of 8-byte stores; the global cursor sees one atomic per (tile, bin).
 template <bool LEVEL1>
-__global__ __launch_bounds__(GP_THREADS) void gp_scatter_kernel(const uint32_t *__restrict__ hashes,
-                                                                const uint2 *__restrict__ in,
-                                                                const uint32_t *__restrict__ seg_start,
-                                                                const uint32_t *__restrict__ tile_start,
-                                                                uint32_t n_seg, uint32_t shift, uint32_t n_bins,
-                                                                uint32_t *__restrict__ cursor,
-                                                                uint2 *__restrict__ out)
+__global__ __launch_bounds__(fqd_partition::THREADS) void gp_scatter_kernel(PairPolicy::Source src,
+                                                                            const uint32_t *__restrict__ seg_start,
+                                                                            const uint32_t *__restrict__ tile_start,
+                                                                            uint32_t n_seg, uint32_t shift,
+                                                                            uint32_t n_bins, uint32_t *__restrict__ cursor,
+                                                                            uint2 *__restrict__ out)
 {
-    __shared__ uint32_t s_hist[GP_MAX_BINS], s_off[GP_MAX_BINS], s_base[GP_MAX_BINS];
-    __shared__ uint32_t s_wave[GP_THREADS / 64];
-    __shared__ uint2 s_stage[GP_TILE];
-    __shared__ uint16_t s_stage_bin[GP_TILE];
-    uint32_t seg, lo, hi;
-    if (!gp_tile_of_block(seg_start, tile_start, n_seg, seg, lo, hi))
-        return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t b = tid; b < n_bins; b += GP_THREADS)
-        s_hist[b] = 0;
-    uint2 v[GP_EPT];
-    uint32_t bin[GP_EPT], rank[GP_EPT];
-#pragma unroll
-    for (uint32_t e = 0; e < GP_EPT; e++) {
-        const uint32_t i = lo + e * GP_THREADS + tid;
-        v[e] = make_uint2(0, 0);
-        if (i < hi)
-            v[e] = gp_load<LEVEL1>(hashes, in, i);
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t e = 0; e < GP_EPT; e++) {
-        bin[e] = 0xFFFFFFFFu;
-        if (lo + e * GP_THREADS + tid < hi) {
-            bin[e] = (v[e].x >> shift) & (n_bins - 1);
-            rank[e] = atomicAdd(&s_hist[bin[e]], 1u);
-        }
-    }
-    __syncthreads();
-    const uint32_t bpt = (n_bins + GP_THREADS - 1) / GP_THREADS;
-    uint32_t mine = 0;
-    for (uint32_t k = 0; k < bpt; k++) {
-        const uint32_t b = tid * bpt + k;
-        mine += b < n_bins ? s_hist[b] : 0u;
-    }
-    uint32_t incl = mine;
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o);
-        if ((int)lane >= o)
-            incl += up;
-    }
-    if (lane == 63)
-        s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - mine;
-    for (uint32_t wv = 0; wv < wave; wv++)
-        run += s_wave[wv];
-    for (uint32_t k = 0; k < bpt; k++) {
-        const uint32_t b = tid * bpt + k;
-        if (b < n_bins) {
-            const uint32_t c = s_hist[b];
-            s_off[b] = run;
-            uint32_t g;
-            if (LEVEL1)
-                g = cursor[(size_t)b * tile_start[n_seg] + blockIdx.x] - c;   // inclusive scan of the matrix
-            else
-                g = c ? atomicAdd(&cursor[seg * n_bins + b], c) : 0u;
-            s_base[b] = g - run;
-            run += c;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t e = 0; e < GP_EPT; e++)
-        if (bin[e] != 0xFFFFFFFFu) {
-            const uint32_t p = s_off[bin[e]] + rank[e];
-            s_stage[p] = v[e];
-            s_stage_bin[p] = (uint16_t)bin[e];
-        }
-    __syncthreads();
-    const uint32_t count = hi - lo;
-#pragma unroll
-    for (uint32_t e = 0; e < GP_EPT; e++) {
-        const uint32_t p = e * GP_THREADS + tid;
-        if (p < count)
-            out[s_base[s_stage_bin[p]] + p] = s_stage[p];
-    }
+    fqd_partition::scatter_body<PairPolicy, LEVEL1>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out);
 }
 
 __global__ void gp_tile_starts_kernel(const uint32_t *__restrict__ seg_start, uint32_t n_seg,
                                       uint32_t *__restrict__ tile_start)
 {
-    // single block, n_seg <= 1024
-    __shared__ uint32_t s[GP_MAX_BINS + 1];
-    for (uint32_t t = threadIdx.x; t < n_seg; t += blockDim.x)
-        s[t] = (seg_start[t + 1] - seg_start[t] + GP_TILE - 1) / GP_TILE;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (uint32_t i = 0; i < n_seg; i++) {
-            const uint32_t c = s[i];
-            s[i] = acc;
-            acc += c;
-        }
-        s[n_seg] = acc;
-    }
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t <= n_seg; t += blockDim.x)
-        tile_start[t] = s[t];
+    fqd_partition::tile_starts_body(seg_start, n_seg, tile_start);
 }
 
 __global__ void gp_matrix_starts_kernel(const uint32_t *__restrict__ matrix_incl, uint32_t n_bins, uint32_t n_tiles,
                                         uint32_t *__restrict__ start)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b <= n_bins)
-        start[b] = b ? matrix_incl[(size_t)b * n_tiles - 1] : 0u;
+    fqd_partition::matrix_starts_body(matrix_incl, n_bins, n_tiles, start);
 }
 
 __global__ void gp_bucket_starts_kernel(const uint32_t *__restrict__ hist_incl, uint32_t n_buckets,
                                         uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ cursor)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > n_buckets)
-        return;
-    const uint32_t v = b ? hist_incl[b - 1] : 0u;
-    bucket_start[b] = v;
-    if (b < n_buckets)
-        cursor[b] = v;
+    fqd_partition::bucket_starts_body(hist_incl, n_buckets, bucket_start, cursor);
 }
 
 template <int K>
@@ -531,9 +388,9 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
 
 namespace fqd {
 
-uint32_t group_tile_size() { return GP_TILE; }
+uint32_t group_tile_size() { return fqd_partition::TILE; }
 uint32_t group_cand_lists() { return GP_LISTS; }
-uint32_t group_max_bins() { return GP_MAX_BINS; }
+uint32_t group_max_bins() { return fqd_partition::MAX_BINS; }
 
 hipError_t launch_group_hist(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
                              const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
@@ -541,12 +398,13 @@ hipError_t launch_group_hist(bool level1, const uint32_t *hashes, const uint32_t
 {
     if (!max_tiles)
         return hipSuccess;
+    const PairPolicy::Source src{hashes, reinterpret_cast<const uint2 *>(in)};
     if (level1)
-        gp_hist_kernel<true><<<max_tiles, GP_THREADS, 0, st>>>(hashes, reinterpret_cast<const uint2 *>(in), seg_start,
-                                                               tile_start, n_seg, shift, n_bins, hist);
+        gp_hist_kernel<true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, shift,
+                                                                           n_bins, hist);
     else
-        gp_hist_kernel<false><<<max_tiles, GP_THREADS, 0, st>>>(hashes, reinterpret_cast<const uint2 *>(in), seg_start,
-                                                                tile_start, n_seg, shift, n_bins, hist);
+        gp_hist_kernel<false><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, shift,
+                                                                            n_bins, hist);
     return hipGetLastError();
 }
 
@@ -556,14 +414,14 @@ hipError_t launch_group_scatter(bool level1, const uint32_t *hashes, const uint3
 {
     if (!max_tiles)
         return hipSuccess;
+    const PairPolicy::Source src{hashes, reinterpret_cast<const uint2 *>(in)};
+    uint2 *out2 = reinterpret_cast<uint2 *>(out);
     if (level1)
-        gp_scatter_kernel<true><<<max_tiles, GP_THREADS, 0, st>>>(hashes, reinterpret_cast<const uint2 *>(in),
-                                                                  seg_start, tile_start, n_seg, shift, n_bins, cursor,
-                                                                  reinterpret_cast<uint2 *>(out));
+        gp_scatter_kernel<true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, shift,
+                                                                              n_bins, cursor, out2);
     else
-        gp_scatter_kernel<false><<<max_tiles, GP_THREADS, 0, st>>>(hashes, reinterpret_cast<const uint2 *>(in),
-                                                                   seg_start, tile_start, n_seg, shift, n_bins, cursor,
-                                                                   reinterpret_cast<uint2 *>(out));
+        gp_scatter_kernel<false><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, shift,
+                                                                               n_bins, cursor, out2);
     return hipGetLastError();
 }
 

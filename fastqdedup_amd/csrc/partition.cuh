@@ -1,0 +1,223 @@
+// partition.cuh -- the LDS-aggregated hash partition used twice on the hot path: by the exact-
+// duplicate collapse (16-byte records, collapse_lds.hip) and by the neighbour search ((segment
+// hash, uid) pairs, group.hip). No reference counterpart: it replaces device-wide radix sorts.
+//
+// Items are partitioned by some bits of a 32-bit key in two levels. Each level is a histogram pass
+// and a scatter pass over TILES of 2048 items; tiles never straddle a segment (level 1: one
+// segment = everything; level 2: the parts level 1 made). Bin counts and the ranks inside a bin
+// are LDS atomics, so global memory sees one counter update per (tile, bin) instead of one per
+// item (a scatter with one global atomic per item took 5.3 ms for 50 M reads; this takes ~1 ms).
+// Level 1 has ONE segment -- thousands of tiles would hammer the same few hundred counters -- so
+// its counts go to a (bin x tile) matrix whose scan in bin-major order IS every (tile, bin)'s
+// output position: no atomics, deterministic placement. In the scatter pass the tile is counting-
+// sorted by bin in LDS before it leaves, so every bin's share goes out as ONE contiguous run of
+// stores (a lone 16-byte store costs a whole 64-byte HBM burst).
+//
+// A Policy names the item type and how an item and its key are fetched:
+//   using Item = ...;  struct Source { ... };
+//   template <bool LEVEL1> static __device__ uint32_t key(const Source &, uint32_t i);          // histogram pass
+//   template <bool LEVEL1> static __device__ uint32_t load(const Source &, uint32_t i, Item &); // scatter pass, returns the key
+#pragma once
+#include "fqd_internal.h"
+
+namespace fqd_partition {
+
+constexpr uint32_t THREADS = 256;
+constexpr uint32_t EPT = 8;                  // items per thread
+constexpr uint32_t TILE = THREADS * EPT;     // items per tile
+constexpr uint32_t MAX_BINS = 1024;
+
+// tile_start[s] = first tile of segment s, tile_start[n_seg] = tile count.
+__device__ __forceinline__ bool tile_of_block(const uint32_t *__restrict__ seg_start,
+                                              const uint32_t *__restrict__ tile_start, uint32_t n_seg,
+                                              uint32_t &seg, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t t = blockIdx.x;
+    if (t >= tile_start[n_seg])
+        return false;
+    uint32_t a = 0, b = n_seg;  // last segment with tile_start <= t
+    while (b - a > 1) {
+        const uint32_t m = (a + b) >> 1;
+        if (tile_start[m] <= t)
+            a = m;
+        else
+            b = m;
+    }
+    seg = a;
+    lo = seg_start[a] + (t - tile_start[a]) * TILE;
+    hi = min(lo + TILE, seg_start[a + 1]);
+    return true;
+}
+
+template <class Policy, bool LEVEL1>
+__device__ __forceinline__ void hist_body(const typename Policy::Source &src, const uint32_t *__restrict__ seg_start,
+                                          const uint32_t *__restrict__ tile_start, uint32_t n_seg, uint32_t shift,
+                                          uint32_t n_bins, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t s_hist[MAX_BINS];
+    uint32_t seg, lo, hi;
+    if (!tile_of_block(seg_start, tile_start, n_seg, seg, lo, hi))
+        return;
+    for (uint32_t b = threadIdx.x; b < n_bins; b += THREADS)
+        s_hist[b] = 0;
+    uint32_t h[EPT];
+#pragma unroll
+    for (uint32_t e = 0; e < EPT; e++) {   // all loads in flight before the first LDS atomic
+        const uint32_t i = lo + e * THREADS + threadIdx.x;
+        h[e] = i < hi ? Policy::template key<LEVEL1>(src, i) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < EPT; e++)
+        if (lo + e * THREADS + threadIdx.x < hi)
+            atomicAdd(&s_hist[(h[e] >> shift) & (n_bins - 1)], 1u);
+    __syncthreads();
+    if (LEVEL1) {
+        const uint32_t n_tiles = tile_start[n_seg];
+        for (uint32_t b = threadIdx.x; b < n_bins; b += THREADS)
+            hist[(size_t)b * n_tiles + blockIdx.x] = s_hist[b];
+    } else {
+        for (uint32_t b = threadIdx.x; b < n_bins; b += THREADS)
+            if (s_hist[b])
+                atomicAdd(&hist[seg * n_bins + b], s_hist[b]);
+    }
+}
+
+// LEVEL1: cursor = inclusive scan of the (bin x tile) count matrix. Level 2: cursor[seg * n_bins + b]
+// = next free position of that bucket (one atomic per (tile, bin)).
+template <class Policy, bool LEVEL1>
+__device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
+                                             const uint32_t *__restrict__ seg_start,
+                                             const uint32_t *__restrict__ tile_start, uint32_t n_seg, uint32_t shift,
+                                             uint32_t n_bins, uint32_t *__restrict__ cursor,
+                                             typename Policy::Item *__restrict__ out)
+{
+    using Item = typename Policy::Item;
+    __shared__ uint32_t s_hist[MAX_BINS];   // tile count per bin
+    __shared__ uint32_t s_off[MAX_BINS];    // first tile-local position of the bin
+    __shared__ uint32_t s_base[MAX_BINS];   // global position of the bin's run, minus s_off
+    __shared__ uint32_t s_wave[THREADS / 64];
+    __shared__ Item s_stage[TILE];
+    __shared__ uint16_t s_stage_bin[TILE];
+    uint32_t seg, lo, hi;
+    if (!tile_of_block(seg_start, tile_start, n_seg, seg, lo, hi))
+        return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t b = tid; b < n_bins; b += THREADS)
+        s_hist[b] = 0;
+    Item v[EPT];
+    uint32_t h[EPT], bin[EPT], rank[EPT];
+#pragma unroll
+    for (uint32_t e = 0; e < EPT; e++) {
+        const uint32_t i = lo + e * THREADS + tid;
+        h[e] = 0;
+        if (i < hi)
+            h[e] = Policy::template load<LEVEL1>(src, i, v[e]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < EPT; e++) {
+        bin[e] = 0xFFFFFFFFu;
+        if (lo + e * THREADS + tid < hi) {
+            bin[e] = (h[e] >> shift) & (n_bins - 1);
+            rank[e] = atomicAdd(&s_hist[bin[e]], 1u);   // position inside the tile's share of the bin
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bin counts (each thread owns bpt consecutive bins) + global bases
+    const uint32_t bpt = (n_bins + THREADS - 1) / THREADS;
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < bpt; k++) {
+        const uint32_t b = tid * bpt + k;
+        mine += b < n_bins ? s_hist[b] : 0u;
+    }
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if ((int)lane >= o)
+            incl += up;
+    }
+    if (lane == 63)
+        s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (uint32_t wv = 0; wv < wave; wv++)
+        run += s_wave[wv];
+    for (uint32_t k = 0; k < bpt; k++) {
+        const uint32_t b = tid * bpt + k;
+        if (b < n_bins) {
+            const uint32_t c = s_hist[b];
+            s_off[b] = run;
+            uint32_t g;
+            if (LEVEL1)
+                g = cursor[(size_t)b * tile_start[n_seg] + blockIdx.x] - c;
+            else
+                g = c ? atomicAdd(&cursor[seg * n_bins + b], c) : 0u;
+            s_base[b] = g - run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < EPT; e++)
+        if (bin[e] != 0xFFFFFFFFu) {
+            const uint32_t p = s_off[bin[e]] + rank[e];
+            s_stage[p] = v[e];
+            s_stage_bin[p] = (uint16_t)bin[e];
+        }
+    __syncthreads();
+    const uint32_t count = hi - lo;
+#pragma unroll
+    for (uint32_t e = 0; e < EPT; e++) {
+        const uint32_t p = e * THREADS + tid;
+        if (p < count)
+            out[s_base[s_stage_bin[p]] + p] = s_stage[p];   // consecutive p of one bin: consecutive addresses
+    }
+}
+
+// tile_start[] for the segments seg_start[0..n_seg] (single block; n_seg <= MAX_BINS)
+__device__ __forceinline__ void tile_starts_body(const uint32_t *__restrict__ seg_start, uint32_t n_seg,
+                                                 uint32_t *__restrict__ tile_start)
+{
+    __shared__ uint32_t s[MAX_BINS + 1];
+    for (uint32_t t = threadIdx.x; t < n_seg; t += blockDim.x)
+        s[t] = (seg_start[t + 1] - seg_start[t] + TILE - 1) / TILE;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < n_seg; i++) {
+            const uint32_t c = s[i];
+            s[i] = acc;
+            acc += c;
+        }
+        s[n_seg] = acc;
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t <= n_seg; t += blockDim.x)
+        tile_start[t] = s[t];
+}
+
+// level 1: part p starts where the scan of the (bin x tile) matrix stood before row p
+__device__ __forceinline__ void matrix_starts_body(const uint32_t *__restrict__ matrix_incl, uint32_t n_bins,
+                                                   uint32_t n_tiles, uint32_t *__restrict__ start)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= n_bins)
+        start[b] = b ? matrix_incl[(size_t)b * n_tiles - 1] : 0u;
+}
+
+// bucket_start[b] = items in buckets < b (from the inclusive scan of the level-2 histogram); the
+// level-2 cursors start there
+__device__ __forceinline__ void bucket_starts_body(const uint32_t *__restrict__ hist_incl, uint32_t n_buckets,
+                                                   uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ cursor)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_buckets)
+        return;
+    const uint32_t v = b ? hist_incl[b - 1] : 0u;
+    bucket_start[b] = v;
+    if (b < n_buckets)
+        cursor[b] = v;
+}
+
+}  // namespace fqd_partition
