@@ -615,6 +615,35 @@ def test_collapse_of_received_reads(F, monkeypatch, L, alphabet, path):
     assert got_ctx.find_edges(1, 0, 0, 1) == want_ctx.find_edges(1, 0, 0, 1)
 
 
+def test_fallback_paths_kept_by_sort_and_grouping_by_sort(F, monkeypatch):
+    """Two fallbacks that large jobs never take: the kept-id list by scan + gather + radix sort
+    (id ranges far larger than the table) and the owner grouping by radix sort (more than 256
+    parts). Both must give what the default paths give."""
+    import torch
+    from fastqdedup_amd.synth import synth_keys
+    dev = torch.device("cuda", 0)
+    n, L = 80_000, 32
+    host = synth_keys(n, L, 8, 61, sub_rate=5e-3, n_rate=3e-4).reshape(-1)
+    a = F.cluster_keys(host, key_len=L, context=F.Context(0))
+    monkeypatch.setenv("FQD_KEPT_BY_SORT", "1")
+    b = F.cluster_keys(host, key_len=L, context=F.Context(0))
+    monkeypatch.delenv("FQD_KEPT_BY_SORT")
+    assert np.array_equal(a.kept_read_ids, b.kept_read_ids) and a.n_clusters == b.n_clusters
+
+    ctx = F.Context(0)
+    ctx.pack_keys(torch.from_numpy(host.copy()).to(dev), None, L)
+    stride = ctx.shape().stride_words
+    outs = []
+    for by_sort in (False, True):
+        if by_sort:
+            monkeypatch.setenv("FQD_GROUP_BY_SORT", "1")
+        recs = torch.empty((n, stride), dtype=torch.int32, device=dev)
+        ids = torch.empty(n, dtype=torch.int64, device=dev)
+        counts = ctx.export_packed_by_segment(7, 2, 0, 5, None, recs, None, ids, None)
+        outs.append((recs.cpu(), ids.cpu(), [int(c) for c in counts]))
+    assert outs[0][2] == outs[1][2] and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_edge_labels_and_kept_except(F, oracle):
     """fqd_edge_labels (components of a caller's edge list) and fqd_list_kept_except (verdicts
     computed elsewhere) against the plain single-context path."""
