@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfqdedup_hip.so")
-SOURCES = ["api.hip", "prims.hip", "pack.hip", "collapse.hip", "collapse_lds.hip", "edges.hip", "group.hip", "edit.hip", "exchange.hip", "graph.hip", "quality.hip", "synth.hip"]
+SOURCES = ["api.hip", "api_search.hip", "api_graph.hip", "api_exchange.hip", "prims.hip", "pack.hip", "collapse.hip", "collapse_lds.hip", "edges.hip", "group.hip", "edit.hip", "exchange.hip", "graph.hip", "quality.hip", "synth.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -23,7 +23,7 @@ def _stale(target: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    headers = [os.path.join(CSRC, "fqd_internal.h"), os.path.join(CSRC, "partition.cuh"),
+    headers = [os.path.join(CSRC, "fqd_internal.h"), os.path.join(CSRC, "partition.cuh"), os.path.join(CSRC, "api_ctx.h"),
                os.path.join(os.path.dirname(HERE), "include", "fqdedup_hip.h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)

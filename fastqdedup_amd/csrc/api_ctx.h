@@ -1,0 +1,326 @@
+// api_ctx.h -- PRIVATE to the api_*.hip files: the context behind the C ABI of
+// libfqdedup_hip.so (include/fqdedup_hip.h), its device buffers, and the small helpers every
+// entry point uses (error strings, host<->device staging, counter read-backs, HIP-event timing).
+// No kernels here.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fqdedup_hip.h"
+#include "fqd_internal.h"
+
+namespace {
+
+std::string g_global_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool borrowed = false;   // p belongs to the caller (FQD_DEVICE_BORROW): never freed, never reused
+    void *own_p = nullptr;   // the context's own allocation, parked while p is borrowed (no
+    size_t own_cap = 0;      // hipFree/hipMalloc per job: a job that borrows every time would churn)
+    void unborrow()
+    {
+        if (borrowed) {
+            p = own_p;
+            cap = own_cap;
+            own_p = nullptr;
+            own_cap = 0;
+            borrowed = false;
+        }
+    }
+    hipError_t reserve(size_t bytes)
+    {
+        unborrow();
+        if (bytes <= cap)
+            return hipSuccess;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = ((bytes + (bytes >> 4)) + 4095) & ~(size_t)4095;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess)
+            cap = want;
+        return e;
+    }
+    void release()
+    {
+        unborrow();
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    // Use the caller's device buffer in place (no copy); the next reserve() lets go of it.
+    void borrow(const void *ptr, size_t bytes)
+    {
+        if (!borrowed) {
+            own_p = p;
+            own_cap = cap;
+        }
+        p = const_cast<void *>(ptr);
+        cap = bytes;
+        borrowed = true;
+    }
+    template <typename T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+enum Stage { ST_EMPTY = 0, ST_PACKED = 1, ST_UNIQUE = 2, ST_EDGES = 3, ST_LABELS = 4, ST_KEPT = 5 };
+
+// small device-side words read back by the host
+enum Ctr { C_BAD = 0, C_COLLISIONS = 1, C_CHANGED = 2, C_MINLEN = 3, C_MAXLEN = 4, C_N32 = 8 };
+enum Ctr64 { C64_EDGES = 0, C64_ROOTS = 1, C64_SUM = 2, C64_STATS = 3, C64_CANDS = 4, C64_CAND_NEED = 5, C64_N = 8 };
+
+}  // namespace
+
+struct fqd_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::string err;
+    int stage = ST_EMPTY;
+
+    bool forced = false;
+    uint8_t forced_present[128];
+    uint32_t forced_max_len = 0;
+    int forced_ragged = 0;
+
+    fqd_shape shape{};
+    KeyShape ks{};
+    DevBuf d_lut, d_ctr32, d_ctr64, d_present, d_stats;
+
+    // stage 1
+    uint64_t n = 0;
+    DevBuf in_bytes, in_offsets, recs, lens, hashes, owners;
+    bool hashes_valid = false;     // `hashes` holds the record hashes of the packed reads (lazy after an import)
+    fqd::OwnerRule owner_rule;     // fqd_set_owner_rule: fqd_pack_keys also writes each read's owner rank
+    fqd::OwnerRule owners_done;    // the rule `owners` was filled with (parts == 0: not filled)
+    // stage 2
+    uint64_t U = 0, n_counted = 0;
+    int id_bits = 64;  // bits needed to sort first-holder ids (read ids 0..n-1 need few)
+    uint64_t id_limit = ~0ull;  // every first-holder id is below this (~0: unknown)
+    bool collapsed = false;  // unique table came from fqd_collapse (keys are pairwise distinct)
+    bool first_distinct = true;  // first-holder ids are pairwise distinct (false: imported without ids)
+    DevBuf seg_tab;   // fqd_collapse_received: id bases and row offsets of the senders' segments
+    DevBuf in_weights, in_read_ids, hs_sorted, ids, ids_sorted, flags, run_idx, run_start, run_weight, live_flag,
+        live_idx, collision_runs;
+    DevBuf urecs, ulens, ucounts, ufirst;
+    DevBuf ld_small, ld_part2, ld_matrix, ld_matrix_incl;
+    DevBuf ld_hist, ld_hist_incl, ld_start, ld_cursor, ld_part, ld_tmp_rec, ld_tmp_count, ld_tmp_first, ld_unique,
+        ld_unique_incl;
+    int collapse_path = 0;  // 1: LDS bucket dedupe, 2: sort + verify (last fqd_collapse)
+    // stage 3
+    uint64_t E = 0, edge_cap = 0;
+    DevBuf seg_hashes, sorted_hash, sorted_uid, uid_iota, edges, sel_hash, sel_uid;
+    DevBuf gp_a, gp_b, gp_small, gp_cands;   // grouped search pass: items after level 1 / level 2, small tables, candidate pairs
+    uint64_t gp_cand_cap = 0;
+    DevBuf q_table, q_pass, q_means, q_bytes, q_offsets;
+    DevBuf len_present, ed_hash, ed_payload, ed_hash_sorted, ed_payload_sorted, ed_cands, ed_cands_sorted, d_alphabet;
+    fqd::PairStats last_stats{};
+    bool stats_pending = false;   // d_stats holds the slots of the last search, not yet summed into last_stats
+    // stage 4
+    uint64_t n_clusters = 0, roots_seen = 0;
+    DevBuf labels, hook_slots;
+    bool labels_flat = false;
+    // stage 5
+    uint64_t n_kept = 0, n_listed = 0;          // kept keys; kept keys whose first holder is in the id window
+    uint64_t id_lo = 0, id_hi = ~0ull;
+    DevBuf best, state, blocked, taint, root_taint, kept, kept_u32, kept_scan, kept_ids, kept_ids_sorted;
+    // scratch
+    DevBuf tmp, stage_a, stage_b, stage_c, stage_d;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+    // per-kernel timing (fqd_kernel_times): a pool of event pairs, drained at every stage end
+    static constexpr int KPOOL = 96;
+    hipEvent_t kev[2 * KPOOL] = {nullptr};
+    int kslot[KPOOL] = {0};
+    int kused = 0;
+    float kms[FQD_K_COUNT] = {0};
+    uint32_t klaunches[FQD_K_COUNT] = {0};
+    float ms[FQD_T_COUNT] = {0};
+    uint32_t launches[FQD_T_COUNT] = {0};
+};
+
+namespace {
+
+int fail(fqd_ctx *c, int code, const std::string &msg)
+{
+    if (c)
+        c->err = msg;
+    return code;
+}
+
+int hip_fail(fqd_ctx *c, hipError_t e, const char *what)
+{
+    // clear the sticky error so later calls report their own
+    (void)hipGetLastError();
+    return fail(c, e == hipErrorOutOfMemory ? FQD_E_NOMEM : FQD_E_DEVICE,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(c, call)                         \
+    do {                                         \
+        hipError_t e_ = (call);                  \
+        if (e_ != hipSuccess)                    \
+            return hip_fail((c), e_, #call);     \
+    } while (0)
+
+#define FQD_TRY(call)        \
+    do {                     \
+        int rc_ = (call);    \
+        if (rc_ != FQD_OK)   \
+            return rc_;      \
+    } while (0)
+
+int bind(fqd_ctx *c)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    return FQD_OK;
+}
+
+// Returns a device pointer for a caller buffer: the buffer itself (FQD_DEVICE)
+// or a staged copy (FQD_HOST).
+template <typename T>
+int to_device(fqd_ctx *c, const T *src, size_t count, int mem, DevBuf &staging, const T **out)
+{
+    if (!src) {
+        *out = nullptr;
+        return FQD_OK;
+    }
+    if (mem == FQD_DEVICE) {
+        *out = src;
+        return FQD_OK;
+    }
+    HIP_TRY(c, staging.reserve(count * sizeof(T) + 16));
+    if (count)
+        HIP_TRY(c, hipMemcpyAsync(staging.p, src, count * sizeof(T), hipMemcpyHostToDevice, c->st));
+    *out = staging.as<T>();
+    return FQD_OK;
+}
+
+template <typename T>
+int from_device(fqd_ctx *c, T *dst, const void *src, size_t count, int mem)
+{
+    if (!dst || !count)
+        return FQD_OK;
+    HIP_TRY(c, hipMemcpyAsync(dst, src, count * sizeof(T),
+                              mem == FQD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    return FQD_OK;
+}
+
+int read_ctr32(fqd_ctx *c, int idx, uint32_t *v)
+{
+    HIP_TRY(c, hipMemcpyAsync(v, c->d_ctr32.as<uint32_t>() + idx, 4, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    return FQD_OK;
+}
+
+int read_ctr64(fqd_ctx *c, int idx, unsigned long long *v, int count = 1)
+{
+    HIP_TRY(c, hipMemcpyAsync(v, c->d_ctr64.as<unsigned long long>() + idx, 8 * (size_t)count,
+                              hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    return FQD_OK;
+}
+
+int zero_ctr32(fqd_ctx *c, int idx, int count = 1)
+{
+    HIP_TRY(c, hipMemsetAsync(c->d_ctr32.as<uint32_t>() + idx, 0, 4 * (size_t)count, c->st));
+    return FQD_OK;
+}
+
+int zero_ctr64(fqd_ctx *c, int idx, int count = 1)
+{
+    HIP_TRY(c, hipMemsetAsync(c->d_ctr64.as<unsigned long long>() + idx, 0, 8 * (size_t)count, c->st));
+    return FQD_OK;
+}
+
+void ktime_collect(fqd_ctx *c);
+
+struct StageTimer {
+    fqd_ctx *c;
+    int slot;
+    StageTimer(fqd_ctx *ctx, int s) : c(ctx), slot(s) { (void)hipEventRecord(c->ev0, c->st); }
+    void stop()
+    {
+        (void)hipEventRecord(c->ev1, c->st);
+        (void)hipEventSynchronize(c->ev1);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess)
+            c->ms[slot] = ms;
+        c->launches[slot] = 1;
+        ktime_collect(c);
+    }
+};
+
+int ktime_begin(fqd_ctx *c, int slot)
+{
+    if (c->kused >= fqd_ctx::KPOOL)
+        return -1;
+    const int i = c->kused++;
+    c->kslot[i] = slot;
+    (void)hipEventRecord(c->kev[2 * i], c->st);
+    return i;
+}
+
+void ktime_end(fqd_ctx *c, int i)
+{
+    if (i >= 0)
+        (void)hipEventRecord(c->kev[2 * i + 1], c->st);
+}
+
+// after the stage's final synchronisation: fold the recorded pairs into the per-kernel sums
+void ktime_collect(fqd_ctx *c)
+{
+    if (!c->kused)
+        return;
+    (void)hipStreamSynchronize(c->st);
+    for (int i = 0; i < c->kused; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->kev[2 * i], c->kev[2 * i + 1]) == hipSuccess) {
+            c->kms[c->kslot[i]] += ms;
+            c->klaunches[c->kslot[i]] += 1;
+        }
+    }
+    c->kused = 0;
+}
+
+// time one kernel launch with HIP events on the context's stream
+#define KTIME(c, slot, call)                 \
+    do {                                     \
+        const int kt_ = ktime_begin((c), (slot)); \
+        HIP_TRY((c), call);                  \
+        ktime_end((c), kt_);                 \
+    } while (0)
+
+int sort_u32_pairs(fqd_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n,
+                   int bits = 32)
+{
+    if (!n)
+        return FQD_OK;
+    const size_t need = fqd::sort_pairs_u32_u32_temp(n, 0, bits);
+    HIP_TRY(c, c->tmp.reserve(need + 16));
+    HIP_TRY(c, fqd::sort_pairs_u32_u32(c->tmp.p, need, kin, kout, vin, vout, n, 0, bits, c->st));
+    return FQD_OK;
+}
+
+int scan_u32(fqd_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n)
+{
+    const size_t need = fqd::scan_u32_temp(n);
+    HIP_TRY(c, c->tmp.reserve(need + 16));
+    HIP_TRY(c, fqd::inclusive_scan_u32(c->tmp.p, need, in, out, n, c->st));
+    return FQD_OK;
+}
+
+}  // namespace
+
+// helpers shared between the api_*.hip files (defined in the file named)
+int fqd_api_ensure_hashes(fqd_ctx *c);                 // api.hip
+int fqd_api_components_queue(fqd_ctx *c, bool flatten);   // api_graph.hip

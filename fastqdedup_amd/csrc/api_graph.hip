@@ -1,0 +1,347 @@
+// api_graph.hip -- C ABI, part 3: components, dissection, the kept-id list and the getters of the
+// unique table (stages 4 and 5; graph.hip holds the kernels).
+#include "api_ctx.h"
+
+extern "C" {
+
+static int ensure_flat_labels(fqd_ctx *c)
+{
+    if (c->labels_flat)
+        return FQD_OK;
+    HIP_TRY(c, c->tmp.reserve(64));
+    KTIME(c, FQD_K_UF_FLATTEN, fqd::launch_uf_flatten(c->labels.as<uint32_t>(), c->U,
+                                                      c->tmp.as<unsigned long long>(), c->st));
+    c->labels_flat = true;
+    return FQD_OK;
+}
+
+// Queue the union-find kernels; the component count stays on the device (C64_ROOTS) until
+// somebody asks for it (fqd_cluster asks after the dissection, so the GPU never waits for the
+// host in between). flatten = false leaves the parent forest unflattened: components = nodes -
+// hooks needs no sweep over the nodes, and only highest_count and the label export read labels
+// (ensure_flat_labels does the sweep then).
+static int components_queue(fqd_ctx *c, bool flatten)
+{
+    const uint64_t U = c->U;
+    HIP_TRY(c, c->labels.reserve(U * 4 + 16));
+    HIP_TRY(c, c->hook_slots.reserve(FQD_HOOK_SLOTS * 64));
+    HIP_TRY(c, hipMemsetAsync(c->hook_slots.p, 0, FQD_HOOK_SLOTS * 64, c->st));
+    HIP_TRY(c, fqd::launch_uf_init(c->labels.as<uint32_t>(), U, c->st));
+    KTIME(c, FQD_K_UF_UNION, fqd::launch_uf_union(c->labels.as<uint32_t>(), c->edges.as<uint32_t>(), c->E,
+                                                  c->hook_slots.as<unsigned long long>(), c->st));
+    HIP_TRY(c, fqd::launch_hook_total(c->hook_slots.as<unsigned long long>(), U,
+                                      c->d_ctr64.as<unsigned long long>() + C64_ROOTS, c->st));
+    c->labels_flat = false;
+    if (flatten)
+        FQD_TRY(ensure_flat_labels(c));
+    return FQD_OK;
+}
+
+int fqd_components(fqd_ctx *c, uint64_t *n_clusters)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_EDGES)
+        return fail(c, FQD_E_STATE, "fqd_components before fqd_find_edges/fqd_import_edges");
+    c->stage = ST_EDGES;
+    StageTimer timer(c, FQD_T_COMPONENTS);
+    FQD_TRY(components_queue(c, false));   // labels are flattened when somebody reads them
+    unsigned long long roots = 0;
+    FQD_TRY(read_ctr64(c, C64_ROOTS, &roots));
+    timer.stop();
+    c->n_clusters = roots;
+    c->stage = ST_LABELS;
+    if (n_clusters)
+        *n_clusters = roots;
+    return FQD_OK;
+}
+
+// Verdicts (best / state) -> kept flags, the counters and the ascending list of kept first-holder
+// ids inside the id window.
+static int list_kept(fqd_ctx *c, int method)
+{
+    const uint64_t U = c->U;
+    c->n_kept = 0;
+    c->n_listed = 0;
+    if (!U)
+        return FQD_OK;
+    // First-holder ids are distinct and bounded (by the id window, or by id_limit): when that
+    // range is not much larger than the table, the ascending list is a compaction of a byte map of
+    // the range -- cheaper than scan + gather + a radix sort of the ids.
+    uint64_t base = 0, window = c->id_limit;
+    if (c->id_hi != ~0ull) {
+        base = c->id_lo;
+        window = std::min(window > base ? window - base : 0, c->id_hi - c->id_lo);
+    }
+    const bool by_map = c->first_distinct && window <= 32 * U && window < 0xFFFFFFF0ull &&
+                        !getenv("FQD_KEPT_BY_SORT");
+    FQD_TRY(zero_ctr64(c, C64_SUM));
+    if (by_map) {
+        HIP_TRY(c, c->stage_c.reserve(window + 16));
+        if (window)
+            HIP_TRY(c, hipMemsetAsync(c->stage_c.p, 0, window, c->st));
+        HIP_TRY(c, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
+                                          c->state.as<uint8_t>(), c->ufirst.as<uint64_t>(), c->id_lo, c->id_hi, U,
+                                          c->kept.as<uint8_t>(), nullptr, c->stage_c.as<uint8_t>(), window,
+                                          c->ucounts.as<uint32_t>(), c->blocked.as<uint32_t>(),
+                                          c->root_taint.as<uint8_t>(),
+                                          c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+        HIP_TRY(c, c->kept_ids_sorted.reserve(std::min(window, U) * 8 + 16));
+        const uint32_t blocks = fqd::window_blocks(window);
+        uint32_t listed = 0;
+        if (blocks) {
+            HIP_TRY(c, c->kept_u32.reserve((size_t)blocks * 4 + 16));
+            HIP_TRY(c, c->kept_scan.reserve((size_t)blocks * 4 + 16));
+            HIP_TRY(c, fqd::launch_window_count(c->stage_c.as<uint8_t>(), window, c->kept_u32.as<uint32_t>(), c->st));
+            FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), blocks));
+            HIP_TRY(c, fqd::launch_window_emit(c->stage_c.as<uint8_t>(), window, c->kept_scan.as<uint32_t>(), base,
+                                               c->kept_ids_sorted.as<uint64_t>(), c->st));
+            HIP_TRY(c, hipMemcpyAsync(&listed, c->kept_scan.as<uint32_t>() + (blocks - 1), 4, hipMemcpyDeviceToHost,
+                                      c->st));
+        }
+        unsigned long long both[2] = {0, 0};      // C64_ROOTS, C64_SUM: one read for fqd_cluster
+        FQD_TRY(read_ctr64(c, C64_ROOTS, both, 2));
+        c->roots_seen = both[0];
+        const unsigned long long total = both[1];
+        c->n_kept = total;
+        c->n_listed = listed;
+        if (getenv("FQD_DEBUG"))
+            fprintf(stderr, "[fqd] kept list by map: U=%llu base=%llu window=%llu id_limit=%llu kept=%llu listed=%u\n",
+                    (unsigned long long)U, (unsigned long long)base, (unsigned long long)window,
+                    (unsigned long long)c->id_limit, total, listed);
+        return FQD_OK;
+    }
+    HIP_TRY(c, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
+                                      c->state.as<uint8_t>(), c->ufirst.as<uint64_t>(), c->id_lo, c->id_hi, U,
+                                      c->kept.as<uint8_t>(), c->kept_u32.as<uint32_t>(), nullptr, 0,
+                                      c->ucounts.as<uint32_t>(), c->blocked.as<uint32_t>(), c->root_taint.as<uint8_t>(),
+                                      c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+    FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), U));
+    uint32_t nk = 0;
+    HIP_TRY(c, hipMemcpyAsync(&nk, c->kept_scan.as<uint32_t>() + (U - 1), 4, hipMemcpyDeviceToHost, c->st));
+    unsigned long long both[2] = {0, 0};
+    FQD_TRY(read_ctr64(c, C64_ROOTS, both, 2));
+    c->roots_seen = both[0];
+    const unsigned long long total = both[1];
+    c->n_kept = total;
+    c->n_listed = nk;
+    HIP_TRY(c, c->kept_ids.reserve((size_t)nk * 8 + 16));
+    HIP_TRY(c, c->kept_ids_sorted.reserve((size_t)nk * 8 + 16));
+    HIP_TRY(c, fqd::launch_gather_kept(c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(),
+                                       c->ufirst.as<uint64_t>(), U, c->kept_ids.as<uint64_t>(), c->st));
+    if (nk) {
+        int sort_bits = c->id_bits;   // listed ids lie below id_hi: fewer radix passes
+        if (c->id_hi != ~0ull) {
+            int wb = 1;
+            while (wb < 64 && (c->id_hi >> wb))
+                wb++;
+            sort_bits = std::min(sort_bits, wb);
+        }
+        const size_t need = fqd::sort_keys_u64_temp(nk);
+        HIP_TRY(c, c->tmp.reserve(need + 16));
+        HIP_TRY(c, fqd::sort_keys_u64(c->tmp.p, need, c->kept_ids.as<uint64_t>(),
+                                      c->kept_ids_sorted.as<uint64_t>(), nk, sort_bits, c->st));
+    }
+    return FQD_OK;
+}
+
+int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_LABELS)
+        return fail(c, FQD_E_STATE, "fqd_dissect before fqd_components");
+    if (method < 0 || method > 2)
+        return fail(c, FQD_E_VALUE, "unknown cluster dissection method");
+    c->stage = ST_LABELS;
+    const uint64_t U = c->U, E = c->E;
+    const KeyShape sh = c->ks;
+    StageTimer timer(c, FQD_T_DISSECT);
+    HIP_TRY(c, c->best.reserve(U * 4 + 16));
+    HIP_TRY(c, c->state.reserve(U + 16));
+    HIP_TRY(c, c->kept.reserve(U + 16));
+    HIP_TRY(c, c->kept_u32.reserve(U * 4 + 16));
+    HIP_TRY(c, c->kept_scan.reserve(U * 4 + 16));
+    HIP_TRY(c, fqd::launch_dissect_init(c->best.as<uint32_t>(), c->state.as<uint8_t>(), U, c->st));
+    uint32_t *d_changed = c->d_ctr32.as<uint32_t>() + C_CHANGED;
+    int list_method = method;      // how list_kept reads the verdicts
+    if (method == FQD_METHOD_HIGHEST_COUNT) {
+        FQD_TRY(ensure_flat_labels(c));
+        HIP_TRY(c, fqd::launch_highest_count(c->labels.as<uint32_t>(), c->ucounts.as<uint32_t>(),
+                                             c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, U,
+                                             c->best.as<uint32_t>(), c->st));
+    } else if (method == FQD_METHOD_DIRECTIONAL && c->collapsed && !getenv("FQD_DIRECTIONAL_ROUNDS")) {
+        // closed form (graph.hip): two passes over the edges, no rounds, no host round trips. It
+        // relies on a strict order of the keys, so a caller's list with repeated keys
+        // (fqd_import_unique) takes the relaxation rounds below.
+        HIP_TRY(c, c->blocked.reserve(U * 4 + 16));   // here: union-find over the count-1 keys
+        HIP_TRY(c, c->taint.reserve(U + 16));
+        HIP_TRY(c, c->root_taint.reserve(U + 16));
+        if (E) {
+            HIP_TRY(c, hipMemsetAsync(c->taint.p, 0, U, c->st));
+            HIP_TRY(c, hipMemsetAsync(c->root_taint.p, 0, U, c->st));
+            HIP_TRY(c, fqd::launch_uf_init(c->blocked.as<uint32_t>(), U, c->st));
+            for (int pass = 1; pass <= 2; pass++)
+                KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_directional_closed(
+                          c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(), c->urecs.as<uint32_t>(),
+                          c->ulens.as<uint32_t>(), sh, c->blocked.as<uint32_t>(), c->state.as<uint8_t>(),
+                          c->taint.as<uint8_t>(), c->root_taint.as<uint8_t>(), c->best.as<uint32_t>(), pass, c->st));
+            list_method = 3;
+        }
+    } else if (method == FQD_METHOD_DIRECTIONAL) {
+        HIP_TRY(c, c->blocked.reserve(U * 4 + 16));   // here: round stamps of the nodes
+        if (E)
+            HIP_TRY(c, hipMemsetAsync(c->blocked.p, 0, U * 4, c->st));
+        // two sweeps per host check: the flag is read back half as often, and a sweep over edges
+        // whose ends did not move is cheap (stamps)
+        for (uint64_t round = 1; E && round <= U + 2; round += 2) {
+            FQD_TRY(zero_ctr32(c, C_CHANGED));
+            for (uint32_t k = 0; k < 2; k++)
+                KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_directional_round(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
+                                                     c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh,
+                                                     c->best.as<uint32_t>(), c->blocked.as<uint32_t>(),
+                                                     (uint32_t)(round + k), d_changed, c->st));
+            uint32_t changed = 0;
+            FQD_TRY(read_ctr32(c, C_CHANGED, &changed));
+            if (!changed)
+                break;
+        }
+    } else {
+        HIP_TRY(c, c->blocked.reserve(U * 4 + 16));
+        HIP_TRY(c, hipMemsetAsync(c->blocked.p, 0, U * 4, c->st));
+        // edges become (higher rank, lower rank); union-find and the other methods do not care
+        HIP_TRY(c, fqd::launch_orient_edges(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
+                                            c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, c->st));
+        for (uint64_t round = 1; round <= U + 2; round += 2) {
+            FQD_TRY(zero_ctr32(c, C_CHANGED));
+            for (uint32_t k = 0; k < 2; k++)
+                KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_adjacency_round(c->edges.as<uint32_t>(), E, U, c->state.as<uint8_t>(),
+                                                   c->blocked.as<uint32_t>(), (uint32_t)(round + k), d_changed, c->st));
+            uint32_t changed = 0;
+            FQD_TRY(read_ctr32(c, C_CHANGED, &changed));
+            if (!changed)
+                break;
+        }
+    }
+    FQD_TRY(list_kept(c, list_method));
+    timer.stop();
+    c->stage = ST_KEPT;
+    if (n_kept)
+        *n_kept = c->n_kept;
+    return FQD_OK;
+}
+
+int fqd_set_id_window(fqd_ctx *c, uint64_t lo, uint64_t hi)
+{
+    c->id_lo = lo;
+    c->id_hi = hi;
+    return FQD_OK;
+}
+
+int fqd_get_kept_count(fqd_ctx *c, uint64_t *n_kept, uint64_t *n_listed)
+{
+    if (c->stage < ST_KEPT)
+        return fail(c, FQD_E_STATE, "no dissection result yet");
+    if (n_kept)
+        *n_kept = c->n_kept;
+    if (n_listed)
+        *n_listed = c->n_listed;
+    return FQD_OK;
+}
+
+int fqd_get_kept_read_ids(fqd_ctx *c, uint64_t *out, int mem)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_KEPT)
+        return fail(c, FQD_E_STATE, "no dissection result yet");
+    return from_device(c, out, c->kept_ids_sorted.p, (size_t)c->n_listed, mem);
+}
+
+int fqd_get_unique_table(fqd_ctx *c, uint64_t *first_ids, uint32_t *counts, uint32_t *labels, uint8_t *kept, int mem)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_UNIQUE)
+        return fail(c, FQD_E_STATE, "no unique table yet");
+    FQD_TRY(from_device(c, first_ids, c->ufirst.p, (size_t)c->U, mem));
+    FQD_TRY(from_device(c, counts, c->ucounts.p, (size_t)c->U, mem));
+    if (labels) {
+        if (c->stage < ST_LABELS)
+            return fail(c, FQD_E_STATE, "no component labels yet");
+        FQD_TRY(ensure_flat_labels(c));
+        FQD_TRY(from_device(c, labels, c->labels.p, (size_t)c->U, mem));
+    }
+    if (kept) {
+        if (c->stage < ST_KEPT)
+            return fail(c, FQD_E_STATE, "no dissection result yet");
+        FQD_TRY(from_device(c, kept, c->kept.p, (size_t)c->U, mem));
+    }
+    return FQD_OK;
+}
+
+// Union-find over n_nodes nodes and a caller's edge list (device): roots[e] = smallest node of
+// edge e's component; *n_components = n_nodes - successful hooks.
+int fqd_edge_labels(fqd_ctx *c, const uint32_t *uv, uint64_t E, uint64_t n_nodes, uint32_t *roots,
+                    uint64_t *n_components, int mem)
+{
+    FQD_TRY(bind(c));
+    if (mem != FQD_DEVICE)
+        return fail(c, FQD_E_VALUE, "fqd_edge_labels works on device buffers");
+    if (n_nodes >= 0xFFFFFFF0ull)
+        return fail(c, FQD_E_VALUE, "at most 2^32-16 nodes");
+    FQD_TRY(zero_ctr32(c, C_BAD));
+    HIP_TRY(c, fqd::launch_check_indices(uv, 2 * E, n_nodes, c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+    uint32_t bad = 0;
+    FQD_TRY(read_ctr32(c, C_BAD, &bad));
+    if (bad)
+        return fail(c, FQD_E_VALUE, "edge end outside [0, n_nodes)");
+    HIP_TRY(c, c->stage_a.reserve(n_nodes * 4 + 16));
+    HIP_TRY(c, c->stage_b.reserve(FQD_HOOK_SLOTS * 64));
+    uint32_t *parent = c->stage_a.as<uint32_t>();
+    HIP_TRY(c, hipMemsetAsync(c->stage_b.p, 0, FQD_HOOK_SLOTS * 64, c->st));
+    HIP_TRY(c, fqd::launch_uf_init(parent, n_nodes, c->st));
+    HIP_TRY(c, fqd::launch_uf_union(parent, uv, E, c->stage_b.as<unsigned long long>(), c->st));
+    HIP_TRY(c, fqd::launch_edge_roots(parent, uv, E, roots, c->st));
+    std::vector<unsigned long long> slots((size_t)FQD_HOOK_SLOTS * 8);
+    HIP_TRY(c, hipMemcpyAsync(slots.data(), c->stage_b.p, FQD_HOOK_SLOTS * 64, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    unsigned long long hooks = 0;
+    for (size_t i = 0; i < slots.size(); i += 8)
+        hooks += slots[i];
+    if (n_components)
+        *n_components = n_nodes - hooks;
+    return FQD_OK;
+}
+
+// The dissection's verdicts came from elsewhere (the rank that held the cluster): every key of
+// the unique table is kept except the listed rows. Fills the kept list like fqd_dissect.
+int fqd_list_kept_except(fqd_ctx *c, const uint32_t *dropped, uint64_t n_dropped, int mem, uint64_t *n_kept)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_UNIQUE)
+        return fail(c, FQD_E_STATE, "no unique table yet");
+    if (mem != FQD_DEVICE && n_dropped)
+        return fail(c, FQD_E_VALUE, "fqd_list_kept_except works on device buffers");
+    const uint64_t U = c->U;
+    StageTimer timer(c, FQD_T_DISSECT);
+    HIP_TRY(c, c->state.reserve(U + 16));
+    HIP_TRY(c, c->kept.reserve(U + 16));
+    HIP_TRY(c, c->kept_u32.reserve(U * 4 + 16));
+    HIP_TRY(c, c->kept_scan.reserve(U * 4 + 16));
+    if (U)
+        HIP_TRY(c, hipMemsetAsync(c->state.p, 1, U, c->st));
+    FQD_TRY(zero_ctr32(c, C_BAD));
+    HIP_TRY(c, fqd::launch_mark_dropped(c->state.as<uint8_t>(), U, dropped, n_dropped,
+                                        c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+    uint32_t bad = 0;
+    FQD_TRY(read_ctr32(c, C_BAD, &bad));
+    if (bad)
+        return fail(c, FQD_E_VALUE, "dropped row outside the unique table");
+    FQD_TRY(list_kept(c, FQD_METHOD_ADJACENCY));   // "state == 1" is the verdict
+    timer.stop();
+    c->stage = ST_KEPT;
+    if (n_kept)
+        *n_kept = c->n_kept;
+    return FQD_OK;
+}
+
+}  // extern "C"
+
+int fqd_api_components_queue(fqd_ctx *c, bool flatten) { return components_queue(c, flatten); }

@@ -1,0 +1,306 @@
+// api_search.hip -- C ABI, part 2: the neighbour search (stage 3): Hamming passes by partition
+// (group.hip) or radix sort (edges.hip), the bucketed edit search (edit.hip).
+#include "api_ctx.h"
+
+namespace {
+
+int find_edges_edit(fqd_ctx *c, uint32_t d, uint32_t shard, uint32_t n_shards)
+{
+    const uint64_t U = c->U;
+    const KeyShape sh = c->ks;
+    if (d > 64)
+        return fail(c, FQD_E_VALUE, "edit distance bound above 64 is not supported on device");
+    HIP_TRY(c, c->len_present.reserve((size_t)sh.max_len + 16));
+    HIP_TRY(c, hipMemsetAsync(c->len_present.p, 0, (size_t)sh.max_len + 1, c->st));
+    HIP_TRY(c, fqd::launch_len_present(c->ulens.as<uint32_t>(), U, sh, c->len_present.as<uint8_t>(), c->st));
+    std::vector<uint8_t> present((size_t)sh.max_len + 1);
+    HIP_TRY(c, hipMemcpyAsync(present.data(), c->len_present.p, present.size(), hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    uint32_t n_lengths = 0;
+    for (uint8_t f : present)
+        n_lengths += f ? 1 : 0;
+    const uint32_t classes = std::min<uint32_t>(2 * d + 1, std::max<uint32_t>(n_lengths, 1));
+    const uint32_t slots = (d + 1) * (1 + classes * (2 * d + 1));
+    const uint64_t R = U * slots;
+    if (R >= 0xFFFFFF00ull)
+        return fail(c, FQD_E_VALUE, "edit search: more than 2^32 index/probe records; lower max_distance or shard the job");
+    HIP_TRY(c, c->ed_hash.reserve(R * 4 + 16));
+    HIP_TRY(c, c->ed_payload.reserve(R * 4 + 16));
+    HIP_TRY(c, c->ed_hash_sorted.reserve(R * 4 + 16));
+    HIP_TRY(c, c->ed_payload_sorted.reserve(R * 4 + 16));
+    HIP_TRY(c, fqd::launch_edit_records(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, sh, d,
+                                        c->len_present.as<uint8_t>(), slots, c->ed_hash.as<uint32_t>(),
+                                        c->ed_payload.as<uint32_t>(), c->st));
+    FQD_TRY(sort_u32_pairs(c, c->ed_hash.as<uint32_t>(), c->ed_hash_sorted.as<uint32_t>(),
+                           c->ed_payload.as<uint32_t>(), c->ed_payload_sorted.as<uint32_t>(), R));
+    uint64_t cap = std::max<uint64_t>(c->ed_cands.cap / 8, std::max<uint64_t>(4096, 4 * U));
+    unsigned long long n_cand = 0;
+    for (;;) {
+        HIP_TRY(c, c->ed_cands.reserve(cap * 8));
+        FQD_TRY(zero_ctr64(c, C64_SUM));
+        HIP_TRY(c, fqd::launch_edit_candidates(c->ed_hash_sorted.as<uint32_t>(), c->ed_payload_sorted.as<uint32_t>(), R,
+                                               c->ulens.as<uint32_t>(), sh, d, shard, n_shards,
+                                               c->ed_cands.as<uint64_t>(), c->d_ctr64.as<unsigned long long>() + C64_SUM,
+                                               cap, c->st));
+        FQD_TRY(read_ctr64(c, C64_SUM, &n_cand));
+        if (n_cand <= cap)
+            break;
+        cap = n_cand + n_cand / 8 + 1024;
+    }
+    c->last_stats.pairs_compared = n_cand;
+    if (!n_cand)
+        return FQD_OK;
+    HIP_TRY(c, c->ed_cands_sorted.reserve(n_cand * 8 + 16));
+    {
+        const size_t need = fqd::sort_keys_u64_temp(n_cand);
+        HIP_TRY(c, c->tmp.reserve(need + 16));
+        HIP_TRY(c, fqd::sort_keys_u64(c->tmp.p, need, c->ed_cands.as<uint64_t>(), c->ed_cands_sorted.as<uint64_t>(),
+                                      n_cand, 64, c->st));
+    }
+    HIP_TRY(c, c->edges.reserve(n_cand * 8 + 16));  // every unique candidate yields at most one edge
+    c->edge_cap = c->edges.cap / 8;
+    HIP_TRY(c, fqd::launch_edit_verify(c->ed_cands_sorted.as<uint64_t>(), n_cand, c->urecs.as<uint32_t>(),
+                                       c->ulens.as<uint32_t>(), sh, d, c->edges.as<uint32_t>(),
+                                       c->d_ctr64.as<unsigned long long>() + C64_EDGES, c->edge_cap, c->st));
+    unsigned long long ne = 0;
+    FQD_TRY(read_ctr64(c, C64_EDGES, &ne));
+    c->E = ne;
+    c->last_stats.edges = ne;
+    return FQD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// One Hamming search pass without a device-wide sort (group.hip): the (segment hash, uid) pairs
+// are partitioned into 2^B buckets of ~200 keys by the top hash bits, then one wave per bucket
+// sub-sorts them in LDS and lists the pairs with equal hashes; a second kernel verifies those.
+// Queues work only (no host round trip).
+static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t d, uint32_t s, uint32_t nseg)
+{
+    const KeyShape sh = c->ks;
+    uint32_t B = 8;
+    while (B < 20 && (U >> B) > 320)   // ~160-320 keys per bucket: a wave sorts them into 64 sub-bins in LDS
+        B++;
+    if (const char *e = getenv("FQD_GROUP_BUCKET_BITS"))   // tests: few, crowded buckets
+        B = (uint32_t)std::max(1, std::min(20, atoi(e)));
+    const uint32_t B1 = B <= 18 ? std::min<uint32_t>(B, 8) : B - 10, B2 = B - B1;
+    const uint32_t bins1 = 1u << B1, bins2 = 1u << B2, n_buckets = 1u << B;
+    const uint32_t tile = fqd::group_tile_size();
+    const uint32_t tiles1 = (uint32_t)((U + tile - 1) / tile), max_tiles2 = tiles1 + bins1;
+    HIP_TRY(c, c->gp_a.reserve(U * 8 + 16));
+    HIP_TRY(c, c->gp_small.reserve(4096 * 4 + (size_t)fqd::group_cand_lists() * 64));
+    HIP_TRY(c, c->ld_start.reserve(((size_t)n_buckets + 1) * 4 + 16));
+    uint32_t *small = c->gp_small.as<uint32_t>();
+    uint32_t *seg1 = small, *tiles1_d = small + 8, *start1 = small + 16, *tiles2_d = small + 2048;
+    const uint32_t seg1_h[2] = {0u, (uint32_t)U}, tiles1_h[2] = {0u, tiles1};
+    HIP_TRY(c, hipMemcpyAsync(seg1, seg1_h, 8, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, hipMemcpyAsync(tiles1_d, tiles1_h, 8, hipMemcpyHostToDevice, c->st));
+    // ---- level 1: (bin x tile) count matrix, scan, placement without atomics
+    const size_t matrix = (size_t)bins1 * tiles1;
+    HIP_TRY(c, c->ld_matrix.reserve(matrix * 4 + 16));
+    HIP_TRY(c, c->ld_matrix_incl.reserve(matrix * 4 + 16));
+    KTIME(c, FQD_K_GROUP_HIST, fqd::launch_group_hist(true, hashes, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1, bins1,
+                                                      c->ld_matrix.as<uint32_t>(), c->st));
+    FQD_TRY(scan_u32(c, c->ld_matrix.as<uint32_t>(), c->ld_matrix_incl.as<uint32_t>(), matrix));
+    HIP_TRY(c, fqd::launch_group_matrix_starts(c->ld_matrix_incl.as<uint32_t>(), bins1, tiles1, start1, c->st));
+    KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(true, hashes, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1,
+                                                            bins1, c->ld_matrix_incl.as<uint32_t>(),
+                                                            c->gp_a.as<uint32_t>(), c->st));
+    const uint32_t *items = c->gp_a.as<uint32_t>();
+    if (B2 == 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->ld_start.p, start1, ((size_t)bins1 + 1) * 4, hipMemcpyDeviceToDevice, c->st));
+    } else {
+        // ---- level 2: every part into 2^B2 buckets by the next hash bits
+        HIP_TRY(c, c->gp_b.reserve(U * 8 + 16));
+        HIP_TRY(c, c->ld_hist.reserve((size_t)n_buckets * 4 + 16));
+        HIP_TRY(c, c->ld_hist_incl.reserve((size_t)n_buckets * 4 + 16));
+        HIP_TRY(c, c->ld_cursor.reserve((size_t)n_buckets * 4 + 16));
+        HIP_TRY(c, fqd::launch_group_tile_starts(start1, bins1, tiles2_d, c->st));
+        HIP_TRY(c, hipMemsetAsync(c->ld_hist.p, 0, (size_t)n_buckets * 4, c->st));
+        KTIME(c, FQD_K_GROUP_HIST, fqd::launch_group_hist(false, nullptr, c->gp_a.as<uint32_t>(), start1, tiles2_d, bins1,
+                                                          max_tiles2, 32 - B, bins2, c->ld_hist.as<uint32_t>(), c->st));
+        FQD_TRY(scan_u32(c, c->ld_hist.as<uint32_t>(), c->ld_hist_incl.as<uint32_t>(), n_buckets));
+        HIP_TRY(c, fqd::launch_group_bucket_starts(c->ld_hist_incl.as<uint32_t>(), n_buckets,
+                                                   c->ld_start.as<uint32_t>(), c->ld_cursor.as<uint32_t>(), c->st));
+        KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(false, nullptr, c->gp_a.as<uint32_t>(), start1, tiles2_d,
+                                                                bins1, max_tiles2, 32 - B, bins2,
+                                                                c->ld_cursor.as<uint32_t>(), c->gp_b.as<uint32_t>(),
+                                                                c->st));
+        items = c->gp_b.as<uint32_t>();
+    }
+    // candidates (pairs with equal segment hashes) -> device list -> verification, one thread per pair
+    if (c->gp_cand_cap < 1024 || !c->gp_cands.p) {
+        c->gp_cand_cap = std::max<uint64_t>(1u << 20, 2 * U);   // split evenly over the lists: leave slack
+        HIP_TRY(c, c->gp_cands.reserve(c->gp_cand_cap * 8));
+    }
+    c->gp_cand_cap = c->gp_cands.cap / 8;
+    // the candidate counters (one per list, a cache line apart) live behind the small tables
+    unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(small + 4096);
+    HIP_TRY(c, hipMemsetAsync(cand_ctr, 0, (size_t)fqd::group_cand_lists() * 64, c->st));
+    unsigned long long *ctr = c->d_ctr64.as<unsigned long long>();
+    KTIME(c, FQD_K_PAIRS, fqd::launch_grouped_candidates(items, c->ld_start.as<uint32_t>(), n_buckets, B,
+                                                         c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,
+                                                         c->st));
+    KTIME(c, FQD_K_VERIFY, fqd::launch_verify_candidates(c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,
+                                                         c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, s, nseg,
+                                                         c->edges.as<uint32_t>(), ctr + C64_EDGES, c->edge_cap,
+                                                         ctr + C64_CAND_NEED, c->d_stats.as<fqd::PairStats>(), c->st));
+    return FQD_OK;
+}
+
+// Shared body of fqd_find_edges / fqd_find_edges_segments: passes [seg_lo, seg_hi) of the
+// (max_distance+1)-way pigeonhole split (the whole range for a plain search).
+static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uint32_t n_shards,
+                           uint32_t seg_lo, uint32_t seg_hi, uint64_t *n_edges)
+{
+    FQD_TRY(bind(c));
+    if (c->stage < ST_UNIQUE)
+        return fail(c, FQD_E_STATE, "fqd_find_edges before fqd_collapse/fqd_import_unique");
+    if (max_distance < 0)
+        return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
+    if (n_shards == 0 || shard >= n_shards)
+        return fail(c, FQD_E_VALUE, "bad shard");
+    const KeyShape sh = c->ks;
+    // Levenshtein <= 1 between keys of ONE length is Hamming <= 1 (an indel changes the length):
+    // that case shares the Hamming search; everything else takes the bucketed edit search.
+    const bool edit_general = metric == FQD_METRIC_EDIT && !(max_distance <= 1 && !sh.ragged);
+    if (seg_hi > (uint32_t)max_distance + 1 || seg_lo > seg_hi)
+        return fail(c, FQD_E_VALUE, "segment range outside [0, max_distance + 1]");
+    if (edit_general && (seg_lo != 0 || seg_hi != (uint32_t)max_distance + 1))
+        return fail(c, FQD_E_VALUE, "the bucketed edit search has no per-segment passes");
+    c->stage = ST_UNIQUE;
+    const uint64_t U = c->U;
+    StageTimer timer(c, FQD_T_EDGES);
+    c->E = 0;
+    c->ms[FQD_T_PAIRS_KERNEL] = 0;
+    c->launches[FQD_T_PAIRS_KERNEL] = 0;
+    c->last_stats = fqd::PairStats{0, 0, 0};
+    c->stats_pending = false;
+    FQD_TRY(zero_ctr64(c, C64_EDGES));
+    HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
+    if (edit_general && U >= 2 && (max_distance > 0 || !c->collapsed)) {
+        FQD_TRY(find_edges_edit(c, (uint32_t)max_distance, shard, n_shards));
+    } else if (U >= 2 && (max_distance > 0 || !c->collapsed)) {
+        // with d >= max_len every segment split has empty segments: still correct (all keys of a
+        // length share the empty segment's bucket), just quadratic.
+        const uint32_t d = (uint32_t)max_distance;
+        const uint32_t nseg = d + 1;
+        HIP_TRY(c, c->seg_hashes.reserve((size_t)(seg_hi - seg_lo) * U * 4 + 16));
+        HIP_TRY(c, c->sorted_hash.reserve(U * 4 + 16));
+        HIP_TRY(c, c->sorted_uid.reserve(U * 4 + 16));
+        HIP_TRY(c, c->uid_iota.reserve(U * 4 + 16));
+        KTIME(c, FQD_K_SEG_HASH, fqd::launch_segment_hashes(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, sh, nseg,
+                                              seg_lo, seg_hi, 0, c->seg_hashes.as<uint32_t>(), c->st));
+        if (c->edge_cap < 1024 || !c->edges.p) {
+            c->edge_cap = std::max<uint64_t>(1024, U);
+            HIP_TRY(c, c->edges.reserve(c->edge_cap * 8));
+        }
+        c->edge_cap = c->edges.cap / 8;
+        unsigned long long have = 0;
+        if (n_shards > 1) {
+            HIP_TRY(c, c->sel_hash.reserve(U * 4 + 16));
+            HIP_TRY(c, c->sel_uid.reserve(U * 4 + 16));
+        }
+        // Grouping by partition (group.hip) unless a bucket shard was asked for or the table is small
+        // (FQD_EDGES=sort|grouped pins the path for tests).
+        const char *pin = getenv("FQD_EDGES");
+        bool grouped = n_shards == 1 && U < 0xFFFFFF00ull && (pin ? !strcmp(pin, "grouped") : U >= 65536);
+        // Candidate pairs are listed before they are verified; a segment value shared by very many
+        // keys (all of them pairwise candidates) would need a list beyond this budget: the search
+        // then runs again on the sort path, which verifies in place and needs no list.
+        uint64_t cand_budget = std::max<uint64_t>(8 * U, 1ull << 24);
+        if (const char *e = getenv("FQD_GROUP_CAND_BUDGET"))
+            cand_budget = strtoull(e, nullptr, 10);
+        bool iota_ready = false;
+        FQD_TRY(zero_ctr64(c, C64_CAND_NEED));
+        // All d+1 passes are queued without a host round trip; the edge count is read ONCE at the
+        // end. If the passes overflowed the edge buffer (the count still says how many edges there
+        // are), the buffer is grown to the known need and the whole search runs again.
+        for (int attempt = 0;; attempt++) {
+            for (uint32_t s = seg_lo; s < seg_hi; s++) {
+                const uint32_t *pass_hashes = c->seg_hashes.as<uint32_t>() + (size_t)(s - seg_lo) * U;
+                uint64_t m = U;  // entries this rank sorts and searches in this pass
+                if (n_shards > 1) {
+                    // only this rank's buckets go through the sort and the pair kernel
+                    FQD_TRY(zero_ctr64(c, C64_SUM));
+                    HIP_TRY(c, fqd::launch_select_shard(pass_hashes, U, shard,
+                                                        n_shards, c->sel_hash.as<uint32_t>(),
+                                                        c->sel_uid.as<uint32_t>(),
+                                                        c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+                    unsigned long long got = 0;
+                    FQD_TRY(read_ctr64(c, C64_SUM, &got));
+                    m = got;
+                    FQD_TRY(sort_u32_pairs(c, c->sel_hash.as<uint32_t>(), c->sorted_hash.as<uint32_t>(),
+                                           c->sel_uid.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), m));
+                } else if (grouped) {
+                    FQD_TRY(grouped_pass(c, pass_hashes, U, d, s, nseg));
+                    continue;
+                } else {
+                    if (!iota_ready) {
+                        HIP_TRY(c, fqd::launch_iota_u32(c->uid_iota.as<uint32_t>(), U, c->st));
+                        iota_ready = true;
+                    }
+                    FQD_TRY(sort_u32_pairs(c, pass_hashes,
+                                           c->sorted_hash.as<uint32_t>(), c->uid_iota.as<uint32_t>(),
+                                           c->sorted_uid.as<uint32_t>(), U));
+                }
+                KTIME(c, FQD_K_PAIRS, fqd::launch_bucket_pairs(
+                               c->sorted_hash.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), m,
+                               c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, s, nseg, 0, 1,
+                               c->edges.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_EDGES, c->edge_cap,
+                               c->d_stats.as<fqd::PairStats>(), c->st));
+            }
+            unsigned long long ctrs[C64_CAND_NEED + 1] = {0};
+            FQD_TRY(read_ctr64(c, 0, ctrs, C64_CAND_NEED + 1));
+            const unsigned long long now = ctrs[C64_EDGES], cand_need = grouped ? ctrs[C64_CAND_NEED] : 0;
+            if (now <= c->edge_cap && cand_need <= c->gp_cand_cap) {
+                have = now;
+                break;
+            }
+            if (attempt > 2)
+                return fail(c, FQD_E_RUNTIME, "edge buffer kept overflowing");
+            if (now > c->edge_cap) {
+                c->edges.release();
+                HIP_TRY(c, c->edges.reserve((size_t)(now + now / 8 + 1024) * 8));
+                c->edge_cap = c->edges.cap / 8;
+            }
+            if (cand_need > c->gp_cand_cap) {
+                if (cand_need > cand_budget) {
+                    grouped = false;
+                } else {
+                    c->gp_cands.release();
+                    HIP_TRY(c, c->gp_cands.reserve((size_t)(cand_need + cand_need / 8 + 1024) * 8));
+                    c->gp_cand_cap = c->gp_cands.cap / 8;
+                }
+            }
+            FQD_TRY(zero_ctr64(c, C64_CAND_NEED));
+            FQD_TRY(zero_ctr64(c, C64_EDGES));
+            HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
+        }
+        c->E = have;
+        c->stats_pending = true;     // the 64 stat slots are summed when fqd_edge_stats asks
+    }
+    timer.stop();
+    c->stage = ST_EDGES;
+    if (n_edges)
+        *n_edges = c->E;
+    return FQD_OK;
+}
+
+int fqd_find_edges(fqd_ctx *c, int max_distance, int metric, uint32_t shard, uint32_t n_shards, uint64_t *n_edges)
+{
+    if (max_distance < 0)
+        return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
+    return find_edges_impl(c, max_distance, metric, shard, n_shards, 0, (uint32_t)max_distance + 1, n_edges);
+}
+
+int fqd_find_edges_segments(fqd_ctx *c, int max_distance, uint32_t seg_lo, uint32_t seg_hi, uint64_t *n_edges)
+{
+    if (max_distance < 0)
+        return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
+    return find_edges_impl(c, max_distance, FQD_METRIC_HAMMING, 0, 1, seg_lo, seg_hi, n_edges);
+}
+
+}  // extern "C"
