@@ -146,9 +146,15 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
                                      32 - B1, bins1, kw, sh.max_len, c->ld_matrix.as<uint32_t>(), c->st));
     FQD_TRY(scan_u32(c, c->ld_matrix.as<uint32_t>(), c->ld_matrix_incl.as<uint32_t>(), matrix));
     HIP_TRY(c, fqd::launch_matrix_starts(c->ld_matrix_incl.as<uint32_t>(), bins1, tiles1, start1, c->st));
+    // received reads without weights: (segment, local index) travels in the record (IdSource)
+    IdSource packed;
+    if (d_ids.packed_bits && !d_w)
+        packed = d_ids;
+    else
+        d_ids.packed_bits = 0;
     KTIME(c, FQD_K_PART_SCATTER1, fqd::launch_part_scatter(true, c->hashes.as<uint32_t>(), c->recs.as<uint32_t>(), seg1, tiles1_d, 1,
                                         tiles1, 32 - B1, bins1, kw, sh.max_len, c->ld_matrix_incl.as<uint32_t>(),
-                                        c->ld_part.as<uint32_t>(), c->st));
+                                        c->ld_part.as<uint32_t>(), c->st, packed));
     const uint32_t *parted = c->ld_part.as<uint32_t>();
     if (B2 == 0) {
         HIP_TRY(c, hipMemcpyAsync(c->ld_start.p, start1, ((size_t)bins1 + 1) * 4, hipMemcpyDeviceToDevice, c->st));
@@ -647,6 +653,24 @@ int fqd_collapse_received(fqd_ctx *c, const uint32_t *weights, const uint64_t *s
     ids.seg_rows = d_rows;
     ids.seg_id0 = d_id0;
     ids.n_seg = n_seg;
+    {   // (segment, local index) in 32 bits? local indices of segment s lie below the gap to the next id base
+        uint64_t max_local = 0;
+        bool known = id_limit != ~0ull;
+        for (uint32_t s = 0; s < n_seg && known; s++) {
+            const uint64_t next = s + 1 < n_seg ? seg_id0[s + 1] : id_limit;
+            if (next < seg_id0[s])
+                known = false;
+            else
+                max_local = std::max(max_local, next - seg_id0[s]);
+        }
+        uint32_t lb = 1, sb = 0;
+        while (lb < 32 && (max_local >> lb))
+            lb++;
+        while ((1u << sb) < n_seg)
+            sb++;
+        if (known && lb + sb <= 32 && lb < 32)
+            ids.packed_bits = lb;
+    }
     return collapse_impl(c, weights, mem, ids, id_limit, n_unique);
 }
 

@@ -42,6 +42,7 @@ struct RecordPolicy {
         const uint32_t *hashes;   // level 1 only, may be NULL
         const uint4 *in;
         uint32_t kw, len;
+        IdSource ids;             // ids.packed_bits != 0: level 1 stamps (segment, local index), see IdSource
     };
     template <bool LEVEL1>
     static __device__ __forceinline__ uint32_t load(const Source &s, uint32_t i, uint4 &v)
@@ -51,11 +52,16 @@ struct RecordPolicy {
             // words past the key are padding: zero on this rank's own packed reads, but a sender's
             // local index on reads received from other ranks (fqd_collapse_received) -- never part
             // of the key
+            uint32_t tag = i;
+            if (s.ids.packed_bits) {
+                const uint32_t local = s.kw == 3 ? v.w : (s.kw == 2 ? v.z : v.y);   // word kw of the record
+                tag = (s.ids.segment_of(i) << s.ids.packed_bits) | local;
+            }
             if (s.kw < 3)
                 v.z = 0;
             if (s.kw < 2)
                 v.y = 0;
-            v.w = i;
+            v.w = tag;
         }
         const uint32_t rec[3] = {v.x, v.y, v.z};
         return fqd_hash_record(rec, s.kw, s.len);
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(
         urecs[begin + j] = tmp_rec[src + j];
         ucounts[begin + j] = tmp_count[src + j];
         const uint32_t f = tmp_first[src + j];
-        ufirst[begin + j] = read_ids.at(f);
+        ufirst[begin + j] = read_ids.packed_bits ? read_ids.from_packed(f) : read_ids.at(f);
     }
 }
 
@@ -280,7 +286,7 @@ hipError_t launch_part_hist(bool level1, const uint32_t *hashes, const uint32_t 
 {
     if (n_bins > fqd_partition::MAX_BINS)
         return hipErrorInvalidValue;
-    const RecordPolicy::Source src{hashes, reinterpret_cast<const uint4 *>(in), kw, len};
+    const RecordPolicy::Source src{hashes, reinterpret_cast<const uint4 *>(in), kw, len, IdSource()};
     if (level1)
         part_hist_kernel<true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, shift,
                                                                              n_bins, hist);
@@ -293,11 +299,11 @@ hipError_t launch_part_hist(bool level1, const uint32_t *hashes, const uint32_t 
 hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
                                const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
-                               hipStream_t st)
+                               hipStream_t st, IdSource packed)
 {
     if (n_bins > fqd_partition::MAX_BINS)
         return hipErrorInvalidValue;
-    const RecordPolicy::Source src{hashes, reinterpret_cast<const uint4 *>(in), kw, len};
+    const RecordPolicy::Source src{hashes, reinterpret_cast<const uint4 *>(in), kw, len, packed};
     uint4 *out4 = reinterpret_cast<uint4 *>(out);
     if (level1)
         part_scatter_kernel<true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg,

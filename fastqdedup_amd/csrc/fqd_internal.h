@@ -148,12 +148,12 @@ struct IdSource {
     const uint32_t *seg_rows = nullptr;   // n_seg + 1 row offsets of the segments (device)
     const uint64_t *seg_id0 = nullptr;    // n_seg id bases (device)
     uint32_t n_seg = 0;
-    __device__ __forceinline__ uint64_t at(uint32_t pos) const
+    // LDS collapse of received reads without weights: the partition stamps (segment << packed_bits |
+    // local index) into the travelling record instead of the position -- the same order, since the
+    // segments arrive in rank order -- and the id needs no look-up in the packed buffer afterwards.
+    uint32_t packed_bits = 0;             // 0: not possible / not used
+    __device__ __forceinline__ uint32_t segment_of(uint32_t pos) const
     {
-        if (ids64)
-            return ids64[pos];
-        if (!stamped)
-            return pos;
         uint32_t a = 0, b = n_seg;        // last segment with seg_rows[a] <= pos
         while (b - a > 1) {
             const uint32_t m = (a + b) >> 1;
@@ -162,7 +162,19 @@ struct IdSource {
             else
                 b = m;
         }
-        return seg_id0[a] + stamped[(uint64_t)pos * stride + spare_word];
+        return a;
+    }
+    __device__ __forceinline__ uint64_t from_packed(uint32_t tag) const
+    {
+        return seg_id0[tag >> packed_bits] + (tag & ((1u << packed_bits) - 1u));
+    }
+    __device__ __forceinline__ uint64_t at(uint32_t pos) const
+    {
+        if (ids64)
+            return ids64[pos];
+        if (!stamped)
+            return pos;
+        return seg_id0[segment_of(pos)] + stamped[(uint64_t)pos * stride + spare_word];
     }
 };
 
@@ -235,7 +247,7 @@ hipError_t launch_part_hist(bool level1, const uint32_t *hashes, const uint32_t 
 hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
                                const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
-                               hipStream_t st);
+                               hipStream_t st, IdSource packed = IdSource());
 uint32_t part_tile_size();
 hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                 hipStream_t st);
