@@ -22,6 +22,45 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _save_resources(path: str, remarks) -> None:
+    """Per-kernel register/scratch/LDS use as the compiler reports it (-Rpass-analysis=
+    kernel-resource-usage), kept next to the object file: tests/test_hip_abi.py checks that no hot
+    kernel spills to scratch memory (a select chain on a vector's components once sent a whole
+    register array there and cost 40 % of a kernel, unnoticed until the next profile)."""
+    import json
+    import re
+    out, cur = {}, None
+    for ln in remarks:
+        m = re.search(r"remark:\s+(.*?) \[-Rpass-analysis", ln)
+        if not m:
+            continue
+        text = m.group(1).strip()
+        if text.startswith("Function Name:"):
+            cur = text.split(":", 1)[1].strip()
+            out[cur] = {}
+        elif cur and ":" in text:
+            k, v = text.rsplit(":", 1)
+            try:
+                out[cur][k.strip()] = int(v)
+            except ValueError:
+                pass
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+def kernel_resources() -> dict:
+    """{mangled kernel name: {"VGPRs": .., "ScratchSize [bytes/lane]": .., ...}} of the last build."""
+    import json
+    res = {}
+    objdir = os.path.join(HERE, "build")
+    for src in SOURCES:
+        path = os.path.join(objdir, src.replace(".hip", ".o") + ".resources.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                res.update(json.load(f))
+    return res
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     headers = [os.path.join(CSRC, "fqd_internal.h"), os.path.join(CSRC, "partition.cuh"), os.path.join(CSRC, "api_ctx.h"),
                os.path.join(os.path.dirname(HERE), "include", "fqdedup_hip.h")]
@@ -31,8 +70,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
-            jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+        if force or _stale(o, [s] + headers) or not os.path.exists(o + ".resources.json"):
+            jobs.append([HIPCC, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -40,8 +79,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(f"{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
-        if verbose and r.stderr:
-            print(r.stderr, file=sys.stderr)
+        remarks = [ln for ln in r.stderr.splitlines() if "kernel-resource-usage" in ln]
+        if remarks:
+            _save_resources(cmd[-1] + ".resources.json", remarks)
+        rest = "\n".join(ln for ln in r.stderr.splitlines() if "kernel-resource-usage" not in ln)
+        if verbose and rest.strip():
+            print(rest, file=sys.stderr)
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))

@@ -668,8 +668,13 @@ int fqd_collapse_received(fqd_ctx *c, const uint32_t *weights, const uint64_t *s
             lb++;
         while ((1u << sb) < n_seg)
             sb++;
-        if (known && lb + sb <= 32 && lb < 32)
+        if (known && n_seg <= 8 && lb + sb <= 32 && lb < 32) {
             ids.packed_bits = lb;
+            // empty segments share their successor's first row: ">=" then counts them all at once
+            uint32_t *row[7] = {&ids.row1, &ids.row2, &ids.row3, &ids.row4, &ids.row5, &ids.row6, &ids.row7};
+            for (uint32_t s = 1; s < n_seg; s++)
+                *row[s - 1] = rows32[s];
+        }
     }
     return collapse_impl(c, weights, mem, ids, id_limit, n_unique);
 }

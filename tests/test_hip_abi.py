@@ -43,3 +43,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(base, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), (base, f)
+
+
+def test_hot_kernels_do_not_spill_to_scratch():
+    """The build records what the compiler reports per kernel (-Rpass-analysis=kernel-resource-usage).
+    Every hand-written kernel of the hot path must keep its state in registers/LDS: scratch memory
+    costs an HBM round trip per access. Allowed: the three kernels that hold the banded-DP rows of
+    the edit predicate in per-thread arrays (single calls / edit verification), and rocPRIM's own."""
+    from fastqdedup_amd.build import build, kernel_resources
+    build()
+    res = kernel_resources()
+    assert len(res) > 50
+    allowed = ("pairs_within_kernel", "contains_kernel", "edit_verify_kernel", "rocprim")
+    ours = {k: v for k, v in res.items() if "rocprim" not in k}
+    assert any("grouped_candidates_kernel" in k for k in ours) and any("pack_kernel" in k for k in ours)
+    spilling = [k for k, v in ours.items()
+                if v.get("ScratchSize [bytes/lane]", 0) and not any(a in k for a in allowed)]
+    assert not spilling, spilling
