@@ -237,8 +237,8 @@ def main():
         "dissect_round_kernel": E * 8,
     }
     rocprof_name = {"part_hist_kernel<1>": "part_hist_kernel<true>", "part_hist_kernel<2>": "part_hist_kernel<false>",
-                    "part_scatter_kernel<1>": "part_scatter_kernel<true>",
-                    "part_scatter_kernel<2>": "part_scatter_kernel<false>",
+                    "part_scatter_kernel<1>": "part_scatter_kernel<true",
+                    "part_scatter_kernel<2>": "part_scatter_kernel<false",
                     "dissect_round_kernel": "_round_kernel" if wl["method"] == "directional" else "adjacency_edges"}
     if kern.get("gp_hist_kernel", (0, 0))[1]:
         # the sort-free search pass ran: the FQD_K_PAIRS slot timed grouped_candidates_kernel

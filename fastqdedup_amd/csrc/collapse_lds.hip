@@ -88,7 +88,7 @@ __global__ __launch_bounds__(fqd_partition::THREADS) void part_hist_kernel(Recor
     fqd_partition::hist_body<RecordPolicy, LEVEL1>(src, seg_start, tile_start, n_seg, shift, n_bins, hist);
 }
 
-template <bool LEVEL1>
+template <bool LEVEL1, uint32_t MAXB>
 __global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter_kernel(RecordPolicy::Source src,
                                                                               const uint32_t *__restrict__ seg_start,
                                                                               const uint32_t *__restrict__ tile_start,
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter_kernel(Re
                                                                               uint32_t *__restrict__ cursor,
                                                                               uint4 *__restrict__ out)
 {
-    fqd_partition::scatter_body<RecordPolicy, LEVEL1>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out);
+    fqd_partition::scatter_body<RecordPolicy, LEVEL1, MAXB>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out);
 }
 
 __global__ void tile_starts_kernel(const uint32_t *__restrict__ seg_start, uint32_t n_seg,
@@ -307,12 +307,16 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
         return hipErrorInvalidValue;
     const RecordPolicy::Source src{hashes, reinterpret_cast<const uint4 *>(in), kw, len, packed};
     uint4 *out4 = reinterpret_cast<uint4 *>(out);
-    if (level1)
-        part_scatter_kernel<true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg,
-                                                                                shift, n_bins, cursor, out4);
-    else
-        part_scatter_kernel<false><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg,
-                                                                                 shift, n_bins, cursor, out4);
+    // few bins (the usual 256): small bin tables, one more workgroup per CU
+#define FQD_SCATTER(L1, MB)                                                                                    \
+    part_scatter_kernel<L1, MB><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, \
+                                                                              shift, n_bins, cursor, out4)
+    if (n_bins <= 256) {
+        if (level1) FQD_SCATTER(true, 256); else FQD_SCATTER(false, 256);
+    } else {
+        if (level1) FQD_SCATTER(true, fqd_partition::MAX_BINS); else FQD_SCATTER(false, fqd_partition::MAX_BINS);
+    }
+#undef FQD_SCATTER
     return hipGetLastError();
 }
 

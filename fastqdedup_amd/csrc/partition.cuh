@@ -85,7 +85,7 @@ __device__ __forceinline__ void hist_body(const typename Policy::Source &src, co
 
 // LEVEL1: cursor = inclusive scan of the (bin x tile) count matrix. Level 2: cursor[seg * n_bins + b]
 // = next free position of that bucket (one atomic per (tile, bin)).
-template <class Policy, bool LEVEL1>
+template <class Policy, bool LEVEL1, uint32_t MAXB = MAX_BINS>
 __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
                                              const uint32_t *__restrict__ seg_start,
                                              const uint32_t *__restrict__ tile_start, uint32_t n_seg, uint32_t shift,
@@ -93,9 +93,12 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
                                              typename Policy::Item *__restrict__ out)
 {
     using Item = typename Policy::Item;
-    __shared__ uint32_t s_hist[MAX_BINS];   // tile count per bin
-    __shared__ uint32_t s_off[MAX_BINS];    // first tile-local position of the bin
-    __shared__ uint32_t s_base[MAX_BINS];   // global position of the bin's run, minus s_off
+    // MAXB bounds n_bins (the three bin tables): 256 instead of 1024 is one more workgroup per CU.
+    // (Halving the staging area as well -- two phases, 21 KB, twice the workgroups -- changed
+    // nothing: the kernel is bound by the write efficiency of its 128-byte runs, not by occupancy.)
+    __shared__ uint32_t s_hist[MAXB];   // tile count per bin
+    __shared__ uint32_t s_off[MAXB];    // first tile-local position of the bin
+    __shared__ uint32_t s_base[MAXB];   // global position of the bin's run, minus s_off
     __shared__ uint32_t s_wave[THREADS / 64];
     __shared__ Item s_stage[TILE];
     __shared__ uint16_t s_stage_bin[TILE];
