@@ -38,6 +38,7 @@ constexpr uint32_t DD_EMPTY = 0xFFFFFFFFu;
 // (4 B instead of the 16-B record), when there is one (reads imported from other ranks have none).
 struct RecordPolicy {
     using Item = uint4;
+    static constexpr uint32_t EPT = 8;          // 2048-record tiles
     struct Source {
         const uint32_t *hashes;   // level 1 only, may be NULL
         const uint4 *in;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter_kernel(Re
 __global__ void tile_starts_kernel(const uint32_t *__restrict__ seg_start, uint32_t n_seg,
                                    uint32_t *__restrict__ tile_start)
 {
-    fqd_partition::tile_starts_body(seg_start, n_seg, tile_start);
+    fqd_partition::tile_starts_body<fqd_partition::THREADS * RecordPolicy::EPT>(seg_start, n_seg, tile_start);
 }
 
 __device__ __forceinline__ uint32_t rec_tag(const uint4 &v)
@@ -320,7 +321,7 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
     return hipGetLastError();
 }
 
-uint32_t part_tile_size() { return fqd_partition::TILE; }
+uint32_t part_tile_size() { return fqd_partition::THREADS * RecordPolicy::EPT; }
 
 hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                 hipStream_t st)

@@ -25,6 +25,7 @@ constexpr uint32_t GP_ECAP = 1024;      // edges buffered per block of the verif
 // hash array (uid = position); level 2 reads level-1's items. The key is the hash.
 struct PairPolicy {
     using Item = uint2;
+    static constexpr uint32_t EPT = 16;         // 4096-pair tiles
     struct Source {
         const uint32_t *hashes;   // level 1
         const uint2 *in;          // level 2
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(fqd_partition::THREADS) void gp_scatter_kernel(Pair
 __global__ void gp_tile_starts_kernel(const uint32_t *__restrict__ seg_start, uint32_t n_seg,
                                       uint32_t *__restrict__ tile_start)
 {
-    fqd_partition::tile_starts_body(seg_start, n_seg, tile_start);
+    fqd_partition::tile_starts_body<fqd_partition::THREADS * PairPolicy::EPT>(seg_start, n_seg, tile_start);
 }
 
 __global__ void gp_matrix_starts_kernel(const uint32_t *__restrict__ matrix_incl, uint32_t n_bins, uint32_t n_tiles,
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
 
 namespace fqd {
 
-uint32_t group_tile_size() { return fqd_partition::TILE; }
+uint32_t group_tile_size() { return fqd_partition::THREADS * PairPolicy::EPT; }
 uint32_t group_cand_lists() { return GP_LISTS; }
 uint32_t group_max_bins() { return fqd_partition::MAX_BINS; }
 
