@@ -9,12 +9,15 @@ Two plans:
 ``segment-routed`` (Hamming; the default). Per-rank work and traffic stay constant as
 ranks are added (weak scaling), except one all-gather of the edge list (8 B/edge):
 
-  1. geometry: 3 words/rank all-gather + all-reduce(MAX) of the symbol table.
+  1. geometry: 2 words/rank all-gather; fixed-length keys are packed at once with the DNA
+     alphabet and a one-word all-reduce says whether anybody met another byte (only then are
+     the keys scanned and the symbol tables merged with a 128-byte all-reduce(MAX)).
   2. all-to-all(v) of packed reads by ``owner = hash(segment 0 of the key) mod G``
      (pigeonhole segments of the d+1 split). All copies of a key meet on one rank, which
      collapses them into ITS rows of the job-wide unique table (uid = rank base + row) --
      and every pair of keys agreeing on segment 0 is already together, so search pass 0
-     is rank-local.
+     is rank-local. 16 bytes per read on the wire for keys of <= 32 nt: the read's index on
+     its rank rides in the record's padding word.
   3. for each further segment s: all-to-all(v) of (record, uid) by
      ``hash(segment s) mod G``; search pass s runs on the received rows. A pair is
      emitted in the first segment it agrees on, so every edge appears once, somewhere.
