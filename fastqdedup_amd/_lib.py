@@ -43,7 +43,7 @@ EXPORTS = [
     "fqd_collapse", "fqd_find_edges", "fqd_components", "fqd_dissect", "fqd_cluster",
     "fqd_set_id_window", "fqd_get_kept_count", "fqd_get_kept_read_ids", "fqd_get_unique_table", "fqd_export_packed", "fqd_export_packed_by_owner", "fqd_import_packed",
     "fqd_export_packed_by_segment", "fqd_export_unique_by_segment", "fqd_gather_unique",
-    "fqd_find_edges_segments", "fqd_edge_labels", "fqd_list_kept_except", "fqd_set_owner_rule", "fqd_declare_distinct_keys", "fqd_collapse_received",
+    "fqd_find_edges_segments", "fqd_edge_labels", "fqd_list_kept_except", "fqd_set_owner_rule", "fqd_declare_distinct_keys", "fqd_collapse_received", "fqd_set_kept_output",
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
     "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_edge_stats", "fqd_synth_keys",
 ]
@@ -100,6 +100,7 @@ def load() -> C.CDLL:
                                                C.c_int]
     L.fqd_set_owner_rule.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.fqd_declare_distinct_keys.argtypes = [vp]
+    L.fqd_set_kept_output.argtypes = [vp, vp, C.c_uint64]
     L.fqd_collapse_received.argtypes = [vp, vp, u64p, u64p, C.c_uint32, C.c_uint64, C.c_int, u64p]
     L.fqd_gather_unique.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_int]
     L.fqd_find_edges_segments.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, u64p]
@@ -414,6 +415,17 @@ class Context:
                                                id0.ctypes.data_as(C.POINTER(C.c_uint64)), len(id0),
                                                int(id_limit), wm if weights is not None else DEVICE, C.byref(nu)))
         return nu.value
+
+    def set_kept_output(self, out=None):
+        """Have the next dissection write its kept-id list straight into `out` (device int64/uint64
+        tensor with room for any outcome); None switches it off."""
+        if out is None:
+            self._ck(self._L.fqd_set_kept_output(self._h, None, 0))
+            return
+        p, m, _k = _ptr_mem(out)
+        if m != DEVICE:
+            raise ValueError("kept output buffer must be a device tensor")
+        self._ck(self._L.fqd_set_kept_output(self._h, p, int(out.numel())))
 
     def declare_distinct_keys(self):
         """The imported rows hold pairwise distinct keys (rows of other ranks' collapsed tables)."""

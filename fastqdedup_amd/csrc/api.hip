@@ -6,6 +6,16 @@
 
 namespace {
 
+int upload_lut(fqd_ctx *c, const uint8_t *lut256)
+{
+    if (c->lut_valid && !memcmp(c->lut_on_device, lut256, 256))
+        return FQD_OK;
+    memcpy(c->lut_on_device, lut256, 256);
+    HIP_TRY(c, hipMemcpyAsync(c->d_lut.p, c->lut_on_device, 256, hipMemcpyHostToDevice, c->st));
+    c->lut_valid = true;
+    return FQD_OK;
+}
+
 void build_alphabet(fqd_ctx *c, const uint8_t *present128, uint8_t *lut256)
 {
     memset(lut256, 0xFF, 256);
@@ -327,7 +337,7 @@ int fqd_configure(fqd_ctx *c, const uint8_t *present128, uint32_t max_len, int r
     uint8_t lut[256];
     build_alphabet(c, c->forced_present, lut);
     FQD_TRY(set_geometry(c, max_len, ragged));
-    HIP_TRY(c, hipMemcpyAsync(c->d_lut.p, lut, 256, hipMemcpyHostToDevice, c->st));
+    FQD_TRY(upload_lut(c, lut));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     c->stage = ST_EMPTY;
     return FQD_OK;
@@ -421,7 +431,7 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
     for (int attempt = 0;; attempt++) {
         build_alphabet(c, present, lut);
         FQD_TRY(set_geometry(c, max_len, ragged));
-        HIP_TRY(c, hipMemcpyAsync(c->d_lut.p, lut, 256, hipMemcpyHostToDevice, c->st));
+        FQD_TRY(upload_lut(c, lut));
         const KeyShape sh = c->ks;
         HIP_TRY(c, c->recs.reserve((size_t)n * sh.stride * 4 + 16));
         HIP_TRY(c, c->hashes.reserve((size_t)n * 4 + 16));

@@ -94,6 +94,12 @@ struct fqd_ctx {
     fqd_shape shape{};
     KeyShape ks{};
     DevBuf d_lut, d_ctr32, d_ctr64, d_present, d_stats;
+    uint8_t lut_on_device[256];    // what d_lut holds (a pageable H2D copy per pack call is a host stall)
+    bool lut_valid = false;
+    uint64_t *kept_out = nullptr;  // fqd_set_kept_output: the kept-id list is written here directly
+    uint64_t kept_out_cap = 0;
+    bool kept_in_out = false;      // the current kept list lives in kept_out, not in kept_ids_sorted
+    bool kept_list_lost = false;   // ... and kept_out has been withdrawn since
 
     // stage 1
     uint64_t n = 0;

@@ -62,6 +62,8 @@ static int list_kept(fqd_ctx *c, int method)
     const uint64_t U = c->U;
     c->n_kept = 0;
     c->n_listed = 0;
+    c->kept_in_out = false;
+    c->kept_list_lost = false;
     if (!U)
         return FQD_OK;
     // First-holder ids are distinct and bounded (by the id window, or by id_limit): when that
@@ -85,7 +87,14 @@ static int list_kept(fqd_ctx *c, int method)
                                           c->ucounts.as<uint32_t>(), c->blocked.as<uint32_t>(),
                                           c->root_taint.as<uint8_t>(),
                                           c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
-        HIP_TRY(c, c->kept_ids_sorted.reserve(std::min(window, U) * 8 + 16));
+        // the list goes straight into the caller's buffer when one was announced and is large enough
+        // for any outcome (fqd_set_kept_output): no copy, no extra round trip afterwards
+        c->kept_in_out = c->kept_out && c->kept_out_cap >= std::min(window, U);
+        uint64_t *list_out = c->kept_out;
+        if (!c->kept_in_out) {
+            HIP_TRY(c, c->kept_ids_sorted.reserve(std::min(window, U) * 8 + 16));
+            list_out = c->kept_ids_sorted.as<uint64_t>();
+        }
         const uint32_t blocks = fqd::window_blocks(window);
         uint32_t listed = 0;
         if (blocks) {
@@ -94,7 +103,7 @@ static int list_kept(fqd_ctx *c, int method)
             HIP_TRY(c, fqd::launch_window_count(c->stage_c.as<uint8_t>(), window, c->kept_u32.as<uint32_t>(), c->st));
             FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), blocks));
             HIP_TRY(c, fqd::launch_window_emit(c->stage_c.as<uint8_t>(), window, c->kept_scan.as<uint32_t>(), base,
-                                               c->kept_ids_sorted.as<uint64_t>(), c->st));
+                                               list_out, c->st));
             HIP_TRY(c, hipMemcpyAsync(&listed, c->kept_scan.as<uint32_t>() + (blocks - 1), 4, hipMemcpyDeviceToHost,
                                       c->st));
         }
@@ -115,6 +124,7 @@ static int list_kept(fqd_ctx *c, int method)
                                       c->kept.as<uint8_t>(), c->kept_u32.as<uint32_t>(), nullptr, 0,
                                       c->ucounts.as<uint32_t>(), c->blocked.as<uint32_t>(), c->root_taint.as<uint8_t>(),
                                       c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+    c->kept_in_out = false;
     FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), U));
     uint32_t nk = 0;
     HIP_TRY(c, hipMemcpyAsync(&nk, c->kept_scan.as<uint32_t>() + (U - 1), 4, hipMemcpyDeviceToHost, c->st));
@@ -252,7 +262,25 @@ int fqd_get_kept_read_ids(fqd_ctx *c, uint64_t *out, int mem)
     FQD_TRY(bind(c));
     if (c->stage < ST_KEPT)
         return fail(c, FQD_E_STATE, "no dissection result yet");
+    if (c->kept_list_lost)
+        return fail(c, FQD_E_STATE, "the kept list was written to a caller's buffer that has been withdrawn");
+    if (c->kept_in_out) {
+        if (out == c->kept_out && mem == FQD_DEVICE)
+            return FQD_OK;            // already there
+        return from_device(c, out, c->kept_out, (size_t)c->n_listed, mem);
+    }
     return from_device(c, out, c->kept_ids_sorted.p, (size_t)c->n_listed, mem);
+}
+
+int fqd_set_kept_output(fqd_ctx *c, uint64_t *out_device, uint64_t capacity)
+{
+    c->kept_out = out_device;
+    c->kept_out_cap = out_device ? capacity : 0;
+    if (!out_device && c->kept_in_out) {
+        c->kept_in_out = false;      // the list lived in the buffer we are letting go of
+        c->kept_list_lost = true;
+    }
+    return FQD_OK;
 }
 
 int fqd_get_unique_table(fqd_ctx *c, uint64_t *first_ids, uint32_t *counts, uint32_t *labels, uint8_t *kept, int mem)

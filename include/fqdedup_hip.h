@@ -136,6 +136,11 @@ int fqd_set_id_window(fqd_ctx *ctx, uint64_t lo, uint64_t hi);
 int fqd_get_kept_count(fqd_ctx *ctx, uint64_t *n_kept, uint64_t *n_listed);
 /* n_listed ids, ascending: the first holder of every kept key (inside the id window). */
 int fqd_get_kept_read_ids(fqd_ctx *ctx, uint64_t *out, int mem);
+/* Optional: announce a DEVICE buffer of `capacity` ids BEFORE fqd_dissect / fqd_cluster; when it can
+ * hold any outcome (capacity >= min(id range, unique keys)) the ascending list is written there
+ * directly and fqd_get_kept_read_ids(ctx, that same pointer, FQD_DEVICE) has nothing left to
+ * copy. NULL switches it off (do that before the buffer goes away). */
+int fqd_set_kept_output(fqd_ctx *ctx, uint64_t *out_device, uint64_t capacity);
 /* Per unique key u in [0, n_unique): first holder, count, component label
  * (= smallest u of the component), kept flag. Any pointer may be NULL. */
 int fqd_get_unique_table(fqd_ctx *ctx, uint64_t *first_ids, uint32_t *counts, uint32_t *labels,

@@ -644,6 +644,34 @@ def test_fallback_paths_kept_by_sort_and_grouping_by_sort(F, monkeypatch):
     assert outs[0][2] == outs[1][2] and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_kept_list_written_into_the_callers_buffer(F):
+    """cluster_keys(kept_out=device tensor): the ascending kept-id list is produced in the caller's
+    buffer (fqd_set_kept_output), same ids as the default; once the buffer is withdrawn the context
+    says so instead of handing out a stale list."""
+    import torch
+    from fastqdedup_amd.synth import synth_keys
+    n, L = 100_000, 32
+    host = synth_keys(n, L, 8, 71, sub_rate=5e-3, n_rate=3e-4).reshape(-1)
+    want = F.cluster_keys(host, key_len=L, context=F.Context(0))
+    ctx = F.Context(0)
+    dev = torch.from_numpy(host.copy()).to("cuda:0")
+    buf = torch.full((n,), -1, dtype=torch.int64, device="cuda:0")
+    got = F.cluster_keys(dev, key_len=L, context=ctx, kept_out=buf)
+    assert got.n_kept == want.n_kept
+    assert np.array_equal(buf[: got.n_kept].cpu().numpy().astype(np.uint64), want.kept_read_ids)
+    assert int(buf[got.n_kept].item()) == -1                      # nothing written past the list
+    with pytest.raises(RuntimeError):
+        ctx.kept_read_ids(got.n_kept)
+    small = torch.empty(16, dtype=torch.int64, device="cuda:0")   # too small to be used directly
+    ctx.set_kept_output(small)
+    try:
+        ctx.pack_keys(dev, None, L)
+        s = ctx.cluster(None, None, max_distance=1, metric=0, method=2)
+        assert np.array_equal(ctx.kept_read_ids(s["n_kept"]), want.kept_read_ids)
+    finally:
+        ctx.set_kept_output(None)
+
+
 def test_edge_labels_and_kept_except(F, oracle):
     """fqd_edge_labels (components of a caller's edge list) and fqd_list_kept_except (verdicts
     computed elsewhere) against the plain single-context path."""
