@@ -279,6 +279,15 @@ def main():
                 "note": "keys start in pageable host memory, kept ids end in host memory"}
         del host_keys
 
+    # whole-job algorithmic traffic as SURVEY.md section 8d defines it (ALG_BYTES_V1): pack + collapse
+    # + (d+1) search passes + edges + dissection, with N, U, E of this run
+    b_key_v1 = 8 * ((L + 31) // 32 + (L + 63) // 64)
+    alg_v1 = (n_total * (L + 2 * b_key_v1 + 24) + U * (b_key_v1 + 8) + nseg * U * (2 * b_key_v1 + 24) + 16 * E
+              + U * (b_key_v1 + 13))
+    job_gbs = alg_v1 / (ms_per_step * 1e-3) / 1e9
+    job_roofline = {"alg_bytes": int(alg_v1), "formula": "ALG_BYTES_V1 (SURVEY.md 8d)", "achieved": round(job_gbs, 1),
+                    "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(job_gbs / (HBM_PEAK_GBS * world), 5)}
+
     out = {
         "metric": "reads/sec clustered (Hamming<=1, 150 bp)", "value": round(value, 1), "unit": "reads/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -294,6 +303,7 @@ def main():
         "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_sum.items()},
         "record_bytes": sh.stride_words * 4, "planes": sh.planes,
         "roofline": roofline,
+        "job_roofline": job_roofline,
         "kernels": kernels,
         "host_input": pcie,
     }
