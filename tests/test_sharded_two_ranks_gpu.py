@@ -139,3 +139,58 @@ def test_ranks_on_one_gpu(oracle, shape, plan):
         assert (n_clusters, n_unique, n_kept, n_reads) == (want["n_clusters"], want["n_unique"],
                                                            len(want_ids), n)
     assert sorted(union) == want_ids
+
+
+def _big_worker(rank, world, port, n_per_rank, L, seed, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fastqdedup_amd as F
+        from fastqdedup_amd.sharded import HipBackend, cluster_keys_sharded
+
+        gpu = torch.device("cuda", 0)
+        ctx = F.Context(0)
+        keys = torch.empty(n_per_rank * L, dtype=torch.uint8, device=gpu)
+        ctx.synth_keys(keys, world * n_per_rank, rank * n_per_rank, n_per_rank, L, L, seed)
+        res = cluster_keys_sharded(HipBackend(ctx, gpu), keys, None, L, max_distance=1, method="directional",
+                                   comm_via_host=True)
+        kept = res.kept_read_ids
+        # a digest instead of millions of ids through the queue
+        q.put((rank, int(kept.shape[0]), int(kept.sum().item()), int((kept * (kept % 1009 + 1)).sum().item()),
+               res.n_clusters, res.n_unique, res.n_kept, bool((kept[1:] > kept[:-1]).all().item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_at_scale_equal_the_single_gpu_job():
+    """2 x 3 M reads through the segment-routed plan (LDS collapse of received reads with carried
+    ids, partitioned search passes, binned candidate lists -- the paths large jobs take) against
+    the plain single-GPU path on the same 6 M reads."""
+    import fastqdedup_amd as F
+    world, n_per_rank, L, seed = 2, 3_000_000, 32, 1777
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_big_worker, args=(r, world, port, n_per_rank, L, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+
+    gpu = torch.device("cuda", 0)
+    one = F.Context(0)
+    n = world * n_per_rank
+    keys = torch.empty(n * L, dtype=torch.uint8, device=gpu)
+    one.synth_keys(keys, n, 0, n, L, L, seed)
+    want = F.cluster_keys(keys, key_len=L, max_distance=1, method="directional", context=one)
+    ids = torch.from_numpy(want.kept_read_ids.astype(np.int64))
+    for rank, count, total, mixed, n_clusters, n_unique, n_kept, ascending in got:
+        mine = ids[(ids >= rank * n_per_rank) & (ids < (rank + 1) * n_per_rank)]
+        assert ascending
+        assert (count, total, mixed) == (int(mine.shape[0]), int(mine.sum().item()),
+                                         int((mine * (mine % 1009 + 1)).sum().item())), rank
+        assert (n_clusters, n_unique, n_kept) == (want.n_clusters, want.n_unique, want.n_kept)
