@@ -120,6 +120,36 @@ def test_against_oracle_synthetic(F, ctx, oracle, n, L, umi, d, sub, nr):
         assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), (m, n, L, d)
 
 
+def test_large_path_sweep_against_oracle(F, oracle):
+    """Random jobs big enough for the paths large inputs take -- LDS collapse (n >= 32768, keys of
+    <= 32 nt), partitioned search passes (>= 65536 unique keys), kept list by window compaction,
+    closed-form directional -- over key lengths, alphabets, distances 0..3, the three dissection
+    rules and quality weights. Every job must give the oracle's kept ids and counters."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    rng = np.random.default_rng(20261004)
+    methods = list(METHODS)
+    for job in range(14):
+        L = int(rng.choice([12, 16, 20, 27, 32, 33, 48, 64, 90]))
+        n = int(rng.integers(90_000, 320_000))
+        umi = int(rng.choice([L, L, max(4, L // 3)]))
+        d = int(rng.choice([0, 1, 1, 2, 3]))
+        sub = float(rng.choice([1e-3, 4e-3, 1e-2]))
+        nr = float(rng.choice([0.0, 3e-4]))
+        copies = int(rng.choice([1, 2, 4, 9]))
+        keys = synth_keys(n, L, umi, 9000 + job, copies=copies, sub_rate=sub, n_rate=nr)
+        if job % 4 == 3:                       # an alphabet that needs a scan: lower-case symbols too
+            low = rng.random(n) < 0.01
+            keys[low] = np.char.lower(keys[low].view("S1")).view(np.uint8)
+        raw = np.ascontiguousarray(keys).reshape(-1)
+        w = None if job % 3 else rng.choice(np.array([0, 1, 1, 1, 3], dtype=np.uint32), size=n)
+        m = methods[job % 3]
+        got = F.cluster_keys(raw, key_len=L, weights=w, max_distance=d, method=m, context=F.Context(0))
+        want = oracle.dedup(raw, fixed_offsets(n, L), w, max_distance=d, method=m)
+        tag = (job, n, L, umi, d, m, copies)
+        assert (got.n_unique, got.n_clusters) == (want["n_unique"], want["n_clusters"]), tag
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), tag
+
+
 def test_edit_d1_equal_length_matches_oracle(F, ctx, oracle):
     """Levenshtein <= 1 on equal-length keys == Hamming <= 1 (BASELINE config 5 shape)."""
     from fastqdedup_amd.synth import fixed_offsets, synth_keys
