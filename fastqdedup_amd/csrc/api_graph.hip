@@ -81,7 +81,7 @@ static int list_kept(fqd_ctx *c, int method)
         HIP_TRY(c, c->stage_c.reserve(window + 16));
         if (window)
             HIP_TRY(c, hipMemsetAsync(c->stage_c.p, 0, window, c->st));
-        HIP_TRY(c, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
+        KTIME(c, FQD_K_KEPT_FLAGS, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
                                           c->state.as<uint8_t>(), c->ufirst.as<uint64_t>(), c->id_lo, c->id_hi, U,
                                           c->kept.as<uint8_t>(), nullptr, c->stage_c.as<uint8_t>(), window,
                                           c->ucounts.as<uint32_t>(), c->blocked.as<uint32_t>(),
@@ -119,7 +119,7 @@ static int list_kept(fqd_ctx *c, int method)
                     (unsigned long long)c->id_limit, total, listed);
         return FQD_OK;
     }
-    HIP_TRY(c, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
+    KTIME(c, FQD_K_KEPT_FLAGS, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
                                       c->state.as<uint8_t>(), c->ufirst.as<uint64_t>(), c->id_lo, c->id_hi, U,
                                       c->kept.as<uint8_t>(), c->kept_u32.as<uint32_t>(), nullptr, 0,
                                       c->ucounts.as<uint32_t>(), c->blocked.as<uint32_t>(), c->root_taint.as<uint8_t>(),

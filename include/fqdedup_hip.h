@@ -273,6 +273,7 @@ int fqd_stage_times(fqd_ctx *ctx, float *ms /* FQD_T_COUNT */, uint32_t *launche
 #define FQD_K_GROUP_HIST    14   /* both levels of the (hash, uid) partition of a search pass */
 #define FQD_K_GROUP_SCATTER 15
 #define FQD_K_VERIFY        16   /* verification of the candidate pairs of a grouped search pass */
+#define FQD_K_KEPT_FLAGS    17   /* verdict per unique key + the byte map of kept first-holder ids */
 #define FQD_K_COUNT         20
 int fqd_kernel_times(fqd_ctx *ctx, float *ms /* FQD_K_COUNT */, uint32_t *launches /* FQD_K_COUNT */,
                      int reset);
