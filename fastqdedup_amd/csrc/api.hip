@@ -136,11 +136,22 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
     HIP_TRY(c, c->ld_unique.reserve((size_t)n_buckets * 4 + 16));
     HIP_TRY(c, c->ld_unique_incl.reserve((size_t)n_buckets * 4 + 16));
     HIP_TRY(c, c->ld_small.reserve(4096 * 4));
+    // Level 2 in SLAB mode: every bucket gets a fixed slab of 1.5 x the mean + 64 slots and an atomic
+    // cursor, so no histogram pass over the 16-byte records is needed (0.2 ms of 1.85). A key with
+    // hundreds of copies overfills its slab: the scatter notices, and level 2 runs again with the
+    // exact histogram (and stays exact for this context).
+    uint32_t slab_cap = 0;
+    if (B2 && !c->slab_off && !getenv("FQD_LDS_NO_SLABS")) {
+        slab_cap = (uint32_t)(((n >> B) * 3 / 2 + 64 + 3) & ~3ull);
+        if ((uint64_t)slab_cap * n_buckets >= 0xFFFFFF00ull)
+            slab_cap = 0;
+    }
+    const uint64_t slots = slab_cap ? (uint64_t)slab_cap * n_buckets : n;
     HIP_TRY(c, c->ld_part.reserve(n * 16 + 16));
-    HIP_TRY(c, c->ld_tmp_rec.reserve(n * 16 + 16));   // level-2 output first, then the dedupe's tmp
-    HIP_TRY(c, c->ld_part2.reserve(n * 16 + 16));
-    HIP_TRY(c, c->ld_tmp_count.reserve(n * 4 + 16));
-    HIP_TRY(c, c->ld_tmp_first.reserve(n * 4 + 16));
+    HIP_TRY(c, c->ld_tmp_rec.reserve(slots * 16 + 16));
+    HIP_TRY(c, c->ld_part2.reserve(slots * 16 + 16));
+    HIP_TRY(c, c->ld_tmp_count.reserve(slots * 4 + 16));
+    HIP_TRY(c, c->ld_tmp_first.reserve(slots * 4 + 16));
     // small device tables: [0] seg_start1 (2) | [8] tile_start1 (2) | [16] start1 (257) | [512] tile_start2 (257)
     uint32_t *small = c->ld_small.as<uint32_t>();
     uint32_t *seg1 = small, *tiles1_d = small + 8, *start1 = small + 16, *tiles2_d = small + 512;
@@ -166,32 +177,49 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
                                         tiles1, 32 - B1, bins1, kw, sh.max_len, c->ld_matrix_incl.as<uint32_t>(),
                                         c->ld_part.as<uint32_t>(), c->st, packed));
     const uint32_t *parted = c->ld_part.as<uint32_t>();
-    if (B2 == 0) {
-        HIP_TRY(c, hipMemcpyAsync(c->ld_start.p, start1, ((size_t)bins1 + 1) * 4, hipMemcpyDeviceToDevice, c->st));
-    } else {
-        // ---- level 2: every part into 2^B2 buckets by the next B2 hash bits
-        HIP_TRY(c, fqd::launch_tile_starts(start1, bins1, tiles2_d, c->st));
-        HIP_TRY(c, hipMemsetAsync(c->ld_hist.p, 0, (size_t)n_buckets * 4, c->st));
-        KTIME(c, FQD_K_PART_HIST2, fqd::launch_part_hist(false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1, max_tiles2,
-                                         32 - B, bins2, kw, sh.max_len, c->ld_hist.as<uint32_t>(), c->st));
-        FQD_TRY(scan_u32(c, c->ld_hist.as<uint32_t>(), c->ld_hist_incl.as<uint32_t>(), n_buckets));
-        HIP_TRY(c, fqd::launch_bucket_starts(c->ld_hist_incl.as<uint32_t>(), n_buckets, c->ld_start.as<uint32_t>(),
-                                             c->ld_cursor.as<uint32_t>(), c->st));
-        KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1,
-                                            max_tiles2, 32 - B, bins2, kw, sh.max_len, c->ld_cursor.as<uint32_t>(),
-                                            c->ld_part2.as<uint32_t>(), c->st));
-        parted = c->ld_part2.as<uint32_t>();
-    }
-    FQD_TRY(zero_ctr32(c, C_BAD));
-    KTIME(c, FQD_K_DEDUPE, fqd::launch_bucket_dedupe(parted, c->ld_start.as<uint32_t>(), n_buckets, d_w,
-                                         c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(),
-                                         c->ld_tmp_first.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
-                                         c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
-    FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
     uint32_t U32 = 0, overflow = 0;
-    HIP_TRY(c, hipMemcpyAsync(&U32, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 4, hipMemcpyDeviceToHost,
-                              c->st));
-    FQD_TRY(read_ctr32(c, C_BAD, &overflow));
+    for (;;) {
+        const uint32_t *bucket_end = nullptr;
+        FQD_TRY(zero_ctr32(c, C_BAD));
+        if (B2 == 0) {
+            HIP_TRY(c, hipMemcpyAsync(c->ld_start.p, start1, ((size_t)bins1 + 1) * 4, hipMemcpyDeviceToDevice, c->st));
+        } else {
+            // ---- level 2: every part into 2^B2 buckets by the next B2 hash bits
+            HIP_TRY(c, fqd::launch_tile_starts(start1, bins1, tiles2_d, c->st));
+            if (slab_cap) {
+                HIP_TRY(c, fqd::launch_slab_starts(n_buckets, slab_cap, c->ld_start.as<uint32_t>(),
+                                                   c->ld_cursor.as<uint32_t>(), c->st));
+                bucket_end = c->ld_cursor.as<uint32_t>();
+            } else {
+                HIP_TRY(c, hipMemsetAsync(c->ld_hist.p, 0, (size_t)n_buckets * 4, c->st));
+                KTIME(c, FQD_K_PART_HIST2, fqd::launch_part_hist(false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1, max_tiles2,
+                                                 32 - B, bins2, kw, sh.max_len, c->ld_hist.as<uint32_t>(), c->st));
+                FQD_TRY(scan_u32(c, c->ld_hist.as<uint32_t>(), c->ld_hist_incl.as<uint32_t>(), n_buckets));
+                HIP_TRY(c, fqd::launch_bucket_starts(c->ld_hist_incl.as<uint32_t>(), n_buckets, c->ld_start.as<uint32_t>(),
+                                                     c->ld_cursor.as<uint32_t>(), c->st));
+            }
+            KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1,
+                                                max_tiles2, 32 - B, bins2, kw, sh.max_len, c->ld_cursor.as<uint32_t>(),
+                                                c->ld_part2.as<uint32_t>(), c->st, IdSource(), slab_cap,
+                                                c->d_ctr32.as<uint32_t>() + C_BAD));
+            parted = c->ld_part2.as<uint32_t>();
+        }
+        KTIME(c, FQD_K_DEDUPE, fqd::launch_bucket_dedupe(parted, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
+                                             c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(),
+                                             c->ld_tmp_first.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
+                                             c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+        FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
+        HIP_TRY(c, hipMemcpyAsync(&U32, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 4, hipMemcpyDeviceToHost,
+                                  c->st));
+        FQD_TRY(read_ctr32(c, C_BAD, &overflow));
+        if (slab_cap && (overflow & 2u)) {
+            // a slab was too small (a key with hundreds of copies): once more with exact bucket sizes
+            c->slab_off = true;
+            slab_cap = 0;
+            continue;
+        }
+        break;
+    }
     if (overflow)
         return FQD_OK;  // some bucket held more distinct keys than the LDS table: sort-based path
     const uint64_t U = U32;

@@ -104,6 +104,7 @@ struct fqd_ctx {
     // stage 1
     uint64_t n = 0;
     DevBuf in_bytes, in_offsets, recs, lens, hashes, owners;
+    bool slab_off = false;         // LDS collapse: a slab of level 2 overflowed once, use exact bucket sizes
     bool hashes_valid = false;     // `hashes` holds the record hashes of the packed reads (lazy after an import)
     fqd::OwnerRule owner_rule;     // fqd_set_owner_rule: fqd_pack_keys also writes each read's owner rank
     fqd::OwnerRule owners_done;    // the rule `owners` was filled with (parts == 0: not filled)

@@ -96,9 +96,24 @@ __global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter_kernel(Re
                                                                               uint32_t n_seg, uint32_t shift,
                                                                               uint32_t n_bins,
                                                                               uint32_t *__restrict__ cursor,
-                                                                              uint4 *__restrict__ out)
+                                                                              uint4 *__restrict__ out,
+                                                                              uint32_t slab_cap,
+                                                                              uint32_t *__restrict__ slab_overflow)
 {
-    fqd_partition::scatter_body<RecordPolicy, LEVEL1, MAXB>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out);
+    fqd_partition::scatter_body<RecordPolicy, LEVEL1, MAXB>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
+                                                            slab_cap, slab_overflow);
+}
+
+// slab mode of level 2: bucket b owns slots [b * cap, (b + 1) * cap); its cursor starts there
+__global__ void slab_starts_kernel(uint32_t n_buckets, uint32_t cap, uint32_t *__restrict__ bucket_start,
+                                   uint32_t *__restrict__ cursor)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_buckets)
+        return;
+    bucket_start[b] = b * cap;
+    if (b < n_buckets)
+        cursor[b] = b * cap;
 }
 
 __global__ void tile_starts_kernel(const uint32_t *__restrict__ seg_start, uint32_t n_seg,
@@ -118,6 +133,7 @@ __device__ __forceinline__ uint32_t rec_tag(const uint4 &v)
 
 __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe_kernel(
     const uint4 *__restrict__ part, const uint32_t *__restrict__ bucket_start /* n_buckets + 1 */,
+    const uint32_t *__restrict__ bucket_end /* NULL, or slab mode: where each bucket's cursor stopped */,
     const uint32_t *__restrict__ weights, uint4 *__restrict__ tmp_rec, uint32_t *__restrict__ tmp_count,
     uint32_t *__restrict__ tmp_first, uint32_t *__restrict__ bucket_unique, uint32_t *__restrict__ overflow)
 {
@@ -125,7 +141,10 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe_kernel(
     __shared__ uint32_t s_wave_tot[DD_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
-    const uint32_t lo = bucket_start[b], hi = bucket_start[b + 1];
+    const uint32_t lo = bucket_start[b];
+    uint32_t hi = bucket_start[b + 1];
+    if (bucket_end)
+        hi = min(hi, bucket_end[b]);
     for (uint32_t s = tid; s < DD_SLOTS; s += DD_THREADS)
         s_tag[s] = DD_EMPTY;
     __syncthreads();
@@ -302,7 +321,7 @@ hipError_t launch_part_hist(bool level1, const uint32_t *hashes, const uint32_t 
 hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
                                const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
-                               hipStream_t st, IdSource packed)
+                               hipStream_t st, IdSource packed, uint32_t slab_cap, uint32_t *slab_overflow)
 {
     if (n_bins > fqd_partition::MAX_BINS)
         return hipErrorInvalidValue;
@@ -311,7 +330,8 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
     // few bins (the usual 256): small bin tables, one more workgroup per CU
 #define FQD_SCATTER(L1, MB)                                                                                    \
     part_scatter_kernel<L1, MB><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, \
-                                                                              shift, n_bins, cursor, out4)
+                                                                              shift, n_bins, cursor, out4, slab_cap, \
+                                                                              slab_overflow)
     if (n_bins <= 256) {
         if (level1) FQD_SCATTER(true, 256); else FQD_SCATTER(false, 256);
     } else {
@@ -337,11 +357,18 @@ hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, u
     return hipGetLastError();
 }
 
-hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, uint32_t n_buckets,
-                                const uint32_t *weights, uint32_t *tmp_rec, uint32_t *tmp_count, uint32_t *tmp_first,
-                                uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st)
+hipError_t launch_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket_start, uint32_t *cursor, hipStream_t st)
 {
-    bucket_dedupe_kernel<<<n_buckets, DD_THREADS, 0, st>>>(reinterpret_cast<const uint4 *>(part), bucket_start, weights,
+    slab_starts_kernel<<<(n_buckets + 1 + 255) / 256, 256, 0, st>>>(n_buckets, cap, bucket_start, cursor);
+    return hipGetLastError();
+}
+
+hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec, uint32_t *tmp_count,
+                                uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st)
+{
+    bucket_dedupe_kernel<<<n_buckets, DD_THREADS, 0, st>>>(reinterpret_cast<const uint4 *>(part), bucket_start, bucket_end,
+                                                           weights,
                                                            reinterpret_cast<uint4 *>(tmp_rec), tmp_count, tmp_first,
                                                            bucket_unique, overflow);
     return hipGetLastError();

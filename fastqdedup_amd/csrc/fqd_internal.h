@@ -256,15 +256,17 @@ hipError_t launch_part_hist(bool level1, const uint32_t *hashes, const uint32_t 
 hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
                                const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
-                               hipStream_t st, IdSource packed = IdSource());
+                               hipStream_t st, IdSource packed = IdSource(), uint32_t slab_cap = 0,
+                               uint32_t *slab_overflow = nullptr);
 uint32_t part_tile_size();
 hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                 hipStream_t st);
 hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
                                 uint32_t *cursor, hipStream_t st);
-hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, uint32_t n_buckets,
-                                const uint32_t *weights, uint32_t *tmp_rec, uint32_t *tmp_count, uint32_t *tmp_first,
-                                uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);
+hipError_t launch_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket_start, uint32_t *cursor, hipStream_t st);
+hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec, uint32_t *tmp_count,
+                                uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);
 hipError_t launch_bucket_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                  const uint32_t *tmp_rec, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                  IdSource read_ids, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,

@@ -94,8 +94,12 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
                                              const uint32_t *__restrict__ seg_start,
                                              const uint32_t *__restrict__ tile_start, uint32_t n_seg, uint32_t shift,
                                              uint32_t n_bins, uint32_t *__restrict__ cursor,
-                                             typename Policy::Item *__restrict__ out)
+                                             typename Policy::Item *__restrict__ out, uint32_t slab_cap = 0,
+                                             uint32_t *__restrict__ slab_overflow = nullptr)
 {
+    // slab_cap != 0 (level 2 only): bucket k owns out[k * slab_cap, (k + 1) * slab_cap) and its cursor
+    // started at k * slab_cap -- no histogram pass told us how full it gets. A run that would cross
+    // the slab's end is dropped and *slab_overflow gets bit 1: the caller redoes the level exactly.
     using Item = typename Policy::Item;
     constexpr uint32_t EPT = Policy::EPT, TILE = THREADS * EPT;
     // MAXB bounds n_bins (the three bin tables): 256 instead of 1024 is one more workgroup per CU.
@@ -162,6 +166,13 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
             else
                 g = c ? atomicAdd(&cursor[seg * n_bins + b], c) : 0u;
             s_base[b] = g - run;
+            if (!LEVEL1 && slab_cap && c) {
+                const uint64_t end = ((uint64_t)seg * n_bins + b + 1) * slab_cap;
+                if ((uint64_t)g + c > end) {
+                    s_base[b] = 0xFFFFFFFFu;        // nothing of this bin leaves the tile
+                    atomicOr(slab_overflow, 2u);
+                }
+            }
             run += c;
         }
     }
@@ -178,8 +189,11 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
 #pragma unroll
     for (uint32_t e = 0; e < EPT; e++) {
         const uint32_t p = e * THREADS + tid;
-        if (p < count)
-            out[s_base[s_stage_bin[p]] + p] = s_stage[p];   // consecutive p of one bin: consecutive addresses
+        if (p < count) {
+            const uint32_t base = s_base[s_stage_bin[p]];
+            if (LEVEL1 || !slab_cap || base != 0xFFFFFFFFu)
+                out[base + p] = s_stage[p];   // consecutive p of one bin: consecutive addresses
+        }
     }
 }
 

@@ -150,6 +150,28 @@ def test_large_path_sweep_against_oracle(F, oracle):
         assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), tag
 
 
+def test_lds_collapse_slab_overflow_retries_exactly(F, oracle):
+    """Level 2 of the LDS collapse gives every bucket a fixed slab (no histogram pass). A key with
+    thousands of copies overfills its slab: the level must be redone with exact bucket sizes, and
+    the answer must be the oracle's -- on this job and on the next one of the same context."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    n, L = 300_000, 32
+    keys = synth_keys(n, L, L, 81, sub_rate=3e-3, n_rate=2e-4)
+    rng = np.random.default_rng(8)
+    heavy = rng.choice(n, size=4000, replace=False)
+    keys[heavy] = keys[heavy[0]]                     # one key, 4000 copies
+    keys[heavy[::9], 5] = ord("N")                   # and a few hundred near copies of it
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    ctx = F.Context(0)
+    want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=1, method="directional")
+    for _ in range(2):
+        got = F.cluster_keys(raw, key_len=L, max_distance=1, method="directional", context=ctx)
+        assert (got.n_unique, got.n_clusters) == (want["n_unique"], want["n_clusters"])
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+    plain = F.cluster_keys(np.ascontiguousarray(synth_keys(n, L, L, 82)).reshape(-1), key_len=L, context=ctx)
+    assert plain.n_unique > 0
+
+
 def test_edit_d1_equal_length_matches_oracle(F, ctx, oracle):
     """Levenshtein <= 1 on equal-length keys == Hamming <= 1 (BASELINE config 5 shape)."""
     from fastqdedup_amd.synth import fixed_offsets, synth_keys
