@@ -76,7 +76,7 @@ enum Stage { ST_EMPTY = 0, ST_PACKED = 1, ST_UNIQUE = 2, ST_EDGES = 3, ST_LABELS
 
 // small device-side words read back by the host
 enum Ctr { C_BAD = 0, C_COLLISIONS = 1, C_CHANGED = 2, C_MINLEN = 3, C_MAXLEN = 4, C_N32 = 8 };
-enum Ctr64 { C64_EDGES = 0, C64_ROOTS = 1, C64_SUM = 2, C64_STATS = 3, C64_CANDS = 4, C64_CAND_NEED = 5, C64_N = 8 };
+enum Ctr64 { C64_EDGES = 0, C64_ROOTS = 1, C64_SUM = 2, C64_STATS = 3, C64_CANDS = 4, C64_CAND_NEED = 5, C64_SLAB = 6, C64_N = 8 };
 
 }  // namespace
 
@@ -104,6 +104,7 @@ struct fqd_ctx {
     // stage 1
     uint64_t n = 0;
     DevBuf in_bytes, in_offsets, recs, lens, hashes, owners;
+    bool gp_slab_off = false;      // grouped search: same, for the (hash, uid) partition
     bool slab_off = false;         // LDS collapse: a slab of level 2 overflowed once, use exact bucket sizes
     bool hashes_valid = false;     // `hashes` holds the record hashes of the packed reads (lazy after an import)
     fqd::OwnerRule owner_rule;     // fqd_set_owner_rule: fqd_pack_keys also writes each read's owner rank

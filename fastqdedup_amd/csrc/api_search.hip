@@ -109,25 +109,40 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
                                                             bins1, c->ld_matrix_incl.as<uint32_t>(),
                                                             c->gp_a.as<uint32_t>(), c->st));
     const uint32_t *items = c->gp_a.as<uint32_t>();
+    const uint32_t *bucket_end = nullptr;
+    // level 2 in slab mode (as the collapse): no histogram pass; an overfull slab -- many keys sharing
+    // a segment -- is flagged in C64_SLAB and the caller searches again with exact bucket sizes
+    uint32_t slab_cap = 0;
+    if (B2 && !c->gp_slab_off && !getenv("FQD_GROUP_NO_SLABS")) {
+        slab_cap = (uint32_t)(((U >> B) * 3 / 2 + 64 + 3) & ~3ull);
+        if ((uint64_t)slab_cap * n_buckets >= 0xFFFFFF00ull)
+            slab_cap = 0;
+    }
     if (B2 == 0) {
         HIP_TRY(c, hipMemcpyAsync(c->ld_start.p, start1, ((size_t)bins1 + 1) * 4, hipMemcpyDeviceToDevice, c->st));
     } else {
         // ---- level 2: every part into 2^B2 buckets by the next hash bits
-        HIP_TRY(c, c->gp_b.reserve(U * 8 + 16));
+        HIP_TRY(c, c->gp_b.reserve((slab_cap ? (uint64_t)slab_cap * n_buckets : U) * 8 + 16));
         HIP_TRY(c, c->ld_hist.reserve((size_t)n_buckets * 4 + 16));
         HIP_TRY(c, c->ld_hist_incl.reserve((size_t)n_buckets * 4 + 16));
         HIP_TRY(c, c->ld_cursor.reserve((size_t)n_buckets * 4 + 16));
         HIP_TRY(c, fqd::launch_group_tile_starts(start1, bins1, tiles2_d, c->st));
-        HIP_TRY(c, hipMemsetAsync(c->ld_hist.p, 0, (size_t)n_buckets * 4, c->st));
-        KTIME(c, FQD_K_GROUP_HIST, fqd::launch_group_hist(false, nullptr, c->gp_a.as<uint32_t>(), start1, tiles2_d, bins1,
-                                                          max_tiles2, 32 - B, bins2, c->ld_hist.as<uint32_t>(), c->st));
-        FQD_TRY(scan_u32(c, c->ld_hist.as<uint32_t>(), c->ld_hist_incl.as<uint32_t>(), n_buckets));
-        HIP_TRY(c, fqd::launch_group_bucket_starts(c->ld_hist_incl.as<uint32_t>(), n_buckets,
-                                                   c->ld_start.as<uint32_t>(), c->ld_cursor.as<uint32_t>(), c->st));
-        KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(false, nullptr, c->gp_a.as<uint32_t>(), start1, tiles2_d,
-                                                                bins1, max_tiles2, 32 - B, bins2,
-                                                                c->ld_cursor.as<uint32_t>(), c->gp_b.as<uint32_t>(),
-                                                                c->st));
+        if (slab_cap) {
+            HIP_TRY(c, fqd::launch_group_slab_starts(n_buckets, slab_cap, c->ld_start.as<uint32_t>(),
+                                                     c->ld_cursor.as<uint32_t>(), c->st));
+            bucket_end = c->ld_cursor.as<uint32_t>();
+        } else {
+            HIP_TRY(c, hipMemsetAsync(c->ld_hist.p, 0, (size_t)n_buckets * 4, c->st));
+            KTIME(c, FQD_K_GROUP_HIST, fqd::launch_group_hist(false, nullptr, c->gp_a.as<uint32_t>(), start1, tiles2_d, bins1,
+                                                              max_tiles2, 32 - B, bins2, c->ld_hist.as<uint32_t>(), c->st));
+            FQD_TRY(scan_u32(c, c->ld_hist.as<uint32_t>(), c->ld_hist_incl.as<uint32_t>(), n_buckets));
+            HIP_TRY(c, fqd::launch_group_bucket_starts(c->ld_hist_incl.as<uint32_t>(), n_buckets,
+                                                       c->ld_start.as<uint32_t>(), c->ld_cursor.as<uint32_t>(), c->st));
+        }
+        KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(
+                  false, nullptr, c->gp_a.as<uint32_t>(), start1, tiles2_d, bins1, max_tiles2, 32 - B, bins2,
+                  c->ld_cursor.as<uint32_t>(), c->gp_b.as<uint32_t>(), c->st, slab_cap,
+                  reinterpret_cast<uint32_t *>(c->d_ctr64.as<unsigned long long>() + C64_SLAB)));
         items = c->gp_b.as<uint32_t>();
     }
     // candidates (pairs with equal segment hashes) -> device list -> verification, one thread per pair
@@ -140,7 +155,7 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
     unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(small + 4096);
     HIP_TRY(c, hipMemsetAsync(cand_ctr, 0, (size_t)fqd::group_cand_lists() * 64, c->st));
     unsigned long long *ctr = c->d_ctr64.as<unsigned long long>();
-    KTIME(c, FQD_K_PAIRS, fqd::launch_grouped_candidates(items, c->ld_start.as<uint32_t>(), n_buckets, B,
+    KTIME(c, FQD_K_PAIRS, fqd::launch_grouped_candidates(items, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, B,
                                                          c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,
                                                          c->st));
     KTIME(c, FQD_K_VERIFY, fqd::launch_verify_candidates(c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,
@@ -214,7 +229,7 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         if (const char *e = getenv("FQD_GROUP_CAND_BUDGET"))
             cand_budget = strtoull(e, nullptr, 10);
         bool iota_ready = false;
-        FQD_TRY(zero_ctr64(c, C64_CAND_NEED));
+        FQD_TRY(zero_ctr64(c, C64_CAND_NEED, 2));    // ... and C64_SLAB
         // All d+1 passes are queued without a host round trip; the edge count is read ONCE at the
         // end. If the passes overflowed the edge buffer (the count still says how many edges there
         // are), the buffer is grown to the known need and the whole search runs again.
@@ -252,10 +267,15 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
                                c->edges.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_EDGES, c->edge_cap,
                                c->d_stats.as<fqd::PairStats>(), c->st));
             }
-            unsigned long long ctrs[C64_CAND_NEED + 1] = {0};
-            FQD_TRY(read_ctr64(c, 0, ctrs, C64_CAND_NEED + 1));
+            unsigned long long ctrs[C64_SLAB + 1] = {0};
+            FQD_TRY(read_ctr64(c, 0, ctrs, C64_SLAB + 1));
             const unsigned long long now = ctrs[C64_EDGES], cand_need = grouped ? ctrs[C64_CAND_NEED] : 0;
-            if (now <= c->edge_cap && cand_need <= c->gp_cand_cap) {
+            const bool slab_over = grouped && ctrs[C64_SLAB] != 0;
+            if (slab_over) {             // a level-2 slab overflowed: exact bucket sizes from now on
+                c->gp_slab_off = true;
+                FQD_TRY(zero_ctr64(c, C64_SLAB));
+            }
+            if (!slab_over && now <= c->edge_cap && cand_need <= c->gp_cand_cap) {
                 have = now;
                 break;
             }

@@ -315,15 +315,18 @@ hipError_t launch_group_hist(bool level1, const uint32_t *hashes, const uint32_t
                              uint32_t n_bins, uint32_t *hist, hipStream_t st);
 hipError_t launch_group_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
                                 const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
-                                uint32_t n_bins, uint32_t *cursor, uint32_t *out, hipStream_t st);
+                                uint32_t n_bins, uint32_t *cursor, uint32_t *out, hipStream_t st, uint32_t slab_cap = 0,
+                                uint32_t *slab_overflow = nullptr);
 hipError_t launch_group_tile_starts(const uint32_t *seg_start, uint32_t n_seg, uint32_t *tile_start, hipStream_t st);
 hipError_t launch_group_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                       hipStream_t st);
 hipError_t launch_group_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
                                       uint32_t *cursor, hipStream_t st);
-hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, uint32_t n_buckets,
-                                     uint32_t bucket_bits, uint64_t *cands, unsigned long long *cand_count,
-                                     uint64_t cand_cap, hipStream_t st);
+hipError_t launch_group_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket_start, uint32_t *cursor,
+                                    hipStream_t st);
+hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                     uint32_t n_buckets, uint32_t bucket_bits, uint64_t *cands,
+                                     unsigned long long *cand_count, uint64_t cand_cap, hipStream_t st);
 hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
                                     const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d, uint32_t seg,
                                     uint32_t nseg, uint32_t *edges, unsigned long long *edge_count, uint64_t edge_cap,

@@ -59,9 +59,23 @@ __global__ __launch_bounds__(fqd_partition::THREADS) void gp_scatter_kernel(Pair
                                                                             const uint32_t *__restrict__ tile_start,
                                                                             uint32_t n_seg, uint32_t shift,
                                                                             uint32_t n_bins, uint32_t *__restrict__ cursor,
-                                                                            uint2 *__restrict__ out)
+                                                                            uint2 *__restrict__ out, uint32_t slab_cap,
+                                                                            uint32_t *__restrict__ slab_overflow)
 {
-    fqd_partition::scatter_body<PairPolicy, LEVEL1>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out);
+    fqd_partition::scatter_body<PairPolicy, LEVEL1>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
+                                                    slab_cap, slab_overflow);
+}
+
+// slab mode of level 2 (as in collapse_lds.hip): bucket b owns slots [b * cap, (b + 1) * cap)
+__global__ void gp_slab_starts_kernel(uint32_t n_buckets, uint32_t cap, uint32_t *__restrict__ bucket_start,
+                                      uint32_t *__restrict__ cursor)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_buckets)
+        return;
+    bucket_start[b] = b * cap;
+    if (b < n_buckets)
+        cursor[b] = b * cap;
 }
 
 __global__ void gp_tile_starts_kernel(const uint32_t *__restrict__ seg_start, uint32_t n_seg,
@@ -135,8 +149,9 @@ constexpr uint32_t GP_WCAP = 128;   // candidates buffered per wave
 constexpr uint32_t GP_LISTS = 64;   // candidate lists (one counter each, a cache line apart): flush atomics spread out
 
 __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
-    const uint2 *__restrict__ items, const uint32_t *__restrict__ bucket_start, uint32_t n_buckets,
-    uint32_t sub_shift, uint2 *__restrict__ cands_all, unsigned long long *__restrict__ cand_counts, uint64_t list_cap)
+    const uint2 *__restrict__ items, const uint32_t *__restrict__ bucket_start,
+    const uint32_t *__restrict__ bucket_end /* NULL, or slab mode: where each bucket's cursor stopped */,
+    uint32_t n_buckets, uint32_t sub_shift, uint2 *__restrict__ cands_all, unsigned long long *__restrict__ cand_counts, uint64_t list_cap)
 {
     constexpr uint32_t WAVES = GP_THREADS / 64;
     // GP_LISTS lists of list_cap pairs each, counters 8 words apart. A wave starts at "its" list
@@ -195,7 +210,11 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
         uint32_t two = 0;
         if (lane < 2)
             two = bucket_start[b + lane];
-        const uint32_t lo = __shfl(two, 0), m = __shfl(two, 1) - lo;
+        const uint32_t lo = __shfl(two, 0);
+        uint32_t hi = __shfl(two, 1);
+        if (bucket_end)
+            hi = min(hi, bucket_end[b]);
+        const uint32_t m = hi - lo;
         if (m < 2)
             continue;
         const uint2 *bucket = items + lo;
@@ -411,7 +430,8 @@ hipError_t launch_group_hist(bool level1, const uint32_t *hashes, const uint32_t
 
 hipError_t launch_group_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
                                 const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
-                                uint32_t n_bins, uint32_t *cursor, uint32_t *out, hipStream_t st)
+                                uint32_t n_bins, uint32_t *cursor, uint32_t *out, hipStream_t st, uint32_t slab_cap,
+                                uint32_t *slab_overflow)
 {
     if (!max_tiles)
         return hipSuccess;
@@ -419,10 +439,11 @@ hipError_t launch_group_scatter(bool level1, const uint32_t *hashes, const uint3
     uint2 *out2 = reinterpret_cast<uint2 *>(out);
     if (level1)
         gp_scatter_kernel<true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, shift,
-                                                                              n_bins, cursor, out2);
+                                                                              n_bins, cursor, out2, 0u, nullptr);
     else
         gp_scatter_kernel<false><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, shift,
-                                                                               n_bins, cursor, out2);
+                                                                               n_bins, cursor, out2, slab_cap,
+                                                                               slab_overflow);
     return hipGetLastError();
 }
 
@@ -446,9 +467,16 @@ hipError_t launch_group_bucket_starts(const uint32_t *hist_incl, uint32_t n_buck
     return hipGetLastError();
 }
 
-hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, uint32_t n_buckets,
-                                     uint32_t bucket_bits, uint64_t *cands, unsigned long long *cand_count,
-                                     uint64_t cand_cap, hipStream_t st)
+hipError_t launch_group_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket_start, uint32_t *cursor,
+                                    hipStream_t st)
+{
+    gp_slab_starts_kernel<<<(n_buckets + 1 + 255) / 256, 256, 0, st>>>(n_buckets, cap, bucket_start, cursor);
+    return hipGetLastError();
+}
+
+hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                     uint32_t n_buckets, uint32_t bucket_bits, uint64_t *cands,
+                                     unsigned long long *cand_count, uint64_t cand_cap, hipStream_t st)
 {
     if (!n_buckets)
         return hipSuccess;
@@ -457,7 +485,7 @@ hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *buck
     const uint32_t blocks = (n_buckets + 3) / 4;
     const unsigned grid = blocks < 8192 ? blocks : 8192;
     grouped_candidates_kernel<<<grid, GP_THREADS, 0, st>>>(reinterpret_cast<const uint2 *>(items), bucket_start,
-                                                           n_buckets, sub_shift, reinterpret_cast<uint2 *>(cands),
+                                                           bucket_end, n_buckets, sub_shift, reinterpret_cast<uint2 *>(cands),
                                                            cand_count, cand_cap / GP_LISTS);
     return hipGetLastError();
 }

@@ -514,6 +514,30 @@ def test_grouped_search_with_a_crowded_segment(F, oracle, monkeypatch, budget):
     assert np.array_equal(res.kept_read_ids, want["kept_read_ids"])
 
 
+def test_grouped_search_slab_overflow_searches_again(F, oracle, monkeypatch):
+    """Level 2 of the search's (hash, uid) partition also uses fixed slabs. 3000 keys sharing their
+    first half overfill one: the search must run again with exact bucket sizes (and keep doing so on
+    this context), with the oracle's answer and the same edges as a context that never used slabs."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    rng = np.random.default_rng(15)
+    n, L = 300_000, 32
+    keys = synth_keys(n, L, L, 47, sub_rate=4e-3, n_rate=2e-4)
+    crowd = rng.choice(n, size=3000, replace=False)
+    keys[crowd, :L // 2] = keys[crowd[0], :L // 2]
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    monkeypatch.setenv("FQD_EDGES", "grouped")
+    want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=1, method="directional")
+    ctx = F.Context(0)
+    for _ in range(2):
+        got = F.cluster_keys(raw, key_len=L, max_distance=1, method="directional", context=ctx)
+        assert (got.n_unique, got.n_clusters) == (want["n_unique"], want["n_clusters"])
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+    monkeypatch.setenv("FQD_GROUP_NO_SLABS", "1")
+    exact = F.cluster_keys(raw, key_len=L, max_distance=1, method="directional", context=F.Context(0))
+    assert exact.n_edges == got.n_edges
+    assert np.array_equal(exact.kept_read_ids, got.kept_read_ids)
+
+
 @pytest.mark.parametrize("edit", [False, True])
 def test_directional_closed_form_equals_rounds(F, oracle, monkeypatch, edit):
     """The directional dissection has a closed form on collapsed tables (two passes over the edges)
