@@ -45,7 +45,7 @@ EXPORTS = [
     "fqd_export_packed_by_segment", "fqd_export_unique_by_segment", "fqd_gather_unique",
     "fqd_find_edges_segments", "fqd_edge_labels", "fqd_list_kept_except", "fqd_set_owner_rule", "fqd_declare_distinct_keys", "fqd_collapse_received", "fqd_set_kept_output",
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
-    "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_edge_stats", "fqd_synth_keys",
+    "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_set_timing", "fqd_edge_stats", "fqd_synth_keys",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -116,6 +116,7 @@ def load() -> C.CDLL:
                                      u64p, C.c_int]
     L.fqd_stage_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.fqd_kernel_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_int]
+    L.fqd_set_timing.argtypes = [vp, C.c_int, C.c_uint32]
     L.fqd_edge_stats.argtypes = [vp, u64p, u64p, u64p]
     L.fqd_synth_keys.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                  C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]
@@ -504,6 +505,12 @@ class Context:
         ln = (C.c_uint32 * 20)()
         self._ck(self._L.fqd_kernel_times(self._h, ms, ln, int(reset)))
         return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(self.KERNELS)}
+
+    def set_timing(self, stage_timers: bool = True, kernels=None):
+        """Which timers record events: the stage timers, and the kernels named in ``kernels``
+        (None = all of KERNELS, () = none)."""
+        mask = 0xFFFFFFFF if kernels is None else sum(1 << self.KERNELS.index(k) for k in kernels)
+        self._ck(self._L.fqd_set_timing(self._h, int(bool(stage_timers)), mask))
 
     def edge_stats(self):
         a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)

@@ -293,8 +293,7 @@ int fqd_create(int device, fqd_ctx **out)
     fqd_ctx *c = new fqd_ctx();
     c->device = device;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&c->st) == hipSuccess &&
-              hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
-              hipEventCreate(&c->evk0) == hipSuccess && hipEventCreate(&c->evk1) == hipSuccess &&
+              [&] { for (hipEvent_t &e : c->tev) if (hipEventCreate(&e) != hipSuccess) return false; return true; }() &&
               [&] { for (hipEvent_t &e : c->kev) if (hipEventCreate(&e) != hipSuccess) return false; return true; }() &&
               c->d_ctr32.reserve(C_N32 * 4) == hipSuccess && c->d_ctr64.reserve(C64_N * 8) == hipSuccess &&
               c->d_lut.reserve(256) == hipSuccess &&
@@ -329,10 +328,8 @@ void fqd_destroy(fqd_ctx *c)
                       &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners, &c->taint, &c->root_taint, &c->gp_a, &c->gp_b, &c->gp_small, &c->gp_cands, &c->seg_tab};
     for (DevBuf *b : bufs)
         b->release();
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->evk0) (void)hipEventDestroy(c->evk0);
-    if (c->evk1) (void)hipEventDestroy(c->evk1);
+    for (hipEvent_t e : c->tev)
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->kev)
         if (e) (void)hipEventDestroy(e);
     if (c->st) (void)hipStreamDestroy(c->st);
@@ -469,23 +466,18 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
             HIP_TRY(c, c->owners.reserve((size_t)n * 4 + 16));
         c->owners_done = fqd::OwnerRule{};
         FQD_TRY(zero_ctr32(c, C_BAD));
-        (void)hipEventRecord(c->evk0, c->st);
+        StageTimer kernel_timer(c, FQD_T_PACK_KERNEL);
         KTIME(c, FQD_K_PACK, fqd::launch_pack(d_bytes, n_bytes, d_off, n, fixed_len, sh, c->d_lut.as<uint8_t>(), lut,
                                     c->recs.as<uint32_t>(), sh.ragged ? c->lens.as<uint32_t>() : nullptr,
                                     c->hashes.as<uint32_t>(), c->owner_rule.parts ? c->owners.as<uint32_t>() : nullptr,
                                     c->owner_rule, c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
-        (void)hipEventRecord(c->evk1, c->st);
+        kernel_timer.stop();
         uint32_t bad = 0;
         FQD_TRY(read_ctr32(c, C_BAD, &bad));
-        float kms = 0;
-        if (hipEventElapsedTime(&kms, c->evk0, c->evk1) == hipSuccess) {
-            c->ms[FQD_T_PACK_KERNEL] = kms;
-            c->launches[FQD_T_PACK_KERNEL] = 1;
-        }
         if (getenv("FQD_DEBUG"))
-            fprintf(stderr, "[fqd] pack attempt %d: n=%llu len=%u K=%u W=%u stride=%u alphabet=%.*s bad=%u kernel=%.3f ms\n",
+            fprintf(stderr, "[fqd] pack attempt %d: n=%llu len=%u K=%u W=%u stride=%u alphabet=%.*s bad=%u\n",
                     attempt, (unsigned long long)n, max_len, sh.planes, sh.words, sh.stride, (int)c->shape.alphabet_size,
-                    (const char *)c->shape.alphabet, bad, kms);
+                    (const char *)c->shape.alphabet, bad);
         if (!bad)
             break;
         if (!optimistic || attempt > 0) {
@@ -728,6 +720,7 @@ int fqd_cluster(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, i
     FQD_TRY(fqd_api_components_queue(c, method == FQD_METHOD_HIGHEST_COUNT));
     c->stage = ST_LABELS;
     c->ms[FQD_T_COMPONENTS] = 0;
+    c->tpending[FQD_T_COMPONENTS] = false;
     FQD_TRY(fqd_dissect(c, method, nullptr));
     if (c->U) {
         c->n_clusters = c->roots_seen;   // read together with the kept counters
@@ -891,8 +884,20 @@ int fqd_quality_filter(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets
 }
 
 // ---- measurement ----------------------------------------------------------------
+int fqd_set_timing(fqd_ctx *c, int stage_timers, uint32_t kernel_mask)
+{
+    FQD_TRY(bind(c));
+    stage_times_resolve(c);
+    ktime_collect(c);
+    c->stage_timing = stage_timers != 0;
+    c->ktime_mask = kernel_mask;
+    return FQD_OK;
+}
+
 int fqd_stage_times(fqd_ctx *c, float *ms, uint32_t *launches)
 {
+    FQD_TRY(bind(c));
+    stage_times_resolve(c);
     if (ms)
         memcpy(ms, c->ms, sizeof c->ms);
     if (launches)

@@ -143,8 +143,14 @@ struct fqd_ctx {
     // scratch
     DevBuf tmp, stage_a, stage_b, stage_c, stage_d;
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
-    // per-kernel timing (fqd_kernel_times): a pool of event pairs, drained at every stage end
+    // stage timers: one event pair per stage, recorded while the work is queued and resolved when
+    // fqd_stage_times asks (a stage end is NOT a host synchronisation point)
+    hipEvent_t tev[2 * FQD_T_COUNT] = {nullptr};
+    bool tpending[FQD_T_COUNT] = {false};
+    bool stage_timing = true;
+    // per-kernel timing (fqd_kernel_times): a pool of event pairs for the kernels in ktime_mask,
+    // folded into the sums at fqd_kernel_times or when the pool runs low
+    uint32_t ktime_mask = 0xFFFFFFFFu;
     static constexpr int KPOOL = 96;
     hipEvent_t kev[2 * KPOOL] = {nullptr};
     int kslot[KPOOL] = {0};
@@ -252,25 +258,51 @@ int zero_ctr64(fqd_ctx *c, int idx, int count = 1)
 
 void ktime_collect(fqd_ctx *c);
 
+void stage_times_resolve(fqd_ctx *c)
+{
+    bool any = false;
+    for (int t = 0; t < FQD_T_COUNT; t++)
+        any |= c->tpending[t];
+    if (!any)
+        return;
+    (void)hipStreamSynchronize(c->st);
+    for (int t = 0; t < FQD_T_COUNT; t++) {
+        if (!c->tpending[t])
+            continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->tev[2 * t], c->tev[2 * t + 1]) == hipSuccess)
+            c->ms[t] = ms;
+        c->launches[t] = 1;
+        c->tpending[t] = false;
+    }
+}
+
 struct StageTimer {
     fqd_ctx *c;
     int slot;
-    StageTimer(fqd_ctx *ctx, int s) : c(ctx), slot(s) { (void)hipEventRecord(c->ev0, c->st); }
+    bool on;
+    StageTimer(fqd_ctx *ctx, int s) : c(ctx), slot(s), on(ctx->stage_timing)
+    {
+        c->tpending[slot] = false;
+        if (on)
+            (void)hipEventRecord(c->tev[2 * slot], c->st);
+        else
+            c->ms[slot] = 0, c->launches[slot] = 0;
+    }
     void stop()
     {
-        (void)hipEventRecord(c->ev1, c->st);
-        (void)hipEventSynchronize(c->ev1);
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess)
-            c->ms[slot] = ms;
-        c->launches[slot] = 1;
-        ktime_collect(c);
+        if (on) {
+            (void)hipEventRecord(c->tev[2 * slot + 1], c->st);
+            c->tpending[slot] = true;
+        }
+        if (c->kused > fqd_ctx::KPOOL - 40)   // keep room for the next stage's kernels
+            ktime_collect(c);
     }
 };
 
 int ktime_begin(fqd_ctx *c, int slot)
 {
-    if (c->kused >= fqd_ctx::KPOOL)
+    if (!((c->ktime_mask >> slot) & 1u) || c->kused >= fqd_ctx::KPOOL)
         return -1;
     const int i = c->kused++;
     c->kslot[i] = slot;

@@ -277,6 +277,11 @@ int fqd_stage_times(fqd_ctx *ctx, float *ms /* FQD_T_COUNT */, uint32_t *launche
 #define FQD_K_COUNT         20
 int fqd_kernel_times(fqd_ctx *ctx, float *ms /* FQD_K_COUNT */, uint32_t *launches /* FQD_K_COUNT */,
                      int reset);
+/* What is timed. Timers never synchronise the host: they are event pairs recorded while the work
+ * is queued and resolved when the getters above are called. stage_timers = 0 records none of the
+ * stage events; only the kernels whose bit (1u << FQD_K_...) is set in kernel_mask get event
+ * pairs. Default: everything timed (an A/B on config 3 shows no cost: 3.75 vs 3.76 ms per job). */
+int fqd_set_timing(fqd_ctx *ctx, int stage_timers, uint32_t kernel_mask);
 /* Bucket statistics of the last fqd_find_edges (for the roofline's unit count):
  * keys gathered by the pair kernel, pairs compared, edges emitted. */
 int fqd_edge_stats(fqd_ctx *ctx, uint64_t *keys_gathered, uint64_t *pairs_compared,
