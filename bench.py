@@ -241,6 +241,13 @@ def main():
                     "part_scatter_kernel<1>": "part_scatter_kernel<true",
                     "part_scatter_kernel<2>": "part_scatter_kernel<false",
                     "dissect_round_kernel": "_round_kernel" if wl["method"] == "directional" else "adjacency_edges"}
+    if kern.get("pack_kernel", (0, 0))[1] and not kern.get("part_scatter_kernel<1>", (0, 0))[1] \
+            and kern.get("part_scatter_kernel<2>", (0, 0))[1]:
+        # fqd_cluster_keys took the fused way in: the pack kernel wrote its records straight into
+        # level 1 of the collapse (key bytes in, 16-byte record out; no hash array)
+        kern["pack_kernel (fused with level 1)"] = kern.pop("pack_kernel")
+        alg["pack_kernel (fused with level 1)"] = n * (L + 16)
+        rocprof_name["pack_kernel (fused with level 1)"] = "pack_kernel"
     if kern.get("gp_hist_kernel", (0, 0))[1]:
         # the sort-free search pass ran: the FQD_K_PAIRS slot timed grouped_candidates_kernel
         # ((hash, uid) items in, candidate pairs out), not bucket_pairs_kernel

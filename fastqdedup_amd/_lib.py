@@ -45,7 +45,7 @@ EXPORTS = [
     "fqd_export_packed_by_segment", "fqd_export_unique_by_segment", "fqd_gather_unique",
     "fqd_find_edges_segments", "fqd_edge_labels", "fqd_list_kept_except", "fqd_set_owner_rule", "fqd_declare_distinct_keys", "fqd_collapse_received", "fqd_set_kept_output",
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
-    "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_set_timing", "fqd_edge_stats", "fqd_synth_keys",
+    "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_set_timing", "fqd_cluster_keys", "fqd_edge_stats", "fqd_synth_keys",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -87,6 +87,8 @@ def load() -> C.CDLL:
     L.fqd_components.argtypes = [vp, u64p]
     L.fqd_dissect.argtypes = [vp, C.c_int, u64p]
     L.fqd_cluster.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Summary)]
+    L.fqd_cluster_keys.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.POINTER(Summary)]
     L.fqd_get_kept_read_ids.argtypes = [vp, vp, C.c_int]
     L.fqd_set_id_window.argtypes = [vp, C.c_uint64, C.c_uint64]
     L.fqd_get_kept_count.argtypes = [vp, u64p, u64p]
@@ -278,6 +280,35 @@ class Context:
         s = Summary()
         self._ck(self._L.fqd_cluster(self._h, wp, rp, mem, int(max_distance), int(metric),
                                      int(method), C.byref(s)))
+        return s.as_dict()
+
+    def cluster_keys(self, keys, offsets=None, key_len: int = 0, weights=None, read_ids=None, *,
+                     max_distance: int = 1, metric: int = METRIC_HAMMING, method: int = 2) -> dict:
+        """pack_keys + cluster in one C call (fqd_cluster_keys): the pack kernel may then feed the
+        collapse directly (short fixed-length keys)."""
+        kp, km, _k = _ptr_mem(keys)
+        op, om, _o = _ptr_mem(offsets)
+        if offsets is None:
+            nbytes = keys.numel() if hasattr(keys, "numel") else keys.size
+            if key_len <= 0:
+                if nbytes:
+                    raise ValueError("key_len must be positive when offsets is None")
+                n = 0
+            else:
+                if nbytes % key_len:
+                    raise ValueError("key buffer is not a multiple of key_len")
+                n = nbytes // key_len
+        else:
+            n = (offsets.numel() if hasattr(offsets, "numel") else offsets.size) - 1
+            if n < 0:
+                raise ValueError("offsets needs n+1 entries")
+        mem = self._same_mem((km, True), (om, offsets is not None))
+        wp, wm, _w = _ptr_mem(weights)
+        rp, rm, _r = _ptr_mem(read_ids)
+        aux = self._same_mem((wm, weights is not None), (rm, read_ids is not None))
+        s = Summary()
+        self._ck(self._L.fqd_cluster_keys(self._h, kp, op, n, int(key_len), mem, wp, rp, aux, int(max_distance),
+                                          int(metric), int(method), C.byref(s)))
         return s.as_dict()
 
     # ---- results --------------------------------------------------------------

@@ -86,13 +86,12 @@ def cluster_keys(keys, offsets=None, key_len: int = 0, weights=None, read_ids=No
     if max_distance < 0:
         raise ValueError("max_distance should be non-negative")
     ctx = context or default_context()
-    ctx.pack_keys(keys, offsets, key_len)
     direct = kept_out is not None and hasattr(kept_out, "is_cuda") and kept_out.is_cuda
     if direct:
         ctx.set_kept_output(kept_out)      # the list is written into the caller's buffer, no copy
     try:
-        s = ctx.cluster(weights, read_ids, max_distance=max_distance,
-                        metric=_metric(use_edit_distance), method=_method_id(method))
+        s = ctx.cluster_keys(keys, offsets, key_len, weights, read_ids, max_distance=max_distance,
+                             metric=_metric(use_edit_distance), method=_method_id(method))
         kept = ctx.kept_read_ids(s["n_kept"], kept_out)
     finally:
         if direct:

@@ -108,7 +108,28 @@ int ensure_hashes(fqd_ctx *c)
     return FQD_OK;
 }
 
-int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
+// `fused` != NULL: level 1 was done by the pack kernel itself (fqd_cluster_keys): c->ld_part holds
+// fused->parts slab segments [seg_start[s], cursor[s]) in c->ld_seg, 2^sub_bits of them per
+// level-1 bin, and the reads exist nowhere else -- any overflow then ends the attempt (*done =
+// false) and the caller starts over with the plain pack.
+struct FusedLevel1 {
+    uint32_t parts, sub_bits, B;
+    uint32_t pack_bad = 0;     // out: the pack kernel met a byte outside the alphabet
+};
+
+// Bucket bits of the LDS collapse for n reads: ~400-800 reads per bucket (2x fewer workgroups than
+// at 200-400, longer runs)
+uint32_t lds_bucket_bits(uint64_t n)
+{
+    uint32_t B = 8;
+    while (B < 18 && (n >> B) > 800)
+        B++;
+    if (const char *e = getenv("FQD_LDS_BUCKET_BITS"))  // tests: few buckets => table overflow => fallback
+        B = (uint32_t)std::max(1, std::min(18, atoi(e)));
+    return B;
+}
+
+int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, FusedLevel1 *fused = nullptr)
 {
     *done = false;
     const uint64_t n = c->n;
@@ -120,11 +141,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
         return FQD_OK;
     if (n < 32768 && !(force && !strcmp(force, "lds")))
         return FQD_OK;
-    uint32_t B = 8;
-    while (B < 18 && (n >> B) > 800)   // ~400-800 reads per bucket: 2x fewer workgroups than at 200-400, longer runs
-        B++;
-    if (const char *e = getenv("FQD_LDS_BUCKET_BITS"))  // tests: few buckets => table overflow => fallback
-        B = (uint32_t)std::max(1, std::min(18, atoi(e)));
+    const uint32_t B = fused ? fused->B : lds_bucket_bits(n);
     const uint32_t B1 = std::min<uint32_t>(B, 8), B2 = B - B1;
     const uint32_t bins1 = 1u << B1, bins2 = 1u << B2, n_buckets = 1u << B;
     const uint32_t kw = sh.planes * sh.words, tile = fqd::part_tile_size();
@@ -141,13 +158,16 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
     // hundreds of copies overfills its slab: the scatter notices, and level 2 runs again with the
     // exact histogram (and stays exact for this context).
     uint32_t slab_cap = 0;
-    if (B2 && !c->slab_off && !getenv("FQD_LDS_NO_SLABS")) {
+    if (B2 && (fused || (!c->slab_off && !getenv("FQD_LDS_NO_SLABS")))) {
         slab_cap = (uint32_t)(((n >> B) * 3 / 2 + 64 + 3) & ~3ull);
-        if ((uint64_t)slab_cap * n_buckets >= 0xFFFFFF00ull)
+        if ((uint64_t)slab_cap * n_buckets + n >= 0xFFFFFF00ull)   // (a cursor may run n past its slab)
             slab_cap = 0;
     }
     const uint64_t slots = slab_cap ? (uint64_t)slab_cap * n_buckets : n;
-    HIP_TRY(c, c->ld_part.reserve(n * 16 + 16));
+    if (fused && !slab_cap)
+        return FQD_OK;
+    if (!fused)
+        HIP_TRY(c, c->ld_part.reserve(n * 16 + 16));
     HIP_TRY(c, c->ld_tmp_rec.reserve(slots * 16 + 16));
     HIP_TRY(c, c->ld_part2.reserve(slots * 16 + 16));
     HIP_TRY(c, c->ld_tmp_count.reserve(slots * 4 + 16));
@@ -156,36 +176,47 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
     uint32_t *small = c->ld_small.as<uint32_t>();
     uint32_t *seg1 = small, *tiles1_d = small + 8, *start1 = small + 16, *tiles2_d = small + 512;
     const uint32_t seg1_h[2] = {0u, (uint32_t)n}, tiles1_h[2] = {0u, tiles1};
-    HIP_TRY(c, hipMemcpyAsync(seg1, seg1_h, 8, hipMemcpyHostToDevice, c->st));
-    HIP_TRY(c, hipMemcpyAsync(tiles1_d, tiles1_h, 8, hipMemcpyHostToDevice, c->st));
-    // ---- level 1: 2^B1 parts by the top B1 hash bits. Counts go to a (bin x tile) matrix whose
-    // scan gives every (tile, bin) its output position (no atomics on 2^B1 hot counters).
-    const size_t matrix = (size_t)bins1 * tiles1;
-    HIP_TRY(c, c->ld_matrix.reserve(matrix * 4 + 16));
-    HIP_TRY(c, c->ld_matrix_incl.reserve(matrix * 4 + 16));
-    KTIME(c, FQD_K_PART_HIST1, fqd::launch_part_hist(true, c->hashes_valid ? c->hashes.as<uint32_t>() : nullptr, c->recs.as<uint32_t>(), seg1, tiles1_d, 1, tiles1,
-                                     32 - B1, bins1, kw, sh.max_len, c->ld_matrix.as<uint32_t>(), c->st));
-    FQD_TRY(scan_u32(c, c->ld_matrix.as<uint32_t>(), c->ld_matrix_incl.as<uint32_t>(), matrix));
-    HIP_TRY(c, fqd::launch_matrix_starts(c->ld_matrix_incl.as<uint32_t>(), bins1, tiles1, start1, c->st));
-    // received reads without weights: (segment, local index) travels in the record (IdSource)
-    IdSource packed;
-    if (d_ids.packed_bits && !d_w)
-        packed = d_ids;
-    else
-        d_ids.packed_bits = 0;
-    KTIME(c, FQD_K_PART_SCATTER1, fqd::launch_part_scatter(true, c->hashes.as<uint32_t>(), c->recs.as<uint32_t>(), seg1, tiles1_d, 1,
-                                        tiles1, 32 - B1, bins1, kw, sh.max_len, c->ld_matrix_incl.as<uint32_t>(),
-                                        c->ld_part.as<uint32_t>(), c->st, packed));
+    if (!fused) {
+        HIP_TRY(c, hipMemcpyAsync(seg1, seg1_h, 8, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(c, hipMemcpyAsync(tiles1_d, tiles1_h, 8, hipMemcpyHostToDevice, c->st));
+        // ---- level 1: 2^B1 parts by the top B1 hash bits. Counts go to a (bin x tile) matrix whose
+        // scan gives every (tile, bin) its output position (no atomics on 2^B1 hot counters).
+        const size_t matrix = (size_t)bins1 * tiles1;
+        HIP_TRY(c, c->ld_matrix.reserve(matrix * 4 + 16));
+        HIP_TRY(c, c->ld_matrix_incl.reserve(matrix * 4 + 16));
+        KTIME(c, FQD_K_PART_HIST1, fqd::launch_part_hist(true, c->hashes_valid ? c->hashes.as<uint32_t>() : nullptr, c->recs.as<uint32_t>(), seg1, tiles1_d, 1, tiles1,
+                                         32 - B1, bins1, kw, sh.max_len, c->ld_matrix.as<uint32_t>(), c->st));
+        FQD_TRY(scan_u32(c, c->ld_matrix.as<uint32_t>(), c->ld_matrix_incl.as<uint32_t>(), matrix));
+        HIP_TRY(c, fqd::launch_matrix_starts(c->ld_matrix_incl.as<uint32_t>(), bins1, tiles1, start1, c->st));
+        // received reads without weights: (segment, local index) travels in the record (IdSource)
+        IdSource packed;
+        if (d_ids.packed_bits && !d_w)
+            packed = d_ids;
+        else
+            d_ids.packed_bits = 0;
+        KTIME(c, FQD_K_PART_SCATTER1, fqd::launch_part_scatter(true, c->hashes.as<uint32_t>(), c->recs.as<uint32_t>(), seg1, tiles1_d, 1,
+                                            tiles1, 32 - B1, bins1, kw, sh.max_len, c->ld_matrix_incl.as<uint32_t>(),
+                                            c->ld_part.as<uint32_t>(), c->st, packed));
+    }
+    // the fused pack's slab segments: [0] seg_start (parts + 1) | cursor = seg_end (parts) | tile_start (parts + 1)
+    const uint32_t f_parts = fused ? fused->parts : 0;
+    uint32_t *f_seg_start = fused ? c->ld_seg.as<uint32_t>() : nullptr;
+    uint32_t *f_seg_end = fused ? f_seg_start + (f_parts + 4) : nullptr;
+    uint32_t *f_tiles = fused ? f_seg_end + (f_parts + 4) : nullptr;
     const uint32_t *parted = c->ld_part.as<uint32_t>();
     uint32_t U32 = 0, overflow = 0;
     for (;;) {
         const uint32_t *bucket_end = nullptr;
-        FQD_TRY(zero_ctr32(c, C_BAD));
+        if (!fused)          // (the fused pack has already run and may have raised bit 4)
+            FQD_TRY(zero_ctr32(c, C_BAD));
         if (B2 == 0) {
             HIP_TRY(c, hipMemcpyAsync(c->ld_start.p, start1, ((size_t)bins1 + 1) * 4, hipMemcpyDeviceToDevice, c->st));
         } else {
             // ---- level 2: every part into 2^B2 buckets by the next B2 hash bits
-            HIP_TRY(c, fqd::launch_tile_starts(start1, bins1, tiles2_d, c->st));
+            if (fused)
+                HIP_TRY(c, fqd::launch_slab_tile_starts(f_seg_start, f_seg_end, f_parts, f_tiles, c->st));
+            else
+                HIP_TRY(c, fqd::launch_tile_starts(start1, bins1, tiles2_d, c->st));
             if (slab_cap) {
                 HIP_TRY(c, fqd::launch_slab_starts(n_buckets, slab_cap, c->ld_start.as<uint32_t>(),
                                                    c->ld_cursor.as<uint32_t>(), c->st));
@@ -198,10 +229,16 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
                 HIP_TRY(c, fqd::launch_bucket_starts(c->ld_hist_incl.as<uint32_t>(), n_buckets, c->ld_start.as<uint32_t>(),
                                                      c->ld_cursor.as<uint32_t>(), c->st));
             }
-            KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1,
-                                                max_tiles2, 32 - B, bins2, kw, sh.max_len, c->ld_cursor.as<uint32_t>(),
-                                                c->ld_part2.as<uint32_t>(), c->st, IdSource(), slab_cap,
-                                                c->d_ctr32.as<uint32_t>() + C_BAD));
+            if (fused)
+                KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(
+                          false, nullptr, c->ld_part.as<uint32_t>(), f_seg_start, f_tiles, f_parts, tiles1 + f_parts,
+                          32 - B, bins2, kw, sh.max_len, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<uint32_t>(), c->st,
+                          IdSource(), slab_cap, c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end, fused->sub_bits));
+            else
+                KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(
+                          false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1, max_tiles2, 32 - B, bins2,
+                          kw, sh.max_len, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<uint32_t>(), c->st, IdSource(),
+                          slab_cap, c->d_ctr32.as<uint32_t>() + C_BAD));
             parted = c->ld_part2.as<uint32_t>();
         }
         KTIME(c, FQD_K_DEDUPE, fqd::launch_bucket_dedupe(parted, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
@@ -211,6 +248,21 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
         FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
         HIP_TRY(c, hipMemcpyAsync(&U32, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 4, hipMemcpyDeviceToHost,
                                   c->st));
+        if (fused) {
+            // one readback: the pack kernel's foreign-byte flag and every overflow flag (bit 4: a
+            // level-1 slab of the fused pack, bit 2: a level-2 slab, bit 1: a bucket's LDS table)
+            uint32_t ctr[C_PACKBAD + 1] = {0};
+            FQD_TRY(read_ctr32n(c, 0, ctr, C_PACKBAD + 1));
+            overflow = ctr[C_BAD];
+            fused->pack_bad = ctr[C_PACKBAD];
+            if (overflow & 4u)
+                c->fused_off = true;
+            if (overflow & 2u)
+                c->slab_off = true;
+            if (overflow || fused->pack_bad)
+                return FQD_OK;
+            break;
+        }
         FQD_TRY(read_ctr32(c, C_BAD, &overflow));
         if (slab_cap && (overflow & 2u)) {
             // a slab was too small (a key with hundreds of copies): once more with exact bucket sizes
@@ -325,7 +377,7 @@ void fqd_destroy(fqd_ctx *c)
                       &c->ed_payload, &c->ed_hash_sorted, &c->ed_payload_sorted, &c->ed_cands, &c->ed_cands_sorted,
                       &c->d_alphabet, &c->labels, &c->best, &c->state,
                       &c->blocked, &c->kept, &c->kept_u32, &c->kept_scan, &c->kept_ids, &c->kept_ids_sorted, &c->tmp,
-                      &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners, &c->taint, &c->root_taint, &c->gp_a, &c->gp_b, &c->gp_small, &c->gp_cands, &c->seg_tab};
+                      &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners, &c->taint, &c->root_taint, &c->gp_a, &c->gp_b, &c->gp_small, &c->gp_cands, &c->seg_tab, &c->ld_seg};
     for (DevBuf *b : bufs)
         b->release();
     for (hipEvent_t e : c->tev)
@@ -493,6 +545,7 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
     c->n = n;
     c->owners_done = c->owner_rule;
     c->hashes_valid = true;
+    c->recs_valid = true;
     c->stage = ST_PACKED;
     return FQD_OK;
 }
@@ -641,10 +694,102 @@ static int collapse_impl(fqd_ctx *c, const uint32_t *weights, int mem, IdSource 
     return FQD_OK;
 }
 
+// Pack + collapse for fqd_cluster_keys with the pack kernel writing straight into level 1 of the
+// LDS collapse (pack.hip FUSED): the packed reads never exist in read order, which saves one write
+// and one read of all records, the hash array and the level-1 histogram pass (1.0 -> 0.55 ms of a
+// 3.9 ms job at 50 M reads). *done = false: not applicable, or some slab / table overflowed or the
+// keys hold a byte outside "ACGNT" -- the caller then goes the plain way, which handles all that.
+static int pack_collapse_fused(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uint32_t fixed_len, int mem,
+                               const uint32_t *weights, int aux_mem, bool *done)
+{
+    *done = false;
+    const char *force = getenv("FQD_COLLAPSE");
+    if (c->fused_off || getenv("FQD_NO_FUSED_PACK") || c->owner_rule.parts || (force && !strcmp(force, "sort")))
+        return FQD_OK;
+    uint64_t min_reads = 8ull << 20;   // below that the 8192 level-1 parts are too small to be worth it
+    if (const char *e = getenv("FQD_FUSED_MIN_READS"))
+        min_reads = strtoull(e, nullptr, 10);
+    if (n < min_reads || n < 32768 || n >= 0xFFFFFF00ull || !fixed_len)
+        return FQD_OK;
+    if (mem == FQD_DEVICE && ((uintptr_t)bytes & 15u))
+        return FQD_OK;                 // fqd_pack_keys reports it
+    uint8_t present[128], lut[256];
+    if (c->forced) {
+        if (c->forced_ragged || c->forced_max_len != fixed_len)
+            return FQD_OK;
+        memcpy(present, c->forced_present, 128);
+    } else {
+        memset(present, 0, sizeof present);
+        for (const char *p = "ACGNT"; *p; p++)
+            present[(int)*p] = 1;
+    }
+    c->stage = ST_EMPTY;
+    build_alphabet(c, present, lut);
+    FQD_TRY(set_geometry(c, fixed_len, 0));
+    const KeyShape sh = c->ks;
+    if (sh.ragged || sh.stride != 4 || sh.planes * sh.words > 3)
+        return FQD_OK;
+    const uint32_t B = lds_bucket_bits(n);
+    if (B <= 8)
+        return FQD_OK;
+    // 256 level-1 bins x 32 sub-parts: tile t adds to sub-part t % 32 of its bins. (Measured at 50 M
+    // reads: up to 16 sub-parts per bin the tiles queue on the part cursors and the kernel takes
+    // 1.0 ms; from 32 on, 0.55-0.6 ms.)
+    const uint32_t sub_bits = 5, parts = 256u << sub_bits;
+    const uint32_t cap1 = (uint32_t)(((n / parts) * 5 / 4 + 256 + 3) & ~3ull);
+    if ((uint64_t)parts * cap1 + n >= 0xFFFFFF00ull)
+        return FQD_OK;
+    FQD_TRY(upload_lut(c, lut));
+    const uint64_t n_bytes = n * (uint64_t)fixed_len;
+    const uint8_t *d_bytes;
+    StageTimer pack_timer(c, FQD_T_PACK);
+    FQD_TRY(to_device(c, bytes, (size_t)n_bytes, mem, c->in_bytes, &d_bytes));
+    HIP_TRY(c, c->ld_part.reserve((size_t)parts * cap1 * 16 + 16));
+    HIP_TRY(c, c->ld_seg.reserve((size_t)3 * (parts + 4) * 4));
+    uint32_t *seg_start = c->ld_seg.as<uint32_t>(), *cursor = seg_start + (parts + 4);
+    FQD_TRY(zero_ctr32(c, 0, C_N32));
+    HIP_TRY(c, fqd::launch_slab_starts(parts, cap1, seg_start, cursor, c->st));
+    const fqd::PackScatter fs{cursor, reinterpret_cast<uint4 *>(c->ld_part.p), c->d_ctr32.as<uint32_t>() + C_BAD,
+                              32 - 8, 256, 1u << sub_bits, cap1};
+    {
+        StageTimer kernel_timer(c, FQD_T_PACK_KERNEL);
+        KTIME(c, FQD_K_PACK, fqd::launch_pack(d_bytes, n_bytes, nullptr, n, fixed_len, sh, c->d_lut.as<uint8_t>(), lut,
+                                              nullptr, nullptr, nullptr, nullptr, fqd::OwnerRule{},
+                                              c->d_ctr32.as<uint32_t>() + C_PACKBAD, c->st, &fs));
+        kernel_timer.stop();
+    }
+    pack_timer.stop();
+    c->n = n;
+    c->hashes_valid = false;
+    c->recs_valid = false;
+    c->owners_done = fqd::OwnerRule{};
+    StageTimer timer(c, FQD_T_COLLAPSE);
+    c->U = 0;
+    c->n_counted = 0;
+    const uint32_t *d_w;
+    FQD_TRY(to_device(c, weights, (size_t)n, aux_mem, c->in_weights, &d_w));
+    FusedLevel1 f{parts, sub_bits, B};
+    bool ok = false;
+    FQD_TRY(collapse_lds(c, weights ? d_w : nullptr, IdSource(), &ok, &f));
+    timer.stop();
+    if (getenv("FQD_DEBUG"))
+        fprintf(stderr, "[fqd] fused pack + collapse: n=%llu parts=%u cap=%u done=%d pack_bad=%u fused_off=%d\n",
+                (unsigned long long)n, parts, cap1, (int)ok, f.pack_bad, (int)c->fused_off);
+    if (!ok)
+        return FQD_OK;
+    c->collapse_path = 1;
+    c->collapsed = true;
+    c->first_distinct = true;
+    set_id_range(c, n);
+    c->stage = ST_UNIQUE;
+    *done = true;
+    return FQD_OK;
+}
+
 int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, int mem, uint64_t *n_unique)
 {
     FQD_TRY(bind(c));
-    if (c->stage < ST_PACKED)
+    if (c->stage < ST_PACKED || !c->recs_valid)
         return fail(c, FQD_E_STATE, "fqd_collapse before fqd_pack_keys/fqd_import_packed");
     IdSource ids;
     if (read_ids && c->n)
@@ -656,7 +801,7 @@ int fqd_collapse_received(fqd_ctx *c, const uint32_t *weights, const uint64_t *s
                           uint32_t n_seg, uint64_t id_limit, int mem, uint64_t *n_unique)
 {
     FQD_TRY(bind(c));
-    if (c->stage < ST_PACKED)
+    if (c->stage < ST_PACKED || !c->recs_valid)
         return fail(c, FQD_E_STATE, "fqd_collapse_received before fqd_import_packed");
     const KeyShape sh = c->ks;
     if (sh.stride <= sh.planes * sh.words)
@@ -709,12 +854,36 @@ int fqd_collapse_received(fqd_ctx *c, const uint32_t *weights, const uint64_t *s
     return collapse_impl(c, weights, mem, ids, id_limit, n_unique);
 }
 
+static int cluster_tail(fqd_ctx *c, int max_distance, int metric, int method, fqd_summary *out);
+
 int fqd_cluster(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, int mem, int max_distance, int metric,
                 int method, fqd_summary *out)
 {
     if (max_distance < 0)
         return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
     FQD_TRY(fqd_collapse(c, weights, read_ids, mem, nullptr));
+    return cluster_tail(c, max_distance, metric, method, out);
+}
+
+int fqd_cluster_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, uint32_t fixed_len, int mem,
+                     const uint32_t *weights, const uint64_t *read_ids, int aux_mem, int max_distance, int metric,
+                     int method, fqd_summary *out)
+{
+    FQD_TRY(bind(c));
+    if (max_distance < 0)
+        return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
+    bool done = false;
+    if (!offsets && !read_ids)
+        FQD_TRY(pack_collapse_fused(c, bytes, n, fixed_len, mem, weights, aux_mem, &done));
+    if (!done) {
+        FQD_TRY(fqd_pack_keys(c, bytes, offsets, n, fixed_len, mem));
+        FQD_TRY(fqd_collapse(c, weights, read_ids, aux_mem, nullptr));
+    }
+    return cluster_tail(c, max_distance, metric, method, out);
+}
+
+static int cluster_tail(fqd_ctx *c, int max_distance, int metric, int method, fqd_summary *out)
+{
     FQD_TRY(fqd_find_edges(c, max_distance, metric, 0, 1, nullptr));
     // no host round trip between components and dissection; labels are flattened only if read
     FQD_TRY(fqd_api_components_queue(c, method == FQD_METHOD_HIGHEST_COUNT));

@@ -75,7 +75,7 @@ struct DevBuf {
 enum Stage { ST_EMPTY = 0, ST_PACKED = 1, ST_UNIQUE = 2, ST_EDGES = 3, ST_LABELS = 4, ST_KEPT = 5 };
 
 // small device-side words read back by the host
-enum Ctr { C_BAD = 0, C_COLLISIONS = 1, C_CHANGED = 2, C_MINLEN = 3, C_MAXLEN = 4, C_N32 = 8 };
+enum Ctr { C_BAD = 0, C_COLLISIONS = 1, C_CHANGED = 2, C_MINLEN = 3, C_MAXLEN = 4, C_PACKBAD = 5, C_N32 = 8 };
 enum Ctr64 { C64_EDGES = 0, C64_ROOTS = 1, C64_SUM = 2, C64_STATS = 3, C64_CANDS = 4, C64_CAND_NEED = 5, C64_SLAB = 6, C64_N = 8 };
 
 }  // namespace
@@ -104,6 +104,8 @@ struct fqd_ctx {
     // stage 1
     uint64_t n = 0;
     DevBuf in_bytes, in_offsets, recs, lens, hashes, owners;
+    bool fused_off = false;        // fqd_cluster_keys: a level-1 slab of the fused pack overflowed once -- plain pack from now on
+    bool recs_valid = false;       // c->recs holds the packed reads in read order (not after the fused pack)
     bool gp_slab_off = false;      // grouped search: same, for the (hash, uid) partition
     bool slab_off = false;         // LDS collapse: a slab of level 2 overflowed once, use exact bucket sizes
     bool hashes_valid = false;     // `hashes` holds the record hashes of the packed reads (lazy after an import)
@@ -119,7 +121,7 @@ struct fqd_ctx {
     DevBuf in_weights, in_read_ids, hs_sorted, ids, ids_sorted, flags, run_idx, run_start, run_weight, live_flag,
         live_idx, collision_runs;
     DevBuf urecs, ulens, ucounts, ufirst;
-    DevBuf ld_small, ld_part2, ld_matrix, ld_matrix_incl;
+    DevBuf ld_small, ld_part2, ld_matrix, ld_matrix_incl, ld_seg;
     DevBuf ld_hist, ld_hist_incl, ld_start, ld_cursor, ld_part, ld_tmp_rec, ld_tmp_count, ld_tmp_first, ld_unique,
         ld_unique_incl;
     int collapse_path = 0;  // 1: LDS bucket dedupe, 2: sort + verify (last fqd_collapse)
@@ -232,6 +234,13 @@ int from_device(fqd_ctx *c, T *dst, const void *src, size_t count, int mem)
 int read_ctr32(fqd_ctx *c, int idx, uint32_t *v)
 {
     HIP_TRY(c, hipMemcpyAsync(v, c->d_ctr32.as<uint32_t>() + idx, 4, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    return FQD_OK;
+}
+
+int read_ctr32n(fqd_ctx *c, int idx, uint32_t *v, int count)
+{
+    HIP_TRY(c, hipMemcpyAsync(v, c->d_ctr32.as<uint32_t>() + idx, 4 * (size_t)count, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     return FQD_OK;
 }

@@ -9,7 +9,7 @@ extern "C" {
 int fqd_export_packed(fqd_ctx *c, uint32_t *recs, uint32_t *lens, uint32_t *hashes, int mem)
 {
     FQD_TRY(bind(c));
-    if (c->stage < ST_PACKED)
+    if (c->stage < ST_PACKED || !c->recs_valid)
         return fail(c, FQD_E_STATE, "nothing packed");
     FQD_TRY(from_device(c, recs, c->recs.p, (size_t)c->n * c->ks.stride, mem));
     if (lens) {
@@ -82,7 +82,7 @@ int fqd_export_packed_by_owner(fqd_ctx *c, uint32_t n_parts, uint64_t id0, const
                                uint32_t *lens, uint64_t *ids, uint32_t *weights_out, uint64_t *counts, int mem)
 {
     FQD_TRY(bind(c));
-    if (c->stage < ST_PACKED)
+    if (c->stage < ST_PACKED || !c->recs_valid)
         return fail(c, FQD_E_STATE, "nothing packed");
     FQD_TRY(check_parts(c, n_parts, mem, "fqd_export_packed_by_owner"));
     const uint64_t n = c->n;
@@ -98,7 +98,7 @@ int fqd_export_packed_by_segment(fqd_ctx *c, uint32_t n_parts, uint32_t n_segmen
                                  uint32_t *weights_out, uint64_t *counts, int mem)
 {
     FQD_TRY(bind(c));
-    if (c->stage < ST_PACKED)
+    if (c->stage < ST_PACKED || !c->recs_valid)
         return fail(c, FQD_E_STATE, "nothing packed");
     FQD_TRY(check_parts(c, n_parts, mem, "fqd_export_packed_by_segment"));
     if (n_segments == 0 || segment >= n_segments)
@@ -201,6 +201,7 @@ int fqd_import_packed(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, ui
     c->n = n;
     c->hashes_valid = false;       // computed when somebody needs them (ensure_hashes)
     c->owners_done = fqd::OwnerRule{};
+    c->recs_valid = true;
     c->stage = ST_PACKED;
     return FQD_OK;
 }

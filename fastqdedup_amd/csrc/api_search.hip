@@ -115,7 +115,7 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
     uint32_t slab_cap = 0;
     if (B2 && !c->gp_slab_off && !getenv("FQD_GROUP_NO_SLABS")) {
         slab_cap = (uint32_t)(((U >> B) * 3 / 2 + 64 + 3) & ~3ull);
-        if ((uint64_t)slab_cap * n_buckets >= 0xFFFFFF00ull)
+        if ((uint64_t)slab_cap * n_buckets + U >= 0xFFFFFF00ull)
             slab_cap = 0;
     }
     if (B2 == 0) {

@@ -98,10 +98,20 @@ __global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter_kernel(Re
                                                                               uint32_t *__restrict__ cursor,
                                                                               uint4 *__restrict__ out,
                                                                               uint32_t slab_cap,
-                                                                              uint32_t *__restrict__ slab_overflow)
+                                                                              uint32_t *__restrict__ slab_overflow,
+                                                                              const uint32_t *__restrict__ seg_end,
+                                                                              uint32_t seg_shift)
 {
     fqd_partition::scatter_body<RecordPolicy, LEVEL1, MAXB>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
-                                                            slab_cap, slab_overflow);
+                                                            slab_cap, slab_overflow, seg_end, seg_shift);
+}
+
+__global__ __launch_bounds__(1024) void slab_tile_starts_kernel(const uint32_t *__restrict__ seg_start,
+                                                                const uint32_t *__restrict__ seg_end, uint32_t n_seg,
+                                                                uint32_t *__restrict__ tile_start)
+{
+    fqd_partition::slab_tile_starts_body<fqd_partition::THREADS * RecordPolicy::EPT>(seg_start, seg_end, n_seg,
+                                                                                     tile_start);
 }
 
 // slab mode of level 2: bucket b owns slots [b * cap, (b + 1) * cap); its cursor starts there
@@ -321,7 +331,8 @@ hipError_t launch_part_hist(bool level1, const uint32_t *hashes, const uint32_t 
 hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
                                const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
-                               hipStream_t st, IdSource packed, uint32_t slab_cap, uint32_t *slab_overflow)
+                               hipStream_t st, IdSource packed, uint32_t slab_cap, uint32_t *slab_overflow,
+                               const uint32_t *seg_end, uint32_t seg_shift)
 {
     if (n_bins > fqd_partition::MAX_BINS)
         return hipErrorInvalidValue;
@@ -331,7 +342,7 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
 #define FQD_SCATTER(L1, MB)                                                                                    \
     part_scatter_kernel<L1, MB><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, \
                                                                               shift, n_bins, cursor, out4, slab_cap, \
-                                                                              slab_overflow)
+                                                                              slab_overflow, seg_end, seg_shift)
     if (n_bins <= 256) {
         if (level1) FQD_SCATTER(true, 256); else FQD_SCATTER(false, 256);
     } else {
@@ -360,6 +371,13 @@ hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, u
 hipError_t launch_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket_start, uint32_t *cursor, hipStream_t st)
 {
     slab_starts_kernel<<<(n_buckets + 1 + 255) / 256, 256, 0, st>>>(n_buckets, cap, bucket_start, cursor);
+    return hipGetLastError();
+}
+
+hipError_t launch_slab_tile_starts(const uint32_t *seg_start, const uint32_t *seg_end, uint32_t n_seg,
+                                   uint32_t *tile_start, hipStream_t st)
+{
+    slab_tile_starts_kernel<<<1, 1024, 0, st>>>(seg_start, seg_end, n_seg, tile_start);
     return hipGetLastError();
 }
 

@@ -218,10 +218,17 @@ hipError_t launch_scan_lens(const uint64_t *offsets, uint64_t n, uint32_t *minma
 struct OwnerRule {
     uint32_t parts = 0, nseg = 1, seg = 0;
 };
+// pack fused with level 1 of the LDS collapse (pack.hip, FUSED): the tile goes out partitioned
+struct PackScatter {
+    uint32_t *cursor;      // n_bins * subs part cursors, cursor[p] starts at p * cap
+    uint4 *out;            // n_bins * subs * cap records
+    uint32_t *overflow;    // bit 4: some part's slab was full
+    uint32_t shift, n_bins, subs, cap;
+};
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
                        uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, const uint8_t *lut_host,
                        uint32_t *recs, uint32_t *lens, uint32_t *hashes, uint32_t *owners, OwnerRule rule,
-                       uint32_t *bad_flag, hipStream_t st);
+                       uint32_t *bad_flag, hipStream_t st, const PackScatter *fused = nullptr);
 hipError_t launch_hash_records(const uint32_t *recs, const uint32_t *lens, uint64_t n, KeyShape sh,
                                uint32_t *hashes, hipStream_t st);
 
@@ -257,7 +264,10 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
                                const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
                                hipStream_t st, IdSource packed = IdSource(), uint32_t slab_cap = 0,
-                               uint32_t *slab_overflow = nullptr);
+                               uint32_t *slab_overflow = nullptr, const uint32_t *seg_end = nullptr,
+                               uint32_t seg_shift = 0);
+hipError_t launch_slab_tile_starts(const uint32_t *seg_start, const uint32_t *seg_end, uint32_t n_seg,
+                                   uint32_t *tile_start, hipStream_t st);
 uint32_t part_tile_size();
 hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                 hipStream_t st);

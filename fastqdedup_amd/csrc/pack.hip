@@ -84,12 +84,20 @@ struct PackHash {
 
 // LDS carve (u32 words): lut[64] | scratch[PACK_WAVES][64] | planes[K][plane_words] | tile[kpb*stride]
 // A "row" is 2048 bytes (64 lanes x 2 groups x 16 bytes) = 64 stream dwords per plane.
-template <int K, bool SWAR>
+// FUSED (one-uint4 records, fixed length, kpb <= 1024): instead of writing the records in read order
+// (phase C), the block partitions its tile by the top hash bits straight into level 1 of the LDS
+// collapse (collapse_lds.hip) -- the records never make the round trip through HBM in read order.
+// No histogram pass can have run (it would have to read the key bytes once more), so level 1 works
+// in slab mode like level 2: part (bin, sub) owns part_out[(bin * subs + sub) * cap, +cap), and a
+// tile reserves its share of a bin with ONE atomic on that part's cursor. `subs` parts per bin
+// (tile t feeds sub t % subs) spread those atomics: with one cursor per bin the 48 K tiles of a
+// 50 M-read job queue up on a few hundred addresses.
+template <int K, bool SWAR, bool FUSED = false>
 __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     const uint8_t *__restrict__ bytes, uint64_t n_bytes, const uint64_t *__restrict__ offsets, uint64_t n,
     uint32_t fixed_len, KeyShape sh, uint32_t kpb, uint32_t plane_words, const uint8_t *__restrict__ lut_g,
     PackHash ph, uint32_t *__restrict__ recs, uint32_t *__restrict__ lens, uint32_t *__restrict__ hashes,
-    uint32_t *__restrict__ owners, fqd::OwnerRule rule, uint32_t *__restrict__ bad_flag)
+    uint32_t *__restrict__ owners, fqd::OwnerRule rule, uint32_t *__restrict__ bad_flag, fqd::PackScatter fs)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *lut32 = smem;                                   // 256 bytes
@@ -256,6 +264,82 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     }
     __syncthreads();
 
+    if (FUSED) {
+        // ---- phase D: the tile leaves partitioned by hash bin --------------------
+        // tables behind the tile: hist[n_bins] | off[n_bins] | base[n_bins] | wave[4] | bin16[kpb]
+        uint32_t *s_hist = tile + (size_t)kpb * 4u, *s_off = s_hist + fs.n_bins, *s_base = s_off + fs.n_bins;
+        uint32_t *s_wave = s_base + fs.n_bins;
+        uint16_t *s_bin16 = reinterpret_cast<uint16_t *>(s_wave + 4);
+        uint4 *tile4 = reinterpret_cast<uint4 *>(tile);
+        constexpr uint32_t R = 4;            // kpb <= 1024
+        for (uint32_t b = tid; b < fs.n_bins; b += PACK_THREADS)
+            s_hist[b] = 0;
+        __syncthreads();
+        uint4 v[R];
+        uint32_t bin[R], rank[R];
+#pragma unroll
+        for (uint32_t e = 0; e < R; e++) {
+            const uint32_t k = e * PACK_THREADS + tid;
+            bin[e] = 0xFFFFFFFFu;
+            if (k < nk) {
+                v[e] = tile4[k];
+                const uint32_t rec[3] = {v[e].x, v[e].y, v[e].z};
+                const uint32_t h = fqd_hash_record(rec, W * K, fixed_len);
+                v[e].w = (uint32_t)(key0 + k);               // the read index travels with the record
+                bin[e] = (h >> fs.shift) & (fs.n_bins - 1);
+                rank[e] = atomicAdd(&s_hist[bin[e]], 1u);
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the bin counts: n_bins <= 256, one bin per thread
+        const uint32_t mine = tid < fs.n_bins ? s_hist[tid] : 0u;
+        uint32_t incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if ((int)lane >= o)
+                incl += up;
+        }
+        if (lane == 63)
+            s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t excl = incl - mine;
+        for (uint32_t wv = 0; wv < wave; wv++)
+            excl += s_wave[wv];
+        if (tid < fs.n_bins) {
+            s_off[tid] = excl;
+            uint32_t base = 0;
+            if (mine) {
+                const uint32_t part = tid * fs.subs + (blockIdx.x & (fs.subs - 1));
+                const uint32_t g = atomicAdd(&fs.cursor[part], mine);
+                if ((uint64_t)g + mine > ((uint64_t)part + 1) * fs.cap)
+                    atomicOr(fs.overflow, 4u);    // the part's slab is full: the caller packs the plain way
+                base = g - excl;
+            }
+            s_base[tid] = base;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t e = 0; e < R; e++)
+            if (bin[e] != 0xFFFFFFFFu) {
+                const uint32_t p = s_off[bin[e]] + rank[e];
+                tile4[p] = v[e];
+                s_bin16[p] = (uint16_t)bin[e];
+            }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t e = 0; e < R; e++) {
+            const uint32_t p = e * PACK_THREADS + tid;
+            if (p < nk) {
+                // (records that would land behind the slab's end are dropped: what is written stays
+                // gap-free, see partition.cuh)
+                const uint32_t bn = s_bin16[p];
+                const uint32_t pos = s_base[bn] + p;
+                if (pos < (bn * fs.subs + (blockIdx.x & (fs.subs - 1)) + 1) * fs.cap)
+                    fs.out[pos] = tile4[p];
+            }
+        }
+        return;
+    }
     // ---- phase C: hash per key, then stream the tile out ---------------------
     for (uint32_t k = tid; k < nk; k += PACK_THREADS) {
         const uint32_t len = offsets ? (uint32_t)(offsets[key0 + k + 1] - offsets[key0 + k]) : fixed_len;
@@ -363,7 +447,7 @@ static bool find_pack_hash(const uint8_t *lut_host, PackHash &ph)
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
                        uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, const uint8_t *lut_host,
                        uint32_t *recs, uint32_t *lens, uint32_t *hashes, uint32_t *owners, OwnerRule rule,
-                       uint32_t *bad_flag, hipStream_t st)
+                       uint32_t *bad_flag, hipStream_t st, const PackScatter *fused)
 {
     if (!rule.parts)
         owners = nullptr;
@@ -383,6 +467,14 @@ hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *o
     uint32_t lds = pack_lds_bytes(kpb, sh, plane_words);
     if (lds > budget)
         return hipErrorInvalidValue;  // a single key does not fit the LDS tile
+    PackScatter fs{};
+    if (fused) {
+        if (offsets || sh.ragged || sh.stride != 4 || sh.planes > 3 || kpb > 1024 || fused->n_bins > 256 ||
+            (fused->n_bins & (fused->n_bins - 1)) || (fused->subs & (fused->subs - 1)) || owners)
+            return hipErrorInvalidValue;
+        fs = *fused;
+        lds += (3 * fs.n_bins + 4) * 4 + kpb * 2;
+    }
     const uint64_t blocks = (n + kpb - 1) / kpb;
     if (blocks > 0x7FFFFFFFull)
         return hipErrorInvalidValue;
@@ -391,7 +483,27 @@ hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *o
 #define FQD_PACK_CASE(KK, SW)                                                                              \
     pack_kernel<KK, SW><<<(unsigned)blocks, PACK_THREADS, lds, st>>>(bytes, n_bytes, offsets, n, fixed_len, sh, \
                                                                      kpb, plane_words, lut_dev, ph, recs, lens, \
-                                                                     hashes, owners, rule, bad_flag)
+                                                                     hashes, owners, rule, bad_flag, fs)
+#define FQD_PACK_FUSED(KK, SW)                                                                             \
+    pack_kernel<KK, SW, true><<<(unsigned)blocks, PACK_THREADS, lds, st>>>(bytes, n_bytes, offsets, n, fixed_len, \
+                                                                           sh, kpb, plane_words, lut_dev, ph, recs, \
+                                                                           lens, hashes, owners, rule, bad_flag, fs)
+    if (fused) {
+        if (swar) {
+            switch (sh.planes) {
+            case 1: FQD_PACK_FUSED(1, true); break;
+            case 2: FQD_PACK_FUSED(2, true); break;
+            default: FQD_PACK_FUSED(3, true); break;
+            }
+        } else {
+            switch (sh.planes) {
+            case 1: FQD_PACK_FUSED(1, false); break;
+            case 2: FQD_PACK_FUSED(2, false); break;
+            default: FQD_PACK_FUSED(3, false); break;
+            }
+        }
+        return hipGetLastError();
+    }
     if (swar) {
         switch (sh.planes) {
         case 1: FQD_PACK_CASE(1, true); break;
@@ -411,6 +523,7 @@ hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *o
         }
     }
 #undef FQD_PACK_CASE
+#undef FQD_PACK_FUSED
     return hipGetLastError();
 }
 

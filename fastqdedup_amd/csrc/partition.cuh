@@ -30,10 +30,12 @@ constexpr uint32_t MAX_BINS = 1024;
 // better for records).
 
 // tile_start[s] = first tile of segment s, tile_start[n_seg] = tile count.
+// seg_end == NULL: segment s ends where s + 1 starts; else segments are slabs with slack behind them.
 template <uint32_t TILE>
 __device__ __forceinline__ bool tile_of_block(const uint32_t *__restrict__ seg_start,
                                               const uint32_t *__restrict__ tile_start, uint32_t n_seg,
-                                              uint32_t &seg, uint32_t &lo, uint32_t &hi)
+                                              uint32_t &seg, uint32_t &lo, uint32_t &hi,
+                                              const uint32_t *__restrict__ seg_end = nullptr)
 {
     const uint32_t t = blockIdx.x;
     if (t >= tile_start[n_seg])
@@ -48,7 +50,10 @@ __device__ __forceinline__ bool tile_of_block(const uint32_t *__restrict__ seg_s
     }
     seg = a;
     lo = seg_start[a] + (t - tile_start[a]) * TILE;
-    hi = min(lo + TILE, seg_start[a + 1]);
+    hi = seg_start[a + 1];
+    if (seg_end)
+        hi = min(hi, seg_end[a]);        // (a cursor that ran past its slab's end: the slab is full)
+    hi = min(lo + TILE, hi);
     return true;
 }
 
@@ -95,11 +100,18 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
                                              const uint32_t *__restrict__ tile_start, uint32_t n_seg, uint32_t shift,
                                              uint32_t n_bins, uint32_t *__restrict__ cursor,
                                              typename Policy::Item *__restrict__ out, uint32_t slab_cap = 0,
-                                             uint32_t *__restrict__ slab_overflow = nullptr)
+                                             uint32_t *__restrict__ slab_overflow = nullptr,
+                                             const uint32_t *__restrict__ seg_end = nullptr, uint32_t seg_shift = 0)
 {
+    // seg_end / seg_shift (level 2 behind the fused pack, pack.hip): the input segments are slabs
+    // [seg_start[s], seg_end[s]) and 2^seg_shift consecutive segments are sub-parts of ONE level-1
+    // part -- they feed the same buckets.
     // slab_cap != 0 (level 2 only): bucket k owns out[k * slab_cap, (k + 1) * slab_cap) and its cursor
-    // started at k * slab_cap -- no histogram pass told us how full it gets. A run that would cross
-    // the slab's end is dropped and *slab_overflow gets bit 1: the caller redoes the level exactly.
+    // started at k * slab_cap -- no histogram pass told us how full it gets. Items that would land
+    // behind the slab's end are dropped and *slab_overflow gets bit 1: the caller redoes the level
+    // exactly. What IS written stays gap-free ([start, min(cursor, end)) holds items of this run and
+    // nothing else): the consumers of an overflowed attempt still run before the flag is read, and
+    // stale bytes taken for (hash, uid) items or read indices would send them out of bounds.
     using Item = typename Policy::Item;
     constexpr uint32_t EPT = Policy::EPT, TILE = THREADS * EPT;
     // MAXB bounds n_bins (the three bin tables): 256 instead of 1024 is one more workgroup per CU.
@@ -112,8 +124,9 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
     __shared__ Item s_stage[TILE];
     __shared__ uint16_t s_stage_bin[TILE];
     uint32_t seg, lo, hi;
-    if (!tile_of_block<TILE>(seg_start, tile_start, n_seg, seg, lo, hi))
+    if (!tile_of_block<TILE>(seg_start, tile_start, n_seg, seg, lo, hi, seg_end))
         return;
+    seg >>= seg_shift;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t b = tid; b < n_bins; b += THREADS)
         s_hist[b] = 0;
@@ -168,10 +181,8 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
             s_base[b] = g - run;
             if (!LEVEL1 && slab_cap && c) {
                 const uint64_t end = ((uint64_t)seg * n_bins + b + 1) * slab_cap;
-                if ((uint64_t)g + c > end) {
-                    s_base[b] = 0xFFFFFFFFu;        // nothing of this bin leaves the tile
+                if ((uint64_t)g + c > end)
                     atomicOr(slab_overflow, 2u);
-                }
             }
             run += c;
         }
@@ -190,9 +201,10 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
     for (uint32_t e = 0; e < EPT; e++) {
         const uint32_t p = e * THREADS + tid;
         if (p < count) {
-            const uint32_t base = s_base[s_stage_bin[p]];
-            if (LEVEL1 || !slab_cap || base != 0xFFFFFFFFu)
-                out[base + p] = s_stage[p];   // consecutive p of one bin: consecutive addresses
+            const uint32_t bn = s_stage_bin[p];
+            const uint32_t pos = s_base[bn] + p;   // consecutive p of one bin: consecutive addresses
+            if (LEVEL1 || !slab_cap || pos < (seg * n_bins + bn + 1) * slab_cap)
+                out[pos] = s_stage[p];
         }
     }
 }
@@ -218,6 +230,41 @@ __device__ __forceinline__ void tile_starts_body(const uint32_t *__restrict__ se
     __syncthreads();
     for (uint32_t t = threadIdx.x; t <= n_seg; t += blockDim.x)
         tile_start[t] = s[t];
+}
+
+// the same for any number of slab segments [seg_start[s], min(seg_end[s], seg_start[s + 1])) (single block of
+// 1024 threads; seg_start has n_seg + 1 entries)
+template <uint32_t TILE>
+__device__ __forceinline__ void slab_tile_starts_body(const uint32_t *__restrict__ seg_start,
+                                                      const uint32_t *__restrict__ seg_end, uint32_t n_seg,
+                                                      uint32_t *__restrict__ tile_start)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t per = (n_seg + blockDim.x - 1) / blockDim.x;
+    const uint32_t s0 = tid * per, s1 = min(s0 + per, n_seg);
+    auto tiles_of = [&](uint32_t t) { return (min(seg_end[t], seg_start[t + 1]) - seg_start[t] + TILE - 1) / TILE; };
+    uint32_t mine = 0;
+    for (uint32_t t = s0; t < s1; t++)
+        mine += tiles_of(t);
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if ((int)lane >= o)
+            incl += up;
+    }
+    if (lane == 63)
+        s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (uint32_t wv = 0; wv < wave; wv++)
+        run += s_wave[wv];
+    for (uint32_t t = s0; t < s1; t++) {
+        tile_start[t] = run;
+        run += tiles_of(t);
+    }
+    if (s1 == n_seg && s0 < n_seg)
+        tile_start[n_seg] = run;
 }
 
 // level 1: part p starts where the scan of the (bin x tile) matrix stood before row p

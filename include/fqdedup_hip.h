@@ -128,6 +128,19 @@ int fqd_dissect(fqd_ctx *ctx, int method, uint64_t *n_kept);
 int fqd_cluster(fqd_ctx *ctx, const uint32_t *weights, const uint64_t *read_ids, int mem,
                 int max_distance, int metric, int method, fqd_summary *out);
 
+/* ---- all of 1..5: the whole hot path in one call ------------------------------
+ * Replaces the reference's per-read Trie.add_sequence loop plus the cluster loop
+ * (src/fastqdedup/__init__.py:240-281) for one batch of keys: fqd_pack_keys + fqd_cluster, with
+ * the same arguments and errors (`mem` places bytes/offsets, `aux_mem` weights/read_ids). Because
+ * the key bytes are at hand for the whole call, short fixed-length keys (records of one uint4)
+ * take a faster way in: the pack kernel partitions its records straight into the collapse, and
+ * the packed reads are never written in read order. After this call the context holds the unique
+ * table and everything behind it, but NOT the packed reads: the fqd_export_packed_* entry points and
+ * fqd_collapse need a fqd_pack_keys first (FQD_E_STATE otherwise). */
+int fqd_cluster_keys(fqd_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n,
+                     uint32_t fixed_len, int mem, const uint32_t *weights, const uint64_t *read_ids,
+                     int aux_mem, int max_distance, int metric, int method, fqd_summary *out);
+
 /* ---- results --------------------------------------------------------------- */
 /* The ids this context LISTS are the first holders that fall into [lo, hi) (default: all).
  * A rank of a multi-GPU job lists the ids of its own reads -- what its pass 2 needs.

@@ -172,6 +172,52 @@ def test_lds_collapse_slab_overflow_retries_exactly(F, oracle):
     assert plain.n_unique > 0
 
 
+@pytest.mark.parametrize("case", ["plain", "weights", "foreign_byte", "crowded_part", "len20"])
+def test_fused_pack_collapse_matches_oracle(F, oracle, monkeypatch, case):
+    """cluster_keys is ONE C call (fqd_cluster_keys); for short fixed-length keys the pack kernel
+    then partitions its records straight into the collapse (no packed reads in read order). Same
+    answer as the oracle and as the two-call way -- also when the attempt has to be abandoned: a byte
+    outside "ACGNT" (the plain pack learns the alphabet) or a key with so many copies that a
+    level-1 slab overflows (plain pack from then on, for this context)."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_FUSED_MIN_READS", "100000")
+    n, L = 300_000, (20 if case == "len20" else 32)
+    keys = synth_keys(n, L, L, 91, sub_rate=3e-3, n_rate=2e-4)
+    rng = np.random.default_rng(4)
+    weights = None
+    if case == "weights":
+        weights = rng.choice(np.array([0, 1, 1, 1], dtype=np.uint32), size=n)
+    if case == "foreign_byte":
+        keys[rng.choice(n, size=50, replace=False), 7] = ord("R")
+    if case == "crowded_part":
+        heavy = rng.choice(n, size=40_000, replace=False)
+        keys[heavy] = keys[heavy[0]]
+        keys[heavy[::11], 3] = ord("N")
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    want = oracle.dedup(raw, fixed_offsets(n, L), weights=weights, max_distance=1, method="directional")
+    ctx = F.Context(0)
+    for job in range(2):        # the second job runs on a context that has learnt (fused_off / slab_off)
+        ctx.kernel_times(reset=True)
+        got = F.cluster_keys(raw, key_len=L, weights=weights, max_distance=1, method="directional", context=ctx)
+        kt = ctx.kernel_times(reset=True)
+        # which way in: the plain level-1 scatter runs only when the fused attempt was given up
+        fused_only = case in ("plain", "weights", "len20")
+        assert kt["part_scatter_kernel<1>"][1] == (0 if fused_only else 1)
+        assert kt["pack_kernel"][1] == (1 if fused_only or (case == "crowded_part" and job == 1) else
+                                        3 if case == "foreign_byte" else 2)
+        assert got.n_counted == (n if weights is None else int(weights.sum()))
+        assert (got.n_unique, got.n_clusters) == (want["n_unique"], want["n_clusters"])
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+    # the two-call way on the same context, and what the one-call way leaves behind
+    ctx.pack_keys(raw, None, L)
+    two = ctx.cluster(weights, None, max_distance=1, method=2)
+    assert (two["n_unique"], two["n_edges"], two["n_kept"]) == (got.n_unique, got.n_edges, got.n_kept)
+    if case == "plain":
+        F.cluster_keys(raw, key_len=L, context=ctx)
+        with pytest.raises(Exception, match="fqd_collapse"):
+            ctx.collapse()       # the packed reads were never written: needs fqd_pack_keys first
+
+
 def test_edit_d1_equal_length_matches_oracle(F, ctx, oracle):
     """Levenshtein <= 1 on equal-length keys == Hamming <= 1 (BASELINE config 5 shape)."""
     from fastqdedup_amd.synth import fixed_offsets, synth_keys
