@@ -224,6 +224,7 @@ struct PackScatter {
     uint4 *out;            // n_bins * subs * cap records
     uint32_t *overflow;    // bit 4: some part's slab was full
     uint32_t shift, n_bins, subs, cap;
+    uint32_t tables_at;    // set by launch_pack: LDS word offset of the partition tables
 };
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
                        uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, const uint8_t *lut_host,
