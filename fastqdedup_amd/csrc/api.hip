@@ -68,7 +68,7 @@ int scan_keys_device(fqd_ctx *c, const uint8_t *d_bytes, const uint64_t *d_offse
     }
     uint32_t seen[256];
     HIP_TRY(c, hipMemcpyAsync(seen, c->d_present.p, sizeof seen, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, stream_wait(c->st));
     for (int b = 128; b < 256; b++)
         if (seen[b])
             return fail(c, FQD_E_VALUE, "Sequence must consist only of ASCII characters");
@@ -246,8 +246,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                                              c->ld_tmp_first.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
                                              c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
         FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
-        HIP_TRY(c, hipMemcpyAsync(&U32, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 4, hipMemcpyDeviceToHost,
-                                  c->st));
+        FQD_TRY(queue_read_u32(c, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 0));
         if (fused) {
             // one readback: the pack kernel's foreign-byte flag and every overflow flag (bit 4: a
             // level-1 slab of the fused pack, bit 2: a level-2 slab, bit 1: a bucket's LDS table)
@@ -261,9 +260,11 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 c->slab_off = true;
             if (overflow || fused->pack_bad)
                 return FQD_OK;
+            U32 = taken_u32(c, 0);
             break;
         }
         FQD_TRY(read_ctr32(c, C_BAD, &overflow));
+        U32 = taken_u32(c, 0);
         if (slab_cap && (overflow & 2u)) {
             // a slab was too small (a key with hundreds of copies): once more with exact bucket sizes
             c->slab_off = true;
@@ -350,6 +351,10 @@ int fqd_create(int device, fqd_ctx **out)
               c->d_ctr32.reserve(C_N32 * 4) == hipSuccess && c->d_ctr64.reserve(C64_N * 8) == hipSuccess &&
               c->d_lut.reserve(256) == hipSuccess &&
               c->d_stats.reserve(FQD_STAT_SLOTS * sizeof(fqd::PairStats)) == hipSuccess;
+    if (ok && hipHostMalloc(&c->h_pin, 256, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        c->h_pin = nullptr;            // read-backs then go through pageable memory
+    }
     if (!ok) {
         g_global_error = "could not create stream/events/buffers on the device";
         fqd_destroy(c);
@@ -380,6 +385,8 @@ void fqd_destroy(fqd_ctx *c)
                       &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners, &c->taint, &c->root_taint, &c->gp_a, &c->gp_b, &c->gp_small, &c->gp_cands, &c->seg_tab, &c->ld_seg};
     for (DevBuf *b : bufs)
         b->release();
+    if (c->h_pin)
+        (void)hipHostFree(c->h_pin);
     for (hipEvent_t e : c->tev)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->kev)
@@ -393,7 +400,7 @@ const char *fqd_last_error(const fqd_ctx *c) { return c ? c->err.c_str() : "null
 int fqd_synchronize(fqd_ctx *c)
 {
     FQD_TRY(bind(c));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, stream_wait(c->st));
     return FQD_OK;
 }
 
@@ -415,7 +422,7 @@ int fqd_configure(fqd_ctx *c, const uint8_t *present128, uint32_t max_len, int r
     build_alphabet(c, c->forced_present, lut);
     FQD_TRY(set_geometry(c, max_len, ragged));
     FQD_TRY(upload_lut(c, lut));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, stream_wait(c->st));
     c->stage = ST_EMPTY;
     return FQD_OK;
 }
@@ -430,7 +437,7 @@ int fqd_scan_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
             n_bytes = offsets[n];
         } else {
             HIP_TRY(c, hipMemcpyAsync(&n_bytes, offsets + n, 8, hipMemcpyDeviceToHost, c->st));
-            HIP_TRY(c, hipStreamSynchronize(c->st));
+            HIP_TRY(c, stream_wait(c->st));
         }
     } else {
         n_bytes = n * (uint64_t)fixed_len;
@@ -464,7 +471,7 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
             n_bytes = n ? offsets[n] : 0;
         } else {
             HIP_TRY(c, hipMemcpyAsync(&n_bytes, offsets + n, 8, hipMemcpyDeviceToHost, c->st));
-            HIP_TRY(c, hipStreamSynchronize(c->st));
+            HIP_TRY(c, stream_wait(c->st));
         }
     } else {
         n_bytes = n * (uint64_t)fixed_len;
@@ -498,7 +505,7 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
             HIP_TRY(c, hipMemcpyAsync(c->d_ctr32.as<uint32_t>() + C_MINLEN, mm, 8, hipMemcpyHostToDevice, c->st));
             HIP_TRY(c, fqd::launch_scan_lens(d_off, n, c->d_ctr32.as<uint32_t>() + C_MINLEN, c->st));
             HIP_TRY(c, hipMemcpyAsync(mm, c->d_ctr32.as<uint32_t>() + C_MINLEN, 8, hipMemcpyDeviceToHost, c->st));
-            HIP_TRY(c, hipStreamSynchronize(c->st));
+            HIP_TRY(c, stream_wait(c->st));
             max_len = mm[1];
             ragged = mm[0] != mm[1];
         } else if (!n) {
@@ -652,7 +659,7 @@ static int collapse_impl(fqd_ctx *c, const uint32_t *weights, int mem, IdSource 
     FQD_TRY(scan_u32(c, c->flags.as<uint32_t>(), c->run_idx.as<uint32_t>(), n));
     uint32_t n_runs = 0;
     HIP_TRY(c, hipMemcpyAsync(&n_runs, c->run_idx.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, stream_wait(c->st));
 
     HIP_TRY(c, c->run_start.reserve(((size_t)n_runs + 1) * 4 + 16));
     HIP_TRY(c, c->run_weight.reserve((size_t)n_runs * 4 + 16));
@@ -820,7 +827,7 @@ int fqd_collapse_received(fqd_ctx *c, const uint32_t *weights, const uint64_t *s
     uint32_t *d_rows = reinterpret_cast<uint32_t *>(d_id0 + n_seg);
     HIP_TRY(c, hipMemcpyAsync(d_id0, seg_id0, (size_t)n_seg * 8, hipMemcpyHostToDevice, c->st));
     HIP_TRY(c, hipMemcpyAsync(d_rows, rows32.data(), ((size_t)n_seg + 1) * 4, hipMemcpyHostToDevice, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));      // rows32 goes out of scope
+    HIP_TRY(c, stream_wait(c->st));      // rows32 goes out of scope
     IdSource ids;
     ids.stamped = c->recs.as<uint32_t>();
     ids.stride = sh.stride;
@@ -968,7 +975,7 @@ int fqd_contains(fqd_ctx *c, const uint8_t *q_bytes, const uint64_t *q_offsets, 
                                     c->st));
     std::vector<uint32_t> flags((size_t)n);
     HIP_TRY(c, hipMemcpyAsync(flags.data(), c->stage_c.p, n * 4, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, stream_wait(c->st));
     for (uint64_t i = 0; i < n; i++)
         out[i] = flags[i] ? 1 : 0;
     return FQD_OK;
@@ -996,7 +1003,7 @@ int fqd_quality_filter(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets
             n_bytes = offsets[n];
         } else {
             HIP_TRY(c, hipMemcpyAsync(&n_bytes, offsets + n, 8, hipMemcpyDeviceToHost, c->st));
-            HIP_TRY(c, hipStreamSynchronize(c->st));
+            HIP_TRY(c, stream_wait(c->st));
         }
     } else {
         n_bytes = n * (uint64_t)fixed_len;
@@ -1012,7 +1019,7 @@ int fqd_quality_filter(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets
         HIP_TRY(c, hipMemcpyAsync(c->d_ctr32.as<uint32_t>() + C_MINLEN, mm, 8, hipMemcpyHostToDevice, c->st));
         HIP_TRY(c, fqd::launch_scan_lens(d_off, n, c->d_ctr32.as<uint32_t>() + C_MINLEN, c->st));
         HIP_TRY(c, hipMemcpyAsync(mm, c->d_ctr32.as<uint32_t>() + C_MINLEN, 8, hipMemcpyDeviceToHost, c->st));
-        HIP_TRY(c, hipStreamSynchronize(c->st));
+        HIP_TRY(c, stream_wait(c->st));
         max_len = mm[1];
     }
     double table[128];
@@ -1094,7 +1101,7 @@ int fqd_edge_stats(fqd_ctx *c, uint64_t *keys_gathered, uint64_t *pairs_compared
         FQD_TRY(bind(c));
         fqd::PairStats slots[FQD_STAT_SLOTS];
         HIP_TRY(c, hipMemcpyAsync(slots, c->d_stats.p, sizeof slots, hipMemcpyDeviceToHost, c->st));
-        HIP_TRY(c, hipStreamSynchronize(c->st));
+        HIP_TRY(c, stream_wait(c->st));
         c->last_stats = fqd::PairStats{0, 0, 0};
         for (const fqd::PairStats &p : slots) {
             c->last_stats.keys_gathered += p.keys_gathered;
@@ -1119,7 +1126,7 @@ int fqd_synth_keys(fqd_ctx *c, uint8_t *out_device, uint64_t n_total, uint64_t s
     if (!copies)
         return fail(c, FQD_E_VALUE, "copies must be positive");
     HIP_TRY(c, fqd::launch_synth(out_device, n_total, start, count, length, umi, seed, copies, thr_n, thr_sub, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, stream_wait(c->st));
     return FQD_OK;
 }
 

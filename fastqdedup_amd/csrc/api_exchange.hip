@@ -65,7 +65,7 @@ static int export_grouped(fqd_ctx *c, uint64_t n, uint32_t n_parts, const uint32
     HIP_TRY(c, fqd::launch_gather_by_owner(order, n, sh, src_recs, src_lens, weights, id0, recs, lens, ids, ids32,
                                            weights_out, c->st, stamp_word));
     HIP_TRY(c, hipMemcpyAsync(counts, c->stage_d.p, (size_t)n_parts * 8, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, stream_wait(c->st));
     return FQD_OK;
 }
 
@@ -164,7 +164,7 @@ int fqd_gather_unique(fqd_ctx *c, const uint32_t *idx, uint64_t n, uint32_t *rec
         return fail(c, FQD_E_VALUE, "row index outside the unique table");
     HIP_TRY(c, fqd::launch_gather_by_owner(idx, n, c->ks, c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(),
                                            c->ucounts.as<uint32_t>(), 0, recs, lens, nullptr, nullptr, counts, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, stream_wait(c->st));
     return FQD_OK;
 }
 
@@ -197,7 +197,7 @@ int fqd_import_packed(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, ui
                 HIP_TRY(c, hipMemcpyAsync(c->lens.p, lens, (size_t)n * 4, kind, c->st));
         }
     }
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, stream_wait(c->st));
     c->n = n;
     c->hashes_valid = false;       // computed when somebody needs them (ensure_hashes)
     c->owners_done = fqd::OwnerRule{};
@@ -269,7 +269,7 @@ int fqd_import_unique(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, co
         else
             HIP_TRY(c, hipMemsetAsync(c->ufirst.p, 0, U * 8, c->st));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, stream_wait(c->st));
     c->U = U;
     c->collapsed = false;  // imported rows may repeat a key (dissection of a caller's list)
     c->first_distinct = first_ids != nullptr;
@@ -315,7 +315,7 @@ int fqd_import_edges(fqd_ctx *c, const uint32_t *uv, uint64_t E, int mem)
     if (E)
         HIP_TRY(c, hipMemcpyAsync(c->edges.p, uv, E * 8,
                                   mem == FQD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, stream_wait(c->st));
     c->E = E;
     c->stage = ST_EDGES;
     return FQD_OK;

@@ -104,11 +104,12 @@ static int list_kept(fqd_ctx *c, int method)
             FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), blocks));
             HIP_TRY(c, fqd::launch_window_emit(c->stage_c.as<uint8_t>(), window, c->kept_scan.as<uint32_t>(), base,
                                                list_out, c->st));
-            HIP_TRY(c, hipMemcpyAsync(&listed, c->kept_scan.as<uint32_t>() + (blocks - 1), 4, hipMemcpyDeviceToHost,
-                                      c->st));
+            FQD_TRY(queue_read_u32(c, c->kept_scan.as<uint32_t>() + (blocks - 1), 0));
         }
         unsigned long long both[2] = {0, 0};      // C64_ROOTS, C64_SUM: one read for fqd_cluster
         FQD_TRY(read_ctr64(c, C64_ROOTS, both, 2));
+        if (blocks)
+            listed = taken_u32(c, 0);
         c->roots_seen = both[0];
         const unsigned long long total = both[1];
         c->n_kept = total;
@@ -127,9 +128,10 @@ static int list_kept(fqd_ctx *c, int method)
     c->kept_in_out = false;
     FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), U));
     uint32_t nk = 0;
-    HIP_TRY(c, hipMemcpyAsync(&nk, c->kept_scan.as<uint32_t>() + (U - 1), 4, hipMemcpyDeviceToHost, c->st));
+    FQD_TRY(queue_read_u32(c, c->kept_scan.as<uint32_t>() + (U - 1), 0));
     unsigned long long both[2] = {0, 0};
     FQD_TRY(read_ctr64(c, C64_ROOTS, both, 2));
+    nk = taken_u32(c, 0);
     c->roots_seen = both[0];
     const unsigned long long total = both[1];
     c->n_kept = total;
@@ -329,7 +331,7 @@ int fqd_edge_labels(fqd_ctx *c, const uint32_t *uv, uint64_t E, uint64_t n_nodes
     HIP_TRY(c, fqd::launch_edge_roots(parent, uv, E, roots, c->st));
     std::vector<unsigned long long> slots((size_t)FQD_HOOK_SLOTS * 8);
     HIP_TRY(c, hipMemcpyAsync(slots.data(), c->stage_b.p, FQD_HOOK_SLOTS * 64, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, stream_wait(c->st));
     unsigned long long hooks = 0;
     for (size_t i = 0; i < slots.size(); i += 8)
         hooks += slots[i];

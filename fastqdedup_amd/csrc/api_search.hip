@@ -15,7 +15,7 @@ int find_edges_edit(fqd_ctx *c, uint32_t d, uint32_t shard, uint32_t n_shards)
     HIP_TRY(c, fqd::launch_len_present(c->ulens.as<uint32_t>(), U, sh, c->len_present.as<uint8_t>(), c->st));
     std::vector<uint8_t> present((size_t)sh.max_len + 1);
     HIP_TRY(c, hipMemcpyAsync(present.data(), c->len_present.p, present.size(), hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, stream_wait(c->st));
     uint32_t n_lengths = 0;
     for (uint8_t f : present)
         n_lengths += f ? 1 : 0;
