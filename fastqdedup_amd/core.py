@@ -76,7 +76,7 @@ class ClusterResult:
 def cluster_keys(keys, offsets=None, key_len: int = 0, weights=None, read_ids=None, *,
                  max_distance: int = DEFAULT_MAX_DISTANCE, use_edit_distance: bool = False,
                  method="directional", context: Optional[Context] = None,
-                 kept_out=None) -> ClusterResult:
+                 kept_out=None, stage_times: bool = True) -> ClusterResult:
     """The whole hot path in one call (reference __init__.py:240-281 + the pass-2
     selection rule :201-206). ``keys`` is the concatenation of the key bytes --
     a numpy uint8 array (host) or a torch uint8 tensor already in HBM --
@@ -96,7 +96,7 @@ def cluster_keys(keys, offsets=None, key_len: int = 0, weights=None, read_ids=No
     finally:
         if direct:
             ctx.set_kept_output(None)
-    ms, _ = ctx.stage_times()
+    ms = ctx.stage_times()[0] if stage_times else {}     # (resolving the event pairs costs ~20 us of host time)
     return ClusterResult(kept, s["n_reads"], s["n_counted"], s["n_unique"], s["n_edges"],
                          s["n_clusters"], s["n_kept"], ms)
 

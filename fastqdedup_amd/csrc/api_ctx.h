@@ -155,7 +155,7 @@ struct fqd_ctx {
     // per-kernel timing (fqd_kernel_times): a pool of event pairs for the kernels in ktime_mask,
     // folded into the sums at fqd_kernel_times or when the pool runs low
     uint32_t ktime_mask = 0xFFFFFFFFu;
-    static constexpr int KPOOL = 96;
+    static constexpr int KPOOL = 512;
     hipEvent_t kev[2 * KPOOL] = {nullptr};
     int kslot[KPOOL] = {0};
     int kused = 0;
