@@ -141,7 +141,7 @@ struct fqd_ctx {
     // stage 5
     uint64_t n_kept = 0, n_listed = 0;          // kept keys; kept keys whose first holder is in the id window
     uint64_t id_lo = 0, id_hi = ~0ull;
-    DevBuf best, state, blocked, taint, root_taint, kept, kept_u32, kept_scan, kept_ids, kept_ids_sorted;
+    DevBuf best, state, blocked, taint, root_taint, kept, kept_u32, kept_scan, kept_ids, kept_ids_sorted, kept_lists;
     // scratch
     DevBuf tmp, stage_a, stage_b, stage_c, stage_d;
 

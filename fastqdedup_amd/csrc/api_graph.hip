@@ -77,6 +77,39 @@ static int list_kept(fqd_ctx *c, int method)
     const bool by_map = c->first_distinct && window <= 32 * U && window < 0xFFFFFFF0ull &&
                         !getenv("FQD_KEPT_BY_SORT");
     FQD_TRY(zero_ctr64(c, C64_SUM));
+    // ... and cheaper still through id bins, without the map (graph.hip kept_bin_kernel): windows of
+    // up to 512 bins x 2^18 ids
+    if (by_map && window && fqd::kept_bin_shift(window) <= 18 &&
+        window * fqd::kept_bin_lists() < 0xF0000000ull && !getenv("FQD_KEPT_BY_MAP")) {
+        const uint32_t shift = fqd::kept_bin_shift(window);
+        const uint64_t slots = (((window + (1ull << shift) - 1) >> shift) << shift) * fqd::kept_bin_lists();
+        HIP_TRY(c, c->kept_lists.reserve(slots * 4 + 16));
+        HIP_TRY(c, c->kept_u32.reserve((size_t)512 * fqd::kept_bin_lists() * 4 + 16));
+        HIP_TRY(c, c->kept_scan.reserve(64));
+        c->kept_in_out = c->kept_out && c->kept_out_cap >= std::min(window, U);
+        uint64_t *list_out = c->kept_out;
+        if (!c->kept_in_out) {
+            HIP_TRY(c, c->kept_ids_sorted.reserve(std::min(window, U) * 8 + 16));
+            list_out = c->kept_ids_sorted.as<uint64_t>();
+        }
+        KTIME(c, FQD_K_KEPT_FLAGS, fqd::launch_kept_bins(
+                  method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(), c->state.as<uint8_t>(),
+                  c->ufirst.as<uint64_t>(), c->id_lo, window, U, c->kept.as<uint8_t>(), c->ucounts.as<uint32_t>(),
+                  c->blocked.as<uint32_t>(), c->root_taint.as<uint8_t>(), c->kept_u32.as<uint32_t>(),
+                  c->kept_lists.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_SUM, base, list_out,
+                  c->kept_scan.as<uint32_t>(), c->st));
+        FQD_TRY(queue_read_u32(c, c->kept_scan.as<uint32_t>(), 0));
+        unsigned long long both[2] = {0, 0};      // C64_ROOTS, C64_SUM: one read for fqd_cluster
+        FQD_TRY(read_ctr64(c, C64_ROOTS, both, 2));
+        c->roots_seen = both[0];
+        c->n_kept = both[1];
+        c->n_listed = taken_u32(c, 0);
+        if (getenv("FQD_DEBUG"))
+            fprintf(stderr, "[fqd] kept list by id bins: U=%llu base=%llu window=%llu shift=%u kept=%llu listed=%llu\n",
+                    (unsigned long long)U, (unsigned long long)base, (unsigned long long)window, shift,
+                    (unsigned long long)c->n_kept, (unsigned long long)c->n_listed);
+        return FQD_OK;
+    }
     if (by_map) {
         HIP_TRY(c, c->stage_c.reserve(window + 16));
         if (window)

@@ -370,6 +370,13 @@ hipError_t launch_quality(const uint8_t *bytes, uint64_t n_bytes, const uint64_t
 hipError_t launch_uf_init(uint32_t *parent, uint64_t U, hipStream_t st);
 hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, unsigned long long *n_hooks,
                            hipStream_t st);
+uint32_t kept_bin_shift(uint64_t window);
+uint32_t kept_bin_lists();
+hipError_t launch_kept_bins(int method, const uint32_t *labels, const uint32_t *best, const uint8_t *state,
+                            const uint64_t *ufirst, uint64_t id_lo, uint64_t window, uint64_t U, uint8_t *kept,
+                            const uint32_t *ucounts, const uint32_t *parent1, const uint8_t *root_taint,
+                            uint32_t *cursor, uint32_t *lists, unsigned long long *n_kept_total, uint64_t id_base,
+                            uint64_t *out, uint32_t *n_listed, hipStream_t st);
 uint32_t window_blocks(uint64_t n);
 hipError_t launch_window_count(const uint8_t *flags, uint64_t n, uint32_t *block_counts, hipStream_t st);
 hipError_t launch_window_emit(const uint8_t *flags, uint64_t n, const uint32_t *block_incl, uint64_t id_base,

@@ -353,6 +353,76 @@ __global__ void adjacency_nodes_kernel(uint64_t U, uint8_t *state, const uint32_
     }
 }
 
+// The dissection's verdict on unique key v (method 3: directional, closed form).
+__device__ __forceinline__ bool kept_verdict(int method, uint32_t v, const uint32_t *__restrict__ labels,
+                                             const uint32_t *__restrict__ best, const uint8_t *__restrict__ state,
+                                             const uint32_t *__restrict__ ucounts,
+                                             const uint32_t *__restrict__ parent1,
+                                             const uint8_t *__restrict__ root_taint)
+{
+    if (method == 0)
+        return best[labels[v]] == v;
+    if (method == 2)
+        return best[v] == v;
+    if (method == 3) {
+        if (ucounts[v] != 1)
+            return state[v] != 2;
+        uint32_t r = v, p = parent1[r];
+        while (p != r) {
+            r = p;
+            p = parent1[r];
+        }
+        return !root_taint[r] && best[r] == v;
+    }
+    return state[v] == 1;
+}
+
+// N verdicts at once. The closed-form directional verdict of a count-1 key follows a chain
+// (count -> parent -> root's taint and best); almost every such key is its own root, so all five
+// arrays are loaded for all N keys at once AS IF it were, and only a key with a real parent walks.
+// (Key by key, the kernel waits for three dependent round trips per key: 0.2 ms for 14 M keys.)
+template <uint32_t N>
+__device__ __forceinline__ void kept_verdicts(int method, const uint32_t (&v)[N], const bool (&valid)[N],
+                                              const uint32_t *__restrict__ labels,
+                                              const uint32_t *__restrict__ best, const uint8_t *__restrict__ state,
+                                              const uint32_t *__restrict__ ucounts,
+                                              const uint32_t *__restrict__ parent1,
+                                              const uint8_t *__restrict__ root_taint, bool (&k)[N])
+{
+    if (method == 3) {
+        uint32_t cnt[N], par[N], bs[N];
+        uint8_t st[N], rt[N];
+#pragma unroll
+        for (uint32_t t = 0; t < N; t++) {
+            cnt[t] = par[t] = bs[t] = 0;
+            st[t] = rt[t] = 0;
+            if (valid[t]) {
+                cnt[t] = ucounts[v[t]];
+                st[t] = state[v[t]];
+                par[t] = parent1[v[t]];
+                rt[t] = root_taint[v[t]];
+                bs[t] = best[v[t]];
+            }
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < N; t++) {
+            k[t] = false;
+            if (!valid[t])
+                continue;
+            if (cnt[t] != 1)
+                k[t] = st[t] != 2;
+            else if (par[t] == v[t])
+                k[t] = !rt[t] && bs[t] == v[t];
+            else
+                k[t] = kept_verdict(3, v[t], labels, best, state, ucounts, parent1, root_taint);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t t = 0; t < N; t++)
+            k[t] = valid[t] && kept_verdict(method, v[t], labels, best, state, ucounts, parent1, root_taint);
+    }
+}
+
 // kept[v]: the dissection's verdict. A key is LISTED when it is kept AND its first holder lies in
 // the id window [id_lo, id_hi) -- the ids this context lists (a rank lists its own reads):
 // kept_u32[v] = 1 (scan + gather + sort path) or window_flags[id - id_lo] = 1 (compaction path).
@@ -383,23 +453,16 @@ __global__ __launch_bounds__(256) void kept_flags_kernel(int method, const uint3
             if (v >= U)
                 continue;
             id[t] = ufirst[v];
-            if (method == 0)
-                k[t] = best[labels[v]] == (uint32_t)v;
-            else if (method == 2)
-                k[t] = best[v] == (uint32_t)v;
-            else if (method == 3) {    // directional, closed form
-                if (ucounts[v] != 1) {
-                    k[t] = state[v] != 2;
-                } else {
-                    uint32_t r = (uint32_t)v, p = parent1[r];
-                    while (p != r) {
-                        r = p;
-                        p = parent1[r];
-                    }
-                    k[t] = !root_taint[r] && best[r] == (uint32_t)v;
-                }
-            } else
-                k[t] = state[v] == 1;
+        }
+        {
+            uint32_t vv[KF];
+            bool valid[KF];
+#pragma unroll
+            for (uint32_t t = 0; t < KF; t++) {
+                vv[t] = (uint32_t)(v0 + t * stride);
+                valid[t] = v0 + t * stride < U;
+            }
+            kept_verdicts<KF>(method, vv, valid, labels, best, state, ucounts, parent1, root_taint, k);
         }
 #pragma unroll
         for (uint32_t t = 0; t < KF; t++) {
@@ -421,8 +484,256 @@ __global__ __launch_bounds__(256) void kept_flags_kernel(int method, const uint3
     }
     for (int o = 32; o; o >>= 1)
         total += __shfl_xor(total, o);
-    if (fqd_lane() == 0 && total)
-        atomicAdd(n_kept_total, total);
+    __shared__ unsigned long long s_total[4];
+    if (fqd_lane() == 0)
+        s_total[threadIdx.x >> 6] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {             // one atomic per workgroup on the job-wide counter
+        const unsigned long long sum = s_total[0] + s_total[1] + s_total[2] + s_total[3];
+        if (sum)
+            atomicAdd(n_kept_total, sum);
+    }
+}
+
+// ---- ascending id list through id bins (no byte map of the window) ---------------------------
+// Setting one byte per kept id in a map of the whole id window is 12 M scattered stores, each a
+// 32-byte sector on the wire (0.27 of the 0.36 ms of kept_flags_kernel). Instead:
+//   kept_bin_kernel   verdicts as in kept_flags_kernel; the listed ids of a tile of 4096 keys are
+//                     partitioned in LDS by id bin (2^bin_shift consecutive ids; <= 512 bins) and leave as one
+//                     run of 4-byte offsets per (tile, bin) behind an atomic cursor. A bin has KB_SUBS
+//                     lists (tile t appends to list t % KB_SUBS: 3400 tiles queueing on ONE cursor
+//                     per bin cost 0.12 ms, a same-address atomic takes ~36 ns), each with room
+//                     for every id of the bin (ids are distinct): no overflow.
+//   kept_emit_kernel  four workgroups per bin: the bin's offsets set bits in LDS bit maps of the
+//                     bin's quarters; the maps are scanned and the ids are written in ascending
+//                     order behind the ids of everything before them.
+constexpr uint32_t KB_THREADS = 256, KB_KPT = 16, KB_TILE = KB_THREADS * KB_KPT, KB_MAX_BINS = 512, KB_SUBS = 1;
+
+__global__ __launch_bounds__(KB_THREADS) void kept_bin_kernel(
+    int method, const uint32_t *__restrict__ labels, const uint32_t *__restrict__ best,
+    const uint8_t *__restrict__ state, const uint64_t *__restrict__ ufirst, uint64_t id_lo, uint64_t window,
+    uint64_t U, uint8_t *__restrict__ kept, const uint32_t *__restrict__ ucounts,
+    const uint32_t *__restrict__ parent1, const uint8_t *__restrict__ root_taint, uint32_t bin_shift,
+    uint32_t n_bins, uint32_t *__restrict__ cursor /* [n_bins][KB_SUBS], starts at (b * KB_SUBS + s) << bin_shift */,
+    uint32_t *__restrict__ lists, unsigned long long *__restrict__ n_kept_total)
+{
+    __shared__ uint32_t s_hist[KB_MAX_BINS], s_off[KB_MAX_BINS], s_base[KB_MAX_BINS], s_wave[KB_THREADS / 64];
+    __shared__ uint32_t s_stage[KB_TILE];
+    __shared__ uint16_t s_stage_bin[KB_TILE];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t v0 = (uint64_t)blockIdx.x * KB_TILE;
+    for (uint32_t b = tid; b < n_bins; b += KB_THREADS)
+        s_hist[b] = 0;
+    __syncthreads();
+    uint32_t off[KB_KPT], rank[KB_KPT];
+    uint32_t bin[KB_KPT];
+    uint32_t total = 0;
+    // eight keys at a time: all their loads are issued together
+#pragma unroll
+    for (uint32_t g = 0; g < KB_KPT; g += 8) {
+        bool k[8], valid[8];
+        uint32_t vv[8];
+        uint64_t id[8];
+#pragma unroll
+        for (uint32_t t = 0; t < 8; t++) {
+            const uint64_t v = v0 + (g + t) * KB_THREADS + tid;
+            valid[t] = v < U;
+            vv[t] = (uint32_t)v;
+            id[t] = valid[t] ? ufirst[v] : 0;
+        }
+        kept_verdicts<8>(method, vv, valid, labels, best, state, ucounts, parent1, root_taint, k);
+#pragma unroll
+        for (uint32_t t = 0; t < 8; t++) {
+            const uint64_t v = v0 + (g + t) * KB_THREADS + tid;
+            bin[g + t] = 0xFFFFFFFFu;
+            if (v >= U)
+                continue;
+            kept[v] = k[t] ? 1 : 0;
+            total += k[t] ? 1u : 0u;
+            if (k[t] && id[t] >= id_lo && id[t] - id_lo < window) {
+                off[g + t] = (uint32_t)(id[t] - id_lo);
+                bin[g + t] = off[g + t] >> bin_shift;
+                rank[g + t] = atomicAdd(&s_hist[bin[g + t]], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bin counts (n_bins <= 512: two bins per thread) + one reservation per bin
+    const uint32_t b0 = 2 * tid, c0 = b0 < n_bins ? s_hist[b0] : 0u, c1 = b0 + 1 < n_bins ? s_hist[b0 + 1] : 0u;
+    const uint32_t mine = c0 + c1;
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if ((int)lane >= o)
+            incl += up;
+    }
+    if (lane == 63)
+        s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (uint32_t wv = 0; wv < wave; wv++)
+        run += s_wave[wv];
+    const uint32_t sub = blockIdx.x % KB_SUBS;
+    if (b0 < n_bins) {
+        s_off[b0] = run;
+        s_base[b0] = (c0 ? atomicAdd(&cursor[b0 * KB_SUBS + sub], c0) : 0u) - run;
+    }
+    if (b0 + 1 < n_bins) {
+        s_off[b0 + 1] = run + c0;
+        s_base[b0 + 1] = (c1 ? atomicAdd(&cursor[(b0 + 1) * KB_SUBS + sub], c1) : 0u) - (run + c0);
+    }
+    uint32_t listed = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < KB_KPT; e++)
+        if (bin[e] != 0xFFFFFFFFu) {
+            const uint32_t p = s_off[bin[e]] + rank[e];
+            s_stage[p] = off[e];
+            s_stage_bin[p] = (uint16_t)bin[e];
+        }
+    __syncthreads();
+    for (uint32_t p = tid; p < listed; p += KB_THREADS)
+        lists[s_base[s_stage_bin[p]] + p] = s_stage[p];
+    // one atomic per workgroup on the job-wide counter (one per wave: 14 K atomics on one address,
+    // ~11 ns each, were most of this kernel's 0.22 ms)
+    for (int o = 32; o; o >>= 1)
+        total += __shfl_xor(total, o);
+    __syncthreads();
+    if (lane == 0)
+        s_wave[wave] = total;
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t sum = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (sum)
+            atomicAdd(n_kept_total, (unsigned long long)sum);
+    }
+}
+
+// KE_Q workgroups per bin, each owning 1/KE_Q of the bin's id range: each reads the bin's offsets,
+// counts those below its range and sets the bits of those inside in its LDS bit map; the map then
+// leaves in chunks through an LDS staging area. Measured on the way (50 M-id window, 12 M ids):
+// reading the offset lists is the slow part (~1.1 TB/s), so ONE pass over them (KE_Q = 1) beats
+// four workgroups per bin (0.20 ms); a 1024-thread workgroup per bin whose threads wrote their own
+// ids straight to `out`, load -> LDS-atomic rounds back to back: 0.13 ms; finding output slot j's
+// bit by binary search over per-thread prefix counts so that stores coalesce: 0.21 ms.
+constexpr uint32_t KE_Q = 1, KE_THREADS = 512;
+
+__global__ __launch_bounds__(KE_THREADS) void kept_emit_kernel(const uint32_t *__restrict__ cursor,
+                                                               const uint32_t *__restrict__ lists,
+                                                               uint32_t bin_shift, uint32_t n_bins, uint64_t id_base,
+                                                               uint64_t *__restrict__ out,
+                                                               uint32_t *__restrict__ n_listed)
+{
+    extern __shared__ uint32_t s_bits[];          // (1 << bin_shift) / 32 / KE_Q words
+    __shared__ uint32_t s_part[3 * KE_THREADS / 64], s_scan[KE_THREADS / 64];
+    __shared__ uint16_t s_ids[KE_THREADS * 32];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t b = blockIdx.x / KE_Q, q = blockIdx.x % KE_Q;
+    const uint32_t words = (1u << (bin_shift - 5)) / KE_Q;       // a multiple of KE_THREADS: bin_shift >= 15
+    for (uint32_t w = tid; w < words; w += KE_THREADS)
+        s_bits[w] = 0;
+    // ids of the bins before this one and of all bins (n_bins <= 512: two per thread)
+    uint32_t before = 0, all = 0;
+    for (uint32_t x = tid; x < n_bins; x += KE_THREADS) {
+        uint32_t cnt = 0;
+        for (uint32_t k = 0; k < KB_SUBS; k++)
+            cnt += cursor[x * KB_SUBS + k] - ((x * KB_SUBS + k) << bin_shift);
+        all += cnt;
+        before += x < b ? cnt : 0u;
+    }
+    __syncthreads();                                             // the bit map is clear
+    const uint32_t first = b << bin_shift;                       // id offset of the bin's first id
+    const uint32_t q_lo = q * words * 32u, q_hi = q_lo + words * 32u;
+    uint32_t below = 0;
+    for (uint32_t k = 0; k < KB_SUBS; k++) {
+        const uint32_t slab = (b * KB_SUBS + k) << bin_shift, n = cursor[b * KB_SUBS + k] - slab;
+        auto mark = [&](uint32_t off) {
+            const uint32_t o = off - first;
+            below += o < q_lo ? 1u : 0u;
+            if (o >= q_lo && o < q_hi)
+                atomicOr(&s_bits[(o - q_lo) >> 5], 1u << (o & 31u));
+        };
+        // 4 x 16 bytes per thread in flight (a bin's list is read by ONE workgroup: the loads in
+        // flight are what bounds it; 8 x 4 bytes per thread took 0.10 ms for 49 MB of lists)
+        const uint4 *list4 = reinterpret_cast<const uint4 *>(lists + slab);     // slab is 2^bin_shift entries: aligned
+        const uint32_t n4 = n / 4;
+        for (uint32_t i0 = 0; i0 < n4; i0 += 4 * KE_THREADS) {
+            uint4 o[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u * KE_THREADS + tid;
+                o[u] = i < n4 ? list4[i] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++)
+                if (i0 + u * KE_THREADS + tid < n4) {
+                    mark(o[u].x);
+                    mark(o[u].y);
+                    mark(o[u].z);
+                    mark(o[u].w);
+                }
+        }
+        if (tid < n - n4 * 4)
+            mark(lists[slab + n4 * 4 + tid]);
+    }
+    for (int o = 32; o; o >>= 1) {
+        before += __shfl_xor(before, o);
+        all += __shfl_xor(all, o);
+        below += __shfl_xor(below, o);
+    }
+    if (lane == 0) {
+        s_part[wave] = before;
+        s_part[KE_THREADS / 64 + wave] = all;
+        s_part[2 * (KE_THREADS / 64) + wave] = below;
+    }
+    __syncthreads();                                             // ... and the bit map is complete
+    uint32_t pos = 0, everything = 0;
+    for (uint32_t w = 0; w < KE_THREADS / 64; w++) {
+        pos += s_part[w] + s_part[2 * (KE_THREADS / 64) + w];
+        everything += s_part[KE_THREADS / 64 + w];
+    }
+    if (blockIdx.x == 0 && tid == 0)
+        *n_listed = everything;
+    // The map leaves in chunks of KE_THREADS words (8192 ids at most): thread t ranks the bits of
+    // word t of the chunk, parks their offsets in LDS in rank order, and the chunk's ids go out as
+    // one contiguous, coalesced run. (Every thread writing its own ids straight to `out` is 64
+    // different cache lines per store instruction: 12 M partial-line writes, as bad as the byte map.)
+    uint64_t at = pos;
+    for (uint32_t c0 = 0; c0 < words; c0 += KE_THREADS) {
+        uint32_t m = s_bits[c0 + tid];
+        const uint32_t mine = __popc(m);
+        uint32_t incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if ((int)lane >= o)
+                incl += up;
+        }
+        __syncthreads();                  // s_scan and s_ids of the chunk before are done with
+        if (lane == 63)
+            s_scan[wave] = incl;
+        __syncthreads();
+        uint32_t r = incl - mine, chunk_total = 0;
+        for (uint32_t w = 0; w < KE_THREADS / 64; w++) {
+            r += w < wave ? s_scan[w] : 0u;
+            chunk_total += s_scan[w];
+        }
+        while (m) {
+            s_ids[r++] = (uint16_t)(((tid) << 5) + (__ffs((int)m) - 1));      // offset inside the chunk
+            m &= m - 1;
+        }
+        __syncthreads();
+        const uint64_t chunk_base = id_base + first + q_lo + ((uint64_t)c0 << 5);
+        for (uint32_t j = tid; j < chunk_total; j += KE_THREADS)
+            out[at + j] = chunk_base + s_ids[j];
+        at += chunk_total;
+    }
+}
+
+__global__ void kept_bin_starts_kernel(uint32_t n_lists, uint32_t bin_shift, uint32_t *__restrict__ cursor)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_lists)
+        cursor[b] = b << bin_shift;
 }
 
 // ---- ascending id list = compaction of the window's byte map (bytes are 0 or 1) -------------
@@ -633,6 +944,36 @@ hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t 
         kept_flags_kernel<<<g, 256, 0, st>>>(method, labels, best, state, ufirst, id_lo, id_hi, U, kept, kept_u32,
                                              window_flags, window_size, ucounts, parent1, root_taint, n_kept_total);
     }
+    return hipGetLastError();
+}
+
+// bins of 2^shift ids, shift >= 15 (the emit kernel's 1024 threads own >= one word each), <= 512 bins
+uint32_t kept_bin_lists() { return KB_SUBS; }
+
+uint32_t kept_bin_shift(uint64_t window)
+{
+    uint32_t s = 15;
+    while (((window + (1ull << s) - 1) >> s) > KB_MAX_BINS)
+        s++;
+    return s;
+}
+
+hipError_t launch_kept_bins(int method, const uint32_t *labels, const uint32_t *best, const uint8_t *state,
+                            const uint64_t *ufirst, uint64_t id_lo, uint64_t window, uint64_t U, uint8_t *kept,
+                            const uint32_t *ucounts, const uint32_t *parent1, const uint8_t *root_taint,
+                            uint32_t *cursor, uint32_t *lists, unsigned long long *n_kept_total, uint64_t id_base,
+                            uint64_t *out, uint32_t *n_listed, hipStream_t st)
+{
+    const uint32_t shift = kept_bin_shift(window);
+    const uint32_t n_bins = (uint32_t)((window + (1ull << shift) - 1) >> shift);
+    if (!U || !n_bins || shift > 18 || ((uint64_t)n_bins * KB_SUBS << shift) > 0xFFFFFFFFull)   // (a 2^18-bit map is 32 KB of LDS)
+        return hipErrorInvalidValue;
+    kept_bin_starts_kernel<<<(n_bins * KB_SUBS + 255) / 256, 256, 0, st>>>(n_bins * KB_SUBS, shift, cursor);
+    kept_bin_kernel<<<(unsigned)((U + KB_TILE - 1) / KB_TILE), KB_THREADS, 0, st>>>(
+        method, labels, best, state, ufirst, id_lo, window, U, kept, ucounts, parent1, root_taint, shift, n_bins, cursor,
+        lists, n_kept_total);
+    kept_emit_kernel<<<n_bins * KE_Q, KE_THREADS, (1u << (shift - 5)) * 4 / KE_Q, st>>>(cursor, lists, shift, n_bins, id_base,
+                                                                                       out, n_listed);
     return hipGetLastError();
 }
 
