@@ -232,7 +232,9 @@ def main():
         "gp_hist_kernel": U * 6,                                     # level 1 reads the hash, level 2 the (hash, uid) item
         "gp_scatter_kernel": U * 14,                                 # 4 + 8 at level 1, 8 + 8 at level 2
         "verify_candidates_kernel": st["pairs_compared"] / nseg * (8 + 2 * b_key) + st["edges"] / nseg * 8,
-        "kept_flags_kernel": U * (4 + 4 + 8 + 1) + res.n_kept,         # count, verdict word, first id in; flag out; a byte per kept id
+        # kept_bin + kept_emit (one timing slot): verdict arrays (count, state, parent, taint, best) and the
+        # first id in, a flag out; per kept id 4 B out + 4 B in (bin lists) and 8 B out (the list)
+        "kept_flags_kernel": U * (4 + 1 + 4 + 1 + 4 + 8 + 1) + res.n_kept * 16,
         "uf_union_kernel": E * 8,
         "uf_flatten_kernel": U * 8,
         "dissect_round_kernel": E * 8,
