@@ -179,59 +179,69 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe_kernel(
           const uint32_t i = base0 + k * DD_THREADS + tid;
           ahead_w[k] = i < hi ? (weights ? weights[ahead[k].w] : 1u) : 0u;
       }
+      // All DD_AHEAD records of the thread go through the table TOGETHER: a round is "claim an
+      // empty slot or stop at a slot whose tag matches" for every pending record, a barrier (the
+      // parked records of the round are visible), "verify against the parked record and count, or
+      // probe on". Usually one round per bucket -- two barriers instead of two per chunk.
+      uint32_t tag[DD_AHEAD], slot[DD_AHEAD], probes[DD_AHEAD];
+      bool pending[DD_AHEAD];
 #pragma unroll
       for (uint32_t k = 0; k < DD_AHEAD; k++) {
-        const uint32_t base = base0 + k * DD_THREADS;
-        if (base >= hi)
-            break;                      // uniform over the workgroup
-        const uint32_t i = base + tid;
-        const bool active = i < hi;
-        const uint4 v = ahead[k];
-        const uint32_t tag = rec_tag(v);
-        const uint32_t w = ahead_w[k];
-        uint32_t slot = (tag * 0x9E3779B1u) >> 22;  // top 10 bits of a re-mix: DD_SLOTS == 1024
-        uint32_t probes = 0;
-        bool pending = active;
-        do {
-            // claim an empty slot, or stop at a slot whose tag matches (to be verified below)
-            if (pending) {
-                for (;;) {
-                    const uint32_t old = atomicCAS(&s_tag[slot], DD_EMPTY, tag);
-                    if (old == DD_EMPTY) {
-                        s_x[slot] = v.x;
-                        s_y[slot] = v.y;
-                        s_z[slot] = v.z;
-                        s_cnt[slot] = w;
-                        s_min[slot] = v.w;
-                        pending = false;
-                        break;
-                    }
-                    if (old == tag)
-                        break;
-                    slot = (slot + 1) & (DD_SLOTS - 1);
-                    if (++probes >= DD_SLOTS) {
-                        full = true;
-                        pending = false;
-                        break;
-                    }
-                }
-            }
-            __syncthreads();  // parked records of this round are visible
-            if (pending) {
-                if (s_x[slot] == v.x && s_y[slot] == v.y && s_z[slot] == v.z) {
-                    atomicAdd(&s_cnt[slot], w);
-                    atomicMin(&s_min[slot], v.w);
-                    pending = false;
-                } else {  // same tag, different key: keep probing
-                    slot = (slot + 1) & (DD_SLOTS - 1);
-                    if (++probes >= DD_SLOTS) {
-                        full = true;
-                        pending = false;
-                    }
-                }
-            }
-        } while (__syncthreads_or(pending));
+          tag[k] = rec_tag(ahead[k]);
+          slot[k] = (tag[k] * 0x9E3779B1u) >> 22;  // top 10 bits of a re-mix: DD_SLOTS == 1024
+          probes[k] = 0;
+          pending[k] = base0 + k * DD_THREADS + tid < hi;
       }
+      bool any;
+      do {
+#pragma unroll
+          for (uint32_t k = 0; k < DD_AHEAD; k++) {
+              if (!pending[k])
+                  continue;
+              const uint4 v = ahead[k];
+              for (;;) {
+                  const uint32_t old = atomicCAS(&s_tag[slot[k]], DD_EMPTY, tag[k]);
+                  if (old == DD_EMPTY) {
+                      s_x[slot[k]] = v.x;
+                      s_y[slot[k]] = v.y;
+                      s_z[slot[k]] = v.z;
+                      s_cnt[slot[k]] = ahead_w[k];
+                      s_min[slot[k]] = v.w;
+                      pending[k] = false;
+                      break;
+                  }
+                  if (old == tag[k])
+                      break;
+                  slot[k] = (slot[k] + 1) & (DD_SLOTS - 1);
+                  if (++probes[k] >= DD_SLOTS) {
+                      full = true;
+                      pending[k] = false;
+                      break;
+                  }
+              }
+          }
+          __syncthreads();  // parked records of this round are visible
+          any = false;
+#pragma unroll
+          for (uint32_t k = 0; k < DD_AHEAD; k++) {
+              if (!pending[k])
+                  continue;
+              const uint4 v = ahead[k];
+              if (s_x[slot[k]] == v.x && s_y[slot[k]] == v.y && s_z[slot[k]] == v.z) {
+                  atomicAdd(&s_cnt[slot[k]], ahead_w[k]);
+                  atomicMin(&s_min[slot[k]], v.w);
+                  pending[k] = false;
+              } else {  // same tag, different key: keep probing
+                  slot[k] = (slot[k] + 1) & (DD_SLOTS - 1);
+                  if (++probes[k] >= DD_SLOTS) {
+                      full = true;
+                      pending[k] = false;
+                  } else {
+                      any = true;
+                  }
+              }
+          }
+      } while (__syncthreads_or(any));
     }
     if (full)
         atomicOr(overflow, 1u);
