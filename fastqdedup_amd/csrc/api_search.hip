@@ -94,9 +94,10 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
     HIP_TRY(c, c->ld_start.reserve(((size_t)n_buckets + 1) * 4 + 16));
     uint32_t *small = c->gp_small.as<uint32_t>();
     uint32_t *seg1 = small, *tiles1_d = small + 8, *start1 = small + 16, *tiles2_d = small + 2048;
-    const uint32_t seg1_h[2] = {0u, (uint32_t)U}, tiles1_h[2] = {0u, tiles1};
-    HIP_TRY(c, hipMemcpyAsync(seg1, seg1_h, 8, hipMemcpyHostToDevice, c->st));
-    HIP_TRY(c, hipMemcpyAsync(tiles1_d, tiles1_h, 8, hipMemcpyHostToDevice, c->st));
+    // the candidate counters (one per list, a cache line apart) live behind the small tables
+    unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(small + 4096);
+    HIP_TRY(c, fqd::launch_group_pass_init(seg1, tiles1_d, (uint32_t)U, tiles1, cand_ctr, fqd::group_cand_lists() * 8,
+                                           c->st));
     // ---- level 1: (bin x tile) count matrix, scan, placement without atomics
     const size_t matrix = (size_t)bins1 * tiles1;
     HIP_TRY(c, c->ld_matrix.reserve(matrix * 4 + 16));
@@ -151,9 +152,6 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
         HIP_TRY(c, c->gp_cands.reserve(c->gp_cand_cap * 8));
     }
     c->gp_cand_cap = c->gp_cands.cap / 8;
-    // the candidate counters (one per list, a cache line apart) live behind the small tables
-    unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(small + 4096);
-    HIP_TRY(c, hipMemsetAsync(cand_ctr, 0, (size_t)fqd::group_cand_lists() * 64, c->st));
     unsigned long long *ctr = c->d_ctr64.as<unsigned long long>();
     KTIME(c, FQD_K_PAIRS, fqd::launch_grouped_candidates(items, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, B,
                                                          c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,

@@ -333,6 +333,8 @@ hipError_t launch_group_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bi
                                       hipStream_t st);
 hipError_t launch_group_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
                                       uint32_t *cursor, hipStream_t st);
+hipError_t launch_group_pass_init(uint32_t *seg1, uint32_t *tiles1, uint32_t n_items, uint32_t n_tiles,
+                                  unsigned long long *cand_ctr, uint32_t ctr_words, hipStream_t st);
 hipError_t launch_group_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket_start, uint32_t *cursor,
                                     hipStream_t st);
 hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,

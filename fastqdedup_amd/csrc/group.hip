@@ -66,6 +66,22 @@ __global__ __launch_bounds__(fqd_partition::THREADS) void gp_scatter_kernel(Pair
                                                     slab_cap, slab_overflow);
 }
 
+// start of a search pass: the level-1 segment / tile bounds and the zeroed candidate counters, in one
+// small launch (two host-to-device copies and a fill, each a stop on the stream, did this before)
+__global__ void gp_pass_init_kernel(uint32_t *__restrict__ seg1, uint32_t *__restrict__ tiles1, uint32_t n_items,
+                                    uint32_t n_tiles, unsigned long long *__restrict__ cand_ctr, uint32_t ctr_words)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        seg1[0] = 0;
+        seg1[1] = n_items;
+        tiles1[0] = 0;
+        tiles1[1] = n_tiles;
+    }
+    if (t < ctr_words)
+        cand_ctr[t] = 0;
+}
+
 // slab mode of level 2 (as in collapse_lds.hip): bucket b owns slots [b * cap, (b + 1) * cap)
 __global__ void gp_slab_starts_kernel(uint32_t n_buckets, uint32_t cap, uint32_t *__restrict__ bucket_start,
                                       uint32_t *__restrict__ cursor)
@@ -464,6 +480,13 @@ hipError_t launch_group_bucket_starts(const uint32_t *hist_incl, uint32_t n_buck
                                       uint32_t *cursor, hipStream_t st)
 {
     gp_bucket_starts_kernel<<<(n_buckets + 1 + 255) / 256, 256, 0, st>>>(hist_incl, n_buckets, bucket_start, cursor);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_pass_init(uint32_t *seg1, uint32_t *tiles1, uint32_t n_items, uint32_t n_tiles,
+                                  unsigned long long *cand_ctr, uint32_t ctr_words, hipStream_t st)
+{
+    gp_pass_init_kernel<<<(ctr_words + 255) / 256 + 1, 256, 0, st>>>(seg1, tiles1, n_items, n_tiles, cand_ctr, ctr_words);
     return hipGetLastError();
 }
 
