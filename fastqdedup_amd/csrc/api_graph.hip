@@ -218,17 +218,20 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
         // relies on a strict order of the keys, so a caller's list with repeated keys
         // (fqd_import_unique) takes the relaxation rounds below.
         HIP_TRY(c, c->blocked.reserve(U * 4 + 16));   // here: union-find over the count-1 keys
-        HIP_TRY(c, c->taint.reserve(U + 16));
+        HIP_TRY(c, c->taint.reserve(E * 4 + 16));       // here: the edges between count-1 keys (edge indices)
         HIP_TRY(c, c->root_taint.reserve(U + 16));
         if (E) {
-            HIP_TRY(c, hipMemsetAsync(c->taint.p, 0, U, c->st));
+            if (E >= 0xFFFFFFFFull)
+                return fail(c, FQD_E_VALUE, "more than 2^32 edges");
             HIP_TRY(c, hipMemsetAsync(c->root_taint.p, 0, U, c->st));
+            FQD_TRY(zero_ctr64(c, C64_CANDS));             // (the search's candidate counter, free here)
             HIP_TRY(c, fqd::launch_uf_init(c->blocked.as<uint32_t>(), U, c->st));
             for (int pass = 1; pass <= 2; pass++)
                 KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_directional_closed(
                           c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(), c->urecs.as<uint32_t>(),
                           c->ulens.as<uint32_t>(), sh, c->blocked.as<uint32_t>(), c->state.as<uint8_t>(),
-                          c->taint.as<uint8_t>(), c->root_taint.as<uint8_t>(), c->best.as<uint32_t>(), pass, c->st));
+                          c->taint.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_CANDS,
+                          c->root_taint.as<uint8_t>(), c->best.as<uint32_t>(), pass, c->st));
             list_method = 3;
         }
     } else if (method == FQD_METHOD_DIRECTIONAL) {

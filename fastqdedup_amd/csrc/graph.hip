@@ -232,74 +232,115 @@ __global__ void directional_round_kernel(const uint32_t *__restrict__ edges, uin
 
 // ---- directional, closed form -------------------------------------------------------
 // Pass 1 over the edges: in-arcs of keys with count >= 2 (state = 2: dropped), count-1 keys that
-// touch a bigger key (taint), and a union-find over the edges between count-1 keys.
-__global__ void directional_edges_kernel(const uint32_t *__restrict__ edges, uint64_t E,
-                                         const uint32_t *__restrict__ ucounts, uint32_t *parent1, uint8_t *state,
-                                         uint8_t *taint)
+// touch a bigger key (state = 3: tainted), and a union-find over the edges between count-1 keys --
+// those edges (few) are listed for pass 2. Four edges per thread, one list reservation per workgroup.
+constexpr uint32_t DE_EPT = 4;
+
+__global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *__restrict__ edges, uint64_t E,
+                                                                const uint32_t *__restrict__ ucounts,
+                                                                uint32_t *parent1, uint8_t *state,
+                                                                uint32_t *__restrict__ list11,
+                                                                unsigned long long *__restrict__ list11_count)
 {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E)
-        return;
-    const uint32_t u = edges[2 * e], v = edges[2 * e + 1];
-    if (u == v)
-        return;
-    const long long cu = ucounts[u], cv = ucounts[v];
-    if (cu == 1 && cv == 1) {
-        uint32_t a = u, b = v;
-        for (;;) {
-            a = uf_find(parent1, a);
-            b = uf_find(parent1, b);
-            if (a == b)
-                break;
-            if (a > b) {
-                const uint32_t t = a;
-                a = b;
-                b = t;
-            }
-            if (atomicCAS(&parent1[b], b, a) == b)
-                break;
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0)
+        s_n = 0;
+    __syncthreads();
+    uint32_t uu[DE_EPT], vv[DE_EPT], cu[DE_EPT], cv[DE_EPT];
+    bool live[DE_EPT];
+#pragma unroll
+    for (uint32_t t = 0; t < DE_EPT; t++) {       // the edge and count gathers of all four edges in flight
+        const uint64_t e = ((uint64_t)blockIdx.x * DE_EPT + t) * blockDim.x + threadIdx.x;
+        live[t] = e < E;
+        uu[t] = vv[t] = 0;
+        if (live[t]) {
+            const uint2 uv = reinterpret_cast<const uint2 *>(edges)[e];
+            uu[t] = uv.x;
+            vv[t] = uv.y;
         }
-        return;
     }
-    if (cv >= 2 && 2 * cv - 1 <= cu)
-        state[v] = 2;          // arc u -> v from a key of larger count
-    if (cu >= 2 && 2 * cu - 1 <= cv)
-        state[u] = 2;
-    if (cu == 1)
-        taint[u] = 1;          // here cv >= 2: v reaches u and outranks all of u's count-1 set
-    if (cv == 1)
-        taint[v] = 1;
+#pragma unroll
+    for (uint32_t t = 0; t < DE_EPT; t++) {
+        live[t] = live[t] && uu[t] != vv[t];
+        cu[t] = live[t] ? ucounts[uu[t]] : 0u;
+        cv[t] = live[t] ? ucounts[vv[t]] : 0u;
+    }
+    uint32_t rank[DE_EPT];
+#pragma unroll
+    for (uint32_t t = 0; t < DE_EPT; t++) {
+        rank[t] = 0xFFFFFFFFu;
+        if (!live[t])
+            continue;
+        const uint32_t u = uu[t], v = vv[t];
+        if (cu[t] == 1 && cv[t] == 1) {
+            uint32_t a = u, b = v;
+            for (;;) {
+                a = uf_find(parent1, a);
+                b = uf_find(parent1, b);
+                if (a == b)
+                    break;
+                if (a > b) {
+                    const uint32_t x = a;
+                    a = b;
+                    b = x;
+                }
+                if (atomicCAS(&parent1[b], b, a) == b)
+                    break;
+            }
+            rank[t] = atomicAdd(&s_n, 1u);
+            continue;
+        }
+        const long long lu = cu[t], lv = cv[t];
+        if (lv >= 2 && 2 * lv - 1 <= lu)
+            state[v] = 2;          // arc u -> v from a key of larger count
+        if (lu >= 2 && 2 * lu - 1 <= lv)
+            state[u] = 2;
+        if (lu == 1)
+            state[u] = 3;          // here cv >= 2: v reaches u and outranks all of u's count-1 set
+        if (lv == 1)
+            state[v] = 3;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n)
+        s_base = (uint32_t)atomicAdd(list11_count, (unsigned long long)s_n);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t t = 0; t < DE_EPT; t++)
+        if (rank[t] != 0xFFFFFFFFu)
+            list11[s_base + rank[t]] =
+                (uint32_t)(((uint64_t)blockIdx.x * DE_EPT + t) * blockDim.x + threadIdx.x);
 }
 
-// Pass 2 (after every union of pass 1): each count-1 key reports to the root of its set.
-__global__ void directional_roots_kernel(const uint32_t *__restrict__ edges, uint64_t E,
+// Pass 2 (after every union of pass 1), over the edges between count-1 keys only: each end reports
+// its taint and its key to the root of its set. (A count-1 key without such an edge is a set of its
+// own: its verdict reads its own state.)
+__global__ void directional_roots_kernel(const uint32_t *__restrict__ edges,
+                                         const uint32_t *__restrict__ list11,
+                                         const unsigned long long *__restrict__ list11_count,
                                          const uint32_t *__restrict__ ucounts, const uint32_t *__restrict__ urecs,
                                          const uint32_t *__restrict__ ulens, KeyShape sh,
                                          const uint32_t *__restrict__ parent1,
-                                         const uint8_t *__restrict__ taint, uint8_t *root_taint, uint32_t *best)
+                                         const uint8_t *__restrict__ state, uint8_t *root_taint, uint32_t *best)
 {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E)
-        return;
-    const uint32_t ends[2] = {edges[2 * e], edges[2 * e + 1]};
-    if (ends[0] == ends[1])
-        return;
+    const uint64_t n = *list11_count;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t e = list11[i];
+        const uint32_t ends[2] = {edges[2 * e], edges[2 * e + 1]};
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const uint32_t x = ends[k];
-        if (ucounts[x] != 1)
-            continue;
-        // every union happened in pass 1 (an earlier launch): a plain read-only walk to the root,
-        // no path halving (those are device-scope atomics)
-        uint32_t r = x, pr = parent1[r];
-        while (pr != r) {
-            r = pr;
-            pr = parent1[r];
+        for (int k = 0; k < 2; k++) {
+            const uint32_t x = ends[k];
+            // every union happened in pass 1 (an earlier launch): a plain read-only walk to the root,
+            // no path halving (those are device-scope atomics)
+            uint32_t r = x, pr = parent1[r];
+            while (pr != r) {
+                r = pr;
+                pr = parent1[r];
+            }
+            if (state[x] == 3)
+                root_taint[r] = 1;
+            if (r != x)
+                raise_best(best, r, x, ucounts, urecs, ulens, sh);
         }
-        if (taint[x])
-            root_taint[r] = 1;
-        if (r != x)
-            raise_best(best, r, x, ucounts, urecs, ulens, sh);
     }
 }
 
@@ -367,6 +408,8 @@ __device__ __forceinline__ bool kept_verdict(int method, uint32_t v, const uint3
     if (method == 3) {
         if (ucounts[v] != 1)
             return state[v] != 2;
+        if (state[v] == 3)
+            return false;          // tainted itself: next to a bigger key
         uint32_t r = v, p = parent1[r];
         while (p != r) {
             r = p;
@@ -411,6 +454,8 @@ __device__ __forceinline__ void kept_verdicts(int method, const uint32_t (&v)[N]
                 continue;
             if (cnt[t] != 1)
                 k[t] = st[t] != 2;
+            else if (st[t] == 3)
+                k[t] = false;
             else if (par[t] == v[t])
                 k[t] = !rt[t] && bs[t] == v[t];
             else
@@ -901,15 +946,17 @@ hipError_t launch_directional_round(const uint32_t *edges, uint64_t E, const uin
 
 hipError_t launch_directional_closed(const uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
                                      const uint32_t *ulens, KeyShape sh, uint32_t *parent1, uint8_t *state,
-                                     uint8_t *taint, uint8_t *root_taint, uint32_t *best, int pass, hipStream_t st)
+                                     uint32_t *list11, unsigned long long *list11_count, uint8_t *root_taint,
+                                     uint32_t *best, int pass, hipStream_t st)
 {
     if (!E)
         return hipSuccess;
     if (pass == 1)
-        directional_edges_kernel<<<grid_for(E), 256, 0, st>>>(edges, E, ucounts, parent1, state, taint);
+        directional_edges_kernel<<<(unsigned)((E + 256 * DE_EPT - 1) / (256 * DE_EPT)), 256, 0, st>>>(
+            edges, E, ucounts, parent1, state, list11, list11_count);
     else
-        directional_roots_kernel<<<grid_for(E), 256, 0, st>>>(edges, E, ucounts, urecs, ulens, sh, parent1, taint,
-                                                              root_taint, best);
+        directional_roots_kernel<<<(unsigned)std::min<uint64_t>(grid_for(E), 1024), 256, 0, st>>>(
+            edges, list11, list11_count, ucounts, urecs, ulens, sh, parent1, state, root_taint, best);
     return hipGetLastError();
 }
 
