@@ -132,6 +132,7 @@ uint32_t lds_bucket_bits(uint64_t n)
 int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, FusedLevel1 *fused = nullptr)
 {
     *done = false;
+    c->seg_hashes_nseg = 0;
     const uint64_t n = c->n;
     const KeyShape sh = c->ks;
     const char *force = getenv("FQD_COLLAPSE");  // "sort" / "lds": tests pin a path
@@ -280,10 +281,24 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
     HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
     HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
     HIP_TRY(c, c->ufirst.reserve(U * 8 + 16));
+    // fqd_cluster[_keys] announced a Hamming search with nseg segments: the compaction writes its
+    // segment hashes on the way (the records are fixed-length here)
+    fqd::SegHashOut sho;
+    c->seg_hashes_nseg = 0;
+    if (c->seg_hint && U && !getenv("FQD_NO_EARLY_SEG_HASHES")) {
+        HIP_TRY(c, c->seg_hashes.reserve((size_t)c->seg_hint * U * 4 + 16));
+        sho.out = c->seg_hashes.as<uint32_t>();
+        sho.nseg = c->seg_hint;
+        sho.n_unique = (uint32_t)U;
+        sho.planes = sh.planes;
+        sho.kw = kw;
+        sho.len = sh.max_len;
+    }
     KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_compact(c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets,
                                           c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(),
                                           c->ld_tmp_first.as<uint32_t>(), d_ids, c->urecs.as<uint32_t>(),
-                                          c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st));
+                                          c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho));
+    c->seg_hashes_nseg = sho.nseg;
     unsigned long long counted = n;
     if (d_w) {
         FQD_TRY(zero_ctr64(c, C64_SUM));
@@ -863,12 +878,26 @@ int fqd_collapse_received(fqd_ctx *c, const uint32_t *weights, const uint64_t *s
 
 static int cluster_tail(fqd_ctx *c, int max_distance, int metric, int method, fqd_summary *out);
 
+// Segments of the pigeonhole search that follows a collapse inside fqd_cluster[_keys] (0: none whose
+// hashes the collapse could prepare: the bucketed edit search, or more segments than pay off)
+static uint32_t search_segments_hint(int max_distance, int metric)
+{
+    if (max_distance < 0 || max_distance > 3)
+        return 0;
+    if (metric == FQD_METRIC_EDIT && max_distance > 1)
+        return 0;
+    return (uint32_t)max_distance + 1;
+}
+
 int fqd_cluster(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, int mem, int max_distance, int metric,
                 int method, fqd_summary *out)
 {
     if (max_distance < 0)
         return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
-    FQD_TRY(fqd_collapse(c, weights, read_ids, mem, nullptr));
+    c->seg_hint = search_segments_hint(max_distance, metric);
+    const int rc = fqd_collapse(c, weights, read_ids, mem, nullptr);
+    c->seg_hint = 0;
+    FQD_TRY(rc);
     return cluster_tail(c, max_distance, metric, method, out);
 }
 
@@ -880,12 +909,17 @@ int fqd_cluster_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, 
     if (max_distance < 0)
         return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
     bool done = false;
+    c->seg_hint = search_segments_hint(max_distance, metric);
+    int rc = FQD_OK;
     if (!offsets && !read_ids)
-        FQD_TRY(pack_collapse_fused(c, bytes, n, fixed_len, mem, weights, aux_mem, &done));
-    if (!done) {
-        FQD_TRY(fqd_pack_keys(c, bytes, offsets, n, fixed_len, mem));
-        FQD_TRY(fqd_collapse(c, weights, read_ids, aux_mem, nullptr));
+        rc = pack_collapse_fused(c, bytes, n, fixed_len, mem, weights, aux_mem, &done);
+    if (rc == FQD_OK && !done) {
+        rc = fqd_pack_keys(c, bytes, offsets, n, fixed_len, mem);
+        if (rc == FQD_OK)
+            rc = fqd_collapse(c, weights, read_ids, aux_mem, nullptr);
     }
+    c->seg_hint = 0;
+    FQD_TRY(rc);
     return cluster_tail(c, max_distance, metric, method, out);
 }
 

@@ -128,6 +128,8 @@ struct fqd_ctx {
     // stage 3
     uint64_t E = 0, edge_cap = 0;
     DevBuf seg_hashes, sorted_hash, sorted_uid, uid_iota, edges, sel_hash, sel_uid;
+    uint32_t seg_hint = 0;          // fqd_cluster[_keys]: segments of the search that follows the collapse
+    uint32_t seg_hashes_nseg = 0;   // != 0: seg_hashes already holds the nseg x U segment hashes of the unique table
     DevBuf gp_a, gp_b, gp_small, gp_cands;   // grouped search pass: items after level 1 / level 2, small tables, candidate pairs
     uint64_t gp_cand_cap = 0;
     DevBuf q_table, q_pass, q_means, q_bytes, q_offsets;

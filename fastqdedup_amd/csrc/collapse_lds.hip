@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(
     const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ unique_incl /* inclusive scan */,
     uint32_t n_buckets, const uint4 *__restrict__ tmp_rec, const uint32_t *__restrict__ tmp_count,
     const uint32_t *__restrict__ tmp_first, IdSource read_ids, uint4 *__restrict__ urecs,
-    uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst)
+    uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst, fqd::SegHashOut sho)
 {
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= n_buckets)
@@ -292,7 +292,15 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(
     const uint32_t end = unique_incl[b], begin = b ? unique_incl[b - 1] : 0u;
     const uint32_t src = bucket_start[b];
     for (uint32_t j = fqd_lane(); j < end - begin; j += 64) {
-        urecs[begin + j] = tmp_rec[src + j];
+        const uint4 rec = tmp_rec[src + j];
+        // the neighbour search that follows groups the keys by hashes of their d + 1 segments: while
+        // the record is in registers anyway (a later segment_hashes_kernel would read it once more)
+        if (sho.nseg) {
+            const uint32_t w[3] = {rec.x, rec.y, rec.z};
+            for (uint32_t sg = 0; sg < sho.nseg; sg++)
+                sho.out[(size_t)sg * sho.n_unique + begin + j] = fqd_segment_hash(w, sho.planes, sho.kw, sho.len, sg, sho.nseg);
+        }
+        urecs[begin + j] = rec;
         ucounts[begin + j] = tmp_count[src + j];
         const uint32_t f = tmp_first[src + j];
         ufirst[begin + j] = read_ids.packed_bits ? read_ids.from_packed(f) : read_ids.at(f);
@@ -405,12 +413,12 @@ hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_sta
 hipError_t launch_bucket_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                  const uint32_t *tmp_rec, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                  IdSource read_ids, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
-                                 hipStream_t st)
+                                 hipStream_t st, SegHashOut seg_hashes)
 {
     const uint64_t threads = (uint64_t)n_buckets * 64;
     bucket_compact_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
         bucket_start, unique_incl, n_buckets, reinterpret_cast<const uint4 *>(tmp_rec), tmp_count, tmp_first, read_ids,
-        reinterpret_cast<uint4 *>(urecs), ucounts, ufirst);
+        reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes);
     return hipGetLastError();
 }
 

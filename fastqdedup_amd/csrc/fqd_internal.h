@@ -278,10 +278,15 @@ hipError_t launch_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket
 hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                 uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec, uint32_t *tmp_count,
                                 uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);
+// bucket_compact_kernel may write the segment hashes of the search that follows (nseg = 0: no)
+struct SegHashOut {
+    uint32_t *out = nullptr;      // [nseg][n_unique]
+    uint32_t nseg = 0, n_unique = 0, planes = 0, kw = 0, len = 0;
+};
 hipError_t launch_bucket_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                  const uint32_t *tmp_rec, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                  IdSource read_ids, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
-                                 hipStream_t st);
+                                 hipStream_t st, SegHashOut seg_hashes = SegHashOut());
 
 // edges.hip
 hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t nseg,
