@@ -250,6 +250,8 @@ def main():
         kern["pack_kernel (fused with level 1)"] = kern.pop("pack_kernel")
         alg["pack_kernel (fused with level 1)"] = n * (L + 16)
         rocprof_name["pack_kernel (fused with level 1)"] = "pack_kernel"
+    if kern.get("bucket_compact_kernel", (0, 0))[1] and not kern.get("segment_hashes_kernel", (0, 0))[1]:
+        alg["bucket_compact_kernel"] += U_own * 4 * nseg      # the compaction wrote the search's segment hashes too
     if kern.get("gp_hist_kernel", (0, 0))[1]:
         # the sort-free search pass ran: the FQD_K_PAIRS slot timed grouped_candidates_kernel
         # ((hash, uid) items in, candidate pairs out), not bucket_pairs_kernel
