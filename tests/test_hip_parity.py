@@ -218,6 +218,42 @@ def test_fused_pack_collapse_matches_oracle(F, oracle, monkeypatch, case):
             ctx.collapse()       # the packed reads were never written: needs fqd_pack_keys first
 
 
+def test_every_fast_path_agrees_with_the_plain_paths(F, monkeypatch):
+    """2 M reads through the default route (pack fused with level 1, slabs at every partition level,
+    segment hashes written by the compaction, kept ids through id bins) and through every
+    alternative the switches select: same counters, same kept ids. (The oracle pins the default
+    route at sizes it finishes in seconds; this ties the other routes to it at a size where every
+    one of them really runs.)"""
+    import torch
+    from fastqdedup_amd.synth import synth_keys
+    monkeypatch.setenv("FQD_FUSED_MIN_READS", "1000000")
+    n, L = 2_000_000, 32
+    keys = torch.from_numpy(np.ascontiguousarray(synth_keys(n, L, L, 2024, sub_rate=2e-3, n_rate=2e-4)).reshape(-1)).cuda()
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        try:
+            ctx = F.Context(0)
+            ctx.kernel_times(reset=True)
+            r = F.cluster_keys(keys, key_len=L, max_distance=1, method="directional", context=ctx)
+            return r, ctx.kernel_times(reset=True)
+        finally:
+            for k in env:
+                monkeypatch.delenv(k)
+
+    base, kt = run()
+    assert kt["part_scatter_kernel<1>"][1] == 0 and kt["segment_hashes_kernel"][1] == 0   # fused pack, early hashes
+    assert base.n_kept == len(base.kept_read_ids) and np.all(np.diff(base.kept_read_ids.astype(np.int64)) > 0)
+    for env in ({"FQD_NO_FUSED_PACK": "1"}, {"FQD_NO_EARLY_SEG_HASHES": "1"}, {"FQD_KEPT_BY_MAP": "1"},
+                {"FQD_KEPT_BY_SORT": "1"}, {"FQD_LDS_NO_SLABS": "1", "FQD_GROUP_NO_SLABS": "1", "FQD_NO_FUSED_PACK": "1"},
+                {"FQD_COLLAPSE": "sort", "FQD_EDGES": "sort"}, {"FQD_DIRECTIONAL_ROUNDS": "1"}):
+        other, _ = run(**env)
+        assert (other.n_unique, other.n_edges, other.n_clusters, other.n_kept) == \
+               (base.n_unique, base.n_edges, base.n_clusters, base.n_kept), env
+        assert np.array_equal(other.kept_read_ids, base.kept_read_ids), env
+
+
 def test_edit_d1_equal_length_matches_oracle(F, ctx, oracle):
     """Levenshtein <= 1 on equal-length keys == Hamming <= 1 (BASELINE config 5 shape)."""
     from fastqdedup_amd.synth import fixed_offsets, synth_keys
