@@ -118,8 +118,8 @@ def pmc_traffic(kernel_substr: str, workload: str, reads_per_gpu: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--reads-per-gpu", type=int, default=0, help="override the workload's n (testing)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
