@@ -250,6 +250,13 @@ def main():
         kern["pack_kernel (fused with level 1)"] = kern.pop("pack_kernel")
         alg["pack_kernel (fused with level 1)"] = n * (L + 16)
         rocprof_name["pack_kernel (fused with level 1)"] = "pack_kernel"
+    if kern.get("bucket_dedupe_kernel", (0, 0))[1] and not kern.get("part_scatter_kernel<2>", (0, 0))[1] \
+            and not kern.get("part_scatter_kernel<1>", (0, 0))[1]:
+        # records longer than one uint4: the collapse worked on (hash, position) pairs and compared the
+        # records where they lie (collapse_pairs.hip)
+        rec = sh.stride_words * 4
+        alg["bucket_dedupe_kernel"] = n_in * 8 + (n_in - U_own) * 2 * rec + U_own * 12
+        alg["bucket_compact_kernel"] = U_own * (12 + rec + rec + 12)
     if kern.get("bucket_compact_kernel", (0, 0))[1] and not kern.get("segment_hashes_kernel", (0, 0))[1]:
         alg["bucket_compact_kernel"] += U_own * 4 * nseg      # the compaction wrote the search's segment hashes too
     if kern.get("gp_hist_kernel", (0, 0))[1]:

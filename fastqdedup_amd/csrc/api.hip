@@ -311,6 +311,79 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
     return FQD_OK;
 }
 
+// Sort-free collapse for fixed-length records of any size (collapse_pairs.hip): (hash, position)
+// pairs are partitioned into buckets, a workgroup per bucket matches them in an LDS table and
+// verifies against the records where they lie. *done = false: not applicable, or a bucket / slab
+// overflowed -- the caller takes the sort-based path.
+int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
+{
+    *done = false;
+    const uint64_t n = c->n;
+    const KeyShape sh = c->ks;
+    const char *force = getenv("FQD_COLLAPSE");  // "sort" / "lds" / "pairs": tests pin a path
+    if (force && (!strcmp(force, "sort") || !strcmp(force, "lds")))
+        return FQD_OK;
+    if (sh.ragged || (sh.stride & 3u) || n >= 0xFFFFFF00ull)
+        return FQD_OK;
+    if (n < 65536 && !(force && !strcmp(force, "pairs")))
+        return FQD_OK;
+    FQD_TRY(ensure_hashes(c));
+    const uint32_t B = lds_bucket_bits(n);
+    const uint32_t n_buckets = 1u << B;
+    uint32_t U32 = 0, overflow = 0;
+    unsigned long long slab_over = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const bool slabs = attempt == 0 && !c->pairs_slab_off && !getenv("FQD_LDS_NO_SLABS");
+        const uint32_t *items = nullptr, *bucket_end = nullptr;
+        FQD_TRY(zero_ctr32(c, C_BAD));
+        FQD_TRY(zero_ctr64(c, C64_SLAB));
+        FQD_TRY(fqd_api_partition_pairs(c, c->hashes.as<uint32_t>(), n, B, slabs, &items, &bucket_end));
+        // tmp rows of a bucket start where its items start (unique keys <= reads of the bucket)
+        const uint64_t slots = c->gp_b.cap >= 16 && items == c->gp_b.as<uint32_t>() ? (c->gp_b.cap - 16) / 8 : n;
+        HIP_TRY(c, c->ld_tmp_rec.reserve(slots * 4 + 16));        // here: the parked read's position
+        HIP_TRY(c, c->ld_tmp_count.reserve(slots * 4 + 16));
+        HIP_TRY(c, c->ld_tmp_first.reserve(slots * 4 + 16));
+        HIP_TRY(c, c->ld_unique.reserve((size_t)n_buckets * 4 + 16));
+        HIP_TRY(c, c->ld_unique_incl.reserve((size_t)n_buckets * 4 + 16));
+        KTIME(c, FQD_K_DEDUPE, fqd::launch_bucket_pairs_dedupe(
+                  items, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, c->recs.as<uint32_t>(), sh.stride, d_w,
+                  c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(), c->ld_tmp_first.as<uint32_t>(),
+                  c->ld_unique.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+        FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
+        FQD_TRY(queue_read_u32(c, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 0));
+        FQD_TRY(queue_read_u32(c, c->d_ctr32.as<uint32_t>() + C_BAD, 1));
+        FQD_TRY(read_ctr64(c, C64_SLAB, &slab_over));
+        U32 = taken_u32(c, 0);
+        overflow = taken_u32(c, 1);
+        if (!slab_over)
+            break;
+        c->pairs_slab_off = true;      // a key with hundreds of copies: exact bucket sizes from now on
+        if (attempt == 1)
+            return FQD_OK;
+    }
+    if (overflow)
+        return FQD_OK;                 // a bucket with more distinct keys than the LDS table holds
+    const uint64_t U = U32;
+    HIP_TRY(c, c->urecs.reserve(U * sh.stride * 4 + 16));
+    HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
+    HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
+    HIP_TRY(c, c->ufirst.reserve(U * 8 + 16));
+    KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_pairs_compact(
+              c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets, c->ld_tmp_rec.as<uint32_t>(),
+              c->ld_tmp_count.as<uint32_t>(), c->ld_tmp_first.as<uint32_t>(), c->recs.as<uint32_t>(), sh.stride, d_ids,
+              c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st));
+    unsigned long long counted = n;
+    if (d_w) {
+        FQD_TRY(zero_ctr64(c, C64_SUM));
+        HIP_TRY(c, fqd::launch_sum_u32(d_w, n, c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
+        FQD_TRY(read_ctr64(c, C64_SUM, &counted));
+    }
+    c->U = U;
+    c->n_counted = counted;
+    *done = true;
+    return FQD_OK;
+}
+
 // Levenshtein neighbour search for the general case (edit.hip): index/probe records ->
 // sort -> candidate pairs -> sort/unique -> banded-DP verification.
 
@@ -637,6 +710,19 @@ static int collapse_impl(fqd_ctx *c, const uint32_t *weights, int mem, IdSource 
         IdSource plain;
         plain.ids64 = c->in_read_ids.as<uint64_t>();
         ids = plain;
+    }
+    bool pairs_done = false;
+    FQD_TRY(collapse_pairs(c, weights ? d_w : nullptr, ids, &pairs_done));
+    if (pairs_done) {
+        timer.stop();
+        c->collapse_path = 3;
+        c->collapsed = true;
+        c->first_distinct = true;
+        set_id_range(c, read_ids ? id_limit : n);
+        c->stage = ST_UNIQUE;
+        if (n_unique)
+            *n_unique = c->U;
+        return FQD_OK;
     }
     c->collapse_path = 2;
     const int bits = hash_bits_from_env();

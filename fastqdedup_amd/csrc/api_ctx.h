@@ -106,6 +106,7 @@ struct fqd_ctx {
     DevBuf in_bytes, in_offsets, recs, lens, hashes, owners;
     bool fused_off = false;        // fqd_cluster_keys: a level-1 slab of the fused pack overflowed once -- plain pack from now on
     bool recs_valid = false;       // c->recs holds the packed reads in read order (not after the fused pack)
+    bool pairs_slab_off = false;   // long-record collapse: same, for its (hash, position) partition
     bool gp_slab_off = false;      // grouped search: same, for the (hash, uid) partition
     bool slab_off = false;         // LDS collapse: a slab of level 2 overflowed once, use exact bucket sizes
     bool hashes_valid = false;     // `hashes` holds the record hashes of the packed reads (lazy after an import)
@@ -399,3 +400,5 @@ int scan_u32(fqd_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n)
 // helpers shared between the api_*.hip files (defined in the file named)
 int fqd_api_ensure_hashes(fqd_ctx *c);                 // api.hip
 int fqd_api_components_queue(fqd_ctx *c, bool flatten);   // api_graph.hip
+extern "C" int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32_t B, bool slabs,
+                                       const uint32_t **items_out, const uint32_t **bucket_end_out);   // api_search.hip

@@ -73,57 +73,53 @@ int find_edges_edit(fqd_ctx *c, uint32_t d, uint32_t shard, uint32_t n_shards)
 
 extern "C" {
 
-// One Hamming search pass without a device-wide sort (group.hip): the (segment hash, uid) pairs
-// are partitioned into 2^B buckets of ~200 keys by the top hash bits, then one wave per bucket
-// sub-sorts them in LDS and lists the pairs with equal hashes; a second kernel verifies those.
-// Queues work only (no host round trip).
-static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t d, uint32_t s, uint32_t nseg)
+// (key, index) pairs of `keys[0..N)` partitioned into 2^B buckets by the top B key bits (group.hip,
+// partition.cuh): level 1 by a count matrix, level 2 on fixed slabs unless `slabs` is false (an
+// overfull slab raises C64_SLAB; the caller then asks again without slabs). Queues work only.
+// *items: the partitioned (key, index) pairs; bucket b is [start[b], min(start[b + 1], end[b])) with
+// start = c->ld_start and end = *bucket_end (NULL: start[b + 1]). Also zeroes the candidate counters
+// behind the small tables (the search pass uses them).
+int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32_t B, bool slabs,
+                            const uint32_t **items_out, const uint32_t **bucket_end_out)
 {
-    const KeyShape sh = c->ks;
-    uint32_t B = 8;
-    while (B < 20 && (U >> B) > 320)   // ~160-320 keys per bucket: a wave sorts them into 64 sub-bins in LDS
-        B++;
-    if (const char *e = getenv("FQD_GROUP_BUCKET_BITS"))   // tests: few, crowded buckets
-        B = (uint32_t)std::max(1, std::min(20, atoi(e)));
     const uint32_t B1 = B <= 18 ? std::min<uint32_t>(B, 8) : B - 10, B2 = B - B1;
     const uint32_t bins1 = 1u << B1, bins2 = 1u << B2, n_buckets = 1u << B;
     const uint32_t tile = fqd::group_tile_size();
-    const uint32_t tiles1 = (uint32_t)((U + tile - 1) / tile), max_tiles2 = tiles1 + bins1;
-    HIP_TRY(c, c->gp_a.reserve(U * 8 + 16));
+    const uint32_t tiles1 = (uint32_t)((N + tile - 1) / tile), max_tiles2 = tiles1 + bins1;
+    HIP_TRY(c, c->gp_a.reserve(N * 8 + 16));
     HIP_TRY(c, c->gp_small.reserve(4096 * 4 + (size_t)fqd::group_cand_lists() * 64));
     HIP_TRY(c, c->ld_start.reserve(((size_t)n_buckets + 1) * 4 + 16));
     uint32_t *small = c->gp_small.as<uint32_t>();
     uint32_t *seg1 = small, *tiles1_d = small + 8, *start1 = small + 16, *tiles2_d = small + 2048;
     // the candidate counters (one per list, a cache line apart) live behind the small tables
     unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(small + 4096);
-    HIP_TRY(c, fqd::launch_group_pass_init(seg1, tiles1_d, (uint32_t)U, tiles1, cand_ctr, fqd::group_cand_lists() * 8,
+    HIP_TRY(c, fqd::launch_group_pass_init(seg1, tiles1_d, (uint32_t)N, tiles1, cand_ctr, fqd::group_cand_lists() * 8,
                                            c->st));
     // ---- level 1: (bin x tile) count matrix, scan, placement without atomics
     const size_t matrix = (size_t)bins1 * tiles1;
     HIP_TRY(c, c->ld_matrix.reserve(matrix * 4 + 16));
     HIP_TRY(c, c->ld_matrix_incl.reserve(matrix * 4 + 16));
-    KTIME(c, FQD_K_GROUP_HIST, fqd::launch_group_hist(true, hashes, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1, bins1,
+    KTIME(c, FQD_K_GROUP_HIST, fqd::launch_group_hist(true, keys, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1, bins1,
                                                       c->ld_matrix.as<uint32_t>(), c->st));
     FQD_TRY(scan_u32(c, c->ld_matrix.as<uint32_t>(), c->ld_matrix_incl.as<uint32_t>(), matrix));
     HIP_TRY(c, fqd::launch_group_matrix_starts(c->ld_matrix_incl.as<uint32_t>(), bins1, tiles1, start1, c->st));
-    KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(true, hashes, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1,
+    KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(true, keys, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1,
                                                             bins1, c->ld_matrix_incl.as<uint32_t>(),
                                                             c->gp_a.as<uint32_t>(), c->st));
     const uint32_t *items = c->gp_a.as<uint32_t>();
     const uint32_t *bucket_end = nullptr;
-    // level 2 in slab mode (as the collapse): no histogram pass; an overfull slab -- many keys sharing
-    // a segment -- is flagged in C64_SLAB and the caller searches again with exact bucket sizes
+    // level 2 in slab mode (as the collapse): no histogram pass; an overfull slab is flagged in C64_SLAB
     uint32_t slab_cap = 0;
-    if (B2 && !c->gp_slab_off && !getenv("FQD_GROUP_NO_SLABS")) {
-        slab_cap = (uint32_t)(((U >> B) * 3 / 2 + 64 + 3) & ~3ull);
-        if ((uint64_t)slab_cap * n_buckets + U >= 0xFFFFFF00ull)
+    if (B2 && slabs) {
+        slab_cap = (uint32_t)(((N >> B) * 3 / 2 + 64 + 3) & ~3ull);
+        if ((uint64_t)slab_cap * n_buckets + N >= 0xFFFFFF00ull)
             slab_cap = 0;
     }
     if (B2 == 0) {
         HIP_TRY(c, hipMemcpyAsync(c->ld_start.p, start1, ((size_t)bins1 + 1) * 4, hipMemcpyDeviceToDevice, c->st));
     } else {
-        // ---- level 2: every part into 2^B2 buckets by the next hash bits
-        HIP_TRY(c, c->gp_b.reserve((slab_cap ? (uint64_t)slab_cap * n_buckets : U) * 8 + 16));
+        // ---- level 2: every part into 2^B2 buckets by the next key bits
+        HIP_TRY(c, c->gp_b.reserve((slab_cap ? (uint64_t)slab_cap * n_buckets : N) * 8 + 16));
         HIP_TRY(c, c->ld_hist.reserve((size_t)n_buckets * 4 + 16));
         HIP_TRY(c, c->ld_hist_incl.reserve((size_t)n_buckets * 4 + 16));
         HIP_TRY(c, c->ld_cursor.reserve((size_t)n_buckets * 4 + 16));
@@ -146,6 +142,30 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
                   reinterpret_cast<uint32_t *>(c->d_ctr64.as<unsigned long long>() + C64_SLAB)));
         items = c->gp_b.as<uint32_t>();
     }
+    *items_out = items;
+    *bucket_end_out = bucket_end;
+    return FQD_OK;
+}
+
+// One Hamming search pass without a device-wide sort (group.hip): the (segment hash, uid) pairs
+// are partitioned into 2^B buckets of ~200 keys by the top hash bits, then one wave per bucket
+// sub-sorts them in LDS and lists the pairs with equal hashes; a second kernel verifies those.
+// Queues work only (no host round trip).
+static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t d, uint32_t s, uint32_t nseg)
+{
+    const KeyShape sh = c->ks;
+    uint32_t B = 8;
+    while (B < 20 && (U >> B) > 320)   // ~160-320 keys per bucket: a wave sorts them into 64 sub-bins in LDS
+        B++;
+    if (const char *e = getenv("FQD_GROUP_BUCKET_BITS"))   // tests: few, crowded buckets
+        B = (uint32_t)std::max(1, std::min(20, atoi(e)));
+    const uint32_t n_buckets = 1u << B;
+    const uint32_t *items = nullptr, *bucket_end = nullptr;
+    // (an overfull level-2 slab -- many keys sharing a segment -- is flagged in C64_SLAB and the caller
+    // searches again with exact bucket sizes)
+    FQD_TRY(fqd_api_partition_pairs(c, hashes, U, B, !c->gp_slab_off && !getenv("FQD_GROUP_NO_SLABS"), &items,
+                                    &bucket_end));
+    unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(c->gp_small.as<uint32_t>() + 4096);
     // candidates (pairs with equal segment hashes) -> device list -> verification, one thread per pair
     if (c->gp_cand_cap < 1024 || !c->gp_cands.p) {
         c->gp_cand_cap = std::max<uint64_t>(1u << 20, 2 * U);   // split evenly over the lists: leave slack

@@ -1,0 +1,234 @@
+// collapse_pairs.hip -- exact-duplicate collapse for records LONGER than one uint4 (keys above
+// 32 nt: BASELINE configs 2, 4, 5), without a device-wide sort. Same contract as collapse.hip and
+// collapse_lds.hip (reference _triemodule.c:235-239, :261-264: an identical key bumps a count;
+// pass-2 rule __init__.py:201-206: the first holder is remembered).
+//
+// The records stay where the pack kernel put them. What moves is one (key hash, read position)
+// pair per read: partitioned by the top hash bits into buckets of ~400-800 pairs (the two-level
+// LDS-aggregated partition of group.hip / partition.cuh), then one workgroup per bucket runs the
+// pairs through an LDS hash table keyed by the 32-bit hash. A slot is claimed with an LDS
+// compare-and-swap by the first read of a hash, which parks its POSITION; every later read with
+// that hash compares its record with the parked read's record in HBM, word by word (a hash only
+// proposes), and then bumps the slot's count / min position with LDS atomics or probes on. Per
+// read: 8 bytes through the partition twice and, for a read that is not the first of its key, two
+// record gathers (its own and the parked one, which the reads before it have pulled into L2).
+// bucket_pairs_compact_kernel then gathers one record per unique key into the unique table.
+#include <cstdlib>
+#include "fqd_internal.h"
+
+namespace {
+
+constexpr uint32_t PD_SLOTS = 1024;        // LDS table slots per bucket (power of two)
+constexpr uint32_t PD_THREADS = 256;
+constexpr uint32_t PD_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t PD_AHEAD = 4;
+
+// records at positions a and b equal? (q_per_rec uint4 each; padding words are zero). Up to eight
+// uint4 of either record are requested before the first comparison: most comparisons are between
+// copies of one key and end in "equal" -- an early exit saves nothing and a word-by-word loop pays
+// one memory round trip per 16 bytes.
+__device__ __forceinline__ bool same_record(const uint4 *__restrict__ recs4, uint32_t q_per_rec, uint32_t a,
+                                            uint32_t b)
+{
+    const uint4 *ra = recs4 + (size_t)a * q_per_rec, *rb = recs4 + (size_t)b * q_per_rec;
+    uint32_t diff = 0;
+    for (uint32_t q0 = 0; q0 < q_per_rec; q0 += 8) {
+        uint4 x[8], y[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+            x[q] = y[q] = make_uint4(0, 0, 0, 0);
+            if (q0 + q < q_per_rec) {
+                x[q] = ra[q0 + q];
+                y[q] = rb[q0 + q];
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++)
+            diff |= (x[q].x ^ y[q].x) | (x[q].y ^ y[q].y) | (x[q].z ^ y[q].z) | (x[q].w ^ y[q].w);
+        if (diff)
+            return false;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
+    const uint2 *__restrict__ items /* (hash, position) */, const uint32_t *__restrict__ bucket_start,
+    const uint32_t *__restrict__ bucket_end /* NULL, or slab mode: where each bucket's cursor stopped */,
+    const uint4 *__restrict__ recs4, uint32_t q_per_rec, const uint32_t *__restrict__ weights,
+    uint32_t *__restrict__ tmp_rep, uint32_t *__restrict__ tmp_count, uint32_t *__restrict__ tmp_first,
+    uint32_t *__restrict__ bucket_unique, uint32_t *__restrict__ overflow,
+    uint32_t tag_mask /* ~0; tests: few bits => different keys share a tag */)
+{
+    __shared__ uint32_t s_tag[PD_SLOTS], s_rep[PD_SLOTS], s_cnt[PD_SLOTS], s_min[PD_SLOTS];
+    __shared__ uint32_t s_wave_tot[PD_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t lo = bucket_start[b];
+    uint32_t hi = bucket_start[b + 1];
+    if (bucket_end)
+        hi = min(hi, bucket_end[b]);
+    for (uint32_t s = tid; s < PD_SLOTS; s += PD_THREADS)
+        s_tag[s] = PD_EMPTY;
+    __syncthreads();
+
+    bool full = false;
+    for (uint32_t base0 = lo; base0 < hi; base0 += PD_AHEAD * PD_THREADS) {
+        uint2 it[PD_AHEAD];
+        uint32_t w[PD_AHEAD], tag[PD_AHEAD], slot[PD_AHEAD], probes[PD_AHEAD];
+        bool pending[PD_AHEAD];
+#pragma unroll
+        for (uint32_t k = 0; k < PD_AHEAD; k++) {
+            const uint32_t i = base0 + k * PD_THREADS + tid;
+            it[k] = make_uint2(0, 0);
+            if (i < hi)
+                it[k] = items[i];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PD_AHEAD; k++) {
+            const uint32_t i = base0 + k * PD_THREADS + tid;
+            pending[k] = i < hi;
+            w[k] = pending[k] ? (weights ? weights[it[k].y] : 1u) : 0u;
+            tag[k] = (it[k].x == PD_EMPTY ? 0u : it[k].x) & tag_mask;
+            slot[k] = (tag[k] * 0x9E3779B1u) >> 22;    // top 10 bits of a re-mix: PD_SLOTS == 1024
+            probes[k] = 0;
+        }
+        // a round: claim an empty slot or stop at a slot whose tag matches, for every pending pair of
+        // the thread; barrier (the parked positions are visible); verify against the parked read's
+        // record and count, or probe on
+        bool any;
+        do {
+#pragma unroll
+            for (uint32_t k = 0; k < PD_AHEAD; k++) {
+                if (!pending[k])
+                    continue;
+                for (;;) {
+                    const uint32_t old = atomicCAS(&s_tag[slot[k]], PD_EMPTY, tag[k]);
+                    if (old == PD_EMPTY) {
+                        s_rep[slot[k]] = it[k].y;
+                        s_cnt[slot[k]] = w[k];
+                        s_min[slot[k]] = it[k].y;
+                        pending[k] = false;
+                        break;
+                    }
+                    if (old == tag[k])
+                        break;
+                    slot[k] = (slot[k] + 1) & (PD_SLOTS - 1);
+                    if (++probes[k] >= PD_SLOTS) {
+                        full = true;
+                        pending[k] = false;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            any = false;
+#pragma unroll
+            for (uint32_t k = 0; k < PD_AHEAD; k++) {
+                if (!pending[k])
+                    continue;
+                if (same_record(recs4, q_per_rec, it[k].y, s_rep[slot[k]])) {
+                    atomicAdd(&s_cnt[slot[k]], w[k]);
+                    atomicMin(&s_min[slot[k]], it[k].y);
+                    pending[k] = false;
+                } else {  // same hash, different key: keep probing
+                    slot[k] = (slot[k] + 1) & (PD_SLOTS - 1);
+                    if (++probes[k] >= PD_SLOTS) {
+                        full = true;
+                        pending[k] = false;
+                    } else {
+                        any = true;
+                    }
+                }
+            }
+        } while (__syncthreads_or(any));
+    }
+    if (full)
+        atomicOr(overflow, 1u);
+    __syncthreads();
+
+    // live slots (count > 0: a key all of whose holders have weight 0 is not in the trie) -> tmp[lo ...)
+    uint32_t mine = 0;
+    for (uint32_t s = tid; s < PD_SLOTS; s += PD_THREADS)
+        mine += (s_tag[s] != PD_EMPTY && s_cnt[s] > 0) ? 1u : 0u;
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if ((int)lane >= o)
+            incl += up;
+    }
+    if (lane == 63)
+        s_wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine;
+    for (uint32_t wv = 0; wv < wave; wv++)
+        before += s_wave_tot[wv];
+    uint32_t total = 0;
+    for (uint32_t wv = 0; wv < PD_THREADS / 64; wv++)
+        total += s_wave_tot[wv];
+    uint32_t out = lo + before;
+    for (uint32_t s = tid; s < PD_SLOTS; s += PD_THREADS)
+        if (s_tag[s] != PD_EMPTY && s_cnt[s] > 0) {
+            tmp_rep[out] = s_rep[s];
+            tmp_count[out] = s_cnt[s];
+            tmp_first[out] = s_min[s];
+            out++;
+        }
+    if (tid == 0)
+        bucket_unique[b] = total;
+}
+
+// one wave per bucket: the record at tmp_rep[bucket_start[b] + j] -> urecs[unique offset of b + j]
+__global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
+    const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ unique_incl /* inclusive scan */,
+    uint32_t n_buckets, const uint32_t *__restrict__ tmp_rep, const uint32_t *__restrict__ tmp_count,
+    const uint32_t *__restrict__ tmp_first, const uint4 *__restrict__ recs4, uint32_t q_per_rec, IdSource read_ids,
+    uint4 *__restrict__ urecs4, uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst)
+{
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= n_buckets)
+        return;
+    const uint32_t end = unique_incl[b], begin = b ? unique_incl[b - 1] : 0u;
+    const uint32_t src = bucket_start[b], cnt = end - begin;
+    for (uint32_t j = fqd_lane(); j < cnt; j += 64) {
+        ucounts[begin + j] = tmp_count[src + j];
+        ufirst[begin + j] = read_ids.at(tmp_first[src + j]);
+    }
+    for (uint32_t x = fqd_lane(); x < cnt * q_per_rec; x += 64) {
+        const uint32_t j = x / q_per_rec, q = x - j * q_per_rec;
+        urecs4[(size_t)(begin + j) * q_per_rec + q] = recs4[(size_t)tmp_rep[src + j] * q_per_rec + q];
+    }
+}
+
+}  // namespace
+
+namespace fqd {
+
+hipError_t launch_bucket_pairs_dedupe(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                      uint32_t n_buckets, const uint32_t *recs, uint32_t stride_words,
+                                      const uint32_t *weights, uint32_t *tmp_rep, uint32_t *tmp_count,
+                                      uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st)
+{
+    if (!n_buckets || (stride_words & 3u))
+        return n_buckets ? hipErrorInvalidValue : hipSuccess;
+    bucket_pairs_dedupe_kernel<<<n_buckets, PD_THREADS, 0, st>>>(
+        reinterpret_cast<const uint2 *>(items), bucket_start, bucket_end, reinterpret_cast<const uint4 *>(recs),
+        stride_words / 4, weights, tmp_rep, tmp_count, tmp_first, bucket_unique, overflow,
+        getenv("FQD_PAIRS_TAG_MASK") ? (uint32_t)strtoul(getenv("FQD_PAIRS_TAG_MASK"), nullptr, 0) : 0xFFFFFFFFu);
+    return hipGetLastError();
+}
+
+hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
+                                       const uint32_t *tmp_rep, const uint32_t *tmp_count, const uint32_t *tmp_first,
+                                       const uint32_t *recs, uint32_t stride_words, IdSource read_ids, uint32_t *urecs,
+                                       uint32_t *ucounts, uint64_t *ufirst, hipStream_t st)
+{
+    if (!n_buckets)
+        return hipSuccess;
+    const uint64_t threads = (uint64_t)n_buckets * 64;
+    bucket_pairs_compact_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
+        bucket_start, unique_incl, n_buckets, tmp_rep, tmp_count, tmp_first, reinterpret_cast<const uint4 *>(recs),
+        stride_words / 4, read_ids, reinterpret_cast<uint4 *>(urecs), ucounts, ufirst);
+    return hipGetLastError();
+}
+
+}  // namespace fqd

@@ -270,6 +270,15 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
 hipError_t launch_slab_tile_starts(const uint32_t *seg_start, const uint32_t *seg_end, uint32_t n_seg,
                                    uint32_t *tile_start, hipStream_t st);
 uint32_t part_tile_size();
+// collapse_pairs.hip -- sort-free collapse for records longer than one uint4
+hipError_t launch_bucket_pairs_dedupe(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                      uint32_t n_buckets, const uint32_t *recs, uint32_t stride_words,
+                                      const uint32_t *weights, uint32_t *tmp_rep, uint32_t *tmp_count,
+                                      uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);
+hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
+                                       const uint32_t *tmp_rep, const uint32_t *tmp_count, const uint32_t *tmp_first,
+                                       const uint32_t *recs, uint32_t stride_words, IdSource read_ids, uint32_t *urecs,
+                                       uint32_t *ucounts, uint64_t *ufirst, hipStream_t st);
 hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                 hipStream_t st);
 hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,

@@ -218,6 +218,49 @@ def test_fused_pack_collapse_matches_oracle(F, oracle, monkeypatch, case):
             ctx.collapse()       # the packed reads were never written: needs fqd_pack_keys first
 
 
+@pytest.mark.parametrize("case", ["plain", "weights", "tag_collisions", "heavy_key", "few_buckets", "len300_d2"])
+def test_long_record_collapse_without_sort_matches_oracle(F, oracle, monkeypatch, case):
+    """Keys above 32 nt (records longer than one uint4) collapse through (hash, position) pairs: the
+    pairs are partitioned, an LDS table per bucket matches them, records are compared where they
+    lie (collapse_pairs.hip). Same answer as the oracle and as the sort-based collapse -- with
+    weights, with different keys sharing a tag (masked tags), with a key whose copies overfill a
+    slab (exact bucket sizes then), and when a bucket overflows the table (sort-based path then)."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    n, L, d = (120_000, 100, 1) if case != "len300_d2" else (70_000, 300, 2)
+    if case == "heavy_key":
+        n = 300_000                      # two partition levels: the second one works on slabs
+    keys = synth_keys(n, L, 12, 61, sub_rate=2e-3, n_rate=2e-4)
+    rng = np.random.default_rng(6)
+    weights = None
+    if case == "weights":
+        weights = rng.choice(np.array([0, 1, 1, 1], dtype=np.uint32), size=n)
+    if case == "heavy_key":
+        heavy = rng.choice(n, size=5000, replace=False)
+        keys[heavy] = keys[heavy[0]]
+        keys[heavy[::13], 40] = ord("N")
+    if case == "tag_collisions":
+        monkeypatch.setenv("FQD_PAIRS_TAG_MASK", "0x7")
+    if case == "few_buckets":
+        monkeypatch.setenv("FQD_LDS_BUCKET_BITS", "2")
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    want = oracle.dedup(raw, fixed_offsets(n, L), weights=weights, max_distance=d, method="directional")
+    ctx = F.Context(0)
+    monkeypatch.setenv("FQD_COLLAPSE", "pairs")
+    for _ in range(2):
+        ctx.kernel_times(reset=True)
+        got = F.cluster_keys(raw, key_len=L, weights=weights, max_distance=d, method="directional", context=ctx)
+        kt = ctx.kernel_times(reset=True)
+        assert kt["bucket_dedupe_kernel"][1] >= 1                       # the pairs path ran ...
+        assert (kt["head_flags_kernel"][1] > 0) == (case == "few_buckets")   # ... and only then the sort path
+        assert got.n_counted == (n if weights is None else int(weights.sum()))
+        assert (got.n_unique, got.n_clusters) == (want["n_unique"], want["n_clusters"])
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+    monkeypatch.setenv("FQD_COLLAPSE", "sort")
+    by_sort = F.cluster_keys(raw, key_len=L, weights=weights, max_distance=d, method="directional", context=F.Context(0))
+    assert (by_sort.n_unique, by_sort.n_edges) == (got.n_unique, got.n_edges)
+    assert np.array_equal(by_sort.kept_read_ids, got.kept_read_ids)
+
+
 def test_every_fast_path_agrees_with_the_plain_paths(F, monkeypatch):
     """2 M reads through the default route (pack fused with level 1, slabs at every partition level,
     segment hashes written by the compaction, kept ids through id bins) and through every
