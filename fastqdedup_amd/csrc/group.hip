@@ -122,13 +122,33 @@ __device__ __forceinline__ bool gp_verify(const uint32_t *__restrict__ urecs, co
         return false;
     const uint32_t W = sh.words;
     const uint32_t *my_rec = urecs + (uint64_t)uid * sh.stride, *other = urecs + (uint64_t)uj * sh.stride;
+    // The first 32-base word alone -- a candidate that is no neighbour at all (a shared segment,
+    // nothing else in common) is out after ONE sector per record -- then eight words per step, their
+    // loads requested together: a true neighbour is read to the end, and a word-by-word loop with an
+    // exit test pays a round trip per word (10 for a 300-nt key). Measured per launch, word by word /
+    // eight at once from the start / this: config 2 0.092 / 0.136 / 0.092 ms, config 5 2.87 / 1.23 / 1.46 ms.
     uint32_t dist = 0;
-    for (uint32_t w = 0; w < W && dist <= d; w++) {
+    {
         uint32_t dw = 0;
 #pragma unroll
         for (int k = 0; k < K; k++)
-            dw |= my_rec[w * K + k] ^ other[w * K + k];
-        dist += __popc(dw);
+            dw |= my_rec[k] ^ other[k];
+        dist = W ? __popc(dw) : 0u;
+    }
+    for (uint32_t w0 = 1; w0 < W && dist <= d; w0 += 8) {
+        uint32_t dw[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            dw[j] = 0;
+            if (w0 + j < W) {
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    dw[j] |= my_rec[(w0 + j) * K + k] ^ other[(w0 + j) * K + k];
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++)
+            dist += __popc(dw[j]);
     }
     if (dist > d)
         return false;
