@@ -25,6 +25,11 @@ struct SegBounds {
     uint32_t lo[8], hi[8];
 };
 
+// A wave takes SH_GROUPS consecutive groups of 64 / Q records, their loads requested together: one
+// group per wave -- a single 16-byte load per lane, then ~200 ALU instructions and out -- left the
+// kernel at 1.5 TB/s on 128-byte records (waves too short for their launch cost).
+constexpr uint32_t SH_GROUPS = 4;
+
 __global__ __launch_bounds__(256) void segment_hashes_kernel(const uint32_t *__restrict__ urecs,
                                                              const uint32_t *__restrict__ ulens, uint64_t U,
                                                              KeyShape sh, uint32_t nseg, uint32_t s_begin,
@@ -33,52 +38,64 @@ __global__ __launch_bounds__(256) void segment_hashes_kernel(const uint32_t *__r
                                                              uint32_t *__restrict__ seg_hashes)
 {
     const uint32_t Q = sh.stride / 4, KW = sh.planes * sh.words;
-    const uint32_t rpw = 64u / Q;                       // records per wave (Q <= 64 checked by the host)
+    const uint32_t rpw = 64u / Q;                       // records per wave and group (Q <= 64 checked by the host)
     const uint32_t lane = fqd_lane();
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     // x / Q and x / K by multiplication (inv = ceil(2^20 / divisor), exact for x < 2^14)
     const uint32_t rl = (lane * inv_q) >> 20, q = lane - rl * Q;
-    const uint64_t u = wave * rpw + rl;
-    const bool active = rl < rpw && u < U;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    uint32_t len = 0;
-    if (active) {
-        v = reinterpret_cast<const uint4 *>(urecs + u * sh.stride)[q];
-        len = fqd_key_len(sh, ulens, u);
+    uint4 vs[SH_GROUPS];
+    uint32_t lens[SH_GROUPS];
+    bool actives[SH_GROUPS];
+#pragma unroll
+    for (uint32_t g = 0; g < SH_GROUPS; g++) {
+        const uint64_t u = (wave * SH_GROUPS + g) * rpw + rl;
+        actives[g] = rl < rpw && u < U;
+        vs[g] = make_uint4(0, 0, 0, 0);
+        lens[g] = 0;
+        if (actives[g]) {
+            vs[g] = reinterpret_cast<const uint4 *>(urecs + u * sh.stride)[q];
+            lens[g] = fqd_key_len(sh, ulens, u);
+        }
     }
-    const uint32_t word[4] = {v.x, v.y, v.z, v.w};
     uint32_t wi[4];   // 32-base word index of each of this lane's 4 record words
 #pragma unroll
     for (uint32_t e = 0; e < 4; e++)
         wi[e] = ((q * 4 + e) * inv_k) >> 20;
-    // segments [s_begin, s_end) of the nseg-way split; row (s - s_begin) of the output. mod != 0
-    // stores hash % mod (the owner rank of a segment-routed exchange).
-    for (uint32_t s = s_begin; s < s_end; s++) {
-        uint32_t lo, hi;
-        if (fixed.n) {
-            lo = fixed.lo[s - s_begin];
-            hi = fixed.hi[s - s_begin];
-        } else {
-            fqd_segment(len, s, nseg, lo, hi);
-        }
-        uint32_t part = 0;
 #pragma unroll
-        for (uint32_t e = 0; e < 4; e++) {
-            const uint32_t j = q * 4 + e;               // word index in the record
-            if (j < KW) {
-                const uint32_t m = fqd_range_mask(wi[e], lo, hi);
-                if (m)
-                    part += fqd_mix32((word[e] & m) + (j + 1u) * 0x9E3779B1u);
+    for (uint32_t g = 0; g < SH_GROUPS; g++) {
+        const uint64_t u = (wave * SH_GROUPS + g) * rpw + rl;
+        const bool active = actives[g];
+        const uint32_t len = lens[g];
+        const uint32_t word[4] = {vs[g].x, vs[g].y, vs[g].z, vs[g].w};
+        // segments [s_begin, s_end) of the nseg-way split; row (s - s_begin) of the output. mod != 0
+        // stores hash % mod (the owner rank of a segment-routed exchange).
+        for (uint32_t s = s_begin; s < s_end; s++) {
+            uint32_t lo, hi;
+            if (fixed.n) {
+                lo = fixed.lo[s - s_begin];
+                hi = fixed.hi[s - s_begin];
+            } else {
+                fqd_segment(len, s, nseg, lo, hi);
             }
-        }
-        for (uint32_t off = 1; off < Q; off <<= 1) {    // segmented sum over the record's Q lanes
-            const uint32_t other = __shfl_down(part, off);
-            if (q + off < Q)
-                part += other;
-        }
-        if (active && q == 0) {
-            const uint32_t h = fqd_mix32(part + fqd_mix32(len * 0x9E3779B1u + s * 0x85EBCA77u + 0x165667B1u));
-            seg_hashes[(uint64_t)(s - s_begin) * U + u] = mod ? h % mod : h;
+            uint32_t part = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < 4; e++) {
+                const uint32_t j = q * 4 + e;               // word index in the record
+                if (j < KW) {
+                    const uint32_t m = fqd_range_mask(wi[e], lo, hi);
+                    if (m)
+                        part += fqd_mix32((word[e] & m) + (j + 1u) * 0x9E3779B1u);
+                }
+            }
+            for (uint32_t off = 1; off < Q; off <<= 1) {    // segmented sum over the record's Q lanes
+                const uint32_t other = __shfl_down(part, off);
+                if (q + off < Q)
+                    part += other;
+            }
+            if (active && q == 0) {
+                const uint32_t h = fqd_mix32(part + fqd_mix32(len * 0x9E3779B1u + s * 0x85EBCA77u + 0x165667B1u));
+                seg_hashes[(uint64_t)(s - s_begin) * U + u] = mod ? h % mod : h;
+            }
         }
     }
 }
@@ -400,7 +417,7 @@ hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, u
     const uint32_t Q = sh.stride / 4;
     if (Q > 64)
         return hipErrorInvalidValue;  // records above 1 KiB: not reachable within the pack tile limit
-    const uint64_t rpw = 64 / Q, waves = (U + rpw - 1) / rpw, blocks = (waves + 3) / 4;
+    const uint64_t rpw = 64 / Q, waves = (U + rpw * SH_GROUPS - 1) / (rpw * SH_GROUPS), blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFull * 256)
         return hipErrorInvalidValue;
     SegBounds fixed{};
