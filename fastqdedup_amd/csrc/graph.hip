@@ -312,15 +312,17 @@ __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *
 }
 
 // Pass 2 (after every union of pass 1), over the edges between count-1 keys only: each end reports
-// its taint and its key to the root of its set. (A count-1 key without such an edge is a set of its
-// own: its verdict reads its own state.)
+// its taint and its key to the root of its set and is marked (state bit 8) as a member of a set of
+// several keys. A count-1 key without such an edge is a set of its own, and the state byte alone is
+// then the verdict of EVERY key: 0 kept, 2 dropped (count >= 2 with an in-arc), 3 dropped (count 1
+// next to a bigger key), bit 8: ask the root.
 __global__ void directional_roots_kernel(const uint32_t *__restrict__ edges,
                                          const uint32_t *__restrict__ list11,
                                          const unsigned long long *__restrict__ list11_count,
                                          const uint32_t *__restrict__ ucounts, const uint32_t *__restrict__ urecs,
                                          const uint32_t *__restrict__ ulens, KeyShape sh,
-                                         const uint32_t *__restrict__ parent1,
-                                         const uint8_t *__restrict__ state, uint8_t *root_taint, uint32_t *best)
+                                         const uint32_t *__restrict__ parent1, uint8_t *state,
+                                         uint8_t *root_taint, uint32_t *best)
 {
     const uint64_t n = *list11_count;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -336,8 +338,12 @@ __global__ void directional_roots_kernel(const uint32_t *__restrict__ edges,
                 r = pr;
                 pr = parent1[r];
             }
-            if (state[x] == 3)
+            const uint8_t sx = state[x];
+            if ((sx & 7) == 3)
                 root_taint[r] = 1;
+            if (!(sx & 8))
+                state[x] = sx | 8;     // member of a set of several count-1 keys: its verdict is its root's
+                                       // (every writer of this byte in this launch writes this same value)
             if (r != x)
                 raise_best(best, r, x, ucounts, urecs, ulens, sh);
         }
@@ -406,10 +412,11 @@ __device__ __forceinline__ bool kept_verdict(int method, uint32_t v, const uint3
     if (method == 2)
         return best[v] == v;
     if (method == 3) {
-        if (ucounts[v] != 1)
-            return state[v] != 2;
-        if (state[v] == 3)
-            return false;          // tainted itself: next to a bigger key
+        const uint8_t st = state[v];
+        if (!(st & 8))
+            return st == 0;        // 2: in-arc from a bigger key, 3: count 1 next to a bigger key
+        if ((st & 7) == 3)
+            return false;
         uint32_t r = v, p = parent1[r];
         while (p != r) {
             r = p;
@@ -420,10 +427,8 @@ __device__ __forceinline__ bool kept_verdict(int method, uint32_t v, const uint3
     return state[v] == 1;
 }
 
-// N verdicts at once. The closed-form directional verdict of a count-1 key follows a chain
-// (count -> parent -> root's taint and best); almost every such key is its own root, so all five
-// arrays are loaded for all N keys at once AS IF it were, and only a key with a real parent walks.
-// (Key by key, the kernel waits for three dependent round trips per key: 0.2 ms for 14 M keys.)
+// N verdicts at once (their loads in flight together: key by key the kernel waits for a chain of
+// dependent round trips per key, 0.2 ms for 14 M keys).
 template <uint32_t N>
 __device__ __forceinline__ void kept_verdicts(int method, const uint32_t (&v)[N], const bool (&valid)[N],
                                               const uint32_t *__restrict__ labels,
@@ -433,32 +438,15 @@ __device__ __forceinline__ void kept_verdicts(int method, const uint32_t (&v)[N]
                                               const uint8_t *__restrict__ root_taint, bool (&k)[N])
 {
     if (method == 3) {
-        uint32_t cnt[N], par[N], bs[N];
-        uint8_t st[N], rt[N];
+        // the state byte decides (pass 2 marked the few keys that have to ask their set's root)
+        uint8_t st[N];
+#pragma unroll
+        for (uint32_t t = 0; t < N; t++)
+            st[t] = valid[t] ? state[v[t]] : (uint8_t)2;
 #pragma unroll
         for (uint32_t t = 0; t < N; t++) {
-            cnt[t] = par[t] = bs[t] = 0;
-            st[t] = rt[t] = 0;
-            if (valid[t]) {
-                cnt[t] = ucounts[v[t]];
-                st[t] = state[v[t]];
-                par[t] = parent1[v[t]];
-                rt[t] = root_taint[v[t]];
-                bs[t] = best[v[t]];
-            }
-        }
-#pragma unroll
-        for (uint32_t t = 0; t < N; t++) {
-            k[t] = false;
-            if (!valid[t])
-                continue;
-            if (cnt[t] != 1)
-                k[t] = st[t] != 2;
-            else if (st[t] == 3)
-                k[t] = false;
-            else if (par[t] == v[t])
-                k[t] = !rt[t] && bs[t] == v[t];
-            else
+            k[t] = st[t] == 0;
+            if (st[t] & 8)
                 k[t] = kept_verdict(3, v[t], labels, best, state, ucounts, parent1, root_taint);
         }
     } else {
