@@ -291,19 +291,40 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(
         return;
     const uint32_t end = unique_incl[b], begin = b ? unique_incl[b - 1] : 0u;
     const uint32_t src = bucket_start[b];
-    for (uint32_t j = fqd_lane(); j < end - begin; j += 64) {
-        const uint4 rec = tmp_rec[src + j];
-        // the neighbour search that follows groups the keys by hashes of their d + 1 segments: while
-        // the record is in registers anyway (a later segment_hashes_kernel would read it once more)
-        if (sho.nseg) {
-            const uint32_t w[3] = {rec.x, rec.y, rec.z};
-            for (uint32_t sg = 0; sg < sho.nseg; sg++)
-                sho.out[(size_t)sg * sho.n_unique + begin + j] = fqd_segment_hash(w, sho.planes, sho.kw, sho.len, sg, sho.nseg);
+    // four rows per lane and step, their loads requested together (a bucket has ~210 unique keys:
+    // usually one step)
+    const uint32_t cnt = end - begin;
+    for (uint32_t j0 = fqd_lane(); j0 < cnt; j0 += 4 * 64) {
+        uint4 rec[4];
+        uint32_t c4[4], f4[4];
+#pragma unroll
+        for (uint32_t t = 0; t < 4; t++) {
+            const uint32_t j = j0 + t * 64;
+            rec[t] = make_uint4(0, 0, 0, 0);
+            c4[t] = f4[t] = 0;
+            if (j < cnt) {
+                rec[t] = tmp_rec[src + j];
+                c4[t] = tmp_count[src + j];
+                f4[t] = tmp_first[src + j];
+            }
         }
-        urecs[begin + j] = rec;
-        ucounts[begin + j] = tmp_count[src + j];
-        const uint32_t f = tmp_first[src + j];
-        ufirst[begin + j] = read_ids.packed_bits ? read_ids.from_packed(f) : read_ids.at(f);
+#pragma unroll
+        for (uint32_t t = 0; t < 4; t++) {
+            const uint32_t j = j0 + t * 64;
+            if (j >= cnt)
+                continue;
+            // the neighbour search that follows groups the keys by hashes of their d + 1 segments: while
+            // the record is in registers anyway (a later segment_hashes_kernel would read it once more)
+            if (sho.nseg) {
+                const uint32_t w[3] = {rec[t].x, rec[t].y, rec[t].z};
+                for (uint32_t sg = 0; sg < sho.nseg; sg++)
+                    sho.out[(size_t)sg * sho.n_unique + begin + j] =
+                        fqd_segment_hash(w, sho.planes, sho.kw, sho.len, sg, sho.nseg);
+            }
+            urecs[begin + j] = rec[t];
+            ucounts[begin + j] = c4[t];
+            ufirst[begin + j] = read_ids.packed_bits ? read_ids.from_packed(f4[t]) : read_ids.at(f4[t]);
+        }
     }
 }
 
