@@ -205,7 +205,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
     uint32_t *f_seg_end = fused ? f_seg_start + (f_parts + 4) : nullptr;
     uint32_t *f_tiles = fused ? f_seg_end + (f_parts + 4) : nullptr;
     const uint32_t *parted = c->ld_part.as<uint32_t>();
-    uint32_t U32 = 0, overflow = 0;
+    uint32_t U32 = 0, overflow = 0, early_nseg = 0;
     for (;;) {
         const uint32_t *bucket_end = nullptr;
         if (!fused)          // (the fused pack has already run and may have raised bit 4)
@@ -247,25 +247,47 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                                              c->ld_tmp_first.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
                                              c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
         FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
+        // One read-back: the unique count, the pack kernel's foreign-byte flag and every overflow flag
+        // (bit 4: a level-1 slab of the fused pack, bit 2: a level-2 slab, bit 1: a bucket's LDS
+        // table). The compaction is queued BEHIND the read-back and before the host waits for it: it
+        // reads the unique count on the device and writes into tables sized for the worst case (as
+        // many unique keys as reads), so the GPU works through the ~50 us the host needs to see the
+        // numbers and react. If a flag says the attempt failed, what it wrote is simply not used.
         FQD_TRY(queue_read_u32(c, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 0));
+        FQD_TRY(queue_read_u32n(c, c->d_ctr32.as<uint32_t>(), C_PACKBAD + 1, 1));
+        FQD_TRY(queued_reads_mark(c));
+        HIP_TRY(c, c->urecs.reserve(n * 16 + 16));
+        HIP_TRY(c, c->ucounts.reserve(n * 4 + 16));
+        HIP_TRY(c, c->ufirst.reserve(n * 8 + 16));
+        // fqd_cluster[_keys] announced a Hamming search with nseg segments: the compaction writes its
+        // segment hashes on the way (the records are fixed-length here)
+        fqd::SegHashOut sho;
+        if (c->seg_hint && !getenv("FQD_NO_EARLY_SEG_HASHES")) {
+            HIP_TRY(c, c->seg_hashes.reserve((size_t)c->seg_hint * n * 4 + 16));
+            sho.out = c->seg_hashes.as<uint32_t>();
+            sho.nseg = c->seg_hint;
+            sho.planes = sh.planes;
+            sho.kw = kw;
+            sho.len = sh.max_len;
+        }
+        KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_compact(
+                  c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets, c->ld_tmp_rec.as<uint32_t>(),
+                  c->ld_tmp_count.as<uint32_t>(), c->ld_tmp_first.as<uint32_t>(), d_ids, c->urecs.as<uint32_t>(),
+                  c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho));
+        early_nseg = sho.nseg;
+        FQD_TRY(queued_reads_wait(c));
+        U32 = taken_u32(c, 0);
+        overflow = taken_u32(c, 1 + C_BAD);
         if (fused) {
-            // one readback: the pack kernel's foreign-byte flag and every overflow flag (bit 4: a
-            // level-1 slab of the fused pack, bit 2: a level-2 slab, bit 1: a bucket's LDS table)
-            uint32_t ctr[C_PACKBAD + 1] = {0};
-            FQD_TRY(read_ctr32n(c, 0, ctr, C_PACKBAD + 1));
-            overflow = ctr[C_BAD];
-            fused->pack_bad = ctr[C_PACKBAD];
+            fused->pack_bad = taken_u32(c, 1 + C_PACKBAD);
             if (overflow & 4u)
                 c->fused_off = true;
             if (overflow & 2u)
                 c->slab_off = true;
             if (overflow || fused->pack_bad)
                 return FQD_OK;
-            U32 = taken_u32(c, 0);
             break;
         }
-        FQD_TRY(read_ctr32(c, C_BAD, &overflow));
-        U32 = taken_u32(c, 0);
         if (slab_cap && (overflow & 2u)) {
             // a slab was too small (a key with hundreds of copies): once more with exact bucket sizes
             c->slab_off = true;
@@ -277,28 +299,8 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
     if (overflow)
         return FQD_OK;  // some bucket held more distinct keys than the LDS table: sort-based path
     const uint64_t U = U32;
-    HIP_TRY(c, c->urecs.reserve(U * 16 + 16));
     HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
-    HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
-    HIP_TRY(c, c->ufirst.reserve(U * 8 + 16));
-    // fqd_cluster[_keys] announced a Hamming search with nseg segments: the compaction writes its
-    // segment hashes on the way (the records are fixed-length here)
-    fqd::SegHashOut sho;
-    c->seg_hashes_nseg = 0;
-    if (c->seg_hint && U && !getenv("FQD_NO_EARLY_SEG_HASHES")) {
-        HIP_TRY(c, c->seg_hashes.reserve((size_t)c->seg_hint * U * 4 + 16));
-        sho.out = c->seg_hashes.as<uint32_t>();
-        sho.nseg = c->seg_hint;
-        sho.n_unique = (uint32_t)U;
-        sho.planes = sh.planes;
-        sho.kw = kw;
-        sho.len = sh.max_len;
-    }
-    KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_compact(c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets,
-                                          c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(),
-                                          c->ld_tmp_first.as<uint32_t>(), d_ids, c->urecs.as<uint32_t>(),
-                                          c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho));
-    c->seg_hashes_nseg = sho.nseg;
+    c->seg_hashes_nseg = U ? early_nseg : 0;
     unsigned long long counted = n;
     if (d_w) {
         FQD_TRY(zero_ctr64(c, C64_SUM));
@@ -439,6 +441,7 @@ int fqd_create(int device, fqd_ctx **out)
               c->d_ctr32.reserve(C_N32 * 4) == hipSuccess && c->d_ctr64.reserve(C64_N * 8) == hipSuccess &&
               c->d_lut.reserve(256) == hipSuccess &&
               c->d_stats.reserve(FQD_STAT_SLOTS * sizeof(fqd::PairStats)) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_rb, hipEventDisableTiming) == hipSuccess;
     if (ok && hipHostMalloc(&c->h_pin, 256, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         c->h_pin = nullptr;            // read-backs then go through pageable memory
@@ -473,6 +476,8 @@ void fqd_destroy(fqd_ctx *c)
                       &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners, &c->taint, &c->root_taint, &c->gp_a, &c->gp_b, &c->gp_small, &c->gp_cands, &c->seg_tab, &c->ld_seg, &c->kept_lists};
     for (DevBuf *b : bufs)
         b->release();
+    if (c->ev_rb)
+        (void)hipEventDestroy(c->ev_rb);
     if (c->h_pin)
         (void)hipHostFree(c->h_pin);
     for (hipEvent_t e : c->tev)

@@ -150,8 +150,9 @@ struct fqd_ctx {
 
     // stage timers: one event pair per stage, recorded while the work is queued and resolved when
     // fqd_stage_times asks (a stage end is NOT a host synchronisation point)
+    hipEvent_t ev_rb = nullptr;    // marks queued read-backs: the host can wait for THEM while later work runs
     void *h_pin = nullptr;         // 256 pinned host bytes: where counter read-backs land
-    uint32_t h_extra[4] = {0};     // (without pinned memory)
+    uint32_t h_extra[16] = {0};    // (without pinned memory)
     hipEvent_t tev[2 * FQD_T_COUNT] = {nullptr};
     bool tpending[FQD_T_COUNT] = {false};
     bool stage_timing = true;
@@ -260,6 +261,28 @@ int queue_read_u32(fqd_ctx *c, const uint32_t *dev, int slot)
     uint32_t *dst = c->h_pin ? reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + 192) + slot
                              : &c->h_extra[slot];
     HIP_TRY(c, hipMemcpyAsync(dst, dev, 4, hipMemcpyDeviceToHost, c->st));
+    return FQD_OK;
+}
+
+// `count` consecutive device words into slots [slot, slot + count) (16 slots)
+int queue_read_u32n(fqd_ctx *c, const uint32_t *dev, int count, int slot)
+{
+    uint32_t *dst = c->h_pin ? reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + 192) + slot
+                             : &c->h_extra[slot];
+    HIP_TRY(c, hipMemcpyAsync(dst, dev, 4 * (size_t)count, hipMemcpyDeviceToHost, c->st));
+    return FQD_OK;
+}
+
+// Wait for the read-backs queued so far -- not for work queued after this call's event.
+int queued_reads_mark(fqd_ctx *c)
+{
+    HIP_TRY(c, hipEventRecord(c->ev_rb, c->st));
+    return FQD_OK;
+}
+
+int queued_reads_wait(fqd_ctx *c)
+{
+    HIP_TRY(c, hipEventSynchronize(c->ev_rb));
     return FQD_OK;
 }
 

@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(
         return;
     const uint32_t end = unique_incl[b], begin = b ? unique_incl[b - 1] : 0u;
     const uint32_t src = bucket_start[b];
+    const uint32_t n_unique = unique_incl[n_buckets - 1];    // (the host may not know it yet)
     // four rows per lane and step, their loads requested together (a bucket has ~210 unique keys:
     // usually one step)
     const uint32_t cnt = end - begin;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(
             if (sho.nseg) {
                 const uint32_t w[3] = {rec[t].x, rec[t].y, rec[t].z};
                 for (uint32_t sg = 0; sg < sho.nseg; sg++)
-                    sho.out[(size_t)sg * sho.n_unique + begin + j] =
+                    sho.out[(size_t)sg * n_unique + begin + j] =
                         fqd_segment_hash(w, sho.planes, sho.kw, sho.len, sg, sho.nseg);
             }
             urecs[begin + j] = rec[t];

@@ -290,7 +290,7 @@ hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_sta
 // bucket_compact_kernel may write the segment hashes of the search that follows (nseg = 0: no)
 struct SegHashOut {
     uint32_t *out = nullptr;      // [nseg][n_unique]
-    uint32_t nseg = 0, n_unique = 0, planes = 0, kw = 0, len = 0;
+    uint32_t nseg = 0, planes = 0, kw = 0, len = 0;
 };
 hipError_t launch_bucket_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                  const uint32_t *tmp_rec, const uint32_t *tmp_count, const uint32_t *tmp_first,
