@@ -1016,7 +1016,11 @@ int fqd_cluster_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, 
 
 static int cluster_tail(fqd_ctx *c, int max_distance, int metric, int method, fqd_summary *out)
 {
-    FQD_TRY(fqd_find_edges(c, max_distance, metric, 0, 1, nullptr));
+    c->pre_init = c->pre_init_closed = false;
+    c->preinit_method = (method >= 0 && method <= 2 && method != FQD_METHOD_HIGHEST_COUNT && !getenv("FQD_NO_PREINIT")) ? method : -1;
+    const int rc_search = fqd_find_edges(c, max_distance, metric, 0, 1, nullptr);
+    c->preinit_method = -1;
+    FQD_TRY(rc_search);
     // no host round trip between components and dissection; labels are flattened only if read
     FQD_TRY(fqd_api_components_queue(c, method == FQD_METHOD_HIGHEST_COUNT));
     c->stage = ST_LABELS;

@@ -141,6 +141,8 @@ struct fqd_ctx {
     uint64_t n_clusters = 0, roots_seen = 0;
     DevBuf labels, hook_slots;
     bool labels_flat = false;
+    bool pre_init = false, pre_init_closed = false;   // fqd_api_graph_preinit ran for this job (its closed-form part too)
+    int preinit_method = -1;        // >= 0: the search queues fqd_api_graph_preinit(method) behind its read-back
     // stage 5
     uint64_t n_kept = 0, n_listed = 0;          // kept keys; kept keys whose first holder is in the id window
     uint64_t id_lo = 0, id_hi = ~0ull;
@@ -153,6 +155,7 @@ struct fqd_ctx {
     hipEvent_t ev_rb = nullptr;    // marks queued read-backs: the host can wait for THEM while later work runs
     void *h_pin = nullptr;         // 256 pinned host bytes: where counter read-backs land
     uint32_t h_extra[16] = {0};    // (without pinned memory)
+    unsigned long long h_extra64[8] = {0};
     hipEvent_t tev[2 * FQD_T_COUNT] = {nullptr};
     bool tpending[FQD_T_COUNT] = {false};
     bool stage_timing = true;
@@ -292,6 +295,20 @@ uint32_t taken_u32(const fqd_ctx *c, int slot)
                     : c->h_extra[slot];
 }
 
+// 64-bit counters into the first bytes of the pinned buffer, to be taken after queued_reads_wait()
+int queue_read_ctr64(fqd_ctx *c, int idx, int count)
+{
+    void *dst = c->h_pin ? c->h_pin : (void *)c->h_extra64;
+    HIP_TRY(c, hipMemcpyAsync(dst, c->d_ctr64.as<unsigned long long>() + idx, 8 * (size_t)count, hipMemcpyDeviceToHost,
+                              c->st));
+    return FQD_OK;
+}
+
+void taken_ctr64(const fqd_ctx *c, unsigned long long *v, int count)
+{
+    memcpy(v, c->h_pin ? c->h_pin : (const void *)c->h_extra64, 8 * (size_t)count);
+}
+
 int read_ctr64(fqd_ctx *c, int idx, unsigned long long *v, int count = 1)
 {
     void *dst = c->h_pin ? c->h_pin : (void *)v;
@@ -423,5 +440,6 @@ int scan_u32(fqd_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n)
 // helpers shared between the api_*.hip files (defined in the file named)
 int fqd_api_ensure_hashes(fqd_ctx *c);                 // api.hip
 int fqd_api_components_queue(fqd_ctx *c, bool flatten);   // api_graph.hip
+int fqd_api_graph_preinit(fqd_ctx *c, int method);          // api_graph.hip
 extern "C" int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32_t B, bool slabs,
                                        const uint32_t **items_out, const uint32_t **bucket_end_out);   // api_search.hip

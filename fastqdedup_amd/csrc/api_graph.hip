@@ -23,10 +23,12 @@ static int ensure_flat_labels(fqd_ctx *c)
 static int components_queue(fqd_ctx *c, bool flatten)
 {
     const uint64_t U = c->U;
-    HIP_TRY(c, c->labels.reserve(U * 4 + 16));
-    HIP_TRY(c, c->hook_slots.reserve(FQD_HOOK_SLOTS * 64));
-    HIP_TRY(c, hipMemsetAsync(c->hook_slots.p, 0, FQD_HOOK_SLOTS * 64, c->st));
-    HIP_TRY(c, fqd::launch_uf_init(c->labels.as<uint32_t>(), U, c->st));
+    if (!c->pre_init) {                // (else: queued by fqd_api_graph_preinit while the host waited for the edge count)
+        HIP_TRY(c, c->labels.reserve(U * 4 + 16));
+        HIP_TRY(c, c->hook_slots.reserve(FQD_HOOK_SLOTS * 64));
+        HIP_TRY(c, hipMemsetAsync(c->hook_slots.p, 0, FQD_HOOK_SLOTS * 64, c->st));
+        HIP_TRY(c, fqd::launch_uf_init(c->labels.as<uint32_t>(), U, c->st));
+    }
     KTIME(c, FQD_K_UF_UNION, fqd::launch_uf_union(c->labels.as<uint32_t>(), c->edges.as<uint32_t>(), c->E,
                                                   c->hook_slots.as<unsigned long long>(), c->st));
     HIP_TRY(c, fqd::launch_hook_total(c->hook_slots.as<unsigned long long>(), U,
@@ -34,6 +36,34 @@ static int components_queue(fqd_ctx *c, bool flatten)
     c->labels_flat = false;
     if (flatten)
         FQD_TRY(ensure_flat_labels(c));
+    return FQD_OK;
+}
+
+// Everything of stages 4 and 5 that depends on the unique table but not on the edges: parents and hook
+// counters of the components, best / state of the dissection, and for the closed-form directional
+// dissection the root taints and the parents of the count-1 sets. fqd_cluster queues this behind the
+// search's read-back of the edge count, so the GPU has work while the host waits for that number.
+static int graph_preinit(fqd_ctx *c, int method)
+{
+    const uint64_t U = c->U;
+    c->pre_init = c->pre_init_closed = false;
+    if (!U)
+        return FQD_OK;
+    HIP_TRY(c, c->labels.reserve(U * 4 + 16));
+    HIP_TRY(c, c->hook_slots.reserve(FQD_HOOK_SLOTS * 64));
+    HIP_TRY(c, c->best.reserve(U * 4 + 16));
+    HIP_TRY(c, c->state.reserve(U + 16));
+    HIP_TRY(c, hipMemsetAsync(c->hook_slots.p, 0, FQD_HOOK_SLOTS * 64, c->st));
+    HIP_TRY(c, fqd::launch_uf_init(c->labels.as<uint32_t>(), U, c->st));
+    HIP_TRY(c, fqd::launch_dissect_init(c->best.as<uint32_t>(), c->state.as<uint8_t>(), U, c->st));
+    if (method == FQD_METHOD_DIRECTIONAL && c->collapsed && !getenv("FQD_DIRECTIONAL_ROUNDS")) {
+        HIP_TRY(c, c->blocked.reserve(U * 4 + 16));
+        HIP_TRY(c, c->root_taint.reserve(U + 16));
+        HIP_TRY(c, hipMemsetAsync(c->root_taint.p, 0, U, c->st));
+        HIP_TRY(c, fqd::launch_uf_init(c->blocked.as<uint32_t>(), U, c->st));
+        c->pre_init_closed = true;
+    }
+    c->pre_init = true;
     return FQD_OK;
 }
 
@@ -205,7 +235,10 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
     HIP_TRY(c, c->kept.reserve(U + 16));
     HIP_TRY(c, c->kept_u32.reserve(U * 4 + 16));
     HIP_TRY(c, c->kept_scan.reserve(U * 4 + 16));
-    HIP_TRY(c, fqd::launch_dissect_init(c->best.as<uint32_t>(), c->state.as<uint8_t>(), U, c->st));
+    const bool pre = c->pre_init, pre_closed = c->pre_init && c->pre_init_closed;
+    c->pre_init = c->pre_init_closed = false;          // (one job's worth)
+    if (!pre)
+        HIP_TRY(c, fqd::launch_dissect_init(c->best.as<uint32_t>(), c->state.as<uint8_t>(), U, c->st));
     uint32_t *d_changed = c->d_ctr32.as<uint32_t>() + C_CHANGED;
     int list_method = method;      // how list_kept reads the verdicts
     if (method == FQD_METHOD_HIGHEST_COUNT) {
@@ -223,9 +256,11 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
         if (E) {
             if (E >= 0xFFFFFFFFull)
                 return fail(c, FQD_E_VALUE, "more than 2^32 edges");
-            HIP_TRY(c, hipMemsetAsync(c->root_taint.p, 0, U, c->st));
             FQD_TRY(zero_ctr64(c, C64_CANDS));             // (the search's candidate counter, free here)
-            HIP_TRY(c, fqd::launch_uf_init(c->blocked.as<uint32_t>(), U, c->st));
+            if (!pre_closed) {
+                HIP_TRY(c, hipMemsetAsync(c->root_taint.p, 0, U, c->st));
+                HIP_TRY(c, fqd::launch_uf_init(c->blocked.as<uint32_t>(), U, c->st));
+            }
             for (int pass = 1; pass <= 2; pass++)
                 KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_directional_closed(
                           c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(), c->urecs.as<uint32_t>(),
@@ -411,3 +446,4 @@ int fqd_list_kept_except(fqd_ctx *c, const uint32_t *dropped, uint64_t n_dropped
 }  // extern "C"
 
 int fqd_api_components_queue(fqd_ctx *c, bool flatten) { return components_queue(c, flatten); }
+int fqd_api_graph_preinit(fqd_ctx *c, int method) { return graph_preinit(c, method); }

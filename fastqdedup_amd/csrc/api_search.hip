@@ -290,7 +290,16 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
                                c->d_stats.as<fqd::PairStats>(), c->st));
             }
             unsigned long long ctrs[C64_SLAB + 1] = {0};
-            FQD_TRY(read_ctr64(c, 0, ctrs, C64_SLAB + 1));
+            // the counters come back while the GPU sets up what fqd_cluster runs next on the unique
+            // table (nothing of that depends on the edges)
+            FQD_TRY(queue_read_ctr64(c, 0, C64_SLAB + 1));
+            FQD_TRY(queued_reads_mark(c));
+            if (c->preinit_method >= 0) {
+                FQD_TRY(fqd_api_graph_preinit(c, c->preinit_method));
+                c->preinit_method = -1;
+            }
+            FQD_TRY(queued_reads_wait(c));
+            taken_ctr64(c, ctrs, C64_SLAB + 1);
             const unsigned long long now = ctrs[C64_EDGES], cand_need = grouped ? ctrs[C64_CAND_NEED] : 0;
             const bool slab_over = grouped && ctrs[C64_SLAB] != 0;
             if (slab_over) {             // a level-2 slab overflowed: exact bucket sizes from now on
