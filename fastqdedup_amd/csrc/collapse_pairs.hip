@@ -8,8 +8,10 @@
 // LDS-aggregated partition of group.hip / partition.cuh), then one workgroup per bucket runs the
 // pairs through an LDS hash table keyed by the 32-bit hash. A slot is claimed with an LDS
 // compare-and-swap by the first read of a hash, which parks its POSITION; every later read with
-// that hash compares its record with the parked read's record in HBM, word by word (a hash only
-// proposes), and then bumps the slot's count / min position with LDS atomics or probes on. Per
+// that hash has its record compared with the parked read's record in HBM (a hash only proposes;
+// the comparisons of a wave are queued in LDS and done by 64 / Q groups of Q lanes, one uint4 of
+// either record per lane, so that every request is a whole record line), and then bumps the
+// slot's count / min position with LDS atomics or probes on. Per
 // read: 8 bytes through the partition twice and, for a read that is not the first of its key, two
 // record gathers (its own and the parked one, which the reads before it have pulled into L2).
 // bucket_pairs_compact_kernel then gathers one record per unique key into the unique table.
@@ -23,34 +25,6 @@ constexpr uint32_t PD_THREADS = 256;
 constexpr uint32_t PD_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t PD_AHEAD = 4;
 
-// records at positions a and b equal? (q_per_rec uint4 each; padding words are zero). Up to eight
-// uint4 of either record are requested before the first comparison: most comparisons are between
-// copies of one key and end in "equal" -- an early exit saves nothing and a word-by-word loop pays
-// one memory round trip per 16 bytes.
-__device__ __forceinline__ bool same_record(const uint4 *__restrict__ recs4, uint32_t q_per_rec, uint32_t a,
-                                            uint32_t b)
-{
-    const uint4 *ra = recs4 + (size_t)a * q_per_rec, *rb = recs4 + (size_t)b * q_per_rec;
-    uint32_t diff = 0;
-    for (uint32_t q0 = 0; q0 < q_per_rec; q0 += 8) {
-        uint4 x[8], y[8];
-#pragma unroll
-        for (uint32_t q = 0; q < 8; q++) {
-            x[q] = y[q] = make_uint4(0, 0, 0, 0);
-            if (q0 + q < q_per_rec) {
-                x[q] = ra[q0 + q];
-                y[q] = rb[q0 + q];
-            }
-        }
-#pragma unroll
-        for (uint32_t q = 0; q < 8; q++)
-            diff |= (x[q].x ^ y[q].x) | (x[q].y ^ y[q].y) | (x[q].z ^ y[q].z) | (x[q].w ^ y[q].w);
-        if (diff)
-            return false;
-    }
-    return true;
-}
-
 __global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
     const uint2 *__restrict__ items /* (hash, position) */, const uint32_t *__restrict__ bucket_start,
     const uint32_t *__restrict__ bucket_end /* NULL, or slab mode: where each bucket's cursor stopped */,
@@ -61,7 +35,12 @@ __global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
 {
     __shared__ uint32_t s_tag[PD_SLOTS], s_rep[PD_SLOTS], s_cnt[PD_SLOTS], s_min[PD_SLOTS];
     __shared__ uint32_t s_wave_tot[PD_THREADS / 64];
+    // comparisons queued by a wave in a round: (position, parked position) in, "differs" out
+    __shared__ uint32_t s_qa[PD_THREADS / 64][64 * PD_AHEAD], s_qb[PD_THREADS / 64][64 * PD_AHEAD];
+    __shared__ uint8_t s_qdiff[PD_THREADS / 64][64 * PD_AHEAD];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t groups = 64u / q_per_rec;            // comparisons a wave does at once (q_per_rec <= 64)
+    const uint32_t gl = lane / q_per_rec, ql = lane - gl * q_per_rec;
     const uint32_t b = blockIdx.x;
     const uint32_t lo = bucket_start[b];
     uint32_t hi = bucket_start[b + 1];
@@ -121,12 +100,51 @@ __global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
                 }
             }
             __syncthreads();
+            // queue this wave's comparisons ...
+            uint32_t qn = 0, qi[PD_AHEAD];
+#pragma unroll
+            for (uint32_t k = 0; k < PD_AHEAD; k++) {
+                const unsigned long long m = __ballot(pending[k]);
+                qi[k] = qn + __popcll(m & fqd_lanemask_lt());
+                if (pending[k]) {
+                    s_qa[wave][qi[k]] = it[k].y;
+                    s_qb[wave][qi[k]] = s_rep[slot[k]];
+                }
+                qn += __popcll(m);
+            }
+            __syncthreads();
+            // ... do them with q_per_rec lanes each, four rounds of loads in flight together ...
+            for (uint32_t base = 0; base < qn; base += 4 * groups) {
+                uint4 xa[4], xb[4];
+                bool valid[4];
+#pragma unroll
+                for (uint32_t t = 0; t < 4; t++) {
+                    const uint32_t e = base + t * groups + gl;
+                    valid[t] = gl < groups && e < qn;
+                    xa[t] = xb[t] = make_uint4(0, 0, 0, 0);
+                    if (valid[t]) {
+                        xa[t] = recs4[(size_t)s_qa[wave][e] * q_per_rec + ql];
+                        xb[t] = recs4[(size_t)s_qb[wave][e] * q_per_rec + ql];
+                    }
+                }
+#pragma unroll
+                for (uint32_t t = 0; t < 4; t++) {
+                    const bool diff = valid[t] && ((xa[t].x ^ xb[t].x) | (xa[t].y ^ xb[t].y) | (xa[t].z ^ xb[t].z) |
+                                                   (xa[t].w ^ xb[t].w)) != 0;
+                    const unsigned long long m = __ballot(diff);
+                    if (valid[t] && ql == 0)      // the group's lanes are [lane, lane + q_per_rec)
+                        s_qdiff[wave][base + t * groups + gl] =
+                            (uint8_t)(((m >> lane) & ((q_per_rec < 64 ? (1ull << q_per_rec) : 0ull) - 1ull)) != 0);
+                }
+            }
+            __syncthreads();
+            // ... and act on the answers
             any = false;
 #pragma unroll
             for (uint32_t k = 0; k < PD_AHEAD; k++) {
                 if (!pending[k])
                     continue;
-                if (same_record(recs4, q_per_rec, it[k].y, s_rep[slot[k]])) {
+                if (!s_qdiff[wave][qi[k]]) {
                     atomicAdd(&s_cnt[slot[k]], w[k]);
                     atomicMin(&s_min[slot[k]], it[k].y);
                     pending[k] = false;
