@@ -12,6 +12,7 @@
 // two histogram passes and two scatter passes, every store part of a contiguous run (0.2 ms).
 // What the sort gave for free -- equal hashes adjacent -- costs lambda/2 LDS hash compares per
 // key here (lambda = keys per bucket), cheap next to a fourth pass over HBM.
+#include <cstdlib>
 #include "fqd_internal.h"
 #include "partition.cuh"
 
@@ -343,7 +344,12 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
 // is the capacity of ONE list): fetch both records, count mismatches,
 // keep the pair only in the pass of the first segment it agrees on; hits leave through an LDS
 // edge buffer. Tens of thousands of independent record fetches are in flight at once.
-template <int K>
+// COOP (fixed-length records longer than one uint4): the 64 candidates of a wave are verified by
+// 64 / Q groups of Q lanes, one uint4 of either record per lane -- every request a whole record line
+// instead of 16 bytes of it (one thread per candidate: 1.46 ms per launch at config 5). The XOR of
+// the two records is staged in LDS, the group's lanes count the mismatches of the 32-base words
+// between them and note which earlier segments disagree; lane 0 of the group adds that up.
+template <int K, bool COOP>
 __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
     const uint2 *__restrict__ cands, const unsigned long long *__restrict__ cand_count, uint64_t cand_cap,
     const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t d, uint32_t seg,
@@ -352,7 +358,13 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
 {
     __shared__ uint32_t s_edges[2 * GP_ECAP];
     __shared__ uint32_t s_ctl[4];
+    __shared__ uint32_t s_x[COOP ? GP_THREADS / 64 : 1][COOP ? 256 : 1];        // XOR dwords of the groups' records
+    __shared__ uint32_t s_part[COOP ? GP_THREADS / 64 : 1][COOP ? 64 : 1][2];   // per lane: mismatches, disagreeing segments
+    __shared__ uint8_t s_hit[COOP ? GP_THREADS / 64 : 1][COOP ? 64 : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t Q = sh.stride / 4, groups = COOP ? 64u / Q : 1u;
+    const uint32_t gl = COOP ? lane / Q : 0u, ql = COOP ? lane - gl * Q : 0u;
     // blocks l, l + GP_LISTS, ... sweep list l
     const uint32_t list = blockIdx.x % GP_LISTS, part = blockIdx.x / GP_LISTS, parts = gridDim.x / GP_LISTS;
     const unsigned long long filled = cand_count[(size_t)list * 8];
@@ -372,7 +384,70 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
         if (idx < total) {
             pr = cands[idx];
             n_pairs++;
-            hit = gp_verify<K>(urecs, ulens, sh, d, seg, nseg, pr.x, pr.y);
+            if (!COOP)
+                hit = gp_verify<K>(urecs, ulens, sh, d, seg, nseg, pr.x, pr.y);
+        }
+        if (COOP) {
+            const uint4 *recs4 = reinterpret_cast<const uint4 *>(urecs);
+            const uint32_t W = sh.words, len = sh.max_len;
+            const unsigned long long have = __ballot(idx < total);
+            for (uint32_t c0 = 0; c0 < 64 && (have >> c0); c0 += 2 * groups) {
+                // two rounds of groups: their four loads per lane are requested together
+                uint4 xs[2];
+                bool on[2];
+#pragma unroll
+                for (uint32_t t = 0; t < 2; t++) {
+                    const uint32_t cnd = c0 + t * groups + gl;
+                    on[t] = gl < groups && cnd < 64 && ((have >> cnd) & 1ull);
+                    const uint32_t pu = __shfl(pr.x, cnd & 63u), pv = __shfl(pr.y, cnd & 63u);
+                    xs[t] = make_uint4(0, 0, 0, 0);
+                    if (on[t]) {
+                        const uint4 a = recs4[(size_t)pu * Q + ql], b = recs4[(size_t)pv * Q + ql];
+                        xs[t] = make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
+                    }
+                }
+#pragma unroll
+                for (uint32_t t = 0; t < 2; t++) {
+                    const uint32_t cnd = c0 + t * groups + gl;
+                    __builtin_amdgcn_wave_barrier();
+                    if (gl < groups)
+                        *reinterpret_cast<uint4 *>(&s_x[wave][(gl * Q + ql) * 4]) = xs[t];
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t dist = 0, seg_mis = 0;
+                    if (on[t]) {
+                        const uint32_t *x = &s_x[wave][gl * Q * 4];
+                        for (uint32_t w = ql; w < W; w += Q) {
+                            uint32_t dw = 0;
+#pragma unroll
+                            for (int k = 0; k < K; k++)
+                                dw |= x[w * K + k];
+                            dist += __popc(dw);
+                            for (uint32_t s2 = 0; s2 < seg; s2++) {
+                                uint32_t slo, shi;
+                                fqd_segment(len, s2, nseg, slo, shi);
+                                if (dw & fqd_range_mask(w, slo, shi))
+                                    seg_mis |= 1u << s2;
+                            }
+                        }
+                    }
+                    s_part[wave][lane][0] = dist;
+                    s_part[wave][lane][1] = seg_mis;
+                    __builtin_amdgcn_wave_barrier();
+                    if (on[t] && ql == 0) {
+                        uint32_t dsum = 0, mis = 0;
+                        for (uint32_t q = 0; q < Q; q++) {
+                            dsum += s_part[wave][lane + q][0];
+                            mis |= s_part[wave][lane + q][1];
+                        }
+                        // a neighbour, reported in the pass of the FIRST segment the pair agrees on: all
+                        // earlier segments must disagree (an empty segment agrees trivially, as in gp_verify)
+                        const uint32_t earlier = seg >= 32 ? 0xFFFFFFFFu : (1u << seg) - 1u;
+                        s_hit[wave][cnd] = (dsum <= d && (mis & earlier) == earlier) ? 1 : 0;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            hit = idx < total && s_hit[wave][lane] != 0;
         }
         const unsigned long long mask = __ballot(hit);
         if (mask) {
@@ -538,11 +613,22 @@ hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long l
                                     uint32_t nseg, uint32_t *edges, unsigned long long *edge_count, uint64_t edge_cap,
                                     unsigned long long *cand_need, PairStats *stats, hipStream_t st)
 {
+    // several lanes per candidate for fixed-length records of four uint4 and more (48-byte records,
+    // config 2: 0.119 ms against 0.092 one thread per candidate -- most candidates there are no
+    // neighbours and are out after one word; 128-byte records, config 5: 0.44 against 1.46 ms), and at
+    // most 32 segments: the per-lane notes are a bit mask
+    const bool coop = !sh.ragged && sh.stride >= 16 && sh.stride <= 256 && !(sh.stride & 3u) && nseg <= 32 &&
+                      !getenv("FQD_VERIFY_NO_COOP");
 #define FQD_GP_CASE(KK)                                                                                              \
     case KK:                                                                                                         \
-        verify_candidates_kernel<KK><<<2048, GP_THREADS, 0, st>>>(reinterpret_cast<const uint2 *>(cands), cand_count, \
-                                                                  cand_cap / GP_LISTS, urecs, ulens, sh, d, seg, nseg, edges, \
-                                                                  edge_count, edge_cap, cand_need, stats);           \
+        if (coop)                                                                                                    \
+            verify_candidates_kernel<KK, true><<<2048, GP_THREADS, 0, st>>>(                                         \
+                reinterpret_cast<const uint2 *>(cands), cand_count, cand_cap / GP_LISTS, urecs, ulens, sh, d, seg, nseg,  \
+                edges, edge_count, edge_cap, cand_need, stats);                                                      \
+        else                                                                                                         \
+            verify_candidates_kernel<KK, false><<<2048, GP_THREADS, 0, st>>>(                                        \
+                reinterpret_cast<const uint2 *>(cands), cand_count, cand_cap / GP_LISTS, urecs, ulens, sh, d, seg, nseg,  \
+                edges, edge_count, edge_cap, cand_need, stats);                                                      \
         break;
     switch (sh.planes) {
         FQD_GP_CASE(1)

@@ -585,11 +585,13 @@ def test_bucket_shards_union_to_the_whole_search(F, oracle, edit, d):
     assert np.array_equal(kept, want["kept_read_ids"])
 
 
-@pytest.mark.parametrize("bits,d,L", [(None, 1, 32), ("4", 2, 36), ("11", 1, 100), ("1", 3, 48)])
+@pytest.mark.parametrize("bits,d,L", [(None, 1, 32), ("4", 2, 36), ("11", 1, 100), ("1", 3, 48), (None, 2, 160),
+                                      ("6", 2, 300), (None, 3, 200)])
 def test_grouped_search_equals_sorted_search(F, oracle, monkeypatch, bits, d, L):
     """The sort-free search pass (group.hip: partition + one wave per bucket) finds exactly the
     edges of the radix-sort pass -- with roomy buckets, with buckets far larger than the LDS slice
-    (few bucket bits), single-level and two-level partitions -- and the oracle's clusters."""
+    (few bucket bits), single-level and two-level partitions, candidates verified by one thread or
+    (records of 64 bytes and more) by several lanes each -- and the oracle's clusters."""
     from fastqdedup_amd.synth import fixed_offsets, synth_keys
     n = 60_000
     raw = synth_keys(n, L, 8, 41, sub_rate=6e-3, n_rate=5e-4).reshape(-1)
