@@ -370,10 +370,23 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
     HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
     HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
     HIP_TRY(c, c->ufirst.reserve(U * 8 + 16));
+    // fqd_cluster[_keys] announced a Hamming search with nseg segments: the compaction writes its
+    // segment hashes on the way (records whose uint4 count divides 64: their lanes sit side by side)
+    fqd::SegHashOut sho;
+    const uint32_t q_per_rec = sh.stride / 4;
+    if (c->seg_hint && U && q_per_rec <= 64 && !(q_per_rec & (q_per_rec - 1)) && !getenv("FQD_NO_EARLY_SEG_HASHES")) {
+        HIP_TRY(c, c->seg_hashes.reserve((size_t)c->seg_hint * U * 4 + 16));
+        sho.out = c->seg_hashes.as<uint32_t>();
+        sho.nseg = c->seg_hint;
+        sho.planes = sh.planes;
+        sho.kw = sh.planes * sh.words;
+        sho.len = sh.max_len;
+    }
     KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_pairs_compact(
               c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets, c->ld_tmp_rec.as<uint32_t>(),
               c->ld_tmp_count.as<uint32_t>(), c->ld_tmp_first.as<uint32_t>(), c->recs.as<uint32_t>(), sh.stride, d_ids,
-              c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st));
+              c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho));
+    c->seg_hashes_nseg = sho.nseg;
     unsigned long long counted = n;
     if (d_w) {
         FQD_TRY(zero_ctr64(c, C64_SUM));

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
     const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ unique_incl /* inclusive scan */,
     uint32_t n_buckets, const uint32_t *__restrict__ tmp_rep, const uint32_t *__restrict__ tmp_count,
     const uint32_t *__restrict__ tmp_first, const uint4 *__restrict__ recs4, uint32_t q_per_rec, IdSource read_ids,
-    uint4 *__restrict__ urecs4, uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst)
+    uint4 *__restrict__ urecs4, uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst,
+    fqd::SegHashOut sho /* nseg != 0 (q_per_rec a power of two): also the segment hashes of the search that follows */)
 {
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= n_buckets)
@@ -211,9 +212,38 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
         ucounts[begin + j] = tmp_count[src + j];
         ufirst[begin + j] = read_ids.at(tmp_first[src + j]);
     }
+    const uint32_t n_unique = unique_incl[n_buckets - 1];
     for (uint32_t x = fqd_lane(); x < cnt * q_per_rec; x += 64) {
         const uint32_t j = x / q_per_rec, q = x - j * q_per_rec;
-        urecs4[(size_t)(begin + j) * q_per_rec + q] = recs4[(size_t)tmp_rep[src + j] * q_per_rec + q];
+        const uint4 v = recs4[(size_t)tmp_rep[src + j] * q_per_rec + q];
+        urecs4[(size_t)(begin + j) * q_per_rec + q] = v;
+        if (sho.nseg) {
+            // as segment_hashes_kernel (edges.hip): the record's q_per_rec lanes sit side by side in
+            // the wave (q_per_rec divides 64), each sums its four words' share of a segment
+            const uint32_t word[4] = {v.x, v.y, v.z, v.w};
+            for (uint32_t sg = 0; sg < sho.nseg; sg++) {
+                uint32_t lo, hi;
+                fqd_segment(sho.len, sg, sho.nseg, lo, hi);
+                uint32_t part = 0;
+#pragma unroll
+                for (uint32_t e = 0; e < 4; e++) {
+                    const uint32_t jw = q * 4 + e;             // word index in the record
+                    if (jw < sho.kw) {
+                        const uint32_t m = fqd_range_mask(jw / sho.planes, lo, hi);
+                        if (m)
+                            part += fqd_mix32((word[e] & m) + (jw + 1u) * 0x9E3779B1u);
+                    }
+                }
+                for (uint32_t off = 1; off < q_per_rec; off <<= 1) {
+                    const uint32_t other = __shfl_down(part, off);
+                    if (q + off < q_per_rec)
+                        part += other;
+                }
+                if (q == 0)
+                    sho.out[(size_t)sg * n_unique + begin + j] =
+                        fqd_mix32(part + fqd_mix32(sho.len * 0x9E3779B1u + sg * 0x85EBCA77u + 0x165667B1u));
+            }
+        }
     }
 }
 
@@ -238,14 +268,17 @@ hipError_t launch_bucket_pairs_dedupe(const uint32_t *items, const uint32_t *buc
 hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                        const uint32_t *tmp_rep, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                        const uint32_t *recs, uint32_t stride_words, IdSource read_ids, uint32_t *urecs,
-                                       uint32_t *ucounts, uint64_t *ufirst, hipStream_t st)
+                                       uint32_t *ucounts, uint64_t *ufirst, hipStream_t st, SegHashOut seg_hashes)
 {
     if (!n_buckets)
         return hipSuccess;
+    const uint32_t q = stride_words / 4;
+    if (seg_hashes.nseg && (q == 0 || q > 64 || (q & (q - 1))))
+        return hipErrorInvalidValue;       // the caller asks only for power-of-two records
     const uint64_t threads = (uint64_t)n_buckets * 64;
     bucket_pairs_compact_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
         bucket_start, unique_incl, n_buckets, tmp_rep, tmp_count, tmp_first, reinterpret_cast<const uint4 *>(recs),
-        stride_words / 4, read_ids, reinterpret_cast<uint4 *>(urecs), ucounts, ufirst);
+        stride_words / 4, read_ids, reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes);
     return hipGetLastError();
 }
 

@@ -270,6 +270,11 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
 hipError_t launch_slab_tile_starts(const uint32_t *seg_start, const uint32_t *seg_end, uint32_t n_seg,
                                    uint32_t *tile_start, hipStream_t st);
 uint32_t part_tile_size();
+// bucket_compact_kernel may write the segment hashes of the search that follows (nseg = 0: no)
+struct SegHashOut {
+    uint32_t *out = nullptr;      // [nseg][n_unique]
+    uint32_t nseg = 0, planes = 0, kw = 0, len = 0;
+};
 // collapse_pairs.hip -- sort-free collapse for records longer than one uint4
 hipError_t launch_bucket_pairs_dedupe(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                       uint32_t n_buckets, const uint32_t *recs, uint32_t stride_words,
@@ -278,7 +283,8 @@ hipError_t launch_bucket_pairs_dedupe(const uint32_t *items, const uint32_t *buc
 hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                        const uint32_t *tmp_rep, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                        const uint32_t *recs, uint32_t stride_words, IdSource read_ids, uint32_t *urecs,
-                                       uint32_t *ucounts, uint64_t *ufirst, hipStream_t st);
+                                       uint32_t *ucounts, uint64_t *ufirst, hipStream_t st,
+                                       SegHashOut seg_hashes = SegHashOut());
 hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                 hipStream_t st);
 hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
@@ -287,11 +293,6 @@ hipError_t launch_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket
 hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                 uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec, uint32_t *tmp_count,
                                 uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);
-// bucket_compact_kernel may write the segment hashes of the search that follows (nseg = 0: no)
-struct SegHashOut {
-    uint32_t *out = nullptr;      // [nseg][n_unique]
-    uint32_t nseg = 0, planes = 0, kw = 0, len = 0;
-};
 hipError_t launch_bucket_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                  const uint32_t *tmp_rec, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                  IdSource read_ids, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
