@@ -293,13 +293,36 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
         // edges become (higher rank, lower rank); union-find and the other methods do not care
         HIP_TRY(c, fqd::launch_orient_edges(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
                                             c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, c->st));
+        // After the first two sweeps only the edges that can still matter are swept (their list is
+        // made while the host waits for the "anything changed?" flag of those sweeps).
+        const uint32_t *sweep_edges = c->edges.as<uint32_t>();
+        uint64_t sweep_E = E;
+        const bool shrink = E >= 65536 && !getenv("FQD_ADJACENCY_ALL_EDGES");
         for (uint64_t round = 1; round <= U + 2; round += 2) {
             FQD_TRY(zero_ctr32(c, C_CHANGED));
             for (uint32_t k = 0; k < 2; k++)
-                KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_adjacency_round(c->edges.as<uint32_t>(), E, U, c->state.as<uint8_t>(),
+                KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_adjacency_round(sweep_edges, sweep_E, U, c->state.as<uint8_t>(),
                                                    c->blocked.as<uint32_t>(), (uint32_t)(round + k), d_changed, c->st));
             uint32_t changed = 0;
-            FQD_TRY(read_ctr32(c, C_CHANGED, &changed));
+            if (round == 1 && shrink) {
+                HIP_TRY(c, c->taint.reserve(E * 8 + 16));        // here: the live edges
+                FQD_TRY(zero_ctr64(c, C64_CANDS));               // (the search's candidate counter, free here)
+                FQD_TRY(queue_read_u32(c, c->d_ctr32.as<uint32_t>() + C_CHANGED, 0));
+                FQD_TRY(queued_reads_mark(c));
+                HIP_TRY(c, fqd::launch_adjacency_live_edges(c->edges.as<uint32_t>(), E, c->state.as<uint8_t>(),
+                                                            c->taint.as<uint32_t>(),
+                                                            c->d_ctr64.as<unsigned long long>() + C64_CANDS, c->st));
+                FQD_TRY(queued_reads_wait(c));
+                changed = taken_u32(c, 0);
+                if (changed) {
+                    unsigned long long live = 0;
+                    FQD_TRY(read_ctr64(c, C64_CANDS, &live));
+                    sweep_edges = c->taint.as<uint32_t>();
+                    sweep_E = live;
+                }
+            } else {
+                FQD_TRY(read_ctr32(c, C_CHANGED, &changed));
+            }
             if (!changed)
                 break;
         }

@@ -415,6 +415,8 @@ hipError_t launch_directional_round(const uint32_t *edges, uint64_t E, const uin
                                     hipStream_t st);
 hipError_t launch_orient_edges(uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
                                const uint32_t *ulens, KeyShape sh, hipStream_t st);
+hipError_t launch_adjacency_live_edges(const uint32_t *edges, uint64_t E, const uint8_t *state, uint32_t *live,
+                                       unsigned long long *live_count, hipStream_t st);
 hipError_t launch_adjacency_round(const uint32_t *edges, uint64_t E, uint64_t U, uint8_t *state, uint32_t *blocked,
                                   uint32_t round, uint32_t *changed, hipStream_t st);
 hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t *best, const uint8_t *state,

@@ -388,6 +388,41 @@ __global__ void adjacency_edges_kernel(const uint32_t *__restrict__ edges, uint6
         *changed = 1;
 }
 
+// The edges that can still matter after some sweeps: the lower end undecided, the higher end not
+// dropped. (Every sweep over ALL edges costs two random state reads per edge; after the first two
+// sweeps a few percent of the edges are left.) One list reservation per workgroup.
+__global__ __launch_bounds__(256) void adjacency_live_edges_kernel(const uint32_t *__restrict__ edges, uint64_t E,
+                                                                   const uint8_t *__restrict__ state,
+                                                                   uint32_t *__restrict__ live,
+                                                                   unsigned long long *__restrict__ live_count)
+{
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0)
+        s_n = 0;
+    __syncthreads();
+    uint2 uv[4];
+    uint32_t rank[4];
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++) {
+        const uint64_t e = ((uint64_t)blockIdx.x * 4 + t) * blockDim.x + threadIdx.x;
+        uv[t] = e < E ? reinterpret_cast<const uint2 *>(edges)[e] : make_uint2(0, 0);
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++) {
+        rank[t] = 0xFFFFFFFFu;
+        if (uv[t].x != uv[t].y && state[uv[t].y] == 0 && state[uv[t].x] != 2)
+            rank[t] = atomicAdd(&s_n, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n)
+        s_base = (uint32_t)atomicAdd(live_count, (unsigned long long)s_n);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++)
+        if (rank[t] != 0xFFFFFFFFu)
+            reinterpret_cast<uint2 *>(live)[s_base + rank[t]] = uv[t];
+}
+
 __global__ void adjacency_nodes_kernel(uint64_t U, uint8_t *state, const uint32_t *__restrict__ blocked,
                                        uint32_t round, uint32_t *changed)
 {
@@ -953,6 +988,14 @@ hipError_t launch_orient_edges(uint32_t *edges, uint64_t E, const uint32_t *ucou
 {
     if (E)
         orient_edges_kernel<<<grid_for(E), 256, 0, st>>>(edges, E, ucounts, urecs, ulens, sh);
+    return hipGetLastError();
+}
+
+hipError_t launch_adjacency_live_edges(const uint32_t *edges, uint64_t E, const uint8_t *state, uint32_t *live,
+                                       unsigned long long *live_count, hipStream_t st)
+{
+    if (E)
+        adjacency_live_edges_kernel<<<(unsigned)((E + 1023) / 1024), 256, 0, st>>>(edges, E, state, live, live_count);
     return hipGetLastError();
 }
 
