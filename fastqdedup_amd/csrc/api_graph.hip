@@ -252,6 +252,7 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
         // (fqd_import_unique) takes the relaxation rounds below.
         HIP_TRY(c, c->blocked.reserve(U * 4 + 16));   // here: union-find over the count-1 keys
         HIP_TRY(c, c->taint.reserve(E * 4 + 16));       // here: the edges between count-1 keys (edge indices)
+        HIP_TRY(c, c->stage_a.reserve(E * 8 + 16));     // ... and the roots of their ends
         HIP_TRY(c, c->root_taint.reserve(U + 16));
         if (E) {
             if (E >= 0xFFFFFFFFull)
@@ -266,7 +267,7 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
                           c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(), c->urecs.as<uint32_t>(),
                           c->ulens.as<uint32_t>(), sh, c->blocked.as<uint32_t>(), c->state.as<uint8_t>(),
                           c->taint.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_CANDS,
-                          c->root_taint.as<uint8_t>(), c->best.as<uint32_t>(), pass, c->st));
+                          c->root_taint.as<uint8_t>(), c->best.as<uint32_t>(), pass, c->st, c->stage_a.as<uint32_t>()));
             list_method = 3;
         }
     } else if (method == FQD_METHOD_DIRECTIONAL) {

@@ -429,7 +429,7 @@ hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t 
 hipError_t launch_directional_closed(const uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
                                      const uint32_t *ulens, KeyShape sh, uint32_t *parent1, uint8_t *state,
                                      uint32_t *list11, unsigned long long *list11_count, uint8_t *root_taint,
-                                     uint32_t *best, int pass, hipStream_t st);
+                                     uint32_t *best, int pass, hipStream_t st, uint32_t *roots /* 2 E words */);
 hipError_t launch_gather_kept(const uint32_t *kept_u32, const uint32_t *kept_scan, const uint64_t *ufirst,
                               uint64_t U, uint64_t *out, hipStream_t st);
 

@@ -311,18 +311,19 @@ __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *
                 (uint32_t)(((uint64_t)blockIdx.x * DE_EPT + t) * blockDim.x + threadIdx.x);
 }
 
-// Pass 2 (after every union of pass 1), over the edges between count-1 keys only: each end reports
-// its taint and its key to the root of its set and is marked (state bit 8) as a member of a set of
-// several keys. A count-1 key without such an edge is a set of its own, and the state byte alone is
-// then the verdict of EVERY key: 0 kept, 2 dropped (count >= 2 with an in-arc), 3 dropped (count 1
-// next to a bigger key), bit 8: ask the root.
+// Pass 2 (after every union of pass 1), over the edges between count-1 keys only, in two launches.
+// 2a: each end finds the root of its set (remembered for 2b), passes its taint on to it and is marked
+// (state bit 8) as a member of a set of several keys. 2b: the ends of UNTAINTED sets report their
+// key to the root (CAS-max by key: a comparison of two whole keys per try) -- a tainted set is
+// dropped whatever its largest key is, and most sets with edges are tainted. A count-1 key without
+// such an edge is a set of its own, and the state byte alone is then the verdict of EVERY key: 0
+// kept, 2 dropped (count >= 2 with an in-arc), 3 dropped (count 1 next to a bigger key), bit 8: ask
+// the root.
 __global__ void directional_roots_kernel(const uint32_t *__restrict__ edges,
                                          const uint32_t *__restrict__ list11,
                                          const unsigned long long *__restrict__ list11_count,
-                                         const uint32_t *__restrict__ ucounts, const uint32_t *__restrict__ urecs,
-                                         const uint32_t *__restrict__ ulens, KeyShape sh,
                                          const uint32_t *__restrict__ parent1, uint8_t *state,
-                                         uint8_t *root_taint, uint32_t *best)
+                                         uint8_t *root_taint, uint32_t *__restrict__ roots /* 2 per listed edge */)
 {
     const uint64_t n = *list11_count;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -338,12 +339,33 @@ __global__ void directional_roots_kernel(const uint32_t *__restrict__ edges,
                 r = pr;
                 pr = parent1[r];
             }
+            roots[2 * i + k] = r;
             const uint8_t sx = state[x];
             if ((sx & 7) == 3)
                 root_taint[r] = 1;
             if (!(sx & 8))
                 state[x] = sx | 8;     // member of a set of several count-1 keys: its verdict is its root's
                                        // (every writer of this byte in this launch writes this same value)
+        }
+    }
+}
+
+__global__ void directional_best_kernel(const uint32_t *__restrict__ edges, const uint32_t *__restrict__ list11,
+                                        const unsigned long long *__restrict__ list11_count,
+                                        const uint32_t *__restrict__ ucounts, const uint32_t *__restrict__ urecs,
+                                        const uint32_t *__restrict__ ulens, KeyShape sh,
+                                        const uint32_t *__restrict__ roots, const uint8_t *__restrict__ root_taint,
+                                        uint32_t *best)
+{
+    const uint64_t n = *list11_count;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t e = list11[i];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t r = roots[2 * i + k];
+            if (root_taint[r])
+                continue;
+            const uint32_t x = edges[2 * e + k];
             if (r != x)
                 raise_best(best, r, x, ucounts, urecs, ulens, sh);
         }
@@ -970,16 +992,20 @@ hipError_t launch_directional_round(const uint32_t *edges, uint64_t E, const uin
 hipError_t launch_directional_closed(const uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
                                      const uint32_t *ulens, KeyShape sh, uint32_t *parent1, uint8_t *state,
                                      uint32_t *list11, unsigned long long *list11_count, uint8_t *root_taint,
-                                     uint32_t *best, int pass, hipStream_t st)
+                                     uint32_t *best, int pass, hipStream_t st, uint32_t *roots)
 {
     if (!E)
         return hipSuccess;
-    if (pass == 1)
+    const unsigned list_grid = (unsigned)std::min<uint64_t>(grid_for(E), 8192);   // (the list's length is on the device)
+    if (pass == 1) {
         directional_edges_kernel<<<(unsigned)((E + 256 * DE_EPT - 1) / (256 * DE_EPT)), 256, 0, st>>>(
             edges, E, ucounts, parent1, state, list11, list11_count);
-    else
-        directional_roots_kernel<<<(unsigned)std::min<uint64_t>(grid_for(E), 1024), 256, 0, st>>>(
-            edges, list11, list11_count, ucounts, urecs, ulens, sh, parent1, state, root_taint, best);
+    } else {
+        directional_roots_kernel<<<list_grid, 256, 0, st>>>(edges, list11, list11_count, parent1, state, root_taint,
+                                                            roots);
+        directional_best_kernel<<<list_grid, 256, 0, st>>>(edges, list11, list11_count, ucounts, urecs, ulens, sh, roots,
+                                                           root_taint, best);
+    }
     return hipGetLastError();
 }
 
