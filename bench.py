@@ -43,13 +43,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def cpu_baseline(ctx, wl, sample_reads: int):
     """The reference CPU path (oracle/_ref: the reference's own trie + distance
     extensions, driven as deduplicate_cluster drives them) on a bounded sample of
-    the same workload; falls back to the oracle's C port when _ref is absent."""
+    the same workload; falls back to the oracle's C port when _ref is absent.
+
+    Parity gate: after the CPU clock has stopped, the HIP path clusters the
+    very same sample and its kept read ids must equal the CPU path's kept keys mapped through
+    their first holders (reference __init__.py:201-206), its counters the CPU path's counters.
+    `parity` reports the outcome; main() fails the run when it is false."""
+    import numpy as np
+    import fastqdedup_amd as F
     from oracle import oracle as O
     n = min(sample_reads, wl["n"])
     dev = torch.empty(n * wl["L"], dtype=torch.uint8, device="cuda:0")
     ctx.synth_keys(dev, n, 0, n, wl["L"], wl["umi"], wl["seed"])
     host = dev.cpu().numpy()
-    del dev
     sample = (f"first {n} reads of the same generator (n_total={n}, L={wl['L']}, umi={wl['umi']}, "
               f"seed={wl['seed']}), d={wl['d']}, {'edit' if wl['edit'] else 'hamming'}, {wl['method']}")
     cores = 1
@@ -58,28 +64,46 @@ def cpu_baseline(ctx, wl, sample_reads: int):
         strs = [s.decode() for s in host.view(f"S{wl['L']}")]
         out = ref_driver.run_reference_path(strs, wl["d"], wl["edit"], wl["method"])
         secs = out["seconds"]
-        return {"value": n / secs["total"], "unit": "reads/s", "cores": cores, "kind": "reference",
+        first = {}
+        for i, s in enumerate(strs):
+            first.setdefault(s, i)
+        cpu_kept = np.sort(np.fromiter((first[k] for k in out["kept_keys"]), dtype=np.uint64,
+                                       count=len(out["kept_keys"])))
+        del strs, first
+        base = {"value": n / secs["total"], "unit": "reads/s", "cores": cores, "kind": "reference",
                 "sample": sample, "seconds": {k: round(v, 3) for k, v in secs.items()},
                 "n_unique": out["n_unique"], "n_clusters": out["n_clusters"], "n_kept": len(out["kept_keys"]),
                 "cpu_count": os.cpu_count(),
                 "note": "reference C extensions (Trie, within_distance) built from the reference sources; "
                         "its Python dissection loops restated in oracle/ref_driver.py"}
-    from fastqdedup_amd.synth import fixed_offsets
-    out = O.dedup(host, fixed_offsets(n, wl["L"]), max_distance=wl["d"], use_edit_distance=wl["edit"],
-                  method=wl["method"])
-    total = sum(out["stage_seconds"].values())
-    return {"value": n / total, "unit": "reads/s", "cores": cores, "kind": "port", "sample": sample,
-            "seconds": {k: round(v, 3) for k, v in out["stage_seconds"].items()},
-            "n_unique": out["n_unique"], "n_clusters": out["n_clusters"],
-            "n_kept": int(len(out["kept_read_ids"])), "cpu_count": os.cpu_count()}
+    else:
+        from fastqdedup_amd.synth import fixed_offsets
+        out = O.dedup(host, fixed_offsets(n, wl["L"]), max_distance=wl["d"], use_edit_distance=wl["edit"],
+                      method=wl["method"])
+        total = sum(out["stage_seconds"].values())
+        cpu_kept = out["kept_read_ids"]
+        base = {"value": n / total, "unit": "reads/s", "cores": cores, "kind": "port", "sample": sample,
+                "seconds": {k: round(v, 3) for k, v in out["stage_seconds"].items()},
+                "n_unique": out["n_unique"], "n_clusters": out["n_clusters"],
+                "n_kept": int(len(out["kept_read_ids"])), "cpu_count": os.cpu_count()}
+    # ---- parity gate: the HIP path on the same sample, after the CPU clock stopped ----
+    got = F.cluster_keys(dev, key_len=wl["L"], max_distance=wl["d"], use_edit_distance=wl["edit"],
+                         method=wl["method"], context=ctx)
+    base["parity"] = bool(got.n_unique == base["n_unique"] and got.n_clusters == base["n_clusters"]
+                          and got.n_kept == base["n_kept"]
+                          and np.array_equal(got.kept_read_ids.astype(np.uint64), cpu_kept))
+    base["parity_checked"] = "kept read-id set, n_unique, n_clusters, n_kept of the HIP path on this sample"
+    del dev
+    return base
 
 
 def pmc_traffic(kernel_substr: str, workload: str, reads_per_gpu: int):
-    """HBM bytes per launch of one kernel from the PMC counters, collected the way
-    MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3
-    passes (kernel-trace only), KB -> bytes, and FETCH_SIZE doubled (on gfx950 it reports
+    """HBM bytes per launch of one kernel, and of ALL kernels of one step, from the PMC counters,
+    collected the way MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
+    rocprofv3 passes (kernel-trace only), KB -> bytes, and FETCH_SIZE doubled (on gfx950 it reports
     half the bytes of a wide coalesced stream; exact for 16-B/lane reads like the pack
-    kernel's, uncalibrated for gathers)."""
+    kernel's, an over-estimate for gathers). The child runs 1 warm-up + 1 timed step: the step
+    total is the sum over every dispatch except the input generator's, halved."""
     import csv
     import glob
     import shutil
@@ -87,13 +111,13 @@ def pmc_traffic(kernel_substr: str, workload: str, reads_per_gpu: int):
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
-    vals = {}
+        return None, None, "rocprofv3 not found"
+    vals, job = {}, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix=f"fqd_pmc_{counter}_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
                sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1",
-               "--workload", workload, "--no-cpu-baseline", "--no-pmc", "--no-host-input"]
+               "--workload", workload, "--no-cpu-baseline", "--no-pmc", "--no-host-input", "--no-copy-peak"]
         if reads_per_gpu:
             cmd += ["--reads-per-gpu", str(reads_per_gpu)]
         env = dict(os.environ, TMPDIR="/tmp")
@@ -101,18 +125,72 @@ def pmc_traffic(kernel_substr: str, workload: str, reads_per_gpu: int):
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, check=True, stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-            got = [float(r["Counter_Value"]) for f in files for r in csv.DictReader(open(f))
-                   if r["Counter_Name"] == counter and kernel_substr in r["Kernel_Name"]]
+            rows = [(r["Kernel_Name"], float(r["Counter_Value"])) for f in files for r in csv.DictReader(open(f))
+                    if r["Counter_Name"] == counter]
+            got = [v for k, v in rows if kernel_substr in k]
             if not got:
-                return None, f"no {counter} rows for {kernel_substr}"
+                return None, None, f"no {counter} rows for {kernel_substr}"
             vals[counter] = sum(got) / len(got)
+            job[counter] = sum(v for k, v in rows if "synth_kernel" not in k) / 2.0
         except Exception as exc:
-            return None, f"{counter} pass failed: {type(exc).__name__}"
+            return None, None, f"{counter} pass failed: {type(exc).__name__}"
         finally:
             shutil.rmtree(out, ignore_errors=True)
     traffic = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-    return traffic, {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
-                     "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024"}
+    job_traffic = (2.0 * job["FETCH_SIZE"] + job["WRITE_SIZE"]) * 1024.0
+    return traffic, job_traffic, {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
+                                  "job_FETCH_SIZE_KB": job["FETCH_SIZE"], "job_WRITE_SIZE_KB": job["WRITE_SIZE"],
+                                  "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024"}
+
+
+def copy_peak_gbs(device, nbytes: int = 2 << 30, reps: int = 5):
+    """Achievable HBM bandwidth in this run, on this GPU: a device-to-device copy of `nbytes`
+    (read + write counted), best of `reps` ('achievable peak')."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    b = torch.empty_like(a)
+    a.zero_()
+    b.copy_(a)
+    best = 0.0
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return round(best, 1)
+
+
+def launch_ranks(n_ranks: int) -> int:
+    """`python bench.py --gpus N` without torch.distributed.run: start N fresh child processes of this
+    script (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on 127.0.0.1) BEFORE this
+    process has touched a GPU, pass their output through (rank 0 prints the JSON line) and return the
+    worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
+                   LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    codes = [None] * n_ranks
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):      # a rank died: the others would wait forever
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+                    codes[i] = p.wait()
+            break
+        time.sleep(0.05)
+    return max((abs(c) for c in codes), default=0)
 
 
 def main():
@@ -128,15 +206,15 @@ def main():
                     help="run the multi-GPU code path even with one rank (diagnostic)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two child rocprofv3 --pmc passes (traffic=null)")
     ap.add_argument("--no-host-input", action="store_true", help="skip the PCIe-inclusive extra step")
+    ap.add_argument("--no-copy-peak", action="store_true", help="skip the device-copy bandwidth measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))      # no external launcher: start the ranks ourselves
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -278,11 +356,14 @@ def main():
     table.sort(key=lambda r: -r["avg_launch_ms"])
     roofline = dict(table[0])
     kernels = [{k: r[k] for k in ("kernel", "avg_launch_ms", "ms_per_step", "achieved", "frac")} for r in table]
+    job_traffic = None
     if rank == 0 and world == 1 and not args.no_pmc:
-        traffic, how = pmc_traffic(rocprof_name.get(roofline["kernel"], roofline["kernel"]), args.workload,
-                                   args.reads_per_gpu)
+        traffic, job_traffic, how = pmc_traffic(rocprof_name.get(roofline["kernel"], roofline["kernel"]),
+                                                args.workload, args.reads_per_gpu)
         roofline["traffic"] = None if traffic is None else int(traffic)
         roofline["traffic_source"] = how
+    if not args.no_copy_peak:
+        roofline["achievable_peak_gbs"] = copy_peak_gbs(device)
 
     # the same step with the keys in (pageable) host memory: PCIe-inclusive, never `value`
     pcie = None
@@ -305,12 +386,20 @@ def main():
               + U * (b_key_v1 + 13))
     job_gbs = alg_v1 / (ms_per_step * 1e-3) / 1e9
     job_roofline = {"alg_bytes": int(alg_v1), "formula": "ALG_BYTES_V1 (SURVEY.md 8d)", "achieved": round(job_gbs, 1),
-                    "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(job_gbs / (HBM_PEAK_GBS * world), 5)}
+                    "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(job_gbs / (HBM_PEAK_GBS * world), 5),
+                    "traffic": None if job_traffic is None else int(job_traffic),
+                    "traffic_note": "PMC bytes of every kernel of one step, (2*FETCH_SIZE + WRITE_SIZE)*1024"}
+    # the whole-job fraction SURVEY.md 8d defines, next to the dominant kernel's
+    roofline["job"] = {k: job_roofline[k] for k in ("alg_bytes", "achieved", "frac", "traffic")}
 
     out = {
         "metric": "reads/sec clustered (Hamming<=1, 150 bp)", "value": round(value, 1), "unit": "reads/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+        "timed_region": "t_dev: key bytes resident in HBM -> ascending kept read ids resident in HBM "
+                        "(value = reads / t_dev); t_e2e (pageable host keys -> host ids, PCIe-inclusive) is "
+                        "reported as t_e2e_ms / host_input and is never `value`",
+        "t_dev_ms": round(ms_per_step, 3), "t_e2e_ms": None if pcie is None else pcie["ms"],
         "data": "synthetic keys generated in HBM (fqd_synth_keys, fastqdedup_amd/synth.py)",
         "config": {"workload": wl["name"], "reads_per_gpu": n, "reads_total": n_total, "key_len": L,
                    "max_distance": wl["d"], "metric": "edit" if wl["edit"] else "hamming",
@@ -337,6 +426,8 @@ def main():
         print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()
+    if out.get("cpu_baseline", {}).get("parity") is False:
+        raise SystemExit("PARITY FAILURE: the HIP path and the CPU reference disagree on the cpu_baseline sample")
 
 
 if __name__ == "__main__":

@@ -62,6 +62,31 @@ def average_error_rate(phred_scores: str, *, phred_offset: int = 33) -> float:
     return float(means[0])
 
 
+def trie_stats(trie) -> str:
+    """The DEBUG-level census the reference prints after pass 1 (__init__.py:133-157): one row per
+    trie layer -- leaves, then inner nodes by child-array width -- a totals row, and the node /
+    suffix / total byte split. Same columns and number formats, so logs stay comparable."""
+    stats = trie.raw_stats()
+    cols = len(trie.alphabet) + 1                       # column 0 = leaves, column k = inner nodes of width k
+    sums = [0] * (cols + 1)
+    cell = "{:10}".format
+    lines = ["layer     terminal  " + "".join(cell(k) for k in range(1, cols)) + "     total"]
+    for depth, row in enumerate(stats):
+        row_total = sum(row)
+        for k in range(cols):
+            sums[k] += row[k]
+        sums[cols] += row_total
+        lines.append("".join(cell(v) for v in [str(depth), *row, row_total]))
+    lines.append("".join(cell(v) for v in ["total", *sums]))
+    node_bytes = sum((8 + 8 * k) * sums[k] for k in range(cols))
+    total_bytes = trie.memory_size()
+    gib = float(1 << 30)
+    lines.append(f"Node memory usage: {node_bytes / gib:.2} GiB")
+    lines.append(f"Suffix memory usage: {(total_bytes - node_bytes) / gib:.2} GiB")
+    lines.append(f"Total memory usage: {total_bytes / gib:.2} GiB")
+    return "\n".join(lines) + "\n"
+
+
 def length_string_to_slices(length_string: str) -> List[slice]:
     """'8,8,8' or '8:16,8,24:8:-1' -> slices (reference __init__.py:364-375)."""
     out = []
@@ -156,43 +181,49 @@ def initiate_logger(verbose: int = 0, quiet: int = 0):
 
 
 def argument_parser() -> argparse.ArgumentParser:
-    """Flag for flag the reference's parser (__init__.py:305-361, README.rst:42-89)."""
-    p = argparse.ArgumentParser(prog="fastqdedup")
+    """The reference's flag surface (__init__.py:305-361, README.rst:42-89): same flags, dests,
+    types and defaults; the help texts are this package's own."""
+    p = argparse.ArgumentParser(
+        prog="fastqdedup",
+        description="Remove duplicate reads from FASTQ files without alignment: read keys are clustered by "
+                    "Hamming or Levenshtein distance on an MI355X and one or more representatives per "
+                    "cluster are written out.")
     p.add_argument("fastq", metavar="FASTQ", nargs="+",
-                   help="Forward FASTQ and optional reverse and UMI FASTQ files.")
+                   help="Input FASTQ file(s): R1, then optionally R2 and/or a UMI file; records are taken "
+                        "in lockstep and their sequences concatenated into one key.")
     p.add_argument("-l", "--check-lengths",
-                   help="Comma-separated string with the maximum string check length of each file. "
-                        "For example 'fastqdedup --check-lengths 16,8 R1.fastq R2.fastq' only checks the "
-                        "first 16 bases of R1 and the first 8 bases of R2 for duplication. Supports slice "
-                        "notation such as '4:8' or '::8'.")
+                   help="One entry per input file, separated by commas, limiting which bases of that file "
+                        "enter the key: a plain number N means the first N bases, and Python slice syntax "
+                        "(start:stop[:step], e.g. '4:8' or '::8') is accepted. Example: '--check-lengths "
+                        "16,8' keys on R1[:16] + R2[:8].")
     p.add_argument("-o", "--output", action="append", required=False,
-                   help="Output file (optional), must be specified multiple times for multiple input "
-                        "files. For example ``fastqdedup -o dedupR1.fastq -o dedupR2.fastq R1.fastq "
-                        "R2.fastq``.")
+                   help="Where to write a deduplicated file; repeat the flag once per input file, in the "
+                        "same order (e.g. '-o out_R1.fastq.gz -o out_R2.fastq.gz'). Without it the names "
+                        "are derived from --prefix.")
     p.add_argument("-p", "--prefix", default=DEFAULT_PREFIX,
-                   help=f"Prefix for the output files. Default: '{DEFAULT_PREFIX}'")
+                   help=f"Stem of the automatic output names <prefix><file number>.fastq.gz "
+                        f"(default '{DEFAULT_PREFIX}').")
     p.add_argument("-d", "--max-distance", type=int, default=DEFAULT_MAX_DISTANCE,
-                   help="The Hamming distance at which inputs are considered different. "
-                        f"Default: {DEFAULT_MAX_DISTANCE}.")
+                   help=f"Keys at most this far apart end up in the same cluster (default {DEFAULT_MAX_DISTANCE}).")
     p.add_argument("-e", "--max-average-error-rate", type=float, default=DEFAULT_MAX_AVERAGE_ERROR_RATE,
-                   help="The maximum average per base error rate for each FASTQ record. Average is "
-                        "evaluated over bases taken into account by --check-lengths."
-                        f"Default: {DEFAULT_MAX_AVERAGE_ERROR_RATE}")
+                   help="Records whose mean per-base error probability (from the phred qualities of the "
+                        "bases selected by --check-lengths) exceeds this value are not counted "
+                        f"(default {DEFAULT_MAX_AVERAGE_ERROR_RATE}).")
     p.add_argument("-E", "--no-average-error-rate-filter", action="store_const",
                    dest="max_average_error_rate", const=1.0,
-                   help="Do not filter on average per base error rate.")
+                   help="Switch the quality filter off.")
     p.add_argument("--edit", action="store_true",
-                   help="Use edit (Levenshtein) distance instead of Hamming distance.")
+                   help="Measure distance as Levenshtein (substitutions, insertions, deletions) rather than "
+                        "Hamming (substitutions only).")
     p.add_argument("-c", "--cluster-dissection-method", choices=CLUSTER_DISSECTION_METHODS.keys(),
                    default=DEFAULT_CLUSTER_DISSECTION,
-                   help="How to approach clusters with multiple reads. 'highest_count' selects only one "
-                        "read, the one with the highest count. 'adjacency' starts from the read with the "
-                        "highest count and selects all reads that are within the specified distance. The "
-                        "process is repeated for the remaining reads. 'directional' is similar to "
-                        "adjacency but uses counts to determine if an error is a PCR/sequencing artifact "
-                        "or derived from a difference in the molecule (default).")
-    p.add_argument("-v", "--verbose", action="count", default=0, help="Increase log verbosity.")
-    p.add_argument("-q", "--quiet", action="count", default=0, help="Reduce log verbosity.")
+                   help="Which members of a cluster survive. highest_count: only the most frequent key. "
+                        "adjacency: the most frequent key, then again the most frequent of those not within "
+                        "the distance of a survivor, and so on. directional (default): like adjacency, but "
+                        "a key is only absorbed by a neighbour that is at least about twice as frequent, "
+                        "so genuine variants with comparable support are both kept.")
+    p.add_argument("-v", "--verbose", action="count", default=0, help="More log output (repeatable).")
+    p.add_argument("-q", "--quiet", action="count", default=0, help="Less log output (repeatable).")
     return p
 
 

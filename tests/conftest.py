@@ -29,7 +29,18 @@ def known_answers():
 
 @pytest.fixture(scope="session")
 def ref_vectors():
+    return load_ref_vectors()
+
+
+GOLDEN_FILES = ("ref_vectors.json.gz", "ref_vectors_long.json.gz")
+
+
+def load_ref_vectors():
+    """Both fixtures minted by tests/golden/make_golden.py, as one {"cases": {...}}."""
     import gzip
     import json
-    with gzip.open(os.path.join(ROOT, "tests", "golden", "ref_vectors.json.gz")) as fh:
-        return json.load(fh)
+    cases = {}
+    for name in GOLDEN_FILES:
+        with gzip.open(os.path.join(ROOT, "tests", "golden", name)) as fh:
+            cases.update(json.load(fh)["cases"])
+    return {"cases": cases}

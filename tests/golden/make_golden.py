@@ -14,8 +14,12 @@ What runs here:
     Nothing of the reference's text is written anywhere.
 
 What is written: DATA only -- input keys and the reference's outputs -- as
-``tests/golden/ref_vectors.json.gz``. ``/root/reference`` does not exist on the
-GPU box; the committed fixture is what travels.
+``tests/golden/ref_vectors.json.gz`` (short keys), ``ref_vectors_long.json.gz``
+(300-nt keys with N at d <= 2; 149/150/151- and 299/300/301-nt mixed-length sets
+for the edit metric) and ``fastq_error_rates.json`` (the reference's
+``_fastq.average_error_rate`` on every valid phred character and on random
+strings, as exact hex floats). ``/root/reference`` does not exist on the GPU
+box; the committed fixtures are what travels.
 """
 from __future__ import annotations
 
@@ -120,11 +124,106 @@ def make_inputs():
     return cases
 
 
+def indel_reads(rng, n_mol, length, n_reads, sub, p_del, p_ins, alphabet="ACGT"):
+    """Reads of `length`-nt molecules: substitutions at rate `sub`; a share p_del loses one base,
+    a share p_ins gains one (the 149/151-nt sub-population next to 150-nt reads)."""
+    mols = ["".join(rng.choice(alphabet) for _ in range(length)) for _ in range(n_mol)]
+    out = []
+    for _ in range(n_reads):
+        s = list(rng.choice(mols))
+        for i in range(len(s)):
+            if rng.random() < sub:
+                s[i] = rng.choice([c for c in alphabet + "N" if c != s[i]])
+        x = rng.random()
+        if x < p_del:
+            del s[rng.randrange(len(s))]
+        elif x < p_del + p_ins:
+            s.insert(rng.randrange(len(s) + 1), rng.choice(alphabet))
+        out.append("".join(s))
+    return out
+
+
+def make_long_inputs():
+    """name -> (keys, weights, [(edit, d), ...]): the shapes of configs 4 and 5."""
+    from fastqdedup_amd.synth import synth_keys
+    cases = {}
+    k = synth_keys(900, 300, 300, 15, sub_rate=2.5e-3, n_rate=1.5e-3)
+    cases["synth_s15_n900_L300_N"] = ([bytes(r).decode() for r in k], [1] * 900,
+                                      [(False, 0), (False, 1), (False, 2), (True, 1), (True, 2)])
+    rng = random.Random(150)
+    keys = indel_reads(rng, 260, 150, 1300, 2e-3, 0.08, 0.08)
+    cases["mixed_149_150_151"] = (keys, [1] * len(keys), [(False, 1), (True, 1), (True, 2)])
+    rng = random.Random(300)
+    keys = indel_reads(rng, 200, 300, 1000, 1.5e-3, 0.06, 0.06)
+    cases["mixed_299_300_301"] = (keys, [1] * len(keys), [(False, 2), (True, 1), (True, 2)])
+    return cases
+
+
+def make_fastq_fixture():
+    """The reference's _fastq.average_error_rate (_fastqmodule.c:38-76) on every valid phred
+    character, on random strings and with other offsets; values as exact hex floats."""
+    import importlib.util
+    d = os.path.join(ROOT, "oracle", "_ref")
+    so = [f for f in os.listdir(d) if f.startswith("_fastq.")][0]
+    spec = importlib.util.spec_from_file_location("_fastq", os.path.join(d, so))
+    fq = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fq)
+    rng = random.Random(94)
+    doc = {"generator": "tests/golden/make_golden.py", "single": {}, "strings": [], "errors": []}
+    for c in range(33, 127):
+        doc["single"][chr(c)] = fq.average_error_rate(chr(c)).hex()
+    for _ in range(120):
+        n = rng.choice([1, 2, 3, 7, 16, 50, 100, 151, 300])
+        lo, hi = rng.choice([(33, 126), (33, 75), (60, 75), (35, 45)])
+        s = "".join(chr(rng.randint(lo, hi)) for _ in range(n))
+        doc["strings"].append({"phred": s, "offset": 33, "value": fq.average_error_rate(s).hex()})
+    for off in (0, 64):
+        for _ in range(20):
+            n = rng.randint(1, 60)
+            s = "".join(chr(rng.randint(off, min(126, off + 62))) for _ in range(n))
+            doc["strings"].append({"phred": s, "offset": off,
+                                   "value": fq.average_error_rate(s, phred_offset=off).hex()})
+    doc["strings"].append({"phred": "", "offset": 33, "value": repr(fq.average_error_rate(""))})   # nan
+    for bad, off in [(" ", 33), ("I\x7f", 33), ("?", 64), ("\x1f", 0 + 33)]:
+        try:
+            fq.average_error_rate(bad, phred_offset=off)
+            raise AssertionError("reference accepted " + repr(bad))
+        except ValueError as exc:
+            doc["errors"].append({"phred": bad, "offset": off, "message": str(exc)})
+    path = os.path.join(HERE, "fastq_error_rates.json")
+    with open(path, "w") as fh:
+        json.dump(doc, fh, indent=0, sort_keys=True)
+        fh.write("\n")
+    print("wrote", path, os.path.getsize(path), "bytes", file=sys.stderr)
+
+
+def _run_record(clusters, kept):
+    uniq = sorted({k for cl in clusters for _, k in cl})
+    index = {k: i for i, k in enumerate(uniq)}
+    return {"n_clusters": len(clusters), "labels": _labels(clusters, index), "counts": _counts(clusters, index),
+            "kept": {m: sorted(index[k] for k in v) for m, v in kept.items()},
+            "pop_order_seed": [index[cl[0][1]] for cl in clusters]}
+
+
 def main():
     from oracle import oracle as O
     O.build()
     ref_trie, ref_dist = O.load_reference()
     dissect = load_reference_dissection(ref_dist.within_distance)
+    make_fastq_fixture()
+    long_out = {"generator": "tests/golden/make_golden.py", "cases": {}}
+    for name, (keys, weights, runs_wanted) in make_long_inputs().items():
+        runs = {}
+        for edit, d in runs_wanted:
+            clusters, kept = run_reference(ref_trie, dissect, keys, weights, d, edit)
+            runs[f"{'L' if edit else 'H'}{d}"] = _run_record(clusters, kept)
+        long_out["cases"][name] = {"keys": keys, "weights": weights, "runs": runs}
+        print(name, len(keys), {k: (v["n_clusters"], len(v["kept"]["directional"]))
+                                for k, v in runs.items()}, file=sys.stderr)
+    path = os.path.join(HERE, "ref_vectors_long.json.gz")
+    with gzip.GzipFile(path, "wb", mtime=0) as fh:
+        fh.write(json.dumps(long_out, separators=(",", ":")).encode())
+    print("wrote", path, os.path.getsize(path), "bytes", file=sys.stderr)
     out = {"generator": "tests/golden/make_golden.py", "cases": {}}
     for name, (keys, weights) in make_inputs().items():
         runs = {}

@@ -51,6 +51,30 @@ def test_quality_means_bit_exact(F, oracle):
         ctx.quality_filter(np.frombuffer(b"III II", dtype=np.uint8), None, 3)
 
 
+def test_quality_kernel_matches_reference_fixture(F):
+    """fqd_quality_filter against tests/golden/fastq_error_rates.json: values the reference's own
+    _fastq.average_error_rate (_fastqmodule.c:38-76) gave, compared bit for bit."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fastq_error_rates.json")) as fh:
+        fx = json.load(fh)
+    ctx = F.Context(0)
+    rows = [{"phred": ch, "offset": 33, "value": v} for ch, v in fx["single"].items()] + fx["strings"]
+    for off in sorted({r["offset"] for r in rows}):
+        sel = [r for r in rows if r["offset"] == off]
+        strs = [r["phred"] for r in sel]
+        raw = np.frombuffer("".join(strs).encode("latin-1") or b"\0", dtype=np.uint8)[: sum(map(len, strs))]
+        offs = np.concatenate([[0], np.cumsum([len(s) for s in strs])]).astype(np.uint64)
+        _, means, _ = ctx.quality_filter(raw if raw.size else np.zeros(1, np.uint8), offs, phred_offset=off,
+                                         want_means=True)
+        for r, m in zip(sel, means.tolist()):
+            assert (math.isnan(m) if r["value"] == "nan" else float(m).hex() == r["value"]), r
+    for r in fx["errors"]:
+        with pytest.raises(ValueError) as err:
+            F.average_error_rate(r["phred"], phred_offset=r["offset"])
+        assert str(err.value) == r["message"]
+
+
 def _fq(path, recs):
     data = "".join(f"@{n}\n{s}\n+\n{q}\n" for n, s, q in recs).encode()
     (gzip.open if path.endswith(".gz") else open)(path, "wb").write(data)

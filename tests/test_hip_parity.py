@@ -32,10 +32,8 @@ def _pack(keys):
 
 
 def _golden_cases():
-    import gzip, json
-    here = os.path.dirname(os.path.abspath(__file__))
-    with gzip.open(os.path.join(here, "golden", "ref_vectors.json.gz")) as fh:
-        return sorted(json.load(fh)["cases"])
+    from conftest import load_ref_vectors
+    return sorted(load_ref_vectors()["cases"])
 
 
 @pytest.mark.parametrize("name", _golden_cases())

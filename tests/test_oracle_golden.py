@@ -7,10 +7,8 @@ METHODS = ("highest_count", "adjacency", "directional")
 
 
 def _case_names():
-    import gzip, json, os
-    here = os.path.dirname(os.path.abspath(__file__))
-    with gzip.open(os.path.join(here, "golden", "ref_vectors.json.gz")) as fh:
-        return sorted(json.load(fh)["cases"])
+    from conftest import load_ref_vectors
+    return sorted(load_ref_vectors()["cases"])
 
 
 @pytest.mark.parametrize("name", _case_names())
