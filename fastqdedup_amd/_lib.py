@@ -46,6 +46,8 @@ EXPORTS = [
     "fqd_find_edges_segments", "fqd_edge_labels", "fqd_list_kept_except", "fqd_set_owner_rule", "fqd_declare_distinct_keys", "fqd_collapse_received", "fqd_set_kept_output",
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
     "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_set_timing", "fqd_cluster_keys", "fqd_edge_stats", "fqd_synth_keys",
+    "fqd_store_add_keys", "fqd_store_remove", "fqd_store_removed_count", "fqd_get_clusters", "fqd_read_clusters",
+    "fqd_trie_order", "fqd_trie_stats", "fqd_store_symbol_events",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -122,6 +124,14 @@ def load() -> C.CDLL:
     L.fqd_edge_stats.argtypes = [vp, u64p, u64p, u64p]
     L.fqd_synth_keys.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                  C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]
+    L.fqd_store_add_keys.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp, C.c_int, u64p]
+    L.fqd_store_remove.argtypes = [vp, vp, C.c_uint64, C.c_int]
+    L.fqd_store_removed_count.argtypes = [vp, u64p]
+    L.fqd_get_clusters.argtypes = [vp, vp, C.c_uint32, u64p, u64p]
+    L.fqd_read_clusters.argtypes = [vp, vp, vp, C.c_int]
+    L.fqd_trie_order.argtypes = [vp, vp, C.c_uint32, vp, C.c_int]
+    L.fqd_trie_stats.argtypes = [vp, vp, C.c_uint32, C.c_uint32, u64p, vp]
+    L.fqd_store_symbol_events.argtypes = [vp, vp, C.c_uint32, C.c_int, vp, C.c_uint32, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -515,6 +525,83 @@ class Context:
                                             float(threshold), None if tb is None else tb.ctypes.data,
                                             fp, mp_, C.byref(nd), mem))
         return flags, means, int(nd.value)
+
+    # ---- the Trie object as a device-resident store ------------------------------
+    @staticmethod
+    def _alphabet_bytes(alphabet: str) -> np.ndarray:
+        return np.frombuffer(alphabet.encode("latin-1") or b"\0", dtype=np.uint8)
+
+    def store_add_keys(self, keys, offsets=None, key_len: int = 0, weights=None, read_ids=None) -> int:
+        """Merge new keys into the resident unique table (fqd_store_add_keys) -> unique keys stored."""
+        kp, km, _k = _ptr_mem(keys)
+        op, om, _o = _ptr_mem(offsets)
+        if offsets is None:
+            nbytes = keys.numel() if hasattr(keys, "numel") else keys.size
+            n = nbytes // key_len if key_len > 0 else 0
+        else:
+            n = (offsets.numel() if hasattr(offsets, "numel") else offsets.size) - 1
+        mem = self._same_mem((km, True), (om, offsets is not None))
+        wp, wm, _w = _ptr_mem(weights)
+        rp, rm, _r = _ptr_mem(read_ids)
+        aux = self._same_mem((wm, weights is not None), (rm, read_ids is not None))
+        u = C.c_uint64(0)
+        self._ck(self._L.fqd_store_add_keys(self._h, kp, op, n, int(key_len), mem, wp, rp, aux, C.byref(u)))
+        return int(u.value)
+
+    def store_remove(self, uids) -> None:
+        up, um, _u = _ptr_mem(uids)
+        n = uids.numel() if hasattr(uids, "numel") else uids.size
+        self._ck(self._L.fqd_store_remove(self._h, up, int(n), um))
+
+    def store_removed_count(self) -> int:
+        v = C.c_uint64(0)
+        self._ck(self._L.fqd_store_removed_count(self._h, C.byref(v)))
+        return int(v.value)
+
+    def clusters(self, alphabet: str):
+        """(offsets uint64[n_clusters + 1], member uids uint32[n_members]) in pop_cluster order."""
+        ab = self._alphabet_bytes(alphabet)
+        nc, nm = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._L.fqd_get_clusters(self._h, ab.ctypes.data, len(alphabet), C.byref(nc), C.byref(nm)))
+        offsets = np.zeros(int(nc.value) + 1, dtype=np.uint64)
+        members = np.zeros(int(nm.value), dtype=np.uint32)
+        self._ck(self._L.fqd_read_clusters(self._h, offsets.ctypes.data,
+                                           members.ctypes.data if members.size else None, HOST))
+        return offsets, members
+
+    def store_symbol_events(self, alphabet: str, symbols: str, after, reuse_order: bool):
+        """One round of the lazy-alphabet search (fqd_store_symbol_events): per symbol
+        (candidate first id | None, depth, partner first id | None)."""
+        ab, sy = self._alphabet_bytes(alphabet), self._alphabet_bytes(symbols)
+        n = len(symbols)
+        none = 0xFFFFFFFFFFFFFFFF
+        aft = np.array([none if a is None else int(a) for a in after], dtype=np.uint64)
+        cand = np.zeros(max(n, 1), dtype=np.uint64)
+        depth = np.zeros(max(n, 1), dtype=np.uint32)
+        partner = np.zeros(max(n, 1), dtype=np.uint64)
+        self._ck(self._L.fqd_store_symbol_events(self._h, ab.ctypes.data, len(alphabet), int(bool(reuse_order)),
+                                                 sy.ctypes.data, n, aft.ctypes.data, cand.ctypes.data,
+                                                 depth.ctypes.data, partner.ctypes.data))
+        return [(None if int(cand[i]) == none else int(cand[i]), int(depth[i]),
+                 None if int(partner[i]) == none else int(partner[i])) for i in range(n)]
+
+    def trie_order(self, alphabet: str, n_unique: int) -> np.ndarray:
+        ab = self._alphabet_bytes(alphabet)
+        out = np.zeros(n_unique, dtype=np.uint32)
+        self._ck(self._L.fqd_trie_order(self._h, ab.ctypes.data, len(alphabet),
+                                        out.ctypes.data if n_unique else None, HOST))
+        return out
+
+    def trie_stats(self, alphabet: str, n_layers: int):
+        """(memory_size, raw_stats as n_layers lists of len(alphabet) + 1 counters)."""
+        ab = self._alphabet_bytes(alphabet)
+        cols = len(alphabet) + 1
+        stats = np.zeros(max(n_layers * cols, 1), dtype=np.uint64)
+        mem = C.c_uint64(0)
+        self._ck(self._L.fqd_trie_stats(self._h, ab.ctypes.data, len(alphabet), int(n_layers), C.byref(mem),
+                                        stats.ctypes.data))
+        rows = stats[: n_layers * cols].reshape(n_layers, cols)
+        return int(mem.value), [[int(v) for v in row] for row in rows]
 
     # ---- measurement ------------------------------------------------------------
     def stage_times(self):

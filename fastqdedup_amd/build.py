@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfqdedup_hip.so")
-SOURCES = ["api.hip", "api_search.hip", "api_graph.hip", "api_exchange.hip", "prims.hip", "pack.hip", "collapse.hip", "collapse_lds.hip", "collapse_pairs.hip", "edges.hip", "group.hip", "edit.hip", "exchange.hip", "graph.hip", "quality.hip", "synth.hip"]
+SOURCES = ["api.hip", "api_search.hip", "api_graph.hip", "api_exchange.hip", "api_trie.hip", "trieorder.hip", "prims.hip", "pack.hip", "collapse.hip", "collapse_lds.hip", "collapse_pairs.hip", "edges.hip", "group.hip", "edit.hip", "exchange.hip", "graph.hip", "quality.hip", "synth.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -17,7 +17,7 @@ from typing import Callable, Iterator, List, Optional, Tuple
 import numpy as np
 
 from . import fastq
-from .core import (CLUSTER_DISSECTION_METHODS, DEFAULT_MAX_DISTANCE, cluster_dissection_directional,
+from .core import (CLUSTER_DISSECTION_METHODS, DEFAULT_MAX_DISTANCE, TableCensus, cluster_dissection_directional,
                    cluster_keys, default_context)
 
 DEFAULT_PREFIX = "fastqdedup_R"
@@ -156,6 +156,12 @@ def deduplicate_cluster(input_files: List[str], output_files: List[str], check_s
                            use_edit_distance=use_edit_distance, method=method, context=ctx)
     n_counted = res.n_counted if res else 0
     logger.info(f"Processed {n_counted} sequences. ({timer.get_difference()})")
+    if logger.level <= logging.DEBUG and res is not None and res.n_unique:
+        # the node census of the trie the reference would hold at this point (__init__.py:260-264),
+        # from the unique table the context still holds
+        stats = trie_stats(TableCensus(ctx))
+        logger.debug(f"Calculated stats. ({timer.get_difference()})")
+        logger.debug("\n" + stats)
     n_kept = res.n_kept if res else 0
     n_clusters = res.n_clusters if res else 0
     logger.info(f"Found {n_kept} distinct reads in {n_clusters} clusters."

@@ -201,22 +201,82 @@ CLUSTER_DISSECTION_METHODS = {
 # Trie  (reference _triemodule.c:596-1009, _trie.pyi:20-44)
 # ---------------------------------------------------------------------------
 
+def lazily_registered(ctx: Context, registered: str, unregistered) -> List[str]:
+    """The symbols of ``unregistered`` that an inner node of the reference's trie would have
+    looked up by now (TrieNode_AddSequence, _triemodule.c:266-273), in the order it would have met
+    them, for the keys stored in ``ctx``: per symbol the earliest (time, depth,
+    new-key-after-old-key) over the keys that hold it; one device round
+    (``fqd_store_symbol_events``) per candidate key -- usually one or two."""
+    listing = registered + "".join(sorted(unregistered))
+    best = {c: None for c in unregistered}
+    after = {c: None for c in unregistered}
+    searching = sorted(unregistered)
+    reuse = False
+    for _ in range(256):                       # (a symbol that needs more candidates keeps its best so far)
+        if not searching:
+            break
+        rows = ctx.store_symbol_events(listing, "".join(searching), [after[c] for c in searching], reuse)
+        reuse = True
+        still = []
+        for c, (fid, depth, partner) in zip(searching, rows):
+            if fid is None or (best[c] is not None and fid >= best[c][0]):
+                continue                       # no further key can be looked up earlier
+            if partner is not None:
+                event = (max(fid, partner), depth, 1 if fid > partner else 0)
+                if best[c] is None or event < best[c]:
+                    best[c] = event
+            after[c] = fid
+            still.append(c)
+        searching = still
+    return [c for _, c in sorted((e, c) for c, e in best.items() if e is not None)]
+
+
+class TableCensus:
+    """What ``trie_stats`` needs (``alphabet``, ``raw_stats()``, ``memory_size()``; reference
+    __init__.py:133-157) for the unique table a context holds after ``cluster_keys``: the trie
+    ``deduplicate_cluster`` would have built from the same reads (``Trie(alphabet="ACGTN")``,
+    __init__.py:240)."""
+
+    def __init__(self, ctx: Context, alphabet: str = "ACGTN"):
+        sh = ctx.shape()
+        present = {chr(b) for b in bytes(sh.alphabet)[: int(sh.alphabet_size)]}
+        others = present - set(alphabet)
+        if others:
+            alphabet += "".join(lazily_registered(ctx, alphabet, others))
+            others -= set(alphabet)
+        self.alphabet = alphabet
+        self._memory, stats = ctx.trie_stats(alphabet + "".join(sorted(others)), int(sh.max_len) + 1)
+        self._stats = [row[: len(alphabet) + 1] for row in stats]
+
+    def raw_stats(self) -> List[List[int]]:
+        return self._stats
+
+    def memory_size(self) -> int:
+        return self._memory
+
+
 class Trie:
-    """Drop-in for ``fastqdedup.Trie`` backed by the device key store.
+    """Drop-in for ``fastqdedup.Trie`` (reference _triemodule.c:596-1009, _trie.pyi:20-44) over a
+    device-resident store: its own context holds the unique-key table; nothing is re-packed.
 
-    ``add_sequence`` only appends to a host-side staging list; the first
-    ``pop_cluster`` / ``contains_sequence`` after an add moves the keys to HBM and
-    clusters them there (pack -> collapse -> bucket pair search -> components).
-    Popped clusters are the connected components the reference's BFS extracts
-    (_triemodule.c:865-895), emitted in the reference's order: ascending seed key
-    in trie-alphabet order, a longer key before its own prefix (:510-551).
+    * ``add_sequence`` appends to a host-side list of pending adds; the next query packs ONLY those
+      and merges them into the resident table on the device (``fqd_store_add_keys``).
+    * ``pop_cluster`` clusters the table on the device (bucket pair search -> components) and
+      asks for the clusters in the reference's order (``fqd_get_clusters``: ascending seed key in
+      alphabet order, a longer key before its own prefix, _triemodule.c:510-551); Python objects
+      are made for the popped cluster only. Popped rows are marked removed on the device
+      (``fqd_store_remove``); an add between pops merges and clusters again.
+    * ``contains_sequence`` searches the resident table (removed rows are skipped).
+    * ``memory_size`` / ``raw_stats`` are the node census of the trie the reference would hold
+      (``fqd_trie_stats``): exact after adds and after adds followed by pops -- what
+      ``deduplicate_cluster`` does; an add into a partly popped trie is merged as if the popped keys
+      had never been stored.
 
-    Representation-specific introspection differs by design:
-    ``alphabet`` lists the constructor alphabet followed by new symbols in order
-    of first appearance (the reference registers a symbol only when an inner
-    node looks it up, :266-273); ``memory_size()`` reports the HBM footprint of
-    the packed store; ``raw_stats()`` (per-layer node census of a pointer trie)
-    does not exist for a bit-plane store.
+    * ``alphabet`` grows the way the reference's does: a symbol outside the constructor alphabet is
+      registered when an INNER node first looks it up (_triemodule.c:266-273) -- not when it first
+      appears, never for bases that only ever sat in a leaf's suffix. The moments are worked out on
+      the device from the stored keys (``fqd_store_symbol_events``) whenever the alphabet, the pop
+      order or the census is asked for while unregistered symbols exist.
     """
 
     def __init__(self, alphabet: str = ""):
@@ -234,23 +294,59 @@ class Trie:
                 raise ValueError("Alphabet should consist of unique characters."
                                  f"Character {ch} was repeated. ")
             seen.add(ch)
-        self._alphabet: List[str] = list(alphabet)
+        self._alphabet: List[str] = list(alphabet)    # registered symbols, index order
         self._seen = seen
-        self._keys: List[str] = []      # unique keys in the store + staged adds
-        self._weights: List[int] = []
+        self._unregistered: set = set()               # symbols met in keys, not (yet) looked up by an inner node
+        self._strings: List[str] = []   # every sequence ever added; a read id is its index here
+        self._merged = 0                # strings[:_merged] are in the device store
         self._nseq = 0
-        self._clusters: Optional[List[List[Tuple[int, str]]]] = None   # remaining, emission order
+        self._max_len = 0               # max_sequence_size of the reference: never shrinks (:700-702)
+        self._n_unique = 0              # rows of the resident table
+        self._offsets: Optional[np.ndarray] = None   # remaining clusters (CSR over table rows), pop order
+        self._members: Optional[np.ndarray] = None
+        self._cursor = 0
         self._params: Optional[Tuple[int, bool]] = None
-        default_context()  # fail now, loudly, when there is no device
+        self._first: Optional[np.ndarray] = None     # per row: first holder id, count
+        self._counts: Optional[np.ndarray] = None
+        default_context()               # fail now, loudly, when there is no device
+        self._ctx: Optional[Context] = None
 
     # -- properties ---------------------------------------------------------
     @property
     def alphabet(self) -> str:
+        self._resolve_alphabet()
         return "".join(self._alphabet)
 
-    @property
-    def number_of_sequences(self) -> int:
-        return self._nseq
+    def _listing(self) -> str:
+        """Every symbol of the stored keys: the registered ones in index order, then the others."""
+        return "".join(self._alphabet) + "".join(sorted(self._unregistered))
+
+    def _resolve_alphabet(self) -> None:
+        """Register the symbols an inner node of the reference's trie has looked up by now."""
+        if not self._unregistered or self._nseq == 0:
+            return
+        self._flush()
+        for c in lazily_registered(self._store(), "".join(self._alphabet), self._unregistered):
+            self._alphabet.append(c)
+            self._unregistered.discard(c)
+
+    # -- the device store ---------------------------------------------------
+    def _store(self) -> Context:
+        if self._ctx is None:
+            self._ctx = Context(default_context().device)
+        return self._ctx
+
+    def _flush(self) -> None:
+        """Pending adds -> the resident table (only they are packed)."""
+        if self._merged == len(self._strings):
+            return
+        pending = self._strings[self._merged:]
+        raw, off = pack_strings(pending)
+        ids = np.arange(self._merged, len(self._strings), dtype=np.uint64)
+        data = raw if raw.size else np.zeros(1, dtype=np.uint8)
+        self._n_unique = self._store().store_add_keys(data, off, 0, None, ids)
+        self._merged = len(self._strings)
+        self._offsets = self._members = self._first = self._counts = None    # rows were renumbered
 
     # -- mutation -----------------------------------------------------------
     def add_sequence(self, sequence, /) -> None:
@@ -260,57 +356,22 @@ class Trie:
             raise ValueError("Sequence must consist only of ASCII characters")
         if len(sequence) > 0xFFFFFFFF:
             raise ValueError("Sequences larger than 4294967295 can not be stored in the Trie")
-        self._unpop()
-        self._keys.append(sequence)
-        self._weights.append(1)
+        self._strings.append(sequence)
         self._nseq += 1
+        self._max_len = max(self._max_len, len(sequence))
         fresh = set(sequence) - self._seen
         if fresh:
-            for ch in sequence:
-                if ch in fresh and ch not in self._seen:
-                    self._seen.add(ch)
-                    self._alphabet.append(ch)
+            self._seen |= fresh
+            self._unregistered |= fresh
 
-    def _unpop(self):
-        """Adds after pops: the not-yet-popped clusters go back into the store."""
-        if self._clusters is not None:
-            self._keys = [k for cl in self._clusters for _, k in cl]
-            self._weights = [c for cl in self._clusters for c, _ in cl]
-            self._clusters = None
-            self._params = None
-
-    def _order_key(self):
-        rank = {ch: i for i, ch in enumerate(self._alphabet)}
-        end = len(rank) + 1
-
-        def key(s: str):
-            return tuple(rank[ch] for ch in s) + (end,)   # longer key before its prefix
-        return key
-
-    def _cluster(self, max_distance: int, use_edit_distance: bool):
-        self._unpop()
-        ctx = default_context()
-        raw, off = pack_strings(self._keys)
-        w = np.asarray(self._weights, dtype=np.uint32)
-        ctx.pack_keys(raw, off)
-        nu = ctx.collapse(w, None)
+    def _cluster(self, max_distance: int, use_edit_distance: bool) -> None:
+        ctx = self._store()
+        self._resolve_alphabet()
         ctx.find_edges(max_distance, _metric(use_edit_distance))
         ctx.components()
-        first, counts, labels, _ = ctx.unique_table(nu, labels=True, kept=False)
-        keys = [self._keys[int(i)] for i in first]
-        order = np.argsort(labels, kind="stable")
-        groups: List[List[Tuple[int, str]]] = []
-        okey = self._order_key()
-        start = 0
-        lab_sorted = labels[order]
-        for end in range(1, nu + 1):
-            if end == nu or lab_sorted[end] != lab_sorted[start]:
-                members = [(int(counts[j]), keys[int(j)]) for j in order[start:end]]
-                members.sort(key=lambda m: okey(m[1]))
-                groups.append(members)
-                start = end
-        groups.sort(key=lambda g: okey(g[0][1]))
-        self._clusters = groups
+        self._offsets, self._members = ctx.clusters(self._listing())
+        self._first, self._counts, _, _ = ctx.unique_table(self._n_unique, labels=False, kept=False)
+        self._cursor = 0
         self._params = (max_distance, bool(use_edit_distance))
 
     def pop_cluster(self, max_distance, use_edit_distance=False) -> List[Tuple[int, str]]:
@@ -320,9 +381,14 @@ class Trie:
             raise ValueError("max_distance should be non-negative")
         if self._nseq == 0:
             raise LookupError("No sequences left in Trie.")
-        if self._clusters is None or self._params != (max_distance, bool(use_edit_distance)):
+        self._flush()
+        if self._offsets is None or self._params != (max_distance, bool(use_edit_distance)):
             self._cluster(max_distance, bool(use_edit_distance))
-        cluster = self._clusters.pop(0)
+        lo, hi = int(self._offsets[self._cursor]), int(self._offsets[self._cursor + 1])
+        self._cursor += 1
+        rows = self._members[lo:hi]
+        cluster = [(int(self._counts[r]), self._strings[int(self._first[r])]) for r in rows]
+        self._store().store_remove(np.ascontiguousarray(rows))
         self._nseq -= sum(c for c, _ in cluster)
         return cluster
 
@@ -333,30 +399,25 @@ class Trie:
             raise ValueError("sequence must contain only ASCII characters")
         if self._nseq == 0:
             return False   # the reference dereferences a NULL root here (_triemodule.c:755)
-        self._unpop()
-        ctx = default_context()
-        raw, off = pack_strings(self._keys)
-        ctx.pack_keys(raw, off)
-        ctx.collapse(np.asarray(self._weights, dtype=np.uint32), None)
+        self._flush()
         q, qo = pack_strings([sequence])
         q = q if q.size else np.zeros(1, dtype=np.uint8)
-        return bool(ctx.contains(q, qo, int(max_distance), _metric(use_edit_distance))[0])
+        return bool(self._store().contains(q, qo, int(max_distance), _metric(use_edit_distance))[0])
 
     # -- introspection ------------------------------------------------------
-    def memory_size(self) -> int:
-        """HBM bytes of the packed key store for the current keys (not comparable
-        with the reference's node bytes, _triemodule.c:553-570)."""
-        if not self._keys:
-            return 0
-        self._unpop()
-        ctx = default_context()
-        raw, off = pack_strings(self._keys)
-        ctx.pack_keys(raw, off)
-        nu = ctx.collapse(np.asarray(self._weights, dtype=np.uint32), None)
-        sh = ctx.shape()
-        return nu * (sh.stride_words * 4 + 4 + 8 + (4 if sh.ragged else 0))
+    def _census(self):
+        layers = self._max_len + 1
+        if self._nseq == 0:
+            return 0, [[0] * (len(self.alphabet) + 1) for _ in range(layers)]
+        self._flush()
+        alphabet = self.alphabet                   # (registers what has been looked up by now)
+        memory, stats = self._store().trie_stats(self._listing(), layers)
+        return memory, [row[: len(alphabet) + 1] for row in stats]
 
-    def raw_stats(self):
-        raise NotImplementedError(
-            "raw_stats() is a per-layer node census of the reference's pointer trie "
-            "(_triemodule.c:572-594); the device store is a flat bit-plane table and has no layers")
+    def memory_size(self) -> int:
+        """Bytes of the reference's trie nodes for the stored keys (_triemodule.c:553-570, :909-913)."""
+        return self._census()[0]
+
+    def raw_stats(self) -> List[List[int]]:
+        """Per trie layer: leaves, then inner nodes by child-array width (_triemodule.c:572-594, :929-964)."""
+        return self._census()[1]

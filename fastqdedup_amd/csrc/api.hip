@@ -486,7 +486,11 @@ void fqd_destroy(fqd_ctx *c)
                       &c->ed_payload, &c->ed_hash_sorted, &c->ed_payload_sorted, &c->ed_cands, &c->ed_cands_sorted,
                       &c->d_alphabet, &c->labels, &c->best, &c->state,
                       &c->blocked, &c->kept, &c->kept_u32, &c->kept_scan, &c->kept_ids, &c->kept_ids_sorted, &c->tmp,
-                      &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners, &c->taint, &c->root_taint, &c->gp_a, &c->gp_b, &c->gp_small, &c->gp_cands, &c->seg_tab, &c->ld_seg, &c->kept_lists};
+                      &c->stage_a, &c->stage_b, &c->stage_c, &c->stage_d, &c->hook_slots, &c->owners, &c->taint, &c->root_taint, &c->gp_a, &c->gp_b, &c->gp_small, &c->gp_cands, &c->seg_tab, &c->ld_seg, &c->kept_lists,
+                      &c->t_idx, &c->t_order, &c->t_order_b, &c->t_rank, &c->t_keys, &c->t_keys_b, &c->t_lcp, &c->t_mark,
+                      &c->t_mark_incl, &c->t_stats, &c->t_seed, &c->t_heads, &c->t_heads_incl, &c->t_member_uids,
+                      &c->t_offsets, &c->store_alive, &c->st_recs, &c->st_lens, &c->st_counts, &c->st_first,
+                      &c->st_comb_recs, &c->st_comb_lens, &c->st_comb_w, &c->st_comb_ids};
     for (DevBuf *b : bufs)
         b->release();
     if (c->ev_rb)
@@ -1112,9 +1116,11 @@ int fqd_contains(fqd_ctx *c, const uint8_t *q_bytes, const uint64_t *q_offsets, 
     HIP_TRY(c, hipMemcpyAsync(c->d_alphabet.p, c->shape.alphabet, 128, hipMemcpyHostToDevice, c->st));
     HIP_TRY(c, c->stage_c.reserve(n * 4 + 16));
     HIP_TRY(c, hipMemsetAsync(c->stage_c.p, 0, n * 4, c->st));
+    // rows taken out by fqd_store_remove (popped clusters) are not in the trie any more
+    const uint8_t *alive = (c->store_removed && c->store_table_U == c->U) ? c->store_alive.as<uint8_t>() : nullptr;
     HIP_TRY(c, fqd::launch_contains(dq, dqo, n, c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), c->U, c->ks,
                                     c->d_alphabet.as<uint8_t>(), max_distance, metric, c->stage_c.as<uint32_t>(),
-                                    c->st));
+                                    c->st, alive));
     std::vector<uint32_t> flags((size_t)n);
     HIP_TRY(c, hipMemcpyAsync(flags.data(), c->stage_c.p, n * 4, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(c, stream_wait(c->st));
@@ -1273,3 +1279,11 @@ int fqd_synth_keys(fqd_ctx *c, uint8_t *out_device, uint64_t n_total, uint64_t s
 }
 
 }  // extern "C"
+
+// the collapse over c->recs with weights and ids that already sit on the device (api_trie.hip: the
+// resident unique table merged with new keys)
+int fqd_api_collapse_device(fqd_ctx *c, const uint32_t *d_weights, IdSource ids, uint64_t id_limit, uint64_t *n_unique)
+{
+    return collapse_impl(c, d_weights, FQD_DEVICE, ids, id_limit, n_unique);
+}
+

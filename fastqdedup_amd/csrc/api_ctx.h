@@ -147,6 +147,14 @@ struct fqd_ctx {
     uint64_t n_kept = 0, n_listed = 0;          // kept keys; kept keys whose first holder is in the id window
     uint64_t id_lo = 0, id_hi = ~0ull;
     DevBuf best, state, blocked, taint, root_taint, kept, kept_u32, kept_scan, kept_ids, kept_ids_sorted, kept_lists;
+    // the reference trie's view of the unique table (api_trie.hip): key order, census, clusters in pop order
+    DevBuf t_idx, t_order, t_order_b, t_rank, t_keys, t_keys_b, t_lcp, t_mark, t_mark_incl, t_stats, t_seed, t_heads,
+        t_heads_incl, t_member_uids, t_offsets;
+    uint64_t t_clusters = 0, t_members = 0;
+    bool t_clusters_valid = false;
+    // the unique table as a store (fqd_store_*): rows removed since the last merge, ids handed out
+    DevBuf store_alive, st_recs, st_lens, st_counts, st_first, st_comb_recs, st_comb_lens, st_comb_w, st_comb_ids;
+    uint64_t store_removed = 0, store_table_U = 0, store_next_id = 0;
     // scratch
     DevBuf tmp, stage_a, stage_b, stage_c, stage_d;
 
@@ -440,6 +448,9 @@ int scan_u32(fqd_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n)
 // helpers shared between the api_*.hip files (defined in the file named)
 int fqd_api_ensure_hashes(fqd_ctx *c);                 // api.hip
 int fqd_api_components_queue(fqd_ctx *c, bool flatten);   // api_graph.hip
+int fqd_api_flat_labels(fqd_ctx *c);                       // api_graph.hip
+// the collapse over c->recs with DEVICE weights and ids (api.hip)
+int fqd_api_collapse_device(fqd_ctx *c, const uint32_t *d_weights, IdSource ids, uint64_t id_limit, uint64_t *n_unique);
 int fqd_api_graph_preinit(fqd_ctx *c, int method);          // api_graph.hip
 extern "C" int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32_t B, bool slabs,
                                        const uint32_t **items_out, const uint32_t **bucket_end_out);   // api_search.hip

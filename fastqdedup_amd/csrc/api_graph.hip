@@ -470,4 +470,5 @@ int fqd_list_kept_except(fqd_ctx *c, const uint32_t *dropped, uint64_t n_dropped
 }  // extern "C"
 
 int fqd_api_components_queue(fqd_ctx *c, bool flatten) { return components_queue(c, flatten); }
+int fqd_api_flat_labels(fqd_ctx *c) { return ensure_flat_labels(c); }
 int fqd_api_graph_preinit(fqd_ctx *c, int method) { return graph_preinit(c, method); }

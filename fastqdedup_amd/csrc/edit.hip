@@ -271,11 +271,14 @@ __global__ __launch_bounds__(256) void contains_kernel(const uint8_t *__restrict
                                                        uint64_t nq, const uint32_t *__restrict__ urecs,
                                                        const uint32_t *__restrict__ ulens, uint64_t U, KeyShape sh,
                                                        const uint8_t *__restrict__ alphabet, int d, int metric,
-                                                       uint32_t *__restrict__ hit_flags)
+                                                       uint32_t *__restrict__ hit_flags,
+                                                       const uint8_t *__restrict__ alive /* NULL: every row */)
 {
     const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t qi = blockIdx.y;
     if (u >= U || qi >= nq)
+        return;
+    if (alive && !alive[u])
         return;
     const ByteSeq a{q + qo[qi]};
     const uint64_t la64 = qo[qi + 1] - qo[qi];
@@ -332,14 +335,14 @@ hipError_t launch_edit_verify(const uint64_t *cands, uint64_t C, const uint32_t 
 
 hipError_t launch_contains(const uint8_t *q, const uint64_t *qo, uint64_t nq, const uint32_t *urecs,
                            const uint32_t *ulens, uint64_t U, KeyShape sh, const uint8_t *alphabet_dev, int d,
-                           int metric, uint32_t *hit_flags, hipStream_t st)
+                           int metric, uint32_t *hit_flags, hipStream_t st, const uint8_t *alive)
 {
     if (!U || !nq)
         return hipSuccess;
     if (nq > 65535)
         return hipErrorInvalidValue;
     dim3 grid(grid_for(U), (unsigned)nq);
-    contains_kernel<<<grid, 256, 0, st>>>(q, qo, nq, urecs, ulens, U, sh, alphabet_dev, d, metric, hit_flags);
+    contains_kernel<<<grid, 256, 0, st>>>(q, qo, nq, urecs, ulens, U, sh, alphabet_dev, d, metric, hit_flags, alive);
     return hipGetLastError();
 }
 

@@ -208,6 +208,12 @@ hipError_t sort_keys_u64(void *tmp, size_t tmp_bytes, const uint64_t *kin, uint6
 size_t scan_u32_temp(uint64_t n);
 hipError_t inclusive_scan_u32(void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, uint64_t n,
                               hipStream_t st);
+size_t sort_pairs_u64_u32_temp(uint64_t n, int end_bit);
+hipError_t sort_pairs_u64_u32(void *tmp, size_t tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin,
+                              uint32_t *vout, uint64_t n, int end_bit, hipStream_t st);
+size_t scan_max_u32_temp(uint64_t n);
+hipError_t inclusive_scan_max_u32(void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, uint64_t n,
+                                  hipStream_t st);
 
 // pack.hip
 hipError_t launch_scan_bytes(const uint8_t *bytes, uint64_t n_bytes, uint32_t *present128_dev,
@@ -330,7 +336,7 @@ hipError_t launch_edit_verify(const uint64_t *cands, uint64_t C, const uint32_t 
                               uint64_t edge_cap, hipStream_t st);
 hipError_t launch_contains(const uint8_t *q, const uint64_t *qo, uint64_t nq, const uint32_t *urecs,
                            const uint32_t *ulens, uint64_t U, KeyShape sh, const uint8_t *alphabet_dev, int d,
-                           int metric, uint32_t *hit_flags, hipStream_t st);
+                           int metric, uint32_t *hit_flags, hipStream_t st, const uint8_t *alive = nullptr);
 
 // group.hip -- one search pass without a sort: two-level partition of (segment hash, uid) + one wave per bucket
 uint32_t group_tile_size();
@@ -432,6 +438,41 @@ hipError_t launch_directional_closed(const uint32_t *edges, uint64_t E, const ui
                                      uint32_t *best, int pass, hipStream_t st, uint32_t *roots /* 2 E words */);
 hipError_t launch_gather_kept(const uint32_t *kept_u32, const uint32_t *kept_scan, const uint64_t *ufirst,
                               uint64_t U, uint64_t *out, hipStream_t st);
+
+// trieorder.hip -- the reference trie's key order, node census and clusters in pop order
+hipError_t launch_trie_iota(uint32_t *out, uint64_t n, hipStream_t st);
+hipError_t launch_trie_chunk_keys(const uint32_t *order, uint64_t U, const uint32_t *urecs, const uint32_t *ulens,
+                                  KeyShape sh, const uint8_t *idx_of_code, uint32_t end_digit, uint32_t bits, uint32_t p0,
+                                  uint32_t P, unsigned long long *keys, hipStream_t st);
+hipError_t launch_trie_rank_of(const uint32_t *order, uint64_t U, uint32_t *rank, hipStream_t st);
+hipError_t launch_trie_lcp(const uint32_t *order, uint64_t U, const uint32_t *urecs, const uint32_t *ulens, KeyShape sh,
+                           uint32_t *lcp, hipStream_t st);
+hipError_t launch_trie_alive_mark(const uint32_t *order, uint64_t U, const uint8_t *alive, uint32_t *mark,
+                                  hipStream_t st);
+hipError_t launch_trie_census(const uint32_t *order, const uint32_t *lcp, uint64_t U, const uint32_t *urecs,
+                              const uint32_t *ulens, KeyShape sh, const uint8_t *idx_of_code, const uint8_t *alive,
+                              const uint32_t *last_alive, uint32_t n_layers, uint32_t n_cols, unsigned long long *stats,
+                              unsigned long long *memory_size, hipStream_t st);
+hipError_t launch_trie_seed_ranks(const uint32_t *labels, const uint32_t *rank, uint64_t U, const uint8_t *alive,
+                                  uint32_t *seed, hipStream_t st);
+hipError_t launch_trie_member_keys(const uint32_t *labels, const uint32_t *rank, uint64_t U, const uint8_t *alive,
+                                   const uint32_t *seed, unsigned long long *keys, hipStream_t st);
+hipError_t launch_trie_member_heads(const unsigned long long *sorted, uint64_t U, const uint32_t *order, uint32_t *heads,
+                                    uint32_t *members, hipStream_t st);
+hipError_t launch_trie_cluster_offsets(const unsigned long long *sorted, const uint32_t *heads, const uint32_t *heads_incl,
+                                       uint64_t U, unsigned long long *offsets, hipStream_t st);
+// one round of the lazy-alphabet search (see trieorder.hip)
+hipError_t launch_symbol_round(const uint32_t *order, const uint32_t *lcp, uint64_t U, const uint32_t *urecs,
+                               const uint32_t *ulens, KeyShape sh, const uint64_t *ufirst, const uint8_t *alive,
+                               const uint8_t *codes, uint32_t n_symbols, const unsigned long long *after,
+                               unsigned long long *cand, uint32_t *depth, unsigned long long *partner, hipStream_t st);
+// the unique table as a store: rows removed, merge weights (count, 0 for removed rows), ids base + i
+hipError_t launch_store_remove(const uint32_t *uids, uint64_t n, uint64_t U, uint8_t *alive, uint32_t *bad, hipStream_t st);
+hipError_t launch_store_weights(const uint32_t *counts, const uint8_t *alive, uint64_t U, uint32_t *out, hipStream_t st);
+hipError_t launch_store_fill_ids(uint64_t *out, uint64_t n, uint64_t base, hipStream_t st);
+// records of one geometry re-encoded into another (a store whose alphabet or key length grew)
+hipError_t launch_transcode_records(const uint32_t *src, const uint32_t *src_lens, uint64_t n, KeyShape from, KeyShape to,
+                                    const uint8_t *code_map, uint32_t *dst, uint32_t *dst_lens, hipStream_t st);
 
 // synth.hip
 hipError_t launch_synth(uint8_t *out, uint64_t n_total, uint64_t start, uint64_t count, uint32_t length,

@@ -242,6 +242,67 @@ int fqd_within_distance(fqd_ctx *ctx, const uint8_t *a_bytes, const uint64_t *a_
 int fqd_contains(fqd_ctx *ctx, const uint8_t *q_bytes, const uint64_t *q_offsets, uint64_t n,
                  int max_distance, int metric, uint8_t *out, int mem);
 
+/* ---- the Trie OBJECT as a device-resident store ------------------------------------
+ * The reference's Trie is filled one add_sequence at a time, emptied one pop_cluster at a time, and
+ * can be asked about its nodes in between (_triemodule.c:596-1009). These entry points give a host
+ * in any language the same object over the unique table of a context -- no host-side key list, no
+ * re-packing of what is already stored.
+ *
+ * `alphabet` (n_alpha symbols) is Trie.alphabet: the order of the child slots. It decides the order
+ * in which clusters are popped and the width of every node's child array; it must list every
+ * symbol that occurs in the keys. */
+
+/* Trie.add_sequence for a batch (_triemodule.c:677-706 -> TrieNode_AddSequence :222-288): the n new
+ * keys are merged into the context's unique table -- counts add up, the first holder of a key that
+ * was already stored stays -- and rows taken out with fqd_store_remove leave the table. On an empty
+ * context this is fqd_pack_keys + fqd_collapse. The geometry (alphabet, longest key, raggedness)
+ * grows as the new keys require; the stored records are re-encoded on the device. read_ids (NULL:
+ * consecutive numbers continuing the earlier batches) must ascend and exceed every id stored so
+ * far. Arguments otherwise as fqd_cluster_keys. uids of the table change with every call. */
+int fqd_store_add_keys(fqd_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, uint32_t fixed_len,
+                       int mem, const uint32_t *weights, const uint64_t *read_ids, int aux_mem, uint64_t *n_unique);
+/* The removal half of Trie.pop_cluster (TrieNode_DeleteSequence, _triemodule.c:301-363, called at
+ * :830 and :875): rows uids[0..n) of the unique table are no longer in the trie. fqd_contains,
+ * fqd_get_clusters and fqd_trie_stats skip them from now on; the rows themselves (and everybody's
+ * uid) stay until the next fqd_store_add_keys. */
+int fqd_store_remove(fqd_ctx *ctx, const uint32_t *uids, uint64_t n, int mem);
+int fqd_store_removed_count(const fqd_ctx *ctx, uint64_t *n_removed);
+/* After fqd_components: the remaining clusters in the order Trie.pop_cluster returns them
+ * (_triemodule.c:778-897: every cluster is seeded with the leftmost key left, TrieNode_GetSequence
+ * :510-551 -- child slots in alphabet order, a longer key before its own prefix), the members of a
+ * cluster in that same key order (the seed first). fqd_get_clusters computes, fqd_read_clusters
+ * copies out: offsets[n_clusters + 1] into member_uids[n_members] (rows of the unique table). */
+int fqd_get_clusters(fqd_ctx *ctx, const uint8_t *alphabet, uint32_t n_alpha, uint64_t *n_clusters,
+                     uint64_t *n_members);
+int fqd_read_clusters(fqd_ctx *ctx, uint64_t *offsets, uint32_t *member_uids, int mem);
+/* One round of the search for WHEN the reference's trie registers symbols that are not in its
+ * constructor alphabet (Trie.alphabet grows lazily: TrieNode_AddSequence registers a byte when an
+ * inner node first looks it up, _triemodule.c:266-273 -- base j of key k at the moment another key
+ * sharing k's first j bases is stored next to it). For each of symbols[0..n_symbols): among the
+ * stored keys added later than after[s] (first-holder id; ~0 = no bound) whose FIRST occurrence of
+ * the symbol lies at or above their longest common prefix with another stored key, the one added
+ * first: cand_first[s] (its first-holder id, ~0 = none), cand_depth[s] (position of the symbol),
+ * partner_first[s] (the earliest-added other key sharing that prefix). The symbol is looked up at
+ * time max(cand_first, partner_first); the caller repeats with after[s] = cand_first[s] while an
+ * earlier time is still possible (fastqdedup_amd/core.py). `alphabet` may be any listing of all
+ * symbols in the keys; reuse_order != 0 skips the sort when table and alphabet are unchanged since
+ * the previous round. HOST arrays; first-holder ids must lie below 2^32. */
+int fqd_store_symbol_events(fqd_ctx *ctx, const uint8_t *alphabet, uint32_t n_alpha, int reuse_order,
+                            const uint8_t *symbols, uint32_t n_symbols, const uint64_t *after, uint64_t *cand_first,
+                            uint32_t *cand_depth, uint64_t *partner_first);
+/* order_out[r] = row of the r-th key in that key order (all rows, removed or not). */
+int fqd_trie_order(fqd_ctx *ctx, const uint8_t *alphabet, uint32_t n_alpha, uint32_t *order_out, int mem);
+/* Trie.memory_size and Trie.raw_stats (_triemodule.c:909-964 over TrieNode_GetMemorySize /
+ * TrieNode_GetStats :553-594) of the trie the reference would hold after adding the table's keys
+ * and then deleting the removed ones: *memory_size = sum over leaves of 8 + suffix bytes and over
+ * inner nodes of 8 + 8 * child slots; stats[layer * (n_alpha + 1) + 0] = leaves in that layer,
+ * [.. + k] = inner nodes with k child slots (HOST array of n_layers * (n_alpha + 1) counters;
+ * n_layers = longest key ever added + 1). Exact for "adds, then pops" histories -- the ones
+ * deduplicate_cluster produces (__init__.py:240-281); an add into a partly popped trie is merged as
+ * if the popped keys had never been stored. */
+int fqd_trie_stats(fqd_ctx *ctx, const uint8_t *alphabet, uint32_t n_alpha, uint32_t n_layers, uint64_t *memory_size,
+                   uint64_t *stats);
+
 /* ---- the quality gate in front of the path ---------------------------------
  * _fastq.average_error_rate (reference _fastqmodule.c:38-76) over n phred strings as
  * deduplicate_cluster uses it (__init__.py:243-250): pass_out[i] = 0 when the mean of

@@ -79,3 +79,28 @@ def check_dissection(impl, ka):
             assert cluster == before, "input list must not be mutated"
             assert len(got) == len(set(got))
             assert set(got) == set(case[method]), (name, method)
+
+
+def check_trie_stats(impl, ka, lazy_alphabet=True):
+    """Trie.memory_size / raw_stats / pop order on the survey's measured known answer
+    (reference _triemodule.c:553-594, :909-964). lazy_alphabet: the implementation also reproduces
+    the order in which the reference's trie registers symbols outside the constructor alphabet."""
+    case = ka["trie_stats_known"]
+    trie = impl.Trie(case["alphabet"])
+    for k in case["adds"]:
+        trie.add_sequence(k)
+    assert trie.memory_size() == case["memory_size"]
+    assert trie.raw_stats() == case["raw_stats"]
+    assert trie.alphabet == case["alphabet"]
+    for want in case["pop_d1"]:
+        got = trie.pop_cluster(1)
+        assert sorted(k for _, k in got) == sorted(want)
+        assert got[0][1] == want[0]
+    assert trie.number_of_sequences == 0
+    assert trie.memory_size() == 0
+    for k in case["then_add"]:
+        trie.add_sequence(k)
+    if lazy_alphabet:
+        assert trie.alphabet == case["alphabet_after"]
+    else:
+        assert trie.alphabet.startswith(case["alphabet"]) and set(trie.alphabet) >= set("".join(case["then_add"]))

@@ -118,6 +118,33 @@ def test_pass2_rule_through_the_cli(F, tmp_path, caplog):
     assert "Found 2 distinct reads in 2 clusters." in text
 
 
+def test_debug_log_prints_the_references_trie_table(F, oracle, tmp_path, caplog):
+    """`-v`: the layer table of the reference's DEBUG log (__init__.py:133-157, :260-264), i.e. the
+    census of the trie built from the reads that passed the filter -- here from the device table,
+    compared with the oracle's real trie. Reads with an 'R' make the alphabet grow lazily."""
+    from fastqdedup_amd.cli import trie_stats
+    rng = random.Random(8)
+    mols = ["".join(rng.choice("ACGT") for _ in range(24)) for _ in range(150)]
+    recs = []
+    for i in range(1500):
+        s = "".join(rng.choice("ACGTNR") if rng.random() < 0.01 else ch for ch in rng.choice(mols))
+        recs.append((f"r{i}", s, "".join(chr(rng.choice([73, 73, 73, 40])) for _ in range(24))))
+    src, dst = str(tmp_path / "in.fastq"), str(tmp_path / "out.fastq")
+    _fq(src, recs)
+    with caplog.at_level(logging.DEBUG, logger="fastqdedup"):
+        logging.getLogger("fastqdedup").setLevel(logging.DEBUG)
+        try:
+            F.deduplicate_cluster([src], [dst], None, max_average_error_rate=0.05)
+        finally:
+            logging.getLogger("fastqdedup").setLevel(logging.NOTSET)
+    trie = oracle.Trie("ACGTN")
+    for _, s, q in recs:
+        if not oracle.average_error_rate(q) > 0.05:
+            trie.add_sequence(s)
+    assert "Calculated stats." in caplog.text
+    assert trie_stats(trie) in caplog.text
+
+
 @pytest.mark.parametrize("args", [
     dict(spec="16,16", d=1, thr=0.001, method="directional", edit=False, gz=True),
     dict(spec=None, d=2, thr=1.0, method="adjacency", edit=False, gz=False),

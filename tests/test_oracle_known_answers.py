@@ -56,3 +56,7 @@ def test_pass2_rule(oracle, known_answers):
     out = oracle.dedup(raw, off, w, max_distance=ka["d"], method=ka["method"])
     assert out["kept_read_ids"].tolist() == ka["kept_read_ids"]
     assert out["n_clusters"] == ka["n_clusters"]
+
+
+def test_trie_stats_known_answer(oracle, known_answers):
+    sc.check_trie_stats(oracle, known_answers, lazy_alphabet=True)
