@@ -47,7 +47,8 @@ EXPORTS = [
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
     "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_set_timing", "fqd_cluster_keys", "fqd_edge_stats", "fqd_synth_keys",
     "fqd_store_add_keys", "fqd_store_remove", "fqd_store_removed_count", "fqd_get_clusters", "fqd_read_clusters",
-    "fqd_trie_order", "fqd_trie_stats", "fqd_store_symbol_events",
+    "fqd_trie_order", "fqd_trie_stats", "fqd_store_symbol_events", "fqd_get_stream", "fqd_pack_collapse",
+    "fqd_cluster_subgraph", "fqd_owner_slab_geometry", "fqd_pack_to_owner_slabs", "fqd_collapse_owner_slabs",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -109,6 +110,8 @@ def load() -> C.CDLL:
     L.fqd_gather_unique.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_int]
     L.fqd_find_edges_segments.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, u64p]
     L.fqd_edge_labels.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, u64p, C.c_int]
+    L.fqd_cluster_subgraph.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, u64p, u64p,
+                                       C.c_int]
     L.fqd_list_kept_except.argtypes = [vp, vp, C.c_uint64, C.c_int, u64p]
     L.fqd_export_unique.argtypes = [vp, vp, vp, vp, vp, C.c_int]
     L.fqd_import_unique.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_int]
@@ -124,6 +127,15 @@ def load() -> C.CDLL:
     L.fqd_edge_stats.argtypes = [vp, u64p, u64p, u64p]
     L.fqd_synth_keys.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                  C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]
+    u32p = C.POINTER(C.c_uint32)
+    L.fqd_owner_slab_geometry.argtypes = [C.c_uint64, C.c_uint32, u32p, u32p, u32p]
+    L.fqd_pack_to_owner_slabs.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, u64p, C.POINTER(C.c_int)]
+    L.fqd_collapse_owner_slabs.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p,
+                                           C.c_uint64, C.c_uint64, C.c_uint32, u64p, C.POINTER(C.c_int)]
+    L.fqd_get_stream.argtypes = [vp]
+    L.fqd_get_stream.restype = C.c_void_p
+    L.fqd_pack_collapse.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp, C.c_int, C.c_uint32, u64p]
     L.fqd_store_add_keys.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp, C.c_int, u64p]
     L.fqd_store_remove.argtypes = [vp, vp, C.c_uint64, C.c_int]
     L.fqd_store_removed_count.argtypes = [vp, u64p]
@@ -228,6 +240,66 @@ class Context:
         mem = self._same_mem((km, True), (om, offsets is not None))
         self._ck(self._L.fqd_pack_keys(self._h, kp, op, n, int(key_len), mem))
         return n
+
+    @staticmethod
+    def owner_slab_geometry(n_max: int, n_parts: int):
+        """(hash bins per owner, slabs per bin, records per slab) of the fused multi-GPU way in."""
+        hb, subs, cap = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        rc = load().fqd_owner_slab_geometry(int(n_max), int(n_parts), C.byref(hb), C.byref(subs), C.byref(cap))
+        if rc:
+            raise ValueError("bad owner slab geometry")
+        return int(hb.value), int(subs.value), int(cap.value)
+
+    def pack_to_owner_slabs(self, keys, key_len: int, n_parts: int, n_segments: int, segment: int, geometry,
+                            slabs_out, cursors_out):
+        """fqd_pack_to_owner_slabs -> reads per owner (list), or None when the general way must be taken."""
+        kp, km, _k = _ptr_mem(keys)
+        nbytes = keys.numel() if hasattr(keys, "numel") else keys.size
+        n = nbytes // key_len if key_len > 0 else 0
+        sp, _sm, _s = _ptr_mem(slabs_out)
+        cp, _cm, _c = _ptr_mem(cursors_out)
+        hb, subs, cap = geometry
+        counts = (C.c_uint64 * n_parts)()
+        done = C.c_int(0)
+        self._ck(self._L.fqd_pack_to_owner_slabs(self._h, kp, n, int(key_len), km, int(n_parts), int(n_segments),
+                                                 int(segment), hb, subs, cap, sp, cp, counts, C.byref(done)))
+        return [int(x) for x in counts] if done.value else None
+
+    def collapse_owner_slabs(self, slabs, cursors, n_senders: int, my_part: int, geometry, sender_id0, id_limit: int,
+                             n_reads: int, search_segments: int = 0):
+        """fqd_collapse_owner_slabs -> unique keys, or None when the general way must be taken."""
+        sp, _sm, _s = _ptr_mem(slabs)
+        cp, _cm, _c = _ptr_mem(cursors)
+        hb, subs, cap = geometry
+        ids = (C.c_uint64 * n_senders)(*[int(x) for x in sender_id0])
+        u, done = C.c_uint64(0), C.c_int(0)
+        self._ck(self._L.fqd_collapse_owner_slabs(self._h, sp, cp, int(n_senders), int(my_part), hb, subs, cap, ids,
+                                                  int(id_limit), int(n_reads), int(search_segments), C.byref(u),
+                                                  C.byref(done)))
+        return int(u.value) if done.value else None
+
+    def stream_handle(self) -> int:
+        """The context's hipStream_t as an integer (torch.cuda.ExternalStream takes it)."""
+        return int(self._L.fqd_get_stream(self._h) or 0)
+
+    def pack_collapse(self, keys, offsets=None, key_len: int = 0, weights=None, read_ids=None,
+                      search_segments: int = 0) -> int:
+        """pack_keys + collapse in one C call (fqd_pack_collapse) -> unique keys."""
+        kp, km, _k = _ptr_mem(keys)
+        op, om, _o = _ptr_mem(offsets)
+        if offsets is None:
+            nbytes = keys.numel() if hasattr(keys, "numel") else keys.size
+            n = nbytes // key_len if key_len > 0 else 0
+        else:
+            n = (offsets.numel() if hasattr(offsets, "numel") else offsets.size) - 1
+        mem = self._same_mem((km, True), (om, offsets is not None))
+        wp, wm, _w = _ptr_mem(weights)
+        rp, rm, _r = _ptr_mem(read_ids)
+        aux = self._same_mem((wm, weights is not None), (rm, read_ids is not None))
+        u = C.c_uint64(0)
+        self._ck(self._L.fqd_pack_collapse(self._h, kp, op, n, int(key_len), mem, wp, rp, aux, int(search_segments),
+                                           C.byref(u)))
+        return int(u.value)
 
     def configure(self, present128: Optional[np.ndarray], max_len: int = 0, ragged: bool = False):
         if present128 is None:
@@ -414,6 +486,17 @@ class Context:
         nc = C.c_uint64(0)
         self._ck(self._L.fqd_edge_labels(self._h, ep, int(n_edges), int(n_nodes), rp, C.byref(nc), DEVICE))
         return nc.value
+
+    def cluster_subgraph(self, uv, roots, n_edges: int, n_nodes: int, n_parts: int, part: int, touched_out, sub_out):
+        """fqd_cluster_subgraph -> (number of touched nodes, number of edges of this part)."""
+        ep, _m, _0 = _ptr_mem(uv)
+        rp, _m, _1 = _ptr_mem(roots)
+        tp, _m, _2 = _ptr_mem(touched_out)
+        sp, _m, _3 = _ptr_mem(sub_out)
+        nt, ns = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._L.fqd_cluster_subgraph(self._h, ep, rp, int(n_edges), int(n_nodes), int(n_parts), int(part), tp,
+                                              sp, C.byref(nt), C.byref(ns), DEVICE))
+        return int(nt.value), int(ns.value)
 
     def list_kept_except(self, dropped, n_dropped: int) -> int:
         dp, dm, _0 = _ptr_mem(dropped)

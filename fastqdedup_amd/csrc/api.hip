@@ -115,6 +115,12 @@ int ensure_hashes(fqd_ctx *c)
 struct FusedLevel1 {
     uint32_t parts, sub_bits, B;
     uint32_t pack_bad = 0;     // out: the pack kernel met a byte outside the alphabet
+    // slabs received from several ranks (fqd_collapse_owner_slabs): level 1 has level1_bits hash bits
+    // (0: the usual 8), segment -> part is (segment >> sub_bits) & part_mask, and level 2 stamps the
+    // sender (segment / stamp_div) above the read index every record carries; the segment tables in
+    // c->ld_seg are filled by the caller (tables_ready)
+    uint32_t level1_bits = 0, part_mask = 0xFFFFFFFFu, stamp_div = 0;
+    bool tables_ready = false;
 };
 
 // Bucket bits of the LDS collapse for n reads: ~400-800 reads per bucket (2x fewer workgroups than
@@ -143,7 +149,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
     if (n < 32768 && !(force && !strcmp(force, "lds")))
         return FQD_OK;
     const uint32_t B = fused ? fused->B : lds_bucket_bits(n);
-    const uint32_t B1 = std::min<uint32_t>(B, 8), B2 = B - B1;
+    const uint32_t B1 = fused && fused->level1_bits ? fused->level1_bits : std::min<uint32_t>(B, 8), B2 = B - B1;
     const uint32_t bins1 = 1u << B1, bins2 = 1u << B2, n_buckets = 1u << B;
     const uint32_t kw = sh.planes * sh.words, tile = fqd::part_tile_size();
     const uint32_t tiles1 = (uint32_t)((n + tile - 1) / tile), max_tiles2 = tiles1 + bins1;
@@ -214,7 +220,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
             HIP_TRY(c, hipMemcpyAsync(c->ld_start.p, start1, ((size_t)bins1 + 1) * 4, hipMemcpyDeviceToDevice, c->st));
         } else {
             // ---- level 2: every part into 2^B2 buckets by the next B2 hash bits
-            if (fused)
+            if (fused)     // (the pack kernel left seg_start / seg_end = cursors there; received slabs: the caller did)
                 HIP_TRY(c, fqd::launch_slab_tile_starts(f_seg_start, f_seg_end, f_parts, f_tiles, c->st));
             else
                 HIP_TRY(c, fqd::launch_tile_starts(start1, bins1, tiles2_d, c->st));
@@ -234,7 +240,8 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(
                           false, nullptr, c->ld_part.as<uint32_t>(), f_seg_start, f_tiles, f_parts, tiles1 + f_parts,
                           32 - B, bins2, kw, sh.max_len, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<uint32_t>(), c->st,
-                          IdSource(), slab_cap, c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end, fused->sub_bits));
+                          fused->stamp_div ? d_ids : IdSource(), slab_cap, c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end,
+                          fused->sub_bits, fused->part_mask, fused->stamp_div));
             else
                 KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(
                           false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1, max_tiles2, 32 - B, bins2,
@@ -513,6 +520,8 @@ int fqd_synchronize(fqd_ctx *c)
     HIP_TRY(c, stream_wait(c->st));
     return FQD_OK;
 }
+
+void *fqd_get_stream(fqd_ctx *c) { return c ? (void *)c->st : nullptr; }
 
 int fqd_configure(fqd_ctx *c, const uint8_t *present128, uint32_t max_len, int ragged)
 {
@@ -916,6 +925,203 @@ static int pack_collapse_fused(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uin
     return FQD_OK;
 }
 
+// ---- multi-GPU: the fused way in, across ranks -----------------------------------------------
+// A rank packs its reads straight into owner-major slabs (bin = owner * hash_bins + top hash bits,
+// `subs` slabs per bin); an owner's share is one contiguous range of slabs that the all-to-all
+// moves as it is -- capacity included: the slack is what contiguity costs, 12 standard deviations
+// of a Poisson slab + 64 records, ~1.16 x at 50 M reads -- and the receiving rank's collapse starts
+// at level 2, reading the slabs of all senders in place. Per read and rank: one pass over the key
+// bytes and one partition pass, like the single-GPU path (the general way -- fqd_pack_keys, grouping
+// by owner, level 1 and level 2 at the receiver -- makes four).
+int fqd_owner_slab_geometry(uint64_t n_max, uint32_t n_parts, uint32_t *hash_bins, uint32_t *subs, uint32_t *cap)
+{
+    if (!n_parts || n_parts > 256 || !hash_bins || !subs || !cap)
+        return FQD_E_VALUE;
+    uint32_t hb = 1;
+    while (hb * 2 * n_parts <= 256)
+        hb *= 2;
+    *hash_bins = hb;
+    *subs = 32;
+    const uint64_t parts = (uint64_t)n_parts * hb * 32;
+    const double mean = (double)n_max / (double)parts;
+    *cap = (uint32_t)(((uint64_t)(mean + 12.0 * std::sqrt(mean) + 64.0) + 3) & ~3ull);
+    return FQD_OK;
+}
+
+int fqd_pack_to_owner_slabs(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uint32_t fixed_len, int mem, uint32_t n_parts,
+                            uint32_t n_segments, uint32_t segment, uint32_t hash_bins, uint32_t subs, uint32_t cap,
+                            uint32_t *slabs_out, uint32_t *cursors_out, uint64_t *counts, int *done)
+{
+    FQD_TRY(bind(c));
+    if (!done || !counts || !slabs_out || !cursors_out)
+        return fail(c, FQD_E_VALUE, "fqd_pack_to_owner_slabs: missing output");
+    *done = 0;
+    const uint32_t n_bins = n_parts * hash_bins, parts = n_bins * subs;
+    if (!n_parts || n_bins > 256 || (hash_bins & (hash_bins - 1)) || subs != 32 || !cap || !n_segments ||
+        segment >= n_segments || ((uintptr_t)slabs_out & 15u))
+        return fail(c, FQD_E_VALUE, "fqd_pack_to_owner_slabs: bad geometry");
+    std::fill(counts, counts + n_parts, 0ull);
+    if (getenv("FQD_NO_FUSED_PACK") || !fixed_len || n >= 0xFFFFFF00ull || (uint64_t)parts * cap + n >= 0xFFFFFF00ull)
+        return FQD_OK;
+    if (mem == FQD_DEVICE && ((uintptr_t)bytes & 15u))
+        return FQD_OK;
+    uint8_t present[128], lut[256];
+    if (c->forced) {
+        if (c->forced_ragged || c->forced_max_len != fixed_len)
+            return FQD_OK;
+        memcpy(present, c->forced_present, 128);
+    } else {
+        memset(present, 0, sizeof present);
+        for (const char *p = "ACGNT"; *p; p++)
+            present[(int)*p] = 1;
+    }
+    c->stage = ST_EMPTY;
+    build_alphabet(c, present, lut);
+    FQD_TRY(set_geometry(c, fixed_len, 0));
+    const KeyShape sh = c->ks;
+    if (sh.stride != 4 || sh.planes * sh.words > 3)
+        return FQD_OK;                       // longer records travel the general way
+    FQD_TRY(upload_lut(c, lut));
+    const uint64_t n_bytes = n * (uint64_t)fixed_len;
+    const uint8_t *d_bytes;
+    StageTimer pack_timer(c, FQD_T_PACK);
+    FQD_TRY(to_device(c, bytes, (size_t)n_bytes, mem, c->in_bytes, &d_bytes));
+    HIP_TRY(c, c->ld_seg.reserve((size_t)(parts + 4) * 4));
+    FQD_TRY(zero_ctr32(c, 0, C_N32));
+    // cursor p starts at the first slot of slab p (in the caller's buffers)
+    HIP_TRY(c, fqd::launch_slab_starts(parts, cap, c->ld_seg.as<uint32_t>(), cursors_out, c->st));
+    uint32_t hb_bits = 0;
+    while ((1u << hb_bits) < hash_bins)
+        hb_bits++;
+    fqd::PackScatter fs{cursors_out, reinterpret_cast<uint4 *>(slabs_out), c->d_ctr32.as<uint32_t>() + C_BAD,
+                        32 - hb_bits, n_bins, subs, cap};
+    fs.owner_parts = n_parts;
+    fs.owner_hb = hash_bins;
+    const fqd::OwnerRule rule{n_parts, n_segments, segment};
+    if (n) {
+        StageTimer kernel_timer(c, FQD_T_PACK_KERNEL);
+        KTIME(c, FQD_K_PACK, fqd::launch_pack(d_bytes, n_bytes, nullptr, n, fixed_len, sh, c->d_lut.as<uint8_t>(), lut,
+                                              nullptr, nullptr, nullptr, nullptr, rule,
+                                              c->d_ctr32.as<uint32_t>() + C_PACKBAD, c->st, &fs));
+        kernel_timer.stop();
+    }
+    // the fill of every slab (for the part sizes), the overflow and foreign-byte flags: one wait
+    std::vector<uint32_t> cur(parts);
+    uint32_t flags[C_PACKBAD + 1];
+    HIP_TRY(c, hipMemcpyAsync(cur.data(), cursors_out, (size_t)parts * 4, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipMemcpyAsync(flags, c->d_ctr32.p, sizeof flags, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, stream_wait(c->st));
+    pack_timer.stop();
+    c->n = n;
+    c->hashes_valid = false;
+    c->recs_valid = false;
+    c->owners_done = fqd::OwnerRule{};
+    if ((flags[C_BAD] & 4u) || flags[C_PACKBAD])
+        return FQD_OK;                       // a slab overflowed, or a byte outside the alphabet: the general way
+    for (uint32_t p = 0; p < parts; p++)
+        counts[p / (hash_bins * subs)] += std::min<uint64_t>(cur[p] - (uint64_t)p * cap, cap);
+    *done = 1;
+    return FQD_OK;
+}
+
+int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *cursors, uint32_t n_senders,
+                             uint32_t my_part, uint32_t hash_bins, uint32_t subs, uint32_t cap, const uint64_t *sender_id0,
+                             uint64_t id_limit, uint64_t n_reads, uint32_t search_segments, uint64_t *n_unique, int *done)
+{
+    FQD_TRY(bind(c));
+    if (!done || !slabs || !cursors || !sender_id0)
+        return fail(c, FQD_E_VALUE, "fqd_collapse_owner_slabs: missing argument");
+    *done = 0;
+    const uint32_t ppo = hash_bins * subs;              // slabs per (sender, owner)
+    const uint64_t parts64 = (uint64_t)n_senders * ppo;
+    if (!n_senders || !hash_bins || (hash_bins & (hash_bins - 1)) || subs != 32 || !cap || parts64 > 65536 ||
+        ((uintptr_t)slabs & 15u))
+        return fail(c, FQD_E_VALUE, "fqd_collapse_owner_slabs: bad geometry");
+    if (!c->shape.planes || c->ks.stride != 4 || c->ks.ragged || c->ks.planes * c->ks.words > 3)
+        return fail(c, FQD_E_STATE, "fqd_collapse_owner_slabs needs the geometry of one-uint4 records");
+    const uint32_t parts = (uint32_t)parts64;
+    if (parts64 * cap + n_reads >= 0xFFFFFF00ull || n_reads >= 0xFFFFFF00ull)
+        return FQD_OK;
+    // (sender, read index on the sender) must fit the record's spare word
+    uint64_t max_local = 0;
+    for (uint32_t s = 0; s < n_senders; s++) {
+        const uint64_t next = s + 1 < n_senders ? sender_id0[s + 1] : id_limit;
+        if (id_limit == ~0ull || next < sender_id0[s])
+            return FQD_OK;
+        max_local = std::max(max_local, next - sender_id0[s]);
+    }
+    uint32_t lb = 1, sb = 0;
+    while (lb < 32 && (max_local >> lb))
+        lb++;
+    while ((1u << sb) < n_senders)
+        sb++;
+    if (lb + sb > 32 || lb >= 32)
+        return FQD_OK;
+    uint32_t hb_bits = 0;
+    while ((1u << hb_bits) < hash_bins)
+        hb_bits++;
+    uint32_t B = std::max<uint32_t>(lds_bucket_bits(n_reads), hb_bits + 1);
+    B = std::min<uint32_t>(B, hb_bits + 10);             // level 2 has at most 1024 bins
+    if (!hb_bits)
+        return FQD_OK;                                   // (more than 128 ranks: the general way)
+    c->stage = ST_EMPTY;
+    c->n = n_reads;
+    c->U = 0;
+    c->n_counted = 0;
+    c->hashes_valid = false;
+    c->recs_valid = false;
+    c->owners_done = fqd::OwnerRule{};
+    StageTimer timer(c, FQD_T_COLLAPSE);
+    if (!n_reads) {
+        timer.stop();
+        c->collapsed = true;
+        c->first_distinct = true;
+        set_id_range(c, id_limit);
+        c->stage = ST_UNIQUE;
+        if (n_unique)
+            *n_unique = 0;
+        *done = 1;
+        return FQD_OK;
+    }
+    // segment tables: seg_start (parts + 1) | seg_end (parts) | tile_start (parts + 1), 4 words apart
+    HIP_TRY(c, c->ld_seg.reserve((size_t)3 * (parts + 4) * 4));
+    uint32_t *seg_start = c->ld_seg.as<uint32_t>(), *seg_end = seg_start + (parts + 4);
+    HIP_TRY(c, fqd::launch_owner_slab_bounds(cursors, n_senders, ppo, my_part, cap, seg_start, seg_end, c->st));
+    c->ld_part.borrow(slabs, (size_t)parts * cap * 16);
+    // id bases of the senders on the device
+    HIP_TRY(c, c->seg_tab.reserve((size_t)n_senders * 8 + 16));
+    HIP_TRY(c, hipMemcpyAsync(c->seg_tab.p, sender_id0, (size_t)n_senders * 8, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, stream_wait(c->st));
+    IdSource ids;
+    ids.seg_id0 = c->seg_tab.as<uint64_t>();
+    ids.n_seg = n_senders;
+    ids.packed_bits = lb;
+    FQD_TRY(zero_ctr32(c, 0, C_N32));
+    FusedLevel1 f{parts, 5, B};
+    f.level1_bits = hb_bits;
+    f.part_mask = hash_bins - 1;
+    f.stamp_div = ppo;
+    f.tables_ready = true;
+    c->seg_hint = search_segments <= 4 ? search_segments : 0;
+    bool ok = false;
+    const int rc = collapse_lds(c, nullptr, ids, &ok, &f);
+    c->seg_hint = 0;
+    c->ld_part.unborrow();
+    timer.stop();
+    FQD_TRY(rc);
+    if (!ok)
+        return FQD_OK;
+    c->collapse_path = 1;
+    c->collapsed = true;
+    c->first_distinct = true;
+    set_id_range(c, id_limit);
+    c->stage = ST_UNIQUE;
+    if (n_unique)
+        *n_unique = c->U;
+    *done = 1;
+    return FQD_OK;
+}
+
 int fqd_collapse(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, int mem, uint64_t *n_unique)
 {
     FQD_TRY(bind(c));
@@ -1007,6 +1213,28 @@ int fqd_cluster(fqd_ctx *c, const uint32_t *weights, const uint64_t *read_ids, i
     c->seg_hint = 0;
     FQD_TRY(rc);
     return cluster_tail(c, max_distance, metric, method, out);
+}
+
+int fqd_pack_collapse(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, uint32_t fixed_len, int mem,
+                      const uint32_t *weights, const uint64_t *read_ids, int aux_mem, uint32_t search_segments,
+                      uint64_t *n_unique)
+{
+    FQD_TRY(bind(c));
+    bool done = false;
+    c->seg_hint = search_segments <= 4 ? search_segments : 0;
+    int rc = FQD_OK;
+    if (!offsets && !read_ids)
+        rc = pack_collapse_fused(c, bytes, n, fixed_len, mem, weights, aux_mem, &done);
+    if (rc == FQD_OK && !done) {
+        rc = fqd_pack_keys(c, bytes, offsets, n, fixed_len, mem);
+        if (rc == FQD_OK)
+            rc = fqd_collapse(c, weights, read_ids, aux_mem, nullptr);
+    }
+    c->seg_hint = 0;
+    FQD_TRY(rc);
+    if (n_unique)
+        *n_unique = c->U;
+    return FQD_OK;
 }
 
 int fqd_cluster_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, uint32_t fixed_len, int mem,

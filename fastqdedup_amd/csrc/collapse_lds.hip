@@ -44,7 +44,14 @@ struct RecordPolicy {
         const uint4 *in;
         uint32_t kw, len;
         IdSource ids;             // ids.packed_bits != 0: level 1 stamps (segment, local index), see IdSource
+        uint32_t stamp_div;       // != 0 (level 2 over slabs received from several ranks): segment / stamp_div is
+                                  // the sender, stamped above the read index the record carries
     };
+    static __device__ __forceinline__ uint32_t segment_tag(const Source &s, uint32_t seg)
+    {
+        return s.stamp_div ? (seg / s.stamp_div) << s.ids.packed_bits : 0u;
+    }
+    static __device__ __forceinline__ void apply_tag(uint4 &v, uint32_t tag) { v.w |= tag; }
     template <bool LEVEL1>
     static __device__ __forceinline__ uint32_t load(const Source &s, uint32_t i, uint4 &v)
     {
@@ -100,10 +107,27 @@ __global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter_kernel(Re
                                                                               uint32_t slab_cap,
                                                                               uint32_t *__restrict__ slab_overflow,
                                                                               const uint32_t *__restrict__ seg_end,
-                                                                              uint32_t seg_shift)
+                                                                              uint32_t seg_shift, uint32_t seg_mask)
 {
     fqd_partition::scatter_body<RecordPolicy, LEVEL1, MAXB>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
-                                                            slab_cap, slab_overflow, seg_end, seg_shift);
+                                                            slab_cap, slab_overflow, seg_end, seg_shift, seg_mask);
+}
+
+// slabs received from n_senders ranks, sender by sender: segment s = sender * ppo + j holds the
+// sender's slab my_part * ppo + j, whose cursor started at that slab's first slot ON THE SENDER
+__global__ void owner_slab_bounds_kernel(const uint32_t *__restrict__ cursors, uint32_t n_senders, uint32_t ppo,
+                                         uint32_t my_part, uint32_t cap, uint32_t *__restrict__ seg_start,
+                                         uint32_t *__restrict__ seg_end)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x, n = n_senders * ppo;
+    if (s > n)
+        return;
+    seg_start[s] = s * cap;
+    if (s < n) {
+        const uint32_t first = (my_part * ppo + s % ppo) * cap;
+        const uint32_t fill = cursors[s] > first ? cursors[s] - first : 0u;
+        seg_end[s] = s * cap + (fill < cap ? fill : cap);
+    }
 }
 
 __global__ __launch_bounds__(1024) void slab_tile_starts_kernel(const uint32_t *__restrict__ seg_start,
@@ -358,7 +382,7 @@ hipError_t launch_part_hist(bool level1, const uint32_t *hashes, const uint32_t 
 {
     if (n_bins > fqd_partition::MAX_BINS)
         return hipErrorInvalidValue;
-    const RecordPolicy::Source src{hashes, reinterpret_cast<const uint4 *>(in), kw, len, IdSource()};
+    const RecordPolicy::Source src{hashes, reinterpret_cast<const uint4 *>(in), kw, len, IdSource(), 0u};
     if (level1)
         part_hist_kernel<true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, shift,
                                                                              n_bins, hist);
@@ -372,17 +396,17 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
                                const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
                                hipStream_t st, IdSource packed, uint32_t slab_cap, uint32_t *slab_overflow,
-                               const uint32_t *seg_end, uint32_t seg_shift)
+                               const uint32_t *seg_end, uint32_t seg_shift, uint32_t seg_mask, uint32_t stamp_div)
 {
     if (n_bins > fqd_partition::MAX_BINS)
         return hipErrorInvalidValue;
-    const RecordPolicy::Source src{hashes, reinterpret_cast<const uint4 *>(in), kw, len, packed};
+    const RecordPolicy::Source src{hashes, reinterpret_cast<const uint4 *>(in), kw, len, packed, stamp_div};
     uint4 *out4 = reinterpret_cast<uint4 *>(out);
     // few bins (the usual 256): small bin tables, one more workgroup per CU
 #define FQD_SCATTER(L1, MB)                                                                                    \
     part_scatter_kernel<L1, MB><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, \
                                                                               shift, n_bins, cursor, out4, slab_cap, \
-                                                                              slab_overflow, seg_end, seg_shift)
+                                                                              slab_overflow, seg_end, seg_shift, seg_mask)
     if (n_bins <= 256) {
         if (level1) FQD_SCATTER(true, 256); else FQD_SCATTER(false, 256);
     } else {
@@ -393,6 +417,16 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
 }
 
 uint32_t part_tile_size() { return fqd_partition::THREADS * RecordPolicy::EPT; }
+
+hipError_t launch_owner_slab_bounds(const uint32_t *cursors, uint32_t n_senders, uint32_t parts_per_owner,
+                                    uint32_t my_part, uint32_t cap, uint32_t *seg_start, uint32_t *seg_end,
+                                    hipStream_t st)
+{
+    const uint32_t n = n_senders * parts_per_owner + 1;
+    owner_slab_bounds_kernel<<<(n + 255) / 256, 256, 0, st>>>(cursors, n_senders, parts_per_owner, my_part, cap, seg_start,
+                                                             seg_end);
+    return hipGetLastError();
+}
 
 hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                 hipStream_t st)

@@ -231,6 +231,9 @@ struct PackScatter {
     uint32_t *overflow;    // bit 4: some part's slab was full
     uint32_t shift, n_bins, subs, cap;
     uint32_t tables_at;    // set by launch_pack: LDS word offset of the partition tables
+    // owner-major bins (multi-GPU): bin = owner * owner_hb + top log2(owner_hb) hash bits, owner by the
+    // OwnerRule handed to launch_pack; n_bins = owner_parts * owner_hb. 0: plain hash bins.
+    uint32_t owner_parts = 0, owner_hb = 0;
 };
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
                        uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, const uint8_t *lut_host,
@@ -272,7 +275,11 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
                                hipStream_t st, IdSource packed = IdSource(), uint32_t slab_cap = 0,
                                uint32_t *slab_overflow = nullptr, const uint32_t *seg_end = nullptr,
-                               uint32_t seg_shift = 0);
+                               uint32_t seg_shift = 0, uint32_t seg_mask = 0xFFFFFFFFu, uint32_t stamp_div = 0);
+// slab segments of reads received from n_senders ranks (fqd_collapse_owner_slabs)
+hipError_t launch_owner_slab_bounds(const uint32_t *cursors, uint32_t n_senders, uint32_t parts_per_owner,
+                                    uint32_t my_part, uint32_t cap, uint32_t *seg_start, uint32_t *seg_end,
+                                    hipStream_t st);
 hipError_t launch_slab_tile_starts(const uint32_t *seg_start, const uint32_t *seg_end, uint32_t n_seg,
                                    uint32_t *tile_start, hipStream_t st);
 uint32_t part_tile_size();
@@ -407,6 +414,10 @@ hipError_t launch_window_emit(const uint8_t *flags, uint64_t n, const uint32_t *
 hipError_t launch_hook_total(const unsigned long long *slots, uint64_t n_nodes, unsigned long long *n_components,
                              hipStream_t st);
 hipError_t launch_edge_roots(uint32_t *parent, const uint32_t *edges, uint64_t E, uint32_t *roots, hipStream_t st);
+hipError_t launch_subgraph_mark(const uint32_t *uv, const uint32_t *roots, uint64_t E, uint32_t n_parts, uint32_t part,
+                                uint32_t *flags, uint32_t *sub, unsigned long long *n_sub, hipStream_t st);
+hipError_t launch_subgraph_finish(const uint32_t *flags, const uint32_t *flags_incl, uint64_t n_nodes, uint64_t E,
+                                  uint32_t *touched, uint32_t *sub, const unsigned long long *n_sub, hipStream_t st);
 hipError_t launch_check_indices(const uint32_t *idx, uint64_t n, uint64_t limit, uint32_t *bad, hipStream_t st);
 hipError_t launch_mark_dropped(uint8_t *state, uint64_t U, const uint32_t *dropped, uint64_t n, uint32_t *bad,
                                hipStream_t st);

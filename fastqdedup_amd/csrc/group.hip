@@ -42,6 +42,8 @@ struct PairPolicy {
     {
         return LEVEL1 ? s.hashes[i] : s.in[i].x;
     }
+    static __device__ __forceinline__ uint32_t segment_tag(const Source &, uint32_t) { return 0u; }
+    static __device__ __forceinline__ void apply_tag(uint2 &, uint32_t) {}
 };
 
 template <bool LEVEL1>

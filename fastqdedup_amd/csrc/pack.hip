@@ -287,7 +287,15 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
                 const uint32_t rec[3] = {v[e].x, v[e].y, v[e].z};
                 const uint32_t h = fqd_hash_record(rec, W * K, fixed_len);
                 v[e].w = (uint32_t)(key0 + k);               // the read index travels with the record
-                bin[e] = (h >> fs.shift) & (fs.n_bins - 1);
+                if (fs.owner_parts) {
+                    // multi-GPU: the bins are owner-major (owner = rank the read goes to, the pigeonhole
+                    // rule of fqd_set_owner_rule), hash bins inside -- an owner's reads leave as ONE
+                    // range of slabs that is already level 1 of the receiver's collapse
+                    const uint32_t owner = fqd_segment_hash(rec, K, W * K, fixed_len, rule.seg, rule.nseg) % fs.owner_parts;
+                    bin[e] = owner * fs.owner_hb + (fs.owner_hb > 1 ? h >> fs.shift : 0u);
+                } else {
+                    bin[e] = (h >> fs.shift) & (fs.n_bins - 1);
+                }
                 rank[e] = atomicAdd(&s_hist[bin[e]], 1u);
             }
         }
@@ -471,7 +479,10 @@ hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *o
     PackScatter fs{};
     if (fused) {
         if (offsets || sh.ragged || sh.stride != 4 || sh.planes > 3 || kpb > 1024 || fused->n_bins > 256 ||
-            (fused->n_bins & (fused->n_bins - 1)) || (fused->subs & (fused->subs - 1)) || owners)
+            (!fused->owner_parts && (fused->n_bins & (fused->n_bins - 1))) || (fused->subs & (fused->subs - 1)) || owners)
+            return hipErrorInvalidValue;
+        if (fused->owner_parts && (fused->owner_parts * fused->owner_hb != fused->n_bins ||
+                                   (fused->owner_hb & (fused->owner_hb - 1)) || rule.parts != fused->owner_parts))
             return hipErrorInvalidValue;
         fs = *fused;
         const uint32_t tables = (3 * fs.n_bins + 4) * 4 + kpb * 2, streams = sh.planes * plane_words * 4;

@@ -17,6 +17,7 @@
 //   using Item = ...;  struct Source { ... };
 //   template <bool LEVEL1> static __device__ uint32_t key(const Source &, uint32_t i);          // histogram pass
 //   template <bool LEVEL1> static __device__ uint32_t load(const Source &, uint32_t i, Item &); // scatter pass, returns the key
+//   static __device__ uint32_t segment_tag(const Source &, uint32_t segment);  static __device__ void apply_tag(Item &, uint32_t tag);
 #pragma once
 #include "fqd_internal.h"
 
@@ -101,11 +102,14 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
                                              uint32_t n_bins, uint32_t *__restrict__ cursor,
                                              typename Policy::Item *__restrict__ out, uint32_t slab_cap = 0,
                                              uint32_t *__restrict__ slab_overflow = nullptr,
-                                             const uint32_t *__restrict__ seg_end = nullptr, uint32_t seg_shift = 0)
+                                             const uint32_t *__restrict__ seg_end = nullptr, uint32_t seg_shift = 0,
+                                             uint32_t seg_mask = 0xFFFFFFFFu)
 {
     // seg_end / seg_shift (level 2 behind the fused pack, pack.hip): the input segments are slabs
     // [seg_start[s], seg_end[s]) and 2^seg_shift consecutive segments are sub-parts of ONE level-1
-    // part -- they feed the same buckets.
+    // part -- they feed the same buckets. seg_mask: slabs received from several ranks come sender by
+    // sender, each sender's in part order: part = (segment >> seg_shift) & seg_mask. Policy::segment_tag
+    // / apply_tag mark every loaded item with something derived from its (unshifted) segment.
     // slab_cap != 0 (level 2 only): bucket k owns out[k * slab_cap, (k + 1) * slab_cap) and its cursor
     // started at k * slab_cap -- no histogram pass told us how full it gets. Items that would land
     // behind the slab's end are dropped and *slab_overflow gets bit 1: the caller redoes the level
@@ -126,7 +130,8 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
     uint32_t seg, lo, hi;
     if (!tile_of_block<TILE>(seg_start, tile_start, n_seg, seg, lo, hi, seg_end))
         return;
-    seg >>= seg_shift;
+    const uint32_t seg_tag = Policy::segment_tag(src, seg);       // (per workgroup: a tile lies in ONE segment)
+    seg = (seg >> seg_shift) & seg_mask;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t b = tid; b < n_bins; b += THREADS)
         s_hist[b] = 0;
@@ -136,8 +141,10 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
     for (uint32_t e = 0; e < EPT; e++) {
         const uint32_t i = lo + e * THREADS + tid;
         h[e] = 0;
-        if (i < hi)
+        if (i < hi) {
             h[e] = Policy::template load<LEVEL1>(src, i, v[e]);
+            Policy::apply_tag(v[e], seg_tag);
+        }
     }
     __syncthreads();
 #pragma unroll

@@ -70,6 +70,7 @@ class HipBackend:
         self.device = device
         self._aux = None      # second context: routed search passes and the clusters dissected here
         self._geometry = None
+        self._ext = {}        # the contexts' HIP streams as torch sees them (ordering by stream waits)
 
     # ---- geometry -------------------------------------------------------------------
     def scan(self, keys, offsets, key_len):
@@ -84,6 +85,18 @@ class HipBackend:
         sh = self.ctx.shape()
         self.stride = int(sh.stride_words)
         self.ragged = bool(sh.ragged)
+
+    def lib_streams(self):
+        """The streams the library works on (one per context in use), as torch stream objects."""
+        if self.device.type != "cuda":
+            return []
+        out = []
+        for c in (self.ctx, self._aux):
+            if c is not None and c.stream_handle():
+                if id(c) not in self._ext:
+                    self._ext[id(c)] = torch.cuda.ExternalStream(c.stream_handle(), device=self.device)
+                out.append(self._ext[id(c)])
+        return out
 
     @property
     def aux(self) -> Context:
@@ -123,6 +136,34 @@ class HipBackend:
         else:
             counts = self.ctx.export_packed_by_owner(n_parts, id0, w_in, recs, lens, ids, w_out)
         return recs, lens, ids, w_out, [int(c) for c in counts]
+
+    # ---- reads -> owner, the fused way (short fixed-length keys, no weights) -------------------
+    def pack_to_owner_slabs(self, keys, key_len, n_parts, n_segments, n_max):
+        """Pack straight into owner-major slabs (fqd_pack_to_owner_slabs): (slab records as rows of
+        4 words, cursors, reads per owner, geometry), or None when the general way must be taken."""
+        geometry = Context.owner_slab_geometry(n_max, n_parts)
+        hb, subs, cap = geometry
+        parts = n_parts * hb * subs
+        if parts * cap * 16 > (64 << 30):
+            return None
+        slabs = torch.empty((parts * cap, 4), dtype=torch.int32, device=self.device)
+        cursors = torch.empty(parts, dtype=torch.int32, device=self.device)
+        counts = self.ctx.pack_to_owner_slabs(keys, key_len, n_parts, n_segments, 0, geometry, slabs, cursors)
+        if counts is None:
+            return None
+        sh = self.ctx.shape()
+        self.stride = int(sh.stride_words)
+        self.ragged = bool(sh.ragged)
+        return slabs, cursors, counts, geometry
+
+    def collapse_owner_slabs(self, slabs, cursors, n_senders, my_part, geometry, sender_id0, id_limit, n_reads,
+                             search_segments):
+        """The receiving side (fqd_collapse_owner_slabs): unique keys of this rank, or None."""
+        nu = self.ctx.collapse_owner_slabs(slabs, cursors, n_senders, my_part, geometry, sender_id0, id_limit, n_reads,
+                                           search_segments)
+        if nu is not None:
+            self.n_unique_local = nu
+        return nu
 
     def collapse_resident(self, recs, lens, weights, read_ids, seg_rows=None, seg_id0=None, id_limit=None) -> int:
         """Collapse the received reads; the unique table stays in the context. read_ids None: the
@@ -175,6 +216,17 @@ class HipBackend:
         n_components = self.ctx.edge_labels(edges, edges.shape[0], n_nodes, roots)
         return roots, n_components
 
+    def cluster_subgraph(self, edges, roots, n_nodes, n_parts, part):
+        """This rank's clusters out of the job-wide edge list: (touched nodes ascending, their
+        edges renumbered to positions in that list) -- fqd_cluster_subgraph."""
+        n_edges = int(edges.shape[0])
+        touched = torch.empty(min(2 * n_edges, n_nodes), dtype=torch.int32, device=self.device)
+        sub = torch.empty((n_edges, 2), dtype=torch.int32, device=self.device)
+        if not n_edges:
+            return touched, sub
+        nt, ns = self.ctx.cluster_subgraph(edges, roots, n_edges, n_nodes, n_parts, part, touched, sub)
+        return touched[:nt], sub[:ns]
+
     def gather_unique(self, rows):
         n = rows.shape[0]
         recs, lens = self._rows(n)
@@ -189,7 +241,11 @@ class HipBackend:
         self.aux.declare_distinct_keys()      # rows of collapsed tables: no key twice
         self.aux.import_edges(edges.contiguous(), edges.shape[0])
         self.aux.components()
-        self.aux.dissect(method)
+        self.aux.set_id_window(0, 0)          # only the verdicts are wanted here: no id is listed
+        try:
+            self.aux.dissect(method)
+        finally:
+            self.aux.set_id_window()
         kept = torch.empty(n, dtype=torch.uint8, device=self.device)
         self.aux.kept_flags_into(kept)
         return kept
@@ -254,40 +310,68 @@ class _PhaseTimer:
 class _Comm:
     """The collectives of the job. ``via_host`` stages every buffer through host memory: the
     two-ranks-on-one-GPU test runs the production arithmetic with gloo in between (RCCL refuses
-    two ranks on one device)."""
+    two ranks on one device).
 
-    def __init__(self, group, device, via_host=False):
+    Ordering between the HIP library's stream and torch's / RCCL's is by stream waits, never by a
+    host synchronisation: ``lib_stream`` (the context's stream as a ``torch.cuda.ExternalStream``)
+    waits for torch's current stream after a collective, torch's current stream waits for it
+    before one. With ONE rank every collective is the identity and nothing is copied."""
+
+    def __init__(self, group, device, via_host=False, lib_streams=None):
         self.group, self.device, self.via_host = group, device, via_host
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        # callable -> the library contexts' streams (the second context appears on first use)
+        self.lib_streams = lib_streams if (device.type == "cuda" and not via_host) else None
 
     def _wire(self, x):
-        return x.cpu() if self.via_host else x
+        if self.via_host:
+            return x.cpu()
+        if self.lib_streams is not None and x.is_cuda:
+            for st in self.lib_streams():      # the library produced x: torch's stream waits for it
+                torch.cuda.current_stream(x.device).wait_stream(st)
+        return x
 
     def _back(self, x):
         if self.via_host:
             return x.to(self.device)
-        # The HIP library works on its own stream: what a collective produced on torch's stream must
-        # be complete before the next library call reads it. (The library's stream is a blocking
-        # stream, which already orders it behind torch's default stream; this makes the dependency
-        # explicit instead of relying on legacy default-stream semantics.)
-        if x.is_cuda:
+        # what a collective produced on torch's stream must be complete before the next library call
+        # reads it: the library's streams wait for torch's (no host round trip)
+        if self.lib_streams is not None and x.is_cuda:
+            for st in self.lib_streams():
+                st.wait_stream(torch.cuda.current_stream(x.device))
+        elif x.is_cuda:
             torch.cuda.current_stream(x.device).synchronize()
         return x
 
     def all_gather_ints(self, values) -> np.ndarray:
         """(world, len(values)) int64 on the host."""
+        if self.world == 1:
+            return np.array([[int(v) for v in values]], dtype=np.int64)
         wire_dev = torch.device("cpu") if self.via_host else self.device
         mine = torch.tensor(list(values), dtype=torch.int64, device=wire_dev)
         everyone = [torch.zeros_like(mine) for _ in range(self.world)]
         dist.all_gather(everyone, mine, group=self.group)
         return torch.stack(everyone).cpu().numpy()
 
+    def any_flag(self, flag: bool) -> bool:
+        """True when any rank raises the flag (a one-word all-reduce)."""
+        if self.world == 1:
+            return bool(flag)
+        wire_dev = torch.device("cpu") if self.via_host else self.device
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=wire_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(t.item()))
+
     def all_reduce_max(self, x: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return x
         w = self._wire(x)
         dist.all_reduce(w, op=dist.ReduceOp.MAX, group=self.group)
         return self._back(w)
 
     def exchange_counts(self, send_counts) -> list:
+        if self.world == 1:
+            return [int(c) for c in send_counts]
         wire_dev = torch.device("cpu") if self.via_host else self.device
         s = torch.tensor([int(c) for c in send_counts], dtype=torch.int64, device=wire_dev)
         r = torch.empty(self.world, dtype=torch.int64, device=wire_dev)
@@ -298,6 +382,8 @@ class _Comm:
         """all-to-all(v) of the rows of x, already grouped by destination rank."""
         if x is None:
             return None
+        if self.world == 1:
+            return x                       # a rank's share of its own rows: no copy
         w = self._wire(x.contiguous())
         out = torch.empty((int(sum(recv_counts)),) + tuple(x.shape[1:]), dtype=x.dtype, device=w.device)
         dist.all_to_all_single(out, w, output_split_sizes=[int(c) for c in recv_counts],
@@ -308,6 +394,8 @@ class _Comm:
         """Concatenation over ranks (rank-major) of tensors that differ in dim 0."""
         if x is None:
             return None
+        if self.world == 1:
+            return x
         sizes = [int(s) for s in self.all_gather_ints([x.shape[0]])[:, 0]]
         cap = max(max(sizes), 1)
         w = self._wire(x)
@@ -342,7 +430,7 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
         raise ValueError(f"unknown plan {plan!r}")
     if use_edit_distance:
         plan = "gathered"      # the edit search buckets keys across lengths and shifts: no per-segment routing
-    comm = _Comm(group, backend.device, comm_via_host)
+    comm = _Comm(group, backend.device, comm_via_host, getattr(backend, "lib_streams", None))
     rank, world = comm.rank, comm.world
     dev = backend.device
     tick = _PhaseTimer(dev) if (timing or os.environ.get("FQD_SHARD_TIMING")) else None
@@ -366,19 +454,52 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
     id_bounds = [0] + [int(x) for x in np.cumsum(n_per_rank)]
     id0, n_total = id_bounds[rank], id_bounds[-1]
     lens_seen = {int(m) for n, m in everyone if n > 0}
+    n_unique_local = None
     if len(lens_seen) == 1 and min(lens_seen) > 0 and not os.environ.get("FQD_SHARD_SCAN"):
         dna = np.zeros(128, dtype=np.uint8)
         dna[[ord(ch) for ch in "ACGNT"]] = 1
-        backend.configure(dna, lens_seen.pop(), False)
-        foreign = 0
-        try:
-            packed = backend.pack_by_owner(keys, offsets, key_len, world, id0, weights, n_segments=owner_segments)
-        except ValueError:
-            foreign = 1
-        if int(comm.all_reduce_max(torch.tensor([foreign], dtype=torch.int32, device=dev)).item()):
-            packed = None
+        fixed = lens_seen.pop()
+        backend.configure(dna, fixed, False)
         g_ragged = False
-    if packed is None:
+        # ---- the fused way in: packed straight into owner-major slabs, the all-to-all moves the
+        # slabs, the owner's collapse starts at level 2 (short keys, no weights, jobs worth it)
+        n_max = int(n_per_rank.max())
+        want_slabs = (plan == "segment-routed" and weights is None and hasattr(backend, "pack_to_owner_slabs")
+                      and n_max >= int(os.environ.get("FQD_OWNER_SLABS_MIN_READS", 1 << 20))
+                      and not os.environ.get("FQD_NO_OWNER_SLABS"))
+        if want_slabs:
+            try:
+                slabs = backend.pack_to_owner_slabs(keys, key_len, world, n_seg, n_max)
+            except ValueError:
+                slabs = None
+            if comm.any_flag(slabs is None):
+                slabs = None                       # somebody cannot: everybody takes the general way
+            if tick:
+                tick.mark("pack-to-owner-slabs")
+            if slabs is not None:
+                s_slabs, s_cur, send_counts, geometry = slabs
+                recv_counts = comm.exchange_counts(send_counts)
+                per_owner = s_slabs.shape[0] // world
+                r_slabs = comm.all_to_all_rows(s_slabs, [per_owner] * world, [per_owner] * world)
+                r_cur = comm.all_to_all_rows(s_cur, [s_cur.shape[0] // world] * world, [s_cur.shape[0] // world] * world)
+                if tick:
+                    tick.mark("all-to-all-slabs")
+                n_unique_local = backend.collapse_owner_slabs(r_slabs, r_cur, world, rank, geometry, id_bounds[:-1],
+                                                              max(n_total, 1), int(sum(recv_counts)), n_seg)
+                if comm.any_flag(n_unique_local is None):
+                    n_unique_local = None          # a bucket overflowed somewhere: once more, the general way
+                del s_slabs, s_cur, r_slabs, r_cur, slabs
+                if tick:
+                    tick.mark("collapse")
+        if n_unique_local is None:
+            foreign = 0
+            try:
+                packed = backend.pack_by_owner(keys, offsets, key_len, world, id0, weights, n_segments=owner_segments)
+            except ValueError:
+                foreign = 1
+            if comm.any_flag(bool(foreign)):
+                packed = None
+    if packed is None and n_unique_local is None:
         present, max_len, ragged = backend.scan(keys, offsets, key_len)
         everyone = comm.all_gather_ints([n_local, max_len, int(ragged)])
         lens_seen = {int(m) for n, m, _ in everyone if n > 0}
@@ -395,29 +516,30 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
                          method_id, g_ragged, id0, n_local, n_total)
 
     # ---- 2. reads to the owner of their segment 0; collapse -------------------------
-    if packed is None:
-        packed = backend.pack_by_owner(keys, offsets, key_len, world, id0, weights, n_segments=n_seg)
-    s_recs, s_lens, s_ids, s_w, send_counts = packed
-    del packed
-    if tick:
-        tick.mark("pack+group-by-owner")
-    recv_counts = comm.exchange_counts(send_counts)
-    r_recs = comm.all_to_all_rows(s_recs, send_counts, recv_counts)
-    r_ids = comm.all_to_all_rows(s_ids, send_counts, recv_counts)
-    r_lens = comm.all_to_all_rows(s_lens, send_counts, recv_counts) if g_ragged else None
-    r_w = comm.all_to_all_rows(s_w, send_counts, recv_counts)
-    del s_recs, s_ids, s_lens, s_w
-    # (s_ids / r_ids are None when the records carry the read index in their padding word.)
-    # The received rows are ALREADY in global id order: all-to-all delivers source ranks in rank
-    # order, rank r's ids precede rank r+1's, and every source sent its rows in id order.
-    if tick:
-        tick.mark("all-to-all-reads")
-    seg_rows = [0] + [int(x) for x in np.cumsum(recv_counts)]
-    n_unique_local = backend.collapse_resident(r_recs, r_lens, r_w, r_ids, seg_rows=seg_rows,
-                                               seg_id0=id_bounds[:-1], id_limit=max(n_total, 1))
-    del r_recs, r_ids, r_lens, r_w
-    if tick:
-        tick.mark("collapse")
+    if n_unique_local is None:
+        if packed is None:
+            packed = backend.pack_by_owner(keys, offsets, key_len, world, id0, weights, n_segments=n_seg)
+        s_recs, s_lens, s_ids, s_w, send_counts = packed
+        del packed
+        if tick:
+            tick.mark("pack+group-by-owner")
+        recv_counts = comm.exchange_counts(send_counts)
+        r_recs = comm.all_to_all_rows(s_recs, send_counts, recv_counts)
+        r_ids = comm.all_to_all_rows(s_ids, send_counts, recv_counts)
+        r_lens = comm.all_to_all_rows(s_lens, send_counts, recv_counts) if g_ragged else None
+        r_w = comm.all_to_all_rows(s_w, send_counts, recv_counts)
+        del s_recs, s_ids, s_lens, s_w
+        # (s_ids / r_ids are None when the records carry the read index in their padding word.)
+        # The received rows are ALREADY in global id order: all-to-all delivers source ranks in rank
+        # order, rank r's ids precede rank r+1's, and every source sent its rows in id order.
+        if tick:
+            tick.mark("all-to-all-reads")
+        seg_rows = [0] + [int(x) for x in np.cumsum(recv_counts)]
+        n_unique_local = backend.collapse_resident(r_recs, r_lens, r_w, r_ids, seg_rows=seg_rows,
+                                                   seg_id0=id_bounds[:-1], id_limit=max(n_total, 1))
+        del r_recs, r_ids, r_lens, r_w
+        if tick:
+            tick.mark("collapse")
     uid_bounds = [0] + [int(x) for x in np.cumsum(comm.all_gather_ints([n_unique_local])[:, 0])]
     uid0, n_unique = uid_bounds[rank], uid_bounds[-1]
     if n_unique >= 2**31 - 16:
@@ -449,10 +571,14 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
     g_edges = comm.all_gather_rows(mine).contiguous()
     n_edges = int(g_edges.shape[0])
     labels, n_clusters = backend.edge_labels(g_edges, n_unique)
-    my_edges = g_edges[(labels % world) == rank]
-    touched, inverse = torch.unique(my_edges.reshape(-1), return_inverse=True)     # ascending uids
-    sub_edges = inverse.reshape(-1, 2).to(torch.int32)
-    del g_edges, labels, my_edges
+    if hasattr(backend, "cluster_subgraph"):
+        touched, sub_edges = backend.cluster_subgraph(g_edges, labels, n_unique, world, rank)
+    else:
+        my_edges = g_edges[(labels % world) == rank]
+        touched, inverse = torch.unique(my_edges.reshape(-1), return_inverse=True)     # ascending uids
+        sub_edges = inverse.reshape(-1, 2).to(torch.int32)
+        del my_edges
+    del g_edges, labels
     if tick:
         tick.mark("gather-edges+label")
 

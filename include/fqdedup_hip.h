@@ -91,6 +91,9 @@ int         fqd_create(int device, fqd_ctx **out);
 void        fqd_destroy(fqd_ctx *ctx);
 const char *fqd_last_error(const fqd_ctx *ctx);
 int         fqd_synchronize(fqd_ctx *ctx);
+/* The context's HIP stream (a hipStream_t), so that a caller working on other streams -- torch,
+ * RCCL -- can order its work against the context's with events instead of host synchronisation. */
+void       *fqd_get_stream(fqd_ctx *ctx);
 
 /* ---- stage 1: keys -> bit-plane records + 32-bit hashes --------------------
  * bytes: concatenated ASCII keys. offsets: n+1 byte offsets, or NULL for n keys
@@ -127,6 +130,14 @@ int fqd_dissect(fqd_ctx *ctx, int method, uint64_t *n_kept);
 /* ---- all of 2..5 ----------------------------------------------------------- */
 int fqd_cluster(fqd_ctx *ctx, const uint32_t *weights, const uint64_t *read_ids, int mem,
                 int max_distance, int metric, int method, fqd_summary *out);
+
+/* ---- 1 + 2 in one call: the insert loop __init__.py:242-252 for one batch of keys. Short
+ * fixed-length keys take the fused way in (see fqd_cluster_keys); search_segments > 0 announces a
+ * Hamming search with that many pigeonhole segments, whose segment hashes the collapse then writes
+ * on its way out. Afterwards the context holds the unique table (not the packed reads). */
+int fqd_pack_collapse(fqd_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, uint32_t fixed_len,
+                      int mem, const uint32_t *weights, const uint64_t *read_ids, int aux_mem,
+                      uint32_t search_segments, uint64_t *n_unique);
 
 /* ---- all of 1..5: the whole hot path in one call ------------------------------
  * Replaces the reference's per-read Trie.add_sequence loop plus the cluster loop
@@ -187,6 +198,30 @@ int fqd_export_packed_by_segment(fqd_ctx *ctx, uint32_t n_parts, uint32_t n_segm
 int fqd_collapse_received(fqd_ctx *ctx, const uint32_t *weights, const uint64_t *seg_rows,
                           const uint64_t *seg_id0, uint32_t n_seg, uint64_t id_limit, int mem,
                           uint64_t *n_unique);
+/* The fused way in across ranks, for fixed-length keys whose record is one uint4 (<= 32 nt over
+ * "ACGNT") and reads without weights: fqd_pack_to_owner_slabs packs this rank's keys straight into
+ * owner-major slabs -- bin = owner * hash_bins + top hash bits of the record, `subs` slabs of `cap`
+ * records per bin, owner by the rule of fqd_set_owner_rule (n_parts, n_segments, segment) -- so an
+ * owner's share is ONE contiguous range of hash_bins * subs slabs (capacity included) of
+ * slabs_out, with cursors_out[p] = first free slot of slab p (slot numbers count from the start of
+ * slabs_out); every record carries its read's index on this rank. counts (HOST, n_parts) = reads
+ * per owner. fqd_collapse_owner_slabs is the receiving side: `slabs` holds, sender by sender, the
+ * ranges the n_senders ranks addressed to owner my_part (read in place), `cursors` their cursor
+ * tables; sender_id0 (HOST) the id base of each sender's reads, id_limit a bound on all ids,
+ * n_reads the reads received in all. The collapse starts at level 2: the senders' bins are its
+ * level 1. *done = 0 (either call): not applicable or a slab overflowed -- nothing was produced,
+ * take the general way (fqd_pack_keys + fqd_export_packed_by_segment / fqd_collapse_received).
+ * fqd_owner_slab_geometry gives (hash_bins, subs, cap) for ranks that pack at most n_max reads each;
+ * all ranks of a job must use the same values. Replaces, per batch and rank, the reference's insert
+ * loop __init__.py:242-252 like fqd_pack_keys + fqd_collapse do. */
+int fqd_owner_slab_geometry(uint64_t n_max, uint32_t n_parts, uint32_t *hash_bins, uint32_t *subs, uint32_t *cap);
+int fqd_pack_to_owner_slabs(fqd_ctx *ctx, const uint8_t *bytes, uint64_t n, uint32_t fixed_len, int mem, uint32_t n_parts,
+                            uint32_t n_segments, uint32_t segment, uint32_t hash_bins, uint32_t subs, uint32_t cap,
+                            uint32_t *slabs_out, uint32_t *cursors_out, uint64_t *counts, int *done);
+int fqd_collapse_owner_slabs(fqd_ctx *ctx, const uint32_t *slabs, const uint32_t *cursors, uint32_t n_senders,
+                             uint32_t my_part, uint32_t hash_bins, uint32_t subs, uint32_t cap,
+                             const uint64_t *sender_id0, uint64_t id_limit, uint64_t n_reads, uint32_t search_segments,
+                             uint64_t *n_unique, int *done);
 /* Optional: announce the owner rule BEFORE fqd_pack_keys, which then works out every read's owner
  * in the same pass; a matching fqd_export_packed_by_segment skips its own pass over the records.
  * n_parts = 0 switches it off. */
@@ -226,6 +261,13 @@ int fqd_find_edges_segments(fqd_ctx *ctx, int max_distance, uint32_t seg_lo, uin
  * partition when the nodes are global unique ids. */
 int fqd_edge_labels(fqd_ctx *ctx, const uint32_t *uv, uint64_t n_edges, uint64_t n_nodes, uint32_t *roots,
                     uint64_t *n_components, int mem);
+/* The clusters one rank dissects, cut out of the job-wide edge list (DEVICE buffers): the edges whose
+ * root (fqd_edge_labels) is congruent to `part` modulo n_parts, their distinct ends in ascending
+ * order (touched_out, up to min(2 E, n_nodes) words) and the edges again with every end replaced by
+ * its position in touched_out (sub_edges_out, 2 E words, any edge order). */
+int fqd_cluster_subgraph(fqd_ctx *ctx, const uint32_t *uv, const uint32_t *roots, uint64_t n_edges, uint64_t n_nodes,
+                         uint32_t n_parts, uint32_t part, uint32_t *touched_out, uint32_t *sub_edges_out,
+                         uint64_t *n_touched, uint64_t *n_sub, int mem);
 /* Kept list when the verdicts were computed on other ranks: every key of the unique table is
  * kept except rows dropped[0..n_dropped) (DEVICE). Afterwards fqd_get_kept_count /
  * fqd_get_kept_read_ids / fqd_get_unique_table(kept) answer as after fqd_dissect. */

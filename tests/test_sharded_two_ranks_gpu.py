@@ -25,6 +25,12 @@ def _worker(rank, world, port, case, plan, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if plan.endswith("+slabs"):
+        # the fused way in (owner-major slabs) also for a job this small
+        plan = plan[: -len("+slabs")]
+        os.environ["FQD_OWNER_SLABS_MIN_READS"] = "1000"
+    else:
+        os.environ["FQD_NO_OWNER_SLABS"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import fastqdedup_amd as F
@@ -45,13 +51,24 @@ def _worker(rank, world, port, case, plan, q):
 
 
 @pytest.mark.parametrize("shape,plan", [("fixed32", "segment-routed"), ("fixed32", "gathered"),
+                                        ("fixed32", "segment-routed+slabs"), ("fixed32_3ranks", "segment-routed+slabs"),
+                                        ("fixed32_foreign", "segment-routed+slabs"),
                                         ("fixed32_foreign", "segment-routed"),
                                         ("fixed100_weights", "segment-routed"), ("fixed100_weights", "gathered"),
+                                        ("fixed300_d2", "segment-routed"),
                                         ("ragged_hamming3", "segment-routed"), ("ragged_edit", "gathered")])
 def test_ranks_on_one_gpu(oracle, shape, plan):
     from fastqdedup_amd.synth import fixed_offsets, synth_keys
     world = 2
-    if shape in ("fixed32", "fixed32_foreign"):
+    if shape == "fixed32_3ranks":
+        # three ranks (3 x 64 owner-major bins), one of them with few reads, d = 2, adjacency
+        world = 3
+        n, L, d, edit, method = 150_000, 32, 2, False, "adjacency"
+        allk = synth_keys(n, L, L, 15, sub_rate=3e-3, n_rate=3e-4)
+        cuts = [0, 80_000, 81_000, n]
+        case = [(allk[cuts[r]:cuts[r + 1]].reshape(-1), None, L, None, d, edit, method) for r in range(3)]
+        raw, off, w = allk.reshape(-1), fixed_offsets(n, L), None
+    elif shape in ("fixed32", "fixed32_foreign"):
         n, L, d, edit, method = 120_000, 32, 1, False, "directional"
         allk = synth_keys(n, L, L, 5, sub_rate=3e-3, n_rate=3e-4)
         cut = 70_000
@@ -60,6 +77,16 @@ def test_ranks_on_one_gpu(oracle, shape, plan):
             # rank must fall back to the scanned, merged symbol table
             allk[cut + 11] = np.frombuffer(bytes(allk[cut + 11]).lower(), dtype=np.uint8)
             allk[cut + 12] = allk[cut + 11]
+        case = [(allk[:cut].reshape(-1), None, L, None, d, edit, method),
+                (allk[cut:].reshape(-1), None, L, None, d, edit, method)]
+        raw, off, w = allk.reshape(-1), fixed_offsets(n, L), None
+        cuts = [0, cut, n]
+    elif shape == "fixed300_d2":
+        # BASELINE config 4's actual plan: key = R1 + R2 (300 nt, 128-byte records), Hamming d = 2,
+        # directional, segment-routed over the ranks (three search passes, two of them routed)
+        n, L, d, edit, method = 80_000, 300, 2, False, "directional"
+        allk = synth_keys(n, L, L, 1004, sub_rate=1e-3, n_rate=1e-4)
+        cut = 45_000
         case = [(allk[:cut].reshape(-1), None, L, None, d, edit, method),
                 (allk[cut:].reshape(-1), None, L, None, d, edit, method)]
         raw, off, w = allk.reshape(-1), fixed_offsets(n, L), None
