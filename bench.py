@@ -36,6 +36,11 @@ WORKLOADS = {
                          "Hamming d=2, directional"),
     "config5": dict(n=50_000_000, L=300, umi=300, d=1, edit=True, method="adjacency", seed=1005,
                     name="50M paired 2x150-bp reads, key = R1+R2 (300 nt), --edit d=1, adjacency"),
+    # SURVEY.md 8d's variant of configs[4]: 1 % of the reads are one base short or long, so the keys
+    # have three lengths and the Levenshtein search proper runs (equal lengths at d=1 reduce to Hamming)
+    "config5v": dict(n=50_000_000, L=300, umi=300, d=1, edit=True, method="adjacency", seed=1005, indel_rate=0.01,
+                     name="50M paired 2x150-bp reads, 1% with a 149- or 151-nt mate (keys of 299/300/301 nt), "
+                          "--edit d=1, adjacency"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -53,15 +58,26 @@ def cpu_baseline(ctx, wl, sample_reads: int):
     import fastqdedup_amd as F
     from oracle import oracle as O
     n = min(sample_reads, wl["n"])
-    dev = torch.empty(n * wl["L"], dtype=torch.uint8, device="cuda:0")
-    ctx.synth_keys(dev, n, 0, n, wl["L"], wl["umi"], wl["seed"])
+    dev_off = host_off = None
+    if wl.get("indel_rate"):
+        dev, dev_off = ctx.synth_indel_keys(n, 0, n, wl["L"], wl["umi"], wl["seed"], indel_rate=wl["indel_rate"])
+        host_off = dev_off.cpu().numpy().astype(np.uint64)
+    else:
+        dev = torch.empty(n * wl["L"], dtype=torch.uint8, device="cuda:0")
+        ctx.synth_keys(dev, n, 0, n, wl["L"], wl["umi"], wl["seed"])
     host = dev.cpu().numpy()
     sample = (f"first {n} reads of the same generator (n_total={n}, L={wl['L']}, umi={wl['umi']}, "
-              f"seed={wl['seed']}), d={wl['d']}, {'edit' if wl['edit'] else 'hamming'}, {wl['method']}")
+              f"seed={wl['seed']}{', indel tail ' + str(wl['indel_rate']) if wl.get('indel_rate') else ''}), "
+              f"d={wl['d']}, {'edit' if wl['edit'] else 'hamming'}, {wl['method']}")
     cores = 1
     if O.reference_available():
         from oracle import ref_driver
-        strs = [s.decode() for s in host.view(f"S{wl['L']}")]
+        if host_off is not None:
+            raw = host.tobytes()
+            strs = [raw[int(host_off[i]):int(host_off[i + 1])].decode() for i in range(n)]
+            del raw
+        else:
+            strs = [s.decode() for s in host.view(f"S{wl['L']}")]
         out = ref_driver.run_reference_path(strs, wl["d"], wl["edit"], wl["method"])
         secs = out["seconds"]
         first = {}
@@ -78,8 +94,8 @@ def cpu_baseline(ctx, wl, sample_reads: int):
                         "its Python dissection loops restated in oracle/ref_driver.py"}
     else:
         from fastqdedup_amd.synth import fixed_offsets
-        out = O.dedup(host, fixed_offsets(n, wl["L"]), max_distance=wl["d"], use_edit_distance=wl["edit"],
-                      method=wl["method"])
+        out = O.dedup(host, host_off if host_off is not None else fixed_offsets(n, wl["L"]), max_distance=wl["d"],
+                      use_edit_distance=wl["edit"], method=wl["method"])
         total = sum(out["stage_seconds"].values())
         cpu_kept = out["kept_read_ids"]
         base = {"value": n / total, "unit": "reads/s", "cores": cores, "kind": "port", "sample": sample,
@@ -87,8 +103,8 @@ def cpu_baseline(ctx, wl, sample_reads: int):
                 "n_unique": out["n_unique"], "n_clusters": out["n_clusters"],
                 "n_kept": int(len(out["kept_read_ids"])), "cpu_count": os.cpu_count()}
     # ---- parity gate: the HIP path on the same sample, after the CPU clock stopped ----
-    got = F.cluster_keys(dev, key_len=wl["L"], max_distance=wl["d"], use_edit_distance=wl["edit"],
-                         method=wl["method"], context=ctx)
+    got = F.cluster_keys(dev, dev_off, 0 if dev_off is not None else wl["L"], max_distance=wl["d"],
+                         use_edit_distance=wl["edit"], method=wl["method"], context=ctx)
     base["parity"] = bool(got.n_unique == base["n_unique"] and got.n_clusters == base["n_clusters"]
                           and got.n_kept == base["n_kept"]
                           and np.array_equal(got.kept_read_ids.astype(np.uint64), cpu_kept))
@@ -200,7 +216,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--reads-per-gpu", type=int, default=0, help="override the workload's n (testing)")
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="reads of the CPU baseline's sample (default: 4 M for keys up to 100 nt, 1 M above)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (diagnostic)")
@@ -235,17 +252,23 @@ def main():
     ctx = F.Context(local_rank)
 
     # synthetic input, generated in HBM before the timed region
-    keys = torch.empty(n * L, dtype=torch.uint8, device=device)
-    ctx.synth_keys(keys, n_total, rank * n, n, L, wl["umi"], wl["seed"])
+    key_offsets = None
+    if wl.get("indel_rate"):
+        keys, key_offsets = ctx.synth_indel_keys(n_total, rank * n, n, L, wl["umi"], wl["seed"],
+                                                 indel_rate=wl["indel_rate"])
+    else:
+        keys = torch.empty(n * L, dtype=torch.uint8, device=device)
+        ctx.synth_keys(keys, n_total, rank * n, n, L, wl["umi"], wl["seed"])
     kept_buf = torch.empty(n, dtype=torch.int64, device=device)
     backend = HipBackend(ctx, device) if sharded else None
 
     def step():
         if not sharded:
-            return F.cluster_keys(keys, key_len=L, max_distance=wl["d"], use_edit_distance=wl["edit"],
-                                  method=wl["method"], context=ctx, kept_out=kept_buf, stage_times=False)
-        return cluster_keys_sharded(backend, keys, None, L, max_distance=wl["d"],
-                                    use_edit_distance=wl["edit"], method=wl["method"])
+            return F.cluster_keys(keys, key_offsets, 0 if key_offsets is not None else L, max_distance=wl["d"],
+                                  use_edit_distance=wl["edit"], method=wl["method"], context=ctx, kept_out=kept_buf,
+                                  stage_times=False)
+        return cluster_keys_sharded(backend, keys, key_offsets, 0 if key_offsets is not None else L,
+                                    max_distance=wl["d"], use_edit_distance=wl["edit"], method=wl["method"])
 
     def fence():
         ctx.synchronize()
@@ -369,10 +392,12 @@ def main():
     pcie = None
     if rank == 0 and world == 1 and not args.no_host_input:
         host_keys = keys.cpu().numpy()
-        F.cluster_keys(host_keys, key_len=L, max_distance=wl["d"], use_edit_distance=wl["edit"],
+        host_offsets = None if key_offsets is None else key_offsets.cpu().numpy().astype("uint64")
+        host_len = 0 if key_offsets is not None else L
+        F.cluster_keys(host_keys, host_offsets, host_len, max_distance=wl["d"], use_edit_distance=wl["edit"],
                        method=wl["method"], context=ctx)
         t1 = time.perf_counter()
-        F.cluster_keys(host_keys, key_len=L, max_distance=wl["d"], use_edit_distance=wl["edit"],
+        F.cluster_keys(host_keys, host_offsets, host_len, max_distance=wl["d"], use_edit_distance=wl["edit"],
                        method=wl["method"], context=ctx)
         dt = time.perf_counter() - t1
         pcie = {"reads_per_s": round(n / dt, 1), "ms": round(dt * 1e3, 3),
@@ -419,7 +444,7 @@ def main():
         out["sharded_phases_ms_rank0"] = phases
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(ctx, wl, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(ctx, wl, args.cpu_sample or (4_000_000 if L <= 100 else 1_000_000))
         except Exception as exc:  # the GPU numbers stand on their own
             out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:

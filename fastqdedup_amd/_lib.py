@@ -47,7 +47,7 @@ EXPORTS = [
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
     "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_set_timing", "fqd_cluster_keys", "fqd_edge_stats", "fqd_synth_keys",
     "fqd_store_add_keys", "fqd_store_remove", "fqd_store_removed_count", "fqd_get_clusters", "fqd_read_clusters",
-    "fqd_trie_order", "fqd_trie_stats", "fqd_store_symbol_events", "fqd_get_stream", "fqd_pack_collapse",
+    "fqd_trie_order", "fqd_trie_stats", "fqd_store_symbol_events", "fqd_get_stream", "fqd_pack_collapse", "fqd_synth_indel_keys",
     "fqd_cluster_subgraph", "fqd_owner_slab_geometry", "fqd_pack_to_owner_slabs", "fqd_collapse_owner_slabs",
 ]
 
@@ -133,6 +133,8 @@ def load() -> C.CDLL:
                                           C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, u64p, C.POINTER(C.c_int)]
     L.fqd_collapse_owner_slabs.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p,
                                            C.c_uint64, C.c_uint64, C.c_uint32, u64p, C.POINTER(C.c_int)]
+    L.fqd_synth_indel_keys.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
+                                       C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, vp]
     L.fqd_get_stream.argtypes = [vp]
     L.fqd_get_stream.restype = C.c_void_p
     L.fqd_pack_collapse.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp, C.c_int, C.c_uint32, u64p]
@@ -717,6 +719,25 @@ class Context:
         a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         self._ck(self._L.fqd_edge_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"keys_gathered": int(a.value), "pairs_compared": int(b.value), "edges": int(c.value)}
+
+    def synth_indel_keys(self, n_total: int, start: int, count: int, length: int, umi: int, seed: int,
+                         indel_rate: float = 0.01, copies: int = 4, sub_rate: float = 1e-3, n_rate: float = 1e-4):
+        """(key bytes uint8, offsets int64[count + 1]) on this context's device: the fixed-length job
+        of synth_keys with an indel tail (three key lengths), byte-identical to synth.indel_variant."""
+        import torch
+        from .synth import rate_threshold
+        dev = torch.device("cuda", self.device)
+        args = (n_total, start, count, length, umi, seed, copies, rate_threshold(n_rate), rate_threshold(sub_rate),
+                rate_threshold(indel_rate))
+        lens = torch.empty(max(count, 1), dtype=torch.int64, device=dev)
+        self._ck(self._L.fqd_synth_indel_keys(self._h, *args, lens.data_ptr(), None, None))
+        offsets = torch.zeros(count + 1, dtype=torch.int64, device=dev)
+        if count:
+            torch.cumsum(lens[:count], 0, out=offsets[1:])
+        total = int(offsets[-1].item())
+        out = torch.empty(max(total, 16), dtype=torch.uint8, device=dev)
+        self._ck(self._L.fqd_synth_indel_keys(self._h, *args, None, offsets.data_ptr(), out.data_ptr()))
+        return out[:total], offsets
 
     def synth_keys(self, out_tensor, n_total: int, start: int, count: int, length: int, umi: int,
                    seed: int, copies: int = 4, sub_rate: float = 1e-3, n_rate: float = 1e-4):

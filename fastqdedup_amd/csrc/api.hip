@@ -332,10 +332,12 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
     const char *force = getenv("FQD_COLLAPSE");  // "sort" / "lds" / "pairs": tests pin a path
     if (force && (!strcmp(force, "sort") || !strcmp(force, "lds")))
         return FQD_OK;
-    if (sh.ragged || (sh.stride & 3u) || n >= 0xFFFFFF00ull)
+    if ((sh.stride & 3u) || sh.stride > 256 || n >= 0xFFFFFF00ull)
         return FQD_OK;
     if (n < 65536 && !(force && !strcmp(force, "pairs")))
         return FQD_OK;
+    // ragged keys (trimmed reads, --check-lengths past a read's end): the lengths are compared with the records
+    const uint32_t *d_lens = sh.ragged ? c->lens.as<uint32_t>() : nullptr;
     FQD_TRY(ensure_hashes(c));
     const uint32_t B = lds_bucket_bits(n);
     const uint32_t n_buckets = 1u << B;
@@ -346,7 +348,7 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
         const uint32_t *items = nullptr, *bucket_end = nullptr;
         FQD_TRY(zero_ctr32(c, C_BAD));
         FQD_TRY(zero_ctr64(c, C64_SLAB));
-        FQD_TRY(fqd_api_partition_pairs(c, c->hashes.as<uint32_t>(), n, B, slabs, &items, &bucket_end));
+        FQD_TRY(fqd_api_partition_pairs(c, c->hashes.as<uint32_t>(), n, B, slabs, &items, &bucket_end, nullptr));
         // tmp rows of a bucket start where its items start (unique keys <= reads of the bucket)
         const uint64_t slots = c->gp_b.cap >= 16 && items == c->gp_b.as<uint32_t>() ? (c->gp_b.cap - 16) / 8 : n;
         HIP_TRY(c, c->ld_tmp_rec.reserve(slots * 4 + 16));        // here: the parked read's position
@@ -357,7 +359,7 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
         KTIME(c, FQD_K_DEDUPE, fqd::launch_bucket_pairs_dedupe(
                   items, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, c->recs.as<uint32_t>(), sh.stride, d_w,
                   c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(), c->ld_tmp_first.as<uint32_t>(),
-                  c->ld_unique.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+                  c->ld_unique.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st, d_lens));
         FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
         FQD_TRY(queue_read_u32(c, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 0));
         FQD_TRY(queue_read_u32(c, c->d_ctr32.as<uint32_t>() + C_BAD, 1));
@@ -381,7 +383,8 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
     // segment hashes on the way (records whose uint4 count divides 64: their lanes sit side by side)
     fqd::SegHashOut sho;
     const uint32_t q_per_rec = sh.stride / 4;
-    if (c->seg_hint && U && q_per_rec <= 64 && !(q_per_rec & (q_per_rec - 1)) && !getenv("FQD_NO_EARLY_SEG_HASHES")) {
+    if (c->seg_hint && U && !sh.ragged && q_per_rec <= 64 && !(q_per_rec & (q_per_rec - 1)) &&
+        !getenv("FQD_NO_EARLY_SEG_HASHES")) {
         HIP_TRY(c, c->seg_hashes.reserve((size_t)c->seg_hint * U * 4 + 16));
         sho.out = c->seg_hashes.as<uint32_t>();
         sho.nseg = c->seg_hint;
@@ -392,7 +395,8 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
     KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_pairs_compact(
               c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets, c->ld_tmp_rec.as<uint32_t>(),
               c->ld_tmp_count.as<uint32_t>(), c->ld_tmp_first.as<uint32_t>(), c->recs.as<uint32_t>(), sh.stride, d_ids,
-              c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho));
+              c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho, d_lens,
+              c->ulens.as<uint32_t>()));
     c->seg_hashes_nseg = sho.nseg;
     unsigned long long counted = n;
     if (d_w) {
@@ -497,13 +501,16 @@ void fqd_destroy(fqd_ctx *c)
                       &c->t_idx, &c->t_order, &c->t_order_b, &c->t_rank, &c->t_keys, &c->t_keys_b, &c->t_lcp, &c->t_mark,
                       &c->t_mark_incl, &c->t_stats, &c->t_seed, &c->t_heads, &c->t_heads_incl, &c->t_member_uids,
                       &c->t_offsets, &c->store_alive, &c->st_recs, &c->st_lens, &c->st_counts, &c->st_first,
-                      &c->st_comb_recs, &c->st_comb_lens, &c->st_comb_w, &c->st_comb_ids};
+                      &c->st_comb_recs, &c->st_comb_lens, &c->st_comb_w, &c->st_comb_ids, &c->eg_tables, &c->eg_per_key,
+                      &c->eg_per_key_incl};
     for (DevBuf *b : bufs)
         b->release();
     if (c->ev_rb)
         (void)hipEventDestroy(c->ev_rb);
     if (c->h_pin)
         (void)hipHostFree(c->h_pin);
+    if (c->h_pin_big)
+        (void)hipHostFree(c->h_pin_big);
     for (hipEvent_t e : c->tev)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->kev)
@@ -1006,10 +1013,22 @@ int fqd_pack_to_owner_slabs(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uint32
         kernel_timer.stop();
     }
     // the fill of every slab (for the part sizes), the overflow and foreign-byte flags: one wait
-    std::vector<uint32_t> cur(parts);
-    uint32_t flags[C_PACKBAD + 1];
-    HIP_TRY(c, hipMemcpyAsync(cur.data(), cursors_out, (size_t)parts * 4, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipMemcpyAsync(flags, c->d_ctr32.p, sizeof flags, hipMemcpyDeviceToHost, c->st));
+    if (!c->h_pin_big && hipHostMalloc(&c->h_pin_big, 1u << 20, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        c->h_pin_big = nullptr;
+    }
+    std::vector<uint32_t> cur_pageable;
+    uint32_t *cur, *flags;
+    if (c->h_pin_big && ((size_t)parts + C_N32) * 4 <= (1u << 20)) {      // (a pageable target waits on its own)
+        cur = static_cast<uint32_t *>(c->h_pin_big);
+        flags = cur + parts;
+    } else {
+        cur_pageable.resize((size_t)parts + C_N32);
+        cur = cur_pageable.data();
+        flags = cur + parts;
+    }
+    HIP_TRY(c, hipMemcpyAsync(cur, cursors_out, (size_t)parts * 4, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipMemcpyAsync(flags, c->d_ctr32.p, (C_PACKBAD + 1) * 4, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(c, stream_wait(c->st));
     pack_timer.stop();
     c->n = n;
@@ -1502,6 +1521,22 @@ int fqd_synth_keys(fqd_ctx *c, uint8_t *out_device, uint64_t n_total, uint64_t s
     if (!copies)
         return fail(c, FQD_E_VALUE, "copies must be positive");
     HIP_TRY(c, fqd::launch_synth(out_device, n_total, start, count, length, umi, seed, copies, thr_n, thr_sub, c->st));
+    HIP_TRY(c, stream_wait(c->st));
+    return FQD_OK;
+}
+
+int fqd_synth_indel_keys(fqd_ctx *c, uint64_t n_total, uint64_t start, uint64_t count, uint32_t length, uint32_t umi,
+                         uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub, uint64_t thr_indel,
+                         uint64_t *lens_out_device, const uint64_t *offsets_device, uint8_t *out_device)
+{
+    FQD_TRY(bind(c));
+    if (!copies)
+        return fail(c, FQD_E_VALUE, "copies must be positive");
+    if (!lens_out_device && !(offsets_device && out_device))
+        return fail(c, FQD_E_VALUE, "fqd_synth_indel_keys: either lens_out or offsets + out");
+    HIP_TRY(c, fqd::launch_synth_indels(n_total, start, count, length, umi, seed, copies, thr_n, thr_sub, thr_indel,
+                                        reinterpret_cast<unsigned long long *>(lens_out_device),
+                                        reinterpret_cast<const unsigned long long *>(offsets_device), out_device, c->st));
     HIP_TRY(c, stream_wait(c->st));
     return FQD_OK;
 }

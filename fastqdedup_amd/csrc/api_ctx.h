@@ -135,6 +135,7 @@ struct fqd_ctx {
     uint64_t gp_cand_cap = 0;
     DevBuf q_table, q_pass, q_means, q_bytes, q_offsets;
     DevBuf len_present, ed_hash, ed_payload, ed_hash_sorted, ed_payload_sorted, ed_cands, ed_cands_sorted, d_alphabet;
+    DevBuf eg_tables, eg_per_key, eg_per_key_incl;   // grouped edit search: class tables, probe items per key
     fqd::PairStats last_stats{};
     bool stats_pending = false;   // d_stats holds the slots of the last search, not yet summed into last_stats
     // stage 4
@@ -162,6 +163,7 @@ struct fqd_ctx {
     // fqd_stage_times asks (a stage end is NOT a host synchronisation point)
     hipEvent_t ev_rb = nullptr;    // marks queued read-backs: the host can wait for THEM while later work runs
     void *h_pin = nullptr;         // 256 pinned host bytes: where counter read-backs land
+    void *h_pin_big = nullptr;     // 1 MiB of pinned host memory for small tables (allocated on first use)
     uint32_t h_extra[16] = {0};    // (without pinned memory)
     unsigned long long h_extra64[8] = {0};
     hipEvent_t tev[2 * FQD_T_COUNT] = {nullptr};
@@ -453,4 +455,5 @@ int fqd_api_flat_labels(fqd_ctx *c);                       // api_graph.hip
 int fqd_api_collapse_device(fqd_ctx *c, const uint32_t *d_weights, IdSource ids, uint64_t id_limit, uint64_t *n_unique);
 int fqd_api_graph_preinit(fqd_ctx *c, int method);          // api_graph.hip
 extern "C" int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32_t B, bool slabs,
-                                       const uint32_t **items_out, const uint32_t **bucket_end_out);   // api_search.hip
+                                       const uint32_t **items_out, const uint32_t **bucket_end_out,
+                                       const uint32_t *values);   // api_search.hip

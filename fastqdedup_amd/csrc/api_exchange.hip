@@ -197,7 +197,8 @@ int fqd_import_packed(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, ui
                 HIP_TRY(c, hipMemcpyAsync(c->lens.p, lens, (size_t)n * 4, kind, c->st));
         }
     }
-    HIP_TRY(c, stream_wait(c->st));
+    if (mem == FQD_HOST)           // (device sources: the copy is ordered on the context's stream, nothing to wait for)
+        HIP_TRY(c, stream_wait(c->st));
     c->n = n;
     c->hashes_valid = false;       // computed when somebody needs them (ensure_hashes)
     c->owners_done = fqd::OwnerRule{};
@@ -269,7 +270,8 @@ int fqd_import_unique(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, co
         else
             HIP_TRY(c, hipMemsetAsync(c->ufirst.p, 0, U * 8, c->st));
     }
-    HIP_TRY(c, stream_wait(c->st));
+    if (mem == FQD_HOST)
+        HIP_TRY(c, stream_wait(c->st));
     c->U = U;
     c->seg_hashes_nseg = 0;
     c->collapsed = false;  // imported rows may repeat a key (dissection of a caller's list)
@@ -316,7 +318,8 @@ int fqd_import_edges(fqd_ctx *c, const uint32_t *uv, uint64_t E, int mem)
     if (E)
         HIP_TRY(c, hipMemcpyAsync(c->edges.p, uv, E * 8,
                                   mem == FQD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->st));
-    HIP_TRY(c, stream_wait(c->st));
+    if (mem != FQD_DEVICE)
+        HIP_TRY(c, stream_wait(c->st));
     c->E = E;
     c->stage = ST_EDGES;
     return FQD_OK;

@@ -71,6 +71,151 @@ int find_edges_edit(fqd_ctx *c, uint32_t d, uint32_t shard, uint32_t n_shards)
 
 }  // namespace
 
+extern "C" int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32_t B, bool slabs,
+                                       const uint32_t **items_out, const uint32_t **bucket_end_out,
+                                       const uint32_t *values);
+
+namespace {
+
+// The same search without a device-wide sort (edit.hip, "grouped"): few items (index items, probe
+// items only from the smaller of two length classes), partitioned by hash bits and matched in LDS
+// by the kernels of the Hamming passes, every pair verified once under its first matching
+// configuration. *done = false: not applicable (d > 3, 2^26 keys or more) -- the sorted way runs.
+int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done)
+{
+    *done = false;
+    const uint64_t U = c->U;
+    const KeyShape sh = c->ks;
+    const char *pin = getenv("FQD_EDIT");                  // "sort" / "grouped": tests pin a path
+    if (d > 3 || d == 0 || U >= (1ull << 26) || (pin && !strcmp(pin, "sort")))
+        return FQD_OK;
+    if (U < 32768 && !(pin && !strcmp(pin, "grouped")))
+        return FQD_OK;
+    const uint32_t nseg = d + 1, L = sh.max_len;
+    // ---- length classes: who probes whom --------------------------------------------------
+    HIP_TRY(c, c->eg_tables.reserve(((size_t)L + 1) * 12 + 64));
+    uint32_t *d_counts = c->eg_tables.as<uint32_t>();          // [L + 1] keys per length, later probe items per key of that length
+    uint8_t *d_mask = reinterpret_cast<uint8_t *>(d_counts + (L + 1));
+    HIP_TRY(c, hipMemsetAsync(d_counts, 0, ((size_t)L + 1) * 4, c->st));
+    HIP_TRY(c, fqd::launch_edit_len_counts(c->ulens.as<uint32_t>(), U, sh, d_counts, c->st));
+    std::vector<uint32_t> counts((size_t)L + 1), probe_count((size_t)L + 1, 0);
+    std::vector<uint8_t> mask((size_t)L + 1, 0);
+    HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, stream_wait(c->st));
+    uint64_t n_probe = 0;
+    for (uint32_t la = 0; la <= L; la++) {
+        if (!counts[la])
+            continue;
+        for (int j = 0; j <= 2 * (int)d; j++) {
+            const long lb = (long)la - (long)d + j;
+            if (lb < 0 || lb > (long)L || !counts[(size_t)lb])
+                continue;
+            // the smaller class probes the larger (ties: the shorter keys probe); the own class with
+            // shifts != 0 only, which d = 1 never needs
+            const bool probes = (uint32_t)lb == la ? d >= 2
+                                                   : (counts[la] < counts[(size_t)lb] ||
+                                                      (counts[la] == counts[(size_t)lb] && la < (uint32_t)lb));
+            if (!probes)
+                continue;
+            mask[la] |= (uint8_t)(1u << j);
+            for (uint32_t s = 0; s < nseg; s++) {
+                const uint32_t lo = (uint32_t)lb * s / nseg, hi = (uint32_t)lb * (s + 1) / nseg;
+                for (int delta = -(int)d; delta <= (int)d; delta++) {
+                    if ((uint32_t)lb == la && delta == 0)
+                        continue;
+                    const long start = (long)lo + delta;
+                    if (start >= 0 && (uint64_t)start + (hi - lo) <= la)
+                        probe_count[la]++;
+                }
+            }
+        }
+        n_probe += (uint64_t)probe_count[la] * counts[la];
+    }
+    const uint64_t R = U * nseg + n_probe;
+    if (R >= 0xFFFFFF00ull)
+        return FQD_OK;
+    HIP_TRY(c, hipMemcpyAsync(d_counts, probe_count.data(), probe_count.size() * 4, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, hipMemcpyAsync(d_mask, mask.data(), mask.size(), hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, stream_wait(c->st));          // (host vectors)
+    // ---- items -------------------------------------------------------------------------
+    HIP_TRY(c, c->ed_hash.reserve(R * 4 + 16));
+    HIP_TRY(c, c->ed_payload.reserve(R * 4 + 16));
+    HIP_TRY(c, c->eg_per_key.reserve(U * 4 + 16));
+    HIP_TRY(c, c->eg_per_key_incl.reserve(U * 4 + 16));
+    if (n_probe) {
+        HIP_TRY(c, fqd::launch_edit_items(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, sh, d, d_mask, d_counts,
+                                          c->eg_per_key.as<uint32_t>(), nullptr, nullptr, nullptr, 0, c->st));
+        FQD_TRY(scan_u32(c, c->eg_per_key.as<uint32_t>(), c->eg_per_key_incl.as<uint32_t>(), U));
+    } else {
+        HIP_TRY(c, hipMemsetAsync(c->eg_per_key_incl.p, 0, U * 4, c->st));
+    }
+    HIP_TRY(c, fqd::launch_edit_items(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, sh, d, d_mask, d_counts,
+                                      c->eg_per_key.as<uint32_t>(), c->eg_per_key_incl.as<uint32_t>(),
+                                      c->ed_hash.as<uint32_t>(), c->ed_payload.as<uint32_t>(), 1, c->st));
+    // ---- partition, candidates, verification; buffers grow and the passes run again if needed -----
+    uint32_t B = 8;
+    while (B < 20 && (R >> B) > 320)
+        B++;
+    if (const char *e = getenv("FQD_GROUP_BUCKET_BITS"))
+        B = (uint32_t)std::max(1, std::min(20, atoi(e)));
+    const uint32_t n_buckets = 1u << B;
+    if (c->gp_cand_cap < 1024 || !c->gp_cands.p) {
+        c->gp_cand_cap = std::max<uint64_t>(1u << 20, 2 * R);
+        HIP_TRY(c, c->gp_cands.reserve(c->gp_cand_cap * 8));
+    }
+    c->gp_cand_cap = c->gp_cands.cap / 8;
+    if (c->edge_cap < 1024 || !c->edges.p) {
+        c->edge_cap = std::max<uint64_t>(1024, U);
+        HIP_TRY(c, c->edges.reserve(c->edge_cap * 8));
+    }
+    c->edge_cap = c->edges.cap / 8;
+    unsigned long long *ctr = c->d_ctr64.as<unsigned long long>();
+    for (int attempt = 0;; attempt++) {
+        FQD_TRY(zero_ctr64(c, C64_EDGES));
+        FQD_TRY(zero_ctr64(c, C64_CAND_NEED, 2));      // ... and C64_SLAB
+        FQD_TRY(zero_ctr64(c, C64_SUM));
+        const uint32_t *items = nullptr, *bucket_end = nullptr;
+        FQD_TRY(fqd_api_partition_pairs(c, c->ed_hash.as<uint32_t>(), R, B,
+                                        !c->gp_slab_off && !getenv("FQD_GROUP_NO_SLABS"), &items, &bucket_end,
+                                        c->ed_payload.as<uint32_t>()));
+        unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(c->gp_small.as<uint32_t>() + 4096);
+        KTIME(c, FQD_K_PAIRS, fqd::launch_grouped_candidates(items, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, B,
+                                                             c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap, c->st));
+        KTIME(c, FQD_K_VERIFY, fqd::launch_edit_grouped_verify(
+                  c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap / fqd::group_cand_lists(), fqd::group_cand_lists(),
+                  c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, d_mask, c->edges.as<uint32_t>(), ctr + C64_EDGES,
+                  c->edge_cap, ctr + C64_CAND_NEED, ctr + C64_SUM, c->st));
+        unsigned long long ctrs[C64_SLAB + 1] = {0};
+        FQD_TRY(read_ctr64(c, 0, ctrs, C64_SLAB + 1));
+        const unsigned long long now = ctrs[C64_EDGES], cand_need = ctrs[C64_CAND_NEED];
+        const bool slab_over = ctrs[C64_SLAB] != 0;
+        if (slab_over)
+            c->gp_slab_off = true;
+        if (!slab_over && now <= c->edge_cap && cand_need <= c->gp_cand_cap) {
+            c->E = now;
+            c->last_stats.pairs_compared = ctrs[C64_SUM];
+            c->last_stats.edges = now;
+            break;
+        }
+        if (attempt > 3)
+            return fail(c, FQD_E_RUNTIME, "edit search: buffers kept overflowing");
+        if (now > c->edge_cap) {
+            c->edges.release();
+            HIP_TRY(c, c->edges.reserve((size_t)(now + now / 8 + 1024) * 8));
+            c->edge_cap = c->edges.cap / 8;
+        }
+        if (cand_need > c->gp_cand_cap) {
+            c->gp_cands.release();
+            HIP_TRY(c, c->gp_cands.reserve((size_t)(cand_need + cand_need / 8 + 1024) * 8));
+            c->gp_cand_cap = c->gp_cands.cap / 8;
+        }
+    }
+    *done = true;
+    return FQD_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 // (key, index) pairs of `keys[0..N)` partitioned into 2^B buckets by the top B key bits (group.hip,
@@ -80,7 +225,7 @@ extern "C" {
 // start = c->ld_start and end = *bucket_end (NULL: start[b + 1]). Also zeroes the candidate counters
 // behind the small tables (the search pass uses them).
 int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32_t B, bool slabs,
-                            const uint32_t **items_out, const uint32_t **bucket_end_out)
+                            const uint32_t **items_out, const uint32_t **bucket_end_out, const uint32_t *values)
 {
     const uint32_t B1 = B <= 18 ? std::min<uint32_t>(B, 8) : B - 10, B2 = B - B1;
     const uint32_t bins1 = 1u << B1, bins2 = 1u << B2, n_buckets = 1u << B;
@@ -105,7 +250,7 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
     HIP_TRY(c, fqd::launch_group_matrix_starts(c->ld_matrix_incl.as<uint32_t>(), bins1, tiles1, start1, c->st));
     KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(true, keys, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1,
                                                             bins1, c->ld_matrix_incl.as<uint32_t>(),
-                                                            c->gp_a.as<uint32_t>(), c->st));
+                                                            c->gp_a.as<uint32_t>(), c->st, 0, nullptr, values));
     const uint32_t *items = c->gp_a.as<uint32_t>();
     const uint32_t *bucket_end = nullptr;
     // level 2 in slab mode (as the collapse): no histogram pass; an overfull slab is flagged in C64_SLAB
@@ -164,7 +309,7 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
     // (an overfull level-2 slab -- many keys sharing a segment -- is flagged in C64_SLAB and the caller
     // searches again with exact bucket sizes)
     FQD_TRY(fqd_api_partition_pairs(c, hashes, U, B, !c->gp_slab_off && !getenv("FQD_GROUP_NO_SLABS"), &items,
-                                    &bucket_end));
+                                    &bucket_end, nullptr));
     unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(c->gp_small.as<uint32_t>() + 4096);
     // candidates (pairs with equal segment hashes) -> device list -> verification, one thread per pair
     if (c->gp_cand_cap < 1024 || !c->gp_cands.p) {
@@ -214,7 +359,11 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
     FQD_TRY(zero_ctr64(c, C64_EDGES));
     HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
     if (edit_general && U >= 2 && (max_distance > 0 || !c->collapsed)) {
-        FQD_TRY(find_edges_edit(c, (uint32_t)max_distance, shard, n_shards));
+        bool grouped_done = false;
+        if (n_shards == 1 && c->collapsed)
+            FQD_TRY(find_edges_edit_grouped(c, (uint32_t)max_distance, &grouped_done));
+        if (!grouped_done)
+            FQD_TRY(find_edges_edit(c, (uint32_t)max_distance, shard, n_shards));
     } else if (U >= 2 && (max_distance > 0 || !c->collapsed)) {
         // with d >= max_len every segment split has empty segments: still correct (all keys of a
         // length share the empty segment's bucket), just quadratic.

@@ -31,7 +31,9 @@ __global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
     const uint4 *__restrict__ recs4, uint32_t q_per_rec, const uint32_t *__restrict__ weights,
     uint32_t *__restrict__ tmp_rep, uint32_t *__restrict__ tmp_count, uint32_t *__restrict__ tmp_first,
     uint32_t *__restrict__ bucket_unique, uint32_t *__restrict__ overflow,
-    uint32_t tag_mask /* ~0; tests: few bits => different keys share a tag */)
+    uint32_t tag_mask /* ~0; tests: few bits => different keys share a tag */,
+    const uint32_t *__restrict__ lens /* ragged keys: equal records of different length are different keys (the
+                                         bases past a key's end hold code 0, like its first symbol might); else NULL */)
 {
     __shared__ uint32_t s_tag[PD_SLOTS], s_rep[PD_SLOTS], s_cnt[PD_SLOTS], s_min[PD_SLOTS];
     __shared__ uint32_t s_wave_tot[PD_THREADS / 64];
@@ -129,8 +131,12 @@ __global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
                 }
 #pragma unroll
                 for (uint32_t t = 0; t < 4; t++) {
-                    const bool diff = valid[t] && ((xa[t].x ^ xb[t].x) | (xa[t].y ^ xb[t].y) | (xa[t].z ^ xb[t].z) |
-                                                   (xa[t].w ^ xb[t].w)) != 0;
+                    bool diff = valid[t] && ((xa[t].x ^ xb[t].x) | (xa[t].y ^ xb[t].y) | (xa[t].z ^ xb[t].z) |
+                                             (xa[t].w ^ xb[t].w)) != 0;
+                    if (lens && valid[t] && ql == 0) {
+                        const uint32_t e = base + t * groups + gl;
+                        diff = diff || lens[s_qa[wave][e]] != lens[s_qb[wave][e]];
+                    }
                     const unsigned long long m = __ballot(diff);
                     if (valid[t] && ql == 0)      // the group's lanes are [lane, lane + q_per_rec)
                         s_qdiff[wave][base + t * groups + gl] =
@@ -201,7 +207,8 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
     uint32_t n_buckets, const uint32_t *__restrict__ tmp_rep, const uint32_t *__restrict__ tmp_count,
     const uint32_t *__restrict__ tmp_first, const uint4 *__restrict__ recs4, uint32_t q_per_rec, IdSource read_ids,
     uint4 *__restrict__ urecs4, uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst,
-    fqd::SegHashOut sho /* nseg != 0 (q_per_rec a power of two): also the segment hashes of the search that follows */)
+    fqd::SegHashOut sho /* nseg != 0 (q_per_rec a power of two): also the segment hashes of the search that follows */,
+    const uint32_t *__restrict__ lens, uint32_t *__restrict__ ulens /* ragged keys: their lengths travel too */)
 {
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= n_buckets)
@@ -211,6 +218,8 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
     for (uint32_t j = fqd_lane(); j < cnt; j += 64) {
         ucounts[begin + j] = tmp_count[src + j];
         ufirst[begin + j] = read_ids.at(tmp_first[src + j]);
+        if (lens)
+            ulens[begin + j] = lens[tmp_rep[src + j]];
     }
     const uint32_t n_unique = unique_incl[n_buckets - 1];
     for (uint32_t x = fqd_lane(); x < cnt * q_per_rec; x += 64) {
@@ -254,21 +263,23 @@ namespace fqd {
 hipError_t launch_bucket_pairs_dedupe(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                       uint32_t n_buckets, const uint32_t *recs, uint32_t stride_words,
                                       const uint32_t *weights, uint32_t *tmp_rep, uint32_t *tmp_count,
-                                      uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st)
+                                      uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st,
+                                      const uint32_t *lens)
 {
     if (!n_buckets || (stride_words & 3u))
         return n_buckets ? hipErrorInvalidValue : hipSuccess;
     bucket_pairs_dedupe_kernel<<<n_buckets, PD_THREADS, 0, st>>>(
         reinterpret_cast<const uint2 *>(items), bucket_start, bucket_end, reinterpret_cast<const uint4 *>(recs),
         stride_words / 4, weights, tmp_rep, tmp_count, tmp_first, bucket_unique, overflow,
-        getenv("FQD_PAIRS_TAG_MASK") ? (uint32_t)strtoul(getenv("FQD_PAIRS_TAG_MASK"), nullptr, 0) : 0xFFFFFFFFu);
+        getenv("FQD_PAIRS_TAG_MASK") ? (uint32_t)strtoul(getenv("FQD_PAIRS_TAG_MASK"), nullptr, 0) : 0xFFFFFFFFu, lens);
     return hipGetLastError();
 }
 
 hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                        const uint32_t *tmp_rep, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                        const uint32_t *recs, uint32_t stride_words, IdSource read_ids, uint32_t *urecs,
-                                       uint32_t *ucounts, uint64_t *ufirst, hipStream_t st, SegHashOut seg_hashes)
+                                       uint32_t *ucounts, uint64_t *ufirst, hipStream_t st, SegHashOut seg_hashes,
+                                       const uint32_t *lens, uint32_t *ulens)
 {
     if (!n_buckets)
         return hipSuccess;
@@ -278,7 +289,7 @@ hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint3
     const uint64_t threads = (uint64_t)n_buckets * 64;
     bucket_pairs_compact_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
         bucket_start, unique_incl, n_buckets, tmp_rep, tmp_count, tmp_first, reinterpret_cast<const uint4 *>(recs),
-        stride_words / 4, read_ids, reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes);
+        stride_words / 4, read_ids, reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, lens, ulens);
     return hipGetLastError();
 }
 

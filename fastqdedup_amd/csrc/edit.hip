@@ -258,6 +258,224 @@ __global__ __launch_bounds__(256) void edit_verify_kernel(const uint64_t *__rest
     }
 }
 
+// ---- the same search without a device-wide sort ("grouped") --------------------------------------
+// Items (substring hash, payload) instead of sorted records; payload = uid (26 bits) | segment (2) |
+// shift + 3 (3) | probe role (1), so d <= 3 and fewer than 2^26 keys. Fewer items, too:
+//   * an INDEX item per key and own segment, as before;
+//   * PROBE items only where one side of a pair has to file them: a pair (a, b) is found as soon as
+//     ONE of the two probes the other's length class (if lev(a, b) <= d, some segment of b occurs in
+//     a within d positions -- whichever of the two is called a), so of two length classes the
+//     smaller one probes the larger (ties: the shorter keys probe), and the own class is probed with
+//     shifts != 0 only (for d >= 2; with d = 1 two keys of one length are one substitution apart or
+//     not neighbours at all). 2 items per key instead of 20 for 300-nt keys with a 1 % indel tail.
+// The items are partitioned by hash bits and matched inside LDS (group.hip, the kernels of the
+// Hamming passes); a candidate pair carries both payloads. A pair usually matches under several
+// (direction, segment, shift) configurations: it is verified and reported under the FIRST matching
+// one only (directions in uid order, then segments, then shifts -- the substrings are compared,
+// a hash only proposes), so every edge comes out exactly once without sorting the candidates.
+constexpr uint32_t EG_UID_BITS = 26, EG_UID_MASK = (1u << EG_UID_BITS) - 1u;
+
+__device__ __forceinline__ uint32_t eg_payload(uint32_t uid, uint32_t seg, int delta, bool probe)
+{
+    return uid | (seg << EG_UID_BITS) | ((uint32_t)(delta + 3) << (EG_UID_BITS + 2)) | (probe ? ROLE_PROBE : 0u);
+}
+
+// does a key of length la file probes for class lb? (probe_mask[la] bit (lb - la + d); same class: shifts != 0)
+__device__ __forceinline__ bool eg_probes(const uint8_t *__restrict__ probe_mask, uint32_t la, uint32_t lb, uint32_t d)
+{
+    const int j = (int)lb - (int)la + (int)d;
+    return j >= 0 && j <= 2 * (int)d && ((probe_mask[la] >> j) & 1u);
+}
+
+__global__ void edit_len_counts_kernel(const uint32_t *__restrict__ ulens, uint64_t U, KeyShape sh,
+                                       uint32_t *__restrict__ counts)
+{
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < U)
+        atomicAdd(&counts[fqd_key_len(sh, ulens, u)], 1u);
+}
+
+// pass 0: per_key[u] = probe items key u files (by its length class). pass 1: the index items (slot
+// u * (d + 1) + s) and the probe items (behind all index items, at the key's scanned offset).
+__global__ __launch_bounds__(256) void edit_items_kernel(const uint32_t *__restrict__ urecs,
+                                                         const uint32_t *__restrict__ ulens, uint64_t U, KeyShape sh,
+                                                         uint32_t d, const uint8_t *__restrict__ probe_mask,
+                                                         const uint32_t *__restrict__ probe_count,
+                                                         uint32_t *__restrict__ per_key,
+                                                         const uint32_t *__restrict__ per_key_incl,
+                                                         uint32_t *__restrict__ hashes, uint32_t *__restrict__ payloads,
+                                                         int pass)
+{
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U)
+        return;
+    const uint32_t len = fqd_key_len(sh, ulens, u);
+    if (pass == 0) {
+        per_key[u] = probe_count[len];
+        return;
+    }
+    const uint32_t K = sh.planes, W = sh.words, nseg = d + 1;
+    const uint32_t *rec = urecs + u * sh.stride;
+    for (uint32_t s = 0; s < nseg; s++) {
+        uint32_t lo, hi;
+        fqd_segment(len, s, nseg, lo, hi);
+        hashes[u * nseg + s] = substring_hash(rec, K, W, len, s, lo, hi - lo);
+        payloads[u * nseg + s] = eg_payload((uint32_t)u, s, 0, false);
+    }
+    const uint32_t mine = probe_count[len];
+    if (!mine)
+        return;
+    uint64_t at = U * nseg + (per_key_incl[u] - mine);
+    for (int j = 0; j <= 2 * (int)d; j++) {
+        if (!((probe_mask[len] >> j) & 1u))
+            continue;
+        const uint32_t l = (uint32_t)((int)len - (int)d + j);
+        for (uint32_t s = 0; s < nseg; s++) {
+            uint32_t lo, hi;
+            fqd_segment(l, s, nseg, lo, hi);
+            const uint32_t nb = hi - lo;
+            for (int delta = -(int)d; delta <= (int)d; delta++) {
+                if (l == len && delta == 0)
+                    continue;
+                const int start = (int)lo + delta;
+                if (start < 0 || (uint32_t)start + nb > len)
+                    continue;
+                hashes[at] = substring_hash(rec, K, W, l, s, (uint32_t)start, nb);
+                payloads[at] = eg_payload((uint32_t)u, s, delta, true);
+                at++;
+            }
+        }
+    }
+}
+
+// bases [sa, sa + nb) of a  ==  bases [sb, sb + nb) of b ?
+__device__ __forceinline__ bool eg_same_substring(const uint32_t *__restrict__ a, uint32_t sa,
+                                                  const uint32_t *__restrict__ b, uint32_t sb, uint32_t nb, uint32_t K,
+                                                  uint32_t W)
+{
+    for (uint32_t off = 0; off < nb; off += 32) {
+        const uint32_t rem = nb - off;
+        const uint32_t mask = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u);
+        for (uint32_t k = 0; k < K; k++)
+            if ((plane_bits(a, K, W, k, sa + off) ^ plane_bits(b, K, W, k, sb + off)) & mask)
+                return false;
+    }
+    return true;
+}
+
+// Does configuration (prober a -> indexed b, segment s of b's class, shift delta) match?
+__device__ __forceinline__ bool eg_config_matches(const uint32_t *__restrict__ ra, uint32_t la,
+                                                  const uint32_t *__restrict__ rb, uint32_t lb, uint32_t s, int delta,
+                                                  uint32_t d, uint32_t K, uint32_t W)
+{
+    uint32_t lo, hi;
+    fqd_segment(lb, s, d + 1, lo, hi);
+    const int start = (int)lo + delta;
+    if (start < 0 || (uint32_t)start + (hi - lo) > la)
+        return false;
+    return eg_same_substring(ra, (uint32_t)start, rb, lo, hi - lo, K, W);
+}
+
+// One thread per candidate (payload, payload). n_lists lists of list_cap candidates, counters 8 words apart
+// (group.hip's layout).
+__global__ __launch_bounds__(256) void edit_grouped_verify_kernel(
+    const uint2 *__restrict__ cands, const unsigned long long *__restrict__ cand_count, uint64_t list_cap,
+    uint32_t n_lists, const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t d,
+    const uint8_t *__restrict__ probe_mask, uint32_t *__restrict__ edges, unsigned long long *__restrict__ edge_count,
+    uint64_t edge_cap, unsigned long long *__restrict__ cand_need, unsigned long long *__restrict__ n_verified)
+{
+    const uint32_t list = blockIdx.x % n_lists, part = blockIdx.x / n_lists, parts = gridDim.x / n_lists;
+    const unsigned long long filled = cand_count[(size_t)list * 8];
+    const unsigned long long total = filled < list_cap ? filled : list_cap;
+    if (part == 0 && threadIdx.x == 0 && filled > list_cap)
+        atomicMax(cand_need, filled * n_lists);
+    cands += (size_t)list * list_cap;
+    const uint32_t K = sh.planes, W = sh.words;
+    unsigned long long verified = 0;
+    for (unsigned long long base = (unsigned long long)part * blockDim.x; base < total;
+         base += (unsigned long long)parts * blockDim.x) {
+        const unsigned long long idx = base + threadIdx.x;
+        bool hit = false;
+        uint32_t eu = 0, ev = 0;
+        if (idx < total) {
+            const uint2 c = cands[idx];
+            uint32_t pa = c.x, pb = c.y;
+            const bool probe_a = (pa & ROLE_PROBE) != 0, probe_b = (pb & ROLE_PROBE) != 0;
+            uint32_t ua = pa & EG_UID_MASK, ub = pb & EG_UID_MASK;
+            if (ua != ub && !(probe_a && probe_b)) {
+                // (prober, indexed): the probe item's owner probes; two index items: the smaller uid "probes"
+                if (probe_b || (!probe_a && ub < ua)) {
+                    const uint32_t t = pa;
+                    pa = pb;
+                    pb = t;
+                    const uint32_t tu = ua;
+                    ua = ub;
+                    ub = tu;
+                }
+                const uint32_t la = fqd_key_len(sh, ulens, ua), lb = fqd_key_len(sh, ulens, ub);
+                const uint32_t gap = la > lb ? la - lb : lb - la;
+                const uint32_t seg = (pa >> EG_UID_BITS) & 3u;
+                const int delta = (int)((pa >> (EG_UID_BITS + 2)) & 7u) - 3;
+                const bool both_index = !((pa | pb) & ROLE_PROBE);
+                // an index item of the other segment number cannot be this probe's partner (hash collision)
+                const bool seg_ok = ((pb >> EG_UID_BITS) & 3u) == seg;
+                if (gap <= d && seg_ok && (!both_index || la == lb)) {
+                    const uint32_t *ra = urecs + (uint64_t)ua * sh.stride, *rb = urecs + (uint64_t)ub * sh.stride;
+                    // the first configuration under which the pair matches, in the order: direction
+                    // (smaller uid probing first), segment, shift -- among the configurations that are filed
+                    const uint32_t x = ua < ub ? ua : ub;
+                    bool mine_is_first = false, found = false;
+                    for (int dir = 0; dir < 2 && !found; dir++) {
+                        const bool a_probes = (dir == 0) == (ua == x);        // this direction has `a` as the prober
+                        const uint32_t *rp = a_probes ? ra : rb, *ri = a_probes ? rb : ra;
+                        const uint32_t lp = a_probes ? la : lb, li = a_probes ? lb : la;
+                        const bool same_class = lp == li;
+                        if (!same_class && !eg_probes(probe_mask, lp, li, d))
+                            continue;
+                        for (uint32_t s = 0; s <= d && !found; s++)
+                            for (int dl = -(int)d; dl <= (int)d && !found; dl++) {
+                                if (same_class) {
+                                    if (dl == 0 ? dir == 1 : !eg_probes(probe_mask, lp, li, d))
+                                        continue;      // shift 0: the index-index match, counted once; shifts != 0: filed for d >= 2
+                                }
+                                if (eg_config_matches(rp, lp, ri, li, s, dl, d, K, W)) {
+                                    found = true;
+                                    mine_is_first = a_probes && s == seg && dl == delta;
+                                }
+                            }
+                    }
+                    if (mine_is_first) {
+                        verified++;
+                        const RecSeq sa{ra, K}, sb{rb, K};
+                        hit = within_edit(sa, la, sb, lb, (int)d);
+                        eu = ua < ub ? ua : ub;
+                        ev = ua < ub ? ub : ua;
+                    }
+                }
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned long long at = 0;
+            if ((int)fqd_lane() == leader)
+                at = atomicAdd(edge_count, (unsigned long long)__popcll(m));
+            at = __shfl(at, leader);
+            if (hit) {
+                at += __popcll(m & fqd_lanemask_lt());
+                if (at < edge_cap) {
+                    edges[2 * at] = eu;
+                    edges[2 * at + 1] = ev;
+                }
+            }
+        }
+    }
+    for (int o = 32; o; o >>= 1)
+        verified += __shfl_xor(verified, o);
+    if (fqd_lane() == 0 && verified)
+        atomicAdd(n_verified, verified);
+}
+
 __global__ void len_present_kernel(const uint32_t *__restrict__ ulens, uint64_t U, KeyShape sh,
                                    uint8_t *__restrict__ len_present)
 {
@@ -330,6 +548,35 @@ hipError_t launch_edit_verify(const uint64_t *cands, uint64_t C, const uint32_t 
 {
     if (C)
         edit_verify_kernel<<<grid_for(C), 256, 0, st>>>(cands, C, urecs, ulens, sh, d, edges, edge_count, edge_cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_edit_len_counts(const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t *counts, hipStream_t st)
+{
+    if (U)
+        edit_len_counts_kernel<<<grid_for(U), 256, 0, st>>>(ulens, U, sh, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_edit_items(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t d,
+                             const uint8_t *probe_mask, const uint32_t *probe_count, uint32_t *per_key,
+                             const uint32_t *per_key_incl, uint32_t *hashes, uint32_t *payloads, int pass, hipStream_t st)
+{
+    if (U)
+        edit_items_kernel<<<grid_for(U), 256, 0, st>>>(urecs, ulens, U, sh, d, probe_mask, probe_count, per_key,
+                                                        per_key_incl, hashes, payloads, pass);
+    return hipGetLastError();
+}
+
+hipError_t launch_edit_grouped_verify(const uint64_t *cands, const unsigned long long *cand_count, uint64_t list_cap,
+                                      uint32_t n_lists, const uint32_t *urecs, const uint32_t *ulens, KeyShape sh,
+                                      uint32_t d, const uint8_t *probe_mask, uint32_t *edges,
+                                      unsigned long long *edge_count, uint64_t edge_cap, unsigned long long *cand_need,
+                                      unsigned long long *n_verified, hipStream_t st)
+{
+    edit_grouped_verify_kernel<<<n_lists * 32, 256, 0, st>>>(reinterpret_cast<const uint2 *>(cands), cand_count, list_cap,
+                                                             n_lists, urecs, ulens, sh, d, probe_mask, edges, edge_count,
+                                                             edge_cap, cand_need, n_verified);
     return hipGetLastError();
 }
 

@@ -292,12 +292,14 @@ struct SegHashOut {
 hipError_t launch_bucket_pairs_dedupe(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                       uint32_t n_buckets, const uint32_t *recs, uint32_t stride_words,
                                       const uint32_t *weights, uint32_t *tmp_rep, uint32_t *tmp_count,
-                                      uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);
+                                      uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st,
+                                      const uint32_t *lens = nullptr);
 hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                        const uint32_t *tmp_rep, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                        const uint32_t *recs, uint32_t stride_words, IdSource read_ids, uint32_t *urecs,
                                        uint32_t *ucounts, uint64_t *ufirst, hipStream_t st,
-                                       SegHashOut seg_hashes = SegHashOut());
+                                       SegHashOut seg_hashes = SegHashOut(), const uint32_t *lens = nullptr,
+                                       uint32_t *ulens = nullptr);
 hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                 hipStream_t st);
 hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
@@ -341,6 +343,16 @@ hipError_t launch_edit_candidates(const uint32_t *sorted_hash, const uint32_t *s
 hipError_t launch_edit_verify(const uint64_t *cands, uint64_t C, const uint32_t *urecs, const uint32_t *ulens,
                               KeyShape sh, uint32_t d, uint32_t *edges, unsigned long long *edge_count,
                               uint64_t edge_cap, hipStream_t st);
+// the bucketed edit search without a sort (edit.hip, "grouped"): items = (substring hash, payload)
+hipError_t launch_edit_len_counts(const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t *counts, hipStream_t st);
+hipError_t launch_edit_items(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t d,
+                             const uint8_t *probe_mask, const uint32_t *probe_count, uint32_t *per_key,
+                             const uint32_t *per_key_incl, uint32_t *hashes, uint32_t *payloads, int pass, hipStream_t st);
+hipError_t launch_edit_grouped_verify(const uint64_t *cands, const unsigned long long *cand_count, uint64_t list_cap,
+                                      uint32_t n_lists, const uint32_t *urecs, const uint32_t *ulens, KeyShape sh,
+                                      uint32_t d, const uint8_t *probe_mask, uint32_t *edges,
+                                      unsigned long long *edge_count, uint64_t edge_cap, unsigned long long *cand_need,
+                                      unsigned long long *n_verified, hipStream_t st);
 hipError_t launch_contains(const uint8_t *q, const uint64_t *qo, uint64_t nq, const uint32_t *urecs,
                            const uint32_t *ulens, uint64_t U, KeyShape sh, const uint8_t *alphabet_dev, int d,
                            int metric, uint32_t *hit_flags, hipStream_t st, const uint8_t *alive = nullptr);
@@ -355,7 +367,7 @@ hipError_t launch_group_hist(bool level1, const uint32_t *hashes, const uint32_t
 hipError_t launch_group_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
                                 const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                 uint32_t n_bins, uint32_t *cursor, uint32_t *out, hipStream_t st, uint32_t slab_cap = 0,
-                                uint32_t *slab_overflow = nullptr);
+                                uint32_t *slab_overflow = nullptr, const uint32_t *values = nullptr);
 hipError_t launch_group_tile_starts(const uint32_t *seg_start, uint32_t n_seg, uint32_t *tile_start, hipStream_t st);
 hipError_t launch_group_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                       hipStream_t st);
@@ -489,5 +501,8 @@ hipError_t launch_transcode_records(const uint32_t *src, const uint32_t *src_len
 hipError_t launch_synth(uint8_t *out, uint64_t n_total, uint64_t start, uint64_t count, uint32_t length,
                         uint32_t umi, uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub,
                         hipStream_t st);
+hipError_t launch_synth_indels(uint64_t n_total, uint64_t start, uint64_t count, uint32_t length, uint32_t umi,
+                               uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub, uint64_t thr_indel,
+                               unsigned long long *lens, const unsigned long long *offsets, uint8_t *out, hipStream_t st);
 
 }  // namespace fqd

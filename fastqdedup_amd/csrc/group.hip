@@ -30,11 +30,12 @@ struct PairPolicy {
     struct Source {
         const uint32_t *hashes;   // level 1
         const uint2 *in;          // level 2
+        const uint32_t *values;   // level 1: what travels with hash i (NULL: its position i)
     };
     template <bool LEVEL1>
     static __device__ __forceinline__ uint32_t load(const Source &s, uint32_t i, uint2 &v)
     {
-        v = LEVEL1 ? make_uint2(s.hashes[i], i) : s.in[i];
+        v = LEVEL1 ? make_uint2(s.hashes[i], s.values ? s.values[i] : i) : s.in[i];
         return v.x;
     }
     template <bool LEVEL1>
@@ -531,7 +532,7 @@ hipError_t launch_group_hist(bool level1, const uint32_t *hashes, const uint32_t
 {
     if (!max_tiles)
         return hipSuccess;
-    const PairPolicy::Source src{hashes, reinterpret_cast<const uint2 *>(in)};
+    const PairPolicy::Source src{hashes, reinterpret_cast<const uint2 *>(in), nullptr};
     if (level1)
         gp_hist_kernel<true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, shift,
                                                                            n_bins, hist);
@@ -544,11 +545,11 @@ hipError_t launch_group_hist(bool level1, const uint32_t *hashes, const uint32_t
 hipError_t launch_group_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
                                 const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                 uint32_t n_bins, uint32_t *cursor, uint32_t *out, hipStream_t st, uint32_t slab_cap,
-                                uint32_t *slab_overflow)
+                                uint32_t *slab_overflow, const uint32_t *values)
 {
     if (!max_tiles)
         return hipSuccess;
-    const PairPolicy::Source src{hashes, reinterpret_cast<const uint2 *>(in)};
+    const PairPolicy::Source src{hashes, reinterpret_cast<const uint2 *>(in), values};
     uint2 *out2 = reinterpret_cast<uint2 *>(out);
     if (level1)
         gp_scatter_kernel<true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, shift,

@@ -17,38 +17,109 @@ __device__ __forceinline__ uint64_t stream_base(uint64_t seed, uint64_t stream)
     return splitmix64(seed + stream * 0xD1B54A32D192ED03ull);
 }
 
-// one thread per (read, base); consecutive threads write consecutive bytes
-__global__ __launch_bounds__(256) void synth_kernel(uint8_t *__restrict__ out, uint64_t n_total, uint64_t start,
-                                                    uint64_t count, uint32_t length, uint32_t umi, uint64_t seed,
-                                                    uint32_t copies, uint64_t thr_n, uint64_t thr_sub)
+struct SynthParams {
+    uint64_t n_total, seed, thr_n, thr_sub;
+    uint32_t length, umi, copies;
+};
+
+// base b of read r of the fixed-length job
+__device__ __forceinline__ uint8_t synth_base(const SynthParams &p, uint64_t r, uint32_t b)
 {
-    uint64_t M = n_total / copies;
+    uint64_t M = p.n_total / p.copies;
     if (M < 1)
         M = 1;
     uint64_t F = M / 4;
     if (F < 1)
         F = 1;
-    const uint64_t total = count * length;
+    const uint64_t mol = splitmix64(stream_base(p.seed, 0) ^ r) % M;
+    uint64_t truth;
+    if (b < p.umi) {
+        truth = splitmix64(stream_base(p.seed, 2) ^ (mol * p.umi + b)) & 3ull;
+    } else {
+        const uint64_t ins = splitmix64(stream_base(p.seed, 1) ^ mol) % F;
+        truth = splitmix64(stream_base(p.seed, 3) ^ (ins * (uint64_t)(p.length - p.umi) + (b - p.umi))) & 3ull;
+    }
+    const uint64_t e = splitmix64(stream_base(p.seed, 4) ^ (r * p.length + b));
+    const uint64_t u = e >> 11;
+    const uint64_t sub = (truth + 1ull + (e & 0x7FFull) % 3ull) & 3ull;
+    const uint64_t code = u < p.thr_n + p.thr_sub ? sub : truth;
+    const char bases[4] = {'A', 'C', 'G', 'T'};
+    return u < p.thr_n ? (uint8_t)'N' : (uint8_t)bases[code];
+}
+
+// one thread per (read, base); consecutive threads write consecutive bytes
+__global__ __launch_bounds__(256) void synth_kernel(uint8_t *__restrict__ out, SynthParams p, uint64_t start,
+                                                    uint64_t count)
+{
+    const uint64_t total = count * p.length;
     // grid-stride: HIP caps a launch at 2^32 threads and config 5 has 1.5e10 bases
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t local = t / length;
-        const uint32_t b = (uint32_t)(t - local * length);
+        const uint64_t local = t / p.length;
+        out[t] = synth_base(p, start + local, (uint32_t)(t - local * p.length));
+    }
+}
+
+// ---- the indel tail (synth.py indel_variant): a share thr_indel / 2^53 of the reads loses one base
+// or gains one, so the job has three key lengths (the 149/151-nt sub-population)
+struct IndelOf {
+    int delta;          // -1, 0, +1
+    uint32_t pos;       // deleted base / position of the inserted base
+    uint8_t base;       // the inserted base
+};
+
+__device__ __forceinline__ IndelOf synth_indel(const SynthParams &p, uint64_t thr_indel, uint64_t r)
+{
+    IndelOf o{0, 0, 0};
+    const uint64_t e = splitmix64(stream_base(p.seed, 5) ^ r);
+    if ((e >> 11) >= thr_indel)
+        return o;
+    const uint64_t h = splitmix64(stream_base(p.seed, 6) ^ r);
+    const char bases[4] = {'A', 'C', 'G', 'T'};
+    if (e & 1ull) {
+        o.delta = 1;
+        o.pos = (uint32_t)((h & 0xFFFFFFFFull) % (p.length + 1));
+        o.base = (uint8_t)bases[(h >> 32) & 3ull];
+    } else {
+        o.delta = -1;
+        o.pos = (uint32_t)((h & 0xFFFFFFFFull) % p.length);
+    }
+    return o;
+}
+
+__global__ void synth_indel_lens_kernel(SynthParams p, uint64_t thr_indel, uint64_t start, uint64_t count,
+                                        unsigned long long *__restrict__ lens)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count)
+        lens[i] = (unsigned long long)((int)p.length + synth_indel(p, thr_indel, start + i).delta);
+}
+
+// one thread per (read, output position < length + 1)
+__global__ __launch_bounds__(256) void synth_indel_bytes_kernel(SynthParams p, uint64_t thr_indel, uint64_t start,
+                                                                uint64_t count,
+                                                                const unsigned long long *__restrict__ offsets,
+                                                                uint8_t *__restrict__ out)
+{
+    const uint32_t span = p.length + 1;
+    const uint64_t total = count * span;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t local = t / span;
+        const uint32_t q = (uint32_t)(t - local * span);
         const uint64_t r = start + local;
-        const uint64_t mol = splitmix64(stream_base(seed, 0) ^ r) % M;
-        uint64_t truth;
-        if (b < umi) {
-            truth = splitmix64(stream_base(seed, 2) ^ (mol * umi + b)) & 3ull;
-        } else {
-            const uint64_t ins = splitmix64(stream_base(seed, 1) ^ mol) % F;
-            truth = splitmix64(stream_base(seed, 3) ^ (ins * (uint64_t)(length - umi) + (b - umi))) & 3ull;
-        }
-        const uint64_t e = splitmix64(stream_base(seed, 4) ^ (r * length + b));
-        const uint64_t u = e >> 11;
-        const uint64_t sub = (truth + 1ull + (e & 0x7FFull) % 3ull) & 3ull;
-        const uint64_t code = u < thr_n + thr_sub ? sub : truth;
-        const char bases[4] = {'A', 'C', 'G', 'T'};
-        out[t] = u < thr_n ? (uint8_t)'N' : (uint8_t)bases[code];
+        const IndelOf in = synth_indel(p, thr_indel, r);
+        const uint32_t len = (uint32_t)((int)p.length + in.delta);
+        if (q >= len)
+            continue;
+        uint8_t ch;
+        if (in.delta < 0)
+            ch = synth_base(p, r, q < in.pos ? q : q + 1);
+        else if (in.delta > 0)
+            ch = q == in.pos ? in.base : synth_base(p, r, q < in.pos ? q : q - 1);
+        else
+            ch = synth_base(p, r, q);
+        out[offsets[local] + q] = ch;
     }
 }
 
@@ -68,8 +139,29 @@ hipError_t launch_synth(uint8_t *out, uint64_t n_total, uint64_t start, uint64_t
     uint64_t blocks = (total + 255) / 256;
     if (blocks > (1u << 20))
         blocks = 1u << 20;
-    synth_kernel<<<(unsigned)blocks, 256, 0, st>>>(out, n_total, start, count, length, umi, seed, copies, thr_n,
-                                                   thr_sub);
+    const SynthParams p{n_total, seed, thr_n, thr_sub, length, umi, copies};
+    synth_kernel<<<(unsigned)blocks, 256, 0, st>>>(out, p, start, count);
+    return hipGetLastError();
+}
+
+// lens != NULL: the key lengths (u64, for a scan into offsets); else offsets + out: the key bytes
+hipError_t launch_synth_indels(uint64_t n_total, uint64_t start, uint64_t count, uint32_t length, uint32_t umi,
+                               uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub, uint64_t thr_indel,
+                               unsigned long long *lens, const unsigned long long *offsets, uint8_t *out, hipStream_t st)
+{
+    if (!count || !length)
+        return hipSuccess;
+    if (umi > length)
+        umi = length;
+    const SynthParams p{n_total, seed, thr_n, thr_sub, length, umi, copies};
+    if (lens) {
+        synth_indel_lens_kernel<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(p, thr_indel, start, count, lens);
+    } else {
+        uint64_t blocks = (count * (length + 1) + 255) / 256;
+        if (blocks > (1u << 20))
+            blocks = 1u << 20;
+        synth_indel_bytes_kernel<<<(unsigned)blocks, 256, 0, st>>>(p, thr_indel, start, count, offsets, out);
+    }
     return hipGetLastError();
 }
 

@@ -91,3 +91,38 @@ def _synth(n, length, umi, seed, copies, sub_rate, n_rate, start, n_total):
 
 def fixed_offsets(n: int, length: int) -> np.ndarray:
     return np.arange(n + 1, dtype=np.uint64) * np.uint64(length)
+
+
+def indel_variant(keys: np.ndarray, seed: int, *, indel_rate: float = 0.01, start: int = 0):
+    """The indel tail of SURVEY.md 8d (a share ``indel_rate`` of the reads is one base short or one
+    base long): ``keys`` is the ``(n, L)`` array of ``synth_keys`` / ``synth_keys_range`` (reads
+    ``start ..``); returns ``(bytes, offsets)`` of the ragged job. Device twin: ``fqd_synth_indel_keys``."""
+    n, L = keys.shape
+    r = np.arange(start, start + n, dtype=np.uint64)
+    e = stream_hash(seed, 5, r)
+    hit = (e >> np.uint64(11)) < np.uint64(rate_threshold(indel_rate))
+    h = stream_hash(seed, 6, r)
+    lens = np.full(n, L, dtype=np.int64)
+    ins = hit & ((e & np.uint64(1)) == np.uint64(1))
+    dele = hit & ~ins
+    lens[ins] += 1
+    lens[dele] -= 1
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens).astype(np.uint64)
+    out = np.empty(int(offsets[-1]), dtype=np.uint8)
+    plain = ~hit
+    # unaffected reads: one vectorised copy
+    idx = (offsets[:-1][plain].astype(np.int64)[:, None] + np.arange(L, dtype=np.int64)[None, :]).reshape(-1)
+    out[idx] = keys[plain].reshape(-1)
+    low = h & np.uint64(0xFFFFFFFF)
+    for i in np.flatnonzero(hit):
+        row = keys[i]
+        o = int(offsets[i])
+        if ins[i]:
+            pos = int(low[i] % np.uint64(L + 1))
+            base = BASES[int((h[i] >> np.uint64(32)) & np.uint64(3))]
+            out[o:o + L + 1] = np.concatenate([row[:pos], [base], row[pos:]])
+        else:
+            pos = int(low[i] % np.uint64(L))
+            out[o:o + L - 1] = np.concatenate([row[:pos], row[pos + 1:]])
+    return out, offsets

@@ -28,7 +28,11 @@
  * usable gfx950 device fqd_create fails with FQD_E_DEVICE.
  *
  * Memory: `mem` says where caller buffers live (FQD_HOST or FQD_DEVICE).
- * Device buffers must be 16-byte aligned and stay valid until the call returns.
+ * Device buffers must be 16-byte aligned and stay valid until the call returns; device SOURCES of
+ * the fqd_import_* calls are copied on the context's stream without a host wait, so they must stay
+ * unchanged until the context has been synchronised (any call that returns a count does that) or
+ * until work of the legacy default stream, which orders itself behind the context's stream, reuses
+ * them -- what a torch caller does.
  * Results are copied into caller-provided buffers.
  */
 #ifndef FQDEDUP_HIP_H
@@ -409,6 +413,16 @@ int fqd_edge_stats(fqd_ctx *ctx, uint64_t *keys_gathered, uint64_t *pairs_compar
 int fqd_synth_keys(fqd_ctx *ctx, uint8_t *out_device, uint64_t n_total, uint64_t start,
                    uint64_t count, uint32_t length, uint32_t umi, uint64_t seed, uint32_t copies,
                    uint64_t thr_n, uint64_t thr_sub);
+
+/* The same job with an indel tail (fastqdedup_amd/synth.py indel_variant, byte-identical): a share
+ * thr_indel / 2^53 of the reads loses one base or gains one, so the keys have three lengths -- the
+ * shape SURVEY.md 8d asks for to exercise the Levenshtein search. Two calls: lens_out_device != NULL
+ * writes the `count` key lengths (uint64, device); with their exclusive scan in offsets_device
+ * (count + 1 entries) the second call writes the key bytes. Bench/test utility. */
+int fqd_synth_indel_keys(fqd_ctx *ctx, uint64_t n_total, uint64_t start, uint64_t count, uint32_t length,
+                         uint32_t umi, uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub,
+                         uint64_t thr_indel, uint64_t *lens_out_device, const uint64_t *offsets_device,
+                         uint8_t *out_device);
 
 #ifdef __cplusplus
 }

@@ -991,3 +991,91 @@ def test_full_size_properties(F, ctx):
     sub = dev.view(n, L)[sel].contiguous().view(-1)
     again = F.cluster_keys(sub, key_len=L, max_distance=1, method="adjacency", context=ctx)
     assert again.n_edges == 0 and again.n_kept == ad.n_kept
+
+
+def test_synth_indel_twin(ctx):
+    """The device generator of the indel tail (fqd_synth_indel_keys) equals synth.indel_variant byte for byte."""
+    from fastqdedup_amd.synth import indel_variant, synth_keys
+    n, L, umi, seed = 30_000, 150, 150, 1005
+    got_bytes, got_off = ctx.synth_indel_keys(n, 0, n, L, umi, seed, indel_rate=0.03)
+    want_bytes, want_off = indel_variant(synth_keys(n, L, umi, seed), seed, indel_rate=0.03)
+    assert np.array_equal(got_off.cpu().numpy().astype(np.uint64), want_off)
+    assert np.array_equal(got_bytes.cpu().numpy(), want_bytes)
+    lens = np.diff(want_off.astype(np.int64))
+    assert set(lens.tolist()) == {L - 1, L, L + 1}
+
+
+@pytest.mark.parametrize("path", ["grouped", "sort"])
+def test_edit_search_with_an_indel_tail_matches_oracle(F, oracle, monkeypatch, path):
+    """SURVEY.md 8d's config-5 variant: paired 2x150 keys (300 nt) of which 1 % are 299 or 301 nt
+    long, Levenshtein d = 1, adjacency -- 250 k reads against the oracle, through the sort-free
+    search (items partitioned and matched in LDS) and through the sorted one; both must also
+    report every edge exactly once (same edge count)."""
+    from fastqdedup_amd.synth import indel_variant, synth_keys
+    monkeypatch.setenv("FQD_EDIT", path)
+    n, L, seed = 250_000, 300, 1005
+    raw, off = indel_variant(synth_keys(n, L, L, seed), seed, indel_rate=0.01)
+    ctx = F.Context(0)
+    got = F.cluster_keys(raw, off, max_distance=1, use_edit_distance=True, method="adjacency", context=ctx)
+    want = oracle.dedup(raw, off, max_distance=1, use_edit_distance=True, method="adjacency")
+    assert got.n_unique == want["n_unique"]
+    assert got.n_clusters == want["n_clusters"]
+    assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+    times = ctx.kernel_times(reset=True)
+    if path == "grouped":
+        assert times["gp_scatter_kernel"][1] and times["verify_candidates_kernel"][1], times   # the sort-free way ran
+    test_edit_search_with_an_indel_tail_matches_oracle.edges = getattr(
+        test_edit_search_with_an_indel_tail_matches_oracle, "edges", {})
+    test_edit_search_with_an_indel_tail_matches_oracle.edges[path] = got.n_edges
+    e = test_edit_search_with_an_indel_tail_matches_oracle.edges
+    if len(e) == 2:
+        assert e["grouped"] == e["sort"]
+
+
+@pytest.mark.parametrize("d,method", [(2, "directional"), (3, "adjacency"), (1, "highest_count")])
+def test_grouped_edit_search_mixed_lengths(F, oracle, monkeypatch, d, method):
+    """Several length classes of comparable size, indels and substitutions, d up to 3: the probing
+    rule (the smaller class probes the larger, the own class with shifts) and the
+    first-matching-configuration rule against the oracle and against the sorted search."""
+    import random
+    rng = random.Random(100 + d)
+    mols = ["".join(rng.choice("ACGT") for _ in range(rng.choice([38, 39, 40, 40, 41]))) for _ in range(2500)]
+    strs = []
+    for _ in range(40_000):
+        s = list(rng.choice(mols))
+        for _ in range(rng.choice([0, 0, 1, 1, 2, 3])):
+            pos = rng.randrange(len(s))
+            s[pos:pos + 1] = rng.choice([[], [rng.choice("ACGTN")], [s[pos], rng.choice("ACGT")]])
+        strs.append("".join(s))
+    raw, off = _pack(strs)
+    ctx = F.Context(0)
+    out = {}
+    for path in ("grouped", "sort"):
+        monkeypatch.setenv("FQD_EDIT", path)
+        out[path] = F.cluster_keys(raw, off, max_distance=d, use_edit_distance=True, method=method, context=ctx)
+    want = oracle.dedup(raw, off, max_distance=d, use_edit_distance=True, method=method)
+    for path, got in out.items():
+        assert got.n_unique == want["n_unique"] and got.n_clusters == want["n_clusters"], path
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), path
+    assert out["grouped"].n_edges == out["sort"].n_edges
+
+
+def test_ragged_keys_collapse_without_a_sort(F, oracle, monkeypatch):
+    """Ragged keys (trimmed reads) through the (hash, position) pairs collapse: lengths are compared
+    with the records -- 'AC' and 'ACA' pack to the same words when A is code 0."""
+    import random
+    rng = random.Random(6)
+    mols = ["".join(rng.choice("ACGT") for _ in range(rng.randint(20, 60))) for _ in range(20_000)]
+    strs = [rng.choice(mols) for _ in range(150_000)]
+    strs += ["A" * k for k in range(1, 70)] * 3 + ["AC", "ACA", "ACAA", "AC"]
+    raw, off = _pack(strs)
+    want = oracle.dedup(raw, off, max_distance=1, method="directional")
+    for path in ("pairs", "sort"):
+        monkeypatch.setenv("FQD_COLLAPSE", path)
+        ctx = F.Context(0)
+        got = F.cluster_keys(raw, off, max_distance=1, method="directional", context=ctx)
+        assert got.n_unique == want["n_unique"], path
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), path
+        times = ctx.kernel_times(reset=True)
+        if path == "pairs":
+            assert times["bucket_dedupe_kernel"][1] and not times["head_flags_kernel"][1], times
