@@ -330,6 +330,10 @@ class Trie:
             self._alphabet.append(c)
             self._unregistered.discard(c)
 
+    @property
+    def number_of_sequences(self) -> int:
+        return self._nseq
+
     # -- the device store ---------------------------------------------------
     def _store(self) -> Context:
         if self._ctx is None:

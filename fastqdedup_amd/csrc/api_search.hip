@@ -81,9 +81,13 @@ namespace {
 // items only from the smaller of two length classes), partitioned by hash bits and matched in LDS
 // by the kernels of the Hamming passes, every pair verified once under its first matching
 // configuration. *done = false: not applicable (d > 3, 2^26 keys or more) -- the sorted way runs.
-int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done)
+// cross_only (d = 1): pairs of keys of ONE length are Hamming neighbours or no neighbours -- the
+// Hamming passes have reported them into c->edges already (c->E of them); this search appends the
+// pairs of different lengths behind them.
+int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done, bool cross_only = false)
 {
     *done = false;
+    const uint64_t base_edges = cross_only ? c->E : 0;
     const uint64_t U = c->U;
     const KeyShape sh = c->ks;
     const char *pin = getenv("FQD_EDIT");                  // "sort" / "grouped": tests pin a path
@@ -96,12 +100,16 @@ int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done)
     HIP_TRY(c, c->eg_tables.reserve(((size_t)L + 1) * 12 + 64));
     uint32_t *d_counts = c->eg_tables.as<uint32_t>();          // [L + 1] keys per length, later probe items per key of that length
     uint8_t *d_mask = reinterpret_cast<uint8_t *>(d_counts + (L + 1));
-    HIP_TRY(c, hipMemsetAsync(d_counts, 0, ((size_t)L + 1) * 4, c->st));
-    HIP_TRY(c, fqd::launch_edit_len_counts(c->ulens.as<uint32_t>(), U, sh, d_counts, c->st));
-    std::vector<uint32_t> counts((size_t)L + 1), probe_count((size_t)L + 1, 0);
+    std::vector<uint32_t> counts((size_t)L + 1, 0), probe_count((size_t)L + 1, 0);
     std::vector<uint8_t> mask((size_t)L + 1, 0);
-    HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, stream_wait(c->st));
+    if (sh.ragged) {
+        HIP_TRY(c, hipMemsetAsync(d_counts, 0, ((size_t)L + 1) * 4, c->st));
+        HIP_TRY(c, fqd::launch_edit_len_counts(c->ulens.as<uint32_t>(), U, sh, d_counts, c->st));
+        HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(c, stream_wait(c->st));
+    } else {
+        counts[L] = (uint32_t)U;               // one length class
+    }
     uint64_t n_probe = 0;
     for (uint32_t la = 0; la <= L; la++) {
         if (!counts[la])
@@ -164,14 +172,15 @@ int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done)
         HIP_TRY(c, c->gp_cands.reserve(c->gp_cand_cap * 8));
     }
     c->gp_cand_cap = c->gp_cands.cap / 8;
-    if (c->edge_cap < 1024 || !c->edges.p) {
+    if (!cross_only && (c->edge_cap < 1024 || !c->edges.p)) {
         c->edge_cap = std::max<uint64_t>(1024, U);
         HIP_TRY(c, c->edges.reserve(c->edge_cap * 8));
     }
     c->edge_cap = c->edges.cap / 8;
     unsigned long long *ctr = c->d_ctr64.as<unsigned long long>();
     for (int attempt = 0;; attempt++) {
-        FQD_TRY(zero_ctr64(c, C64_EDGES));
+        c->h_extra64[7] = base_edges;                  // the edge counter starts behind the edges already there
+        HIP_TRY(c, hipMemcpyAsync(ctr + C64_EDGES, &c->h_extra64[7], 8, hipMemcpyHostToDevice, c->st));
         FQD_TRY(zero_ctr64(c, C64_CAND_NEED, 2));      // ... and C64_SLAB
         FQD_TRY(zero_ctr64(c, C64_SUM));
         const uint32_t *items = nullptr, *bucket_end = nullptr;
@@ -184,7 +193,7 @@ int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done)
         KTIME(c, FQD_K_VERIFY, fqd::launch_edit_grouped_verify(
                   c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap / fqd::group_cand_lists(), fqd::group_cand_lists(),
                   c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, d_mask, c->edges.as<uint32_t>(), ctr + C64_EDGES,
-                  c->edge_cap, ctr + C64_CAND_NEED, ctr + C64_SUM, c->st));
+                  c->edge_cap, ctr + C64_CAND_NEED, ctr + C64_SUM, cross_only ? 1 : 0, c->st));
         unsigned long long ctrs[C64_SLAB + 1] = {0};
         FQD_TRY(read_ctr64(c, 0, ctrs, C64_SLAB + 1));
         const unsigned long long now = ctrs[C64_EDGES], cand_need = ctrs[C64_CAND_NEED];
@@ -193,15 +202,21 @@ int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done)
             c->gp_slab_off = true;
         if (!slab_over && now <= c->edge_cap && cand_need <= c->gp_cand_cap) {
             c->E = now;
-            c->last_stats.pairs_compared = ctrs[C64_SUM];
+            c->last_stats.pairs_compared += ctrs[C64_SUM];
             c->last_stats.edges = now;
             break;
         }
         if (attempt > 3)
             return fail(c, FQD_E_RUNTIME, "edit search: buffers kept overflowing");
         if (now > c->edge_cap) {
+            // a larger edge buffer; the edges that were there before this search move over
+            DevBuf bigger;
+            HIP_TRY(c, bigger.reserve((size_t)(now + now / 8 + 1024) * 8));
+            if (base_edges)
+                HIP_TRY(c, hipMemcpyAsync(bigger.p, c->edges.p, (size_t)base_edges * 8, hipMemcpyDeviceToDevice, c->st));
+            HIP_TRY(c, stream_wait(c->st));
             c->edges.release();
-            HIP_TRY(c, c->edges.reserve((size_t)(now + now / 8 + 1024) * 8));
+            c->edges = bigger;
             c->edge_cap = c->edges.cap / 8;
         }
         if (cand_need > c->gp_cand_cap) {
@@ -343,7 +358,16 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
     const KeyShape sh = c->ks;
     // Levenshtein <= 1 between keys of ONE length is Hamming <= 1 (an indel changes the length):
     // that case shares the Hamming search; everything else takes the bucketed edit search.
-    const bool edit_general = metric == FQD_METRIC_EDIT && !(max_distance <= 1 && !sh.ragged);
+    bool edit_general = metric == FQD_METRIC_EDIT && !(max_distance <= 1 && !sh.ragged);
+    // Levenshtein d = 1 over several key lengths: pairs of ONE length are the Hamming passes' (one edit
+    // that keeps the length is a substitution); only pairs of different lengths need the edit search
+    // proper, which then runs behind the passes and appends to their edges (FQD_EDIT pins a path).
+    bool cross_after = false;
+    if (edit_general && max_distance == 1 && n_shards == 1 && c->collapsed && c->U >= 32768 &&
+        c->U < (1ull << 26) && seg_lo == 0 && seg_hi == 2 && !getenv("FQD_EDIT")) {
+        edit_general = false;
+        cross_after = true;
+    }
     if (seg_hi > (uint32_t)max_distance + 1 || seg_lo > seg_hi)
         return fail(c, FQD_E_VALUE, "segment range outside [0, max_distance + 1]");
     if (edit_general && (seg_lo != 0 || seg_hi != (uint32_t)max_distance + 1))
@@ -481,6 +505,15 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         }
         c->E = have;
         c->stats_pending = true;     // the 64 stat slots are summed when fqd_edge_stats asks
+    }
+    if (cross_after && U >= 2) {
+        bool cross_done = false;
+        FQD_TRY(find_edges_edit_grouped(c, 1, &cross_done, true));
+        if (!cross_done) {           // (cannot happen for d = 1 below 2^26 keys; the sorted search redoes everything)
+            FQD_TRY(zero_ctr64(c, C64_EDGES));
+            c->E = 0;
+            FQD_TRY(find_edges_edit(c, 1, shard, n_shards));
+        }
     }
     timer.stop();
     c->stage = ST_EDGES;

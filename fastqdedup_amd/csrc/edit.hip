@@ -287,12 +287,44 @@ __device__ __forceinline__ bool eg_probes(const uint8_t *__restrict__ probe_mask
     return j >= 0 && j <= 2 * (int)d && ((probe_mask[la] >> j) & 1u);
 }
 
-__global__ void edit_len_counts_kernel(const uint32_t *__restrict__ ulens, uint64_t U, KeyShape sh,
-                                       uint32_t *__restrict__ counts)
+// keys per length. Almost all keys share one or two lengths (26 M single adds on one address took
+// 290 ms, ~11 ns each): a workgroup counts its 4096 keys in an LDS histogram -- runs of equal
+// lengths in a register first -- and adds the non-empty bins once. Lengths of 2048 and more (rare)
+// go to the global counters directly.
+constexpr uint32_t EG_LEN_BINS = 2048;
+
+__global__ __launch_bounds__(256) void edit_len_counts_kernel(const uint32_t *__restrict__ ulens, uint64_t U, KeyShape sh,
+                                                              uint32_t *__restrict__ counts)
 {
-    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u < U)
-        atomicAdd(&counts[fqd_key_len(sh, ulens, u)], 1u);
+    __shared__ uint32_t s_hist[EG_LEN_BINS];
+    for (uint32_t b = threadIdx.x; b < EG_LEN_BINS; b += 256)
+        s_hist[b] = 0;
+    __syncthreads();
+    const uint64_t u0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    uint32_t run_len = 0, run = 0;
+    auto flush = [&]() {
+        if (!run)
+            return;
+        if (run_len < EG_LEN_BINS)
+            atomicAdd(&s_hist[run_len], run);
+        else
+            atomicAdd(&counts[run_len], run);
+    };
+    for (uint32_t t = 0; t < 16 && u0 + t < U; t++) {
+        const uint32_t len = fqd_key_len(sh, ulens, u0 + t);
+        if (run && len == run_len) {
+            run++;
+        } else {
+            flush();
+            run_len = len;
+            run = 1;
+        }
+    }
+    flush();
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < EG_LEN_BINS && b <= sh.max_len; b += 256)
+        if (s_hist[b])
+            atomicAdd(&counts[b], s_hist[b]);
 }
 
 // pass 0: per_key[u] = probe items key u files (by its length class). pass 1: the index items (slot
@@ -376,13 +408,84 @@ __device__ __forceinline__ bool eg_config_matches(const uint32_t *__restrict__ r
     return eg_same_substring(ra, (uint32_t)start, rb, lo, hi - lo, K, W);
 }
 
+// bases a[i...] and b[j...] agree for how many positions? (bit planes: XOR, OR over the planes, count zeros)
+__device__ __forceinline__ uint32_t eg_lcp(const uint32_t *__restrict__ a, uint32_t i, uint32_t la,
+                                           const uint32_t *__restrict__ b, uint32_t j, uint32_t lb, uint32_t K, uint32_t W)
+{
+    const uint32_t n = (la - i) < (lb - j) ? la - i : lb - j;
+    for (uint32_t off = 0; off < n; off += 32) {
+        uint32_t x = 0;
+        for (uint32_t k = 0; k < K; k++)
+            x |= plane_bits(a, K, W, k, i + off) ^ plane_bits(b, K, W, k, j + off);
+        if (x) {
+            const uint32_t t = off + (uint32_t)__ffs((int)x) - 1u;
+            return t < n ? t : n;
+        }
+    }
+    return n;
+}
+
+// Levenshtein(a, b) <= d for d <= 3 by diagonals (Landau-Vishkin): with e edits, how far down
+// diagonal k = j - i does a match run? Every extension is an eg_lcp over whole words -- a few dozen
+// word operations per pair where the banded table of within_edit touches every base three times
+// through a scratch array (272 ms instead of ~2 for the 11 M candidates of config 5's variant).
+// The same predicate as distances.h:33-88.
+__device__ bool eg_within_edit(const uint32_t *__restrict__ a, uint32_t la, const uint32_t *__restrict__ b, uint32_t lb,
+                               int d, uint32_t K, uint32_t W)
+{
+    const int goal = (int)lb - (int)la;                  // the diagonal both keys end on
+    if (goal > d || -goal > d)
+        return false;
+    constexpr int NONE = -1000000;
+    int prev[7], cur[7];                                 // diagonals -3 .. 3 at index k + 3
+#pragma unroll
+    for (int t = 0; t < 7; t++)
+        prev[t] = NONE;
+    prev[3] = (int)eg_lcp(a, 0, la, b, 0, lb, K, W);
+    if (goal == 0 && prev[3] >= (int)la)
+        return true;
+    for (int e = 1; e <= d; e++) {
+#pragma unroll
+        for (int t = 0; t < 7; t++) {
+            const int k = t - 3;
+            cur[t] = NONE;
+            if (k < -e || k > e)
+                continue;
+            int row = NONE;
+            if (prev[t] != NONE)
+                row = prev[t] + 1;                                   // substitution
+            if (t + 1 < 7 && prev[t + 1] != NONE && prev[t + 1] + 1 > row)
+                row = prev[t + 1] + 1;                               // a base of a skipped
+            if (t > 0 && prev[t - 1] != NONE && prev[t - 1] > row)
+                row = prev[t - 1];                                   // a base of b skipped
+            if (row == NONE)
+                continue;
+            if (row > (int)la)
+                row = (int)la;
+            if (row + k > (int)lb)
+                row = (int)lb - k;
+            if (row < 0 || row + k < 0)
+                continue;
+            row += (int)eg_lcp(a, (uint32_t)row, la, b, (uint32_t)(row + k), lb, K, W);
+            cur[t] = row;
+            if (k == goal && row >= (int)la)
+                return true;
+        }
+#pragma unroll
+        for (int t = 0; t < 7; t++)
+            prev[t] = cur[t];
+    }
+    return false;
+}
+
 // One thread per candidate (payload, payload). n_lists lists of list_cap candidates, counters 8 words apart
 // (group.hip's layout).
 __global__ __launch_bounds__(256) void edit_grouped_verify_kernel(
     const uint2 *__restrict__ cands, const unsigned long long *__restrict__ cand_count, uint64_t list_cap,
     uint32_t n_lists, const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t d,
     const uint8_t *__restrict__ probe_mask, uint32_t *__restrict__ edges, unsigned long long *__restrict__ edge_count,
-    uint64_t edge_cap, unsigned long long *__restrict__ cand_need, unsigned long long *__restrict__ n_verified)
+    uint64_t edge_cap, unsigned long long *__restrict__ cand_need, unsigned long long *__restrict__ n_verified,
+    int cross_only /* pairs of ONE length are somebody else's (d = 1: the Hamming passes have reported them) */)
 {
     const uint32_t list = blockIdx.x % n_lists, part = blockIdx.x / n_lists, parts = gridDim.x / n_lists;
     const unsigned long long filled = cand_count[(size_t)list * 8];
@@ -419,7 +522,7 @@ __global__ __launch_bounds__(256) void edit_grouped_verify_kernel(
                 const bool both_index = !((pa | pb) & ROLE_PROBE);
                 // an index item of the other segment number cannot be this probe's partner (hash collision)
                 const bool seg_ok = ((pb >> EG_UID_BITS) & 3u) == seg;
-                if (gap <= d && seg_ok && (!both_index || la == lb)) {
+                if (gap <= d && seg_ok && (!both_index || la == lb) && !(cross_only && la == lb)) {
                     const uint32_t *ra = urecs + (uint64_t)ua * sh.stride, *rb = urecs + (uint64_t)ub * sh.stride;
                     // the first configuration under which the pair matches, in the order: direction
                     // (smaller uid probing first), segment, shift -- among the configurations that are filed
@@ -446,8 +549,7 @@ __global__ __launch_bounds__(256) void edit_grouped_verify_kernel(
                     }
                     if (mine_is_first) {
                         verified++;
-                        const RecSeq sa{ra, K}, sb{rb, K};
-                        hit = within_edit(sa, la, sb, lb, (int)d);
+                        hit = eg_within_edit(ra, la, rb, lb, (int)d, K, W);
                         eu = ua < ub ? ua : ub;
                         ev = ua < ub ? ub : ua;
                     }
@@ -554,7 +656,7 @@ hipError_t launch_edit_verify(const uint64_t *cands, uint64_t C, const uint32_t 
 hipError_t launch_edit_len_counts(const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t *counts, hipStream_t st)
 {
     if (U)
-        edit_len_counts_kernel<<<grid_for(U), 256, 0, st>>>(ulens, U, sh, counts);
+        edit_len_counts_kernel<<<(unsigned)((U + 4095) / 4096), 256, 0, st>>>(ulens, U, sh, counts);
     return hipGetLastError();
 }
 
@@ -572,11 +674,11 @@ hipError_t launch_edit_grouped_verify(const uint64_t *cands, const unsigned long
                                       uint32_t n_lists, const uint32_t *urecs, const uint32_t *ulens, KeyShape sh,
                                       uint32_t d, const uint8_t *probe_mask, uint32_t *edges,
                                       unsigned long long *edge_count, uint64_t edge_cap, unsigned long long *cand_need,
-                                      unsigned long long *n_verified, hipStream_t st)
+                                      unsigned long long *n_verified, int cross_only, hipStream_t st)
 {
     edit_grouped_verify_kernel<<<n_lists * 32, 256, 0, st>>>(reinterpret_cast<const uint2 *>(cands), cand_count, list_cap,
                                                              n_lists, urecs, ulens, sh, d, probe_mask, edges, edge_count,
-                                                             edge_cap, cand_need, n_verified);
+                                                             edge_cap, cand_need, n_verified, cross_only);
     return hipGetLastError();
 }
 

@@ -352,7 +352,7 @@ hipError_t launch_edit_grouped_verify(const uint64_t *cands, const unsigned long
                                       uint32_t n_lists, const uint32_t *urecs, const uint32_t *ulens, KeyShape sh,
                                       uint32_t d, const uint8_t *probe_mask, uint32_t *edges,
                                       unsigned long long *edge_count, uint64_t edge_cap, unsigned long long *cand_need,
-                                      unsigned long long *n_verified, hipStream_t st);
+                                      unsigned long long *n_verified, int cross_only, hipStream_t st);
 hipError_t launch_contains(const uint8_t *q, const uint64_t *qo, uint64_t nq, const uint32_t *urecs,
                            const uint32_t *ulens, uint64_t U, KeyShape sh, const uint8_t *alphabet_dev, int d,
                            int metric, uint32_t *hit_flags, hipStream_t st, const uint8_t *alive = nullptr);

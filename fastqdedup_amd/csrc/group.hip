@@ -392,19 +392,25 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
         }
         if (COOP) {
             const uint4 *recs4 = reinterpret_cast<const uint4 *>(urecs);
-            const uint32_t W = sh.words, len = sh.max_len;
+            const uint32_t W = sh.words;
             const unsigned long long have = __ballot(idx < total);
             for (uint32_t c0 = 0; c0 < 64 && (have >> c0); c0 += 2 * groups) {
                 // two rounds of groups: their four loads per lane are requested together
                 uint4 xs[2];
                 bool on[2];
+                uint32_t lens2[2];     // the pair's key length; keys of different lengths are no Hamming neighbours
 #pragma unroll
                 for (uint32_t t = 0; t < 2; t++) {
                     const uint32_t cnd = c0 + t * groups + gl;
                     on[t] = gl < groups && cnd < 64 && ((have >> cnd) & 1ull);
                     const uint32_t pu = __shfl(pr.x, cnd & 63u), pv = __shfl(pr.y, cnd & 63u);
                     xs[t] = make_uint4(0, 0, 0, 0);
+                    lens2[t] = sh.max_len;
                     if (on[t]) {
+                        if (sh.ragged) {
+                            lens2[t] = ulens[pu];
+                            on[t] = ulens[pv] == lens2[t];
+                        }
                         const uint4 a = recs4[(size_t)pu * Q + ql], b = recs4[(size_t)pv * Q + ql];
                         xs[t] = make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
                     }
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
                             dist += __popc(dw);
                             for (uint32_t s2 = 0; s2 < seg; s2++) {
                                 uint32_t slo, shi;
-                                fqd_segment(len, s2, nseg, slo, shi);
+                                fqd_segment(lens2[t], s2, nseg, slo, shi);
                                 if (dw & fqd_range_mask(w, slo, shi))
                                     seg_mis |= 1u << s2;
                             }
@@ -436,6 +442,8 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
                     s_part[wave][lane][0] = dist;
                     s_part[wave][lane][1] = seg_mis;
                     __builtin_amdgcn_wave_barrier();
+                    if (gl < groups && cnd < 64 && ql == 0)
+                        s_hit[wave][cnd] = 0;          // (a pair of different lengths stays a miss)
                     if (on[t] && ql == 0) {
                         uint32_t dsum = 0, mis = 0;
                         for (uint32_t q = 0; q < Q; q++) {
@@ -620,7 +628,7 @@ hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long l
     // config 2: 0.119 ms against 0.092 one thread per candidate -- most candidates there are no
     // neighbours and are out after one word; 128-byte records, config 5: 0.44 against 1.46 ms), and at
     // most 32 segments: the per-lane notes are a bit mask
-    const bool coop = !sh.ragged && sh.stride >= 16 && sh.stride <= 256 && !(sh.stride & 3u) && nseg <= 32 &&
+    const bool coop = sh.stride >= 16 && sh.stride <= 256 && !(sh.stride & 3u) && nseg <= 32 &&
                       !getenv("FQD_VERIFY_NO_COOP");
 #define FQD_GP_CASE(KK)                                                                                              \
     case KK:                                                                                                         \

@@ -60,3 +60,34 @@ def test_hot_kernels_do_not_spill_to_scratch():
     spilling = [k for k, v in ours.items()
                 if v.get("ScratchSize [bytes/lane]", 0) and not any(a in k for a in allowed)]
     assert not spilling, spilling
+
+
+def test_python_surface_has_the_references_names():
+    """Every name a user of the reference imports exists under both package names (reference
+    src/fastqdedup/__init__.py, _trie.pyi:20-44, _distance.pyi, _fastq.pyi): attribute presence
+    and signatures only -- no device needed."""
+    import inspect
+    import fastqdedup
+    import fastqdedup_amd as F
+    for name in ("Trie", "within_distance", "cluster_dissection_directional", "cluster_dissection_adjacency",
+                 "cluster_dissection_highest_count", "CLUSTER_DISSECTION_METHODS", "deduplicate_cluster", "main",
+                 "argument_parser", "length_string_to_slices", "DEFAULT_MAX_DISTANCE", "DEFAULT_PREFIX",
+                 "DEFAULT_CLUSTER_DISSECTION", "DEFAULT_MAX_AVERAGE_ERROR_RATE"):
+        assert hasattr(F, name) and hasattr(fastqdedup, name), name
+    for name in ("trie_stats", "Timer", "initiate_logger", "fastq_average_error_rate"):
+        assert hasattr(fastqdedup, name), name
+    from fastqdedup._trie import Trie
+    from fastqdedup._distance import within_distance  # noqa: F401
+    from fastqdedup._fastq import average_error_rate  # noqa: F401
+    assert Trie is F.Trie
+    for member in ("add_sequence", "contains_sequence", "pop_cluster", "memory_size", "raw_stats", "alphabet",
+                   "number_of_sequences"):
+        assert hasattr(Trie, member), member
+    assert isinstance(inspect.getattr_static(Trie, "alphabet"), property)
+    assert isinstance(inspect.getattr_static(Trie, "number_of_sequences"), property)
+    assert list(inspect.signature(Trie.pop_cluster).parameters) == ["self", "max_distance", "use_edit_distance"]
+    assert list(inspect.signature(Trie.contains_sequence).parameters) == ["self", "sequence", "max_distance",
+                                                                          "use_edit_distance"]
+    flags = {a.dest for a in F.argument_parser()._actions}
+    assert {"fastq", "check_lengths", "output", "prefix", "max_distance", "max_average_error_rate", "edit",
+            "cluster_dissection_method", "verbose", "quiet"} <= flags
