@@ -53,16 +53,17 @@ static int graph_preinit(fqd_ctx *c, int method)
     HIP_TRY(c, c->hook_slots.reserve(FQD_HOOK_SLOTS * 64));
     HIP_TRY(c, c->best.reserve(U * 4 + 16));
     HIP_TRY(c, c->state.reserve(U + 16));
-    HIP_TRY(c, hipMemsetAsync(c->hook_slots.p, 0, FQD_HOOK_SLOTS * 64, c->st));
-    HIP_TRY(c, fqd::launch_uf_init(c->labels.as<uint32_t>(), U, c->st));
-    HIP_TRY(c, fqd::launch_dissect_init(c->best.as<uint32_t>(), c->state.as<uint8_t>(), U, c->st));
-    if (method == FQD_METHOD_DIRECTIONAL && c->collapsed && !getenv("FQD_DIRECTIONAL_ROUNDS")) {
+    const bool closed = method == FQD_METHOD_DIRECTIONAL && c->collapsed && !getenv("FQD_DIRECTIONAL_ROUNDS");
+    if (closed) {
         HIP_TRY(c, c->blocked.reserve(U * 4 + 16));
         HIP_TRY(c, c->root_taint.reserve(U + 16));
-        HIP_TRY(c, hipMemsetAsync(c->root_taint.p, 0, U, c->st));
-        HIP_TRY(c, fqd::launch_uf_init(c->blocked.as<uint32_t>(), U, c->st));
-        c->pre_init_closed = true;
     }
+    // one launch for all of it (graph.hip graph_preinit_kernel)
+    HIP_TRY(c, fqd::launch_graph_preinit(c->labels.as<uint32_t>(), c->best.as<uint32_t>(), c->state.as<uint8_t>(),
+                                         closed ? c->blocked.as<uint32_t>() : nullptr,
+                                         closed ? c->root_taint.as<uint8_t>() : nullptr, U,
+                                         c->hook_slots.as<unsigned long long>(), FQD_HOOK_SLOTS * 8, c->st));
+    c->pre_init_closed = closed;
     c->pre_init = true;
     return FQD_OK;
 }

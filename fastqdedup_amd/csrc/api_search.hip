@@ -311,7 +311,12 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
 // are partitioned into 2^B buckets of ~200 keys by the top hash bits, then one wave per bucket
 // sub-sorts them in LDS and lists the pairs with equal hashes; a second kernel verifies those.
 // Queues work only (no host round trip).
-static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t d, uint32_t s, uint32_t nseg)
+// fused_U != 0: `hashes` holds the hashes of ALL nseg passes, pass s at [s * fused_U, (s + 1) * fused_U):
+// one partition, one candidate kernel and one verification for the whole search (the hash of a
+// segment mixes its number in, so items of different passes do not meet; a candidate's pass is its
+// position / fused_U). Half the launches of two passes, and kernels twice as long.
+static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t d, uint32_t s, uint32_t nseg,
+                        uint32_t fused_U = 0)
 {
     const KeyShape sh = c->ks;
     uint32_t B = 8;
@@ -339,7 +344,8 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
     KTIME(c, FQD_K_VERIFY, fqd::launch_verify_candidates(c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,
                                                          c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, s, nseg,
                                                          c->edges.as<uint32_t>(), ctr + C64_EDGES, c->edge_cap,
-                                                         ctr + C64_CAND_NEED, c->d_stats.as<fqd::PairStats>(), c->st));
+                                                         ctr + C64_CAND_NEED, c->d_stats.as<fqd::PairStats>(), c->st,
+                                                         fused_U));
     return FQD_OK;
 }
 
@@ -428,8 +434,14 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         // All d+1 passes are queued without a host round trip; the edge count is read ONCE at the
         // end. If the passes overflowed the edge buffer (the count still says how many edges there
         // are), the buffer is grown to the known need and the whole search runs again.
+        // all passes of a plain search in one (see grouped_pass): positions in the hash array must fit 32 bits
+        const bool fuse_passes = grouped && seg_lo == 0 && seg_hi == nseg && nseg >= 2 && nseg <= 8 &&
+                                 (uint64_t)nseg * U < 0xFFFFFF00ull && !getenv("FQD_GROUP_NO_FUSED_PASSES");
         for (int attempt = 0;; attempt++) {
-            for (uint32_t s = seg_lo; s < seg_hi; s++) {
+            if (fuse_passes && grouped) {
+                FQD_TRY(grouped_pass(c, c->seg_hashes.as<uint32_t>(), (uint64_t)nseg * U, d, 0, nseg, (uint32_t)U));
+            }
+            for (uint32_t s = seg_lo; s < seg_hi && !(fuse_passes && grouped); s++) {
                 const uint32_t *pass_hashes = c->seg_hashes.as<uint32_t>() + (size_t)(s - seg_lo) * U;
                 uint64_t m = U;  // entries this rank sorts and searches in this pass
                 if (n_shards > 1) {

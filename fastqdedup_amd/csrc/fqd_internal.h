@@ -383,7 +383,8 @@ hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *buck
 hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
                                     const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d, uint32_t seg,
                                     uint32_t nseg, uint32_t *edges, unsigned long long *edge_count, uint64_t edge_cap,
-                                    unsigned long long *cand_need, PairStats *stats, hipStream_t st);
+                                    unsigned long long *cand_need, PairStats *stats, hipStream_t st,
+                                    uint32_t fused_U = 0);
 
 // exchange.hip -- group packed reads by owner rank
 hipError_t launch_owner(const uint32_t *hashes, uint64_t n, uint32_t parts, uint32_t *owner, hipStream_t st);
@@ -435,6 +436,8 @@ hipError_t launch_mark_dropped(uint8_t *state, uint64_t U, const uint32_t *dropp
                                hipStream_t st);
 hipError_t launch_uf_flatten(uint32_t *parent, uint64_t U, unsigned long long *n_roots, hipStream_t st);
 hipError_t launch_dissect_init(uint32_t *best, uint8_t *state, uint64_t U, hipStream_t st);
+hipError_t launch_graph_preinit(uint32_t *parent, uint32_t *best, uint8_t *state, uint32_t *parent1, uint8_t *root_taint,
+                                uint64_t U, unsigned long long *hook_slots, uint32_t hook_words, hipStream_t st);
 hipError_t launch_highest_count(const uint32_t *labels, const uint32_t *ucounts, const uint32_t *urecs,
                                 const uint32_t *ulens, KeyShape sh, uint64_t U, uint32_t *best,
                                 hipStream_t st);

@@ -24,6 +24,7 @@
 //   adjacency      greedy "take the max, drop its neighbours, repeat" (:112-122) is
 //                  the lexicographically-first maximal independent set in rank
 //                  order: v is kept iff none of its higher-rank neighbours is kept.
+#include <algorithm>
 #include "fqd_internal.h"
 
 namespace {
@@ -225,6 +226,42 @@ __global__ __launch_bounds__(256) void uf_flatten_kernel(uint32_t *parent, uint6
 }
 
 // ---- dissection ------------------------------------------------------------------
+// Everything stages 4 and 5 set up over the unique table, in ONE launch (fqd_api_graph_preinit: five
+// launches and two fills of ~5 us each, plus the gaps between them, were 70 us of a 2.9 ms job):
+// parent[i] = i (components), best[i] = i, state[i] = 0 (dissection), and for the closed-form
+// directional dissection parent1[i] = i, root_taint[i] = 0; block 0 also clears the hook counters.
+__global__ void graph_preinit_kernel(uint32_t *__restrict__ parent, uint32_t *__restrict__ best,
+                                     uint8_t *__restrict__ state, uint32_t *__restrict__ parent1 /* may be NULL */,
+                                     uint8_t *__restrict__ root_taint /* with parent1 */, uint64_t U,
+                                     unsigned long long *__restrict__ hook_slots, uint32_t hook_words)
+{
+    // four keys per thread: 16-byte stores for the word arrays, 4-byte stores for the byte arrays
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = q * 4;
+    if (blockIdx.x == 0)
+        for (uint32_t w = threadIdx.x; w < hook_words; w += blockDim.x)
+            hook_slots[w] = 0ull;
+    if (i0 + 4 <= U) {
+        const uint4 v = make_uint4((uint32_t)i0, (uint32_t)i0 + 1, (uint32_t)i0 + 2, (uint32_t)i0 + 3);
+        reinterpret_cast<uint4 *>(parent)[q] = v;
+        reinterpret_cast<uint4 *>(best)[q] = v;
+        reinterpret_cast<uint32_t *>(state)[q] = 0u;
+        if (parent1) {
+            reinterpret_cast<uint4 *>(parent1)[q] = v;
+            reinterpret_cast<uint32_t *>(root_taint)[q] = 0u;
+        }
+    } else {
+        for (uint64_t i = i0; i < U; i++) {
+            parent[i] = (uint32_t)i;
+            best[i] = (uint32_t)i;
+            state[i] = 0;
+            if (parent1) {
+                parent1[i] = (uint32_t)i;
+                root_taint[i] = 0;
+            }
+        }
+    }
+}
+
 __global__ void dissect_init_kernel(uint32_t *best, uint8_t *state, uint64_t U)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -650,7 +687,9 @@ __global__ __launch_bounds__(256) void kept_flags_kernel(int method, const uint3
 //   kept_bin_kernel   verdicts as in kept_flags_kernel; the listed ids of a tile of 4096 keys are
 //                     partitioned in LDS by id bin (2^bin_shift consecutive ids; <= 512 bins) and leave as one
 //                     run of 4-byte offsets per (tile, bin) behind an atomic cursor. A bin has KB_SUBS
-//                     lists (tile t appends to list t % KB_SUBS: 3400 tiles queueing on ONE cursor
+//                     lists (KB_SUBS = 1: four lists per bin, tile t appending to list t % 4, changed nothing --
+//                     0.240 against 0.247 ms -- so the cursors are not what bounds this kernel; the idea was that
+//                     tile t appends to list t % KB_SUBS: 3400 tiles queueing on ONE cursor
 //                     per bin cost 0.12 ms, a same-address atomic takes ~36 ns), each with room
 //                     for every id of the bin (ids are distinct): no overflow.
 //   kept_emit_kernel  four workgroups per bin: the bin's offsets set bits in LDS bit maps of the
@@ -1038,6 +1077,16 @@ hipError_t launch_uf_flatten(uint32_t *parent, uint64_t U, unsigned long long *n
             g = 2048;
         uf_flatten_kernel<<<g, 256, 0, st>>>(parent, U, n_roots);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_graph_preinit(uint32_t *parent, uint32_t *best, uint8_t *state, uint32_t *parent1, uint8_t *root_taint,
+                                uint64_t U, unsigned long long *hook_slots, uint32_t hook_words, hipStream_t st)
+{
+    const uint64_t quads = (U + 3) / 4;
+    graph_preinit_kernel<<<(unsigned)std::max<uint64_t>(1, (quads + 255) / 256), 256, 0, st>>>(parent, best, state, parent1,
+                                                                                           root_taint, U, hook_slots,
+                                                                                           hook_words);
     return hipGetLastError();
 }
 

@@ -357,7 +357,9 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
     const uint2 *__restrict__ cands, const unsigned long long *__restrict__ cand_count, uint64_t cand_cap,
     const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t d, uint32_t seg,
     uint32_t nseg, uint32_t *__restrict__ edges, unsigned long long *__restrict__ edge_count, uint64_t edge_cap,
-    unsigned long long *__restrict__ cand_need, fqd::PairStats *__restrict__ stats)
+    unsigned long long *__restrict__ cand_need, fqd::PairStats *__restrict__ stats,
+    uint32_t fused_U /* != 0: ALL passes in one -- a candidate holds positions in the [nseg][U] hash array (segment
+                        * U + uid), and the pass it belongs to is its segment */)
 {
     __shared__ uint32_t s_edges[2 * GP_ECAP];
     __shared__ uint32_t s_ctl[4];
@@ -382,18 +384,33 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
     const unsigned long long step = (unsigned long long)parts * GP_THREADS;
     for (unsigned long long base = (unsigned long long)part * GP_THREADS; base < total; base += step) {
         const unsigned long long idx = base + tid;
-        bool hit = false;
+        bool hit = false, live = false;
         uint2 pr = make_uint2(0, 0);
+        uint32_t my_seg = seg;
         if (idx < total) {
             pr = cands[idx];
             n_pairs++;
-            if (!COOP)
-                hit = gp_verify<K>(urecs, ulens, sh, d, seg, nseg, pr.x, pr.y);
+            live = true;
+            if (fused_U) {
+                uint32_t sx = 0, sy = 0;
+                while (pr.x >= fused_U) {
+                    pr.x -= fused_U;
+                    sx++;
+                }
+                while (pr.y >= fused_U) {
+                    pr.y -= fused_U;
+                    sy++;
+                }
+                my_seg = sx;
+                live = sx == sy;             // (hashes of different segments meet only by collision)
+            }
+            if (!COOP && live)
+                hit = gp_verify<K>(urecs, ulens, sh, d, my_seg, nseg, pr.x, pr.y);
         }
         if (COOP) {
             const uint4 *recs4 = reinterpret_cast<const uint4 *>(urecs);
             const uint32_t W = sh.words;
-            const unsigned long long have = __ballot(idx < total);
+            const unsigned long long have = __ballot(live);
             for (uint32_t c0 = 0; c0 < 64 && (have >> c0); c0 += 2 * groups) {
                 // two rounds of groups: their four loads per lane are requested together
                 uint4 xs[2];
@@ -418,6 +435,7 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
 #pragma unroll
                 for (uint32_t t = 0; t < 2; t++) {
                     const uint32_t cnd = c0 + t * groups + gl;
+                    const uint32_t cseg = __shfl(my_seg, cnd & 63u);     // the candidate's pass
                     __builtin_amdgcn_wave_barrier();
                     if (gl < groups)
                         *reinterpret_cast<uint4 *>(&s_x[wave][(gl * Q + ql) * 4]) = xs[t];
@@ -431,7 +449,7 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
                             for (int k = 0; k < K; k++)
                                 dw |= x[w * K + k];
                             dist += __popc(dw);
-                            for (uint32_t s2 = 0; s2 < seg; s2++) {
+                            for (uint32_t s2 = 0; s2 < cseg; s2++) {
                                 uint32_t slo, shi;
                                 fqd_segment(lens2[t], s2, nseg, slo, shi);
                                 if (dw & fqd_range_mask(w, slo, shi))
@@ -452,13 +470,13 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
                         }
                         // a neighbour, reported in the pass of the FIRST segment the pair agrees on: all
                         // earlier segments must disagree (an empty segment agrees trivially, as in gp_verify)
-                        const uint32_t earlier = seg >= 32 ? 0xFFFFFFFFu : (1u << seg) - 1u;
+                        const uint32_t earlier = cseg >= 32 ? 0xFFFFFFFFu : (1u << cseg) - 1u;
                         s_hit[wave][cnd] = (dsum <= d && (mis & earlier) == earlier) ? 1 : 0;
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            hit = idx < total && s_hit[wave][lane] != 0;
+            hit = live && s_hit[wave][lane] != 0;
         }
         const unsigned long long mask = __ballot(hit);
         if (mask) {
@@ -622,7 +640,7 @@ hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *buck
 hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
                                     const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d, uint32_t seg,
                                     uint32_t nseg, uint32_t *edges, unsigned long long *edge_count, uint64_t edge_cap,
-                                    unsigned long long *cand_need, PairStats *stats, hipStream_t st)
+                                    unsigned long long *cand_need, PairStats *stats, hipStream_t st, uint32_t fused_U)
 {
     // several lanes per candidate for fixed-length records of four uint4 and more (48-byte records,
     // config 2: 0.119 ms against 0.092 one thread per candidate -- most candidates there are no
@@ -635,11 +653,11 @@ hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long l
         if (coop)                                                                                                    \
             verify_candidates_kernel<KK, true><<<2048, GP_THREADS, 0, st>>>(                                         \
                 reinterpret_cast<const uint2 *>(cands), cand_count, cand_cap / GP_LISTS, urecs, ulens, sh, d, seg, nseg,  \
-                edges, edge_count, edge_cap, cand_need, stats);                                                      \
+                edges, edge_count, edge_cap, cand_need, stats, fused_U);                                             \
         else                                                                                                         \
             verify_candidates_kernel<KK, false><<<2048, GP_THREADS, 0, st>>>(                                        \
                 reinterpret_cast<const uint2 *>(cands), cand_count, cand_cap / GP_LISTS, urecs, ulens, sh, d, seg, nseg,  \
-                edges, edge_count, edge_cap, cand_need, stats);                                                      \
+                edges, edge_count, edge_cap, cand_need, stats, fused_U);                                             \
         break;
     switch (sh.planes) {
         FQD_GP_CASE(1)

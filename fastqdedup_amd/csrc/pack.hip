@@ -343,6 +343,8 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
                 // gap-free, see partition.cuh)
                 const uint32_t bn = s_bin16[p];
                 const uint32_t pos = s_base[bn] + p;
+                // (non-temporal stores here: 0.89 ms instead of 0.56 -- the runs of consecutive tiles complete
+                // each other's partial lines in the XCD's L2, which a non-temporal store forgoes)
                 if (pos < (bn * fs.subs + (blockIdx.x & (fs.subs - 1)) + 1) * fs.cap)
                     fs.out[pos] = tile4[p];
             }
