@@ -10,6 +10,7 @@ from __future__ import annotations
 import argparse
 import datetime
 import logging
+import os
 import resource
 import time
 from typing import Callable, Iterator, List, Optional, Tuple
@@ -127,33 +128,46 @@ def deduplicate_cluster(input_files: List[str], output_files: List[str], check_s
     logger = logging.getLogger("fastqdedup")
     timer = Timer()
     ctx = default_context()
-
-    tables, n = fastq.read_all(input_files)
-    fastq.check_mates(tables, n)
     slices = check_slices if check_slices else None
-    keys, key_off, key_len = fastq.build_strings(tables, slices, n, "sequence")
-
     filter_on_quality = max_average_error_rate < 1.0
-    weights = None
-    discarded = 0
-    if filter_on_quality and n:
-        quals, qual_off, qual_len = fastq.build_strings(tables, slices, n, "qualities")
-        data = quals if len(quals) else np.zeros(1, dtype=np.uint8)
-        weights, _, discarded = ctx.quality_filter(data, None if qual_len else qual_off, qual_len,
-                                                   threshold=max_average_error_rate,
-                                                   table=SCORE_TO_ERROR_RATE)
-        del quals, qual_off
+    chunk_records = int(os.environ.get("FQD_FASTQ_CHUNK_RECORDS", 2_000_000))
+
+    # ---- pass 1 (reference :242-252): the files are streamed in chunks of records; what stays in host
+    # memory is the KEYS (and one weight per record), never a whole file
+    key_parts, off_parts, weight_parts = [], [], []
+    n, discarded, key_len, key_bytes = 0, 0, None, 0
+    for tables, m, _first in fastq.zip_chunks(input_files, chunk_records):
+        fastq.check_mates(tables, m)
+        keys, key_off, fixed = fastq.build_strings(tables, slices, m, "sequence")
+        if filter_on_quality:
+            quals, qual_off, qual_len = fastq.build_strings(tables, slices, m, "qualities")
+            data = quals if len(quals) else np.zeros(1, dtype=np.uint8)
+            w, _, d = ctx.quality_filter(data, None if qual_len else qual_off, qual_len,
+                                         threshold=max_average_error_rate, table=SCORE_TO_ERROR_RATE)
+            weight_parts.append(np.asarray(w, dtype=np.uint32))
+            discarded += d
+        key_parts.append(keys)
+        off_parts.append(key_off[1:].astype(np.uint64) + np.uint64(key_bytes))
+        key_bytes += len(keys)
+        key_len = fixed if key_len is None else (key_len if key_len == fixed else 0)
+        n += m
+    if filter_on_quality:
         logger.info(f"{discarded} records out of {n} "
                     f"records had an error rate higher than {max_average_error_rate} "
                     f"and were discarded.")
-    elif filter_on_quality:
-        logger.info(f"0 records out of 0 records had an error rate higher than "
-                    f"{max_average_error_rate} and were discarded.")
 
     res = None
     if n:
-        res = cluster_keys(keys, None if key_len else key_off, key_len, weights, max_distance=max_distance,
+        keys = key_parts[0] if len(key_parts) == 1 else np.concatenate(key_parts)
+        del key_parts
+        key_off = None
+        if not key_len:
+            key_off = np.concatenate([np.zeros(1, dtype=np.uint64)] + off_parts)
+        del off_parts
+        weights = (weight_parts[0] if len(weight_parts) == 1 else np.concatenate(weight_parts)) if weight_parts else None
+        res = cluster_keys(keys, key_off, key_len or 0, weights, max_distance=max_distance,
                            use_edit_distance=use_edit_distance, method=method, context=ctx)
+        del keys, key_off, weights
     n_counted = res.n_counted if res else 0
     logger.info(f"Processed {n_counted} sequences. ({timer.get_difference()})")
     if logger.level <= logging.DEBUG and res is not None and res.n_unique:
@@ -167,9 +181,19 @@ def deduplicate_cluster(input_files: List[str], output_files: List[str], check_s
     logger.info(f"Found {n_kept} distinct reads in {n_clusters} clusters."
                 f"({timer.get_difference()})")
 
+    # ---- pass 2 (reference :189-206): the files are streamed again; the records whose numbers the
+    # GPU returned are written (the first holder of every kept key, filtered or not)
     keep = res.kept_read_ids.astype(np.int64) if res else np.zeros(0, dtype=np.int64)
-    for table, path in zip(tables, output_files):
-        fastq.write_records(table, keep, path)
+    outs = [fastq.open_write(path) for path in output_files]
+    try:
+        for tables, m, first in fastq.zip_chunks(input_files, chunk_records):
+            lo, hi = np.searchsorted(keep, [first, first + m])
+            local = keep[lo:hi] - first
+            for table, out in zip(tables, outs):
+                fastq.write_records_to(table, local, out)
+    finally:
+        for out in outs:
+            out.close()
     logger.info(f"Filtered FASTQ files based on distinct reads from each cluster. "
                 f"({timer.get_difference()}) ")
 

@@ -78,10 +78,10 @@ class FastqTable:
             self.qual_start, self.qual_end)), self.normalized)
 
 
-def read_fastq(path: str) -> FastqTable:
-    with _open_read(path) as fh:
-        data = fh.read()
-    buf = np.frombuffer(data, dtype=np.uint8)
+def parse_fastq(data, first_line: int = 0) -> FastqTable:
+    """Whole records in ``data`` (bytes or uint8 array) -> table. ``first_line``: the line number of
+    the buffer's first line in its file, for error messages."""
+    buf = data if isinstance(data, np.ndarray) else np.frombuffer(data, dtype=np.uint8)
     nl = np.flatnonzero(buf == 10).astype(np.int64)
     ends = nl
     if len(buf) and (len(nl) == 0 or nl[-1] != len(buf) - 1):
@@ -91,7 +91,7 @@ def read_fastq(path: str) -> FastqTable:
     while n_lines and starts[n_lines - 1] >= ends[n_lines - 1] and n_lines % 4:   # trailing blank lines
         n_lines -= 1
     if n_lines % 4:
-        raise FastqFormatError("Premature end of file encountered.", line=n_lines)
+        raise FastqFormatError("Premature end of file encountered.", line=first_line + n_lines)
     starts, ends = starts[:n_lines], ends[:n_lines]
     # '\r\n' line ends: drop the '\r'
     content_end = ends.copy()
@@ -101,20 +101,88 @@ def read_fastq(path: str) -> FastqTable:
     if n_lines:
         bad = np.flatnonzero((buf[starts[l0]] != ord("@")) | (content_end[l0] == starts[l0]))
         if len(bad):
-            raise FastqFormatError("Line expected to start with '@'", line=int(bad[0]) * 4)
+            raise FastqFormatError("Line expected to start with '@'", line=first_line + int(bad[0]) * 4)
         plus_ok = (content_end[l2] > starts[l2]) & (buf[np.minimum(starts[l2], len(buf) - 1)] == ord("+"))
         bad = np.flatnonzero(~plus_ok)
         if len(bad):
-            raise FastqFormatError("Line expected to start with '+'", line=int(bad[0]) * 4 + 2)
+            raise FastqFormatError("Line expected to start with '+'", line=first_line + int(bad[0]) * 4 + 2)
         bad = np.flatnonzero((content_end[l1] - starts[l1]) != (content_end[l3] - starts[l3]))
         if len(bad):
-            raise FastqFormatError("Length of sequence and qualities differ", line=int(bad[0]) * 4 + 3)
+            raise FastqFormatError("Length of sequence and qualities differ", line=first_line + int(bad[0]) * 4 + 3)
     rec_end = np.minimum(ends[l3] + 1, len(buf)) if n_lines else np.zeros(0, np.int64)
     normalized = bool(n_lines == 0 or (not has_cr.any() and np.all(content_end[l2] - starts[l2] == 1)
                                        and np.all(buf[np.minimum(ends[l3], len(buf) - 1)] == 10)
                                        and int(ends[-1]) < len(buf)))
     return FastqTable(buf, starts[l0], rec_end, starts[l0] + 1, content_end[l0], starts[l1], content_end[l1],
                       starts[l3], content_end[l3], normalized)
+
+
+def read_fastq(path: str) -> FastqTable:
+    with _open_read(path) as fh:
+        return parse_fastq(fh.read())
+
+
+class FastqChunks:
+    """A FASTQ file as a sequence of tables of at most ``chunk_records`` records each: the file is
+    decompressed block by block and never held whole (the reference streams records one by one,
+    __init__.py:54-57; a 50 M-pair run is > 30 GB of text)."""
+
+    def __init__(self, path: str, chunk_records: int, block_bytes: int = 64 << 20):
+        self.path, self.chunk_records, self.block_bytes = path, int(chunk_records), int(block_bytes)
+
+    def __iter__(self):
+        want_lines = 4 * self.chunk_records
+        with _open_read(self.path) as fh:
+            pending: List[bytes] = []       # blocks of the chunk being assembled
+            pending_lines = 0
+            line0 = 0
+            eof = False
+            while not eof or pending:
+                block = b"" if eof else fh.read(self.block_bytes)
+                if not block:
+                    eof = True
+                    if pending:
+                        data = b"".join(pending)
+                        pending, pending_lines = [], 0
+                        table = parse_fastq(data, line0)
+                        if len(table):
+                            yield table
+                    break
+                arr = np.frombuffer(block, dtype=np.uint8)
+                nl = np.flatnonzero(arr == 10)
+                start = 0
+                while pending_lines + (len(nl) - np.searchsorted(nl, start)) >= want_lines:
+                    # the chunk's last newline lies in this block
+                    first_nl = int(np.searchsorted(nl, start))
+                    cut = int(nl[first_nl + (want_lines - pending_lines) - 1]) + 1
+                    data = b"".join(pending + [block[start:cut]])
+                    pending, pending_lines = [], 0
+                    yield parse_fastq(data, line0)
+                    line0 += want_lines
+                    start = cut
+                if start < len(block):
+                    pending.append(block[start:])
+                    pending_lines += len(nl) - int(np.searchsorted(nl, start))
+
+
+def zip_chunks(paths: Sequence[str], chunk_records: int):
+    """Chunk k of every file, cut to the shortest: ``(tables, n, first record number)``; stops with
+    the shortest file like the reference's zip() over its readers (__init__.py:180)."""
+    its = [iter(FastqChunks(p, chunk_records)) for p in paths]
+    base = 0
+    while True:
+        tables = []
+        for it in its:
+            t = next(it, None)
+            if t is None:
+                return
+            tables.append(t)
+        n = min(len(t) for t in tables)
+        if n:
+            yield tables, n, base
+        base += n
+        if any(len(t) < chunk_records for t in tables):
+            return          # some file has ended: a tuple needs a record of every file
 
 
 # ---------------------------------------------------------------------------
@@ -252,23 +320,28 @@ def build_strings(tables: Sequence[FastqTable], slices: Optional[Sequence[Option
 # pass 2
 # ---------------------------------------------------------------------------
 
-def write_records(table: FastqTable, keep: np.ndarray, path: str) -> None:
-    """Write records `keep` (ascending record numbers) as dnaio's ``fastq_bytes`` would."""
+def write_records_to(table: FastqTable, keep: np.ndarray, out) -> None:
+    """Append records `keep` (ascending record numbers of this table) as dnaio's ``fastq_bytes`` would."""
     keep = np.asarray(keep, dtype=np.int64)
+    if not len(keep):
+        return
+    if table.normalized:
+        mark = np.zeros(len(table.buf) + 1, dtype=np.int8)
+        np.add.at(mark, table.rec_start[keep], 1)
+        np.add.at(mark, table.rec_end[keep], -1)
+        out.write(table.buf[np.cumsum(mark[:-1]) > 0].tobytes())
+        return
+    b = table.buf
+    for i in keep:
+        out.write(b"@" + b[table.name_start[i]:table.name_end[i]].tobytes() + b"\n" +
+                  b[table.seq_start[i]:table.seq_end[i]].tobytes() + b"\n+\n" +
+                  b[table.qual_start[i]:table.qual_end[i]].tobytes() + b"\n")
+
+
+def write_records(table: FastqTable, keep: np.ndarray, path: str) -> None:
+    """Write records `keep` (ascending record numbers) to a new file."""
     with open_write(path) as out:
-        if not len(keep):
-            return
-        if table.normalized:
-            mark = np.zeros(len(table.buf) + 1, dtype=np.int8)
-            np.add.at(mark, table.rec_start[keep], 1)
-            np.add.at(mark, table.rec_end[keep], -1)
-            out.write(table.buf[np.cumsum(mark[:-1]) > 0].tobytes())
-            return
-        b = table.buf
-        for i in keep:
-            out.write(b"@" + b[table.name_start[i]:table.name_end[i]].tobytes() + b"\n" +
-                      b[table.seq_start[i]:table.seq_end[i]].tobytes() + b"\n+\n" +
-                      b[table.qual_start[i]:table.qual_end[i]].tobytes() + b"\n")
+        write_records_to(table, keep, out)
 
 
 def read_all(paths: List[str]) -> Tuple[List[FastqTable], int]:

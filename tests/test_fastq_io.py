@@ -122,3 +122,40 @@ def test_argument_parser_surface():
     assert (b.max_average_error_rate, b.edit, b.cluster_dissection_method) == (1.0, True, "adjacency")
     assert (b.verbose, b.quiet) == (2, 1)
     assert argument_parser().parse_args(["-e", "0.05", "x"]).max_average_error_rate == 0.05
+
+
+@pytest.mark.parametrize("variant", ["plain", "gz", "crlf", "nofinal"])
+def test_chunked_reader_equals_whole_file_reader(tmp_path, variant):
+    """FastqChunks cuts a file into tables of whole records, whatever the block size (record ends
+    falling on and off block borders, a last line without newline, CR LF)."""
+    rng = random.Random(2)
+    recs = _records(rng, 1003)
+    p = str(tmp_path / ("in.fastq.gz" if variant == "gz" else "in.fastq"))
+    _write(p, recs, eol="\r\n" if variant == "crlf" else "\n", final_newline=variant != "nofinal", gz=variant == "gz")
+    for chunk, block in ((100, 257), (333, 1 << 16), (5000, 64), (1, 4096)):
+        got = []
+        for t in fastq.FastqChunks(p, chunk, block):
+            assert 0 < len(t) <= chunk
+            got += [(bytes(t.buf[a:b]).decode(), bytes(t.buf[c:d]).decode(), bytes(t.buf[e:f]).decode())
+                    for a, b, c, d, e, f in zip(t.name_start, t.name_end, t.seq_start, t.seq_end, t.qual_start,
+                                                t.qual_end)]
+        assert got == recs, (chunk, block)
+    with open(str(tmp_path / "broken.fastq"), "w") as fh:
+        fh.write("@a\nACGT\n+\nIIII\n@b\nAC\n")
+    with pytest.raises(fastq.FastqFormatError, match="Premature end of file"):
+        list(fastq.FastqChunks(str(tmp_path / "broken.fastq"), 10))
+
+
+def test_zip_chunks_stops_with_the_shortest_file(tmp_path):
+    """reference __init__.py:180: zip() over the readers -- tuples end where the shortest file ends."""
+    rng = random.Random(3)
+    a, b = _records(rng, 950), _records(rng, 700)
+    pa, pb = str(tmp_path / "a.fastq"), str(tmp_path / "b.fastq.gz")
+    _write(pa, a)
+    _write(pb, b, gz=True)
+    seen, numbers = 0, []
+    for tables, n, first in fastq.zip_chunks([pa, pb], 256):
+        assert first == seen and all(len(t) >= n for t in tables)
+        numbers.append(n)
+        seen += n
+    assert seen == 700 and numbers == [256, 256, 188]

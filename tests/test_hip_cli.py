@@ -180,6 +180,29 @@ def test_cli_end_to_end_matches_oracle(F, oracle, tmp_path, args):
     assert _names(o2) == [r2[i][0] for i in kept]
 
 
+def test_cli_streams_the_files_in_chunks(F, oracle, tmp_path, monkeypatch):
+    """The files are read chunk by chunk in both passes (FQD_FASTQ_CHUNK_RECORDS; default 2 M records):
+    chunks of 257 records must give what one chunk gives, on files of different lengths, ragged keys,
+    quality-failed first holders spread over the chunks."""
+    rng = random.Random(5)
+    mols = ["".join(rng.choice("ACGT") for _ in range(rng.randint(30, 36))) for _ in range(300)]
+    r1 = []
+    for i in range(2500):
+        s = "".join(rng.choice("ACGTN") if rng.random() < 0.01 else ch for ch in rng.choice(mols))
+        r1.append((f"q{i}", s, "".join(chr(rng.choice([73, 73, 35])) for _ in range(len(s)))))
+    f1 = str(tmp_path / "a.fastq.gz")
+    _fq(f1, r1)
+    outs = {}
+    for chunk in ("257", "100000"):
+        monkeypatch.setenv("FQD_FASTQ_CHUNK_RECORDS", chunk)
+        o = str(tmp_path / f"o{chunk}.fastq")
+        F.main([f1, "-o", o, "-d", "1", "-e", "0.2", "-q"])
+        outs[chunk] = _names(o)
+    assert outs["257"] == outs["100000"]
+    kept, _, _, _ = _oracle_cli(oracle, [r1], None, 1, 0.2, "directional", False)
+    assert outs["257"] == [r1[i][0] for i in kept]
+
+
 def test_cli_detects_unsynced_files(F, tmp_path):
     from fastqdedup_amd.fastq import FastqFormatError
     f1, f2 = str(tmp_path / "a.fastq"), str(tmp_path / "b.fastq")

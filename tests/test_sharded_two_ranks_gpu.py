@@ -29,6 +29,8 @@ def _worker(rank, world, port, case, plan, q):
         # the fused way in (owner-major slabs) also for a job this small
         plan = plan[: -len("+slabs")]
         os.environ["FQD_OWNER_SLABS_MIN_READS"] = "1000"
+        if world == 5:
+            os.environ["FQD_LDS_BUCKET_BITS"] = "18"
     else:
         os.environ["FQD_NO_OWNER_SLABS"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -52,6 +54,7 @@ def _worker(rank, world, port, case, plan, q):
 
 @pytest.mark.parametrize("shape,plan", [("fixed32", "segment-routed"), ("fixed32", "gathered"),
                                         ("fixed32", "segment-routed+slabs"), ("fixed32_3ranks", "segment-routed+slabs"),
+                                        ("fixed32_5ranks", "segment-routed+slabs"),
                                         ("fixed32_foreign", "segment-routed+slabs"),
                                         ("fixed32_foreign", "segment-routed"),
                                         ("fixed100_weights", "segment-routed"), ("fixed100_weights", "gathered"),
@@ -60,7 +63,16 @@ def _worker(rank, world, port, case, plan, q):
 def test_ranks_on_one_gpu(oracle, shape, plan):
     from fastqdedup_amd.synth import fixed_offsets, synth_keys
     world = 2
-    if shape == "fixed32_3ranks":
+    if shape == "fixed32_5ranks":
+        # five ranks: 32 hash bins per owner, and (FQD_LDS_BUCKET_BITS, set in the worker) the widest
+        # level 2 the receiving collapse can have (1024 bins) -- the geometry of an 8-GPU job
+        world = 5
+        n, L, d, edit, method = 200_000, 32, 1, False, "directional"
+        allk = synth_keys(n, L, L, 25, sub_rate=3e-3, n_rate=3e-4)
+        cuts = [0, 50_000, 90_000, 90_500, 150_000, n]
+        case = [(allk[cuts[r]:cuts[r + 1]].reshape(-1), None, L, None, d, edit, method) for r in range(5)]
+        raw, off, w = allk.reshape(-1), fixed_offsets(n, L), None
+    elif shape == "fixed32_3ranks":
         # three ranks (3 x 64 owner-major bins), one of them with few reads, d = 2, adjacency
         world = 3
         n, L, d, edit, method = 150_000, 32, 2, False, "adjacency"

@@ -41,7 +41,7 @@ def main():
         out = tempfile.mkdtemp(prefix=f"fqd_pmc_{counter}_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
                sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--workload",
-               args.workload, "--no-cpu-baseline", "--no-pmc", "--no-host-input", *args.extra]
+               args.workload, "--no-cpu-baseline", "--no-pmc", "--no-host-input", "--no-copy-peak", *args.extra]
         subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
         for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
