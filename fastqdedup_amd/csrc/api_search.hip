@@ -320,7 +320,10 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
 {
     const KeyShape sh = c->ks;
     uint32_t B = 8;
-    while (B < 20 && (U >> B) > 320)   // ~160-320 keys per bucket: a wave sorts them into 64 sub-bins in LDS
+    // ~160-320 keys per bucket: a wave sorts them into 64 sub-bins in LDS. (All passes in one: up to 480 -- at
+    // config 3, 28 M items in 2^16 buckets of ~430 take 0.64 ms, in 2^17 buckets 0.67: level 2 of the
+    // partition then has 512 bins and half as long runs.)
+    while (B < 20 && (U >> B) > (fused_U ? 480u : 320u))
         B++;
     if (const char *e = getenv("FQD_GROUP_BUCKET_BITS"))   // tests: few, crowded buckets
         B = (uint32_t)std::max(1, std::min(20, atoi(e)));

@@ -464,9 +464,10 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
         # ---- the fused way in: packed straight into owner-major slabs, the all-to-all moves the
         # slabs, the owner's collapse starts at level 2 (short keys, no weights, jobs worth it)
         n_max = int(n_per_rank.max())
-        want_slabs = (plan == "segment-routed" and weights is None and hasattr(backend, "pack_to_owner_slabs")
-                      and n_max >= int(os.environ.get("FQD_OWNER_SLABS_MIN_READS", 1 << 20))
-                      and not os.environ.get("FQD_NO_OWNER_SLABS"))
+        can_slabs = (plan == "segment-routed" and weights is None and hasattr(backend, "pack_to_owner_slabs")
+                     and n_max >= int(os.environ.get("FQD_OWNER_SLABS_MIN_READS", 1 << 20))
+                     and not os.environ.get("FQD_NO_OWNER_SLABS"))
+        want_slabs = not comm.any_flag(not can_slabs)      # (weights, switches: every rank must agree)
         if want_slabs:
             try:
                 slabs = backend.pack_to_owner_slabs(keys, key_len, world, n_seg, n_max)
