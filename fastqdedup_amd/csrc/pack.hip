@@ -291,7 +291,18 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
                     // multi-GPU: the bins are owner-major (owner = rank the read goes to, the pigeonhole
                     // rule of fqd_set_owner_rule), hash bins inside -- an owner's reads leave as ONE
                     // range of slabs that is already level 1 of the receiver's collapse
-                    const uint32_t owner = fqd_segment_hash(rec, K, W * K, fixed_len, rule.seg, rule.nseg) % fs.owner_parts;
+                    // (any function of the segment's bases will do -- every copy of a key and every pair of
+                    // keys agreeing on the segment must meet on one rank -- so not fqd_segment_hash, whose
+                    // ~45 operations per record showed as +0.08 ms on this bandwidth-bound kernel: one
+                    // multiply-xor per plane word, the record being a single 32-base word per plane)
+                    uint32_t slo, shi;
+                    fqd_segment(fixed_len, rule.seg, rule.nseg, slo, shi);
+                    const uint32_t sm = fqd_range_mask(0, slo, shi);
+                    uint32_t oh = 0x9E3779B9u;
+#pragma unroll
+                    for (int k = 0; k < K; k++)
+                        oh = (oh ^ (rec[k] & sm)) * 0x85EBCA6Bu;
+                    const uint32_t owner = fqd_mix32(oh) % fs.owner_parts;
                     bin[e] = owner * fs.owner_hb + (fs.owner_hb > 1 ? h >> fs.shift : 0u);
                 } else {
                     bin[e] = (h >> fs.shift) & (fs.n_bins - 1);
