@@ -47,7 +47,7 @@ EXPORTS = [
     "fqd_export_unique", "fqd_import_unique", "fqd_export_edges", "fqd_import_edges",
     "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_set_timing", "fqd_cluster_keys", "fqd_edge_stats", "fqd_synth_keys",
     "fqd_store_add_keys", "fqd_store_remove", "fqd_store_removed_count", "fqd_get_clusters", "fqd_read_clusters",
-    "fqd_trie_order", "fqd_trie_stats", "fqd_store_symbol_events", "fqd_get_stream", "fqd_pack_collapse", "fqd_synth_indel_keys",
+    "fqd_trie_order", "fqd_trie_stats", "fqd_store_symbol_events", "fqd_get_stream", "fqd_pack_collapse", "fqd_synth_indel_keys", "fqd_copy_bandwidth",
     "fqd_cluster_subgraph", "fqd_owner_slab_geometry", "fqd_pack_to_owner_slabs", "fqd_collapse_owner_slabs",
 ]
 
@@ -135,6 +135,7 @@ def load() -> C.CDLL:
                                            C.c_uint64, C.c_uint64, C.c_uint32, u64p, C.POINTER(C.c_int)]
     L.fqd_synth_indel_keys.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
                                        C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, vp]
+    L.fqd_copy_bandwidth.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
     L.fqd_get_stream.argtypes = [vp]
     L.fqd_get_stream.restype = C.c_void_p
     L.fqd_pack_collapse.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp, C.c_int, C.c_uint32, u64p]
@@ -719,6 +720,14 @@ class Context:
         a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         self._ck(self._L.fqd_edge_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"keys_gathered": int(a.value), "pairs_compared": int(b.value), "edges": int(c.value)}
+
+    def copy_bandwidth(self, src, dst, reps: int = 5) -> float:
+        """GB/s (read + write) of a device-to-device copy of ``src`` into ``dst`` (fqd_copy_bandwidth)."""
+        nbytes = src.numel() * src.element_size()
+        out = C.c_double(0.0)
+        self._ck(self._L.fqd_copy_bandwidth(self._h, src.data_ptr(), dst.data_ptr(), int(nbytes) & ~15, int(reps),
+                                            C.byref(out)))
+        return float(out.value)
 
     def synth_indel_keys(self, n_total: int, start: int, count: int, length: int, umi: int, seed: int,
                          indel_rate: float = 0.01, copies: int = 4, sub_rate: float = 1e-3, n_rate: float = 1e-4):

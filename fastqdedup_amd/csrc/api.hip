@@ -1525,6 +1525,31 @@ int fqd_synth_keys(fqd_ctx *c, uint8_t *out_device, uint64_t n_total, uint64_t s
     return FQD_OK;
 }
 
+int fqd_copy_bandwidth(fqd_ctx *c, const void *src_device, void *dst_device, uint64_t bytes, uint32_t reps, double *gb_per_s)
+{
+    FQD_TRY(bind(c));
+    if (!gb_per_s || !src_device || !dst_device || (bytes & 15u) || (((uintptr_t)src_device | (uintptr_t)dst_device) & 15u))
+        return fail(c, FQD_E_VALUE, "fqd_copy_bandwidth: 16-byte aligned device buffers, a multiple of 16 bytes");
+    *gb_per_s = 0.0;
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    HIP_TRY(c, fqd::launch_copy16(src_device, dst_device, bytes, c->st));       // warm-up
+    for (uint32_t r = 0; r < std::max<uint32_t>(reps, 1); r++) {
+        HIP_TRY(c, hipEventRecord(e0, c->st));
+        HIP_TRY(c, fqd::launch_copy16(src_device, dst_device, bytes, c->st));
+        HIP_TRY(c, hipEventRecord(e1, c->st));
+        HIP_TRY(c, hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+        if (ms > 0)
+            *gb_per_s = std::max(*gb_per_s, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return FQD_OK;
+}
+
 int fqd_synth_indel_keys(fqd_ctx *c, uint64_t n_total, uint64_t start, uint64_t count, uint32_t length, uint32_t umi,
                          uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub, uint64_t thr_indel,
                          uint64_t *lens_out_device, const uint64_t *offsets_device, uint8_t *out_device)

@@ -504,6 +504,7 @@ hipError_t launch_transcode_records(const uint32_t *src, const uint32_t *src_len
 hipError_t launch_synth(uint8_t *out, uint64_t n_total, uint64_t start, uint64_t count, uint32_t length,
                         uint32_t umi, uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub,
                         hipStream_t st);
+hipError_t launch_copy16(const void *src, void *dst, uint64_t bytes, hipStream_t st);
 hipError_t launch_synth_indels(uint64_t n_total, uint64_t start, uint64_t count, uint32_t length, uint32_t umi,
                                uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub, uint64_t thr_indel,
                                unsigned long long *lens, const unsigned long long *offsets, uint8_t *out, hipStream_t st);

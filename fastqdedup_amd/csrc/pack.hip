@@ -126,6 +126,7 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
             uint4 v = make_uint4(ph.fill, ph.fill, ph.fill, ph.fill);
             if (row < n_rows) {
                 if (at + 16 <= n_bytes) {
+                    // (a non-temporal load here measured the same: 0.5635 vs 0.566 ms at 50 M x 32)
                     v = *reinterpret_cast<const uint4 *>(bytes + at);
                 } else if (at < n_bytes) {
                     uint32_t w[4] = {ph.fill, ph.fill, ph.fill, ph.fill};

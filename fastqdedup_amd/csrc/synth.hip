@@ -1,5 +1,6 @@
 // synth.hip -- device twin of fastqdedup_amd/synth.py (byte-identical output).
 // Bench/test utility: lets bench.py create its workload directly in HBM.
+#include <cstdlib>
 #include "fqd_internal.h"
 
 namespace {
@@ -123,6 +124,33 @@ __global__ __launch_bounds__(256) void synth_indel_bytes_kernel(SynthParams p, u
     }
 }
 
+// Device-to-device copy, 16 bytes per lane and step, four loads in flight per lane: the "achievable
+// HBM bandwidth" reference of bench.py (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int MODE>
+__global__ __launch_bounds__(256) void copy16_kernel(const u32x4_t *__restrict__ src, u32x4_t *__restrict__ dst, uint64_t n16)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto ld = [&](uint64_t k) { return MODE & 1 ? __builtin_nontemporal_load(src + k) : src[k]; };
+    auto st = [&](uint64_t k, u32x4_t v) {
+        if (MODE & 2)
+            __builtin_nontemporal_store(v, dst + k);
+        else
+            dst[k] = v;
+    };
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4_t a = ld(i), b = ld(i + stride), c = ld(i + 2 * stride), d = ld(i + 3 * stride);
+        st(i, a);
+        st(i + stride, b);
+        st(i + 2 * stride, c);
+        st(i + 3 * stride, d);
+    }
+    for (; i < n16; i += stride)
+        st(i, ld(i));
+}
+
 }  // namespace
 
 namespace fqd {
@@ -141,6 +169,20 @@ hipError_t launch_synth(uint8_t *out, uint64_t n_total, uint64_t start, uint64_t
         blocks = 1u << 20;
     const SynthParams p{n_total, seed, thr_n, thr_sub, length, umi, copies};
     synth_kernel<<<(unsigned)blocks, 256, 0, st>>>(out, p, start, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy16(const void *src, void *dst, uint64_t bytes, hipStream_t st)
+{
+    const uint64_t n16 = bytes / 16;
+    if (!n16)
+        return hipSuccess;
+    const u32x4_t *s4 = reinterpret_cast<const u32x4_t *>(src);
+    u32x4_t *d4 = reinterpret_cast<u32x4_t *>(dst);
+    // measured on MI355X boxes (2 GiB, GB/s read + write): plain loads and stores 4.6-4.8 (5.1 with 65 536
+    // blocks), non-temporal stores 4.8-5.1, non-temporal loads AND stores 5.2-5.6 at 8 192-16 384 blocks;
+    // torch's copy 5.4-5.5
+    copy16_kernel<3><<<16384, 256, 0, st>>>(s4, d4, n16);
     return hipGetLastError();
 }
 

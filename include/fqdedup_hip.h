@@ -414,6 +414,11 @@ int fqd_synth_keys(fqd_ctx *ctx, uint8_t *out_device, uint64_t n_total, uint64_t
                    uint64_t count, uint32_t length, uint32_t umi, uint64_t seed, uint32_t copies,
                    uint64_t thr_n, uint64_t thr_sub);
 
+/* Achievable HBM bandwidth on this GPU, now: the best of `reps` device-to-device copies of `bytes`
+ * bytes by a 16-byte-per-lane copy kernel on the context's stream, read + write counted, in GB/s
+ * (MI355X_MICROARCH.md: 6.29 TB/s for a float4 copy). bench.py's `achievable_peak_gbs`. */
+int fqd_copy_bandwidth(fqd_ctx *ctx, const void *src_device, void *dst_device, uint64_t bytes, uint32_t reps,
+                       double *gb_per_s);
 /* The same job with an indel tail (fastqdedup_amd/synth.py indel_variant, byte-identical): a share
  * thr_indel / 2^53 of the reads loses one base or gains one, so the keys have three lengths -- the
  * shape SURVEY.md 8d asks for to exercise the Levenshtein search. Two calls: lens_out_device != NULL
