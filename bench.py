@@ -328,6 +328,10 @@ def main():
         "part_scatter_kernel<2>": n_in * (16 + 16),
         "bucket_dedupe_kernel": n_in * 16 + U_own * 24,                  # reads in, unique (record, count, first) out
         "bucket_compact_kernel": U_own * (24 + 28),
+        # compact records (csrc/collapse_lds.hip): level 2 turns the 16-byte records into 12 bytes (two key words
+        # + read index), the dedupe reads those
+        "part_scatter12_kernel": n_in * (16 + 12),
+        "bucket_dedupe12_kernel": n_in * 12 + U_own * 16,                # reads in, one uint4 row per unique key out
         "head_flags_kernel": n_in * (4 + 4 + b_key + 4),             # (hash, id), the record once, a flag
         "write_unique_kernel": U_own * (2 * b_key + 16),
         "segment_hashes_kernel": U * (b_key + 4 * nseg),
@@ -346,14 +350,18 @@ def main():
     rocprof_name = {"part_hist_kernel<1>": "part_hist_kernel<true>", "part_hist_kernel<2>": "part_hist_kernel<false>",
                     "part_scatter_kernel<1>": "part_scatter_kernel<true",
                     "part_scatter_kernel<2>": "part_scatter_kernel<false",
+                    "part_scatter12_kernel": "part_scatter12_kernel", "bucket_dedupe12_kernel": "bucket_dedupe12_kernel",
                     "dissect_round_kernel": "_round_kernel" if wl["method"] == "directional" else "adjacency_edges"}
+    compact_records = bool(kern.get("part_scatter12_kernel", (0, 0))[1])
     if kern.get("pack_kernel", (0, 0))[1] and not kern.get("part_scatter_kernel<1>", (0, 0))[1] \
-            and kern.get("part_scatter_kernel<2>", (0, 0))[1]:
+            and (kern.get("part_scatter_kernel<2>", (0, 0))[1] or compact_records):
         # fqd_cluster_keys took the fused way in: the pack kernel wrote its records straight into
         # level 1 of the collapse (key bytes in, 16-byte record out; no hash array)
         kern["pack_kernel (fused with level 1)"] = kern.pop("pack_kernel")
         alg["pack_kernel (fused with level 1)"] = n * (L + 16)
         rocprof_name["pack_kernel (fused with level 1)"] = "pack_kernel"
+    if compact_records:
+        alg["bucket_compact_kernel"] = U_own * (16 + 28)
     if kern.get("bucket_dedupe_kernel", (0, 0))[1] and not kern.get("part_scatter_kernel<2>", (0, 0))[1] \
             and not kern.get("part_scatter_kernel<1>", (0, 0))[1]:
         # records longer than one uint4: the collapse worked on (hash, position) pairs and compared the
@@ -438,6 +446,7 @@ def main():
                    "n_kept": res.n_kept},
         "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_sum.items()},
         "record_bytes": sh.stride_words * 4, "planes": sh.planes,
+        "dedupe_record_bytes": 12 if compact_records else sh.stride_words * 4,
         "roofline": roofline,
         "job_roofline": job_roofline,
         "kernels": kernels,

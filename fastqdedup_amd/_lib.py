@@ -701,7 +701,8 @@ class Context:
     KERNELS = ["pack_kernel", "part_hist_kernel<1>", "part_scatter_kernel<1>", "part_hist_kernel<2>",
                "part_scatter_kernel<2>", "bucket_dedupe_kernel", "bucket_compact_kernel", "head_flags_kernel",
                "write_unique_kernel", "segment_hashes_kernel", "bucket_pairs_kernel", "uf_union_kernel",
-               "uf_flatten_kernel", "dissect_round_kernel", "gp_hist_kernel", "gp_scatter_kernel", "verify_candidates_kernel", "kept_flags_kernel"]
+               "uf_flatten_kernel", "dissect_round_kernel", "gp_hist_kernel", "gp_scatter_kernel", "verify_candidates_kernel", "kept_flags_kernel",
+               "part_scatter12_kernel", "bucket_dedupe12_kernel"]
 
     def kernel_times(self, reset: bool = True):
         """{kernel: (ms summed over launches, launches)} since the last reset."""

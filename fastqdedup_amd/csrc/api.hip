@@ -121,6 +121,10 @@ struct FusedLevel1 {
     // c->ld_seg are filled by the caller (tables_ready)
     uint32_t level1_bits = 0, part_mask = 0xFFFFFFFFu, stamp_div = 0;
     bool tables_ready = false;
+    // compact records (fqd_internal.h Rec12; squeeze code 1 or 2): level 2 writes 12-byte items, keys with an N
+    // take the side path (c->ld_side / c->ld_side_table, sized by the caller: side_slabs x side_cap records, a
+    // hash table of side_slots slots)
+    uint32_t compact = 0, side_slabs = 0, side_cap = 0, side_slots = 0;
 };
 
 // Bucket bits of the LDS collapse for n reads: ~400-800 reads per bucket (2x fewer workgroups than
@@ -151,7 +155,8 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
     const uint32_t B = fused ? fused->B : lds_bucket_bits(n);
     const uint32_t B1 = fused && fused->level1_bits ? fused->level1_bits : std::min<uint32_t>(B, 8), B2 = B - B1;
     const uint32_t bins1 = 1u << B1, bins2 = 1u << B2, n_buckets = 1u << B;
-    const uint32_t kw = sh.planes * sh.words, tile = fqd::part_tile_size();
+    const uint32_t compact = fused ? fused->compact : 0;
+    const uint32_t kw = sh.planes * sh.words, tile = compact ? fqd::part_tile_size12() : fqd::part_tile_size();
     const uint32_t tiles1 = (uint32_t)((n + tile - 1) / tile), max_tiles2 = tiles1 + bins1;
     HIP_TRY(c, c->ld_hist.reserve((size_t)n_buckets * 4 + 1024 * 4));
     HIP_TRY(c, c->ld_hist_incl.reserve((size_t)n_buckets * 4 + 1024 * 4));
@@ -176,9 +181,11 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
     if (!fused)
         HIP_TRY(c, c->ld_part.reserve(n * 16 + 16));
     HIP_TRY(c, c->ld_tmp_rec.reserve(slots * 16 + 16));
-    HIP_TRY(c, c->ld_part2.reserve(slots * 16 + 16));
-    HIP_TRY(c, c->ld_tmp_count.reserve(slots * 4 + 16));
-    HIP_TRY(c, c->ld_tmp_first.reserve(slots * 4 + 16));
+    HIP_TRY(c, c->ld_part2.reserve(slots * (compact ? 12 : 16) + 16));
+    if (!compact) {
+        HIP_TRY(c, c->ld_tmp_count.reserve(slots * 4 + 16));
+        HIP_TRY(c, c->ld_tmp_first.reserve(slots * 4 + 16));
+    }
     // small device tables: [0] seg_start1 (2) | [8] tile_start1 (2) | [16] start1 (257) | [512] tile_start2 (257)
     uint32_t *small = c->ld_small.as<uint32_t>();
     uint32_t *seg1 = small, *tiles1_d = small + 8, *start1 = small + 16, *tiles2_d = small + 512;
@@ -210,6 +217,16 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
     uint32_t *f_seg_start = fused ? c->ld_seg.as<uint32_t>() : nullptr;
     uint32_t *f_seg_end = fused ? f_seg_start + (f_parts + 4) : nullptr;
     uint32_t *f_tiles = fused ? f_seg_end + (f_parts + 4) : nullptr;
+    // compact records, squeeze 1: the side slabs' cursors (and their starts, unused) live behind the hash table
+    fqd::SideSlabs side;
+    if (compact == 1) {
+        uint32_t *tail = c->ld_side_table.as<uint32_t>() + fqd::side_table_words(fused->side_slots);
+        side.recs = c->ld_side.as<uint4>();
+        side.cursor = tail;
+        side.n_slabs = fused->side_slabs;
+        side.cap = fused->side_cap;
+        side.overflow = c->d_ctr32.as<uint32_t>() + C_BAD;
+    }
     const uint32_t *parted = c->ld_part.as<uint32_t>();
     uint32_t U32 = 0, overflow = 0, early_nseg = 0;
     for (;;) {
@@ -236,7 +253,22 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 HIP_TRY(c, fqd::launch_bucket_starts(c->ld_hist_incl.as<uint32_t>(), n_buckets, c->ld_start.as<uint32_t>(),
                                                      c->ld_cursor.as<uint32_t>(), c->st));
             }
-            if (fused)
+            if (compact) {
+                if (compact == 1)
+                    HIP_TRY(c, fqd::launch_slab_starts(side.n_slabs, side.cap, side.cursor + side.n_slabs, side.cursor,
+                                                       c->st));
+                KTIME(c, FQD_K_PART_SCATTER12, fqd::launch_part_scatter12(
+                          c->ld_part.as<uint32_t>(), compact, side, f_seg_start, f_tiles, f_parts, tiles1 + f_parts,
+                          32 - B, bins2, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<fqd::Rec12>(), c->st, slab_cap,
+                          c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end, fused->sub_bits));
+                // the keys with an N: collapsed apart, to the head of the unique table (few: a table in global memory)
+                if (compact == 1)
+                    HIP_TRY(c, fqd::launch_side_collapse(
+                                   side.recs, side.cursor, 0, side.n_slabs, side.cap, d_w, c->ld_side_table.as<uint32_t>(),
+                                   fused->side_slots, c->ld_side_table.as<uint32_t>() + 3 * (size_t)fused->side_slots,
+                                   c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(),
+                                   c->d_ctr32.as<uint32_t>() + C_SIDE, c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+            } else if (fused)
                 KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(
                           false, nullptr, c->ld_part.as<uint32_t>(), f_seg_start, f_tiles, f_parts, tiles1 + f_parts,
                           32 - B, bins2, kw, sh.max_len, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<uint32_t>(), c->st,
@@ -249,6 +281,12 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                           slab_cap, c->d_ctr32.as<uint32_t>() + C_BAD));
             parted = c->ld_part2.as<uint32_t>();
         }
+        if (compact)
+            KTIME(c, FQD_K_DEDUPE12, fqd::launch_bucket_dedupe12(reinterpret_cast<const fqd::Rec12 *>(parted),
+                                                               c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
+                                                               c->ld_tmp_rec.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
+                                                               c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+        else
         KTIME(c, FQD_K_DEDUPE, fqd::launch_bucket_dedupe(parted, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
                                              c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(),
                                              c->ld_tmp_first.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
@@ -261,7 +299,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         // many unique keys as reads), so the GPU works through the ~50 us the host needs to see the
         // numbers and react. If a flag says the attempt failed, what it wrote is simply not used.
         FQD_TRY(queue_read_u32(c, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 0));
-        FQD_TRY(queue_read_u32n(c, c->d_ctr32.as<uint32_t>(), C_PACKBAD + 1, 1));
+        FQD_TRY(queue_read_u32n(c, c->d_ctr32.as<uint32_t>(), C_SIDE + 1, 1));
         FQD_TRY(queued_reads_mark(c));
         HIP_TRY(c, c->urecs.reserve(n * 16 + 16));
         HIP_TRY(c, c->ucounts.reserve(n * 4 + 16));
@@ -277,16 +315,24 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
             sho.kw = kw;
             sho.len = sh.max_len;
         }
+        if (compact)
+            KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_compact12(
+                      c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets,
+                      c->ld_tmp_rec.as<uint32_t>(), compact, compact == 1 ? c->d_ctr32.as<uint32_t>() + C_SIDE : nullptr,
+                      c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho));
+        else
         KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_compact(
                   c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets, c->ld_tmp_rec.as<uint32_t>(),
                   c->ld_tmp_count.as<uint32_t>(), c->ld_tmp_first.as<uint32_t>(), d_ids, c->urecs.as<uint32_t>(),
                   c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho));
         early_nseg = sho.nseg;
         FQD_TRY(queued_reads_wait(c));
-        U32 = taken_u32(c, 0);
+        U32 = taken_u32(c, 0) + (compact == 1 ? taken_u32(c, 1 + C_SIDE) : 0u);
         overflow = taken_u32(c, 1 + C_BAD);
         if (fused) {
             fused->pack_bad = taken_u32(c, 1 + C_PACKBAD);
+            if (overflow & 16u)
+                c->compact_off = true;
             if (overflow & 4u)
                 c->fused_off = true;
             if (overflow & 2u)
@@ -845,8 +891,23 @@ static int collapse_impl(fqd_ctx *c, const uint32_t *weights, int mem, IdSource 
 // and one read of all records, the hash array and the level-1 histogram pass (1.0 -> 0.55 ms of a
 // 3.9 ms job at 50 M reads). *done = false: not applicable, or some slab / table overflowed or the
 // keys hold a byte outside "ACGNT" -- the caller then goes the plain way, which handles all that.
+static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uint32_t fixed_len, int mem,
+                                    const uint32_t *weights, int aux_mem, bool *done);
+
+// Compact records first (12 bytes per read through the partition, keys with an N on a side path); when their side
+// slabs overflow -- the data has many keys with an N -- once more with uint4 records, and so from then on.
 static int pack_collapse_fused(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uint32_t fixed_len, int mem,
                                const uint32_t *weights, int aux_mem, bool *done)
+{
+    const bool was_off = c->compact_off;
+    FQD_TRY(pack_collapse_fused_once(c, bytes, n, fixed_len, mem, weights, aux_mem, done));
+    if (!*done && !was_off && c->compact_off && !c->fused_off)
+        FQD_TRY(pack_collapse_fused_once(c, bytes, n, fixed_len, mem, weights, aux_mem, done));
+    return FQD_OK;
+}
+
+static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uint32_t fixed_len, int mem,
+                                    const uint32_t *weights, int aux_mem, bool *done)
 {
     *done = false;
     const char *force = getenv("FQD_COLLAPSE");
@@ -886,6 +947,30 @@ static int pack_collapse_fused(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uin
     if ((uint64_t)parts * cap1 + n >= 0xFFFFFF00ull)
         return FQD_OK;
     FQD_TRY(upload_lut(c, lut));
+    // compact records (fqd_internal.h Rec12): one 32-base word per plane, and either two planes or
+    // the three of exactly "ACGNT" (a key with an N -- code 3 -- then takes the side path)
+    uint32_t compact = 0;
+    if (!c->compact_off && !getenv("FQD_NO_COMPACT_RECORDS") && sh.words == 1) {
+        if (sh.planes == 2) {
+            compact = 2;
+        } else if (sh.planes == 3) {
+            uint32_t others = present[0] ? 1u : 0u;
+            for (int b = 1; b < 128; b++)
+                others += present[b] && !strchr("ACGNT", b) ? 1u : 0u;
+            if (!others && present['A'] && present['C'] && present['G'] && present['N'] && present['T'])
+                compact = 1;
+        }
+    }
+    // side path of the compact records: 256 slabs for n / 64 + 16 Ki keys with an N in all (more: uint4 records
+    // from then on), a hash table of twice as many slots
+    uint32_t side_slabs = 0, side_cap = 0, side_slots = 0;
+    if (compact == 1) {
+        side_slabs = 256;
+        side_cap = (uint32_t)((((n >> 6) + 16384) / side_slabs + 3) & ~3ull);
+        side_slots = 1024;
+        while (side_slots < 2ull * side_slabs * side_cap)
+            side_slots *= 2;
+    }
     const uint64_t n_bytes = n * (uint64_t)fixed_len;
     const uint8_t *d_bytes;
     StageTimer pack_timer(c, FQD_T_PACK);
@@ -897,6 +982,14 @@ static int pack_collapse_fused(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uin
     HIP_TRY(c, fqd::launch_slab_starts(parts, cap1, seg_start, cursor, c->st));
     const fqd::PackScatter fs{cursor, reinterpret_cast<uint4 *>(c->ld_part.p), c->d_ctr32.as<uint32_t>() + C_BAD,
                               32 - 8, 256, 1u << sub_bits, cap1};
+    if (compact == 1) {
+        HIP_TRY(c, c->ld_side.reserve((size_t)side_slabs * side_cap * 16 + 16));
+        HIP_TRY(c, c->ld_side_table.reserve(((size_t)fqd::side_table_words(side_slots) + 2 * side_slabs + 4) * 4 + 16));
+        // (the side path writes the head of the unique table before the compaction is queued)
+        HIP_TRY(c, c->urecs.reserve(n * 16 + 16));
+        HIP_TRY(c, c->ucounts.reserve(n * 4 + 16));
+        HIP_TRY(c, c->ufirst.reserve(n * 8 + 16));
+    }
     {
         StageTimer kernel_timer(c, FQD_T_PACK_KERNEL);
         KTIME(c, FQD_K_PACK, fqd::launch_pack(d_bytes, n_bytes, nullptr, n, fixed_len, sh, c->d_lut.as<uint8_t>(), lut,
@@ -915,12 +1008,16 @@ static int pack_collapse_fused(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uin
     const uint32_t *d_w;
     FQD_TRY(to_device(c, weights, (size_t)n, aux_mem, c->in_weights, &d_w));
     FusedLevel1 f{parts, sub_bits, B};
+    f.compact = compact;
+    f.side_slabs = side_slabs;
+    f.side_cap = side_cap;
+    f.side_slots = side_slots;
     bool ok = false;
     FQD_TRY(collapse_lds(c, weights ? d_w : nullptr, IdSource(), &ok, &f));
     timer.stop();
     if (getenv("FQD_DEBUG"))
-        fprintf(stderr, "[fqd] fused pack + collapse: n=%llu parts=%u cap=%u done=%d pack_bad=%u fused_off=%d\n",
-                (unsigned long long)n, parts, cap1, (int)ok, f.pack_bad, (int)c->fused_off);
+        fprintf(stderr, "[fqd] fused pack + collapse: n=%llu parts=%u cap=%u compact=%u done=%d pack_bad=%u fused_off=%d compact_off=%d\n",
+                (unsigned long long)n, parts, cap1, compact, (int)ok, f.pack_bad, (int)c->fused_off, (int)c->compact_off);
     if (!ok)
         return FQD_OK;
     c->collapse_path = 1;

@@ -75,7 +75,7 @@ struct DevBuf {
 enum Stage { ST_EMPTY = 0, ST_PACKED = 1, ST_UNIQUE = 2, ST_EDGES = 3, ST_LABELS = 4, ST_KEPT = 5 };
 
 // small device-side words read back by the host
-enum Ctr { C_BAD = 0, C_COLLISIONS = 1, C_CHANGED = 2, C_MINLEN = 3, C_MAXLEN = 4, C_PACKBAD = 5, C_N32 = 8 };
+enum Ctr { C_BAD = 0, C_COLLISIONS = 1, C_CHANGED = 2, C_MINLEN = 3, C_MAXLEN = 4, C_PACKBAD = 5, C_SIDE = 6, C_N32 = 8 };
 enum Ctr64 { C64_EDGES = 0, C64_ROOTS = 1, C64_SUM = 2, C64_STATS = 3, C64_CANDS = 4, C64_CAND_NEED = 5, C64_SLAB = 6, C64_N = 8 };
 
 }  // namespace
@@ -104,6 +104,7 @@ struct fqd_ctx {
     // stage 1
     uint64_t n = 0;
     DevBuf in_bytes, in_offsets, recs, lens, hashes, owners;
+    bool compact_off = false;      // fqd_cluster_keys: the side slabs of the compact records overflowed once (many keys with an N) -- uint4 records from now on
     bool fused_off = false;        // fqd_cluster_keys: a level-1 slab of the fused pack overflowed once -- plain pack from now on
     bool recs_valid = false;       // c->recs holds the packed reads in read order (not after the fused pack)
     bool pairs_slab_off = false;   // long-record collapse: same, for its (hash, position) partition
@@ -122,7 +123,7 @@ struct fqd_ctx {
     DevBuf in_weights, in_read_ids, hs_sorted, ids, ids_sorted, flags, run_idx, run_start, run_weight, live_flag,
         live_idx, collision_runs;
     DevBuf urecs, ulens, ucounts, ufirst;
-    DevBuf ld_small, ld_part2, ld_matrix, ld_matrix_incl, ld_seg;
+    DevBuf ld_small, ld_part2, ld_matrix, ld_matrix_incl, ld_seg, ld_side, ld_side_table;
     DevBuf ld_hist, ld_hist_incl, ld_start, ld_cursor, ld_part, ld_tmp_rec, ld_tmp_count, ld_tmp_first, ld_unique,
         ld_unique_incl;
     int collapse_path = 0;  // 1: LDS bucket dedupe, 2: sort + verify (last fqd_collapse)

@@ -39,6 +39,8 @@ constexpr uint32_t DD_EMPTY = 0xFFFFFFFFu;
 struct RecordPolicy {
     using Item = uint4;
     static constexpr uint32_t EPT = 8;          // 2048-record tiles
+    static constexpr bool MAY_SKIP = false;
+    static __device__ __forceinline__ bool skip(const uint4 &) { return false; }
     struct Source {
         const uint32_t *hashes;   // level 1 only, may be NULL
         const uint4 *in;
@@ -365,6 +367,381 @@ __global__ void bucket_starts_kernel(const uint32_t *__restrict__ hist_incl, uin
     fqd_partition::bucket_starts_body(hist_incl, n_buckets, bucket_start, cursor);
 }
 
+
+// ---- compact records (fqd_internal.h Rec12): 12-byte items out of level 2 ------------------------------
+// What differs from the uint4 pipeline above: level 2 WRITES Rec12 items (two key words + read index; a key with
+// an N leaves through a side slab instead), the dedupe reads 12 instead of 16 bytes per read and keeps no third
+// key word in its LDS table (20 KB, one more workgroup per CU), its tmp rows are ONE uint4 per unique key (a, b,
+// count, first index), and the compaction turns the two words back into the three planes of the unique table,
+// behind the few keys of the side path at its head.
+// (The pack kernel itself writing Rec12 items into level 1 was measured: 0.98 ms instead of 0.57 -- its 4-record
+// runs become 48 bytes at any 4-byte offset, and such writes cost more than the quarter of the bytes saves;
+// level 2 writes 8-record runs.)
+struct CompactPolicy {
+    using Item = fqd::Rec12;
+    static constexpr uint32_t EPT = 8;
+    static constexpr bool MAY_SKIP = true;
+    struct Source {
+        const uint4 *in;          // the pack kernel's records: planes + read index
+        uint32_t squeeze;
+        fqd::SideSlabs side;
+    };
+    static __device__ __forceinline__ uint32_t segment_tag(const Source &, uint32_t) { return 0u; }
+    static __device__ __forceinline__ void apply_tag(fqd::Rec12 &, uint32_t) {}
+    // a record that left through the side slabs: not staged, not written
+    static __device__ __forceinline__ bool skip(const fqd::Rec12 &v) { return v.id == 0xFFFFFFFFu; }
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint32_t load(const Source &s, uint32_t i, fqd::Rec12 &v)
+    {
+        const uint4 r = s.in[i];
+        if (s.squeeze == 1) {
+            if (r.x & r.y) {
+                // a key with an N (few: one global atomic each, spread over the side slabs by workgroup)
+                const uint32_t slab = blockIdx.x & (s.side.n_slabs - 1);
+                const uint32_t pos = atomicAdd(&s.side.cursor[slab], 1u);
+                if (pos < (slab + 1) * s.side.cap)
+                    s.side.recs[pos] = r;
+                else
+                    atomicOr(s.side.overflow, 16u);
+                v = fqd::Rec12{0u, 0u, 0xFFFFFFFFu};
+                return 0u;
+            }
+            v = fqd::Rec12{r.x | r.z, r.y | r.z, r.w};
+        } else {
+            v = fqd::Rec12{r.x, r.y, r.w};
+        }
+        return fqd::fqd_hash_rec12(v.a, v.b);
+    }
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint32_t key(const Source &s, uint32_t i)
+    {
+        fqd::Rec12 v;
+        return load<false>(s, i, v);
+    }
+};
+
+template <uint32_t MAXB>
+__global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter12_kernel(
+    CompactPolicy::Source src, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ tile_start,
+    uint32_t n_seg, uint32_t shift, uint32_t n_bins, uint32_t *__restrict__ cursor, fqd::Rec12 *__restrict__ out,
+    uint32_t slab_cap, uint32_t *__restrict__ slab_overflow, const uint32_t *__restrict__ seg_end, uint32_t seg_shift)
+{
+    fqd_partition::scatter_body<CompactPolicy, false, MAXB>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
+                                                            slab_cap, slab_overflow, seg_end, seg_shift, 0xFFFFFFFFu);
+}
+
+__device__ __forceinline__ uint32_t rec12_tag(uint32_t a, uint32_t b)
+{
+    uint32_t h = (a ^ 0x9E3779B9u) * 0x85EBCA6Bu;
+    h = (h ^ (h >> 15) ^ b) * 0xC2B2AE35u;
+    h = (h ^ (h >> 13)) * 0x27D4EB2Fu;
+    h ^= h >> 16;
+    return h == DD_EMPTY ? 0u : h;
+}
+
+// bucket_dedupe_kernel for Rec12 items (same rounds: claim or stop at a matching tag, barrier, verify against
+// the parked key); a live slot leaves as ONE uint4 (a, b, count, first index) at tmp[lo + rank]
+__global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
+    const fqd::Rec12 *__restrict__ part, const uint32_t *__restrict__ bucket_start,
+    const uint32_t *__restrict__ bucket_end, const uint32_t *__restrict__ weights, uint4 *__restrict__ tmp,
+    uint32_t *__restrict__ bucket_unique, uint32_t *__restrict__ overflow)
+{
+    __shared__ uint32_t s_tag[DD_SLOTS], s_x[DD_SLOTS], s_y[DD_SLOTS], s_cnt[DD_SLOTS], s_min[DD_SLOTS];
+    __shared__ uint32_t s_wave_tot[DD_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t lo = bucket_start[b];
+    uint32_t hi = bucket_start[b + 1];
+    if (bucket_end)
+        hi = min(hi, bucket_end[b]);
+    for (uint32_t s = tid; s < DD_SLOTS; s += DD_THREADS)
+        s_tag[s] = DD_EMPTY;
+    __syncthreads();
+
+    bool full = false;
+    constexpr uint32_t DD_AHEAD = 4;
+    for (uint32_t base0 = lo; base0 < hi; base0 += DD_AHEAD * DD_THREADS) {
+        fqd::Rec12 ahead[DD_AHEAD];
+        uint32_t ahead_w[DD_AHEAD];
+#pragma unroll
+        for (uint32_t k = 0; k < DD_AHEAD; k++) {
+            const uint32_t i = base0 + k * DD_THREADS + tid;
+            ahead[k] = fqd::Rec12{0, 0, 0};
+            if (i < hi)
+                ahead[k] = part[i];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < DD_AHEAD; k++) {
+            const uint32_t i = base0 + k * DD_THREADS + tid;
+            ahead_w[k] = i < hi ? (weights ? weights[ahead[k].id] : 1u) : 0u;
+        }
+        uint32_t tag[DD_AHEAD], slot[DD_AHEAD], probes[DD_AHEAD];
+        bool pending[DD_AHEAD];
+#pragma unroll
+        for (uint32_t k = 0; k < DD_AHEAD; k++) {
+            tag[k] = rec12_tag(ahead[k].a, ahead[k].b);
+            slot[k] = (tag[k] * 0x9E3779B1u) >> 22;
+            probes[k] = 0;
+            pending[k] = base0 + k * DD_THREADS + tid < hi;
+        }
+        bool any;
+        do {
+#pragma unroll
+            for (uint32_t k = 0; k < DD_AHEAD; k++) {
+                if (!pending[k])
+                    continue;
+                for (;;) {
+                    const uint32_t old = atomicCAS(&s_tag[slot[k]], DD_EMPTY, tag[k]);
+                    if (old == DD_EMPTY) {
+                        s_x[slot[k]] = ahead[k].a;
+                        s_y[slot[k]] = ahead[k].b;
+                        s_cnt[slot[k]] = ahead_w[k];
+                        s_min[slot[k]] = ahead[k].id;
+                        pending[k] = false;
+                        break;
+                    }
+                    if (old == tag[k])
+                        break;
+                    slot[k] = (slot[k] + 1) & (DD_SLOTS - 1);
+                    if (++probes[k] >= DD_SLOTS) {
+                        full = true;
+                        pending[k] = false;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            any = false;
+#pragma unroll
+            for (uint32_t k = 0; k < DD_AHEAD; k++) {
+                if (!pending[k])
+                    continue;
+                if (s_x[slot[k]] == ahead[k].a && s_y[slot[k]] == ahead[k].b) {
+                    atomicAdd(&s_cnt[slot[k]], ahead_w[k]);
+                    atomicMin(&s_min[slot[k]], ahead[k].id);
+                    pending[k] = false;
+                } else {
+                    slot[k] = (slot[k] + 1) & (DD_SLOTS - 1);
+                    if (++probes[k] >= DD_SLOTS) {
+                        full = true;
+                        pending[k] = false;
+                    } else {
+                        any = true;
+                    }
+                }
+            }
+        } while (__syncthreads_or(any));
+    }
+    if (full)
+        atomicOr(overflow, 1u);
+    __syncthreads();
+
+    uint32_t mine = 0;
+    for (uint32_t s = tid; s < DD_SLOTS; s += DD_THREADS)
+        mine += (s_tag[s] != DD_EMPTY && s_cnt[s] > 0) ? 1u : 0u;
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if ((int)lane >= o)
+            incl += up;
+    }
+    if (lane == 63)
+        s_wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine;
+    for (uint32_t wv = 0; wv < wave; wv++)
+        before += s_wave_tot[wv];
+    uint32_t total = 0;
+    for (uint32_t wv = 0; wv < DD_THREADS / 64; wv++)
+        total += s_wave_tot[wv];
+    uint32_t out = lo + before;
+    for (uint32_t s = tid; s < DD_SLOTS; s += DD_THREADS)
+        if (s_tag[s] != DD_EMPTY && s_cnt[s] > 0)
+            tmp[out++] = make_uint4(s_x[s], s_y[s], s_cnt[s], s_min[s]);
+    if (tid == 0)
+        bucket_unique[b] = total;
+}
+
+// the planes of a compact key (squeeze 1: (p0 | p2, p1 | p2) of an N-free "ACGNT" key; 2: the two planes themselves)
+__device__ __forceinline__ void rec12_planes(uint32_t squeeze, uint32_t a, uint32_t b, uint32_t w[3])
+{
+    if (squeeze == 1) {
+        w[0] = a & ~b;
+        w[1] = b & ~a;
+        w[2] = a & b;
+    } else {
+        w[0] = a;
+        w[1] = b;
+        w[2] = 0;
+    }
+}
+
+// one wave per bucket: tmp[bucket_start[b] + j] -> row side + uoff[b] + j of the unique table, side = *side_unique
+// keys that launch_side_collapse has put at the head of the table already; the waves behind the last bucket
+// write the segment hashes of those keys (their total was not known when they were written)
+__global__ __launch_bounds__(256) void bucket_compact12_kernel(
+    const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ unique_incl, uint32_t n_buckets,
+    const uint4 *__restrict__ tmp, uint32_t squeeze, const uint32_t *__restrict__ side_unique,
+    uint4 *__restrict__ urecs, uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst, fqd::SegHashOut sho)
+{
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t side = side_unique ? *side_unique : 0u;
+    const uint32_t n_unique = side + unique_incl[n_buckets - 1];
+    if (b >= n_buckets) {
+        if (!sho.nseg)
+            return;
+        const uint32_t n_waves = (gridDim.x * blockDim.x >> 6) - n_buckets;
+        for (uint32_t j = (b - n_buckets) * 64 + fqd_lane(); j < side; j += n_waves * 64) {
+            const uint4 r = urecs[j];
+            const uint32_t w[3] = {r.x, r.y, r.z};
+            for (uint32_t sg = 0; sg < sho.nseg; sg++)
+                sho.out[(size_t)sg * n_unique + j] = fqd_segment_hash(w, sho.planes, sho.kw, sho.len, sg, sho.nseg);
+        }
+        return;
+    }
+    const uint32_t end = unique_incl[b], begin = b ? unique_incl[b - 1] : 0u;
+    const uint32_t src = bucket_start[b];
+    const uint32_t cnt = end - begin;
+    for (uint32_t j0 = fqd_lane(); j0 < cnt; j0 += 4 * 64) {
+        uint4 row[4];
+#pragma unroll
+        for (uint32_t t = 0; t < 4; t++) {
+            const uint32_t j = j0 + t * 64;
+            row[t] = make_uint4(0, 0, 0, 0);
+            if (j < cnt)
+                row[t] = tmp[src + j];
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < 4; t++) {
+            const uint32_t j = j0 + t * 64;
+            if (j >= cnt)
+                continue;
+            uint32_t w[3];
+            rec12_planes(squeeze, row[t].x, row[t].y, w);
+            const uint32_t u = side + begin + j;
+            if (sho.nseg)
+                for (uint32_t sg = 0; sg < sho.nseg; sg++)
+                    sho.out[(size_t)sg * n_unique + u] = fqd_segment_hash(w, sho.planes, sho.kw, sho.len, sg, sho.nseg);
+            urecs[u] = make_uint4(w[0], w[1], w[2], 0u);
+            ucounts[u] = row[t].z;
+            ufirst[u] = row[t].w;
+        }
+    }
+}
+
+// ---- the side path: keys with the rare symbol (uint4 records in `subs` slabs) -----------------------------
+// An open-addressing table in global memory, one word triple per slot: the POSITION of the record that claimed
+// the slot, the count and the smallest read index. A later record compares itself with the claimer's record in
+// the slabs (written by an earlier kernel) -- no record is parked in the table, so nothing can be read half
+// written. Then the live slots are counted per block of 1024 and written, in table order, to the head of the
+// unique table.
+constexpr uint32_t SIDE_EMPTY = 0xFFFFFFFFu, SIDE_BLOCK = 1024;
+
+__global__ void side_clear_kernel(uint32_t *__restrict__ table, uint32_t table_slots)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < table_slots) {
+        table[i] = SIDE_EMPTY;                       // claimer
+        table[table_slots + i] = 0u;                 // count
+        table[2 * table_slots + i] = 0xFFFFFFFFu;    // first index
+    }
+}
+
+// cursor[sub]: the pack kernel's cursor of side slab `sub`; it started at (first_part + sub) * cap and may have run
+// past the slab's end (the pack kernel has raised the overflow flag then)
+__global__ void side_insert_kernel(const uint4 *__restrict__ side, const uint32_t *__restrict__ cursor,
+                                   uint32_t first_part, uint32_t cap, const uint32_t *__restrict__ weights,
+                                   uint32_t *table, uint32_t table_slots, uint32_t *__restrict__ overflow)
+{
+    const uint32_t sub = blockIdx.y;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t filled = cursor[sub] - (first_part + sub) * cap;
+    if (i >= min(filled, cap))
+        return;
+    const uint32_t pos = sub * cap + i;
+    const uint4 v = side[pos];
+    const uint32_t w = weights ? weights[v.w] : 1u;
+    uint32_t h = (v.x ^ 0x9E3779B9u) * 0x85EBCA6Bu;
+    h = (h ^ (h >> 15) ^ v.y) * 0xC2B2AE35u;
+    h = (h ^ (h >> 13) ^ v.z) * 0x27D4EB2Fu;
+    h ^= h >> 16;
+    uint32_t slot = h & (table_slots - 1);
+    for (uint32_t probes = 0; probes < table_slots; probes++) {
+        uint32_t owner = atomicCAS(&table[slot], SIDE_EMPTY, pos);
+        if (owner == SIDE_EMPTY)
+            owner = pos;
+        const uint4 o = owner == pos ? v : side[owner];
+        if (o.x == v.x && o.y == v.y && o.z == v.z) {
+            atomicAdd(&table[table_slots + slot], w);
+            atomicMin(&table[2 * table_slots + slot], v.w);
+            return;
+        }
+        slot = (slot + 1) & (table_slots - 1);
+    }
+    atomicOr(overflow, 16u);
+}
+
+__global__ __launch_bounds__(SIDE_BLOCK) void side_count_kernel(const uint32_t *__restrict__ table, uint32_t table_slots,
+                                                                uint32_t *__restrict__ block_counts)
+{
+    const uint32_t i = blockIdx.x * SIDE_BLOCK + threadIdx.x;
+    const bool live = i < table_slots && table[i] != SIDE_EMPTY && table[table_slots + i] > 0;
+    const uint32_t n = __syncthreads_count(live);
+    if (threadIdx.x == 0)
+        block_counts[blockIdx.x] = n;
+}
+
+__global__ __launch_bounds__(SIDE_BLOCK) void side_emit_kernel(const uint4 *__restrict__ side,
+                                                               const uint32_t *__restrict__ table, uint32_t table_slots,
+                                                               const uint32_t *__restrict__ block_counts,
+                                                               uint4 *__restrict__ urecs, uint32_t *__restrict__ ucounts,
+                                                               uint64_t *__restrict__ ufirst,
+                                                               uint32_t *__restrict__ side_unique)
+{
+    __shared__ uint32_t s_part[SIDE_BLOCK / 64], s_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // rows before this block: the counts of the blocks before it (at most a few hundred)
+    uint32_t before = 0;
+    for (uint32_t k = tid; k < blockIdx.x; k += SIDE_BLOCK)
+        before += block_counts[k];
+    for (int o = 32; o; o >>= 1)
+        before += __shfl_xor(before, o);
+    if (lane == 0)
+        s_part[wave] = before;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t sum = 0;
+        for (uint32_t k = 0; k < SIDE_BLOCK / 64; k++)
+            sum += s_part[k];
+        s_base = sum;
+    }
+    __syncthreads();
+    const uint32_t base = s_base;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * SIDE_BLOCK + tid;
+    const bool live = i < table_slots && table[i] != SIDE_EMPTY && table[table_slots + i] > 0;
+    const unsigned long long m = __ballot(live);
+    if (lane == 0)
+        s_part[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (uint32_t k = 0; k < wave; k++)
+        rank += s_part[k];
+    if (live) {
+        const uint4 v = side[table[i]];
+        const uint32_t u = base + rank;
+        urecs[u] = make_uint4(v.x, v.y, v.z, 0u);
+        ucounts[u] = table[table_slots + i];
+        ufirst[u] = table[2 * table_slots + i];
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        uint32_t total = base;
+        for (uint32_t k = 0; k < SIDE_BLOCK / 64; k++)
+            total += s_part[k];
+        *side_unique = total;
+    }
+}
+
 }  // namespace
 
 namespace fqd {
@@ -463,6 +840,69 @@ hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_sta
                                                            weights,
                                                            reinterpret_cast<uint4 *>(tmp_rec), tmp_count, tmp_first,
                                                            bucket_unique, overflow);
+    return hipGetLastError();
+}
+
+uint32_t part_tile_size12() { return fqd_partition::THREADS * CompactPolicy::EPT; }
+
+hipError_t launch_part_scatter12(const uint32_t *in, uint32_t squeeze, SideSlabs side, const uint32_t *seg_start,
+                                 const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
+                                 uint32_t n_bins, uint32_t *cursor, Rec12 *out, hipStream_t st, uint32_t slab_cap,
+                                 uint32_t *slab_overflow, const uint32_t *seg_end, uint32_t seg_shift)
+{
+    if (n_bins > fqd_partition::MAX_BINS || (squeeze != 1 && squeeze != 2))
+        return hipErrorInvalidValue;
+    if (squeeze == 1 && (!side.recs || !side.cursor || !side.overflow || !side.cap || !side.n_slabs ||
+                         (side.n_slabs & (side.n_slabs - 1))))
+        return hipErrorInvalidValue;
+    const CompactPolicy::Source src{reinterpret_cast<const uint4 *>(in), squeeze, side};
+    if (n_bins <= 256)
+        part_scatter12_kernel<256><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
+            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift);
+    else
+        part_scatter12_kernel<fqd_partition::MAX_BINS><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
+            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift);
+    return hipGetLastError();
+}
+
+hipError_t launch_bucket_dedupe12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                  uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
+                                  uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st)
+{
+    bucket_dedupe12_kernel<<<n_buckets, DD_THREADS, 0, st>>>(part, bucket_start, bucket_end, weights,
+                                                             reinterpret_cast<uint4 *>(tmp_rec), bucket_unique, overflow);
+    return hipGetLastError();
+}
+
+hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
+                                   const uint32_t *tmp_rec, uint32_t squeeze, const uint32_t *side_unique,
+                                   uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, hipStream_t st,
+                                   SegHashOut seg_hashes)
+{
+    // one wave per bucket + 64 waves for the segment hashes of the side path's keys
+    const uint64_t threads = ((uint64_t)n_buckets + (side_unique && seg_hashes.nseg ? 64 : 0)) * 64;
+    bucket_compact12_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
+        bucket_start, unique_incl, n_buckets, reinterpret_cast<const uint4 *>(tmp_rec), squeeze, side_unique,
+        reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes);
+    return hipGetLastError();
+}
+
+uint32_t side_table_words(uint32_t table_slots) { return 3 * table_slots + (table_slots + SIDE_BLOCK - 1) / SIDE_BLOCK; }
+
+hipError_t launch_side_collapse(const uint4 *side, const uint32_t *cursor, uint32_t first_part, uint32_t subs, uint32_t cap,
+                                const uint32_t *weights, uint32_t *table, uint32_t table_slots, uint32_t *block_counts,
+                                uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, uint32_t *side_unique,
+                                uint32_t *overflow, hipStream_t st)
+{
+    if (!table_slots || (table_slots & (table_slots - 1)) || !subs || !cap)
+        return hipErrorInvalidValue;
+    const uint32_t blocks = (table_slots + SIDE_BLOCK - 1) / SIDE_BLOCK;
+    side_clear_kernel<<<(table_slots + 255) / 256, 256, 0, st>>>(table, table_slots);
+    side_insert_kernel<<<dim3((cap + 255) / 256, subs), 256, 0, st>>>(side, cursor, first_part, cap, weights, table,
+                                                                     table_slots, overflow);
+    side_count_kernel<<<blocks, SIDE_BLOCK, 0, st>>>(table, table_slots, block_counts);
+    side_emit_kernel<<<blocks, SIDE_BLOCK, 0, st>>>(side, table, table_slots, block_counts,
+                                                    reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, side_unique);
     return hipGetLastError();
 }
 

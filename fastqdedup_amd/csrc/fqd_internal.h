@@ -235,6 +235,22 @@ struct PackScatter {
     // OwnerRule handed to launch_pack; n_bins = owner_parts * owner_hb. 0: plain hash bins.
     uint32_t owner_parts = 0, owner_hb = 0;
 };
+// Compact records of the LDS collapse (collapse_lds.hip; single GPU, one 32-base word per plane): level 2 turns the
+// pack kernel's uint4 records into 12 bytes -- two key words + the read index -- which the dedupe then reads.
+//   squeeze 1: the "ACGNT" code table (A 0, C 1, G 2, N 3, T 4): planes (p0, p1, p2) -> (p0 | p2, p1 | p2), a
+//              bijection on N-free keys; a key with an N (p0 & p1 != 0) leaves level 2 as the uint4 it is, through
+//              one of the side slabs (SideSlabs), and is collapsed apart (launch_side_collapse)
+//   squeeze 2: two planes: the record's two words as they are, no side path
+struct Rec12 {
+    uint32_t a, b, id;
+};
+__device__ __forceinline__ uint32_t fqd_hash_rec12(uint32_t a, uint32_t b)
+{
+    uint32_t h = (a ^ 0x9E3779B9u) * 0x9E3779B1u;
+    h ^= h >> 15;
+    h = (h ^ b) * 0x85EBCA6Bu;
+    return fqd_mix32(h);
+}
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
                        uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, const uint8_t *lut_host,
                        uint32_t *recs, uint32_t *lens, uint32_t *hashes, uint32_t *owners, OwnerRule rule,
@@ -312,6 +328,37 @@ hipError_t launch_bucket_compact(const uint32_t *bucket_start, const uint32_t *u
                                  const uint32_t *tmp_rec, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                  IdSource read_ids, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
                                  hipStream_t st, SegHashOut seg_hashes = SegHashOut());
+// the same three steps with Rec12 items: level 2 over the pack kernel's slabs (uint4 in, Rec12 out), dedupe (tmp
+// rows are one uint4: a, b, count, first index), compaction behind the *side_unique keys that
+// launch_side_collapse put at the head of the unique table
+struct SideSlabs {
+    uint4 *recs = nullptr;         // n_slabs * cap records
+    uint32_t *cursor = nullptr;    // cursor[s] starts at s * cap (launch_slab_starts)
+    uint32_t n_slabs = 0, cap = 0; // n_slabs: a power of two
+    uint32_t *overflow = nullptr;  // bit 16: a side slab was full
+};
+hipError_t launch_part_scatter12(const uint32_t *in /* uint4 records */, uint32_t squeeze, SideSlabs side,
+                                 const uint32_t *seg_start, const uint32_t *tile_start, uint32_t n_seg,
+                                 uint32_t max_tiles, uint32_t shift, uint32_t n_bins, uint32_t *cursor, Rec12 *out,
+                                 hipStream_t st, uint32_t slab_cap, uint32_t *slab_overflow, const uint32_t *seg_end,
+                                 uint32_t seg_shift);
+uint32_t part_tile_size12();
+hipError_t launch_bucket_dedupe12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                  uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
+                                  uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);
+hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
+                                   const uint32_t *tmp_rec, uint32_t squeeze, const uint32_t *side_unique,
+                                   uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, hipStream_t st,
+                                   SegHashOut seg_hashes = SegHashOut());
+// the keys of the side slabs (few: the reads with an N) collapsed through a hash table in global memory and
+// written to the head of the unique table; table: side_table_words(table_slots) words (table_slots a power of
+// two), cleared here; block_counts = table + 3 * table_slots
+uint32_t side_table_words(uint32_t table_slots);
+hipError_t launch_side_collapse(const uint4 *side, const uint32_t *cursor /* of the subs side slabs */,
+                                uint32_t first_part /* the cursors started at (first_part + sub) * cap */, uint32_t subs, uint32_t cap,
+                                const uint32_t *weights, uint32_t *table, uint32_t table_slots, uint32_t *block_counts,
+                                uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, uint32_t *side_unique,
+                                uint32_t *overflow, hipStream_t st);
 
 // edges.hip
 hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t nseg,

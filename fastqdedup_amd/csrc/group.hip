@@ -27,6 +27,8 @@ constexpr uint32_t GP_ECAP = 1024;      // edges buffered per block of the verif
 struct PairPolicy {
     using Item = uint2;
     static constexpr uint32_t EPT = 16;         // 4096-pair tiles
+    static constexpr bool MAY_SKIP = false;
+    static __device__ __forceinline__ bool skip(const uint2 &) { return false; }
     struct Source {
         const uint32_t *hashes;   // level 1
         const uint2 *in;          // level 2

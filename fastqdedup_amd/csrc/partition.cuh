@@ -18,6 +18,7 @@
 //   template <bool LEVEL1> static __device__ uint32_t key(const Source &, uint32_t i);          // histogram pass
 //   template <bool LEVEL1> static __device__ uint32_t load(const Source &, uint32_t i, Item &); // scatter pass, returns the key
 //   static __device__ uint32_t segment_tag(const Source &, uint32_t segment);  static __device__ void apply_tag(Item &, uint32_t tag);
+//   static constexpr bool MAY_SKIP;  static __device__ bool skip(const Item &);   // scatter pass: an item load() has disposed of otherwise
 #pragma once
 #include "fqd_internal.h"
 
@@ -150,7 +151,7 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
 #pragma unroll
     for (uint32_t e = 0; e < EPT; e++) {
         bin[e] = 0xFFFFFFFFu;
-        if (lo + e * THREADS + tid < hi) {
+        if (lo + e * THREADS + tid < hi && !(Policy::MAY_SKIP && Policy::skip(v[e]))) {
             bin[e] = (h[e] >> shift) & (n_bins - 1);
             rank[e] = atomicAdd(&s_hist[bin[e]], 1u);   // position inside the tile's share of the bin
         }
@@ -175,6 +176,9 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
     uint32_t run = incl - mine;
     for (uint32_t wv = 0; wv < wave; wv++)
         run += s_wave[wv];
+    uint32_t staged = 0;                                  // items of the tile that go out (all, unless the Policy skips some)
+    for (uint32_t wv = 0; wv < THREADS / 64; wv++)
+        staged += s_wave[wv];
     for (uint32_t k = 0; k < bpt; k++) {
         const uint32_t b = tid * bpt + k;
         if (b < n_bins) {
@@ -203,7 +207,7 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
             s_stage_bin[p] = (uint16_t)bin[e];
         }
     __syncthreads();
-    const uint32_t count = hi - lo;
+    const uint32_t count = Policy::MAY_SKIP ? staged : hi - lo;
 #pragma unroll
     for (uint32_t e = 0; e < EPT; e++) {
         const uint32_t p = e * THREADS + tid;

@@ -394,6 +394,8 @@ int fqd_stage_times(fqd_ctx *ctx, float *ms /* FQD_T_COUNT */, uint32_t *launche
 #define FQD_K_GROUP_SCATTER 15
 #define FQD_K_VERIFY        16   /* verification of the candidate pairs of a grouped search pass */
 #define FQD_K_KEPT_FLAGS    17   /* verdict per unique key + the byte map of kept first-holder ids */
+#define FQD_K_PART_SCATTER12 18  /* level 2 and the dedupe of the compact (12-byte) records of fqd_cluster_keys */
+#define FQD_K_DEDUPE12      19
 #define FQD_K_COUNT         20
 int fqd_kernel_times(fqd_ctx *ctx, float *ms /* FQD_K_COUNT */, uint32_t *launches /* FQD_K_COUNT */,
                      int reset);

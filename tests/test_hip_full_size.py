@@ -58,7 +58,8 @@ def full_size(oracle):
 def test_timed_configuration_matches_oracle_at_full_size(full_size, name, monkeypatch):
     F, ctx, jobs = full_size
     for var in ("FQD_COLLAPSE", "FQD_NO_FUSED_PACK", "FQD_FUSED_MIN_READS", "FQD_EDGES", "FQD_LDS_NO_SLABS",
-                "FQD_GROUP_NO_SLABS", "FQD_KEPT_BY_MAP", "FQD_KEPT_BY_SORT", "FQD_DIRECTIONAL_ROUNDS"):
+                "FQD_GROUP_NO_SLABS", "FQD_KEPT_BY_MAP", "FQD_KEPT_BY_SORT", "FQD_DIRECTIONAL_ROUNDS",
+                "FQD_NO_COMPACT_RECORDS"):
         monkeypatch.delenv(var, raising=False)       # the switches bench.py runs with: none
     n, L, umi, seed, d, method = CONFIGS[name]
     dev, run = jobs[name]
@@ -67,9 +68,11 @@ def test_timed_configuration_matches_oracle_at_full_size(full_size, name, monkey
     assert np.array_equal(got.kept_read_ids, again.kept_read_ids)      # a warm context answers the same
     times = ctx.kernel_times(reset=True)
     if name == "config3":
-        # the route bench.py times: pack fused with level 1 (no level-1 scatter launch), LDS dedupe
+        # the route bench.py times: pack fused with level 1 (no level-1 scatter launch), 12-byte records through
+        # level 2 and the LDS dedupe (the keys with an N -- 160 K of 50 M reads -- through the side path)
         assert times["pack_kernel"][1] and not times["part_scatter_kernel<1>"][1], times
-        assert times["part_scatter_kernel<2>"][1] and times["bucket_dedupe_kernel"][1], times
+        assert times["part_scatter12_kernel"][1] and times["bucket_dedupe12_kernel"][1], times
+        assert not times["part_scatter_kernel<2>"][1] and not times["bucket_dedupe_kernel"][1], times
     want = run.result()
     assert got.n_reads == n
     assert got.n_unique == want["n_unique"]

@@ -170,7 +170,8 @@ def test_lds_collapse_slab_overflow_retries_exactly(F, oracle):
     assert plain.n_unique > 0
 
 
-@pytest.mark.parametrize("case", ["plain", "weights", "foreign_byte", "crowded_part", "len20"])
+@pytest.mark.parametrize("case", ["plain", "weights", "foreign_byte", "crowded_part", "len20", "uint4_records",
+                                  "many_n", "n_copies", "acgt_two_planes", "acgt_weights"])
 def test_fused_pack_collapse_matches_oracle(F, oracle, monkeypatch, case):
     """cluster_keys is ONE C call (fqd_cluster_keys); for short fixed-length keys the pack kernel
     then partitions its records straight into the collapse (no packed reads in read order). Same
@@ -180,11 +181,23 @@ def test_fused_pack_collapse_matches_oracle(F, oracle, monkeypatch, case):
     from fastqdedup_amd.synth import fixed_offsets, synth_keys
     monkeypatch.setenv("FQD_FUSED_MIN_READS", "100000")
     n, L = 300_000, (20 if case == "len20" else 32)
-    keys = synth_keys(n, L, L, 91, sub_rate=3e-3, n_rate=2e-4)
+    # the records travel as 12 bytes (two key words + read index), keys with an N as uint4 through side slabs
+    # and a hash table of their own: "uint4_records" pins the older format, "many_n" overfills the side slabs
+    # (uint4 records from then on), "n_copies" gives the side path duplicates to count, "acgt_*": a two-plane
+    # alphabet needs no side path
+    if case == "uint4_records":
+        monkeypatch.setenv("FQD_NO_COMPACT_RECORDS", "1")
+    two_planes = case.startswith("acgt")
+    keys = synth_keys(n, L, L, 91, sub_rate=3e-3, n_rate=0 if two_planes else 2e-2 if case == "many_n" else 2e-4)
     rng = np.random.default_rng(4)
     weights = None
-    if case == "weights":
+    if case in ("weights", "acgt_weights"):
         weights = rng.choice(np.array([0, 1, 1, 1], dtype=np.uint32), size=n)
+    if case == "n_copies":
+        src = rng.choice(n, size=400, replace=False)
+        keys[src, rng.integers(0, L, size=400)] = ord("N")
+        for k in range(5):                      # five more holders of each of those keys
+            keys[rng.choice(n, size=400, replace=False)] = keys[src]
     if case == "foreign_byte":
         keys[rng.choice(n, size=50, replace=False), 7] = ord("R")
     if case == "crowded_part":
@@ -194,15 +207,25 @@ def test_fused_pack_collapse_matches_oracle(F, oracle, monkeypatch, case):
     raw = np.ascontiguousarray(keys).reshape(-1)
     want = oracle.dedup(raw, fixed_offsets(n, L), weights=weights, max_distance=1, method="directional")
     ctx = F.Context(0)
-    for job in range(2):        # the second job runs on a context that has learnt (fused_off / slab_off)
+    if two_planes:
+        present = np.zeros(128, dtype=np.uint8)
+        present[[ord(ch) for ch in "ACGT"]] = 1
+        ctx.configure(present, L, False)
+    for job in range(2):        # the second job runs on a context that has learnt (fused_off / slab_off / compact_off)
         ctx.kernel_times(reset=True)
         got = F.cluster_keys(raw, key_len=L, weights=weights, max_distance=1, method="directional", context=ctx)
         kt = ctx.kernel_times(reset=True)
         # which way in: the plain level-1 scatter runs only when the fused attempt was given up
-        fused_only = case in ("plain", "weights", "len20")
+        fused_only = case not in ("foreign_byte", "crowded_part")
         assert kt["part_scatter_kernel<1>"][1] == (0 if fused_only else 1)
-        assert kt["pack_kernel"][1] == (1 if fused_only or (case == "crowded_part" and job == 1) else
+        assert kt["pack_kernel"][1] == (2 if case == "many_n" and job == 0 else
+                                        1 if fused_only or (case == "crowded_part" and job == 1) else
                                         3 if case == "foreign_byte" else 2)
+        # ... and which records: 12-byte ones unless pinned or given up
+        if fused_only:
+            compact = case != "uint4_records" and not (case == "many_n" and job == 1)
+            assert kt["part_scatter12_kernel"][1] == (1 if compact else 0)
+            assert kt["part_scatter_kernel<2>"][1] == (0 if compact and case != "many_n" else 1)
         assert got.n_counted == (n if weights is None else int(weights.sum()))
         assert (got.n_unique, got.n_clusters) == (want["n_unique"], want["n_clusters"])
         assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
