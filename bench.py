@@ -371,7 +371,7 @@ def main():
         alg["bucket_compact_kernel"] = U_own * (12 + rec + rec + 12)
     if kern.get("bucket_compact_kernel", (0, 0))[1] and not kern.get("segment_hashes_kernel", (0, 0))[1]:
         alg["bucket_compact_kernel"] += U_own * 4 * nseg      # the compaction wrote the search's segment hashes too
-    if kern.get("gp_hist_kernel", (0, 0))[1]:
+    if kern.get("gp_scatter_kernel", (0, 0))[1]:
         # the sort-free search pass ran: the FQD_K_PAIRS slot timed grouped_candidates_kernel
         # ((hash, uid) items in, candidate pairs out), not bucket_pairs_kernel
         kern["grouped_candidates_kernel"] = kern.pop("bucket_pairs_kernel")

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfqdedup_hip.so")
 SOURCES = ["api.hip", "api_search.hip", "api_graph.hip", "api_exchange.hip", "api_trie.hip", "trieorder.hip", "prims.hip", "pack.hip", "collapse.hip", "collapse_lds.hip", "collapse_pairs.hip", "edges.hip", "group.hip", "edit.hip", "exchange.hip", "graph.hip", "quality.hip", "synth.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("FQD_EXTRA_FLAGS", "").split()
 
 
 def _stale(target: str, deps) -> bool:

@@ -217,6 +217,11 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
     uint32_t *f_seg_start = fused ? c->ld_seg.as<uint32_t>() : nullptr;
     uint32_t *f_seg_end = fused ? f_seg_start + (f_parts + 4) : nullptr;
     uint32_t *f_tiles = fused ? f_seg_end + (f_parts + 4) : nullptr;
+    // the segment of every level-2 tile, behind the three tables when the caller left room for tiles1 + parts + 4
+    // more words (fqd_cluster_keys does; slabs received from other ranks: a search per tile instead)
+    uint32_t *f_tile_seg = fused && c->ld_seg.cap >= ((size_t)3 * (f_parts + 4) + tiles1 + f_parts + 4) * 4 &&
+                                   !getenv("FQD_NO_TILE_SEG")
+                               ? f_tiles + (f_parts + 4) : nullptr;
     // compact records, squeeze 1: the side slabs' cursors (and their starts, unused) live behind the hash table
     fqd::SideSlabs side;
     if (compact == 1) {
@@ -229,6 +234,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
     }
     const uint32_t *parted = c->ld_part.as<uint32_t>();
     uint32_t U32 = 0, overflow = 0, early_nseg = 0;
+    bool side_pending = false;
     for (;;) {
         const uint32_t *bucket_end = nullptr;
         if (!fused)          // (the fused pack has already run and may have raised bit 4)
@@ -238,7 +244,8 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         } else {
             // ---- level 2: every part into 2^B2 buckets by the next B2 hash bits
             if (fused)     // (the pack kernel left seg_start / seg_end = cursors there; received slabs: the caller did)
-                HIP_TRY(c, fqd::launch_slab_tile_starts(f_seg_start, f_seg_end, f_parts, f_tiles, c->st));
+                HIP_TRY(c, fqd::launch_slab_tile_starts(f_seg_start, f_seg_end, f_parts, f_tiles, c->st, compact != 0,
+                                                        f_tile_seg));
             else
                 HIP_TRY(c, fqd::launch_tile_starts(start1, bins1, tiles2_d, c->st));
             if (slab_cap) {
@@ -260,20 +267,27 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 KTIME(c, FQD_K_PART_SCATTER12, fqd::launch_part_scatter12(
                           c->ld_part.as<uint32_t>(), compact, side, f_seg_start, f_tiles, f_parts, tiles1 + f_parts,
                           32 - B, bins2, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<fqd::Rec12>(), c->st, slab_cap,
-                          c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end, fused->sub_bits));
-                // the keys with an N: collapsed apart, to the head of the unique table (few: a table in global memory)
-                if (compact == 1)
+                          c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end, fused->sub_bits, f_tile_seg));
+                // the keys with an N: collapsed apart, to the head of the unique table (few: a table in global
+                // memory) -- on the context's second stream, beside the dedupe of the other keys: four short
+                // kernels (0.05 ms in a row) that the compaction, not the dedupe, waits for
+                if (compact == 1) {
+                    HIP_TRY(c, hipEventRecord(c->ev_fork, c->st));
+                    HIP_TRY(c, hipStreamWaitEvent(c->st_side, c->ev_fork, 0));
                     HIP_TRY(c, fqd::launch_side_collapse(
                                    side.recs, side.cursor, 0, side.n_slabs, side.cap, d_w, c->ld_side_table.as<uint32_t>(),
                                    fused->side_slots, c->ld_side_table.as<uint32_t>() + 3 * (size_t)fused->side_slots,
                                    c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(),
-                                   c->d_ctr32.as<uint32_t>() + C_SIDE, c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+                                   c->d_ctr32.as<uint32_t>() + C_SIDE, c->d_ctr32.as<uint32_t>() + C_BAD, c->st_side));
+                    HIP_TRY(c, hipEventRecord(c->ev_join, c->st_side));
+                    side_pending = true;
+                }
             } else if (fused)
                 KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(
                           false, nullptr, c->ld_part.as<uint32_t>(), f_seg_start, f_tiles, f_parts, tiles1 + f_parts,
                           32 - B, bins2, kw, sh.max_len, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<uint32_t>(), c->st,
                           fused->stamp_div ? d_ids : IdSource(), slab_cap, c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end,
-                          fused->sub_bits, fused->part_mask, fused->stamp_div));
+                          fused->sub_bits, fused->part_mask, fused->stamp_div, f_tile_seg));
             else
                 KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(
                           false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1, max_tiles2, 32 - B, bins2,
@@ -292,6 +306,10 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                                              c->ld_tmp_first.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
                                              c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
         FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
+        if (side_pending) {                // (the read-back below takes the side path's count and flag too)
+            HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join, 0));
+            side_pending = false;
+        }
         // One read-back: the unique count, the pack kernel's foreign-byte flag and every overflow flag
         // (bit 4: a level-1 slab of the fused pack, bit 2: a level-2 slab, bit 1: a bucket's LDS
         // table). The compaction is queued BEHIND the read-back and before the host waits for it: it
@@ -512,6 +530,9 @@ int fqd_create(int device, fqd_ctx **out)
               c->d_lut.reserve(256) == hipSuccess &&
               c->d_stats.reserve(FQD_STAT_SLOTS * sizeof(fqd::PairStats)) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_rb, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->st_side, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     if (ok && hipHostMalloc(&c->h_pin, 256, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         c->h_pin = nullptr;            // read-backs then go through pageable memory
@@ -548,11 +569,17 @@ void fqd_destroy(fqd_ctx *c)
                       &c->t_mark_incl, &c->t_stats, &c->t_seed, &c->t_heads, &c->t_heads_incl, &c->t_member_uids,
                       &c->t_offsets, &c->store_alive, &c->st_recs, &c->st_lens, &c->st_counts, &c->st_first,
                       &c->st_comb_recs, &c->st_comb_lens, &c->st_comb_w, &c->st_comb_ids, &c->eg_tables, &c->eg_per_key,
-                      &c->eg_per_key_incl};
+                      &c->eg_per_key_incl, &c->ld_side, &c->ld_side_table};
     for (DevBuf *b : bufs)
         b->release();
     if (c->ev_rb)
         (void)hipEventDestroy(c->ev_rb);
+    if (c->ev_fork)
+        (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join)
+        (void)hipEventDestroy(c->ev_join);
+    if (c->st_side)
+        (void)hipStreamDestroy(c->st_side);
     if (c->h_pin)
         (void)hipHostFree(c->h_pin);
     if (c->h_pin_big)
@@ -942,7 +969,12 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     // 256 level-1 bins x 32 sub-parts: tile t adds to sub-part t % 32 of its bins. (Measured at 50 M
     // reads: up to 16 sub-parts per bin the tiles queue on the part cursors and the kernel takes
     // 1.0 ms; from 32 on, 0.55-0.6 ms.)
-    const uint32_t sub_bits = 5, parts = 256u << sub_bits;
+    uint32_t l1_bits = 8, sub_bits = 5;
+    if (const char *e = getenv("FQD_EXP_L1_BITS"))
+        l1_bits = (uint32_t)atoi(e);
+    if (const char *e = getenv("FQD_EXP_SUB_BITS"))
+        sub_bits = (uint32_t)atoi(e);
+    const uint32_t parts = (1u << l1_bits) << sub_bits;
     const uint32_t cap1 = (uint32_t)(((n / parts) * 5 / 4 + 256 + 3) & ~3ull);
     if ((uint64_t)parts * cap1 + n >= 0xFFFFFF00ull)
         return FQD_OK;
@@ -976,12 +1008,13 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     StageTimer pack_timer(c, FQD_T_PACK);
     FQD_TRY(to_device(c, bytes, (size_t)n_bytes, mem, c->in_bytes, &d_bytes));
     HIP_TRY(c, c->ld_part.reserve((size_t)parts * cap1 * 16 + 16));
-    HIP_TRY(c, c->ld_seg.reserve((size_t)3 * (parts + 4) * 4));
+    // seg_start | cursor = seg_end | tile_start (parts + 4 words each) | the segment of every level-2 tile
+    HIP_TRY(c, c->ld_seg.reserve(((size_t)3 * (parts + 4) + n / 2048 + 1 + parts + 4) * 4));
     uint32_t *seg_start = c->ld_seg.as<uint32_t>(), *cursor = seg_start + (parts + 4);
     FQD_TRY(zero_ctr32(c, 0, C_N32));
     HIP_TRY(c, fqd::launch_slab_starts(parts, cap1, seg_start, cursor, c->st));
     const fqd::PackScatter fs{cursor, reinterpret_cast<uint4 *>(c->ld_part.p), c->d_ctr32.as<uint32_t>() + C_BAD,
-                              32 - 8, 256, 1u << sub_bits, cap1};
+                              32 - l1_bits, 1u << l1_bits, 1u << sub_bits, cap1};
     if (compact == 1) {
         HIP_TRY(c, c->ld_side.reserve((size_t)side_slabs * side_cap * 16 + 16));
         HIP_TRY(c, c->ld_side_table.reserve(((size_t)fqd::side_table_words(side_slots) + 2 * side_slabs + 4) * 4 + 16));
@@ -1008,6 +1041,8 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     const uint32_t *d_w;
     FQD_TRY(to_device(c, weights, (size_t)n, aux_mem, c->in_weights, &d_w));
     FusedLevel1 f{parts, sub_bits, B};
+    f.level1_bits = l1_bits;
+    f.part_mask = (1u << l1_bits) - 1;
     f.compact = compact;
     f.side_slabs = side_slabs;
     f.side_cap = side_cap;

@@ -162,6 +162,8 @@ struct fqd_ctx {
 
     // stage timers: one event pair per stage, recorded while the work is queued and resolved when
     // fqd_stage_times asks (a stage end is NOT a host synchronisation point)
+    hipStream_t st_side = nullptr; // the side path of the compact collapse runs here, beside the dedupe (ev_fork / ev_join order it)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_rb = nullptr;    // marks queued read-backs: the host can wait for THEM while later work runs
     void *h_pin = nullptr;         // 256 pinned host bytes: where counter read-backs land
     void *h_pin_big = nullptr;     // 1 MiB of pinned host memory for small tables (allocated on first use)

@@ -412,6 +412,8 @@ int fqd_edge_labels(fqd_ctx *c, const uint32_t *uv, uint64_t E, uint64_t n_nodes
         return fail(c, FQD_E_VALUE, "fqd_edge_labels works on device buffers");
     if (n_nodes >= 0xFFFFFFF0ull)
         return fail(c, FQD_E_VALUE, "at most 2^32-16 nodes");
+    if ((uintptr_t)uv & 7u)
+        return fail(c, FQD_E_VALUE, "the edge list must be 8-byte aligned");
     FQD_TRY(zero_ctr32(c, C_BAD));
     HIP_TRY(c, fqd::launch_check_indices(uv, 2 * E, n_nodes, c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
     uint32_t bad = 0;

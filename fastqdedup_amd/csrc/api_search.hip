@@ -255,19 +255,10 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
     unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(small + 4096);
     HIP_TRY(c, fqd::launch_group_pass_init(seg1, tiles1_d, (uint32_t)N, tiles1, cand_ctr, fqd::group_cand_lists() * 8,
                                            c->st));
-    // ---- level 1: (bin x tile) count matrix, scan, placement without atomics
-    const size_t matrix = (size_t)bins1 * tiles1;
-    HIP_TRY(c, c->ld_matrix.reserve(matrix * 4 + 16));
-    HIP_TRY(c, c->ld_matrix_incl.reserve(matrix * 4 + 16));
-    KTIME(c, FQD_K_GROUP_HIST, fqd::launch_group_hist(true, keys, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1, bins1,
-                                                      c->ld_matrix.as<uint32_t>(), c->st));
-    FQD_TRY(scan_u32(c, c->ld_matrix.as<uint32_t>(), c->ld_matrix_incl.as<uint32_t>(), matrix));
-    HIP_TRY(c, fqd::launch_group_matrix_starts(c->ld_matrix_incl.as<uint32_t>(), bins1, tiles1, start1, c->st));
-    KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(true, keys, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1,
-                                                            bins1, c->ld_matrix_incl.as<uint32_t>(),
-                                                            c->gp_a.as<uint32_t>(), c->st, 0, nullptr, values));
-    const uint32_t *items = c->gp_a.as<uint32_t>();
-    const uint32_t *bucket_end = nullptr;
+    // ---- level 1. Many items (>= 1024 tiles), slabs allowed and a level 2 to follow: slab mode as in the fused
+    // pack -- 32 sub-parts per bin (tile t feeds sub-part t % 32), one atomic per (tile, bin) on the part's cursor,
+    // no histogram pass over the keys, no count matrix (0.04 ms + a scan at config 3); an overfull part raises
+    // C64_SLAB like an overfull level-2 slab. Else: (bin x tile) count matrix, scan, placement without atomics.
     // level 2 in slab mode (as the collapse): no histogram pass; an overfull slab is flagged in C64_SLAB
     uint32_t slab_cap = 0;
     if (B2 && slabs) {
@@ -275,6 +266,46 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
         if ((uint64_t)slab_cap * n_buckets + N >= 0xFFFFFF00ull)
             slab_cap = 0;
     }
+    uint32_t l1_subs = 0, cap1 = 0, parts = 0;
+    uint32_t l1_min_tiles = 1024;
+    if (const char *e = getenv("FQD_GROUP_L1_SLABS_MIN_TILES"))   // tests: small jobs through the slab mode; 0: never
+        l1_min_tiles = (uint32_t)strtoul(e, nullptr, 10);
+    if (slab_cap && l1_min_tiles && tiles1 >= l1_min_tiles && bins1 <= 256) {
+        l1_subs = 32;
+        parts = bins1 * l1_subs;
+        cap1 = (uint32_t)(((N / parts) * 5 / 4 + 256 + 3) & ~3ull);
+        if ((uint64_t)parts * cap1 + N >= 0xFFFFFF00ull)
+            l1_subs = 0;
+    }
+    // level-1 slab tables: seg_start (parts + 1) | cursor = seg_end (parts) | tile_start (parts + 1), 4 words apart
+    uint32_t *l1_start = nullptr, *l1_cursor = nullptr, *l1_tiles = nullptr, *l1_tile_seg = nullptr;
+    if (l1_subs) {
+        HIP_TRY(c, c->gp_a.reserve((size_t)parts * cap1 * 8 + 16));
+        HIP_TRY(c, c->ld_seg.reserve(((size_t)3 * (parts + 4) + tiles1 + parts + 4) * 4));
+        l1_start = c->ld_seg.as<uint32_t>();
+        l1_cursor = l1_start + (parts + 4);
+        l1_tiles = l1_cursor + (parts + 4);
+        l1_tile_seg = l1_tiles + (parts + 4);             // the segment of every level-2 tile (<= tiles1 + parts tiles)
+        if (getenv("FQD_NO_TILE_SEG"))
+            l1_tile_seg = nullptr;
+        HIP_TRY(c, fqd::launch_group_slab_starts(parts, cap1, l1_start, l1_cursor, c->st));
+        KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(
+                  true, keys, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1, bins1, l1_cursor, c->gp_a.as<uint32_t>(), c->st,
+                  cap1, reinterpret_cast<uint32_t *>(c->d_ctr64.as<unsigned long long>() + C64_SLAB), values, l1_subs));
+    } else {
+        const size_t matrix = (size_t)bins1 * tiles1;
+        HIP_TRY(c, c->ld_matrix.reserve(matrix * 4 + 16));
+        HIP_TRY(c, c->ld_matrix_incl.reserve(matrix * 4 + 16));
+        KTIME(c, FQD_K_GROUP_HIST, fqd::launch_group_hist(true, keys, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1, bins1,
+                                                          c->ld_matrix.as<uint32_t>(), c->st));
+        FQD_TRY(scan_u32(c, c->ld_matrix.as<uint32_t>(), c->ld_matrix_incl.as<uint32_t>(), matrix));
+        HIP_TRY(c, fqd::launch_group_matrix_starts(c->ld_matrix_incl.as<uint32_t>(), bins1, tiles1, start1, c->st));
+        KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(true, keys, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1,
+                                                                bins1, c->ld_matrix_incl.as<uint32_t>(),
+                                                                c->gp_a.as<uint32_t>(), c->st, 0, nullptr, values));
+    }
+    const uint32_t *items = c->gp_a.as<uint32_t>();
+    const uint32_t *bucket_end = nullptr;
     if (B2 == 0) {
         HIP_TRY(c, hipMemcpyAsync(c->ld_start.p, start1, ((size_t)bins1 + 1) * 4, hipMemcpyDeviceToDevice, c->st));
     } else {
@@ -283,7 +314,10 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
         HIP_TRY(c, c->ld_hist.reserve((size_t)n_buckets * 4 + 16));
         HIP_TRY(c, c->ld_hist_incl.reserve((size_t)n_buckets * 4 + 16));
         HIP_TRY(c, c->ld_cursor.reserve((size_t)n_buckets * 4 + 16));
-        HIP_TRY(c, fqd::launch_group_tile_starts(start1, bins1, tiles2_d, c->st));
+        if (l1_subs)
+            HIP_TRY(c, fqd::launch_group_slab_tile_starts(l1_start, l1_cursor, parts, l1_tiles, c->st, l1_tile_seg));
+        else
+            HIP_TRY(c, fqd::launch_group_tile_starts(start1, bins1, tiles2_d, c->st));
         if (slab_cap) {
             HIP_TRY(c, fqd::launch_group_slab_starts(n_buckets, slab_cap, c->ld_start.as<uint32_t>(),
                                                      c->ld_cursor.as<uint32_t>(), c->st));
@@ -296,6 +330,13 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
             HIP_TRY(c, fqd::launch_group_bucket_starts(c->ld_hist_incl.as<uint32_t>(), n_buckets,
                                                        c->ld_start.as<uint32_t>(), c->ld_cursor.as<uint32_t>(), c->st));
         }
+        if (l1_subs)
+            KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(
+                      false, nullptr, c->gp_a.as<uint32_t>(), l1_start, l1_tiles, parts, tiles1 + parts, 32 - B, bins2,
+                      c->ld_cursor.as<uint32_t>(), c->gp_b.as<uint32_t>(), c->st, slab_cap,
+                      reinterpret_cast<uint32_t *>(c->d_ctr64.as<unsigned long long>() + C64_SLAB), nullptr, 0, l1_cursor,
+                      bins1 - 1, l1_tile_seg));
+        else
         KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(
                   false, nullptr, c->gp_a.as<uint32_t>(), start1, tiles2_d, bins1, max_tiles2, 32 - B, bins2,
                   c->ld_cursor.as<uint32_t>(), c->gp_b.as<uint32_t>(), c->st, slab_cap,

@@ -24,6 +24,16 @@
 #include "fqd_internal.h"
 #include "partition.cuh"
 
+// Items per thread of part_scatter12_kernel and the rounds its tile is staged in (partition.cuh ROUNDS). Measured at
+// config 3: 8 / 1 (2048-record tiles) 0.42-0.45 ms; 16 / 2 (4096-record tiles, half the cursor atomics, 16-record
+// runs, the same LDS) 0.49 ms -- 113 instead of 56 VGPRs cost more than the longer runs give.
+#ifndef FQD_SCATTER12_EPT
+#define FQD_SCATTER12_EPT 8
+#endif
+#ifndef FQD_SCATTER12_ROUNDS
+#define FQD_SCATTER12_ROUNDS 1
+#endif
+
 namespace {
 
 constexpr uint32_t DD_SLOTS = 1024;        // LDS table slots per bucket (power of two)
@@ -39,6 +49,7 @@ constexpr uint32_t DD_EMPTY = 0xFFFFFFFFu;
 struct RecordPolicy {
     using Item = uint4;
     static constexpr uint32_t EPT = 8;          // 2048-record tiles
+    static constexpr uint32_t ROUNDS = 1;
     static constexpr bool MAY_SKIP = false;
     static __device__ __forceinline__ bool skip(const uint4 &) { return false; }
     struct Source {
@@ -109,10 +120,12 @@ __global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter_kernel(Re
                                                                               uint32_t slab_cap,
                                                                               uint32_t *__restrict__ slab_overflow,
                                                                               const uint32_t *__restrict__ seg_end,
-                                                                              uint32_t seg_shift, uint32_t seg_mask)
+                                                                              uint32_t seg_shift, uint32_t seg_mask,
+                                                                              const uint32_t *__restrict__ tile_seg)
 {
     fqd_partition::scatter_body<RecordPolicy, LEVEL1, MAXB>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
-                                                            slab_cap, slab_overflow, seg_end, seg_shift, seg_mask);
+                                                            slab_cap, slab_overflow, seg_end, seg_shift, seg_mask, 0,
+                                                            tile_seg);
 }
 
 // slabs received from n_senders ranks, sender by sender: segment s = sender * ppo + j holds the
@@ -134,10 +147,11 @@ __global__ void owner_slab_bounds_kernel(const uint32_t *__restrict__ cursors, u
 
 __global__ __launch_bounds__(1024) void slab_tile_starts_kernel(const uint32_t *__restrict__ seg_start,
                                                                 const uint32_t *__restrict__ seg_end, uint32_t n_seg,
-                                                                uint32_t *__restrict__ tile_start)
+                                                                uint32_t *__restrict__ tile_start,
+                                                                uint32_t *__restrict__ tile_seg)
 {
     fqd_partition::slab_tile_starts_body<fqd_partition::THREADS * RecordPolicy::EPT>(seg_start, seg_end, n_seg,
-                                                                                     tile_start);
+                                                                                    tile_start, tile_seg);
 }
 
 // slab mode of level 2: bucket b owns slots [b * cap, (b + 1) * cap); its cursor starts there
@@ -379,7 +393,8 @@ __global__ void bucket_starts_kernel(const uint32_t *__restrict__ hist_incl, uin
 // level 2 writes 8-record runs.)
 struct CompactPolicy {
     using Item = fqd::Rec12;
-    static constexpr uint32_t EPT = 8;
+    static constexpr uint32_t EPT = FQD_SCATTER12_EPT;
+    static constexpr uint32_t ROUNDS = FQD_SCATTER12_ROUNDS;
     static constexpr bool MAY_SKIP = true;
     struct Source {
         const uint4 *in;          // the pack kernel's records: planes + read index
@@ -394,23 +409,23 @@ struct CompactPolicy {
     static __device__ __forceinline__ uint32_t load(const Source &s, uint32_t i, fqd::Rec12 &v)
     {
         const uint4 r = s.in[i];
-        if (s.squeeze == 1) {
-            if (r.x & r.y) {
-                // a key with an N (few: one global atomic each, spread over the side slabs by workgroup)
-                const uint32_t slab = blockIdx.x & (s.side.n_slabs - 1);
-                const uint32_t pos = atomicAdd(&s.side.cursor[slab], 1u);
-                if (pos < (slab + 1) * s.side.cap)
-                    s.side.recs[pos] = r;
-                else
-                    atomicOr(s.side.overflow, 16u);
-                v = fqd::Rec12{0u, 0u, 0xFFFFFFFFu};
-                return 0u;
-            }
-            v = fqd::Rec12{r.x | r.z, r.y | r.z, r.w};
-        } else {
-            v = fqd::Rec12{r.x, r.y, r.w};
+        const bool squeeze = s.squeeze == 1;
+        const bool rare = squeeze && (r.x & r.y) != 0u;
+        if (rare) {
+            // a key with an N (few: one global atomic each, spread over the side slabs by workgroup)
+            const uint32_t slab = blockIdx.x & (s.side.n_slabs - 1);
+            const uint32_t pos = atomicAdd(&s.side.cursor[slab], 1u);
+            if (pos < (slab + 1) * s.side.cap)
+                s.side.recs[pos] = r;
+            else
+                atomicOr(s.side.overflow, 16u);
         }
-        return fqd::fqd_hash_rec12(v.a, v.b);
+        // (the item's words as selects, not as assignments on the two sides of the branch above: with 16 items
+        // per thread hipcc 7.2 merged those into "id = 0xFFFFFFFF" for every lane and the kernel skipped all items)
+        v.a = squeeze ? r.x | r.z : r.x;
+        v.b = squeeze ? r.y | r.z : r.y;
+        v.id = rare ? 0xFFFFFFFFu : r.w;
+        return rare ? 0u : fqd::fqd_hash_rec12(v.a, v.b);
     }
     template <bool LEVEL1>
     static __device__ __forceinline__ uint32_t key(const Source &s, uint32_t i)
@@ -420,14 +435,26 @@ struct CompactPolicy {
     }
 };
 
+// (the tiles of part_scatter12_kernel)
+__global__ __launch_bounds__(1024) void slab_tile_starts12_kernel(const uint32_t *__restrict__ seg_start,
+                                                                  const uint32_t *__restrict__ seg_end, uint32_t n_seg,
+                                                                  uint32_t *__restrict__ tile_start,
+                                                                  uint32_t *__restrict__ tile_seg)
+{
+    fqd_partition::slab_tile_starts_body<fqd_partition::THREADS * CompactPolicy::EPT>(seg_start, seg_end, n_seg,
+                                                                                     tile_start, tile_seg);
+}
+
 template <uint32_t MAXB>
 __global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter12_kernel(
     CompactPolicy::Source src, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ tile_start,
     uint32_t n_seg, uint32_t shift, uint32_t n_bins, uint32_t *__restrict__ cursor, fqd::Rec12 *__restrict__ out,
-    uint32_t slab_cap, uint32_t *__restrict__ slab_overflow, const uint32_t *__restrict__ seg_end, uint32_t seg_shift)
+    uint32_t slab_cap, uint32_t *__restrict__ slab_overflow, const uint32_t *__restrict__ seg_end, uint32_t seg_shift,
+    const uint32_t *__restrict__ tile_seg)
 {
     fqd_partition::scatter_body<CompactPolicy, false, MAXB>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
-                                                            slab_cap, slab_overflow, seg_end, seg_shift, 0xFFFFFFFFu);
+                                                            slab_cap, slab_overflow, seg_end, seg_shift, 0xFFFFFFFFu, 0,
+                                                            tile_seg);
 }
 
 __device__ __forceinline__ uint32_t rec12_tag(uint32_t a, uint32_t b)
@@ -450,6 +477,8 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
     __shared__ uint32_t s_wave_tot[DD_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
+    // (slab mode: requesting the first 1024 slots of the slab at once, before the bucket's end is known -- the
+    // start is b * slab_cap -- saves a round trip but reads a third more: 0.329 instead of 0.313 ms)
     const uint32_t lo = bucket_start[b];
     uint32_t hi = bucket_start[b + 1];
     if (bucket_end)
@@ -773,7 +802,8 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
                                const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
                                hipStream_t st, IdSource packed, uint32_t slab_cap, uint32_t *slab_overflow,
-                               const uint32_t *seg_end, uint32_t seg_shift, uint32_t seg_mask, uint32_t stamp_div)
+                               const uint32_t *seg_end, uint32_t seg_shift, uint32_t seg_mask, uint32_t stamp_div,
+                               const uint32_t *tile_seg)
 {
     if (n_bins > fqd_partition::MAX_BINS)
         return hipErrorInvalidValue;
@@ -783,7 +813,8 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
 #define FQD_SCATTER(L1, MB)                                                                                    \
     part_scatter_kernel<L1, MB><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, \
                                                                               shift, n_bins, cursor, out4, slab_cap, \
-                                                                              slab_overflow, seg_end, seg_shift, seg_mask)
+                                                                              slab_overflow, seg_end, seg_shift, seg_mask, \
+                                                                              tile_seg)
     if (n_bins <= 256) {
         if (level1) FQD_SCATTER(true, 256); else FQD_SCATTER(false, 256);
     } else {
@@ -826,9 +857,12 @@ hipError_t launch_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket
 }
 
 hipError_t launch_slab_tile_starts(const uint32_t *seg_start, const uint32_t *seg_end, uint32_t n_seg,
-                                   uint32_t *tile_start, hipStream_t st)
+                                   uint32_t *tile_start, hipStream_t st, bool tiles12, uint32_t *tile_seg)
 {
-    slab_tile_starts_kernel<<<1, 1024, 0, st>>>(seg_start, seg_end, n_seg, tile_start);
+    if (tiles12)
+        slab_tile_starts12_kernel<<<1, 1024, 0, st>>>(seg_start, seg_end, n_seg, tile_start, tile_seg);
+    else
+        slab_tile_starts_kernel<<<1, 1024, 0, st>>>(seg_start, seg_end, n_seg, tile_start, tile_seg);
     return hipGetLastError();
 }
 
@@ -848,7 +882,8 @@ uint32_t part_tile_size12() { return fqd_partition::THREADS * CompactPolicy::EPT
 hipError_t launch_part_scatter12(const uint32_t *in, uint32_t squeeze, SideSlabs side, const uint32_t *seg_start,
                                  const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                  uint32_t n_bins, uint32_t *cursor, Rec12 *out, hipStream_t st, uint32_t slab_cap,
-                                 uint32_t *slab_overflow, const uint32_t *seg_end, uint32_t seg_shift)
+                                 uint32_t *slab_overflow, const uint32_t *seg_end, uint32_t seg_shift,
+                                 const uint32_t *tile_seg)
 {
     if (n_bins > fqd_partition::MAX_BINS || (squeeze != 1 && squeeze != 2))
         return hipErrorInvalidValue;
@@ -858,10 +893,12 @@ hipError_t launch_part_scatter12(const uint32_t *in, uint32_t squeeze, SideSlabs
     const CompactPolicy::Source src{reinterpret_cast<const uint4 *>(in), squeeze, side};
     if (n_bins <= 256)
         part_scatter12_kernel<256><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
-            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift);
+            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift,
+            tile_seg);
     else
         part_scatter12_kernel<fqd_partition::MAX_BINS><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
-            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift);
+            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift,
+            tile_seg);
     return hipGetLastError();
 }
 

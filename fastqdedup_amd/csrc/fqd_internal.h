@@ -230,7 +230,8 @@ struct PackScatter {
     uint4 *out;            // n_bins * subs * cap records
     uint32_t *overflow;    // bit 4: some part's slab was full
     uint32_t shift, n_bins, subs, cap;
-    uint32_t tables_at;    // set by launch_pack: LDS word offset of the partition tables
+    uint32_t tables_at;    // set by launch_pack: LDS word offsets of the partition tables (off | base | wave | bin16)
+    uint32_t hist_at;      // ... and of the bin counts, which live across the workgroup's tiles
     // owner-major bins (multi-GPU): bin = owner * owner_hb + top log2(owner_hb) hash bits, owner by the
     // OwnerRule handed to launch_pack; n_bins = owner_parts * owner_hb. 0: plain hash bins.
     uint32_t owner_parts = 0, owner_hb = 0;
@@ -291,13 +292,15 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
                                hipStream_t st, IdSource packed = IdSource(), uint32_t slab_cap = 0,
                                uint32_t *slab_overflow = nullptr, const uint32_t *seg_end = nullptr,
-                               uint32_t seg_shift = 0, uint32_t seg_mask = 0xFFFFFFFFu, uint32_t stamp_div = 0);
+                               uint32_t seg_shift = 0, uint32_t seg_mask = 0xFFFFFFFFu, uint32_t stamp_div = 0,
+                               const uint32_t *tile_seg = nullptr);
 // slab segments of reads received from n_senders ranks (fqd_collapse_owner_slabs)
 hipError_t launch_owner_slab_bounds(const uint32_t *cursors, uint32_t n_senders, uint32_t parts_per_owner,
                                     uint32_t my_part, uint32_t cap, uint32_t *seg_start, uint32_t *seg_end,
                                     hipStream_t st);
 hipError_t launch_slab_tile_starts(const uint32_t *seg_start, const uint32_t *seg_end, uint32_t n_seg,
-                                   uint32_t *tile_start, hipStream_t st);
+                                   uint32_t *tile_start, hipStream_t st, bool tiles12 = false /* part_tile_size12() */,
+                                   uint32_t *tile_seg = nullptr /* out: the segment of every tile (scatter: no search) */);
 uint32_t part_tile_size();
 // bucket_compact_kernel may write the segment hashes of the search that follows (nseg = 0: no)
 struct SegHashOut {
@@ -341,7 +344,7 @@ hipError_t launch_part_scatter12(const uint32_t *in /* uint4 records */, uint32_
                                  const uint32_t *seg_start, const uint32_t *tile_start, uint32_t n_seg,
                                  uint32_t max_tiles, uint32_t shift, uint32_t n_bins, uint32_t *cursor, Rec12 *out,
                                  hipStream_t st, uint32_t slab_cap, uint32_t *slab_overflow, const uint32_t *seg_end,
-                                 uint32_t seg_shift);
+                                 uint32_t seg_shift, const uint32_t *tile_seg = nullptr);
 uint32_t part_tile_size12();
 hipError_t launch_bucket_dedupe12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                   uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
@@ -414,7 +417,11 @@ hipError_t launch_group_hist(bool level1, const uint32_t *hashes, const uint32_t
 hipError_t launch_group_scatter(bool level1, const uint32_t *hashes, const uint32_t *in, const uint32_t *seg_start,
                                 const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                 uint32_t n_bins, uint32_t *cursor, uint32_t *out, hipStream_t st, uint32_t slab_cap = 0,
-                                uint32_t *slab_overflow = nullptr, const uint32_t *values = nullptr);
+                                uint32_t *slab_overflow = nullptr, const uint32_t *values = nullptr, uint32_t l1_subs = 0,
+                                const uint32_t *seg_end = nullptr, uint32_t seg_mask = 0xFFFFFFFFu,
+                                const uint32_t *tile_seg = nullptr);
+hipError_t launch_group_slab_tile_starts(const uint32_t *seg_start, const uint32_t *seg_end, uint32_t n_seg,
+                                         uint32_t *tile_start, hipStream_t st, uint32_t *tile_seg = nullptr);
 hipError_t launch_group_tile_starts(const uint32_t *seg_start, uint32_t n_seg, uint32_t *tile_start, hipStream_t st);
 hipError_t launch_group_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                       hipStream_t st);

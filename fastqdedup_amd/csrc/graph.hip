@@ -74,8 +74,19 @@ __global__ void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ e
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool hooked = false;
     if (e < E) {
-        uint32_t a = edges[2 * e], b = edges[2 * e + 1];
-        for (;;) {
+        const uint2 uv = reinterpret_cast<const uint2 *>(edges)[e];
+        uint32_t a = uv.x, b = uv.y;
+        // the first parent of both ends in flight together (most ends are still their own roots: the two
+        // dependent round trips of find(a); find(b) become one)
+        const uint32_t pa = load_relaxed(&parent[a]), pb = load_relaxed(&parent[b]);
+        if (pa == a && pb == b && a != b) {
+            const uint32_t lo = min(a, b), hi = max(a, b);
+            if (atomicCAS(&parent[hi], hi, lo) == hi) {
+                hooked = true;
+                a = b = lo;          // done
+            }
+        }
+        for (; a != b;) {
             a = uf_find(parent, a);
             b = uf_find(parent, b);
             if (a == b)

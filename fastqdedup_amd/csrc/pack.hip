@@ -18,6 +18,9 @@
 //            copied to HBM with uint4 stores.
 #include "fqd_internal.h"
 
+#ifndef FQD_PACK_NSUB
+#define FQD_PACK_NSUB 2   // tiles per workgroup of the fused pack (1: 0.56-0.58 ms at config 3, 2: 0.51-0.52)
+#endif
 namespace {
 
 constexpr int PACK_THREADS = 256;
@@ -106,8 +109,32 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     uint32_t *tile = planes + K * plane_words;                // kpb * stride (16-byte aligned by host)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint64_t key0 = (uint64_t)blockIdx.x * kpb;
+    // FUSED: a workgroup packs NSUB tiles of kpb keys one after the other, keeps their records in registers and
+    // partitions them TOGETHER -- one cursor reservation and one run of 2 x 4 records per bin instead of two of
+    // each (with one tile per workgroup the kernel is bound by its 12.5 M cursor atomics and 64-byte runs, not by
+    // HBM: 128 bins instead of 256 made it 0.50 instead of 0.56 ms, but level 2 then pays more than that)
+    constexpr uint32_t NSUB = FUSED ? FQD_PACK_NSUB : 1, R = 4;      // R: records per thread and tile (kpb <= 1024)
+    uint32_t *s_hist = smem + fs.hist_at, *s_off = smem + fs.tables_at, *s_base = s_off + fs.n_bins;
+    uint32_t *s_wave = s_base + fs.n_bins;
+    uint16_t *s_bin16 = reinterpret_cast<uint16_t *>(s_wave + 4);
+    uint4 *tile4 = reinterpret_cast<uint4 *>(tile);
+    uint4 v[NSUB * R];
+    uint32_t bin[NSUB * R], rank[NSUB * R];
+    uint32_t n_block = 0;                                // keys of this workgroup
+    if (FUSED) {
+        for (uint32_t b = tid; b < fs.n_bins; b += PACK_THREADS)
+            s_hist[b] = 0;                               // (visible after the first barrier below)
+#pragma unroll
+        for (uint32_t e = 0; e < NSUB * R; e++)
+            bin[e] = 0xFFFFFFFFu;
+    }
+#pragma unroll
+  for (uint32_t sub = 0; sub < NSUB; sub++) {
+    const uint64_t key0 = ((uint64_t)blockIdx.x * NSUB + sub) * kpb;
+    if (key0 >= n)
+        break;                                           // (the same for every thread of the workgroup)
     const uint32_t nk = (uint32_t)min((uint64_t)kpb, n - key0);
+    n_block += nk;
     const uint64_t b0 = offsets ? offsets[key0] : key0 * fixed_len;
     const uint64_t b1 = offsets ? offsets[key0 + nk] : (key0 + nk) * fixed_len;
     const uint64_t a0 = b0 & ~15ull;
@@ -266,23 +293,11 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     __syncthreads();
 
     if (FUSED) {
-        // ---- phase D: the tile leaves partitioned by hash bin --------------------
-        // tables: hist[n_bins] | off[n_bins] | base[n_bins] | wave[4] | bin16[kpb] -- over the bit
-        // streams of phase A (dead since the barrier above) when they fit there, else behind the tile
-        uint32_t *s_hist = smem + fs.tables_at, *s_off = s_hist + fs.n_bins, *s_base = s_off + fs.n_bins;
-        uint32_t *s_wave = s_base + fs.n_bins;
-        uint16_t *s_bin16 = reinterpret_cast<uint16_t *>(s_wave + 4);
-        uint4 *tile4 = reinterpret_cast<uint4 *>(tile);
-        constexpr uint32_t R = 4;            // kpb <= 1024 (2048-key tiles: 0.84 ms instead of 0.58, 512: 0.93)
-        for (uint32_t b = tid; b < fs.n_bins; b += PACK_THREADS)
-            s_hist[b] = 0;
-        __syncthreads();
-        uint4 v[R];
-        uint32_t bin[R], rank[R];
+        // ---- phase D, first half: this tile's records into registers, their bins and ranks inside the bins
 #pragma unroll
-        for (uint32_t e = 0; e < R; e++) {
-            const uint32_t k = e * PACK_THREADS + tid;
-            bin[e] = 0xFFFFFFFFu;
+        for (uint32_t e0 = 0; e0 < R; e0++) {
+            const uint32_t e = sub * R + e0;
+            const uint32_t k = e0 * PACK_THREADS + tid;
             if (k < nk) {
                 v[e] = tile4[k];
                 const uint32_t rec[3] = {v[e].x, v[e].y, v[e].z};
@@ -301,8 +316,8 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
                     const uint32_t sm = fqd_range_mask(0, slo, shi);
                     uint32_t oh = 0x9E3779B9u;
 #pragma unroll
-                    for (int k = 0; k < K; k++)
-                        oh = (oh ^ (rec[k] & sm)) * 0x85EBCA6Bu;
+                    for (int kk = 0; kk < K; kk++)
+                        oh = (oh ^ (rec[kk] & sm)) * 0x85EBCA6Bu;
                     const uint32_t owner = fqd_mix32(oh) % fs.owner_parts;
                     bin[e] = owner * fs.owner_hb + (fs.owner_hb > 1 ? h >> fs.shift : 0u);
                 } else {
@@ -311,6 +326,25 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
                 rank[e] = atomicAdd(&s_hist[bin[e]], 1u);
             }
         }
+        continue;      // (the next tile's phase B waits behind the barrier that ends its phase A: every thread has its records by then)
+    }
+    // ---- phase C: hash per key, then stream the tile out ---------------------
+    for (uint32_t k = tid; k < nk; k += PACK_THREADS) {
+        const uint32_t len = offsets ? (uint32_t)(offsets[key0 + k + 1] - offsets[key0 + k]) : fixed_len;
+        hashes[key0 + k] = fqd_hash_record(tile + k * stride, W * K, len);
+        if (lens)
+            lens[key0 + k] = len;
+        if (owners)   // multi-GPU: the rank this read goes to
+            owners[key0 + k] = fqd_segment_hash(tile + k * stride, K, W * K, len, rule.seg, rule.nseg) % rule.parts;
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(recs + key0 * stride);
+    const uint4 *src = reinterpret_cast<const uint4 *>(tile);
+    for (uint32_t i = tid; i < nk * stride / 4u; i += PACK_THREADS)
+        dst[i] = src[i];
+  }
+    if (FUSED) {
+        // ---- phase D, second half: the workgroup's tiles leave partitioned by hash bin ------------
+        // tables: hist[n_bins] | off[n_bins] | base[n_bins] | wave[4] | bin16[kpb], behind the record tile
         __syncthreads();
         // exclusive scan of the bin counts: n_bins <= 256, one bin per thread
         const uint32_t mine = tid < fs.n_bins ? s_hist[tid] : 0u;
@@ -326,11 +360,12 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
         uint32_t excl = incl - mine;
         for (uint32_t wv = 0; wv < wave; wv++)
             excl += s_wave[wv];
+        const uint32_t my_sub = blockIdx.x & (fs.subs - 1);
         if (tid < fs.n_bins) {
             s_off[tid] = excl;
             uint32_t base = 0;
             if (mine) {
-                const uint32_t part = tid * fs.subs + (blockIdx.x & (fs.subs - 1));
+                const uint32_t part = tid * fs.subs + my_sub;
                 const uint32_t g = atomicAdd(&fs.cursor[part], mine);
                 if ((uint64_t)g + mine > ((uint64_t)part + 1) * fs.cap)
                     atomicOr(fs.overflow, 4u);    // the part's slab is full: the caller packs the plain way
@@ -339,43 +374,35 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
             s_base[tid] = base;
         }
         __syncthreads();
+        // the records leave in rounds of kpb sorted positions through the one-tile staging area
+        for (uint32_t round0 = 0; round0 < n_block; round0 += kpb) {
 #pragma unroll
-        for (uint32_t e = 0; e < R; e++)
-            if (bin[e] != 0xFFFFFFFFu) {
-                const uint32_t p = s_off[bin[e]] + rank[e];
-                tile4[p] = v[e];
-                s_bin16[p] = (uint16_t)bin[e];
-            }
-        __syncthreads();
+            for (uint32_t e = 0; e < NSUB * R; e++)
+                if (bin[e] != 0xFFFFFFFFu) {
+                    const uint32_t p = s_off[bin[e]] + rank[e] - round0;
+                    if (p < kpb) {
+                        tile4[p] = v[e];
+                        s_bin16[p] = (uint16_t)bin[e];
+                    }
+                }
+            __syncthreads();
 #pragma unroll
-        for (uint32_t e = 0; e < R; e++) {
-            const uint32_t p = e * PACK_THREADS + tid;
-            if (p < nk) {
-                // (records that would land behind the slab's end are dropped: what is written stays
-                // gap-free, see partition.cuh)
-                const uint32_t bn = s_bin16[p];
-                const uint32_t pos = s_base[bn] + p;
-                // (non-temporal stores here: 0.89 ms instead of 0.56 -- the runs of consecutive tiles complete
-                // each other's partial lines in the XCD's L2, which a non-temporal store forgoes)
-                if (pos < (bn * fs.subs + (blockIdx.x & (fs.subs - 1)) + 1) * fs.cap)
-                    fs.out[pos] = tile4[p];
+            for (uint32_t e = 0; e < R; e++) {
+                const uint32_t p = e * PACK_THREADS + tid;
+                if (p < kpb && round0 + p < n_block) {
+                    // (records that would land behind the slab's end are dropped: what is written stays
+                    // gap-free, see partition.cuh)
+                    const uint32_t bn = s_bin16[p];
+                    const uint32_t pos = s_base[bn] + round0 + p;
+                    // (non-temporal stores here: 0.89 ms instead of 0.56 -- the runs of consecutive tiles complete
+                    // each other's partial lines in the XCD's L2, which a non-temporal store forgoes)
+                    if (pos < (bn * fs.subs + my_sub + 1) * fs.cap)
+                        fs.out[pos] = tile4[p];
+                }
             }
+            __syncthreads();
         }
-        return;
     }
-    // ---- phase C: hash per key, then stream the tile out ---------------------
-    for (uint32_t k = tid; k < nk; k += PACK_THREADS) {
-        const uint32_t len = offsets ? (uint32_t)(offsets[key0 + k + 1] - offsets[key0 + k]) : fixed_len;
-        hashes[key0 + k] = fqd_hash_record(tile + k * stride, W * K, len);
-        if (lens)
-            lens[key0 + k] = len;
-        if (owners)   // multi-GPU: the rank this read goes to
-            owners[key0 + k] = fqd_segment_hash(tile + k * stride, K, W * K, len, rule.seg, rule.nseg) % rule.parts;
-    }
-    uint4 *dst = reinterpret_cast<uint4 *>(recs + key0 * stride);
-    const uint4 *src = reinterpret_cast<const uint4 *>(tile);
-    for (uint32_t i = tid; i < nk * stride / 4u; i += PACK_THREADS)
-        dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void hash_records_kernel(const uint32_t *__restrict__ recs,
@@ -499,16 +526,28 @@ hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *o
                                    (fused->owner_hb & (fused->owner_hb - 1)) || rule.parts != fused->owner_parts))
             return hipErrorInvalidValue;
         fs = *fused;
-        const uint32_t tables = (3 * fs.n_bins + 4) * 4 + kpb * 2, streams = sh.planes * plane_words * 4;
+        // The bin counts are needed across the workgroup's tiles: they take the byte scratch of the LUT path (256
+        // words, unused by the SWAR conversion) or sit behind the record tile. The other tables (offsets, bases,
+        // wave totals, the bins of the staged records) are used when the last tile's bit streams are dead: over
+        // those when they fit there, else behind the tile as well. (Everything behind the tile: one workgroup
+        // fewer per CU, 0.57 instead of 0.51 ms.)
+        const uint32_t tables = (2 * fs.n_bins + 4) * 4 + kpb * 2, streams = sh.planes * plane_words * 4;
         fs.tables_at = 64 + PACK_WAVES * 64;             // = where the streams start (words)
         if (tables > streams) {
             fs.tables_at = lds / 4;
             lds += tables;
         }
+        fs.hist_at = 64;                                 // the scratch words
+        PackHash ph_probe{};
+        if (!(sh.planes <= 3 && find_pack_hash(lut_host, ph_probe)) || fs.n_bins > PACK_WAVES * 64) {
+            fs.hist_at = lds / 4;
+            lds += fs.n_bins * 4;
+        }
         if (lds > 64 * 1024)
             return hipErrorInvalidValue;
     }
-    const uint64_t blocks = (n + kpb - 1) / kpb;
+    const uint64_t tiles_per_block = fused ? FQD_PACK_NSUB : 1;      // (pack_kernel NSUB)
+    const uint64_t blocks = (n + kpb * tiles_per_block - 1) / (kpb * tiles_per_block);
     if (blocks > 0x7FFFFFFFull)
         return hipErrorInvalidValue;
     PackHash ph{};

@@ -19,6 +19,7 @@
 //   template <bool LEVEL1> static __device__ uint32_t load(const Source &, uint32_t i, Item &); // scatter pass, returns the key
 //   static __device__ uint32_t segment_tag(const Source &, uint32_t segment);  static __device__ void apply_tag(Item &, uint32_t tag);
 //   static constexpr bool MAY_SKIP;  static __device__ bool skip(const Item &);   // scatter pass: an item load() has disposed of otherwise
+//   static constexpr uint32_t EPT, ROUNDS;   // items per thread (tile = 256 * EPT); staging rounds of the scatter pass
 #pragma once
 #include "fqd_internal.h"
 
@@ -37,18 +38,25 @@ template <uint32_t TILE>
 __device__ __forceinline__ bool tile_of_block(const uint32_t *__restrict__ seg_start,
                                               const uint32_t *__restrict__ tile_start, uint32_t n_seg,
                                               uint32_t &seg, uint32_t &lo, uint32_t &hi,
-                                              const uint32_t *__restrict__ seg_end = nullptr)
+                                              const uint32_t *__restrict__ seg_end = nullptr,
+                                              const uint32_t *__restrict__ tile_seg = nullptr)
 {
     const uint32_t t = blockIdx.x;
     if (t >= tile_start[n_seg])
         return false;
     uint32_t a = 0, b = n_seg;  // last segment with tile_start <= t
-    while (b - a > 1) {
-        const uint32_t m = (a + b) >> 1;
-        if (tile_start[m] <= t)
-            a = m;
-        else
-            b = m;
+    if (tile_seg) {
+        // (slab_tile_starts_body wrote every tile's segment down: one load instead of the 13 dependent scalar loads
+        // of a search over 8192 slabs -- which, measured, cost nothing: 0.435 ms either way for level 2 at config 3)
+        a = tile_seg[t];
+    } else {
+        while (b - a > 1) {
+            const uint32_t m = (a + b) >> 1;
+            if (tile_start[m] <= t)
+                a = m;
+            else
+                b = m;
+        }
     }
     seg = a;
     lo = seg_start[a] + (t - tile_start[a]) * TILE;
@@ -104,8 +112,13 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
                                              typename Policy::Item *__restrict__ out, uint32_t slab_cap = 0,
                                              uint32_t *__restrict__ slab_overflow = nullptr,
                                              const uint32_t *__restrict__ seg_end = nullptr, uint32_t seg_shift = 0,
-                                             uint32_t seg_mask = 0xFFFFFFFFu)
+                                             uint32_t seg_mask = 0xFFFFFFFFu, uint32_t l1_subs = 0,
+                                             const uint32_t *__restrict__ tile_seg = nullptr)
 {
+    // l1_subs != 0 (LEVEL1 only; a power of two): level 1 in slab mode too, without the count matrix and its
+    // histogram pass -- tile t adds to sub-part t % l1_subs of every bin: part (sub, bin) owns
+    // out[(sub * n_bins + bin) * slab_cap, +slab_cap), cursor[sub * n_bins + bin] started at its first slot; the
+    // parts are the slab segments of level 2 (part -> bin: segment & (n_bins - 1), its seg_mask).
     // seg_end / seg_shift (level 2 behind the fused pack, pack.hip): the input segments are slabs
     // [seg_start[s], seg_end[s]) and 2^seg_shift consecutive segments are sub-parts of ONE level-1
     // part -- they feed the same buckets. seg_mask: slabs received from several ranks come sender by
@@ -119,6 +132,11 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
     // stale bytes taken for (hash, uid) items or read indices would send them out of bounds.
     using Item = typename Policy::Item;
     constexpr uint32_t EPT = Policy::EPT, TILE = THREADS * EPT;
+    // Policy::ROUNDS > 1: the tile is held in registers and leaves through a staging area of TILE / ROUNDS items,
+    // ROUNDS ranges of sorted positions one after the other -- a tile twice as long (half the cursor atomics, runs
+    // twice as long) without twice the LDS
+    constexpr uint32_t ROUNDS = Policy::ROUNDS, STAGE = TILE / ROUNDS;
+    static_assert(TILE % ROUNDS == 0 && EPT % ROUNDS == 0, "rounds must divide the tile");
     // MAXB bounds n_bins (the three bin tables): 256 instead of 1024 is one more workgroup per CU.
     // (Halving the staging area as well -- two phases, 21 KB, twice the workgroups -- changed
     // nothing: the kernel is bound by the write efficiency of its 128-byte runs, not by occupancy.)
@@ -126,13 +144,16 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
     __shared__ uint32_t s_off[MAXB];    // first tile-local position of the bin
     __shared__ uint32_t s_base[MAXB];   // global position of the bin's run, minus s_off
     __shared__ uint32_t s_wave[THREADS / 64];
-    __shared__ Item s_stage[TILE];
-    __shared__ uint16_t s_stage_bin[TILE];
+    __shared__ Item s_stage[STAGE];
+    __shared__ uint16_t s_stage_bin[STAGE];
     uint32_t seg, lo, hi;
-    if (!tile_of_block<TILE>(seg_start, tile_start, n_seg, seg, lo, hi, seg_end))
+    if (!tile_of_block<TILE>(seg_start, tile_start, n_seg, seg, lo, hi, seg_end, tile_seg))
         return;
     const uint32_t seg_tag = Policy::segment_tag(src, seg);       // (per workgroup: a tile lies in ONE segment)
     seg = (seg >> seg_shift) & seg_mask;
+    const bool matrix = LEVEL1 && !l1_subs;
+    if (LEVEL1 && l1_subs)
+        seg = blockIdx.x & (l1_subs - 1);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t b = tid; b < n_bins; b += THREADS)
         s_hist[b] = 0;
@@ -185,12 +206,12 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
             const uint32_t c = s_hist[b];
             s_off[b] = run;
             uint32_t g;
-            if (LEVEL1)
+            if (matrix)
                 g = cursor[(size_t)b * tile_start[n_seg] + blockIdx.x] - c;
             else
                 g = c ? atomicAdd(&cursor[seg * n_bins + b], c) : 0u;
             s_base[b] = g - run;
-            if (!LEVEL1 && slab_cap && c) {
+            if (!matrix && slab_cap && c) {
                 const uint64_t end = ((uint64_t)seg * n_bins + b + 1) * slab_cap;
                 if ((uint64_t)g + c > end)
                     atomicOr(slab_overflow, 2u);
@@ -199,24 +220,30 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
         }
     }
     __syncthreads();
-#pragma unroll
-    for (uint32_t e = 0; e < EPT; e++)
-        if (bin[e] != 0xFFFFFFFFu) {
-            const uint32_t p = s_off[bin[e]] + rank[e];
-            s_stage[p] = v[e];
-            s_stage_bin[p] = (uint16_t)bin[e];
-        }
-    __syncthreads();
     const uint32_t count = Policy::MAY_SKIP ? staged : hi - lo;
+    for (uint32_t r0 = 0; r0 < (ROUNDS > 1 ? count : 1u); r0 += STAGE) {
 #pragma unroll
-    for (uint32_t e = 0; e < EPT; e++) {
-        const uint32_t p = e * THREADS + tid;
-        if (p < count) {
-            const uint32_t bn = s_stage_bin[p];
-            const uint32_t pos = s_base[bn] + p;   // consecutive p of one bin: consecutive addresses
-            if (LEVEL1 || !slab_cap || pos < (seg * n_bins + bn + 1) * slab_cap)
-                out[pos] = s_stage[p];
+        for (uint32_t e = 0; e < EPT; e++)
+            if (bin[e] != 0xFFFFFFFFu) {
+                const uint32_t p = s_off[bin[e]] + rank[e] - r0;
+                if (ROUNDS == 1 || p < STAGE) {
+                    s_stage[p] = v[e];
+                    s_stage_bin[p] = (uint16_t)bin[e];
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t e = 0; e < EPT / ROUNDS; e++) {
+            const uint32_t p = e * THREADS + tid;
+            if (r0 + p < count) {
+                const uint32_t bn = s_stage_bin[p];
+                const uint32_t pos = s_base[bn] + r0 + p;   // consecutive p of one bin: consecutive addresses
+                if (matrix || !slab_cap || pos < (seg * n_bins + bn + 1) * slab_cap)
+                    out[pos] = s_stage[p];
+            }
         }
+        if (ROUNDS > 1)
+            __syncthreads();
     }
 }
 
@@ -244,20 +271,39 @@ __device__ __forceinline__ void tile_starts_body(const uint32_t *__restrict__ se
 }
 
 // the same for any number of slab segments [seg_start[s], min(seg_end[s], seg_start[s + 1])) (single block of
-// 1024 threads; seg_start has n_seg + 1 entries)
+// 1024 threads; seg_start has n_seg + 1 entries). Up to 8192 segments -- the fused pack's and the search's level
+// 1 -- the tile counts are first fetched into LDS with coalesced, independent loads (thread t takes segments
+// t, t + 1024, ...): a thread walking its own 8 consecutive segments waited for 8 dependent round trips, 13.7 us
+// for the whole kernel, on the critical path between two partition levels.
 template <uint32_t TILE>
 __device__ __forceinline__ void slab_tile_starts_body(const uint32_t *__restrict__ seg_start,
                                                       const uint32_t *__restrict__ seg_end, uint32_t n_seg,
-                                                      uint32_t *__restrict__ tile_start)
+                                                      uint32_t *__restrict__ tile_start,
+                                                      uint32_t *__restrict__ tile_seg = nullptr /* segment of every tile */)
 {
+    constexpr uint32_t STAGED = 8192;
     __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_tiles[STAGED];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t per = (n_seg + blockDim.x - 1) / blockDim.x;
     const uint32_t s0 = tid * per, s1 = min(s0 + per, n_seg);
     auto tiles_of = [&](uint32_t t) { return (min(seg_end[t], seg_start[t + 1]) - seg_start[t] + TILE - 1) / TILE; };
+    const bool staged = n_seg <= STAGED;
+    if (staged) {
+#pragma unroll
+        for (uint32_t k = 0; k < STAGED / 1024; k++) {
+            const uint32_t t = k * 1024 + tid;
+            if (t < n_seg && blockDim.x == 1024)
+                s_tiles[t] = tiles_of(t);
+        }
+        if (blockDim.x != 1024)
+            for (uint32_t t = tid; t < n_seg; t += blockDim.x)
+                s_tiles[t] = tiles_of(t);
+        __syncthreads();
+    }
     uint32_t mine = 0;
     for (uint32_t t = s0; t < s1; t++)
-        mine += tiles_of(t);
+        mine += staged ? s_tiles[t] : tiles_of(t);
     uint32_t incl = mine;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t up = __shfl_up(incl, o);
@@ -272,7 +318,11 @@ __device__ __forceinline__ void slab_tile_starts_body(const uint32_t *__restrict
         run += s_wave[wv];
     for (uint32_t t = s0; t < s1; t++) {
         tile_start[t] = run;
-        run += tiles_of(t);
+        const uint32_t k = staged ? s_tiles[t] : tiles_of(t);
+        if (tile_seg)
+            for (uint32_t j = 0; j < k; j++)
+                tile_seg[run + j] = t;
+        run += k;
     }
     if (s1 == n_seg && s0 < n_seg)
         tile_start[n_seg] = run;

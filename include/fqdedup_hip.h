@@ -262,7 +262,7 @@ int fqd_find_edges_segments(fqd_ctx *ctx, int max_distance, uint32_t seg_lo, uin
                             uint64_t *n_edges);
 /* Components of a caller's edge list over n_nodes nodes (DEVICE buffers): roots[e] = smallest
  * node of edge e's component; *n_components = n_nodes - merges. The job-wide pop_cluster
- * partition when the nodes are global unique ids. */
+ * partition when the nodes are global unique ids. uv: pairs of node ids, 8-byte aligned. */
 int fqd_edge_labels(fqd_ctx *ctx, const uint32_t *uv, uint64_t n_edges, uint64_t n_nodes, uint32_t *roots,
                     uint64_t *n_components, int mem);
 /* The clusters one rank dissects, cut out of the job-wide edge list (DEVICE buffers): the edges whose

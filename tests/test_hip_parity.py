@@ -311,8 +311,11 @@ def test_every_fast_path_agrees_with_the_plain_paths(F, monkeypatch):
     assert base.n_kept == len(base.kept_read_ids) and np.all(np.diff(base.kept_read_ids.astype(np.int64)) > 0)
     for env in ({"FQD_NO_FUSED_PACK": "1"}, {"FQD_NO_EARLY_SEG_HASHES": "1"}, {"FQD_KEPT_BY_MAP": "1"},
                 {"FQD_KEPT_BY_SORT": "1"}, {"FQD_LDS_NO_SLABS": "1", "FQD_GROUP_NO_SLABS": "1", "FQD_NO_FUSED_PACK": "1"},
-                {"FQD_COLLAPSE": "sort", "FQD_EDGES": "sort"}, {"FQD_DIRECTIONAL_ROUNDS": "1"}):
-        other, _ = run(**env)
+                {"FQD_COLLAPSE": "sort", "FQD_EDGES": "sort"}, {"FQD_DIRECTIONAL_ROUNDS": "1"},
+                {"FQD_NO_COMPACT_RECORDS": "1"}, {"FQD_GROUP_L1_SLABS_MIN_TILES": "1"}):
+        other, okt = run(**env)
+        if "FQD_GROUP_L1_SLABS_MIN_TILES" in env:      # level 1 of the search partition in slab mode: no histogram pass
+            assert okt["gp_hist_kernel"][1] == 0 and kt["gp_hist_kernel"][1] >= 1
         assert (other.n_unique, other.n_edges, other.n_clusters, other.n_kept) == \
                (base.n_unique, base.n_edges, base.n_clusters, base.n_kept), env
         assert np.array_equal(other.kept_read_ids, base.kept_read_ids), env
@@ -662,10 +665,14 @@ def test_grouped_search_with_a_crowded_segment(F, oracle, monkeypatch, budget):
     assert np.array_equal(res.kept_read_ids, want["kept_read_ids"])
 
 
-def test_grouped_search_slab_overflow_searches_again(F, oracle, monkeypatch):
-    """Level 2 of the search's (hash, uid) partition also uses fixed slabs. 3000 keys sharing their
+@pytest.mark.parametrize("level1_slabs", [False, True])
+def test_grouped_search_slab_overflow_searches_again(F, oracle, monkeypatch, level1_slabs):
+    """Level 2 of the search's (hash, uid) partition also uses fixed slabs (and, for millions of items, level 1 --
+    here by a lowered threshold). 3000 keys sharing their
     first half overfill one: the search must run again with exact bucket sizes (and keep doing so on
     this context), with the oracle's answer and the same edges as a context that never used slabs."""
+    if level1_slabs:
+        monkeypatch.setenv("FQD_GROUP_L1_SLABS_MIN_TILES", "1")
     from fastqdedup_amd.synth import fixed_offsets, synth_keys
     rng = np.random.default_rng(15)
     n, L = 300_000, 32
