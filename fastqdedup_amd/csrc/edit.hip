@@ -329,6 +329,11 @@ __global__ __launch_bounds__(256) void edit_len_counts_kernel(const uint32_t *__
 
 // pass 0: per_key[u] = probe items key u files (by its length class). pass 1: the index items (slot
 // u * (d + 1) + s) and the probe items (behind all index items, at the key's scanned offset).
+// STAGED (pass 1, records of up to 47 words): the workgroup's 256 records come in with coalesced 16-byte loads
+// and are read from LDS, one record per thread at a stride of stride + 1 words (no bank conflicts) -- a thread
+// walking its own 128-byte record in global memory shares no line with its neighbours (config 5's variant:
+// 4.5 ms of a 25.8 ms step for 14 M keys).
+template <bool STAGED>
 __global__ __launch_bounds__(256) void edit_items_kernel(const uint32_t *__restrict__ urecs,
                                                          const uint32_t *__restrict__ ulens, uint64_t U, KeyShape sh,
                                                          uint32_t d, const uint8_t *__restrict__ probe_mask,
@@ -338,7 +343,24 @@ __global__ __launch_bounds__(256) void edit_items_kernel(const uint32_t *__restr
                                                          uint32_t *__restrict__ hashes, uint32_t *__restrict__ payloads,
                                                          int pass)
 {
-    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ uint32_t s_recs[];
+    const uint64_t u0 = (uint64_t)blockIdx.x * blockDim.x;
+    const uint64_t u = u0 + threadIdx.x;
+    if (STAGED) {
+        const uint32_t S = sh.stride, S4 = S / 4;               // (the stride is a multiple of four words)
+        const uint32_t nk = (uint32_t)min((uint64_t)blockDim.x, U - u0);
+        const uint4 *src = reinterpret_cast<const uint4 *>(urecs + u0 * S);
+        for (uint32_t i = threadIdx.x; i < nk * S4; i += blockDim.x) {
+            const uint4 q = src[i];
+            const uint32_t r = i / S4, w = (i - r * S4) * 4;
+            uint32_t *dst = s_recs + r * (S + 1) + w;
+            dst[0] = q.x;
+            dst[1] = q.y;
+            dst[2] = q.z;
+            dst[3] = q.w;
+        }
+        __syncthreads();
+    }
     if (u >= U)
         return;
     const uint32_t len = fqd_key_len(sh, ulens, u);
@@ -347,7 +369,7 @@ __global__ __launch_bounds__(256) void edit_items_kernel(const uint32_t *__restr
         return;
     }
     const uint32_t K = sh.planes, W = sh.words, nseg = d + 1;
-    const uint32_t *rec = urecs + u * sh.stride;
+    const uint32_t *rec = STAGED ? s_recs + threadIdx.x * (sh.stride + 1) : urecs + u * sh.stride;
     for (uint32_t s = 0; s < nseg; s++) {
         uint32_t lo, hi;
         fqd_segment(len, s, nseg, lo, hi);
@@ -664,9 +686,15 @@ hipError_t launch_edit_items(const uint32_t *urecs, const uint32_t *ulens, uint6
                              const uint8_t *probe_mask, const uint32_t *probe_count, uint32_t *per_key,
                              const uint32_t *per_key_incl, uint32_t *hashes, uint32_t *payloads, int pass, hipStream_t st)
 {
-    if (U)
-        edit_items_kernel<<<grid_for(U), 256, 0, st>>>(urecs, ulens, U, sh, d, probe_mask, probe_count, per_key,
-                                                        per_key_incl, hashes, payloads, pass);
+    if (!U)
+        return hipSuccess;
+    const size_t lds = (size_t)256 * (sh.stride + 1) * 4;
+    if (pass == 1 && sh.stride % 4 == 0 && lds <= 48 * 1024)
+        edit_items_kernel<true><<<grid_for(U), 256, lds, st>>>(urecs, ulens, U, sh, d, probe_mask, probe_count, per_key,
+                                                               per_key_incl, hashes, payloads, pass);
+    else
+        edit_items_kernel<false><<<grid_for(U), 256, 0, st>>>(urecs, ulens, U, sh, d, probe_mask, probe_count, per_key,
+                                                              per_key_incl, hashes, payloads, pass);
     return hipGetLastError();
 }
 
@@ -676,6 +704,9 @@ hipError_t launch_edit_grouped_verify(const uint64_t *cands, const unsigned long
                                       unsigned long long *edge_count, uint64_t edge_cap, unsigned long long *cand_need,
                                       unsigned long long *n_verified, int cross_only, hipStream_t st)
 {
+    // (Staging both records of a candidate in LDS first -- 128 candidates per workgroup, 8 lanes fetching a record --
+    // was slower: 4.2 instead of 3.3 ms at config 5's variant; at 34 KB per workgroup too few waves are left to hide
+    // the gathers.)
     edit_grouped_verify_kernel<<<n_lists * 32, 256, 0, st>>>(reinterpret_cast<const uint2 *>(cands), cand_count, list_cap,
                                                              n_lists, urecs, ulens, sh, d, probe_mask, edges, edge_count,
                                                              edge_cap, cand_need, n_verified, cross_only);

@@ -57,18 +57,42 @@ __global__ __launch_bounds__(256) void scan_bytes_kernel(const uint8_t *__restri
 __global__ void scan_lens_kernel(const uint64_t *__restrict__ offsets, uint64_t n, uint32_t *__restrict__ minmax)
 {
     uint32_t lo = 0xFFFFFFFFu, hi = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t l = offsets[i + 1] - offsets[i];
-        uint32_t l32 = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
-        lo = min(lo, l32);
-        hi = max(hi, l32);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        uint64_t a[4], b[4];                      // four lengths per step, their loads in flight together
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint64_t i = i0 + t * stride;
+            a[t] = i < n ? offsets[i] : 0;
+            b[t] = i < n ? offsets[i + 1] : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (i0 + t * stride >= n)
+                continue;
+            const uint64_t l = b[t] - a[t];
+            const uint32_t l32 = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+            lo = min(lo, l32);
+            hi = max(hi, l32);
+        }
     }
     for (int o = 32; o; o >>= 1) {
         lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
         hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
     }
+    // one pair of atomics per workgroup (one per wave: 16 K atomics on two words, ~36 ns each -- most of the
+    // kernel's 1 ms at 50 M keys)
+    __shared__ uint32_t s_lo[4], s_hi[4];
     if (fqd_lane() == 0) {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < blockDim.x / 64; w++) {
+            lo = min(lo, s_lo[w]);
+            hi = max(hi, s_hi[w]);
+        }
         atomicMin(&minmax[0], lo);
         atomicMax(&minmax[1], hi);
     }
@@ -437,8 +461,8 @@ hipError_t launch_scan_lens(const uint64_t *offsets, uint64_t n, uint32_t *minma
     if (!n)
         return hipSuccess;
     uint64_t blocks = (n + 255) / 256;
-    if (blocks > 2048)
-        blocks = 2048;
+    if (blocks > 1024)
+        blocks = 1024;
     scan_lens_kernel<<<(unsigned)blocks, 256, 0, st>>>(offsets, n, minmax_dev);
     return hipGetLastError();
 }
