@@ -217,11 +217,6 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
     uint32_t *f_seg_start = fused ? c->ld_seg.as<uint32_t>() : nullptr;
     uint32_t *f_seg_end = fused ? f_seg_start + (f_parts + 4) : nullptr;
     uint32_t *f_tiles = fused ? f_seg_end + (f_parts + 4) : nullptr;
-    // the segment of every level-2 tile, behind the three tables when the caller left room for tiles1 + parts + 4
-    // more words (fqd_cluster_keys does; slabs received from other ranks: a search per tile instead)
-    uint32_t *f_tile_seg = fused && c->ld_seg.cap >= ((size_t)3 * (f_parts + 4) + tiles1 + f_parts + 4) * 4 &&
-                                   !getenv("FQD_NO_TILE_SEG")
-                               ? f_tiles + (f_parts + 4) : nullptr;
     // compact records, squeeze 1: the side slabs' cursors (and their starts, unused) live behind the hash table
     fqd::SideSlabs side;
     if (compact == 1) {
@@ -244,8 +239,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         } else {
             // ---- level 2: every part into 2^B2 buckets by the next B2 hash bits
             if (fused)     // (the pack kernel left seg_start / seg_end = cursors there; received slabs: the caller did)
-                HIP_TRY(c, fqd::launch_slab_tile_starts(f_seg_start, f_seg_end, f_parts, f_tiles, c->st, compact != 0,
-                                                        f_tile_seg));
+                HIP_TRY(c, fqd::launch_slab_tile_starts(f_seg_start, f_seg_end, f_parts, f_tiles, c->st, compact != 0));
             else
                 HIP_TRY(c, fqd::launch_tile_starts(start1, bins1, tiles2_d, c->st));
             if (slab_cap) {
@@ -267,7 +261,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 KTIME(c, FQD_K_PART_SCATTER12, fqd::launch_part_scatter12(
                           c->ld_part.as<uint32_t>(), compact, side, f_seg_start, f_tiles, f_parts, tiles1 + f_parts,
                           32 - B, bins2, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<fqd::Rec12>(), c->st, slab_cap,
-                          c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end, fused->sub_bits, f_tile_seg));
+                          c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end, fused->sub_bits));
                 // the keys with an N: collapsed apart, to the head of the unique table (few: a table in global
                 // memory) -- on the context's second stream, beside the dedupe of the other keys: four short
                 // kernels (0.05 ms in a row) that the compaction, not the dedupe, waits for
@@ -287,7 +281,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                           false, nullptr, c->ld_part.as<uint32_t>(), f_seg_start, f_tiles, f_parts, tiles1 + f_parts,
                           32 - B, bins2, kw, sh.max_len, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<uint32_t>(), c->st,
                           fused->stamp_div ? d_ids : IdSource(), slab_cap, c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end,
-                          fused->sub_bits, fused->part_mask, fused->stamp_div, f_tile_seg));
+                          fused->sub_bits, fused->part_mask, fused->stamp_div));
             else
                 KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(
                           false, nullptr, c->ld_part.as<uint32_t>(), start1, tiles2_d, bins1, max_tiles2, 32 - B, bins2,
@@ -530,7 +524,12 @@ int fqd_create(int device, fqd_ctx **out)
               c->d_lut.reserve(256) == hipSuccess &&
               c->d_stats.reserve(FQD_STAT_SLOTS * sizeof(fqd::PairStats)) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_rb, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->st_side, hipStreamNonBlocking) == hipSuccess &&
+    // (the side stream at the highest priority: its four short kernels share the GPU with the dedupe kernel and,
+    // queueing for CUs behind that kernel's 65 536 workgroups, would finish after it -- one of them was seen to
+    // take 0.27 ms that way)
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    ok = ok && hipStreamCreateWithPriority(&c->st_side, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
          hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     if (ok && hipHostMalloc(&c->h_pin, 256, hipHostMallocDefault) != hipSuccess) {
@@ -1008,8 +1007,7 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     StageTimer pack_timer(c, FQD_T_PACK);
     FQD_TRY(to_device(c, bytes, (size_t)n_bytes, mem, c->in_bytes, &d_bytes));
     HIP_TRY(c, c->ld_part.reserve((size_t)parts * cap1 * 16 + 16));
-    // seg_start | cursor = seg_end | tile_start (parts + 4 words each) | the segment of every level-2 tile
-    HIP_TRY(c, c->ld_seg.reserve(((size_t)3 * (parts + 4) + n / 2048 + 1 + parts + 4) * 4));
+    HIP_TRY(c, c->ld_seg.reserve((size_t)3 * (parts + 4) * 4));
     uint32_t *seg_start = c->ld_seg.as<uint32_t>(), *cursor = seg_start + (parts + 4);
     FQD_TRY(zero_ctr32(c, 0, C_N32));
     HIP_TRY(c, fqd::launch_slab_starts(parts, cap1, seg_start, cursor, c->st));

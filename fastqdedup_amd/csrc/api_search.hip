@@ -278,16 +278,13 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
             l1_subs = 0;
     }
     // level-1 slab tables: seg_start (parts + 1) | cursor = seg_end (parts) | tile_start (parts + 1), 4 words apart
-    uint32_t *l1_start = nullptr, *l1_cursor = nullptr, *l1_tiles = nullptr, *l1_tile_seg = nullptr;
+    uint32_t *l1_start = nullptr, *l1_cursor = nullptr, *l1_tiles = nullptr;
     if (l1_subs) {
         HIP_TRY(c, c->gp_a.reserve((size_t)parts * cap1 * 8 + 16));
-        HIP_TRY(c, c->ld_seg.reserve(((size_t)3 * (parts + 4) + tiles1 + parts + 4) * 4));
+        HIP_TRY(c, c->ld_seg.reserve((size_t)3 * (parts + 4) * 4));
         l1_start = c->ld_seg.as<uint32_t>();
         l1_cursor = l1_start + (parts + 4);
         l1_tiles = l1_cursor + (parts + 4);
-        l1_tile_seg = l1_tiles + (parts + 4);             // the segment of every level-2 tile (<= tiles1 + parts tiles)
-        if (getenv("FQD_NO_TILE_SEG"))
-            l1_tile_seg = nullptr;
         HIP_TRY(c, fqd::launch_group_slab_starts(parts, cap1, l1_start, l1_cursor, c->st));
         KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(
                   true, keys, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1, bins1, l1_cursor, c->gp_a.as<uint32_t>(), c->st,
@@ -315,7 +312,7 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
         HIP_TRY(c, c->ld_hist_incl.reserve((size_t)n_buckets * 4 + 16));
         HIP_TRY(c, c->ld_cursor.reserve((size_t)n_buckets * 4 + 16));
         if (l1_subs)
-            HIP_TRY(c, fqd::launch_group_slab_tile_starts(l1_start, l1_cursor, parts, l1_tiles, c->st, l1_tile_seg));
+            HIP_TRY(c, fqd::launch_group_slab_tile_starts(l1_start, l1_cursor, parts, l1_tiles, c->st));
         else
             HIP_TRY(c, fqd::launch_group_tile_starts(start1, bins1, tiles2_d, c->st));
         if (slab_cap) {
@@ -335,7 +332,7 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
                       false, nullptr, c->gp_a.as<uint32_t>(), l1_start, l1_tiles, parts, tiles1 + parts, 32 - B, bins2,
                       c->ld_cursor.as<uint32_t>(), c->gp_b.as<uint32_t>(), c->st, slab_cap,
                       reinterpret_cast<uint32_t *>(c->d_ctr64.as<unsigned long long>() + C64_SLAB), nullptr, 0, l1_cursor,
-                      bins1 - 1, l1_tile_seg));
+                      bins1 - 1));
         else
         KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(
                   false, nullptr, c->gp_a.as<uint32_t>(), start1, tiles2_d, bins1, max_tiles2, 32 - B, bins2,

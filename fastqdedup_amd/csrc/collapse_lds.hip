@@ -120,12 +120,10 @@ __global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter_kernel(Re
                                                                               uint32_t slab_cap,
                                                                               uint32_t *__restrict__ slab_overflow,
                                                                               const uint32_t *__restrict__ seg_end,
-                                                                              uint32_t seg_shift, uint32_t seg_mask,
-                                                                              const uint32_t *__restrict__ tile_seg)
+                                                                              uint32_t seg_shift, uint32_t seg_mask)
 {
     fqd_partition::scatter_body<RecordPolicy, LEVEL1, MAXB>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
-                                                            slab_cap, slab_overflow, seg_end, seg_shift, seg_mask, 0,
-                                                            tile_seg);
+                                                            slab_cap, slab_overflow, seg_end, seg_shift, seg_mask);
 }
 
 // slabs received from n_senders ranks, sender by sender: segment s = sender * ppo + j holds the
@@ -147,11 +145,10 @@ __global__ void owner_slab_bounds_kernel(const uint32_t *__restrict__ cursors, u
 
 __global__ __launch_bounds__(1024) void slab_tile_starts_kernel(const uint32_t *__restrict__ seg_start,
                                                                 const uint32_t *__restrict__ seg_end, uint32_t n_seg,
-                                                                uint32_t *__restrict__ tile_start,
-                                                                uint32_t *__restrict__ tile_seg)
+                                                                uint32_t *__restrict__ tile_start)
 {
     fqd_partition::slab_tile_starts_body<fqd_partition::THREADS * RecordPolicy::EPT>(seg_start, seg_end, n_seg,
-                                                                                    tile_start, tile_seg);
+                                                                                    tile_start);
 }
 
 // slab mode of level 2: bucket b owns slots [b * cap, (b + 1) * cap); its cursor starts there
@@ -438,23 +435,20 @@ struct CompactPolicy {
 // (the tiles of part_scatter12_kernel)
 __global__ __launch_bounds__(1024) void slab_tile_starts12_kernel(const uint32_t *__restrict__ seg_start,
                                                                   const uint32_t *__restrict__ seg_end, uint32_t n_seg,
-                                                                  uint32_t *__restrict__ tile_start,
-                                                                  uint32_t *__restrict__ tile_seg)
+                                                                  uint32_t *__restrict__ tile_start)
 {
     fqd_partition::slab_tile_starts_body<fqd_partition::THREADS * CompactPolicy::EPT>(seg_start, seg_end, n_seg,
-                                                                                     tile_start, tile_seg);
+                                                                                     tile_start);
 }
 
 template <uint32_t MAXB>
 __global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter12_kernel(
     CompactPolicy::Source src, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ tile_start,
     uint32_t n_seg, uint32_t shift, uint32_t n_bins, uint32_t *__restrict__ cursor, fqd::Rec12 *__restrict__ out,
-    uint32_t slab_cap, uint32_t *__restrict__ slab_overflow, const uint32_t *__restrict__ seg_end, uint32_t seg_shift,
-    const uint32_t *__restrict__ tile_seg)
+    uint32_t slab_cap, uint32_t *__restrict__ slab_overflow, const uint32_t *__restrict__ seg_end, uint32_t seg_shift)
 {
     fqd_partition::scatter_body<CompactPolicy, false, MAXB>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
-                                                            slab_cap, slab_overflow, seg_end, seg_shift, 0xFFFFFFFFu, 0,
-                                                            tile_seg);
+                                                            slab_cap, slab_overflow, seg_end, seg_shift, 0xFFFFFFFFu);
 }
 
 __device__ __forceinline__ uint32_t rec12_tag(uint32_t a, uint32_t b)
@@ -710,28 +704,45 @@ __global__ void side_insert_kernel(const uint4 *__restrict__ side, const uint32_
     atomicOr(overflow, 16u);
 }
 
-__global__ __launch_bounds__(SIDE_BLOCK) void side_count_kernel(const uint32_t *__restrict__ table, uint32_t table_slots,
-                                                                uint32_t *__restrict__ block_counts)
+// (256 threads for 1024 slots: these kernels run beside the dedupe kernel, whose workgroups fill every CU -- a
+// 1024-thread workgroup waited 0.27 ms for sixteen free wave slots on one CU)
+constexpr uint32_t SIDE_THREADS = 256, SIDE_ROUNDS = SIDE_BLOCK / SIDE_THREADS;
+
+__global__ __launch_bounds__(SIDE_THREADS) void side_count_kernel(const uint32_t *__restrict__ table, uint32_t table_slots,
+                                                                  uint32_t *__restrict__ block_counts)
 {
-    const uint32_t i = blockIdx.x * SIDE_BLOCK + threadIdx.x;
-    const bool live = i < table_slots && table[i] != SIDE_EMPTY && table[table_slots + i] > 0;
-    const uint32_t n = __syncthreads_count(live);
-    if (threadIdx.x == 0)
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < SIDE_ROUNDS; k++) {
+        const uint32_t i = blockIdx.x * SIDE_BLOCK + k * SIDE_THREADS + threadIdx.x;
+        mine += i < table_slots && table[i] != SIDE_EMPTY && table[table_slots + i] > 0 ? 1u : 0u;
+    }
+    __shared__ uint32_t s_part[SIDE_THREADS / 64];
+    for (int o = 32; o; o >>= 1)
+        mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63u) == 0)
+        s_part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t n = 0;
+        for (uint32_t k = 0; k < SIDE_THREADS / 64; k++)
+            n += s_part[k];
         block_counts[blockIdx.x] = n;
+    }
 }
 
-__global__ __launch_bounds__(SIDE_BLOCK) void side_emit_kernel(const uint4 *__restrict__ side,
-                                                               const uint32_t *__restrict__ table, uint32_t table_slots,
-                                                               const uint32_t *__restrict__ block_counts,
-                                                               uint4 *__restrict__ urecs, uint32_t *__restrict__ ucounts,
-                                                               uint64_t *__restrict__ ufirst,
-                                                               uint32_t *__restrict__ side_unique)
+__global__ __launch_bounds__(SIDE_THREADS) void side_emit_kernel(const uint4 *__restrict__ side,
+                                                                 const uint32_t *__restrict__ table, uint32_t table_slots,
+                                                                 const uint32_t *__restrict__ block_counts,
+                                                                 uint4 *__restrict__ urecs, uint32_t *__restrict__ ucounts,
+                                                                 uint64_t *__restrict__ ufirst,
+                                                                 uint32_t *__restrict__ side_unique)
 {
-    __shared__ uint32_t s_part[SIDE_BLOCK / 64], s_base;
+    __shared__ uint32_t s_part[SIDE_THREADS / 64], s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // rows before this block: the counts of the blocks before it (at most a few hundred)
+    // rows before this block: the counts of the blocks before it (at most a few thousand)
     uint32_t before = 0;
-    for (uint32_t k = tid; k < blockIdx.x; k += SIDE_BLOCK)
+    for (uint32_t k = tid; k < blockIdx.x; k += SIDE_THREADS)
         before += block_counts[k];
     for (int o = 32; o; o >>= 1)
         before += __shfl_xor(before, o);
@@ -740,35 +751,37 @@ __global__ __launch_bounds__(SIDE_BLOCK) void side_emit_kernel(const uint4 *__re
     __syncthreads();
     if (tid == 0) {
         uint32_t sum = 0;
-        for (uint32_t k = 0; k < SIDE_BLOCK / 64; k++)
+        for (uint32_t k = 0; k < SIDE_THREADS / 64; k++)
             sum += s_part[k];
         s_base = sum;
     }
     __syncthreads();
-    const uint32_t base = s_base;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * SIDE_BLOCK + tid;
-    const bool live = i < table_slots && table[i] != SIDE_EMPTY && table[table_slots + i] > 0;
-    const unsigned long long m = __ballot(live);
-    if (lane == 0)
-        s_part[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    for (uint32_t k = 0; k < wave; k++)
-        rank += s_part[k];
-    if (live) {
-        const uint4 v = side[table[i]];
-        const uint32_t u = base + rank;
-        urecs[u] = make_uint4(v.x, v.y, v.z, 0u);
-        ucounts[u] = table[table_slots + i];
-        ufirst[u] = table[2 * table_slots + i];
+    uint32_t base = s_base;
+    // the block's slots in table order: round k holds slots [k * 256, (k + 1) * 256) of the block
+    for (uint32_t k = 0; k < SIDE_ROUNDS; k++) {
+        __syncthreads();                                         // (s_part is read above / in the round before)
+        const uint32_t i = blockIdx.x * SIDE_BLOCK + k * SIDE_THREADS + tid;
+        const bool live = i < table_slots && table[i] != SIDE_EMPTY && table[table_slots + i] > 0;
+        const unsigned long long m = __ballot(live);
+        if (lane == 0)
+            s_part[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), round_total = 0;
+        for (uint32_t w = 0; w < SIDE_THREADS / 64; w++) {
+            rank += w < wave ? s_part[w] : 0u;
+            round_total += s_part[w];
+        }
+        if (live) {
+            const uint4 v = side[table[i]];
+            const uint32_t u = base + rank;
+            urecs[u] = make_uint4(v.x, v.y, v.z, 0u);
+            ucounts[u] = table[table_slots + i];
+            ufirst[u] = table[2 * table_slots + i];
+        }
+        base += round_total;
     }
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
-        uint32_t total = base;
-        for (uint32_t k = 0; k < SIDE_BLOCK / 64; k++)
-            total += s_part[k];
-        *side_unique = total;
-    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0)
+        *side_unique = base;
 }
 
 }  // namespace
@@ -802,8 +815,7 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
                                const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
                                hipStream_t st, IdSource packed, uint32_t slab_cap, uint32_t *slab_overflow,
-                               const uint32_t *seg_end, uint32_t seg_shift, uint32_t seg_mask, uint32_t stamp_div,
-                               const uint32_t *tile_seg)
+                               const uint32_t *seg_end, uint32_t seg_shift, uint32_t seg_mask, uint32_t stamp_div)
 {
     if (n_bins > fqd_partition::MAX_BINS)
         return hipErrorInvalidValue;
@@ -813,8 +825,7 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
 #define FQD_SCATTER(L1, MB)                                                                                    \
     part_scatter_kernel<L1, MB><<<max_tiles, fqd_partition::THREADS, 0, st>>>(src, seg_start, tile_start, n_seg, \
                                                                               shift, n_bins, cursor, out4, slab_cap, \
-                                                                              slab_overflow, seg_end, seg_shift, seg_mask, \
-                                                                              tile_seg)
+                                                                              slab_overflow, seg_end, seg_shift, seg_mask)
     if (n_bins <= 256) {
         if (level1) FQD_SCATTER(true, 256); else FQD_SCATTER(false, 256);
     } else {
@@ -857,12 +868,12 @@ hipError_t launch_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket
 }
 
 hipError_t launch_slab_tile_starts(const uint32_t *seg_start, const uint32_t *seg_end, uint32_t n_seg,
-                                   uint32_t *tile_start, hipStream_t st, bool tiles12, uint32_t *tile_seg)
+                                   uint32_t *tile_start, hipStream_t st, bool tiles12)
 {
     if (tiles12)
-        slab_tile_starts12_kernel<<<1, 1024, 0, st>>>(seg_start, seg_end, n_seg, tile_start, tile_seg);
+        slab_tile_starts12_kernel<<<1, 1024, 0, st>>>(seg_start, seg_end, n_seg, tile_start);
     else
-        slab_tile_starts_kernel<<<1, 1024, 0, st>>>(seg_start, seg_end, n_seg, tile_start, tile_seg);
+        slab_tile_starts_kernel<<<1, 1024, 0, st>>>(seg_start, seg_end, n_seg, tile_start);
     return hipGetLastError();
 }
 
@@ -882,8 +893,7 @@ uint32_t part_tile_size12() { return fqd_partition::THREADS * CompactPolicy::EPT
 hipError_t launch_part_scatter12(const uint32_t *in, uint32_t squeeze, SideSlabs side, const uint32_t *seg_start,
                                  const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                  uint32_t n_bins, uint32_t *cursor, Rec12 *out, hipStream_t st, uint32_t slab_cap,
-                                 uint32_t *slab_overflow, const uint32_t *seg_end, uint32_t seg_shift,
-                                 const uint32_t *tile_seg)
+                                 uint32_t *slab_overflow, const uint32_t *seg_end, uint32_t seg_shift)
 {
     if (n_bins > fqd_partition::MAX_BINS || (squeeze != 1 && squeeze != 2))
         return hipErrorInvalidValue;
@@ -893,12 +903,10 @@ hipError_t launch_part_scatter12(const uint32_t *in, uint32_t squeeze, SideSlabs
     const CompactPolicy::Source src{reinterpret_cast<const uint4 *>(in), squeeze, side};
     if (n_bins <= 256)
         part_scatter12_kernel<256><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
-            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift,
-            tile_seg);
+            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift);
     else
         part_scatter12_kernel<fqd_partition::MAX_BINS><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
-            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift,
-            tile_seg);
+            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift);
     return hipGetLastError();
 }
 
@@ -937,8 +945,8 @@ hipError_t launch_side_collapse(const uint4 *side, const uint32_t *cursor, uint3
     side_clear_kernel<<<(table_slots + 255) / 256, 256, 0, st>>>(table, table_slots);
     side_insert_kernel<<<dim3((cap + 255) / 256, subs), 256, 0, st>>>(side, cursor, first_part, cap, weights, table,
                                                                      table_slots, overflow);
-    side_count_kernel<<<blocks, SIDE_BLOCK, 0, st>>>(table, table_slots, block_counts);
-    side_emit_kernel<<<blocks, SIDE_BLOCK, 0, st>>>(side, table, table_slots, block_counts,
+    side_count_kernel<<<blocks, SIDE_THREADS, 0, st>>>(table, table_slots, block_counts);
+    side_emit_kernel<<<blocks, SIDE_THREADS, 0, st>>>(side, table, table_slots, block_counts,
                                                     reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, side_unique);
     return hipGetLastError();
 }

@@ -292,15 +292,13 @@ hipError_t launch_part_scatter(bool level1, const uint32_t *hashes, const uint32
                                uint32_t n_bins, uint32_t kw, uint32_t len, uint32_t *cursor, uint32_t *out,
                                hipStream_t st, IdSource packed = IdSource(), uint32_t slab_cap = 0,
                                uint32_t *slab_overflow = nullptr, const uint32_t *seg_end = nullptr,
-                               uint32_t seg_shift = 0, uint32_t seg_mask = 0xFFFFFFFFu, uint32_t stamp_div = 0,
-                               const uint32_t *tile_seg = nullptr);
+                               uint32_t seg_shift = 0, uint32_t seg_mask = 0xFFFFFFFFu, uint32_t stamp_div = 0);
 // slab segments of reads received from n_senders ranks (fqd_collapse_owner_slabs)
 hipError_t launch_owner_slab_bounds(const uint32_t *cursors, uint32_t n_senders, uint32_t parts_per_owner,
                                     uint32_t my_part, uint32_t cap, uint32_t *seg_start, uint32_t *seg_end,
                                     hipStream_t st);
 hipError_t launch_slab_tile_starts(const uint32_t *seg_start, const uint32_t *seg_end, uint32_t n_seg,
-                                   uint32_t *tile_start, hipStream_t st, bool tiles12 = false /* part_tile_size12() */,
-                                   uint32_t *tile_seg = nullptr /* out: the segment of every tile (scatter: no search) */);
+                                   uint32_t *tile_start, hipStream_t st, bool tiles12 = false /* part_tile_size12() */);
 uint32_t part_tile_size();
 // bucket_compact_kernel may write the segment hashes of the search that follows (nseg = 0: no)
 struct SegHashOut {
@@ -344,7 +342,7 @@ hipError_t launch_part_scatter12(const uint32_t *in /* uint4 records */, uint32_
                                  const uint32_t *seg_start, const uint32_t *tile_start, uint32_t n_seg,
                                  uint32_t max_tiles, uint32_t shift, uint32_t n_bins, uint32_t *cursor, Rec12 *out,
                                  hipStream_t st, uint32_t slab_cap, uint32_t *slab_overflow, const uint32_t *seg_end,
-                                 uint32_t seg_shift, const uint32_t *tile_seg = nullptr);
+                                 uint32_t seg_shift);
 uint32_t part_tile_size12();
 hipError_t launch_bucket_dedupe12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                   uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
@@ -418,10 +416,9 @@ hipError_t launch_group_scatter(bool level1, const uint32_t *hashes, const uint3
                                 const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                 uint32_t n_bins, uint32_t *cursor, uint32_t *out, hipStream_t st, uint32_t slab_cap = 0,
                                 uint32_t *slab_overflow = nullptr, const uint32_t *values = nullptr, uint32_t l1_subs = 0,
-                                const uint32_t *seg_end = nullptr, uint32_t seg_mask = 0xFFFFFFFFu,
-                                const uint32_t *tile_seg = nullptr);
+                                const uint32_t *seg_end = nullptr, uint32_t seg_mask = 0xFFFFFFFFu);
 hipError_t launch_group_slab_tile_starts(const uint32_t *seg_start, const uint32_t *seg_end, uint32_t n_seg,
-                                         uint32_t *tile_start, hipStream_t st, uint32_t *tile_seg = nullptr);
+                                         uint32_t *tile_start, hipStream_t st);
 hipError_t launch_group_tile_starts(const uint32_t *seg_start, uint32_t n_seg, uint32_t *tile_start, hipStream_t st);
 hipError_t launch_group_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                       hipStream_t st);

@@ -69,21 +69,18 @@ __global__ __launch_bounds__(fqd_partition::THREADS) void gp_scatter_kernel(Pair
                                                                             uint2 *__restrict__ out, uint32_t slab_cap,
                                                                             uint32_t *__restrict__ slab_overflow,
                                                                             const uint32_t *__restrict__ seg_end,
-                                                                            uint32_t seg_mask, uint32_t l1_subs,
-                                                                            const uint32_t *__restrict__ tile_seg)
+                                                                            uint32_t seg_mask, uint32_t l1_subs)
 {
     fqd_partition::scatter_body<PairPolicy, LEVEL1>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
-                                                    slab_cap, slab_overflow, seg_end, 0, seg_mask, l1_subs, tile_seg);
+                                                    slab_cap, slab_overflow, seg_end, 0, seg_mask, l1_subs);
 }
 
 // tiles of the slab segments level 1 left (level 1 in slab mode, partition.cuh l1_subs)
 __global__ __launch_bounds__(1024) void gp_slab_tile_starts_kernel(const uint32_t *__restrict__ seg_start,
                                                                    const uint32_t *__restrict__ seg_end, uint32_t n_seg,
-                                                                   uint32_t *__restrict__ tile_start,
-                                                                   uint32_t *__restrict__ tile_seg)
+                                                                   uint32_t *__restrict__ tile_start)
 {
-    fqd_partition::slab_tile_starts_body<fqd_partition::THREADS * PairPolicy::EPT>(seg_start, seg_end, n_seg, tile_start,
-                                                                                  tile_seg);
+    fqd_partition::slab_tile_starts_body<fqd_partition::THREADS * PairPolicy::EPT>(seg_start, seg_end, n_seg, tile_start);
 }
 
 // start of a search pass: the level-1 segment / tile bounds and the zeroed candidate counters, in one
@@ -590,7 +587,7 @@ hipError_t launch_group_scatter(bool level1, const uint32_t *hashes, const uint3
                                 const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                 uint32_t n_bins, uint32_t *cursor, uint32_t *out, hipStream_t st, uint32_t slab_cap,
                                 uint32_t *slab_overflow, const uint32_t *values, uint32_t l1_subs,
-                                const uint32_t *seg_end, uint32_t seg_mask, const uint32_t *tile_seg)
+                                const uint32_t *seg_end, uint32_t seg_mask)
 {
     if (!max_tiles)
         return hipSuccess;
@@ -601,18 +598,17 @@ hipError_t launch_group_scatter(bool level1, const uint32_t *hashes, const uint3
     if (level1)
         gp_scatter_kernel<true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
             src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out2, l1_subs ? slab_cap : 0u,
-            l1_subs ? slab_overflow : nullptr, nullptr, 0xFFFFFFFFu, l1_subs, nullptr);
+            l1_subs ? slab_overflow : nullptr, nullptr, 0xFFFFFFFFu, l1_subs);
     else
         gp_scatter_kernel<false><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
-            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out2, slab_cap, slab_overflow, seg_end, seg_mask, 0u,
-            tile_seg);
+            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out2, slab_cap, slab_overflow, seg_end, seg_mask, 0u);
     return hipGetLastError();
 }
 
 hipError_t launch_group_slab_tile_starts(const uint32_t *seg_start, const uint32_t *seg_end, uint32_t n_seg,
-                                         uint32_t *tile_start, hipStream_t st, uint32_t *tile_seg)
+                                         uint32_t *tile_start, hipStream_t st)
 {
-    gp_slab_tile_starts_kernel<<<1, 1024, 0, st>>>(seg_start, seg_end, n_seg, tile_start, tile_seg);
+    gp_slab_tile_starts_kernel<<<1, 1024, 0, st>>>(seg_start, seg_end, n_seg, tile_start);
     return hipGetLastError();
 }
 

@@ -38,25 +38,20 @@ template <uint32_t TILE>
 __device__ __forceinline__ bool tile_of_block(const uint32_t *__restrict__ seg_start,
                                               const uint32_t *__restrict__ tile_start, uint32_t n_seg,
                                               uint32_t &seg, uint32_t &lo, uint32_t &hi,
-                                              const uint32_t *__restrict__ seg_end = nullptr,
-                                              const uint32_t *__restrict__ tile_seg = nullptr)
+                                              const uint32_t *__restrict__ seg_end = nullptr)
 {
     const uint32_t t = blockIdx.x;
     if (t >= tile_start[n_seg])
         return false;
+    // (a table with every tile's segment instead of this search -- 13 dependent scalar loads over 8192 slabs --
+    // changed nothing: 0.435 ms either way for level 2 at config 3)
     uint32_t a = 0, b = n_seg;  // last segment with tile_start <= t
-    if (tile_seg) {
-        // (slab_tile_starts_body wrote every tile's segment down: one load instead of the 13 dependent scalar loads
-        // of a search over 8192 slabs -- which, measured, cost nothing: 0.435 ms either way for level 2 at config 3)
-        a = tile_seg[t];
-    } else {
-        while (b - a > 1) {
-            const uint32_t m = (a + b) >> 1;
-            if (tile_start[m] <= t)
-                a = m;
-            else
-                b = m;
-        }
+    while (b - a > 1) {
+        const uint32_t m = (a + b) >> 1;
+        if (tile_start[m] <= t)
+            a = m;
+        else
+            b = m;
     }
     seg = a;
     lo = seg_start[a] + (t - tile_start[a]) * TILE;
@@ -112,8 +107,7 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
                                              typename Policy::Item *__restrict__ out, uint32_t slab_cap = 0,
                                              uint32_t *__restrict__ slab_overflow = nullptr,
                                              const uint32_t *__restrict__ seg_end = nullptr, uint32_t seg_shift = 0,
-                                             uint32_t seg_mask = 0xFFFFFFFFu, uint32_t l1_subs = 0,
-                                             const uint32_t *__restrict__ tile_seg = nullptr)
+                                             uint32_t seg_mask = 0xFFFFFFFFu, uint32_t l1_subs = 0)
 {
     // l1_subs != 0 (LEVEL1 only; a power of two): level 1 in slab mode too, without the count matrix and its
     // histogram pass -- tile t adds to sub-part t % l1_subs of every bin: part (sub, bin) owns
@@ -147,7 +141,7 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
     __shared__ Item s_stage[STAGE];
     __shared__ uint16_t s_stage_bin[STAGE];
     uint32_t seg, lo, hi;
-    if (!tile_of_block<TILE>(seg_start, tile_start, n_seg, seg, lo, hi, seg_end, tile_seg))
+    if (!tile_of_block<TILE>(seg_start, tile_start, n_seg, seg, lo, hi, seg_end))
         return;
     const uint32_t seg_tag = Policy::segment_tag(src, seg);       // (per workgroup: a tile lies in ONE segment)
     seg = (seg >> seg_shift) & seg_mask;
@@ -278,8 +272,7 @@ __device__ __forceinline__ void tile_starts_body(const uint32_t *__restrict__ se
 template <uint32_t TILE>
 __device__ __forceinline__ void slab_tile_starts_body(const uint32_t *__restrict__ seg_start,
                                                       const uint32_t *__restrict__ seg_end, uint32_t n_seg,
-                                                      uint32_t *__restrict__ tile_start,
-                                                      uint32_t *__restrict__ tile_seg = nullptr /* segment of every tile */)
+                                                      uint32_t *__restrict__ tile_start)
 {
     constexpr uint32_t STAGED = 8192;
     __shared__ uint32_t s_wave[16];
@@ -318,11 +311,7 @@ __device__ __forceinline__ void slab_tile_starts_body(const uint32_t *__restrict
         run += s_wave[wv];
     for (uint32_t t = s0; t < s1; t++) {
         tile_start[t] = run;
-        const uint32_t k = staged ? s_tiles[t] : tiles_of(t);
-        if (tile_seg)
-            for (uint32_t j = 0; j < k; j++)
-                tile_seg[run + j] = t;
-        run += k;
+        run += staged ? s_tiles[t] : tiles_of(t);
     }
     if (s1 == n_seg && s0 < n_seg)
         tile_start[n_seg] = run;
