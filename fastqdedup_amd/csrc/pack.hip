@@ -19,7 +19,7 @@
 #include "fqd_internal.h"
 
 #ifndef FQD_PACK_NSUB
-#define FQD_PACK_NSUB 2   // tiles per workgroup of the fused pack (1: 0.56-0.58 ms at config 3, 2: 0.51-0.52)
+#define FQD_PACK_NSUB 2   // tiles per workgroup of the fused pack (config 3: 1: 0.56-0.58 ms, 2: 0.51-0.52, 3: 0.58 -- 107 VGPRs)
 #endif
 namespace {
 
