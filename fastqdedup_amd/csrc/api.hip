@@ -125,6 +125,11 @@ struct FusedLevel1 {
     // take the side path (c->ld_side / c->ld_side_table, sized by the caller: side_slabs x side_cap records, a
     // hash table of side_slots slots)
     uint32_t compact = 0, side_slabs = 0, side_cap = 0, side_slots = 0;
+    uint32_t slab_cap1 = 0;    // the capacity of every level-1 slab when they all have one (the pack kernel's own slabs)
+    // the caller has queued the slab starts of level 2 (c->ld_start / c->ld_cursor for 2^B buckets of the capacity
+    // collapse_lds computes) and of the side path already -- fqd_cluster_keys does, BEFORE the pack kernel, so that
+    // nothing but the pack kernel stands between the key bytes and level 2
+    bool starts_ready = false;
 };
 
 // Bucket bits of the LDS collapse for n reads: ~400-800 reads per bucket (2x fewer workgroups than
@@ -238,13 +243,20 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
             HIP_TRY(c, hipMemcpyAsync(c->ld_start.p, start1, ((size_t)bins1 + 1) * 4, hipMemcpyDeviceToDevice, c->st));
         } else {
             // ---- level 2: every part into 2^B2 buckets by the next B2 hash bits
-            if (fused)     // (the pack kernel left seg_start / seg_end = cursors there; received slabs: the caller did)
+            // (the pack kernel left seg_start / seg_end = cursors there; received slabs: the caller did.)
+            // Slabs of one capacity (fqd_cluster_keys): no tile table -- every slab gets the tiles a full one has
+            const uint32_t f_cap = fused && !fused->tables_ready ? fused->slab_cap1 : 0u;
+            const uint32_t f_grid = f_cap ? f_parts * ((f_cap + tile - 1) / tile) : tiles1 + f_parts;
+            if (fused && f_cap)
+                f_tiles = nullptr;
+            else if (fused)
                 HIP_TRY(c, fqd::launch_slab_tile_starts(f_seg_start, f_seg_end, f_parts, f_tiles, c->st, compact != 0));
             else
                 HIP_TRY(c, fqd::launch_tile_starts(start1, bins1, tiles2_d, c->st));
             if (slab_cap) {
-                HIP_TRY(c, fqd::launch_slab_starts(n_buckets, slab_cap, c->ld_start.as<uint32_t>(),
-                                                   c->ld_cursor.as<uint32_t>(), c->st));
+                if (!(fused && fused->starts_ready))
+                    HIP_TRY(c, fqd::launch_slab_starts(n_buckets, slab_cap, c->ld_start.as<uint32_t>(),
+                                                       c->ld_cursor.as<uint32_t>(), c->st));
                 bucket_end = c->ld_cursor.as<uint32_t>();
             } else {
                 HIP_TRY(c, hipMemsetAsync(c->ld_hist.p, 0, (size_t)n_buckets * 4, c->st));
@@ -255,11 +267,11 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                                                      c->ld_cursor.as<uint32_t>(), c->st));
             }
             if (compact) {
-                if (compact == 1)
+                if (compact == 1 && !fused->starts_ready)
                     HIP_TRY(c, fqd::launch_slab_starts(side.n_slabs, side.cap, side.cursor + side.n_slabs, side.cursor,
                                                        c->st));
                 KTIME(c, FQD_K_PART_SCATTER12, fqd::launch_part_scatter12(
-                          c->ld_part.as<uint32_t>(), compact, side, f_seg_start, f_tiles, f_parts, tiles1 + f_parts,
+                          c->ld_part.as<uint32_t>(), compact, side, f_seg_start, f_tiles, f_parts, f_grid,
                           32 - B, bins2, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<fqd::Rec12>(), c->st, slab_cap,
                           c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end, fused->sub_bits));
                 // the keys with an N: collapsed apart, to the head of the unique table (few: a table in global
@@ -278,7 +290,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 }
             } else if (fused)
                 KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(
-                          false, nullptr, c->ld_part.as<uint32_t>(), f_seg_start, f_tiles, f_parts, tiles1 + f_parts,
+                          false, nullptr, c->ld_part.as<uint32_t>(), f_seg_start, f_tiles, f_parts, f_grid,
                           32 - B, bins2, kw, sh.max_len, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<uint32_t>(), c->st,
                           fused->stamp_div ? d_ids : IdSource(), slab_cap, c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end,
                           fused->sub_bits, fused->part_mask, fused->stamp_div));
@@ -1010,7 +1022,6 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     HIP_TRY(c, c->ld_seg.reserve((size_t)3 * (parts + 4) * 4));
     uint32_t *seg_start = c->ld_seg.as<uint32_t>(), *cursor = seg_start + (parts + 4);
     FQD_TRY(zero_ctr32(c, 0, C_N32));
-    HIP_TRY(c, fqd::launch_slab_starts(parts, cap1, seg_start, cursor, c->st));
     const fqd::PackScatter fs{cursor, reinterpret_cast<uint4 *>(c->ld_part.p), c->d_ctr32.as<uint32_t>() + C_BAD,
                               32 - l1_bits, 1u << l1_bits, 1u << sub_bits, cap1};
     if (compact == 1) {
@@ -1020,6 +1031,24 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
         HIP_TRY(c, c->urecs.reserve(n * 16 + 16));
         HIP_TRY(c, c->ucounts.reserve(n * 4 + 16));
         HIP_TRY(c, c->ufirst.reserve(n * 8 + 16));
+    }
+    // the slab starts of the pack kernel's parts and, ahead of the pack, of level 2 (the geometry collapse_lds will
+    // compute) and of the side path: one launch
+    bool starts_ready = false;
+    {
+        const uint32_t n_buckets = 1u << B;
+        const uint32_t slab_cap2 = (uint32_t)(((n >> B) * 3 / 2 + 64 + 3) & ~3ull);
+        uint32_t *tail = compact == 1 ? c->ld_side_table.as<uint32_t>() + fqd::side_table_words(side_slots) : nullptr;
+        if ((uint64_t)slab_cap2 * n_buckets + n < 0xFFFFFF00ull) {
+            HIP_TRY(c, c->ld_start.reserve(((size_t)n_buckets + 1) * 4 + 16));
+            HIP_TRY(c, c->ld_cursor.reserve((size_t)n_buckets * 4 + 1024 * 4));
+            HIP_TRY(c, fqd::launch_slab_starts3(parts, cap1, seg_start, cursor, n_buckets, slab_cap2,
+                                                c->ld_start.as<uint32_t>(), c->ld_cursor.as<uint32_t>(), side_slabs, side_cap,
+                                                tail ? tail + side_slabs : nullptr, tail, c->st));
+            starts_ready = true;
+        } else {
+            HIP_TRY(c, fqd::launch_slab_starts(parts, cap1, seg_start, cursor, c->st));
+        }
     }
     {
         StageTimer kernel_timer(c, FQD_T_PACK_KERNEL);
@@ -1041,6 +1070,8 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     FusedLevel1 f{parts, sub_bits, B};
     f.level1_bits = l1_bits;
     f.part_mask = (1u << l1_bits) - 1;
+    f.slab_cap1 = cap1;
+    f.starts_ready = starts_ready;
     f.compact = compact;
     f.side_slabs = side_slabs;
     f.side_cap = side_cap;

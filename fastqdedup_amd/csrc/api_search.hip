@@ -285,7 +285,10 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
         l1_start = c->ld_seg.as<uint32_t>();
         l1_cursor = l1_start + (parts + 4);
         l1_tiles = l1_cursor + (parts + 4);
-        HIP_TRY(c, fqd::launch_group_slab_starts(parts, cap1, l1_start, l1_cursor, c->st));
+        // the slab starts of both levels in one launch, ahead of level 1 (l1_subs implies slab mode at level 2)
+        HIP_TRY(c, c->ld_cursor.reserve((size_t)n_buckets * 4 + 16));
+        HIP_TRY(c, fqd::launch_slab_starts3(parts, cap1, l1_start, l1_cursor, n_buckets, slab_cap, c->ld_start.as<uint32_t>(),
+                                            c->ld_cursor.as<uint32_t>(), 0, 0, nullptr, nullptr, c->st));
         KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(
                   true, keys, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1, bins1, l1_cursor, c->gp_a.as<uint32_t>(), c->st,
                   cap1, reinterpret_cast<uint32_t *>(c->d_ctr64.as<unsigned long long>() + C64_SLAB), values, l1_subs));
@@ -316,8 +319,9 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
         else
             HIP_TRY(c, fqd::launch_group_tile_starts(start1, bins1, tiles2_d, c->st));
         if (slab_cap) {
-            HIP_TRY(c, fqd::launch_group_slab_starts(n_buckets, slab_cap, c->ld_start.as<uint32_t>(),
-                                                     c->ld_cursor.as<uint32_t>(), c->st));
+            if (!l1_subs)
+                HIP_TRY(c, fqd::launch_group_slab_starts(n_buckets, slab_cap, c->ld_start.as<uint32_t>(),
+                                                         c->ld_cursor.as<uint32_t>(), c->st));
             bucket_end = c->ld_cursor.as<uint32_t>();
         } else {
             HIP_TRY(c, hipMemsetAsync(c->ld_hist.p, 0, (size_t)n_buckets * 4, c->st));

@@ -21,6 +21,7 @@
 // million copies makes one long bucket (slow for that workgroup, still exact); a bucket
 // with more distinct keys than the table holds raises `overflow` and the caller falls
 // back to the sort-based collapse.
+#include <algorithm>
 #include "fqd_internal.h"
 #include "partition.cuh"
 
@@ -152,6 +153,26 @@ __global__ __launch_bounds__(1024) void slab_tile_starts_kernel(const uint32_t *
 }
 
 // slab mode of level 2: bucket b owns slots [b * cap, (b + 1) * cap); its cursor starts there
+// three slab sets at once (the pack kernel's parts, level 2's buckets, the side path's slabs: one launch at the head
+// of fqd_cluster_keys instead of three)
+struct SlabSet {
+    uint32_t n, cap;
+    uint32_t *start, *cursor;
+};
+__global__ void slab_starts3_kernel(SlabSet a, SlabSet b, SlabSet c3)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const SlabSet sets[3] = {a, b, c3};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (sets[k].start && i <= sets[k].n) {
+            sets[k].start[i] = i * sets[k].cap;
+            if (i < sets[k].n)
+                sets[k].cursor[i] = i * sets[k].cap;
+        }
+    }
+}
+
 __global__ void slab_starts_kernel(uint32_t n_buckets, uint32_t cap, uint32_t *__restrict__ bucket_start,
                                    uint32_t *__restrict__ cursor)
 {
@@ -858,6 +879,17 @@ hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, u
                                 uint32_t *cursor, hipStream_t st)
 {
     bucket_starts_kernel<<<(n_buckets + 1 + 255) / 256, 256, 0, st>>>(hist_incl, n_buckets, bucket_start, cursor);
+    return hipGetLastError();
+}
+
+hipError_t launch_slab_starts3(uint32_t n1, uint32_t cap1, uint32_t *start1, uint32_t *cursor1, uint32_t n2, uint32_t cap2,
+                               uint32_t *start2, uint32_t *cursor2, uint32_t n3, uint32_t cap3, uint32_t *start3,
+                               uint32_t *cursor3, hipStream_t st)
+{
+    const uint32_t most = std::max(n1, std::max(start2 ? n2 : 0u, start3 ? n3 : 0u));
+    slab_starts3_kernel<<<(most + 1 + 255) / 256, 256, 0, st>>>(SlabSet{n1, cap1, start1, cursor1},
+                                                               SlabSet{n2, cap2, start2, cursor2},
+                                                               SlabSet{n3, cap3, start3, cursor3});
     return hipGetLastError();
 }
 

@@ -322,6 +322,10 @@ hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, ui
 hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
                                 uint32_t *cursor, hipStream_t st);
 hipError_t launch_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket_start, uint32_t *cursor, hipStream_t st);
+// up to three slab sets in one launch (start2 / start3 NULL: fewer)
+hipError_t launch_slab_starts3(uint32_t n1, uint32_t cap1, uint32_t *start1, uint32_t *cursor1, uint32_t n2, uint32_t cap2,
+                               uint32_t *start2, uint32_t *cursor2, uint32_t n3, uint32_t cap3, uint32_t *start3,
+                               uint32_t *cursor3, hipStream_t st);
 hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                 uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec, uint32_t *tmp_count,
                                 uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);

@@ -41,6 +41,23 @@ __device__ __forceinline__ bool tile_of_block(const uint32_t *__restrict__ seg_s
                                               const uint32_t *__restrict__ seg_end = nullptr)
 {
     const uint32_t t = blockIdx.x;
+    if (!tile_start) {
+        // slab segments of one capacity, no tile table: the grid is n_seg x (tiles a full slab has), a workgroup
+        // whose tile lies behind its slab's cursor leaves at once. Worth it where slabs usually hold several tiles
+        // (the collapse: 3 of 4; no single-workgroup kernel and its hand-overs between the pack and level 2); where
+        // a second tile is rare (the search: 8192 empty workgroups, each holding 52 KB of LDS for ~2 us) it cost
+        // 0.06 ms, and one workgroup per slab looping over its tiles doubled the registers of this function.
+        const uint32_t per = gridDim.x / n_seg;
+        seg = t / per;
+        lo = seg_start[seg] + (t - seg * per) * TILE;
+        hi = seg_start[seg + 1];
+        if (seg_end)
+            hi = min(hi, seg_end[seg]);
+        if (lo >= hi)
+            return false;
+        hi = min(lo + TILE, hi);
+        return true;
+    }
     if (t >= tile_start[n_seg])
         return false;
     // (a table with every tile's segment instead of this search -- 13 dependent scalar loads over 8192 slabs --
