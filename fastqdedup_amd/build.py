@@ -1,5 +1,7 @@
 """Builds ``libfqdedup_hip.so`` in-tree with hipcc for gfx950 (cross-compiles
-without a GPU). ``python -m fastqdedup_amd.build`` or ``__graft_entry__.build()``."""
+without a GPU). ``python -m fastqdedup_amd.build`` or ``__graft_entry__.build()``.
+``FQD_EXTRA_FLAGS`` adds compiler flags (the tile-shape experiments: ``-DFQD_PACK_NSUB=3``,
+``-DFQD_SCATTER12_EPT=16 -DFQD_SCATTER12_ROUNDS=2``; touch the source to rebuild it)."""
 from __future__ import annotations
 
 import os

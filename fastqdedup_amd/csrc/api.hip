@@ -981,10 +981,12 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     // reads: up to 16 sub-parts per bin the tiles queue on the part cursors and the kernel takes
     // 1.0 ms; from 32 on, 0.55-0.6 ms.)
     uint32_t l1_bits = 8, sub_bits = 5;
-    if (const char *e = getenv("FQD_EXP_L1_BITS"))
-        l1_bits = (uint32_t)atoi(e);
-    if (const char *e = getenv("FQD_EXP_SUB_BITS"))
-        sub_bits = (uint32_t)atoi(e);
+    if (const char *e = getenv("FQD_FUSED_L1_BITS"))       // (experiments: 128 bins make the pack faster and level 2 slower)
+        l1_bits = (uint32_t)std::max(4, std::min(8, atoi(e)));
+    if (const char *e = getenv("FQD_FUSED_SUB_BITS"))
+        sub_bits = (uint32_t)std::max(0, std::min(6, atoi(e)));
+    if (B > l1_bits + 10)                                  // level 2 has at most 1024 bins
+        l1_bits = B - 10;
     const uint32_t parts = (1u << l1_bits) << sub_bits;
     const uint32_t cap1 = (uint32_t)(((n / parts) * 5 / 4 + 256 + 3) & ~3ull);
     if ((uint64_t)parts * cap1 + n >= 0xFFFFFF00ull)
