@@ -320,6 +320,9 @@ class _Comm:
     def __init__(self, group, device, via_host=False, lib_streams=None):
         self.group, self.device, self.via_host = group, device, via_host
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        # one rank: every collective is the identity -- unless FQD_COMM_NO_SHORTCUT=1 sends it through the backend
+        # anyway (a rehearsal of the RCCL calls and of their stream ordering on a one-GPU box)
+        self.alone = self.world == 1 and not os.environ.get("FQD_COMM_NO_SHORTCUT")
         # callable -> the library contexts' streams (the second context appears on first use)
         self.lib_streams = lib_streams if (device.type == "cuda" and not via_host) else None
 
@@ -345,7 +348,7 @@ class _Comm:
 
     def all_gather_ints(self, values) -> np.ndarray:
         """(world, len(values)) int64 on the host."""
-        if self.world == 1:
+        if self.alone:
             return np.array([[int(v) for v in values]], dtype=np.int64)
         wire_dev = torch.device("cpu") if self.via_host else self.device
         mine = torch.tensor(list(values), dtype=torch.int64, device=wire_dev)
@@ -355,7 +358,7 @@ class _Comm:
 
     def any_flag(self, flag: bool) -> bool:
         """True when any rank raises the flag (a one-word all-reduce)."""
-        if self.world == 1:
+        if self.alone:
             return bool(flag)
         wire_dev = torch.device("cpu") if self.via_host else self.device
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=wire_dev)
@@ -363,14 +366,14 @@ class _Comm:
         return bool(int(t.item()))
 
     def all_reduce_max(self, x: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if self.alone:
             return x
         w = self._wire(x)
         dist.all_reduce(w, op=dist.ReduceOp.MAX, group=self.group)
         return self._back(w)
 
     def exchange_counts(self, send_counts) -> list:
-        if self.world == 1:
+        if self.alone:
             return [int(c) for c in send_counts]
         wire_dev = torch.device("cpu") if self.via_host else self.device
         s = torch.tensor([int(c) for c in send_counts], dtype=torch.int64, device=wire_dev)
@@ -382,7 +385,7 @@ class _Comm:
         """all-to-all(v) of the rows of x, already grouped by destination rank."""
         if x is None:
             return None
-        if self.world == 1:
+        if self.alone:
             return x                       # a rank's share of its own rows: no copy
         w = self._wire(x.contiguous())
         out = torch.empty((int(sum(recv_counts)),) + tuple(x.shape[1:]), dtype=x.dtype, device=w.device)
@@ -394,7 +397,7 @@ class _Comm:
         """Concatenation over ranks (rank-major) of tensors that differ in dim 0."""
         if x is None:
             return None
-        if self.world == 1:
+        if self.alone:
             return x
         sizes = [int(s) for s in self.all_gather_ints([x.shape[0]])[:, 0]]
         cap = max(max(sizes), 1)

@@ -940,15 +940,20 @@ def test_edge_labels_and_kept_except(F, oracle):
     assert np.array_equal(kept_ids, want["kept_read_ids"])
 
 
-def test_sharded_path_on_rccl_world1(F, oracle):
+@pytest.mark.parametrize("shortcuts", [True, False])
+def test_sharded_path_on_rccl_world1(F, oracle, monkeypatch, shortcuts):
     """The production multi-GPU code path (HipBackend + torch.distributed 'nccl' = RCCL) with a
-    one-rank group: every collective, every export/import of the C ABI, against the oracle."""
+    one-rank group: every collective, every export/import of the C ABI, against the oracle. With ONE rank
+    the collectives are the identity; FQD_COMM_NO_SHORTCUT=1 sends them through RCCL all the same (all-to-all(v),
+    all-gather, all-reduce of one rank with itself, ordered against the library's stream by stream waits)."""
+    if not shortcuts:
+        monkeypatch.setenv("FQD_COMM_NO_SHORTCUT", "1")
     import torch
     import torch.distributed as dist
     from fastqdedup_amd.sharded import HipBackend, cluster_keys_sharded
     from fastqdedup_amd.synth import fixed_offsets, synth_keys
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29611")
+    os.environ["MASTER_PORT"] = "29611" if shortcuts else "29612"
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -970,6 +975,14 @@ def test_sharded_path_on_rccl_world1(F, oracle):
             assert got.n_unique == want["n_unique"] and got.n_clusters == want["n_clusters"], (d, m, plan)
             assert np.array_equal(got.kept_read_ids.cpu().numpy().astype(np.uint64), want["kept_read_ids"]), (d, m, plan)
             assert got.n_kept == len(want["kept_read_ids"])
+        # short keys: the fused way in (owner-major slabs, exchanged as they are)
+        monkeypatch.setenv("FQD_OWNER_SLABS_MIN_READS", "1000")
+        n, L = 200000, 32
+        host = synth_keys(n, L, L, 23, sub_rate=3e-3, n_rate=3e-4).reshape(-1)
+        got = cluster_keys_sharded(backend, torch.from_numpy(host).to(dev), None, L, max_distance=1, method="directional")
+        want = oracle.dedup(host, fixed_offsets(n, L), max_distance=1, method="directional")
+        assert (got.n_unique, got.n_clusters) == (want["n_unique"], want["n_clusters"])
+        assert np.array_equal(got.kept_read_ids.cpu().numpy().astype(np.uint64), want["kept_read_ids"])
         # ragged + edit metric through the same path
         rag = ["ACGTACGTAC", "ACGTACGTA", "ACGTACGTACG", "TTTTTTTTTT", "TTTTTTTTT", "GGGGG"] * 50
         raw, off = _pack(rag)
