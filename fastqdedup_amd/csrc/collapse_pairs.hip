@@ -222,35 +222,59 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
             ulens[begin + j] = lens[tmp_rep[src + j]];
     }
     const uint32_t n_unique = unique_incl[n_buckets - 1];
-    for (uint32_t x = fqd_lane(); x < cnt * q_per_rec; x += 64) {
-        const uint32_t j = x / q_per_rec, q = x - j * q_per_rec;
-        const uint4 v = recs4[(size_t)tmp_rep[src + j] * q_per_rec + q];
-        urecs4[(size_t)(begin + j) * q_per_rec + q] = v;
-        if (sho.nseg) {
-            // as segment_hashes_kernel (edges.hip): the record's q_per_rec lanes sit side by side in
-            // the wave (q_per_rec divides 64), each sums its four words' share of a segment
-            const uint32_t word[4] = {v.x, v.y, v.z, v.w};
-            for (uint32_t sg = 0; sg < sho.nseg; sg++) {
-                uint32_t lo, hi;
-                fqd_segment(sho.len, sg, sho.nseg, lo, hi);
-                uint32_t part = 0;
+    // four record quarters per lane and step: the four position loads go out together, then the four record
+    // gathers (one after the other, every step waited for a chain of two dependent round trips -- 25-50 steps per
+    // wave: 1.3 ms for 12.9 M records of 128 bytes, config 4)
+    constexpr uint32_t CP = 4;
+    const uint32_t total = cnt * q_per_rec;
+    for (uint32_t x0 = fqd_lane(); x0 < total; x0 += CP * 64) {
+        uint32_t rep[CP];
+        uint4 v[CP];
 #pragma unroll
-                for (uint32_t e = 0; e < 4; e++) {
-                    const uint32_t jw = q * 4 + e;             // word index in the record
-                    if (jw < sho.kw) {
-                        const uint32_t m = fqd_range_mask(jw / sho.planes, lo, hi);
-                        if (m)
-                            part += fqd_mix32((word[e] & m) + (jw + 1u) * 0x9E3779B1u);
+        for (uint32_t t = 0; t < CP; t++) {
+            const uint32_t x = x0 + t * 64;
+            rep[t] = x < total ? tmp_rep[src + x / q_per_rec] : 0u;
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < CP; t++) {
+            const uint32_t x = x0 + t * 64;
+            v[t] = make_uint4(0, 0, 0, 0);
+            if (x < total)
+                v[t] = recs4[(size_t)rep[t] * q_per_rec + x % q_per_rec];
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < CP; t++) {
+            const uint32_t x = x0 + t * 64;
+            if (x >= total)
+                continue;              // (a record's q_per_rec lanes stay or leave together: 64 is a multiple of it when hashes are asked for)
+            const uint32_t j = x / q_per_rec, q = x - j * q_per_rec;
+            urecs4[(size_t)(begin + j) * q_per_rec + q] = v[t];
+            if (sho.nseg) {
+                // as segment_hashes_kernel (edges.hip): the record's q_per_rec lanes sit side by side in
+                // the wave (q_per_rec divides 64), each sums its four words' share of a segment
+                const uint32_t word[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+                for (uint32_t sg = 0; sg < sho.nseg; sg++) {
+                    uint32_t lo, hi;
+                    fqd_segment(sho.len, sg, sho.nseg, lo, hi);
+                    uint32_t part = 0;
+#pragma unroll
+                    for (uint32_t e = 0; e < 4; e++) {
+                        const uint32_t jw = q * 4 + e;             // word index in the record
+                        if (jw < sho.kw) {
+                            const uint32_t m = fqd_range_mask(jw / sho.planes, lo, hi);
+                            if (m)
+                                part += fqd_mix32((word[e] & m) + (jw + 1u) * 0x9E3779B1u);
+                        }
                     }
+                    for (uint32_t off = 1; off < q_per_rec; off <<= 1) {
+                        const uint32_t other = __shfl_down(part, off);
+                        if (q + off < q_per_rec)
+                            part += other;
+                    }
+                    if (q == 0)
+                        sho.out[(size_t)sg * n_unique + begin + j] =
+                            fqd_mix32(part + fqd_mix32(sho.len * 0x9E3779B1u + sg * 0x85EBCA77u + 0x165667B1u));
                 }
-                for (uint32_t off = 1; off < q_per_rec; off <<= 1) {
-                    const uint32_t other = __shfl_down(part, off);
-                    if (q + off < q_per_rec)
-                        part += other;
-                }
-                if (q == 0)
-                    sho.out[(size_t)sg * n_unique + begin + j] =
-                        fqd_mix32(part + fqd_mix32(sho.len * 0x9E3779B1u + sg * 0x85EBCA77u + 0x165667B1u));
             }
         }
     }
