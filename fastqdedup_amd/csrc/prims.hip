@@ -1,6 +1,7 @@
 // prims.hip -- device-wide sort / scan from rocPRIM (AMD's own primitives
-// library, tuned per-arch incl. gfx950). Kept in one translation unit so the
-// heavy headers are compiled once. Everything domain-specific (packing,
+// library, tuned per-arch incl. gfx950) for the fall-back paths and long arrays, and a
+// one-launch scan of our own for the short arrays of the hot path. Kept in one translation unit so
+// the heavy headers are compiled once. Everything domain-specific (packing,
 // bucket pair search, components, dissection) is hand-written elsewhere.
 #include <cstring>
 
@@ -74,9 +75,76 @@ size_t scan_u32_temp(uint64_t n)
     return bytes;
 }
 
+// Short scans -- the per-bucket unique counts of the collapse, 2^16 words at config 3 -- by ONE workgroup in ONE
+// launch (rocPRIM's look-back scan is two: 4 + 6 us and a hand-over, between the dedupe and the compaction):
+// 16 consecutive words per thread and step (four 16-byte loads in flight), scanned in registers, the thread totals
+// through a wave scan and LDS, a running carry across the steps of 16 384 words.
+constexpr uint32_t SS_THREADS = 1024, SS_PER = 16, SS_MAX = 1u << 18;
+
+__global__ __launch_bounds__(SS_THREADS) void scan_small_kernel(const uint32_t *__restrict__ in,
+                                                                uint32_t *__restrict__ out, uint32_t n)
+{
+    __shared__ uint32_t s_wave[SS_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += SS_THREADS * SS_PER) {
+        const uint32_t i0 = base + tid * SS_PER;
+        uint32_t v[SS_PER];
+        if (i0 + SS_PER <= n) {
+#pragma unroll
+            for (uint32_t k = 0; k < SS_PER; k += 4) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(in + i0 + k);   // (i0 is a multiple of 16 words)
+                v[k] = q.x;
+                v[k + 1] = q.y;
+                v[k + 2] = q.z;
+                v[k + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < SS_PER; k++)
+                v[k] = i0 + k < n ? in[i0 + k] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 1; k < SS_PER; k++)
+            v[k] += v[k - 1];
+        uint32_t incl = v[SS_PER - 1];
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if ((int)lane >= o)
+                incl += up;
+        }
+        __syncthreads();                                   // (s_wave of the step before has been read)
+        if (lane == 63)
+            s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry + incl - v[SS_PER - 1];
+        uint32_t step_total = 0;
+        for (uint32_t w = 0; w < SS_THREADS / 64; w++) {
+            before += w < wave ? s_wave[w] : 0u;
+            step_total += s_wave[w];
+        }
+        if (i0 + SS_PER <= n) {
+#pragma unroll
+            for (uint32_t k = 0; k < SS_PER; k += 4)
+                *reinterpret_cast<uint4 *>(out + i0 + k) =
+                    make_uint4(v[k] + before, v[k + 1] + before, v[k + 2] + before, v[k + 3] + before);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < SS_PER; k++)
+                if (i0 + k < n)
+                    out[i0 + k] = v[k] + before;
+        }
+        carry += step_total;
+    }
+}
+
 hipError_t inclusive_scan_u32(void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, uint64_t n,
                               hipStream_t st)
 {
+    if (n && n <= SS_MAX && !((uintptr_t)in & 15u) && !((uintptr_t)out & 15u)) {
+        scan_small_kernel<<<1, SS_THREADS, 0, st>>>(in, out, (uint32_t)n);
+        return hipGetLastError();
+    }
     return rocprim::inclusive_scan(tmp, tmp_bytes, in, out, n, rocprim::plus<uint32_t>(), st);
 }
 
