@@ -190,6 +190,8 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
     }
     __syncthreads();
     // exclusive scan of the bin counts (each thread owns bpt consecutive bins) + global bases
+    // (reserving bins 2k and 2k + 1 with ONE 64-bit add on their adjacent cursors -- half the cursor atomics --
+    // changed nothing: 0.42-0.46 ms for level 2 of the collapse, 0.29 for the search's two levels, either way)
     const uint32_t bpt = (n_bins + THREADS - 1) / THREADS;
     uint32_t mine = 0;
     for (uint32_t k = 0; k < bpt; k++) {
