@@ -27,7 +27,9 @@
 
 // Items per thread of part_scatter12_kernel and the rounds its tile is staged in (partition.cuh ROUNDS). Measured at
 // config 3: 8 / 1 (2048-record tiles) 0.42-0.45 ms; 16 / 2 (4096-record tiles, half the cursor atomics, 16-record
-// runs, the same LDS) 0.49 ms -- 113 instead of 56 VGPRs cost more than the longer runs give.
+// runs, the same LDS) 0.49 ms, 16 / 4 0.50 ms; 8 / 2 (half the staging area, eight waves per SIMD instead of
+// five) 0.427 ms -- neither occupancy nor run length nor the number of cursor atomics moves this kernel (its waves
+// are parked 80 % of their cycles, profiles/r02_sq_per_kernel_config3.json).
 #ifndef FQD_SCATTER12_EPT
 #define FQD_SCATTER12_EPT 8
 #endif

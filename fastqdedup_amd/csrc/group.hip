@@ -16,6 +16,11 @@
 #include "fqd_internal.h"
 #include "partition.cuh"
 
+// staging rounds of the pair partition's 4096-item tiles (partition.cuh ROUNDS): 2 halves the staging area (52 -> 33 KB
+// of LDS, four workgroups per CU instead of three): 0.273 instead of 0.290 ms for both levels at config 3; 4: 0.271
+#ifndef FQD_PAIR_ROUNDS
+#define FQD_PAIR_ROUNDS 2
+#endif
 namespace {
 
 constexpr uint32_t GP_THREADS = 256;
@@ -27,7 +32,7 @@ constexpr uint32_t GP_ECAP = 1024;      // edges buffered per block of the verif
 struct PairPolicy {
     using Item = uint2;
     static constexpr uint32_t EPT = 16;         // 4096-pair tiles
-    static constexpr uint32_t ROUNDS = 1;
+    static constexpr uint32_t ROUNDS = FQD_PAIR_ROUNDS;
     static constexpr bool MAY_SKIP = false;
     static __device__ __forceinline__ bool skip(const uint2 &) { return false; }
     struct Source {
