@@ -84,7 +84,9 @@ namespace {
 // cross_only (d = 1): pairs of keys of ONE length are Hamming neighbours or no neighbours -- the
 // Hamming passes have reported them into c->edges already (c->E of them); this search appends the
 // pairs of different lengths behind them.
-int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done, bool cross_only = false)
+// index_ready (with cross_only): c->seg_hashes holds the [d + 1][U] segment hashes the Hamming passes grouped by --
+// they are the index items' hashes, no key is hashed twice and only the probing keys' records are read.
+int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done, bool cross_only = false, bool index_ready = false)
 {
     *done = false;
     const uint64_t base_edges = cross_only ? c->E : 0;
@@ -110,7 +112,7 @@ int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done, bool cross_only 
     } else {
         counts[L] = (uint32_t)U;               // one length class
     }
-    uint64_t n_probe = 0;
+    uint64_t n_probe = 0, n_probers = 0;       // probe items; keys that file any
     for (uint32_t la = 0; la <= L; la++) {
         if (!counts[la])
             continue;
@@ -138,6 +140,7 @@ int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done, bool cross_only 
             }
         }
         n_probe += (uint64_t)probe_count[la] * counts[la];
+        n_probers += probe_count[la] ? counts[la] : 0u;
     }
     const uint64_t R = U * nseg + n_probe;
     if (R >= 0xFFFFFF00ull)
@@ -157,9 +160,14 @@ int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done, bool cross_only 
     } else {
         HIP_TRY(c, hipMemsetAsync(c->eg_per_key_incl.p, 0, U * 4, c->st));
     }
+    // (the per-key counts have been scanned: their array now takes the list of the probing keys)
+    FQD_TRY(zero_ctr64(c, C64_SUM));
     HIP_TRY(c, fqd::launch_edit_items(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, sh, d, d_mask, d_counts,
                                       c->eg_per_key.as<uint32_t>(), c->eg_per_key_incl.as<uint32_t>(),
-                                      c->ed_hash.as<uint32_t>(), c->ed_payload.as<uint32_t>(), 1, c->st));
+                                      c->ed_hash.as<uint32_t>(), c->ed_payload.as<uint32_t>(), 1, c->st,
+                                      cross_only && index_ready && !getenv("FQD_EDIT_OWN_INDEX_HASHES")
+                                          ? c->seg_hashes.as<uint32_t>() : nullptr,
+                                      c->eg_per_key.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_SUM, n_probers));
     // ---- partition, candidates, verification; buffers grow and the passes run again if needed -----
     uint32_t B = 8;
     while (B < 20 && (R >> B) > 320)
@@ -188,8 +196,10 @@ int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done, bool cross_only 
                                         !c->gp_slab_off && !getenv("FQD_GROUP_NO_SLABS"), &items, &bucket_end,
                                         c->ed_payload.as<uint32_t>()));
         unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(c->gp_small.as<uint32_t>() + 4096);
+        // (pairs of different lengths only: one of the two items is then a probe item -- bit 31 of its payload)
         KTIME(c, FQD_K_PAIRS, fqd::launch_grouped_candidates(items, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, B,
-                                                             c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap, c->st));
+                                                             c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap, c->st,
+                                                             cross_only ? 0x80000000u : 0u));
         KTIME(c, FQD_K_VERIFY, fqd::launch_edit_grouped_verify(
                   c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap / fqd::group_cand_lists(), fqd::group_cand_lists(),
                   c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, d_mask, c->edges.as<uint32_t>(), ctr + C64_EDGES,
@@ -565,7 +575,7 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
     }
     if (cross_after && U >= 2) {
         bool cross_done = false;
-        FQD_TRY(find_edges_edit_grouped(c, 1, &cross_done, true));
+        FQD_TRY(find_edges_edit_grouped(c, 1, &cross_done, true, true));
         if (!cross_done) {           // (cannot happen for d = 1 below 2^26 keys; the sorted search redoes everything)
             FQD_TRY(zero_ctr64(c, C64_EDGES));
             c->E = 0;

@@ -46,6 +46,30 @@ __device__ __forceinline__ uint32_t substring_hash(const uint32_t *rec, uint32_t
     return fqd_mix32(h);
 }
 
+// The hash fqd_segment_hash gives segment seg of a key of cls_len bases whose segment holds the nb bases that THIS
+// record has from base `start` on: the record is read through a window shifted by delta = start - lo, word by word
+// in the indexed key's coordinates. With it a probe item meets the index items the Hamming passes have hashed
+// already (segment_hashes_kernel), and the edit search need not hash the index side again.
+__device__ __forceinline__ uint32_t shifted_segment_hash(const uint32_t *rec, uint32_t K, uint32_t W, uint32_t cls_len,
+                                                         uint32_t seg, uint32_t nseg, int delta)
+{
+    uint32_t lo, hi;
+    fqd_segment(cls_len, seg, nseg, lo, hi);
+    uint32_t part = 0;
+    for (uint32_t w = lo >> 5; w * 32u < hi; w++) {
+        const uint32_t m = fqd_range_mask(w, lo, hi);
+        if (!m)
+            continue;
+        const int at = (int)(w * 32u) + delta;                // the record's base under bit 0 of word w
+        for (uint32_t k = 0; k < K; k++) {
+            const uint32_t bits = at >= 0 ? plane_bits(rec, K, W, k, (uint32_t)at)
+                                          : plane_bits(rec, K, W, k, 0u) << (uint32_t)(-at);
+            part += fqd_mix32((bits & m) + (w * K + k + 1u) * 0x9E3779B1u);
+        }
+    }
+    return fqd_mix32(part + fqd_mix32(cls_len * 0x9E3779B1u + seg * 0x85EBCA77u + 0x165667B1u));
+}
+
 constexpr uint32_t ROLE_PROBE = 0x80000000u;
 constexpr uint32_t DEAD_HASH = 0xFFFFFFFFu;
 
@@ -341,8 +365,24 @@ __global__ __launch_bounds__(256) void edit_items_kernel(const uint32_t *__restr
                                                          uint32_t *__restrict__ per_key,
                                                          const uint32_t *__restrict__ per_key_incl,
                                                          uint32_t *__restrict__ hashes, uint32_t *__restrict__ payloads,
-                                                         int pass)
+                                                         int pass,
+                                                         const uint32_t *__restrict__ index_from /* NULL, or the
+                                                         [d + 1][U] segment hashes of the Hamming passes: they ARE the index
+                                                         items' hashes, the probe items are hashed to meet them
+                                                         (shifted_segment_hash), and only the probing keys' records
+                                                         are read -- never with STAGED */,
+                                                         uint32_t *__restrict__ probers /* != NULL: pass 1 lists the keys
+                                                         that file probe items here (any order) for edit_probe_items_kernel
+                                                         instead of hashing them itself: one such key in a hundred kept
+                                                         half of the waves in the probe loops */,
+                                                         unsigned long long *__restrict__ n_probers)
 {
+    __shared__ uint32_t s_n, s_at;
+    if (probers && pass == 1) {
+        if (threadIdx.x == 0)
+            s_n = 0;
+        __syncthreads();
+    }
     extern __shared__ uint32_t s_recs[];
     const uint64_t u0 = (uint64_t)blockIdx.x * blockDim.x;
     const uint64_t u = u0 + threadIdx.x;
@@ -361,6 +401,30 @@ __global__ __launch_bounds__(256) void edit_items_kernel(const uint32_t *__restr
         }
         __syncthreads();
     }
+    if (probers && pass == 1) {
+        // index items by everybody, the probing keys of the workgroup appended to the list with one atomic
+        const bool live = u < U;
+        const uint32_t len = live ? fqd_key_len(sh, ulens, u) : 0u;
+        const uint32_t K = sh.planes, W = sh.words, nseg = d + 1;
+        const uint32_t *rec = STAGED ? s_recs + threadIdx.x * (sh.stride + 1) : urecs + u * sh.stride;
+        for (uint32_t s = 0; live && s < nseg; s++) {
+            uint32_t lo, hi;
+            fqd_segment(len, s, nseg, lo, hi);
+            hashes[u * nseg + s] = index_from ? index_from[(uint64_t)s * U + u] : substring_hash(rec, K, W, len, s, lo, hi - lo);
+            payloads[u * nseg + s] = eg_payload((uint32_t)u, s, 0, false);
+        }
+        const bool files = live && probe_count[len] != 0;
+        uint32_t slot = 0;
+        if (files)
+            slot = atomicAdd(&s_n, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_n)
+            s_at = (uint32_t)atomicAdd(n_probers, (unsigned long long)s_n);
+        __syncthreads();
+        if (files)
+            probers[s_at + slot] = (uint32_t)u;
+        return;
+    }
     if (u >= U)
         return;
     const uint32_t len = fqd_key_len(sh, ulens, u);
@@ -373,7 +437,7 @@ __global__ __launch_bounds__(256) void edit_items_kernel(const uint32_t *__restr
     for (uint32_t s = 0; s < nseg; s++) {
         uint32_t lo, hi;
         fqd_segment(len, s, nseg, lo, hi);
-        hashes[u * nseg + s] = substring_hash(rec, K, W, len, s, lo, hi - lo);
+        hashes[u * nseg + s] = index_from ? index_from[(uint64_t)s * U + u] : substring_hash(rec, K, W, len, s, lo, hi - lo);
         payloads[u * nseg + s] = eg_payload((uint32_t)u, s, 0, false);
     }
     const uint32_t mine = probe_count[len];
@@ -394,8 +458,128 @@ __global__ __launch_bounds__(256) void edit_items_kernel(const uint32_t *__restr
                 const int start = (int)lo + delta;
                 if (start < 0 || (uint32_t)start + nb > len)
                     continue;
-                hashes[at] = substring_hash(rec, K, W, l, s, (uint32_t)start, nb);
+                hashes[at] = index_from ? shifted_segment_hash(rec, K, W, l, s, nseg, delta)
+                                        : substring_hash(rec, K, W, l, s, (uint32_t)start, nb);
                 payloads[at] = eg_payload((uint32_t)u, s, delta, true);
+                at++;
+            }
+        }
+    }
+}
+
+// Light versions of edit_items_kernel's two cheap jobs, four keys per thread with their loads in flight together
+// (inside the big kernel -- many registers, few waves -- each of them took 0.64 ms for 26 M keys, a chain of two
+// dependent loads per key): pass 0 (per_key[u] = probe items of u's length class), and pass 1 when the index
+// hashes exist already (index_from): copy them into item order, add the payloads, list the probing keys.
+constexpr uint32_t EL_KEYS = 4;
+
+__global__ __launch_bounds__(256) void edit_probe_counts_kernel(const uint32_t *__restrict__ ulens, uint64_t U, KeyShape sh,
+                                                                const uint32_t *__restrict__ probe_count,
+                                                                uint32_t *__restrict__ per_key)
+{
+    const uint64_t u0 = ((uint64_t)blockIdx.x * EL_KEYS) * blockDim.x + threadIdx.x;
+    uint32_t len[EL_KEYS];
+#pragma unroll
+    for (uint32_t t = 0; t < EL_KEYS; t++) {
+        const uint64_t u = u0 + (uint64_t)t * blockDim.x;
+        len[t] = u < U ? fqd_key_len(sh, ulens, u) : 0u;
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < EL_KEYS; t++) {
+        const uint64_t u = u0 + (uint64_t)t * blockDim.x;
+        if (u < U)
+            per_key[u] = probe_count[len[t]];
+    }
+}
+
+__global__ __launch_bounds__(256) void edit_index_items_kernel(const uint32_t *__restrict__ ulens, uint64_t U, KeyShape sh,
+                                                               uint32_t d, const uint32_t *__restrict__ probe_count,
+                                                               const uint32_t *__restrict__ index_from,
+                                                               uint32_t *__restrict__ hashes, uint32_t *__restrict__ payloads,
+                                                               uint32_t *__restrict__ probers,
+                                                               unsigned long long *__restrict__ n_probers)
+{
+    __shared__ uint32_t s_n, s_at;
+    if (threadIdx.x == 0)
+        s_n = 0;
+    __syncthreads();
+    const uint32_t nseg = d + 1;
+    const uint64_t u0 = ((uint64_t)blockIdx.x * EL_KEYS) * blockDim.x + threadIdx.x;
+    uint32_t len[EL_KEYS], slot[EL_KEYS];
+    bool files[EL_KEYS];
+#pragma unroll
+    for (uint32_t t = 0; t < EL_KEYS; t++) {
+        const uint64_t u = u0 + (uint64_t)t * blockDim.x;
+        len[t] = u < U ? fqd_key_len(sh, ulens, u) : 0u;
+    }
+    for (uint32_t s = 0; s < nseg; s++) {
+        uint32_t h[EL_KEYS];
+#pragma unroll
+        for (uint32_t t = 0; t < EL_KEYS; t++) {
+            const uint64_t u = u0 + (uint64_t)t * blockDim.x;
+            h[t] = u < U ? index_from[(uint64_t)s * U + u] : 0u;
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < EL_KEYS; t++) {
+            const uint64_t u = u0 + (uint64_t)t * blockDim.x;
+            if (u < U) {
+                hashes[u * nseg + s] = h[t];
+                payloads[u * nseg + s] = eg_payload((uint32_t)u, s, 0, false);
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < EL_KEYS; t++) {
+        const uint64_t u = u0 + (uint64_t)t * blockDim.x;
+        files[t] = u < U && probe_count[len[t]] != 0;
+        slot[t] = files[t] ? atomicAdd(&s_n, 1u) : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n)
+        s_at = (uint32_t)atomicAdd(n_probers, (unsigned long long)s_n);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t t = 0; t < EL_KEYS; t++)
+        if (files[t])
+            probers[s_at + slot[t]] = (uint32_t)(u0 + (uint64_t)t * blockDim.x);
+}
+
+// The probe items of the keys edit_items_kernel listed: one thread per probing key (dense waves).
+__global__ __launch_bounds__(256) void edit_probe_items_kernel(const uint32_t *__restrict__ urecs,
+                                                               const uint32_t *__restrict__ ulens, uint64_t U, KeyShape sh,
+                                                               uint32_t d, const uint8_t *__restrict__ probe_mask,
+                                                               const uint32_t *__restrict__ probe_count,
+                                                               const uint32_t *__restrict__ per_key_incl,
+                                                               const uint32_t *__restrict__ probers, uint64_t n_probers,
+                                                               bool segment_hashes, uint32_t *__restrict__ hashes,
+                                                               uint32_t *__restrict__ payloads)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_probers)
+        return;
+    const uint32_t u = probers[i];
+    const uint32_t len = fqd_key_len(sh, ulens, u);
+    const uint32_t K = sh.planes, W = sh.words, nseg = d + 1;
+    const uint32_t *rec = urecs + (uint64_t)u * sh.stride;
+    const uint32_t mine = probe_count[len];
+    uint64_t at = U * nseg + (per_key_incl[u] - mine);
+    for (int j = 0; j <= 2 * (int)d; j++) {
+        if (!((probe_mask[len] >> j) & 1u))
+            continue;
+        const uint32_t l = (uint32_t)((int)len - (int)d + j);
+        for (uint32_t s = 0; s < nseg; s++) {
+            uint32_t lo, hi;
+            fqd_segment(l, s, nseg, lo, hi);
+            const uint32_t nb = hi - lo;
+            for (int delta = -(int)d; delta <= (int)d; delta++) {
+                if (l == len && delta == 0)
+                    continue;
+                const int start = (int)lo + delta;
+                if (start < 0 || (uint32_t)start + nb > len)
+                    continue;
+                hashes[at] = segment_hashes ? shifted_segment_hash(rec, K, W, l, s, nseg, delta)
+                                            : substring_hash(rec, K, W, l, s, (uint32_t)start, nb);
+                payloads[at] = eg_payload(u, s, delta, true);
                 at++;
             }
         }
@@ -684,17 +868,39 @@ hipError_t launch_edit_len_counts(const uint32_t *ulens, uint64_t U, KeyShape sh
 
 hipError_t launch_edit_items(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t d,
                              const uint8_t *probe_mask, const uint32_t *probe_count, uint32_t *per_key,
-                             const uint32_t *per_key_incl, uint32_t *hashes, uint32_t *payloads, int pass, hipStream_t st)
+                             const uint32_t *per_key_incl, uint32_t *hashes, uint32_t *payloads, int pass, hipStream_t st,
+                             const uint32_t *index_from, uint32_t *probers, unsigned long long *n_probers_dev,
+                             uint64_t n_probers)
 {
     if (!U)
         return hipSuccess;
+    const unsigned light_grid = (unsigned)((U + 256 * EL_KEYS - 1) / (256 * EL_KEYS));
+    if (pass == 0) {
+        edit_probe_counts_kernel<<<light_grid, 256, 0, st>>>(ulens, U, sh, probe_count, per_key);
+        return hipGetLastError();
+    }
+    if (index_from && probers) {
+        edit_index_items_kernel<<<light_grid, 256, 0, st>>>(ulens, U, sh, d, probe_count, index_from, hashes, payloads,
+                                                            probers, n_probers_dev);
+        if (n_probers)
+            edit_probe_items_kernel<<<grid_for(n_probers), 256, 0, st>>>(urecs, ulens, U, sh, d, probe_mask, probe_count,
+                                                                        per_key_incl, probers, n_probers, true, hashes,
+                                                                        payloads);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)256 * (sh.stride + 1) * 4;
-    if (pass == 1 && sh.stride % 4 == 0 && lds <= 48 * 1024)
+    if (pass == 1 && !index_from && sh.stride % 4 == 0 && lds <= 48 * 1024)
         edit_items_kernel<true><<<grid_for(U), 256, lds, st>>>(urecs, ulens, U, sh, d, probe_mask, probe_count, per_key,
-                                                               per_key_incl, hashes, payloads, pass);
+                                                               per_key_incl, hashes, payloads, pass, nullptr, probers,
+                                                               n_probers_dev);
     else
         edit_items_kernel<false><<<grid_for(U), 256, 0, st>>>(urecs, ulens, U, sh, d, probe_mask, probe_count, per_key,
-                                                              per_key_incl, hashes, payloads, pass);
+                                                              per_key_incl, hashes, payloads, pass, index_from, probers,
+                                                              n_probers_dev);
+    if (pass == 1 && probers && n_probers)
+        edit_probe_items_kernel<<<grid_for(n_probers), 256, 0, st>>>(urecs, ulens, U, sh, d, probe_mask, probe_count,
+                                                                    per_key_incl, probers, n_probers, index_from != nullptr,
+                                                                    hashes, payloads);
     return hipGetLastError();
 }
 

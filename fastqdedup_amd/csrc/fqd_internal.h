@@ -399,7 +399,11 @@ hipError_t launch_edit_verify(const uint64_t *cands, uint64_t C, const uint32_t 
 hipError_t launch_edit_len_counts(const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t *counts, hipStream_t st);
 hipError_t launch_edit_items(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t d,
                              const uint8_t *probe_mask, const uint32_t *probe_count, uint32_t *per_key,
-                             const uint32_t *per_key_incl, uint32_t *hashes, uint32_t *payloads, int pass, hipStream_t st);
+                             const uint32_t *per_key_incl, uint32_t *hashes, uint32_t *payloads, int pass, hipStream_t st,
+                             const uint32_t *index_from = nullptr /* [d + 1][U] segment hashes: the index items' hashes */,
+                             uint32_t *probers = nullptr /* pass 1: room for the n_probers keys that file probe items; their
+                                                            items come from a second, dense kernel */,
+                             unsigned long long *n_probers_dev = nullptr /* zeroed by the caller */, uint64_t n_probers = 0);
 hipError_t launch_edit_grouped_verify(const uint64_t *cands, const unsigned long long *cand_count, uint64_t list_cap,
                                       uint32_t n_lists, const uint32_t *urecs, const uint32_t *ulens, KeyShape sh,
                                       uint32_t d, const uint8_t *probe_mask, uint32_t *edges,
@@ -434,7 +438,8 @@ hipError_t launch_group_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *
                                     hipStream_t st);
 hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                      uint32_t n_buckets, uint32_t bucket_bits, uint64_t *cands,
-                                     unsigned long long *cand_count, uint64_t cand_cap, hipStream_t st);
+                                     unsigned long long *cand_count, uint64_t cand_cap, hipStream_t st,
+                                     uint32_t require_any = 0 /* list only pairs with one of these bits in a value */);
 hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
                                     const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d, uint32_t seg,
                                     uint32_t nseg, uint32_t *edges, unsigned long long *edge_count, uint64_t edge_cap,

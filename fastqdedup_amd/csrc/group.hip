@@ -209,7 +209,11 @@ constexpr uint32_t GP_LISTS = 64;   // candidate lists (one counter each, a cach
 __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
     const uint2 *__restrict__ items, const uint32_t *__restrict__ bucket_start,
     const uint32_t *__restrict__ bucket_end /* NULL, or slab mode: where each bucket's cursor stopped */,
-    uint32_t n_buckets, uint32_t sub_shift, uint2 *__restrict__ cands_all, unsigned long long *__restrict__ cand_counts, uint64_t list_cap)
+    uint32_t n_buckets, uint32_t sub_shift, uint2 *__restrict__ cands_all, unsigned long long *__restrict__ cand_counts, uint64_t list_cap,
+    uint32_t require_any /* != 0: only pairs one of whose values has one of these bits are listed (the Levenshtein
+                          * search for pairs of DIFFERENT lengths: a pair of two index items is a pair of one length,
+                          * which the Hamming passes have found already -- 11 M of 11.2 M candidates at config 5's
+                          * variant, each of them fetched and dropped by the verification before) */)
 {
     constexpr uint32_t WAVES = GP_THREADS / 64;
     // GP_LISTS lists of list_cap pairs each, counters 8 words apart. A wave starts at "its" list
@@ -335,7 +339,9 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
                 while (match) {
                     const uint32_t bit = __ffs((int)match) - 1;
                     match &= match - 1;
-                    note(ui, uids[jbase + bit]);
+                    const uint32_t uj = uids[jbase + bit];
+                    if (!require_any || ((ui | uj) & require_any))
+                        note(ui, uj);
                 }
             }
         }
@@ -344,11 +350,11 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
             const uint2 me = bucket[t];
             const uint32_t sb = (me.x >> sub_shift) & 63u;
             for (uint32_t j = off[sb]; j < off[sb + 1]; j++)
-                if (hashes[j] == me.x)
+                if (hashes[j] == me.x && (!require_any || ((uids[j] | me.y) & require_any)))
                     note(uids[j], me.y);
             for (uint32_t t2 = t + 1; t2 < m; t2++) {
                 const uint2 it = bucket[t2];
-                if (it.x == me.x)
+                if (it.x == me.x && (!require_any || ((me.y | it.y) & require_any)))
                     note(me.y, it.y);
             }
         }
@@ -653,7 +659,8 @@ hipError_t launch_group_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *
 
 hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                      uint32_t n_buckets, uint32_t bucket_bits, uint64_t *cands,
-                                     unsigned long long *cand_count, uint64_t cand_cap, hipStream_t st)
+                                     unsigned long long *cand_count, uint64_t cand_cap, hipStream_t st,
+                                     uint32_t require_any)
 {
     if (!n_buckets)
         return hipSuccess;
@@ -663,7 +670,7 @@ hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *buck
     const unsigned grid = blocks < 8192 ? blocks : 8192;
     grouped_candidates_kernel<<<grid, GP_THREADS, 0, st>>>(reinterpret_cast<const uint2 *>(items), bucket_start,
                                                            bucket_end, n_buckets, sub_shift, reinterpret_cast<uint2 *>(cands),
-                                                           cand_count, cand_cap / GP_LISTS);
+                                                           cand_count, cand_cap / GP_LISTS, require_any);
     return hipGetLastError();
 }
 
