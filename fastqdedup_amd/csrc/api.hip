@@ -453,7 +453,7 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
     // segment hashes on the way (records whose uint4 count divides 64: their lanes sit side by side)
     fqd::SegHashOut sho;
     const uint32_t q_per_rec = sh.stride / 4;
-    if (c->seg_hint && U && !sh.ragged && q_per_rec <= 64 && !(q_per_rec & (q_per_rec - 1)) &&
+    if (c->seg_hint && U && (!sh.ragged || d_lens) && q_per_rec <= 64 && !(q_per_rec & (q_per_rec - 1)) &&
         !getenv("FQD_NO_EARLY_SEG_HASHES")) {
         HIP_TRY(c, c->seg_hashes.reserve((size_t)c->seg_hint * U * 4 + 16));
         sho.out = c->seg_hashes.as<uint32_t>();

@@ -459,7 +459,7 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         HIP_TRY(c, c->sorted_uid.reserve(U * 4 + 16));
         HIP_TRY(c, c->uid_iota.reserve(U * 4 + 16));
         // (the LDS collapse inside fqd_cluster[_keys] has written them already, on its way out)
-        if (!(c->seg_hashes_nseg == nseg && seg_lo == 0 && !sh.ragged))
+        if (!(c->seg_hashes_nseg == nseg && seg_lo == 0))
             KTIME(c, FQD_K_SEG_HASH, fqd::launch_segment_hashes(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, sh,
                                                                 nseg, seg_lo, seg_hi, 0, c->seg_hashes.as<uint32_t>(),
                                                                 c->st));

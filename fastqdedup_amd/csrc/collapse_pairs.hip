@@ -253,9 +253,10 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
                 // as segment_hashes_kernel (edges.hip): the record's q_per_rec lanes sit side by side in
                 // the wave (q_per_rec divides 64), each sums its four words' share of a segment
                 const uint32_t word[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+                const uint32_t klen = lens ? lens[rep[t]] : sho.len;       // (ragged keys: segments of the key's own length)
                 for (uint32_t sg = 0; sg < sho.nseg; sg++) {
                     uint32_t lo, hi;
-                    fqd_segment(sho.len, sg, sho.nseg, lo, hi);
+                    fqd_segment(klen, sg, sho.nseg, lo, hi);
                     uint32_t part = 0;
 #pragma unroll
                     for (uint32_t e = 0; e < 4; e++) {
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
                     }
                     if (q == 0)
                         sho.out[(size_t)sg * n_unique + begin + j] =
-                            fqd_mix32(part + fqd_mix32(sho.len * 0x9E3779B1u + sg * 0x85EBCA77u + 0x165667B1u));
+                            fqd_mix32(part + fqd_mix32(klen * 0x9E3779B1u + sg * 0x85EBCA77u + 0x165667B1u));
                 }
             }
         }
