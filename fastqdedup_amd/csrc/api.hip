@@ -1225,12 +1225,20 @@ int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *
     if (parts64 * cap + n_reads >= 0xFFFFFF00ull || n_reads >= 0xFFFFFF00ull)
         return FQD_OK;
     // (sender, read index on the sender) must fit the record's spare word
+    // (senders in ANY order -- a rank's reads may arrive as several senders, chunk by chunk: a sender's reads lie
+    // below the next larger id base)
     uint64_t max_local = 0;
-    for (uint32_t s = 0; s < n_senders; s++) {
-        const uint64_t next = s + 1 < n_senders ? sender_id0[s + 1] : id_limit;
-        if (id_limit == ~0ull || next < sender_id0[s])
+    {
+        if (id_limit == ~0ull)
             return FQD_OK;
-        max_local = std::max(max_local, next - sender_id0[s]);
+        std::vector<uint64_t> bases(sender_id0, sender_id0 + n_senders);
+        std::sort(bases.begin(), bases.end());
+        for (uint32_t s = 0; s < n_senders; s++) {
+            const uint64_t next = s + 1 < n_senders ? bases[s + 1] : id_limit;
+            if (next < bases[s])
+                return FQD_OK;
+            max_local = std::max(max_local, next - bases[s]);
+        }
     }
     uint32_t lb = 1, sb = 0;
     while (lb < 32 && (max_local >> lb))
@@ -1270,14 +1278,27 @@ int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *
     uint32_t *seg_start = c->ld_seg.as<uint32_t>(), *seg_end = seg_start + (parts + 4);
     HIP_TRY(c, fqd::launch_owner_slab_bounds(cursors, n_senders, ppo, my_part, cap, seg_start, seg_end, c->st));
     c->ld_part.borrow(slabs, (size_t)parts * cap * 16);
-    // id bases of the senders on the device
-    HIP_TRY(c, c->seg_tab.reserve((size_t)n_senders * 8 + 16));
-    HIP_TRY(c, hipMemcpyAsync(c->seg_tab.p, sender_id0, (size_t)n_senders * 8, hipMemcpyHostToDevice, c->st));
-    HIP_TRY(c, stream_wait(c->st));
+    // id bases of the senders on the device, in ascending order, and every sender's rank in that order: the rank is
+    // what level 2 stamps above the read index, so stamped words compare like the ids they stand for
+    std::vector<uint32_t> order(n_senders), rank_of(n_senders);
+    for (uint32_t s = 0; s < n_senders; s++)
+        order[s] = s;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sender_id0[a] < sender_id0[b]; });
+    std::vector<uint64_t> sorted_id0(n_senders);
+    for (uint32_t r = 0; r < n_senders; r++) {
+        sorted_id0[r] = sender_id0[order[r]];
+        rank_of[order[r]] = r;
+    }
+    HIP_TRY(c, c->seg_tab.reserve((size_t)n_senders * 12 + 16));
+    uint32_t *d_rank_of = reinterpret_cast<uint32_t *>(c->seg_tab.as<uint64_t>() + n_senders);
+    HIP_TRY(c, hipMemcpyAsync(c->seg_tab.p, sorted_id0.data(), (size_t)n_senders * 8, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, hipMemcpyAsync(d_rank_of, rank_of.data(), (size_t)n_senders * 4, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, stream_wait(c->st));          // (host vectors)
     IdSource ids;
     ids.seg_id0 = c->seg_tab.as<uint64_t>();
     ids.n_seg = n_senders;
     ids.packed_bits = lb;
+    ids.stamp_map = d_rank_of;
     FQD_TRY(zero_ctr32(c, 0, C_N32));
     FusedLevel1 f{parts, 5, B};
     f.level1_bits = hb_bits;

@@ -65,7 +65,10 @@ struct RecordPolicy {
     };
     static __device__ __forceinline__ uint32_t segment_tag(const Source &s, uint32_t seg)
     {
-        return s.stamp_div ? (seg / s.stamp_div) << s.ids.packed_bits : 0u;
+        if (!s.stamp_div)
+            return 0u;
+        const uint32_t sender = seg / s.stamp_div;
+        return (s.ids.stamp_map ? s.ids.stamp_map[sender] : sender) << s.ids.packed_bits;
     }
     static __device__ __forceinline__ void apply_tag(uint4 &v, uint32_t tag) { v.w |= tag; }
     template <bool LEVEL1>

@@ -152,6 +152,10 @@ struct IdSource {
     // local index) into the travelling record instead of the position -- the same order, since the
     // segments arrive in rank order -- and the id needs no look-up in the packed buffer afterwards.
     uint32_t packed_bits = 0;             // 0: not possible / not used
+    // slabs received from several senders (fqd_collapse_owner_slabs): the number stamped for sender v of the
+    // buffer (NULL: v itself) -- the senders' ranks by id base, so that the smallest stamped word of a key is its
+    // first holder also when a rank's reads arrive as several senders out of id order (chunk by chunk)
+    const uint32_t *stamp_map = nullptr;
     // first rows of segments 1..7 (up to 8 ranks; unused = ~0): SCALAR members on purpose -- with
     // an array member the partition kernel's argument struct was no longer split into registers
     // and the whole kernel went through scratch memory (0.49 -> 0.70 ms)

@@ -138,23 +138,16 @@ class HipBackend:
         return recs, lens, ids, w_out, [int(c) for c in counts]
 
     # ---- reads -> owner, the fused way (short fixed-length keys, no weights) -------------------
-    def pack_to_owner_slabs(self, keys, key_len, n_parts, n_segments, n_max):
-        """Pack straight into owner-major slabs (fqd_pack_to_owner_slabs): (slab records as rows of
-        4 words, cursors, reads per owner, geometry), or None when the general way must be taken."""
-        geometry = Context.owner_slab_geometry(n_max, n_parts)
-        hb, subs, cap = geometry
-        parts = n_parts * hb * subs
-        if parts * cap * 16 > (64 << 30):
-            return None
-        slabs = torch.empty((parts * cap, 4), dtype=torch.int32, device=self.device)
-        cursors = torch.empty(parts, dtype=torch.int32, device=self.device)
-        counts = self.ctx.pack_to_owner_slabs(keys, key_len, n_parts, n_segments, 0, geometry, slabs, cursors)
+    def pack_into_owner_slabs(self, keys, key_len, n_parts, n_segments, geometry, slabs_out, cursors_out):
+        """One chunk of this rank's reads into the caller's slab buffers (rows of 4 words; cursors): reads per
+        owner, or None when the general way must be taken."""
+        counts = self.ctx.pack_to_owner_slabs(keys, key_len, n_parts, n_segments, 0, geometry, slabs_out, cursors_out)
         if counts is None:
             return None
         sh = self.ctx.shape()
         self.stride = int(sh.stride_words)
         self.ragged = bool(sh.ragged)
-        return slabs, cursors, counts, geometry
+        return counts
 
     def collapse_owner_slabs(self, slabs, cursors, n_senders, my_part, geometry, sender_id0, id_limit, n_reads,
                              search_segments):
@@ -393,6 +386,31 @@ class _Comm:
                                input_split_sizes=[int(c) for c in send_counts], group=self.group)
         return self._back(out)
 
+    def all_to_all_into(self, out, x):
+        """Equal-split all-to-all of the rows of x into `out` (same shape), WITHOUT making the library's streams wait
+        for it: the caller packs its next chunk meanwhile and calls settle() before the library reads `out`."""
+        if self.alone:
+            if out.data_ptr() != x.data_ptr():
+                out.copy_(x)
+            return
+        w = self._wire(x)
+        if self.via_host:
+            o = torch.empty_like(w)
+            dist.all_to_all_single(o, w, group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, w, group=self.group)
+
+    def settle(self):
+        """What the collectives queued so far produce is complete before the library's next call."""
+        if self.alone:
+            return
+        if self.lib_streams is not None:
+            for st in self.lib_streams():
+                st.wait_stream(torch.cuda.current_stream(self.device))
+        elif self.device.type == "cuda" and not self.via_host:
+            torch.cuda.current_stream(self.device).synchronize()
+
     def all_gather_rows(self, x):
         """Concatenation over ranks (rank-major) of tensors that differ in dim 0."""
         if x is None:
@@ -467,34 +485,66 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
         # ---- the fused way in: packed straight into owner-major slabs, the all-to-all moves the
         # slabs, the owner's collapse starts at level 2 (short keys, no weights, jobs worth it)
         n_max = int(n_per_rank.max())
-        can_slabs = (plan == "segment-routed" and weights is None and hasattr(backend, "pack_to_owner_slabs")
+        can_slabs = (plan == "segment-routed" and weights is None and hasattr(backend, "pack_into_owner_slabs")
                      and n_max >= int(os.environ.get("FQD_OWNER_SLABS_MIN_READS", 1 << 20))
                      and not os.environ.get("FQD_NO_OWNER_SLABS"))
         want_slabs = not comm.any_flag(not can_slabs)      # (weights, switches: every rank must agree)
         if want_slabs:
-            try:
-                slabs = backend.pack_to_owner_slabs(keys, key_len, world, n_seg, n_max)
-            except ValueError:
-                slabs = None
-            if comm.any_flag(slabs is None):
-                slabs = None                       # somebody cannot: everybody takes the general way
-            if tick:
-                tick.mark("pack-to-owner-slabs")
-            if slabs is not None:
-                s_slabs, s_cur, send_counts, geometry = slabs
-                recv_counts = comm.exchange_counts(send_counts)
-                per_owner = s_slabs.shape[0] // world
-                r_slabs = comm.all_to_all_rows(s_slabs, [per_owner] * world, [per_owner] * world)
-                r_cur = comm.all_to_all_rows(s_cur, [s_cur.shape[0] // world] * world, [s_cur.shape[0] // world] * world)
+            # FQD_SHARD_CHUNKS=n: the reads leave in n pieces -- while chunk k travels (the all-to-all runs on
+            # torch's / RCCL's stream, ordered behind the pack of chunk k only), the library packs chunk k + 1 on
+            # its own stream. A rank's chunks arrive as n senders of their own (chunk-major), each with its id
+            # base. One chunk by default: every chunk needs slabs of its own, sized for the largest chunk of the
+            # job, and the relative slack of a slab grows with their number (1.16 x the reads on the wire at one
+            # chunk of 50 M, 1.24 x at two, 1.35 x at four) -- on one rank two chunks cost 0.18 ms (4.65 -> 4.83 ms:
+            # two packs, twice the segments at the owner's level 2) against the <= 0.35 ms of pack time they can
+            # hide, and on a link-bound exchange (6 ms at two ranks) the extra bytes cost more than that.
+            chunks = 1
+            if os.environ.get("FQD_SHARD_CHUNKS"):
+                chunks = max(1, min(int(os.environ["FQD_SHARD_CHUNKS"]), 16))
+
+            def chunk_bounds(n):          # chunk starts on multiples of 16 reads (16-byte aligned key bytes)
+                return [min(n, (n * k // chunks + 15) // 16 * 16) for k in range(chunks)] + [n]
+            all_bounds = [chunk_bounds(int(n)) for n in n_per_rank]
+            n_max_chunk = max(max(b[k + 1] - b[k] for k in range(chunks)) for b in all_bounds)
+            geometry = Context.owner_slab_geometry(max(n_max_chunk, 1), world)
+            hb, subs, cap = geometry
+            parts = world * hb * subs
+            n_unique_local = None
+            if chunks * parts * cap * 16 <= (64 << 30):
+                send = torch.empty((chunks, parts * cap, 4), dtype=torch.int32, device=dev)
+                scur = torch.empty((chunks, parts), dtype=torch.int32, device=dev)
+                recv, rcur = (send, scur) if comm.alone else (torch.empty_like(send), torch.empty_like(scur))
+                ok, totals = True, [0] * world
+                mine = all_bounds[rank]
+                for k in range(chunks):
+                    lo, hi = mine[k] * key_len, mine[k + 1] * key_len
+                    try:
+                        counts = backend.pack_into_owner_slabs(keys if chunks == 1 else keys[lo:hi], key_len, world, n_seg,
+                                                               geometry, send[k], scur[k])
+                    except ValueError:
+                        counts = None
+                    if counts is None:
+                        ok = False                 # (the buffers still travel: every rank takes part in every collective)
+                    else:
+                        totals = [a + b for a, b in zip(totals, counts)]
+                    comm.all_to_all_into(recv[k], send[k])
+                    comm.all_to_all_into(rcur[k], scur[k])
+                comm.settle()
                 if tick:
-                    tick.mark("all-to-all-slabs")
-                n_unique_local = backend.collapse_owner_slabs(r_slabs, r_cur, world, rank, geometry, id_bounds[:-1],
-                                                              max(n_total, 1), int(sum(recv_counts)), n_seg)
-                if comm.any_flag(n_unique_local is None):
-                    n_unique_local = None          # a bucket overflowed somewhere: once more, the general way
-                del s_slabs, s_cur, r_slabs, r_cur, slabs
-                if tick:
-                    tick.mark("collapse")
+                    tick.mark("pack-to-owner-slabs")        # (with the exchange of all chunks but the last under it)
+                if not comm.any_flag(not ok):               # somebody cannot: everybody takes the general way
+                    recv_counts = comm.exchange_counts(totals)
+                    if tick:
+                        tick.mark("all-to-all-slabs")
+                    sender_id0 = [id_bounds[s_] + all_bounds[s_][k] for k in range(chunks) for s_ in range(world)]
+                    n_unique_local = backend.collapse_owner_slabs(recv.reshape(-1, 4), rcur.reshape(-1), world * chunks, rank,
+                                                                  geometry, sender_id0, max(n_total, 1),
+                                                                  int(sum(recv_counts)), n_seg)
+                    if comm.any_flag(n_unique_local is None):
+                        n_unique_local = None      # a bucket overflowed somewhere: once more, the general way
+                    if tick:
+                        tick.mark("collapse")
+                del send, scur, recv, rcur
         if n_unique_local is None:
             foreign = 0
             try:

@@ -975,8 +975,11 @@ def test_sharded_path_on_rccl_world1(F, oracle, monkeypatch, shortcuts):
             assert got.n_unique == want["n_unique"] and got.n_clusters == want["n_clusters"], (d, m, plan)
             assert np.array_equal(got.kept_read_ids.cpu().numpy().astype(np.uint64), want["kept_read_ids"]), (d, m, plan)
             assert got.n_kept == len(want["kept_read_ids"])
-        # short keys: the fused way in (owner-major slabs, exchanged as they are)
+        # short keys: the fused way in (owner-major slabs, exchanged as they are -- in three chunks when the
+        # collectives are real: the exchange of a chunk under the pack of the next)
         monkeypatch.setenv("FQD_OWNER_SLABS_MIN_READS", "1000")
+        if not shortcuts:
+            monkeypatch.setenv("FQD_SHARD_CHUNKS", "3")
         n, L = 200000, 32
         host = synth_keys(n, L, L, 23, sub_rate=3e-3, n_rate=3e-4).reshape(-1)
         got = cluster_keys_sharded(backend, torch.from_numpy(host).to(dev), None, L, max_distance=1, method="directional")

@@ -25,6 +25,10 @@ def _worker(rank, world, port, case, plan, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if plan.endswith("+chunks3"):
+        # ... leaving in three chunks per rank (the exchange of a chunk runs under the pack of the next)
+        plan = plan[: -len("+chunks3")]
+        os.environ["FQD_SHARD_CHUNKS"] = "3"
     if plan.endswith("+slabs"):
         # the fused way in (owner-major slabs) also for a job this small
         plan = plan[: -len("+slabs")]
@@ -55,6 +59,8 @@ def _worker(rank, world, port, case, plan, q):
 @pytest.mark.parametrize("shape,plan", [("fixed32", "segment-routed"), ("fixed32", "gathered"),
                                         ("fixed32", "segment-routed+slabs"), ("fixed32_3ranks", "segment-routed+slabs"),
                                         ("fixed32_5ranks", "segment-routed+slabs"),
+                                        ("fixed32", "segment-routed+slabs+chunks3"),
+                                        ("fixed32_3ranks", "segment-routed+slabs+chunks3"),
                                         ("fixed32_foreign", "segment-routed+slabs"),
                                         ("fixed32_foreign", "segment-routed"),
                                         ("fixed100_weights", "segment-routed"), ("fixed100_weights", "gathered"),
