@@ -212,7 +212,10 @@ int fqd_collapse_received(fqd_ctx *ctx, const uint32_t *weights, const uint64_t 
  * per owner. fqd_collapse_owner_slabs is the receiving side: `slabs` holds, sender by sender, the
  * ranges the n_senders ranks addressed to owner my_part (read in place), `cursors` their cursor
  * tables; sender_id0 (HOST) the id base of each sender's reads, id_limit a bound on all ids,
- * n_reads the reads received in all. The collapse starts at level 2: the senders' bins are its
+ * n_reads the reads received in all. A "sender" is one fqd_pack_to_owner_slabs call: a rank that
+ * packs its reads in several pieces (so that a piece travels while the next is packed) sends
+ * several, in any order -- a sender's reads lie below the next larger id base. The collapse starts
+ * at level 2: the senders' bins are its
  * level 1. *done = 0 (either call): not applicable or a slab overflowed -- nothing was produced,
  * take the general way (fqd_pack_keys + fqd_export_packed_by_segment / fqd_collapse_received).
  * fqd_owner_slab_geometry gives (hash_bins, subs, cap) for ranks that pack at most n_max reads each;
