@@ -239,6 +239,33 @@ def test_fused_pack_collapse_matches_oracle(F, oracle, monkeypatch, case):
             ctx.collapse()       # the packed reads were never written: needs fqd_pack_keys first
 
 
+@pytest.mark.parametrize("L,n_rate,d", [(1, 0.0, 0), (7, 1e-3, 1), (16, 0.05, 1), (17, 1e-4, 2), (31, 1e-3, 1),
+                                        (32, 0.003, 2), (24, 0.0, 1)])
+def test_compact_records_over_lengths_and_n_rates(F, oracle, monkeypatch, L, n_rate, d):
+    """The 12-byte records of the fused collapse (two key words; keys with an N through the side path) against the
+    oracle and against the uint4 records, over key lengths 1..32, N rates from none to so many that the side slabs
+    overflow (uint4 records then), and distances 0..2."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_FUSED_MIN_READS", "50000")
+    n = 260_000                   # (the fused way needs two partition levels: more than 204 800 reads)
+    keys = synth_keys(n, L, min(L, 12), 300 + L, sub_rate=4e-3, n_rate=n_rate)
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=d, method="directional")
+    ctx = F.Context(0)
+    got = F.cluster_keys(raw, key_len=L, max_distance=d, method="directional", context=ctx)
+    kt = ctx.kernel_times(reset=True)
+    assert kt["pack_kernel"][1] >= 1
+    assert kt["part_scatter12_kernel"][1] == 1                                        # 12-byte records (tried first)
+    if L >= 16:    # (very short keys -- 5 or 16 384 distinct ones -- overfill their slabs: the plain way takes over)
+        assert kt["part_scatter_kernel<1>"][1] == 0                                   # ... the fused way in
+    assert (got.n_unique, got.n_clusters) == (want["n_unique"], want["n_clusters"])
+    assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+    monkeypatch.setenv("FQD_NO_COMPACT_RECORDS", "1")
+    other = F.cluster_keys(raw, key_len=L, max_distance=d, method="directional", context=F.Context(0))
+    assert (other.n_unique, other.n_edges, other.n_kept) == (got.n_unique, got.n_edges, got.n_kept)
+    assert np.array_equal(other.kept_read_ids, got.kept_read_ids)
+
+
 @pytest.mark.parametrize("case", ["plain", "weights", "tag_collisions", "heavy_key", "few_buckets", "len300_d2"])
 def test_long_record_collapse_without_sort_matches_oracle(F, oracle, monkeypatch, case):
     """Keys above 32 nt (records longer than one uint4) collapse through (hash, position) pairs: the
