@@ -1078,15 +1078,17 @@ def test_synth_indel_twin(ctx):
     assert set(lens.tolist()) == {L - 1, L, L + 1}
 
 
-@pytest.mark.parametrize("path", ["grouped", "sort", "auto"])
+@pytest.mark.parametrize("path", ["grouped", "sort", "auto", "auto_own_index_hashes"])
 def test_edit_search_with_an_indel_tail_matches_oracle(F, oracle, monkeypatch, path):
     """SURVEY.md 8d's config-5 variant: paired 2x150 keys (300 nt) of which 1 % are 299 or 301 nt
     long, Levenshtein d = 1, adjacency -- 250 k reads against the oracle, through the sort-free
     search (items partitioned and matched in LDS) and through the sorted one; both must also
     report every edge exactly once (same edge count)."""
     from fastqdedup_amd.synth import indel_variant, synth_keys
-    if path == "auto":       # d = 1: Hamming passes for pairs of one length, the edit search for the others
+    if path.startswith("auto"):   # d = 1: Hamming passes for pairs of one length, the edit search for the others
         monkeypatch.delenv("FQD_EDIT", raising=False)
+        if path == "auto_own_index_hashes":     # ... hashing its index items itself instead of taking the passes' hashes
+            monkeypatch.setenv("FQD_EDIT_OWN_INDEX_HASHES", "1")
     else:
         monkeypatch.setenv("FQD_EDIT", path)
     n, L, seed = 250_000, 300, 1005
