@@ -33,6 +33,11 @@
 #ifndef FQD_SCATTER12_EPT
 #define FQD_SCATTER12_EPT 8
 #endif
+// 256-record chunks of a bucket the dedupe requests before it hashes the first (3: 0.344 ms instead of 0.32 at config 3 --
+// a bucket of ~763 records then needs a second trip)
+#ifndef FQD_DD12_AHEAD
+#define FQD_DD12_AHEAD 4
+#endif
 #ifndef FQD_SCATTER12_ROUNDS
 #define FQD_SCATTER12_ROUNDS 1
 #endif
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
     __syncthreads();
 
     bool full = false;
-    constexpr uint32_t DD_AHEAD = 4;
+    constexpr uint32_t DD_AHEAD = FQD_DD12_AHEAD;
     for (uint32_t base0 = lo; base0 < hi; base0 += DD_AHEAD * DD_THREADS) {
         fqd::Rec12 ahead[DD_AHEAD];
         uint32_t ahead_w[DD_AHEAD];
