@@ -463,8 +463,11 @@ def main():
         print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()
-    if out.get("cpu_baseline", {}).get("parity") is False:
-        raise SystemExit("PARITY FAILURE: the HIP path and the CPU reference disagree on the cpu_baseline sample")
+    if "cpu_baseline" in out and out["cpu_baseline"].get("parity") is not True:
+        # false: the two disagree; missing: the baseline or the parity run raised -- neither is a pass
+        raise SystemExit("PARITY FAILURE: the HIP path and the CPU reference disagree on the cpu_baseline sample"
+                         if out["cpu_baseline"].get("parity") is False else
+                         f"PARITY UNCHECKED: {out['cpu_baseline'].get('error', 'no parity verdict')}")
 
 
 if __name__ == "__main__":

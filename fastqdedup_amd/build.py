@@ -82,7 +82,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if r.returncode:
             raise RuntimeError(f"{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
         remarks = [ln for ln in r.stderr.splitlines() if "kernel-resource-usage" in ln]
-        if remarks:
+        if "-c" in cmd:  # objects without kernels get an empty table, so they are not rebuilt every time
             _save_resources(cmd[-1] + ".resources.json", remarks)
         rest = "\n".join(ln for ln in r.stderr.splitlines() if "kernel-resource-usage" not in ln)
         if verbose and rest.strip():

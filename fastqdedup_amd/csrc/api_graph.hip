@@ -29,6 +29,8 @@ static int components_queue(fqd_ctx *c, bool flatten)
         HIP_TRY(c, hipMemsetAsync(c->hook_slots.p, 0, FQD_HOOK_SLOTS * 64, c->st));
         HIP_TRY(c, fqd::launch_uf_init(c->labels.as<uint32_t>(), U, c->st));
     }
+    if (c->store_removed && c->store_table_U == U)     // keys of popped clusters link nothing any more
+        HIP_TRY(c, fqd::launch_mask_dead_edges(c->edges.as<uint32_t>(), c->E, c->store_alive.as<uint8_t>(), c->st));
     KTIME(c, FQD_K_UF_UNION, fqd::launch_uf_union(c->labels.as<uint32_t>(), c->edges.as<uint32_t>(), c->E,
                                                   c->hook_slots.as<unsigned long long>(), c->st));
     HIP_TRY(c, fqd::launch_hook_total(c->hook_slots.as<unsigned long long>(), U,

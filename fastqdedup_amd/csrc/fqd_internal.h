@@ -475,6 +475,7 @@ hipError_t launch_quality(const uint8_t *bytes, uint64_t n_bytes, const uint64_t
 
 // graph.hip -- union-find + dissection
 hipError_t launch_uf_init(uint32_t *parent, uint64_t U, hipStream_t st);
+hipError_t launch_mask_dead_edges(uint32_t *edges, uint64_t E, const uint8_t *alive, hipStream_t st);
 hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, unsigned long long *n_hooks,
                            hipStream_t st);
 uint32_t kept_bin_shift(uint64_t window);

@@ -118,6 +118,19 @@ __global__ void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ e
     }
 }
 
+// An edge with an end taken out of the store (fqd_store_remove: a popped cluster's key) becomes a
+// self-loop, which every consumer skips: a popped key must not bridge two stored keys when the
+// caller pops again with another distance (the reference's trie no longer holds it, _triemodule.c:830).
+__global__ void mask_dead_edges_kernel(uint32_t *edges, uint64_t E, const uint8_t *__restrict__ alive)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E)
+        return;
+    const uint2 uv = reinterpret_cast<const uint2 *>(edges)[e];
+    if (uv.x != uv.y && !(alive[uv.x] && alive[uv.y]))
+        reinterpret_cast<uint2 *>(edges)[e] = make_uint2(uv.x, uv.x);
+}
+
 // *n_components = n_nodes - sum of the hook slots (one wave)
 __global__ void hook_total_kernel(const unsigned long long *__restrict__ slots, uint64_t n_nodes,
                                   unsigned long long *n_components)
@@ -1036,6 +1049,13 @@ hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, 
 {
     if (E)
         uf_union_kernel<<<grid_for(E), 256, 0, st>>>(parent, edges, E, n_hooks);
+    return hipGetLastError();
+}
+
+hipError_t launch_mask_dead_edges(uint32_t *edges, uint64_t E, const uint8_t *alive, hipStream_t st)
+{
+    if (E)
+        mask_dead_edges_kernel<<<grid_for(E), 256, 0, st>>>(edges, E, alive);
     return hipGetLastError();
 }
 

@@ -85,6 +85,34 @@ def test_trie_census_fuzz_matches_oracle_trie(F, oracle):
         assert a.memory_size() == 0 and a.number_of_sequences == 0
 
 
+def test_pops_with_changing_parameters_never_see_popped_keys(F, oracle):
+    """pop_cluster(d) then pop_cluster(d') on the same object: the second clustering runs over the
+    resident table, whose popped rows must link nothing (the reference deleted them from its trie,
+    _triemodule.c:830-831,875-876). AAAA / AACC / CCAA: once AAAA is gone, d=2 leaves AACC and CCAA apart."""
+    a, b = F.Trie("ACGTN"), oracle.Trie("ACGTN")
+    for s in ("AAAA", "AACC", "CCAA"):
+        a.add_sequence(s)
+        b.add_sequence(s)
+    assert sorted(a.pop_cluster(1)) == sorted(b.pop_cluster(1)) == [(1, "AAAA")]
+    while b.number_of_sequences:
+        ca, cb = a.pop_cluster(2), b.pop_cluster(2)
+        assert sorted(ca) == sorted(cb) and ca[0] == cb[0]
+    assert a.number_of_sequences == 0
+    rng = random.Random(5)
+    for trial in range(60):
+        syms = rng.choice(["ACGT", "ACGTN", "AC"])
+        a, b = F.Trie("ACGTN"), oracle.Trie("ACGTN")
+        for _ in range(rng.randint(2, 50)):
+            s = _rand(rng, syms, 3, 6)
+            a.add_sequence(s)
+            b.add_sequence(s)
+        while b.number_of_sequences:
+            d, edit = rng.randint(0, 3), rng.random() < 0.5     # new parameters at every pop
+            ca, cb = a.pop_cluster(d, edit), b.pop_cluster(d, edit)
+            assert sorted(ca) == sorted(cb) and ca[0] == cb[0], (trial, d, edit)
+            assert a.number_of_sequences == b.number_of_sequences
+
+
 def test_census_at_scale_matches_oracle_trie(F, oracle):
     """30 k reads of 40 nt (config-like synthetic keys with N): the census after pass 1 -- what the
     reference's DEBUG log prints (__init__.py:260-264) -- and after popping half of the clusters."""
