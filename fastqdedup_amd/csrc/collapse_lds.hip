@@ -491,29 +491,31 @@ __device__ __forceinline__ uint32_t rec12_tag(uint32_t a, uint32_t b)
     return h == DD_EMPTY ? 0u : h;
 }
 
-// bucket_dedupe_kernel for Rec12 items (same rounds: claim or stop at a matching tag, barrier, verify against
-// the parked key); a live slot leaves as ONE uint4 (a, b, count, first index) at tmp[lo + rank]
+// bucket_dedupe_kernel for Rec12 items. The two key words of an item ARE the key, so a slot is one 64-bit word
+// and ONE 64-bit LDS compare-and-swap both claims an empty slot and recognises the key in a taken one: no tag,
+// no parked record to verify against, hence no workgroup barrier between claiming and verifying -- the rounds of
+// the uint4 kernel above (claim, barrier, verify, barrier) were what bounded this kernel (0.32 ms at config 3:
+// 65 536 workgroups of ~10 us, parked on barriers half of their cycles). The all-ones key (32 x 'T') doubles as
+// the EMPTY mark and is counted in a slot of its own behind the table. A live slot leaves as ONE uint4
+// (a, b, count, first index) at tmp[lo + rank].
+constexpr unsigned long long DD_EMPTY64 = ~0ull;
+
 __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
     const fqd::Rec12 *__restrict__ part, const uint32_t *__restrict__ bucket_start,
     const uint32_t *__restrict__ bucket_end, const uint32_t *__restrict__ weights, uint4 *__restrict__ tmp,
     uint32_t *__restrict__ bucket_unique, uint32_t *__restrict__ overflow)
 {
-    __shared__ uint32_t s_tag[DD_SLOTS], s_x[DD_SLOTS], s_y[DD_SLOTS], s_cnt[DD_SLOTS], s_min[DD_SLOTS];
+    __shared__ unsigned long long s_key[DD_SLOTS + 1];
+    __shared__ uint32_t s_cnt[DD_SLOTS + 1], s_min[DD_SLOTS + 1];
     __shared__ uint32_t s_wave_tot[DD_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
-    // (slab mode: requesting the first 1024 slots of the slab at once, before the bucket's end is known -- the
-    // start is b * slab_cap -- saves a round trip but reads a third more: 0.329 instead of 0.313 ms)
     const uint32_t lo = bucket_start[b];
     uint32_t hi = bucket_start[b + 1];
     if (bucket_end)
         hi = min(hi, bucket_end[b]);
-    for (uint32_t s = tid; s < DD_SLOTS; s += DD_THREADS)
-        s_tag[s] = DD_EMPTY;
-    __syncthreads();
-
-    bool full = false;
     constexpr uint32_t DD_AHEAD = FQD_DD12_AHEAD;
+    bool full = false;
     for (uint32_t base0 = lo; base0 < hi; base0 += DD_AHEAD * DD_THREADS) {
         fqd::Rec12 ahead[DD_AHEAD];
         uint32_t ahead_w[DD_AHEAD];
@@ -524,75 +526,68 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
             if (i < hi)
                 ahead[k] = part[i];
         }
+        if (base0 == lo) {                    // (the table is cleared while the first items are on their way)
+            for (uint32_t s = tid; s <= DD_SLOTS; s += DD_THREADS) {
+                s_key[s] = DD_EMPTY64;
+                s_cnt[s] = 0u;
+                s_min[s] = 0xFFFFFFFFu;
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (uint32_t k = 0; k < DD_AHEAD; k++) {
             const uint32_t i = base0 + k * DD_THREADS + tid;
             ahead_w[k] = i < hi ? (weights ? weights[ahead[k].id] : 1u) : 0u;
         }
-        uint32_t tag[DD_AHEAD], slot[DD_AHEAD], probes[DD_AHEAD];
-        bool pending[DD_AHEAD];
+        unsigned long long key[DD_AHEAD];
+        uint32_t slot[DD_AHEAD];
+        uint32_t pend = 0;
 #pragma unroll
         for (uint32_t k = 0; k < DD_AHEAD; k++) {
-            tag[k] = rec12_tag(ahead[k].a, ahead[k].b);
-            slot[k] = (tag[k] * 0x9E3779B1u) >> 22;
-            probes[k] = 0;
-            pending[k] = base0 + k * DD_THREADS + tid < hi;
-        }
-        bool any;
-        do {
-#pragma unroll
-            for (uint32_t k = 0; k < DD_AHEAD; k++) {
-                if (!pending[k])
-                    continue;
-                for (;;) {
-                    const uint32_t old = atomicCAS(&s_tag[slot[k]], DD_EMPTY, tag[k]);
-                    if (old == DD_EMPTY) {
-                        s_x[slot[k]] = ahead[k].a;
-                        s_y[slot[k]] = ahead[k].b;
-                        s_cnt[slot[k]] = ahead_w[k];
-                        s_min[slot[k]] = ahead[k].id;
-                        pending[k] = false;
-                        break;
-                    }
-                    if (old == tag[k])
-                        break;
-                    slot[k] = (slot[k] + 1) & (DD_SLOTS - 1);
-                    if (++probes[k] >= DD_SLOTS) {
-                        full = true;
-                        pending[k] = false;
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-            any = false;
-#pragma unroll
-            for (uint32_t k = 0; k < DD_AHEAD; k++) {
-                if (!pending[k])
-                    continue;
-                if (s_x[slot[k]] == ahead[k].a && s_y[slot[k]] == ahead[k].b) {
-                    atomicAdd(&s_cnt[slot[k]], ahead_w[k]);
-                    atomicMin(&s_min[slot[k]], ahead[k].id);
-                    pending[k] = false;
+            key[k] = ((unsigned long long)ahead[k].b << 32) | ahead[k].a;
+            slot[k] = (rec12_tag(ahead[k].a, ahead[k].b) * 0x9E3779B1u) >> 22;   // top 10 bits of a re-mix: DD_SLOTS == 1024
+            if (base0 + k * DD_THREADS + tid < hi) {
+                if (key[k] == DD_EMPTY64) {
+                    atomicAdd(&s_cnt[DD_SLOTS], ahead_w[k]);
+                    atomicMin(&s_min[DD_SLOTS], ahead[k].id);
                 } else {
-                    slot[k] = (slot[k] + 1) & (DD_SLOTS - 1);
-                    if (++probes[k] >= DD_SLOTS) {
-                        full = true;
-                        pending[k] = false;
-                    } else {
-                        any = true;
-                    }
+                    pend |= 1u << k;
                 }
             }
-        } while (__syncthreads_or(any));
+        }
+        for (uint32_t probes = 0; pend && probes < DD_SLOTS; probes++) {
+            unsigned long long old[DD_AHEAD];
+#pragma unroll
+            for (uint32_t k = 0; k < DD_AHEAD; k++)       // the compare-and-swaps of all pending items in flight together
+                if (pend >> k & 1u)
+                    old[k] = atomicCAS(&s_key[slot[k]], DD_EMPTY64, key[k]);
+#pragma unroll
+            for (uint32_t k = 0; k < DD_AHEAD; k++)
+                if (pend >> k & 1u) {
+                    if (old[k] == DD_EMPTY64 || old[k] == key[k]) {
+                        atomicAdd(&s_cnt[slot[k]], ahead_w[k]);
+                        atomicMin(&s_min[slot[k]], ahead[k].id);
+                        pend &= ~(1u << k);
+                    } else {
+                        slot[k] = (slot[k] + 1) & (DD_SLOTS - 1);
+                    }
+                }
+        }
+        full = full || pend;
     }
     if (full)
         atomicOr(overflow, 1u);
     __syncthreads();
 
+    // live slots (count > 0: a key all of whose holders have weight 0 is not in the trie), the slot behind the
+    // table included
+    constexpr uint32_t PER = (DD_SLOTS + DD_THREADS) / DD_THREADS;     // slots per thread, table + 1
     uint32_t mine = 0;
-    for (uint32_t s = tid; s < DD_SLOTS; s += DD_THREADS)
-        mine += (s_tag[s] != DD_EMPTY && s_cnt[s] > 0) ? 1u : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t s = tid + k * DD_THREADS;
+        mine += (s <= DD_SLOTS && s_cnt[s] > 0) ? 1u : 0u;
+    }
     uint32_t incl = mine;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t up = __shfl_up(incl, o);
@@ -609,9 +604,14 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
     for (uint32_t wv = 0; wv < DD_THREADS / 64; wv++)
         total += s_wave_tot[wv];
     uint32_t out = lo + before;
-    for (uint32_t s = tid; s < DD_SLOTS; s += DD_THREADS)
-        if (s_tag[s] != DD_EMPTY && s_cnt[s] > 0)
-            tmp[out++] = make_uint4(s_x[s], s_y[s], s_cnt[s], s_min[s]);
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t s = tid + k * DD_THREADS;
+        if (s <= DD_SLOTS && s_cnt[s] > 0) {
+            const unsigned long long kk = s_key[s];     // (the extra slot's key was never written: it IS the EMPTY pattern)
+            tmp[out++] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), s_cnt[s], s_min[s]);
+        }
+    }
     if (tid == 0)
         bucket_unique[b] = total;
 }
