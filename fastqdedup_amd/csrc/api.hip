@@ -327,7 +327,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         FQD_TRY(queued_reads_mark(c));
         HIP_TRY(c, c->urecs.reserve(n * 16 + 16));
         HIP_TRY(c, c->ucounts.reserve(n * 4 + 16));
-        HIP_TRY(c, c->ufirst.reserve(n * 8 + 16));
+        HIP_TRY(c, c->ufirst.reserve(n * 8 + 64));
         // fqd_cluster[_keys] announced a Hamming search with nseg segments: the compaction writes its
         // segment hashes on the way (the records are fixed-length here)
         fqd::SegHashOut sho;
@@ -448,7 +448,7 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
     HIP_TRY(c, c->urecs.reserve(U * sh.stride * 4 + 16));
     HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
     HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
-    HIP_TRY(c, c->ufirst.reserve(U * 8 + 16));
+    HIP_TRY(c, c->ufirst.reserve(U * 8 + 64));
     // fqd_cluster[_keys] announced a Hamming search with nseg segments: the compaction writes its
     // segment hashes on the way (records whose uint4 count divides 64: their lanes sit side by side)
     fqd::SegHashOut sho;
@@ -905,7 +905,7 @@ static int collapse_impl(fqd_ctx *c, const uint32_t *weights, int mem, IdSource 
     HIP_TRY(c, c->urecs.reserve(U * sh.stride * 4 + 16));
     HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
     HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
-    HIP_TRY(c, c->ufirst.reserve(U * 8 + 16));
+    HIP_TRY(c, c->ufirst.reserve(U * 8 + 64));
     KTIME(c, FQD_K_WRITE_UNIQUE, fqd::launch_write_unique(c->run_start.as<uint32_t>(), c->run_weight.as<uint32_t>(),
                                         c->live_flag.as<uint32_t>(), c->live_idx.as<uint32_t>(), n_runs,
                                         c->ids_sorted.as<uint32_t>(), c->recs.as<uint32_t>(), c->lens.as<uint32_t>(),
@@ -1032,7 +1032,7 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
         // (the side path writes the head of the unique table before the compaction is queued)
         HIP_TRY(c, c->urecs.reserve(n * 16 + 16));
         HIP_TRY(c, c->ucounts.reserve(n * 4 + 16));
-        HIP_TRY(c, c->ufirst.reserve(n * 8 + 16));
+        HIP_TRY(c, c->ufirst.reserve(n * 8 + 64));
     }
     // the slab starts of the pack kernel's parts and, ahead of the pack, of level 2 (the geometry collapse_lds will
     // compute) and of the side path: one launch

@@ -253,7 +253,7 @@ int fqd_import_unique(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, co
         HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
     }
     HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
-    HIP_TRY(c, c->ufirst.reserve(U * 8 + 16));
+    HIP_TRY(c, c->ufirst.reserve(U * 8 + 64));
     if (U) {
         if (!borrow) {
             HIP_TRY(c, hipMemcpyAsync(c->urecs.p, recs, U * sh.stride * 4, kind, c->st));

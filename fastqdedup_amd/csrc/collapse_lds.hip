@@ -76,10 +76,18 @@ struct RecordPolicy {
         return (s.ids.stamp_map ? s.ids.stamp_map[sender] : sender) << s.ids.packed_bits;
     }
     static __device__ __forceinline__ void apply_tag(uint4 &v, uint32_t tag) { v.w |= tag; }
+    using Raw = uint4;
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint4 fetch(const Source &s, uint32_t i) { return s.in[i]; }
     template <bool LEVEL1>
     static __device__ __forceinline__ uint32_t load(const Source &s, uint32_t i, uint4 &v)
     {
-        v = s.in[i];
+        return finish<LEVEL1>(s, i, s.in[i], v, true);
+    }
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint32_t finish(const Source &s, uint32_t i, const uint4 &raw, uint4 &v, bool)
+    {
+        v = raw;
         if (LEVEL1) {
             // words past the key are padding: zero on this rank's own packed reads, but a sender's
             // local index on reads received from other ranks (fqd_collapse_received) -- never part
@@ -100,13 +108,21 @@ struct RecordPolicy {
         const uint32_t rec[3] = {v.x, v.y, v.z};
         return fqd_hash_record(rec, s.kw, s.len);
     }
+    using KeyRaw = uint4;
     template <bool LEVEL1>
-    static __device__ __forceinline__ uint32_t key(const Source &s, uint32_t i)
+    static __device__ __forceinline__ uint4 key_fetch(const Source &s, uint32_t i)
     {
         if (LEVEL1 && s.hashes)
-            return s.hashes[i];
+            return make_uint4(s.hashes[i], 0u, 0u, 0u);
+        return s.in[i];
+    }
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint32_t key_finish(const Source &s, uint32_t i, const uint4 &raw)
+    {
+        if (LEVEL1 && s.hashes)
+            return raw.x;
         uint4 v;
-        return load<false>(s, i, v);
+        return finish<false>(s, i, raw, v, true);
     }
 };
 
@@ -433,13 +449,20 @@ struct CompactPolicy {
     static __device__ __forceinline__ void apply_tag(fqd::Rec12 &, uint32_t) {}
     // a record that left through the side slabs: not staged, not written
     static __device__ __forceinline__ bool skip(const fqd::Rec12 &v) { return v.id == 0xFFFFFFFFu; }
+    using Raw = uint4;
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint4 fetch(const Source &s, uint32_t i) { return s.in[i]; }
     template <bool LEVEL1>
     static __device__ __forceinline__ uint32_t load(const Source &s, uint32_t i, fqd::Rec12 &v)
     {
-        const uint4 r = s.in[i];
+        return finish<LEVEL1>(s, i, s.in[i], v, true);
+    }
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint32_t finish(const Source &s, uint32_t, const uint4 &r, fqd::Rec12 &v, bool valid)
+    {
         const bool squeeze = s.squeeze == 1;
         const bool rare = squeeze && (r.x & r.y) != 0u;
-        if (rare) {
+        if (rare && valid) {
             // a key with an N (few: one global atomic each, spread over the side slabs by workgroup)
             const uint32_t slab = blockIdx.x & (s.side.n_slabs - 1);
             const uint32_t pos = atomicAdd(&s.side.cursor[slab], 1u);
@@ -455,11 +478,14 @@ struct CompactPolicy {
         v.id = rare ? 0xFFFFFFFFu : r.w;
         return rare ? 0u : fqd::fqd_hash_rec12(v.a, v.b);
     }
+    using KeyRaw = uint4;
     template <bool LEVEL1>
-    static __device__ __forceinline__ uint32_t key(const Source &s, uint32_t i)
+    static __device__ __forceinline__ uint4 key_fetch(const Source &s, uint32_t i) { return s.in[i]; }
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint32_t key_finish(const Source &s, uint32_t i, const uint4 &raw)
     {
         fqd::Rec12 v;
-        return load<false>(s, i, v);
+        return finish<false>(s, i, raw, v, false);     // (a histogram pass puts nothing on the side path)
     }
 };
 
@@ -516,24 +542,24 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
         hi = min(hi, bucket_end[b]);
     constexpr uint32_t DD_AHEAD = FQD_DD12_AHEAD;
     bool full = false;
-    for (uint32_t base0 = lo; base0 < hi; base0 += DD_AHEAD * DD_THREADS) {
-        fqd::Rec12 ahead[DD_AHEAD];
-        uint32_t ahead_w[DD_AHEAD];
+    fqd::Rec12 ahead[DD_AHEAD];
+    const uint32_t last = max(hi, lo + 1) - 1;       // (an empty bucket still owns its slab: part[lo] is readable)
+    auto fetch = [&](uint32_t base0) {
 #pragma unroll
-        for (uint32_t k = 0; k < DD_AHEAD; k++) {
-            const uint32_t i = base0 + k * DD_THREADS + tid;
-            ahead[k] = fqd::Rec12{0, 0, 0};
-            if (i < hi)
-                ahead[k] = part[i];
-        }
-        if (base0 == lo) {                    // (the table is cleared while the first items are on their way)
-            for (uint32_t s = tid; s <= DD_SLOTS; s += DD_THREADS) {
-                s_key[s] = DD_EMPTY64;
-                s_cnt[s] = 0u;
-                s_min[s] = 0xFFFFFFFFu;
-            }
-            __syncthreads();
-        }
+        for (uint32_t k = 0; k < DD_AHEAD; k++)      // clamped, not conditional: the loads are in flight together
+            ahead[k] = part[min(base0 + k * DD_THREADS + tid, last)];
+    };
+    fetch(lo);                                // (the table is cleared while the first items are on their way)
+    for (uint32_t s = tid; s <= DD_SLOTS; s += DD_THREADS) {
+        s_key[s] = DD_EMPTY64;
+        s_cnt[s] = 0u;
+        s_min[s] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (uint32_t base0 = lo; base0 < hi; base0 += DD_AHEAD * DD_THREADS) {
+        if (base0 != lo)
+            fetch(base0);
+        uint32_t ahead_w[DD_AHEAD];
 #pragma unroll
         for (uint32_t k = 0; k < DD_AHEAD; k++) {
             const uint32_t i = base0 + k * DD_THREADS + tid;

@@ -378,18 +378,15 @@ __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *
     for (uint32_t t = 0; t < DE_EPT; t++) {       // the edge and count gathers of all four edges in flight
         const uint64_t e = ((uint64_t)blockIdx.x * DE_EPT + t) * blockDim.x + threadIdx.x;
         live[t] = e < E;
-        uu[t] = vv[t] = 0;
-        if (live[t]) {
-            const uint2 uv = reinterpret_cast<const uint2 *>(edges)[e];
-            uu[t] = uv.x;
-            vv[t] = uv.y;
-        }
+        const uint2 uv = reinterpret_cast<const uint2 *>(edges)[min(e, E - 1)];    // (clamped, unconditional: in flight together)
+        uu[t] = uv.x;
+        vv[t] = uv.y;
     }
 #pragma unroll
     for (uint32_t t = 0; t < DE_EPT; t++) {
         live[t] = live[t] && uu[t] != vv[t];
-        cu[t] = live[t] ? ucounts[uu[t]] : 0u;
-        cv[t] = live[t] ? ucounts[vv[t]] : 0u;
+        cu[t] = ucounts[uu[t]];
+        cv[t] = ucounts[vv[t]];
     }
     uint32_t rank[DE_EPT];
 #pragma unroll
@@ -622,20 +619,27 @@ __device__ __forceinline__ void kept_verdicts(int method, const uint32_t (&v)[N]
 {
     if (method == 3) {
         // the state byte decides (pass 2 marked the few keys that have to ask their set's root)
+        // (v[t] of an invalid entry is a clamped, readable index: the loads are unconditional, so that all N are in
+        // flight together -- "valid ? state[v] : 2" compiles to N branches with a wait in each)
         uint8_t st[N];
 #pragma unroll
         for (uint32_t t = 0; t < N; t++)
-            st[t] = valid[t] ? state[v[t]] : (uint8_t)2;
+            st[t] = state[v[t]];
 #pragma unroll
         for (uint32_t t = 0; t < N; t++) {
+            if (!valid[t])
+                st[t] = 2;
             k[t] = st[t] == 0;
             if (st[t] & 8)
                 k[t] = kept_verdict(3, v[t], labels, best, state, ucounts, parent1, root_taint);
         }
     } else {
 #pragma unroll
+        for (uint32_t t = 0; t < N; t++)     // (unconditional, as above)
+            k[t] = kept_verdict(method, v[t], labels, best, state, ucounts, parent1, root_taint);
+#pragma unroll
         for (uint32_t t = 0; t < N; t++)
-            k[t] = valid[t] && kept_verdict(method, v[t], labels, best, state, ucounts, parent1, root_taint);
+            k[t] = k[t] && valid[t];
     }
 }
 
@@ -665,17 +669,14 @@ __global__ __launch_bounds__(256) void kept_flags_kernel(int method, const uint3
         for (uint32_t t = 0; t < KF; t++) {
             const uint64_t v = v0 + t * stride;
             k[t] = false;
-            id[t] = 0;
-            if (v >= U)
-                continue;
-            id[t] = ufirst[v];
+            id[t] = ufirst[min(v, U - 1)];
         }
         {
             uint32_t vv[KF];
             bool valid[KF];
 #pragma unroll
             for (uint32_t t = 0; t < KF; t++) {
-                vv[t] = (uint32_t)(v0 + t * stride);
+                vv[t] = (uint32_t)min(v0 + t * stride, U - 1);
                 valid[t] = v0 + t * stride < U;
             }
             kept_verdicts<KF>(method, vv, valid, labels, best, state, ucounts, parent1, root_taint, k);
@@ -725,60 +726,109 @@ __global__ __launch_bounds__(256) void kept_flags_kernel(int method, const uint3
 //   kept_emit_kernel  four workgroups per bin: the bin's offsets set bits in LDS bit maps of the
 //                     bin's quarters; the maps are scanned and the ids are written in ascending
 //                     order behind the ids of everything before them.
-constexpr uint32_t KB_THREADS = 256, KB_KPT = FQD_KB_KPT, KB_TILE = KB_THREADS * KB_KPT, KB_MAX_BINS = 512, KB_SUBS = FQD_KB_SUBS;
+constexpr uint32_t KB_KPT = FQD_KB_KPT, KB_MAX_BINS = 512;
 
-__global__ __launch_bounds__(KB_THREADS) void kept_bin_kernel(
-    int method, const uint32_t *__restrict__ labels, const uint32_t *__restrict__ best,
+// lists per id bin (tile t appends to list t % subs): FQD_KB_SUBS in the environment, else the compile-time default
+static uint32_t kb_subs()
+{
+    static const uint32_t v = [] {
+        const char *e = getenv("FQD_KB_SUBS");
+        const int x = e ? atoi(e) : FQD_KB_SUBS;
+        return (uint32_t)(x < 1 ? 1 : x > 8 ? 8 : x);
+    }();
+    return v;
+}
+
+// METHOD and the workgroup size are template parameters (with the method in a register the kernel carried the loads
+// and registers of all four verdict rules). A thread takes KB_KPT / 4 groups of FOUR CONSECUTIVE keys: their first-
+// holder ids are two 16-byte loads, their state bytes one dword, their kept flags one dword store (key by key: 16
+// 8-byte loads, 16 byte loads and 16 byte stores per thread, each store instruction a 64-byte piece of a line);
+// every load of the tile is issued before the first verdict (clamped addresses, no branch around a load). The
+// staged offset names its own bin (offset >> bin_shift): no second staging array, so a 1024-thread workgroup stages
+// 16 Ki offsets in 64 KB and a (tile, bin) run is 4 x as long as with 256 threads.
+template <int METHOD, uint32_t THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void kept_bin_kernel(
+    uint32_t KB_SUBS, const uint32_t *__restrict__ labels, const uint32_t *__restrict__ best,
     const uint8_t *__restrict__ state, const uint64_t *__restrict__ ufirst, uint64_t id_lo, uint64_t window,
     uint64_t U, uint8_t *__restrict__ kept, const uint32_t *__restrict__ ucounts,
     const uint32_t *__restrict__ parent1, const uint8_t *__restrict__ root_taint, uint32_t bin_shift,
     uint32_t n_bins, uint32_t *__restrict__ cursor /* [n_bins][KB_SUBS], starts at (b * KB_SUBS + s) << bin_shift */,
     uint32_t *__restrict__ lists, unsigned long long *__restrict__ n_kept_total)
 {
-    __shared__ uint32_t s_hist[KB_MAX_BINS], s_off[KB_MAX_BINS], s_base[KB_MAX_BINS], s_wave[KB_THREADS / 64];
-    __shared__ uint32_t s_stage[KB_TILE];
-    __shared__ uint16_t s_stage_bin[KB_TILE];
+    constexpr uint32_t TILE = THREADS * KB_KPT, WAVES = THREADS / 64, GROUPS = KB_KPT / 4;
+    constexpr uint32_t BPT = KB_MAX_BINS > THREADS ? KB_MAX_BINS / THREADS : 1u;       // bins per thread of the scan
+    static_assert(KB_KPT % 4 == 0, "groups of four keys");
+    __shared__ uint32_t s_hist[KB_MAX_BINS], s_off[KB_MAX_BINS], s_base[KB_MAX_BINS], s_wave[WAVES];
+    __shared__ uint32_t s_stage[TILE];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint64_t v0 = (uint64_t)blockIdx.x * KB_TILE;
-    for (uint32_t b = tid; b < n_bins; b += KB_THREADS)
+    const uint64_t v0 = (uint64_t)blockIdx.x * TILE;
+    const uint64_t last4 = (U - 1) & ~3ull;      // the last group of four (its tail may lie behind the table: the
+                                                 // buffers have the slack, the verdicts are masked)
+    // ---- every load of the tile
+    ulonglong2 idv[GROUPS][2];
+    uint32_t st4[GROUPS];
+#pragma unroll
+    for (uint32_t g = 0; g < GROUPS; g++) {
+        const uint64_t vb = min(v0 + ((uint64_t)g * THREADS + tid) * 4, last4);
+        const ulonglong2 *f2 = reinterpret_cast<const ulonglong2 *>(ufirst + vb);
+        idv[g][0] = f2[0];
+        idv[g][1] = f2[1];
+        st4[g] = METHOD == 3 || METHOD == 1 ? *reinterpret_cast<const uint32_t *>(state + vb) : 0u;
+    }
+    for (uint32_t b = tid; b < n_bins; b += THREADS)
         s_hist[b] = 0;
     __syncthreads();
     uint32_t off[KB_KPT], rank[KB_KPT];
-    uint32_t bin[KB_KPT];
-    uint32_t total = 0;
-    // eight keys at a time: all their loads are issued together
+    uint32_t total = 0, listed_mask = 0;
 #pragma unroll
-    for (uint32_t g = 0; g < KB_KPT; g += 8) {
-        bool k[8], valid[8];
-        uint32_t vv[8];
-        uint64_t id[8];
+    for (uint32_t g = 0; g < GROUPS; g++) {
+        const uint64_t vg = v0 + ((uint64_t)g * THREADS + tid) * 4, vb = min(vg, last4);
+        const uint64_t id[4] = {idv[g][0].x, idv[g][0].y, idv[g][1].x, idv[g][1].y};
+        bool k[4];
+        if (METHOD == 3 || METHOD == 1) {
 #pragma unroll
-        for (uint32_t t = 0; t < 8; t++) {
-            const uint64_t v = v0 + (g + t) * KB_THREADS + tid;
-            valid[t] = v < U;
-            vv[t] = (uint32_t)v;
-            id[t] = valid[t] ? ufirst[v] : 0;
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t st = (st4[g] >> (8 * j)) & 0xFFu;
+                k[j] = METHOD == 1 ? st == 1 : st == 0;
+                if (METHOD == 3 && (st & 8) && vb + j < U)     // (few) a member of a set of count-1 keys asks its root
+                    k[j] = kept_verdict(3, (uint32_t)(vb + j), labels, best, state, ucounts, parent1, root_taint);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)       // (unconditional loads at clamped keys)
+                k[j] = kept_verdict(METHOD, (uint32_t)min(vb + j, U - 1), labels, best, state, ucounts, parent1, root_taint);
         }
-        kept_verdicts<8>(method, vv, valid, labels, best, state, ucounts, parent1, root_taint, k);
+        uint32_t flags = 0;
 #pragma unroll
-        for (uint32_t t = 0; t < 8; t++) {
-            const uint64_t v = v0 + (g + t) * KB_THREADS + tid;
-            bin[g + t] = 0xFFFFFFFFu;
-            if (v >= U)
-                continue;
-            kept[v] = k[t] ? 1 : 0;
-            total += k[t] ? 1u : 0u;
-            if (k[t] && id[t] >= id_lo && id[t] - id_lo < window) {
-                off[g + t] = (uint32_t)(id[t] - id_lo);
-                bin[g + t] = off[g + t] >> bin_shift;
-                rank[g + t] = atomicAdd(&s_hist[bin[g + t]], 1u);
+        for (uint32_t j = 0; j < 4; j++) {
+            const bool valid = vg == vb && vb + j < U;     // (a clamped group repeats keys another thread owns)
+            k[j] = k[j] && valid;
+            flags |= k[j] ? 1u << (8 * j) : 0u;
+            total += k[j] ? 1u : 0u;
+            if (k[j] && id[j] >= id_lo && id[j] - id_lo < window) {
+                off[g * 4 + j] = (uint32_t)(id[j] - id_lo);
+                rank[g * 4 + j] = atomicAdd(&s_hist[off[g * 4 + j] >> bin_shift], 1u);
+                listed_mask |= 1u << (g * 4 + j);
+            }
+        }
+        if (vg == vb) {
+            if (vb + 4 <= U) {
+                *reinterpret_cast<uint32_t *>(kept + vb) = flags;
+            } else {
+                for (uint32_t j = 0; vb + j < U; j++)
+                    kept[vb + j] = (uint8_t)(flags >> (8 * j));
             }
         }
     }
     __syncthreads();
-    // exclusive scan of the bin counts (n_bins <= 512: two bins per thread) + one reservation per bin
-    const uint32_t b0 = 2 * tid, c0 = b0 < n_bins ? s_hist[b0] : 0u, c1 = b0 + 1 < n_bins ? s_hist[b0 + 1] : 0u;
-    const uint32_t mine = c0 + c1;
+    // exclusive scan of the bin counts (n_bins <= KB_MAX_BINS: BPT consecutive bins per thread) + one reservation per bin
+    uint32_t cnt[BPT], mine = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < BPT; q++) {
+        const uint32_t b = tid * BPT + q;
+        cnt[q] = b < n_bins ? s_hist[b] : 0u;
+        mine += cnt[q];
+    }
     uint32_t incl = mine;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t up = __shfl_up(incl, o);
@@ -788,30 +838,40 @@ __global__ __launch_bounds__(KB_THREADS) void kept_bin_kernel(
     if (lane == 63)
         s_wave[wave] = incl;
     __syncthreads();
-    uint32_t run = incl - mine;
-    for (uint32_t wv = 0; wv < wave; wv++)
-        run += s_wave[wv];
+    uint32_t run = incl - mine, listed = 0;
+    for (uint32_t wv = 0; wv < WAVES; wv++) {
+        run += wv < wave ? s_wave[wv] : 0u;
+        listed += s_wave[wv];
+    }
     const uint32_t sub = blockIdx.x % KB_SUBS;
-    if (b0 < n_bins) {
-        s_off[b0] = run;
-        s_base[b0] = (c0 ? atomicAdd(&cursor[b0 * KB_SUBS + sub], c0) : 0u) - run;
+    // the cursor reservations of the thread are issued here and consumed after the tile has been staged (which
+    // needs the tile-local offsets only): their round trip runs under the staging, not in front of it
+    uint32_t gb[BPT], at[BPT];
+#pragma unroll
+    for (uint32_t q = 0; q < BPT; q++) {
+        const uint32_t b = tid * BPT + q;
+        at[q] = run;
+        gb[q] = 0;
+        if (b < n_bins) {
+            s_off[b] = run;
+            gb[q] = cnt[q] ? atomicAdd(&cursor[b * KB_SUBS + sub], cnt[q]) : 0u;
+        }
+        run += cnt[q];
     }
-    if (b0 + 1 < n_bins) {
-        s_off[b0 + 1] = run + c0;
-        s_base[b0 + 1] = (c1 ? atomicAdd(&cursor[(b0 + 1) * KB_SUBS + sub], c1) : 0u) - (run + c0);
-    }
-    uint32_t listed = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     __syncthreads();
 #pragma unroll
     for (uint32_t e = 0; e < KB_KPT; e++)
-        if (bin[e] != 0xFFFFFFFFu) {
-            const uint32_t p = s_off[bin[e]] + rank[e];
-            s_stage[p] = off[e];
-            s_stage_bin[p] = (uint16_t)bin[e];
-        }
+        if (listed_mask >> e & 1u)
+            s_stage[s_off[off[e] >> bin_shift] + rank[e]] = off[e];
+#pragma unroll
+    for (uint32_t q = 0; q < BPT; q++)
+        if (tid * BPT + q < n_bins)
+            s_base[tid * BPT + q] = gb[q] - at[q];
     __syncthreads();
-    for (uint32_t p = tid; p < listed; p += KB_THREADS)
-        lists[s_base[s_stage_bin[p]] + p] = s_stage[p];
+    for (uint32_t p = tid; p < listed; p += THREADS) {
+        const uint32_t o = s_stage[p];
+        lists[s_base[o >> bin_shift] + p] = o;
+    }
     // one atomic per workgroup on the job-wide counter (one per wave: 14 K atomics on one address,
     // ~11 ns each, were most of this kernel's 0.22 ms)
     for (int o = 32; o; o >>= 1)
@@ -821,7 +881,9 @@ __global__ __launch_bounds__(KB_THREADS) void kept_bin_kernel(
         s_wave[wave] = total;
     __syncthreads();
     if (tid == 0) {
-        const uint32_t sum = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        uint32_t sum = 0;
+        for (uint32_t wv = 0; wv < WAVES; wv++)
+            sum += s_wave[wv];
         if (sum)
             atomicAdd(n_kept_total, (unsigned long long)sum);
     }
@@ -836,7 +898,7 @@ __global__ __launch_bounds__(KB_THREADS) void kept_bin_kernel(
 // bit by binary search over per-thread prefix counts so that stores coalesce: 0.21 ms.
 constexpr uint32_t KE_Q = 1, KE_THREADS = 512;
 
-__global__ __launch_bounds__(KE_THREADS) void kept_emit_kernel(const uint32_t *__restrict__ cursor,
+__global__ __launch_bounds__(KE_THREADS) void kept_emit_kernel(uint32_t KB_SUBS, const uint32_t *__restrict__ cursor,
                                                                const uint32_t *__restrict__ lists,
                                                                uint32_t bin_shift, uint32_t n_bins, uint64_t id_base,
                                                                uint64_t *__restrict__ out,
@@ -1215,7 +1277,7 @@ hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t 
 }
 
 // bins of 2^shift ids, shift >= 15 (the emit kernel's 1024 threads own >= one word each), <= 512 bins
-uint32_t kept_bin_lists() { return KB_SUBS; }
+uint32_t kept_bin_lists() { return kb_subs(); }
 
 uint32_t kept_bin_shift(uint64_t window)
 {
@@ -1233,14 +1295,38 @@ hipError_t launch_kept_bins(int method, const uint32_t *labels, const uint32_t *
 {
     const uint32_t shift = kept_bin_shift(window);
     const uint32_t n_bins = (uint32_t)((window + (1ull << shift) - 1) >> shift);
+    const uint32_t KB_SUBS = kb_subs();
     if (!U || !n_bins || shift > 18 || ((uint64_t)n_bins * KB_SUBS << shift) > 0xFFFFFFFFull)   // (a 2^18-bit map is 32 KB of LDS)
         return hipErrorInvalidValue;
     kept_bin_starts_kernel<<<(n_bins * KB_SUBS + 255) / 256, 256, 0, st>>>(n_bins * KB_SUBS, shift, cursor);
-    kept_bin_kernel<<<(unsigned)((U + KB_TILE - 1) / KB_TILE), KB_THREADS, 0, st>>>(
-        method, labels, best, state, ufirst, id_lo, window, U, kept, ucounts, parent1, root_taint, shift, n_bins, cursor,
-        lists, n_kept_total);
-    kept_emit_kernel<<<n_bins * KE_Q, KE_THREADS, (1u << (shift - 5)) * 4 / KE_Q, st>>>(cursor, lists, shift, n_bins, id_base,
-                                                                                       out, n_listed);
+    // 1024-thread workgroups (16 Ki keys per tile) from 2^22 keys on: runs per (tile, bin) four times as long, a
+    // quarter of the cursor atomics; small tables keep 256 threads (more workgroups than CUs)
+    static const int kb_threads_env = getenv("FQD_KB_THREADS") ? atoi(getenv("FQD_KB_THREADS")) : 0;
+    const uint32_t threads = kb_threads_env == 256 || kb_threads_env == 512 || kb_threads_env == 1024
+                                 ? (uint32_t)kb_threads_env : (U >= (1ull << 22) ? 1024u : 256u);
+    const unsigned grid = (unsigned)((U + (uint64_t)threads * KB_KPT - 1) / ((uint64_t)threads * KB_KPT));
+#define FQD_KB_LAUNCH_T(M, T)                                                                                            \
+    kept_bin_kernel<M, T><<<grid, T, 0, st>>>(KB_SUBS, labels, best, state, ufirst, id_lo, window, U, kept, ucounts,      \
+                                              parent1, root_taint, shift, n_bins, cursor, lists, n_kept_total)
+#define FQD_KB_LAUNCH(M)                                                                                                 \
+    do {                                                                                                                 \
+        if (threads == 1024)                                                                                             \
+            FQD_KB_LAUNCH_T(M, 1024);                                                                                    \
+        else if (threads == 512)                                                                                         \
+            FQD_KB_LAUNCH_T(M, 512);                                                                                     \
+        else                                                                                                             \
+            FQD_KB_LAUNCH_T(M, 256);                                                                                     \
+    } while (0)
+    switch (method) {
+    case 0: FQD_KB_LAUNCH(0); break;
+    case 2: FQD_KB_LAUNCH(2); break;
+    case 3: FQD_KB_LAUNCH(3); break;
+    default: FQD_KB_LAUNCH(1); break;      // adjacency: state[v] == 1
+    }
+#undef FQD_KB_LAUNCH
+#undef FQD_KB_LAUNCH_T
+    kept_emit_kernel<<<n_bins * KE_Q, KE_THREADS, (1u << (shift - 5)) * 4 / KE_Q, st>>>(KB_SUBS, cursor, lists, shift, n_bins,
+                                                                                       id_base, out, n_listed);
     return hipGetLastError();
 }
 

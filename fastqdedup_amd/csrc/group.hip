@@ -40,17 +40,32 @@ struct PairPolicy {
         const uint2 *in;          // level 2
         const uint32_t *values;   // level 1: what travels with hash i (NULL: its position i)
     };
+    using Raw = uint2;
     template <bool LEVEL1>
-    static __device__ __forceinline__ uint32_t load(const Source &s, uint32_t i, uint2 &v)
+    static __device__ __forceinline__ uint2 fetch(const Source &s, uint32_t i)
     {
-        v = LEVEL1 ? make_uint2(s.hashes[i], s.values ? s.values[i] : i) : s.in[i];
+        return LEVEL1 ? make_uint2(s.hashes[i], s.values ? s.values[i] : i) : s.in[i];
+    }
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint32_t finish(const Source &, uint32_t, const uint2 &raw, uint2 &v, bool)
+    {
+        v = raw;
         return v.x;
     }
     template <bool LEVEL1>
-    static __device__ __forceinline__ uint32_t key(const Source &s, uint32_t i)
+    static __device__ __forceinline__ uint32_t load(const Source &s, uint32_t i, uint2 &v)
+    {
+        v = fetch<LEVEL1>(s, i);
+        return v.x;
+    }
+    using KeyRaw = uint32_t;
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint32_t key_fetch(const Source &s, uint32_t i)
     {
         return LEVEL1 ? s.hashes[i] : s.in[i].x;
     }
+    template <bool LEVEL1>
+    static __device__ __forceinline__ uint32_t key_finish(const Source &, uint32_t, uint32_t raw) { return raw; }
     static __device__ __forceinline__ uint32_t segment_tag(const Source &, uint32_t) { return 0u; }
     static __device__ __forceinline__ void apply_tag(uint2 &, uint32_t) {}
 };

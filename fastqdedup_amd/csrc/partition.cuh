@@ -15,8 +15,13 @@
 //
 // A Policy names the item type and how an item and its key are fetched:
 //   using Item = ...;  struct Source { ... };
-//   template <bool LEVEL1> static __device__ uint32_t key(const Source &, uint32_t i);          // histogram pass
-//   template <bool LEVEL1> static __device__ uint32_t load(const Source &, uint32_t i, Item &); // scatter pass, returns the key
+//   using KeyRaw = ...;  key_fetch<LEVEL1>(src, i) -> KeyRaw;  key_finish<LEVEL1>(src, i, raw) -> key   // histogram pass
+//   using Raw = ...;                                                                            // scatter pass, two steps:
+//   template <bool LEVEL1> static __device__ Raw fetch(const Source &, uint32_t i);             //   the loads alone (no branch, no side effect)
+//   template <bool LEVEL1> static __device__ uint32_t finish(const Source &, uint32_t i, const Raw &, Item &, bool valid);  // -> key
+//   (the loads of a whole tile must be in flight together: "if (i < hi) { load; hash }" compiles to one branch per
+//   item with s_waitcnt vmcnt(0) inside -- EPT dependent round trips per tile; see tools/isa_skeleton.py. The bodies
+//   below therefore fetch at min(i, hi - 1), unconditionally, and finish afterwards; valid = i < hi)
 //   static __device__ uint32_t segment_tag(const Source &, uint32_t segment);  static __device__ void apply_tag(Item &, uint32_t tag);
 //   static constexpr bool MAY_SKIP;  static __device__ bool skip(const Item &);   // scatter pass: an item load() has disposed of otherwise
 //   static constexpr uint32_t EPT, ROUNDS;   // items per thread (tile = 256 * EPT); staging rounds of the scatter pass
@@ -92,10 +97,14 @@ __device__ __forceinline__ void hist_body(const typename Policy::Source &src, co
     for (uint32_t b = threadIdx.x; b < n_bins; b += THREADS)
         s_hist[b] = 0;
     uint32_t h[EPT];
+    {
+        typename Policy::KeyRaw raw[EPT];
 #pragma unroll
-    for (uint32_t e = 0; e < EPT; e++) {   // all loads in flight before the first LDS atomic
-        const uint32_t i = lo + e * THREADS + threadIdx.x;
-        h[e] = i < hi ? Policy::template key<LEVEL1>(src, i) : 0u;
+        for (uint32_t e = 0; e < EPT; e++)   // all loads in flight before the first LDS atomic (clamped, not conditional)
+            raw[e] = Policy::template key_fetch<LEVEL1>(src, min(lo + e * THREADS + threadIdx.x, hi - 1));
+#pragma unroll
+        for (uint32_t e = 0; e < EPT; e++)
+            h[e] = Policy::template key_finish<LEVEL1>(src, min(lo + e * THREADS + threadIdx.x, hi - 1), raw[e]);
     }
     __syncthreads();
 #pragma unroll
@@ -170,12 +179,15 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
         s_hist[b] = 0;
     Item v[EPT];
     uint32_t h[EPT], bin[EPT], rank[EPT];
+    {
+        typename Policy::Raw raw[EPT];
 #pragma unroll
-    for (uint32_t e = 0; e < EPT; e++) {
-        const uint32_t i = lo + e * THREADS + tid;
-        h[e] = 0;
-        if (i < hi) {
-            h[e] = Policy::template load<LEVEL1>(src, i, v[e]);
+        for (uint32_t e = 0; e < EPT; e++)      // every load of the tile in flight: clamped indices, no branch
+            raw[e] = Policy::template fetch<LEVEL1>(src, min(lo + e * THREADS + tid, hi - 1));
+#pragma unroll
+        for (uint32_t e = 0; e < EPT; e++) {
+            const uint32_t i = lo + e * THREADS + tid;
+            h[e] = Policy::template finish<LEVEL1>(src, min(i, hi - 1), raw[e], v[e], i < hi);
             Policy::apply_tag(v[e], seg_tag);
         }
     }
@@ -213,28 +225,31 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
     uint32_t staged = 0;                                  // items of the tile that go out (all, unless the Policy skips some)
     for (uint32_t wv = 0; wv < THREADS / 64; wv++)
         staged += s_wave[wv];
-    for (uint32_t k = 0; k < bpt; k++) {
+    // The cursor reservations (one global atomic per (tile, bin), ~2 us until the answer is back) are ISSUED here
+    // and consumed only after the tile has been staged: staging needs the tile-local offsets alone, so the
+    // round trip runs under it instead of in front of it.
+    constexpr uint32_t BPT_MAX = (MAXB + THREADS - 1) / THREADS;
+    uint32_t g_base[BPT_MAX], g_cnt[BPT_MAX], g_run[BPT_MAX];
+#pragma unroll
+    for (uint32_t k = 0; k < BPT_MAX; k++) {
         const uint32_t b = tid * bpt + k;
-        if (b < n_bins) {
+        g_cnt[k] = 0;
+        g_base[k] = 0;
+        g_run[k] = run;
+        if (k < bpt && b < n_bins) {
             const uint32_t c = s_hist[b];
             s_off[b] = run;
-            uint32_t g;
+            g_cnt[k] = c;
             if (matrix)
-                g = cursor[(size_t)b * tile_start[n_seg] + blockIdx.x] - c;
+                g_base[k] = cursor[(size_t)b * tile_start[n_seg] + blockIdx.x] - c;
             else
-                g = c ? atomicAdd(&cursor[seg * n_bins + b], c) : 0u;
-            s_base[b] = g - run;
-            if (!matrix && slab_cap && c) {
-                const uint64_t end = ((uint64_t)seg * n_bins + b + 1) * slab_cap;
-                if ((uint64_t)g + c > end)
-                    atomicOr(slab_overflow, 2u);
-            }
+                g_base[k] = c ? atomicAdd(&cursor[seg * n_bins + b], c) : 0u;
             run += c;
         }
     }
     __syncthreads();
     const uint32_t count = Policy::MAY_SKIP ? staged : hi - lo;
-    for (uint32_t r0 = 0; r0 < (ROUNDS > 1 ? count : 1u); r0 += STAGE) {
+    auto stage_round = [&](uint32_t r0) {
 #pragma unroll
         for (uint32_t e = 0; e < EPT; e++)
             if (bin[e] != 0xFFFFFFFFu) {
@@ -244,6 +259,23 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
                     s_stage_bin[p] = (uint16_t)bin[e];
                 }
             }
+    };
+    stage_round(0);
+#pragma unroll
+    for (uint32_t k = 0; k < BPT_MAX; k++) {
+        const uint32_t b = tid * bpt + k;
+        if (k < bpt && b < n_bins) {
+            s_base[b] = g_base[k] - g_run[k];
+            if (!matrix && slab_cap && g_cnt[k]) {
+                const uint64_t end = ((uint64_t)seg * n_bins + b + 1) * slab_cap;
+                if ((uint64_t)g_base[k] + g_cnt[k] > end)
+                    atomicOr(slab_overflow, 2u);
+            }
+        }
+    }
+    for (uint32_t r0 = 0; r0 < (ROUNDS > 1 ? count : 1u); r0 += STAGE) {
+        if (r0)
+            stage_round(r0);
         __syncthreads();
 #pragma unroll
         for (uint32_t e = 0; e < EPT / ROUNDS; e++) {
