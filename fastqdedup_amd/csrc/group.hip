@@ -25,7 +25,7 @@ namespace {
 
 constexpr uint32_t GP_THREADS = 256;
 constexpr uint32_t GP_SLICE = 512;      // hashes of one bucket held in LDS per wave
-constexpr uint32_t GP_ECAP = 1024;      // edges buffered per block of the verify kernel
+constexpr uint32_t GP_ECAP = 2048;      // edges buffered per block of the verify kernel (>= 4 x 256 hits of a sweep + ECAP / 2 left over)
 
 // What a (segment hash, uid) item looks like to the partition (partition.cuh): LEVEL 1 reads the
 // hash array (uid = position); level 2 reads level-1's items. The key is the hash.
@@ -152,7 +152,7 @@ __global__ void gp_bucket_starts_kernel(const uint32_t *__restrict__ hist_incl, 
 template <int K>
 __device__ __forceinline__ bool gp_verify(const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens,
                                           const KeyShape &sh, uint32_t d, uint32_t seg, uint32_t nseg, uint32_t uid,
-                                          uint32_t uj)
+                                          uint32_t uj, uint32_t dw_first /* OR over the planes of word 0 of a ^ b */)
 {
     const uint32_t len = fqd_key_len(sh, ulens, uid);
     if (fqd_key_len(sh, ulens, uj) != len)
@@ -164,14 +164,7 @@ __device__ __forceinline__ bool gp_verify(const uint32_t *__restrict__ urecs, co
     // loads requested together: a true neighbour is read to the end, and a word-by-word loop with an
     // exit test pays a round trip per word (10 for a 300-nt key). Measured per launch, word by word /
     // eight at once from the start / this: config 2 0.092 / 0.136 / 0.092 ms, config 5 2.87 / 1.23 / 1.46 ms.
-    uint32_t dist = 0;
-    {
-        uint32_t dw = 0;
-#pragma unroll
-        for (int k = 0; k < K; k++)
-            dw |= my_rec[k] ^ other[k];
-        dist = W ? __popc(dw) : 0u;
-    }
+    uint32_t dist = W ? __popc(dw_first) : 0u;
     for (uint32_t w0 = 1; w0 < W && dist <= d; w0 += 8) {
         uint32_t dw[8];
 #pragma unroll
@@ -196,10 +189,13 @@ __device__ __forceinline__ bool gp_verify(const uint32_t *__restrict__ urecs, co
         bool agree = true;
         if (shi > slo) {
             for (uint32_t w = slo >> 5; w <= ((shi - 1) >> 5) && agree; w++) {
-                uint32_t dw = 0;
+                uint32_t dw = dw_first;
+                if (w) {
+                    dw = 0;
 #pragma unroll
-                for (int k = 0; k < K; k++)
-                    dw |= my_rec[w * K + k] ^ other[w * K + k];
+                    for (int k = 0; k < K; k++)
+                        dw |= my_rec[w * K + k] ^ other[w * K + k];
+                }
                 if (dw & fqd_range_mask(w, slo, shi))
                     agree = false;
             }
@@ -420,13 +416,59 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
     if (tid == 0)
         s_ctl[0] = 0;
     __syncthreads();
-    const unsigned long long step = (unsigned long long)parts * GP_THREADS;
-    for (unsigned long long base = (unsigned long long)part * GP_THREADS; base < total; base += step) {
+    // One thread per candidate; without COOP a thread takes VE candidates per sweep: the candidates, then the first
+    // words of all 2 * VE records are requested together (clamped, unconditional) -- one candidate per sweep was two
+    // dependent round trips and a barrier per 256 candidates.
+    constexpr uint32_t VE = COOP ? 1u : 4u;
+    const unsigned long long step = (unsigned long long)parts * GP_THREADS * VE;
+    for (unsigned long long base = (unsigned long long)part * GP_THREADS * VE; base < total; base += step) {
+        bool hits[VE];
+        uint2 prs[VE];
+        if (!COOP) {
+            bool lives[VE];
+            uint32_t segs[VE], dw0[VE];
+#pragma unroll
+            for (uint32_t t = 0; t < VE; t++) {
+                const unsigned long long idx = base + (unsigned long long)t * GP_THREADS + tid;
+                lives[t] = idx < total;
+                prs[t] = cands[idx < total ? idx : total - 1];
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < VE; t++) {
+                segs[t] = seg;
+                n_pairs += lives[t] ? 1ull : 0ull;
+                if (fused_U) {
+                    uint32_t sx = 0, sy = 0;
+                    while (prs[t].x >= fused_U) {
+                        prs[t].x -= fused_U;
+                        sx++;
+                    }
+                    while (prs[t].y >= fused_U) {
+                        prs[t].y -= fused_U;
+                        sy++;
+                    }
+                    segs[t] = sx;
+                    lives[t] = lives[t] && sx == sy;     // (hashes of different segments meet only by collision)
+                }
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < VE; t++) {
+                const uint32_t *a = urecs + (uint64_t)prs[t].x * sh.stride, *b = urecs + (uint64_t)prs[t].y * sh.stride;
+                uint32_t dw = 0;
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    dw |= a[k] ^ b[k];
+                dw0[t] = dw;
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < VE; t++)
+                hits[t] = lives[t] && gp_verify<K>(urecs, ulens, sh, d, segs[t], nseg, prs[t].x, prs[t].y, dw0[t]);
+        }
         const unsigned long long idx = base + tid;
         bool hit = false, live = false;
         uint2 pr = make_uint2(0, 0);
         uint32_t my_seg = seg;
-        if (idx < total) {
+        if (COOP && idx < total) {
             pr = cands[idx];
             n_pairs++;
             live = true;
@@ -443,8 +485,6 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
                 my_seg = sx;
                 live = sx == sy;             // (hashes of different segments meet only by collision)
             }
-            if (!COOP && live)
-                hit = gp_verify<K>(urecs, ulens, sh, d, my_seg, nseg, pr.x, pr.y);
         }
         if (COOP) {
             const uint4 *recs4 = reinterpret_cast<const uint4 *>(urecs);
@@ -516,20 +556,25 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
             }
             __builtin_amdgcn_wave_barrier();
             hit = live && s_hit[wave][lane] != 0;
+            hits[0] = hit;
+            prs[0] = pr;
         }
-        const unsigned long long mask = __ballot(hit);
-        if (mask) {
-            uint32_t at = 0;
-            const int leader = __ffsll((long long)mask) - 1;
-            if ((int)lane == leader)
-                at = atomicAdd(&s_ctl[0], (uint32_t)__popcll(mask));
-            at = __shfl(at, leader);
-            if (hit) {
-                at += __popcll(mask & fqd_lanemask_lt());
-                const uint32_t eu = pr.x < pr.y ? pr.x : pr.y, ev = pr.x < pr.y ? pr.y : pr.x;
-                s_edges[2 * at] = eu;          // at < 256 hits per sweep + < GP_ECAP / 2 left over
-                s_edges[2 * at + 1] = ev;
-                n_hits++;
+#pragma unroll
+        for (uint32_t t = 0; t < VE; t++) {
+            const unsigned long long mask = __ballot(hits[t]);
+            if (mask) {
+                uint32_t at = 0;
+                const int leader = __ffsll((long long)mask) - 1;
+                if ((int)lane == leader)
+                    at = atomicAdd(&s_ctl[0], (uint32_t)__popcll(mask));
+                at = __shfl(at, leader);
+                if (hits[t]) {
+                    at += __popcll(mask & fqd_lanemask_lt());
+                    const uint32_t eu = prs[t].x < prs[t].y ? prs[t].x : prs[t].y, ev = prs[t].x < prs[t].y ? prs[t].y : prs[t].x;
+                    s_edges[2 * at] = eu;          // at < VE * 256 hits per sweep + < GP_ECAP / 2 left over
+                    s_edges[2 * at + 1] = ev;
+                    n_hits++;
+                }
             }
         }
         __syncthreads();

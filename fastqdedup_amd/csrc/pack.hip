@@ -21,6 +21,9 @@
 #ifndef FQD_PACK_NSUB
 #define FQD_PACK_NSUB 2   // tiles per workgroup of the fused pack (config 3: 1: 0.56-0.58 ms, 2: 0.51-0.52, 3: 0.58 -- 107 VGPRs)
 #endif
+#ifndef FQD_PACK_PREFETCH
+#define FQD_PACK_PREFETCH 1
+#endif
 namespace {
 
 constexpr int PACK_THREADS = 256;
@@ -229,6 +232,19 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
                 dst[64u + lane] = (uint16_t)(a >> 16); // ... of bytes [1024 + 16*lane, +16)
             }
         };
+#if FQD_PACK_PREFETCH == 2
+        // two rows ahead: four 16-byte loads per lane in flight while a row is converted (one row ahead: two)
+        uint4 c0 = load_group(wave, 0), c1 = load_group(wave, 1);
+        uint4 d0 = load_group(wave + PACK_WAVES, 0), d1 = load_group(wave + PACK_WAVES, 1);
+        for (uint32_t row = wave; row < n_rows; row += PACK_WAVES) {
+            const uint4 n0 = load_group(row + 2 * PACK_WAVES, 0), n1 = load_group(row + 2 * PACK_WAVES, 1);
+            convert_row(row, c0, c1);
+            c0 = d0;
+            c1 = d1;
+            d0 = n0;
+            d1 = n1;
+        }
+#else
         uint4 c0 = load_group(wave, 0), c1 = load_group(wave, 1);
         for (uint32_t row = wave; row < n_rows; row += PACK_WAVES) {
             const uint4 n0 = load_group(row + PACK_WAVES, 0), n1 = load_group(row + PACK_WAVES, 1);
@@ -236,6 +252,7 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
             c0 = n0;
             c1 = n1;
         }
+#endif
     } else {
         const uint8_t *lut = reinterpret_cast<const uint8_t *>(lut32);
         uint32_t *my_scratch = scratch + wave * 64;
