@@ -301,17 +301,24 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                           slab_cap, c->d_ctr32.as<uint32_t>() + C_BAD));
             parted = c->ld_part2.as<uint32_t>();
         }
+        // compact records behind a fused pack that zeroed the group totals (c->ld_hist) with its slab starts: the
+        // dedupe adds every bucket's unique count to its group of 256 buckets, the compaction finds its offsets from
+        // those -- no scan kernel (18 us on one workgroup, and its two hand-overs) between the two
+        const uint32_t n_groups = std::max(n_buckets >> 8, 1u);
+        uint32_t *group_total = compact && fused->starts_ready && slab_cap && c->h_pin_big && n_groups <= 4096
+                                    ? c->ld_hist.as<uint32_t>() : nullptr;
         if (compact)
             KTIME(c, FQD_K_DEDUPE12, fqd::launch_bucket_dedupe12(reinterpret_cast<const fqd::Rec12 *>(parted),
                                                                c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
                                                                c->ld_tmp_rec.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
-                                                               c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+                                                               c->d_ctr32.as<uint32_t>() + C_BAD, c->st, group_total));
         else
         KTIME(c, FQD_K_DEDUPE, fqd::launch_bucket_dedupe(parted, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
                                              c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(),
                                              c->ld_tmp_first.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
                                              c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
-        FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
+        if (!group_total)
+            FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
         if (side_pending) {                // (the read-back below takes the side path's count and flag too)
             HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join, 0));
             side_pending = false;
@@ -322,7 +329,10 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         // reads the unique count on the device and writes into tables sized for the worst case (as
         // many unique keys as reads), so the GPU works through the ~50 us the host needs to see the
         // numbers and react. If a flag says the attempt failed, what it wrote is simply not used.
-        FQD_TRY(queue_read_u32(c, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 0));
+        if (group_total)       // (the unique count is the sum of the group totals: the host adds them up)
+            HIP_TRY(c, hipMemcpyAsync(c->h_pin_big, group_total, (size_t)n_groups * 4, hipMemcpyDeviceToHost, c->st));
+        else
+            FQD_TRY(queue_read_u32(c, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 0));
         FQD_TRY(queue_read_u32n(c, c->d_ctr32.as<uint32_t>(), C_SIDE + 1, 1));
         FQD_TRY(queued_reads_mark(c));
         HIP_TRY(c, c->urecs.reserve(n * 16 + 16));
@@ -343,7 +353,8 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
             KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_compact12(
                       c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets,
                       c->ld_tmp_rec.as<uint32_t>(), compact, compact == 1 ? c->d_ctr32.as<uint32_t>() + C_SIDE : nullptr,
-                      c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho));
+                      c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho,
+                      c->ld_unique.as<uint32_t>(), group_total));
         else
         KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_compact(
                   c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets, c->ld_tmp_rec.as<uint32_t>(),
@@ -351,7 +362,13 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                   c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho));
         early_nseg = sho.nseg;
         FQD_TRY(queued_reads_wait(c));
-        U32 = taken_u32(c, 0) + (compact == 1 ? taken_u32(c, 1 + C_SIDE) : 0u);
+        uint32_t main_unique = 0;
+        if (group_total)
+            for (uint32_t g = 0; g < n_groups; g++)
+                main_unique += static_cast<const uint32_t *>(c->h_pin_big)[g];
+        else
+            main_unique = taken_u32(c, 0);
+        U32 = main_unique + (compact == 1 ? taken_u32(c, 1 + C_SIDE) : 0u);
         overflow = taken_u32(c, 1 + C_BAD);
         if (fused) {
             fused->pack_bad = taken_u32(c, 1 + C_PACKBAD);
@@ -547,6 +564,10 @@ int fqd_create(int device, fqd_ctx **out)
     if (ok && hipHostMalloc(&c->h_pin, 256, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         c->h_pin = nullptr;            // read-backs then go through pageable memory
+    }
+    if (ok && hipHostMalloc(&c->h_pin_big, 1u << 20, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        c->h_pin_big = nullptr;
     }
     if (!ok) {
         g_global_error = "could not create stream/events/buffers on the device";
@@ -1044,9 +1065,13 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
         if ((uint64_t)slab_cap2 * n_buckets + n < 0xFFFFFF00ull) {
             HIP_TRY(c, c->ld_start.reserve(((size_t)n_buckets + 1) * 4 + 16));
             HIP_TRY(c, c->ld_cursor.reserve((size_t)n_buckets * 4 + 1024 * 4));
+            // ... and the zeros of the dedupe's group totals (c->ld_hist, free in slab mode)
+            HIP_TRY(c, c->ld_hist.reserve((size_t)n_buckets * 4 + 1024 * 4));
             HIP_TRY(c, fqd::launch_slab_starts3(parts, cap1, seg_start, cursor, n_buckets, slab_cap2,
                                                 c->ld_start.as<uint32_t>(), c->ld_cursor.as<uint32_t>(), side_slabs, side_cap,
-                                                tail ? tail + side_slabs : nullptr, tail, c->st));
+                                                tail ? tail + side_slabs : nullptr, tail, c->st,
+                                                compact ? std::max(n_buckets >> 8, 1u) : 0u,
+                                                compact ? c->ld_hist.as<uint32_t>() : nullptr));
             starts_ready = true;
         } else {
             HIP_TRY(c, fqd::launch_slab_starts(parts, cap1, seg_start, cursor, c->st));
@@ -1464,13 +1489,20 @@ int fqd_cluster_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, 
 
 static int cluster_tail(fqd_ctx *c, int max_distance, int metric, int method, fqd_summary *out)
 {
+    if (c->join_pending) {           // (an earlier job that failed between the fork and the join)
+        HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join, 0));
+        c->join_pending = false;
+    }
     c->pre_init = c->pre_init_closed = false;
     c->preinit_method = (method >= 0 && method <= 2 && method != FQD_METHOD_HIGHEST_COUNT && !getenv("FQD_NO_PREINIT")) ? method : -1;
     const int rc_search = fqd_find_edges(c, max_distance, metric, 0, 1, nullptr);
     c->preinit_method = -1;
     FQD_TRY(rc_search);
     // no host round trip between components and dissection; labels are flattened only if read
-    FQD_TRY(fqd_api_components_queue(c, method == FQD_METHOD_HIGHEST_COUNT));
+    // (directional, closed form: the dissection never reads the labels -- the union-find runs beside its first pass)
+    const bool beside = method == FQD_METHOD_DIRECTIONAL && c->collapsed && !getenv("FQD_DIRECTIONAL_ROUNDS") &&
+                        !getenv("FQD_NO_GRAPH_OVERLAP");
+    FQD_TRY(fqd_api_components_queue(c, method == FQD_METHOD_HIGHEST_COUNT, beside));
     c->stage = ST_LABELS;
     c->ms[FQD_T_COMPONENTS] = 0;
     c->tpending[FQD_T_COMPONENTS] = false;

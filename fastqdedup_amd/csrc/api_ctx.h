@@ -108,6 +108,7 @@ struct fqd_ctx {
     bool fused_off = false;        // fqd_cluster_keys: a level-1 slab of the fused pack overflowed once -- plain pack from now on
     bool recs_valid = false;       // c->recs holds the packed reads in read order (not after the fused pack)
     bool pairs_slab_off = false;   // long-record collapse: same, for its (hash, position) partition
+    bool search_zero_pending = false;   // find_edges: the job counters and statistics are zeroed by the partition's first launch
     bool gp_slab_off = false;      // grouped search: same, for the (hash, uid) partition
     bool slab_off = false;         // LDS collapse: a slab of level 2 overflowed once, use exact bucket sizes
     bool hashes_valid = false;     // `hashes` holds the record hashes of the packed reads (lazy after an import)
@@ -162,6 +163,7 @@ struct fqd_ctx {
 
     // stage timers: one event pair per stage, recorded while the work is queued and resolved when
     // fqd_stage_times asks (a stage end is NOT a host synchronisation point)
+    bool join_pending = false;     // the components were queued on st_side: ev_join must be waited for before their counter is read
     hipStream_t st_side = nullptr; // the side path of the compact collapse runs here, beside the dedupe (ev_fork / ev_join order it)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_rb = nullptr;    // marks queued read-backs: the host can wait for THEM while later work runs
@@ -389,20 +391,20 @@ struct StageTimer {
     }
 };
 
-int ktime_begin(fqd_ctx *c, int slot)
+int ktime_begin(fqd_ctx *c, int slot, hipStream_t st = nullptr)
 {
     if (!((c->ktime_mask >> slot) & 1u) || c->kused >= fqd_ctx::KPOOL)
         return -1;
     const int i = c->kused++;
     c->kslot[i] = slot;
-    (void)hipEventRecord(c->kev[2 * i], c->st);
+    (void)hipEventRecord(c->kev[2 * i], st ? st : c->st);
     return i;
 }
 
-void ktime_end(fqd_ctx *c, int i)
+void ktime_end(fqd_ctx *c, int i, hipStream_t st = nullptr)
 {
     if (i >= 0)
-        (void)hipEventRecord(c->kev[2 * i + 1], c->st);
+        (void)hipEventRecord(c->kev[2 * i + 1], st ? st : c->st);
 }
 
 // after the stage's final synchronisation: fold the recorded pairs into the per-kernel sums
@@ -429,6 +431,14 @@ void ktime_collect(fqd_ctx *c)
         ktime_end((c), kt_);                 \
     } while (0)
 
+// ... on another stream of the context (the events must be recorded where the kernel runs)
+#define KTIME_ON(c, slot, st, call)                      \
+    do {                                                 \
+        const int kt_ = ktime_begin((c), (slot), (st));  \
+        HIP_TRY((c), call);                              \
+        ktime_end((c), kt_, (st));                       \
+    } while (0)
+
 int sort_u32_pairs(fqd_ctx *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n,
                    int bits = 32)
 {
@@ -452,7 +462,7 @@ int scan_u32(fqd_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n)
 
 // helpers shared between the api_*.hip files (defined in the file named)
 int fqd_api_ensure_hashes(fqd_ctx *c);                 // api.hip
-int fqd_api_components_queue(fqd_ctx *c, bool flatten);   // api_graph.hip
+int fqd_api_components_queue(fqd_ctx *c, bool flatten, bool on_side = false);   // api_graph.hip
 int fqd_api_flat_labels(fqd_ctx *c);                       // api_graph.hip
 // the collapse over c->recs with DEVICE weights and ids (api.hip)
 int fqd_api_collapse_device(fqd_ctx *c, const uint32_t *d_weights, IdSource ids, uint64_t id_limit, uint64_t *n_unique);

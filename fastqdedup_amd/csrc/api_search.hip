@@ -263,8 +263,18 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
     uint32_t *seg1 = small, *tiles1_d = small + 8, *start1 = small + 16, *tiles2_d = small + 2048;
     // the candidate counters (one per list, a cache line apart) live behind the small tables
     unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(small + 4096);
-    HIP_TRY(c, fqd::launch_group_pass_init(seg1, tiles1_d, (uint32_t)N, tiles1, cand_ctr, fqd::group_cand_lists() * 8,
-                                           c->st));
+    // (what this first launch also sets up, see fqd::PassInitMore: the slab starts of both levels when level 1 runs
+    // in slab mode, and for a search inside fqd_find_edges its counters and statistics)
+    fqd::PassInitMore more;
+    if (c->search_zero_pending) {
+        more.ctr64 = c->d_ctr64.as<unsigned long long>();
+        more.zero_a = C64_EDGES;
+        more.zero_b = C64_CAND_NEED;
+        more.zero_c = C64_SLAB;
+        more.stats = c->d_stats.as<uint32_t>();
+        more.stat_words = (uint32_t)(FQD_STAT_SLOTS * sizeof(fqd::PairStats) / 4);
+        c->search_zero_pending = false;
+    }
     // ---- level 1. Many items (>= 1024 tiles), slabs allowed and a level 2 to follow: slab mode as in the fused
     // pack -- 32 sub-parts per bin (tile t feeds sub-part t % 32), one atomic per (tile, bin) on the part's cursor,
     // no histogram pass over the keys, no count matrix (0.04 ms + a scan at config 3); an overfull part raises
@@ -295,14 +305,24 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
         l1_start = c->ld_seg.as<uint32_t>();
         l1_cursor = l1_start + (parts + 4);
         l1_tiles = l1_cursor + (parts + 4);
-        // the slab starts of both levels in one launch, ahead of level 1 (l1_subs implies slab mode at level 2)
+        // the slab starts of both levels with the pass's first launch, ahead of level 1 (l1_subs implies slab mode at level 2)
         HIP_TRY(c, c->ld_cursor.reserve((size_t)n_buckets * 4 + 16));
-        HIP_TRY(c, fqd::launch_slab_starts3(parts, cap1, l1_start, l1_cursor, n_buckets, slab_cap, c->ld_start.as<uint32_t>(),
-                                            c->ld_cursor.as<uint32_t>(), 0, 0, nullptr, nullptr, c->st));
+        more.start1 = l1_start;
+        more.cursor1 = l1_cursor;
+        more.n1 = parts;
+        more.cap1 = cap1;
+        more.start2 = c->ld_start.as<uint32_t>();
+        more.cursor2 = c->ld_cursor.as<uint32_t>();
+        more.n2 = n_buckets;
+        more.cap2 = slab_cap;
+        HIP_TRY(c, fqd::launch_group_pass_init(seg1, tiles1_d, (uint32_t)N, tiles1, cand_ctr, fqd::group_cand_lists() * 8,
+                                               c->st, more));
         KTIME(c, FQD_K_GROUP_SCATTER, fqd::launch_group_scatter(
                   true, keys, nullptr, seg1, tiles1_d, 1, tiles1, 32 - B1, bins1, l1_cursor, c->gp_a.as<uint32_t>(), c->st,
                   cap1, reinterpret_cast<uint32_t *>(c->d_ctr64.as<unsigned long long>() + C64_SLAB), values, l1_subs));
     } else {
+        HIP_TRY(c, fqd::launch_group_pass_init(seg1, tiles1_d, (uint32_t)N, tiles1, cand_ctr, fqd::group_cand_lists() * 8,
+                                               c->st, more));
         const size_t matrix = (size_t)bins1 * tiles1;
         HIP_TRY(c, c->ld_matrix.reserve(matrix * 4 + 16));
         HIP_TRY(c, c->ld_matrix_incl.reserve(matrix * 4 + 16));
@@ -441,8 +461,15 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
     c->launches[FQD_T_PAIRS_KERNEL] = 0;
     c->last_stats = fqd::PairStats{0, 0, 0};
     c->stats_pending = false;
-    FQD_TRY(zero_ctr64(c, C64_EDGES));
-    HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
+    // (zeroed by the first launch of the partitioned Hamming search when that is what runs: see search_zero_pending)
+    const char *pin_path = getenv("FQD_EDGES");
+    const bool grouped_first = !edit_general && U >= 2 && (max_distance > 0 || !c->collapsed) && n_shards == 1 &&
+                               U < 0xFFFFFF00ull && (pin_path ? !strcmp(pin_path, "grouped") : U >= 65536);
+    c->search_zero_pending = false;
+    if (!grouped_first) {
+        FQD_TRY(zero_ctr64(c, C64_EDGES));
+        HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
+    }
     if (edit_general && U >= 2 && (max_distance > 0 || !c->collapsed)) {
         bool grouped_done = false;
         if (n_shards == 1 && c->collapsed)
@@ -485,7 +512,10 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         if (const char *e = getenv("FQD_GROUP_CAND_BUDGET"))
             cand_budget = strtoull(e, nullptr, 10);
         bool iota_ready = false;
-        FQD_TRY(zero_ctr64(c, C64_CAND_NEED, 2));    // ... and C64_SLAB
+        if (grouped_first && grouped)
+            c->search_zero_pending = true;           // edges, candidate need, slab flag, statistics: with the partition's first launch
+        else
+            FQD_TRY(zero_ctr64(c, C64_CAND_NEED, 2));    // ... and C64_SLAB
         // All d+1 passes are queued without a host round trip; the edge count is read ONCE at the
         // end. If the passes overflowed the edge buffer (the count still says how many edges there
         // are), the buffer is grown to the known need and the whole search runs again.

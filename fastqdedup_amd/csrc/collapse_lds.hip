@@ -185,12 +185,12 @@ struct SlabSet {
     uint32_t n, cap;
     uint32_t *start, *cursor;
 };
-__global__ void slab_starts3_kernel(SlabSet a, SlabSet b, SlabSet c3)
+__global__ void slab_starts3_kernel(SlabSet a, SlabSet b, SlabSet c3, SlabSet d4)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const SlabSet sets[3] = {a, b, c3};
+    const SlabSet sets[4] = {a, b, c3, d4};      // (a set of capacity 0 is a table of zeros)
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 4; k++) {
         if (sets[k].start && i <= sets[k].n) {
             sets[k].start[i] = i * sets[k].cap;
             if (i < sets[k].n)
@@ -529,13 +529,21 @@ constexpr unsigned long long DD_EMPTY64 = ~0ull;
 __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
     const fqd::Rec12 *__restrict__ part, const uint32_t *__restrict__ bucket_start,
     const uint32_t *__restrict__ bucket_end, const uint32_t *__restrict__ weights, uint4 *__restrict__ tmp,
-    uint32_t *__restrict__ bucket_unique, uint32_t *__restrict__ overflow)
+    uint32_t *__restrict__ bucket_unique, uint32_t *__restrict__ overflow,
+    uint32_t *__restrict__ group_total /* NULL, or [b >> 8] += unique keys of bucket b: with it the compaction finds
+                                        * its offsets itself (bucket_compact12_kernel) and no scan runs in between */)
 {
     __shared__ unsigned long long s_key[DD_SLOTS + 1];
     __shared__ uint32_t s_cnt[DD_SLOTS + 1], s_min[DD_SLOTS + 1];
     __shared__ uint32_t s_wave_tot[DD_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t b = blockIdx.x;
+    // With group totals, consecutive workgroups take buckets of DIFFERENT groups (workgroup i: group i % G): the 256
+    // buckets of one group in 256 workgroups that run side by side queued on the group's counter (+0.12 ms).
+    uint32_t b = blockIdx.x;
+    if (group_total && gridDim.x >= 512) {
+        const uint32_t G = gridDim.x >> 8;
+        b = ((blockIdx.x % G) << 8) + blockIdx.x / G;
+    }
     const uint32_t lo = bucket_start[b];
     uint32_t hi = bucket_start[b + 1];
     if (bucket_end)
@@ -638,8 +646,11 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
             tmp[out++] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), s_cnt[s], s_min[s]);
         }
     }
-    if (tid == 0)
+    if (tid == 0) {
         bucket_unique[b] = total;
+        if (group_total && total)
+            atomicAdd(&group_total[b >> 8], total);
+    }
 }
 
 // the planes of a compact key (squeeze 1: (p0 | p2, p1 | p2) of an N-free "ACGNT" key; 2: the two planes themselves)
@@ -662,11 +673,35 @@ __device__ __forceinline__ void rec12_planes(uint32_t squeeze, uint32_t a, uint3
 __global__ __launch_bounds__(256) void bucket_compact12_kernel(
     const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ unique_incl, uint32_t n_buckets,
     const uint4 *__restrict__ tmp, uint32_t squeeze, const uint32_t *__restrict__ side_unique,
-    uint4 *__restrict__ urecs, uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst, fqd::SegHashOut sho)
+    uint4 *__restrict__ urecs, uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst, fqd::SegHashOut sho,
+    const uint32_t *__restrict__ bucket_unique, const uint32_t *__restrict__ group_total)
 {
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t side = side_unique ? *side_unique : 0u;
-    const uint32_t n_unique = side + unique_incl[n_buckets - 1];
+    // group_total != NULL: no scan of the bucket counts has run -- the wave adds up the totals of the groups of 256
+    // buckets before its own and the counts of the buckets before it inside its group (2 KB of L2-resident words)
+    uint32_t g_begin = 0, g_all = 0, g_cnt = 0;
+    if (group_total) {
+        const uint32_t lane = fqd_lane(), n_groups = max(n_buckets >> 8, 1u), my_group = min(b, n_buckets - 1) >> 8;
+        for (uint32_t g0 = 0; g0 < n_groups; g0 += 64) {
+            const uint32_t g = g0 + lane, t = g < n_groups ? group_total[g] : 0u;
+            g_all += t;
+            g_begin += g < my_group ? t : 0u;
+        }
+        if (b < n_buckets) {
+#pragma unroll
+            for (uint32_t j0 = 0; j0 < 256; j0 += 64) {
+                const uint32_t x = (my_group << 8) + j0 + lane;
+                g_begin += x < b ? bucket_unique[x] : 0u;
+            }
+            g_cnt = bucket_unique[b];
+        }
+        for (int o = 32; o; o >>= 1) {
+            g_begin += __shfl_xor(g_begin, o);
+            g_all += __shfl_xor(g_all, o);
+        }
+    }
+    const uint32_t n_unique = side + (group_total ? g_all : unique_incl[n_buckets - 1]);
     if (b >= n_buckets) {
         if (!sho.nseg)
             return;
@@ -679,9 +714,9 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
         }
         return;
     }
-    const uint32_t end = unique_incl[b], begin = b ? unique_incl[b - 1] : 0u;
+    const uint32_t begin = group_total ? g_begin : (b ? unique_incl[b - 1] : 0u);
+    const uint32_t cnt = group_total ? g_cnt : unique_incl[b] - begin;
     const uint32_t src = bucket_start[b];
-    const uint32_t cnt = end - begin;
     for (uint32_t j0 = fqd_lane(); j0 < cnt; j0 += 4 * 64) {
         uint4 row[4];
 #pragma unroll
@@ -920,12 +955,14 @@ hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, u
 
 hipError_t launch_slab_starts3(uint32_t n1, uint32_t cap1, uint32_t *start1, uint32_t *cursor1, uint32_t n2, uint32_t cap2,
                                uint32_t *start2, uint32_t *cursor2, uint32_t n3, uint32_t cap3, uint32_t *start3,
-                               uint32_t *cursor3, hipStream_t st)
+                               uint32_t *cursor3, hipStream_t st, uint32_t n_zero, uint32_t *zero)
 {
-    const uint32_t most = std::max(n1, std::max(start2 ? n2 : 0u, start3 ? n3 : 0u));
+    // zero[0 .. n_zero] = 0 on the way (the dedupe's group totals)
+    const uint32_t most = std::max(std::max(n1, zero ? n_zero : 0u), std::max(start2 ? n2 : 0u, start3 ? n3 : 0u));
     slab_starts3_kernel<<<(most + 1 + 255) / 256, 256, 0, st>>>(SlabSet{n1, cap1, start1, cursor1},
                                                                SlabSet{n2, cap2, start2, cursor2},
-                                                               SlabSet{n3, cap3, start3, cursor3});
+                                                               SlabSet{n3, cap3, start3, cursor3},
+                                                               SlabSet{zero ? n_zero : 0u, 0u, zero, zero});
     return hipGetLastError();
 }
 
@@ -980,23 +1017,24 @@ hipError_t launch_part_scatter12(const uint32_t *in, uint32_t squeeze, SideSlabs
 
 hipError_t launch_bucket_dedupe12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                   uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
-                                  uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st)
+                                  uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st, uint32_t *group_total)
 {
     bucket_dedupe12_kernel<<<n_buckets, DD_THREADS, 0, st>>>(part, bucket_start, bucket_end, weights,
-                                                             reinterpret_cast<uint4 *>(tmp_rec), bucket_unique, overflow);
+                                                             reinterpret_cast<uint4 *>(tmp_rec), bucket_unique, overflow,
+                                                             group_total);
     return hipGetLastError();
 }
 
 hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                    const uint32_t *tmp_rec, uint32_t squeeze, const uint32_t *side_unique,
                                    uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, hipStream_t st,
-                                   SegHashOut seg_hashes)
+                                   SegHashOut seg_hashes, const uint32_t *bucket_unique, const uint32_t *group_total)
 {
     // one wave per bucket + 64 waves for the segment hashes of the side path's keys
     const uint64_t threads = ((uint64_t)n_buckets + (side_unique && seg_hashes.nseg ? 64 : 0)) * 64;
     bucket_compact12_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
         bucket_start, unique_incl, n_buckets, reinterpret_cast<const uint4 *>(tmp_rec), squeeze, side_unique,
-        reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes);
+        reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, bucket_unique, group_total);
     return hipGetLastError();
 }
 

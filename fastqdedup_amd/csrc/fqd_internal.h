@@ -329,7 +329,7 @@ hipError_t launch_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket
 // up to three slab sets in one launch (start2 / start3 NULL: fewer)
 hipError_t launch_slab_starts3(uint32_t n1, uint32_t cap1, uint32_t *start1, uint32_t *cursor1, uint32_t n2, uint32_t cap2,
                                uint32_t *start2, uint32_t *cursor2, uint32_t n3, uint32_t cap3, uint32_t *start3,
-                               uint32_t *cursor3, hipStream_t st);
+                               uint32_t *cursor3, hipStream_t st, uint32_t n_zero = 0, uint32_t *zero = nullptr);
 hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                 uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec, uint32_t *tmp_count,
                                 uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);
@@ -354,11 +354,13 @@ hipError_t launch_part_scatter12(const uint32_t *in /* uint4 records */, uint32_
 uint32_t part_tile_size12();
 hipError_t launch_bucket_dedupe12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                   uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
-                                  uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);
+                                  uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st,
+                                  uint32_t *group_total = nullptr);
 hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                    const uint32_t *tmp_rec, uint32_t squeeze, const uint32_t *side_unique,
                                    uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, hipStream_t st,
-                                   SegHashOut seg_hashes = SegHashOut());
+                                   SegHashOut seg_hashes = SegHashOut(), const uint32_t *bucket_unique = nullptr,
+                                   const uint32_t *group_total = nullptr);
 // the keys of the side slabs (few: the reads with an N) collapsed through a hash table in global memory and
 // written to the head of the unique table; table: side_table_words(table_slots) words (table_slots a power of
 // two), cleared here; block_counts = table + 3 * table_slots
@@ -436,8 +438,18 @@ hipError_t launch_group_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bi
                                       hipStream_t st);
 hipError_t launch_group_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,
                                       uint32_t *cursor, hipStream_t st);
+// what else the first launch of a search inside fqd_find_edges sets up (all optional)
+struct PassInitMore {
+    unsigned long long *ctr64 = nullptr;     // ctr64[zero_a] = ctr64[zero_b] = ctr64[zero_c] = 0
+    uint32_t zero_a = 0, zero_b = 0, zero_c = 0;
+    uint32_t *stats = nullptr;               // stat_words words of zeros
+    uint32_t stat_words = 0;
+    uint32_t *start1 = nullptr, *cursor1 = nullptr, n1 = 0, cap1 = 0;    // slab starts of partition level 1 ...
+    uint32_t *start2 = nullptr, *cursor2 = nullptr, n2 = 0, cap2 = 0;    // ... and level 2
+};
 hipError_t launch_group_pass_init(uint32_t *seg1, uint32_t *tiles1, uint32_t n_items, uint32_t n_tiles,
-                                  unsigned long long *cand_ctr, uint32_t ctr_words, hipStream_t st);
+                                  unsigned long long *cand_ctr, uint32_t ctr_words, hipStream_t st,
+                                  PassInitMore more = PassInitMore());
 hipError_t launch_group_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket_start, uint32_t *cursor,
                                     hipStream_t st);
 hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,

@@ -105,8 +105,11 @@ __global__ __launch_bounds__(1024) void gp_slab_tile_starts_kernel(const uint32_
 
 // start of a search pass: the level-1 segment / tile bounds and the zeroed candidate counters, in one
 // small launch (two host-to-device copies and a fill, each a stop on the stream, did this before)
+// `more` (a search inside fqd_find_edges): also the search's job counters (edges, candidate need, slab flag), its
+// statistics slots, and the slab starts of both partition levels -- four fills and a launch less on the stream
 __global__ void gp_pass_init_kernel(uint32_t *__restrict__ seg1, uint32_t *__restrict__ tiles1, uint32_t n_items,
-                                    uint32_t n_tiles, unsigned long long *__restrict__ cand_ctr, uint32_t ctr_words)
+                                    uint32_t n_tiles, unsigned long long *__restrict__ cand_ctr, uint32_t ctr_words,
+                                    fqd::PassInitMore more)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) {
@@ -114,9 +117,26 @@ __global__ void gp_pass_init_kernel(uint32_t *__restrict__ seg1, uint32_t *__res
         seg1[1] = n_items;
         tiles1[0] = 0;
         tiles1[1] = n_tiles;
+        if (more.ctr64) {
+            more.ctr64[more.zero_a] = 0ull;
+            more.ctr64[more.zero_b] = 0ull;
+            more.ctr64[more.zero_c] = 0ull;
+        }
     }
     if (t < ctr_words)
         cand_ctr[t] = 0;
+    if (t < more.stat_words)
+        more.stats[t] = 0u;
+    if (more.start1 && t <= more.n1) {
+        more.start1[t] = t * more.cap1;
+        if (t < more.n1)
+            more.cursor1[t] = t * more.cap1;
+    }
+    if (more.start2 && t <= more.n2) {
+        more.start2[t] = t * more.cap2;
+        if (t < more.n2)
+            more.cursor2[t] = t * more.cap2;
+    }
 }
 
 // slab mode of level 2 (as in collapse_lds.hip): bucket b owns slots [b * cap, (b + 1) * cap)
@@ -704,9 +724,14 @@ hipError_t launch_group_bucket_starts(const uint32_t *hist_incl, uint32_t n_buck
 }
 
 hipError_t launch_group_pass_init(uint32_t *seg1, uint32_t *tiles1, uint32_t n_items, uint32_t n_tiles,
-                                  unsigned long long *cand_ctr, uint32_t ctr_words, hipStream_t st)
+                                  unsigned long long *cand_ctr, uint32_t ctr_words, hipStream_t st, PassInitMore more)
 {
-    gp_pass_init_kernel<<<(ctr_words + 255) / 256 + 1, 256, 0, st>>>(seg1, tiles1, n_items, n_tiles, cand_ctr, ctr_words);
+    uint32_t most = std::max(ctr_words, more.stat_words);
+    if (more.start1)
+        most = std::max(most, more.n1 + 1);
+    if (more.start2)
+        most = std::max(most, more.n2 + 1);
+    gp_pass_init_kernel<<<(most + 255) / 256 + 1, 256, 0, st>>>(seg1, tiles1, n_items, n_tiles, cand_ctr, ctr_words, more);
     return hipGetLastError();
 }
 
