@@ -176,7 +176,7 @@ struct fqd_ctx {
     bool stage_timing = true;
     // per-kernel timing (fqd_kernel_times): a pool of event pairs for the kernels in ktime_mask,
     // folded into the sums at fqd_kernel_times or when the pool runs low
-    uint32_t ktime_mask = 0xFFFFFFFFu;
+    uint32_t ktime_mask = 0;       // (fqd_create: all kernels with FQD_KERNEL_TIMERS=1 in the environment; fqd_set_timing)
     static constexpr int KPOOL = 512;
     hipEvent_t kev[2 * KPOOL] = {nullptr};
     int kslot[KPOOL] = {0};

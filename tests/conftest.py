@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the GPU tests read fqd_kernel_times to assert WHICH kernels ran (the route a call took): event pairs around every
+# launch, off by default in the library
+os.environ.setdefault("FQD_KERNEL_TIMERS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
