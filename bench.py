@@ -230,7 +230,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two child rocprofv3 --pmc passes (traffic=null)")
     ap.add_argument("--no-host-input", action="store_true", help="skip the PCIe-inclusive extra step")
     ap.add_argument("--no-copy-peak", action="store_true", help="skip the device-copy bandwidth measurement")
-    ap.add_argument("--kernel-timers", default="all", choices=["all", "dominant", "none"],
+    ap.add_argument("--kernel-timers", default="dominant", choices=["all", "dominant", "none"],
                     help="HIP-event pairs around the hand-written kernels during the timed steps (diagnostic A/B)")
     args = ap.parse_args()
 

@@ -259,17 +259,20 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t *hashes = s_hash[wave], *uids = s_uid[wave], *off = s_off[wave];
     uint2 *wbuf = s_wbuf[wave];
-    volatile uint32_t *wcnt = &s_wcnt[wave];   // written by the leader lane, read by all: never cached in a register
-    volatile uint32_t *wflush = &s_wflush[wave];
+    // s_wcnt / s_wflush: written by the leader lane, read by all -- relaxed workgroup-scope atomics, never cached in a
+    // register (a volatile pointer to them lost its LDS address space: FLAT loads and stores, which wait on both the
+    // vector-memory and the LDS counters)
+    auto ld_shared = [](uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto st_shared = [](uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
     // the wave's buffer -> the next list (called by converged lanes: `n` of them, ranks 0..n-1)
     auto flush = [&](uint32_t have, uint32_t n, uint32_t rank, int leader) {
-        const uint32_t turn = *wflush;
+        const uint32_t turn = ld_shared(&s_wflush[wave]);
         const uint32_t list = (list0 + turn) % GP_LISTS;
         unsigned long long g = 0;
         if ((int)lane == leader) {
             g = atomicAdd(cand_counts + (size_t)list * 8, (unsigned long long)have);
-            *wflush = turn + 1;
+            st_shared(&s_wflush[wave], turn + 1);
         }
         g = __shfl(g, leader);
         uint2 *dst = cands_all + (size_t)list * list_cap;
@@ -284,19 +287,19 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
         const unsigned long long act = __ballot(1);
         const uint32_t n = (uint32_t)__popcll(act), rank = (uint32_t)__popcll(act & fqd_lanemask_lt());
         const int leader = __ffsll((long long)act) - 1;
-        uint32_t have = *wcnt;
+        uint32_t have = ld_shared(&s_wcnt[wave]);
         if (have + n > GP_WCAP) {
             flush(have, n, rank, leader);
             have = 0;
         }
         wbuf[have + rank] = make_uint2(a, b);
         if ((int)lane == leader)
-            *wcnt = have + n;
+            st_shared(&s_wcnt[wave], have + n);
     };
 
     if (lane == 0) {
-        *wcnt = 0;
-        *wflush = 0;
+        st_shared(&s_wcnt[wave], 0u);
+        st_shared(&s_wflush[wave], 0u);
     }
 
     for (uint32_t b = blockIdx.x * WAVES + wave; b < n_buckets; b += gridDim.x * WAVES) {
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
     }
     // what is left in the wave's buffer (all lanes are back together here)
     {
-        const uint32_t have = *wcnt;
+        const uint32_t have = ld_shared(&s_wcnt[wave]);
         if (have)
             flush(have, 64, lane, 0);
     }
