@@ -48,7 +48,7 @@ EXPORTS = [
     "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_set_timing", "fqd_cluster_keys", "fqd_edge_stats", "fqd_synth_keys",
     "fqd_store_add_keys", "fqd_store_remove", "fqd_store_removed_count", "fqd_get_clusters", "fqd_read_clusters",
     "fqd_trie_order", "fqd_trie_stats", "fqd_store_symbol_events", "fqd_get_stream", "fqd_pack_collapse", "fqd_synth_indel_keys", "fqd_copy_bandwidth",
-    "fqd_cluster_subgraph", "fqd_owner_slab_geometry", "fqd_pack_to_owner_slabs", "fqd_collapse_owner_slabs",
+    "fqd_synth_keys_skewed", "fqd_cluster_subgraph", "fqd_owner_slab_geometry", "fqd_pack_to_owner_slabs", "fqd_collapse_owner_slabs",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -127,6 +127,8 @@ def load() -> C.CDLL:
     L.fqd_edge_stats.argtypes = [vp, u64p, u64p, u64p]
     L.fqd_synth_keys.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                  C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]
+    L.fqd_synth_keys_skewed.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                        C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]
     u32p = C.POINTER(C.c_uint32)
     L.fqd_owner_slab_geometry.argtypes = [C.c_uint64, C.c_uint32, u32p, u32p, u32p]
     L.fqd_pack_to_owner_slabs.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -750,8 +752,15 @@ class Context:
         return out[:total], offsets
 
     def synth_keys(self, out_tensor, n_total: int, start: int, count: int, length: int, umi: int,
-                   seed: int, copies: int = 4, sub_rate: float = 1e-3, n_rate: float = 1e-4):
+                   seed: int, copies: int = 4, sub_rate: float = 1e-3, n_rate: float = 1e-4, skew=None):
         from .synth import rate_threshold
+        if skew:
+            self._ck(self._L.fqd_synth_keys_skewed(self._h, out_tensor.data_ptr(), n_total, start, count, length,
+                                                   umi, seed, copies, rate_threshold(n_rate), rate_threshold(sub_rate),
+                                                   rate_threshold(skew.get("hot", 0.0)),
+                                                   rate_threshold(skew.get("ladder", 0.0)),
+                                                   int(skew.get("lowc_every", 0))))
+            return
         self._ck(self._L.fqd_synth_keys(self._h, out_tensor.data_ptr(), n_total, start, count, length,
                                         umi, seed, copies, rate_threshold(n_rate),
                                         rate_threshold(sub_rate)))

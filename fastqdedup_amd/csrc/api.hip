@@ -130,6 +130,9 @@ struct FusedLevel1 {
     // collapse_lds computes) and of the side path already -- fqd_cluster_keys does, BEFORE the pack kernel, so that
     // nothing but the pack kernel stands between the key bytes and level 2
     bool starts_ready = false;
+    // the routed collapse: bins by segment 0 (route_mask), search pass 0 in the compaction (p0.mask != 0)
+    uint32_t route_mask = 0, group_at = 0;      // group_at: the dedupe's group totals start at c->ld_hist + group_at
+    fqd::Pass0 p0;
 };
 
 // Bucket bits of the LDS collapse for n reads: ~400-800 reads per bucket (2x fewer workgroups than
@@ -148,6 +151,8 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
 {
     *done = false;
     c->seg_hashes_nseg = 0;
+    c->seg_hashes_first = 0;
+    c->pass0_done = false;
     const uint64_t n = c->n;
     const KeyShape sh = c->ks;
     const char *force = getenv("FQD_COLLAPSE");  // "sort" / "lds": tests pin a path
@@ -273,7 +278,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 KTIME(c, FQD_K_PART_SCATTER12, fqd::launch_part_scatter12(
                           c->ld_part.as<uint32_t>(), compact, side, f_seg_start, f_tiles, f_parts, f_grid,
                           32 - B, bins2, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<fqd::Rec12>(), c->st, slab_cap,
-                          c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end, fused->sub_bits));
+                          c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end, fused->sub_bits, fused->route_mask));
                 // the keys with an N: collapsed apart, to the head of the unique table (few: a table in global
                 // memory) -- on the context's second stream, beside the dedupe of the other keys: four short
                 // kernels (0.05 ms in a row) that the compaction, not the dedupe, waits for
@@ -284,7 +289,8 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                                    side.recs, side.cursor, 0, side.n_slabs, side.cap, d_w, c->ld_side_table.as<uint32_t>(),
                                    fused->side_slots, c->ld_side_table.as<uint32_t>() + 3 * (size_t)fused->side_slots,
                                    c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(),
-                                   c->d_ctr32.as<uint32_t>() + C_SIDE, c->d_ctr32.as<uint32_t>() + C_BAD, c->st_side));
+                                   c->d_ctr32.as<uint32_t>() + C_SIDE, c->d_ctr32.as<uint32_t>() + C_BAD, c->st_side,
+                                   fused->p0));
                     HIP_TRY(c, hipEventRecord(c->ev_join, c->st_side));
                     side_pending = true;
                 }
@@ -306,7 +312,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         // those -- no scan kernel (18 us on one workgroup, and its two hand-overs) between the two
         const uint32_t n_groups = std::max(n_buckets >> 8, 1u);
         uint32_t *group_total = compact && fused->starts_ready && slab_cap && c->h_pin_big && n_groups <= 4096
-                                    ? c->ld_hist.as<uint32_t>() : nullptr;
+                                    ? c->ld_hist.as<uint32_t>() + fused->group_at : nullptr;
         if (compact)
             KTIME(c, FQD_K_DEDUPE12, fqd::launch_bucket_dedupe12(reinterpret_cast<const fqd::Rec12 *>(parted),
                                                                c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
@@ -333,7 +339,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
             HIP_TRY(c, hipMemcpyAsync(c->h_pin_big, group_total, (size_t)n_groups * 4, hipMemcpyDeviceToHost, c->st));
         else
             FQD_TRY(queue_read_u32(c, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 0));
-        FQD_TRY(queue_read_u32n(c, c->d_ctr32.as<uint32_t>(), C_SIDE + 1, 1));
+        FQD_TRY(queue_read_u32n(c, c->d_ctr32.as<uint32_t>(), C_P0 + 1, 1));
         FQD_TRY(queued_reads_mark(c));
         HIP_TRY(c, c->urecs.reserve(n * 16 + 16));
         HIP_TRY(c, c->ucounts.reserve(n * 4 + 16));
@@ -341,26 +347,29 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         // fqd_cluster[_keys] announced a Hamming search with nseg segments: the compaction writes its
         // segment hashes on the way (the records are fixed-length here)
         fqd::SegHashOut sho;
-        if (c->seg_hint && !getenv("FQD_NO_EARLY_SEG_HASHES")) {
+        const bool routed = fused && fused->p0.mask != 0;
+        if (c->seg_hint && (routed || !getenv("FQD_NO_EARLY_SEG_HASHES"))) {
             HIP_TRY(c, c->seg_hashes.reserve((size_t)c->seg_hint * n * 4 + 16));
             sho.out = c->seg_hashes.as<uint32_t>();
             sho.nseg = c->seg_hint;
             sho.planes = sh.planes;
             sho.kw = kw;
             sho.len = sh.max_len;
+            sho.first = routed ? 1u : 0u;        // (pass 0 happens in the compaction itself)
         }
         if (compact)
             KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_compact12(
                       c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets,
                       c->ld_tmp_rec.as<uint32_t>(), compact, compact == 1 ? c->d_ctr32.as<uint32_t>() + C_SIDE : nullptr,
                       c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho,
-                      c->ld_unique.as<uint32_t>(), group_total));
+                      c->ld_unique.as<uint32_t>(), group_total, fused ? fused->p0 : fqd::Pass0()));
         else
         KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_compact(
                   c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets, c->ld_tmp_rec.as<uint32_t>(),
                   c->ld_tmp_count.as<uint32_t>(), c->ld_tmp_first.as<uint32_t>(), d_ids, c->urecs.as<uint32_t>(),
                   c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho));
         early_nseg = sho.nseg;
+        c->seg_hashes_first = sho.first;
         FQD_TRY(queued_reads_wait(c));
         uint32_t main_unique = 0;
         if (group_total)
@@ -378,8 +387,13 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 c->fused_off = true;
             if (overflow & 2u)
                 c->slab_off = true;
+            if (overflow && fused->route_mask)
+                c->route_off = true;       // (keys crowding on one segment-0 value: whole-key hashing from now on)
             if (overflow || fused->pack_bad)
                 return FQD_OK;
+            // the compaction did search pass 0 unless it met a bucket too large for that or a full probe list
+            c->pass0_done = fused->p0.mask != 0 && taken_u32(c, 1 + C_P0) == 0 && sho.first == 1;
+            c->pass0_nseg = c->pass0_done ? sho.nseg : 0;
             break;
         }
         if (slab_cap && (overflow & 2u)) {
@@ -1049,8 +1063,6 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     HIP_TRY(c, c->ld_seg.reserve((size_t)3 * (parts + 4) * 4));
     uint32_t *seg_start = c->ld_seg.as<uint32_t>(), *cursor = seg_start + (parts + 4);
     FQD_TRY(zero_ctr32(c, 0, C_N32));
-    const fqd::PackScatter fs{cursor, reinterpret_cast<uint4 *>(c->ld_part.p), c->d_ctr32.as<uint32_t>() + C_BAD,
-                              32 - l1_bits, 1u << l1_bits, 1u << sub_bits, cap1};
     if (compact == 1) {
         HIP_TRY(c, c->ld_side.reserve((size_t)side_slabs * side_cap * 16 + 16));
         HIP_TRY(c, c->ld_side_table.reserve(((size_t)fqd::side_table_words(side_slots) + 2 * side_slabs + 4) * 4 + 16));
@@ -1059,28 +1071,66 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
         HIP_TRY(c, c->ucounts.reserve(n * 4 + 16));
         HIP_TRY(c, c->ufirst.reserve(n * 8 + 64));
     }
+    // The routed collapse: a Hamming search with nseg = d + 1 segments follows (c->seg_hint) -- the reads are binned by
+    // a hash of segment 0 alone, so that every bucket of the collapse holds ALL keys sharing its segment-0 values and
+    // the compaction does search pass 0 on the spot (fqd::Pass0): half of the (hash, uid) items never exist.
+    const uint32_t n_buckets = 1u << B;
+    const uint32_t n_groups = std::max(n_buckets >> 8, 1u);
+    uint32_t route_mask = 0;
+    fqd::Pass0 p0;
+    if (compact && c->seg_hint >= 2 && !c->route_off && !getenv("FQD_NO_ROUTED_COLLAPSE") && sh.words == 1) {
+        const uint32_t seg0_len = fixed_len / c->seg_hint;         // fqd_segment(len, 0, nseg): [0, len / nseg)
+        if (seg0_len >= 8) {                                       // (a shorter segment 0 has too few values to spread the reads)
+            route_mask = seg0_len >= 32 ? 0xFFFFFFFFu : ((1u << seg0_len) - 1u);
+            HIP_TRY(c, c->p0_probe.reserve((size_t)n_buckets * fqd::FQD_P0_PROBE_CAP * 4 + 16));
+            const uint64_t want_edges = std::max<uint64_t>(c->edges.cap / 8, std::max<uint64_t>(1u << 20, n / 8));
+            if (c->edge_cap < want_edges || !c->edges.p) {
+                HIP_TRY(c, c->edges.reserve(want_edges * 8));
+                c->edge_cap = c->edges.cap / 8;
+            }
+            p0.mask = route_mask;
+            p0.d = c->seg_hint - 1;
+            p0.bucket_bits = B;
+            p0.probe = c->p0_probe.as<uint32_t>();
+            p0.edges = c->edges.as<uint32_t>();
+            p0.edge_count = c->d_ctr64.as<unsigned long long>() + C64_EDGES;
+            p0.edge_cap = c->edge_cap;
+            p0.flag = c->d_ctr32.as<uint32_t>() + C_P0;
+            p0.stats = c->d_stats.as<fqd::PairStats>();
+        }
+    }
     // the slab starts of the pack kernel's parts and, ahead of the pack, of level 2 (the geometry collapse_lds will
     // compute) and of the side path: one launch
     bool starts_ready = false;
+    uint32_t group_at = 0;
     {
-        const uint32_t n_buckets = 1u << B;
         const uint32_t slab_cap2 = (uint32_t)(((n >> B) * 3 / 2 + 64 + 3) & ~3ull);
         uint32_t *tail = compact == 1 ? c->ld_side_table.as<uint32_t>() + fqd::side_table_words(side_slots) : nullptr;
         if ((uint64_t)slab_cap2 * n_buckets + n < 0xFFFFFF00ull) {
             HIP_TRY(c, c->ld_start.reserve(((size_t)n_buckets + 1) * 4 + 16));
             HIP_TRY(c, c->ld_cursor.reserve((size_t)n_buckets * 4 + 1024 * 4));
-            // ... and the zeros of the dedupe's group totals (c->ld_hist, free in slab mode)
-            HIP_TRY(c, c->ld_hist.reserve((size_t)n_buckets * 4 + 1024 * 4));
+            // ... and the zeros of the dedupe's group totals and of the probe counts of pass 0 (c->ld_hist, free in slab
+            // mode: [0, n_buckets) probe counts, behind them the group totals), of the edge counter and the statistics
+            HIP_TRY(c, c->ld_hist.reserve(((size_t)n_buckets + n_groups) * 4 + 1024 * 4));
+            group_at = p0.mask ? n_buckets : 0u;
+            p0.probe_n = p0.mask ? c->ld_hist.as<uint32_t>() : nullptr;
             HIP_TRY(c, fqd::launch_slab_starts3(parts, cap1, seg_start, cursor, n_buckets, slab_cap2,
                                                 c->ld_start.as<uint32_t>(), c->ld_cursor.as<uint32_t>(), side_slabs, side_cap,
                                                 tail ? tail + side_slabs : nullptr, tail, c->st,
-                                                compact ? std::max(n_buckets >> 8, 1u) : 0u,
-                                                compact ? c->ld_hist.as<uint32_t>() : nullptr));
+                                                compact ? group_at + n_groups : 0u,
+                                                compact ? c->ld_hist.as<uint32_t>() : nullptr,
+                                                p0.mask ? reinterpret_cast<uint32_t *>(p0.edge_count) : nullptr, 1u,
+                                                p0.mask ? reinterpret_cast<uint32_t *>(p0.stats) : nullptr,
+                                                (uint32_t)(FQD_STAT_SLOTS * sizeof(fqd::PairStats) / 4) - 1u));
             starts_ready = true;
         } else {
             HIP_TRY(c, fqd::launch_slab_starts(parts, cap1, seg_start, cursor, c->st));
+            p0 = fqd::Pass0();
+            route_mask = 0;
         }
     }
+    const fqd::PackScatter fs{cursor, reinterpret_cast<uint4 *>(c->ld_part.p), c->d_ctr32.as<uint32_t>() + C_BAD,
+                              32 - l1_bits, 1u << l1_bits, 1u << sub_bits, cap1, 0u, 0u, 0u, 0u, route_mask};
     {
         StageTimer kernel_timer(c, FQD_T_PACK_KERNEL);
         KTIME(c, FQD_K_PACK, fqd::launch_pack(d_bytes, n_bytes, nullptr, n, fixed_len, sh, c->d_lut.as<uint8_t>(), lut,
@@ -1107,6 +1157,9 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     f.side_slabs = side_slabs;
     f.side_cap = side_cap;
     f.side_slots = side_slots;
+    f.route_mask = route_mask;
+    f.group_at = group_at;
+    f.p0 = p0;
     bool ok = false;
     FQD_TRY(collapse_lds(c, weights ? d_w : nullptr, IdSource(), &ok, &f));
     timer.stop();
@@ -1741,6 +1794,21 @@ int fqd_synth_keys(fqd_ctx *c, uint8_t *out_device, uint64_t n_total, uint64_t s
     if (!copies)
         return fail(c, FQD_E_VALUE, "copies must be positive");
     HIP_TRY(c, fqd::launch_synth(out_device, n_total, start, count, length, umi, seed, copies, thr_n, thr_sub, c->st));
+    HIP_TRY(c, stream_wait(c->st));
+    return FQD_OK;
+}
+
+int fqd_synth_keys_skewed(fqd_ctx *c, uint8_t *out_device, uint64_t n_total, uint64_t start, uint64_t count, uint32_t length,
+                          uint32_t umi, uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub, uint64_t thr_hot,
+                          uint64_t thr_ladder, uint32_t lowc_every)
+{
+    FQD_TRY(bind(c));
+    if (!copies)
+        return fail(c, FQD_E_VALUE, "copies must be positive");
+    if (length < 8)
+        return fail(c, FQD_E_VALUE, "the ladder of the skewed model needs keys of 8 bases or more");
+    HIP_TRY(c, fqd::launch_synth(out_device, n_total, start, count, length, umi, seed, copies, thr_n, thr_sub, c->st,
+                                 thr_hot, thr_ladder, lowc_every, 1u));
     HIP_TRY(c, stream_wait(c->st));
     return FQD_OK;
 }

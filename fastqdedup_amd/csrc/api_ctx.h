@@ -75,7 +75,7 @@ struct DevBuf {
 enum Stage { ST_EMPTY = 0, ST_PACKED = 1, ST_UNIQUE = 2, ST_EDGES = 3, ST_LABELS = 4, ST_KEPT = 5 };
 
 // small device-side words read back by the host
-enum Ctr { C_BAD = 0, C_COLLISIONS = 1, C_CHANGED = 2, C_MINLEN = 3, C_MAXLEN = 4, C_PACKBAD = 5, C_SIDE = 6, C_N32 = 8 };
+enum Ctr { C_BAD = 0, C_COLLISIONS = 1, C_CHANGED = 2, C_MINLEN = 3, C_MAXLEN = 4, C_PACKBAD = 5, C_SIDE = 6, C_P0 = 7, C_N32 = 8 };
 enum Ctr64 { C64_EDGES = 0, C64_ROOTS = 1, C64_SUM = 2, C64_STATS = 3, C64_CANDS = 4, C64_CAND_NEED = 5, C64_SLAB = 6, C64_N = 8 };
 
 }  // namespace
@@ -108,6 +108,7 @@ struct fqd_ctx {
     bool fused_off = false;        // fqd_cluster_keys: a level-1 slab of the fused pack overflowed once -- plain pack from now on
     bool recs_valid = false;       // c->recs holds the packed reads in read order (not after the fused pack)
     bool pairs_slab_off = false;   // long-record collapse: same, for its (hash, position) partition
+    bool search_keeps_edges = false;    // ... except the edge counter and the statistics: pass 0 of this search has run (fqd::Pass0)
     bool search_zero_pending = false;   // find_edges: the job counters and statistics are zeroed by the partition's first launch
     bool gp_slab_off = false;      // grouped search: same, for the (hash, uid) partition
     bool slab_off = false;         // LDS collapse: a slab of level 2 overflowed once, use exact bucket sizes
@@ -132,7 +133,15 @@ struct fqd_ctx {
     uint64_t E = 0, edge_cap = 0;
     DevBuf seg_hashes, sorted_hash, sorted_uid, uid_iota, edges, sel_hash, sel_uid;
     uint32_t seg_hint = 0;          // fqd_cluster[_keys]: segments of the search that follows the collapse
-    uint32_t seg_hashes_nseg = 0;   // != 0: seg_hashes already holds the nseg x U segment hashes of the unique table
+    uint32_t seg_hashes_nseg = 0;   // != 0: seg_hashes already holds the segment hashes of the unique table, [nseg - first][U]
+    uint32_t seg_hashes_first = 0;  // ... from this segment on (1: the collapse did search pass 0 itself)
+    // the routed collapse (fqd_cluster_keys, compact records): reads binned by segment 0 of the key, search pass 0
+    // inside the compaction (fqd::Pass0). pass0_done: the edge list holds pass 0 of a search with pass0_nseg
+    // segments, for the next fqd_find_edges to continue; route_off: a bucket's LDS table overflowed under the
+    // routing (many keys share a segment-0 value) -- this context keeps to whole-key hashing.
+    bool pass0_done = false, route_off = false;
+    uint32_t pass0_nseg = 0;
+    DevBuf p0_probe;
     DevBuf gp_a, gp_b, gp_small, gp_cands;   // grouped search pass: items after level 1 / level 2, small tables, candidate pairs
     uint64_t gp_cand_cap = 0;
     DevBuf q_table, q_pass, q_means, q_bytes, q_offsets;

@@ -268,11 +268,13 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
     fqd::PassInitMore more;
     if (c->search_zero_pending) {
         more.ctr64 = c->d_ctr64.as<unsigned long long>();
-        more.zero_a = C64_EDGES;
+        more.zero_a = c->search_keeps_edges ? C64_CAND_NEED : C64_EDGES;     // (pass 0's pairs and statistics stay)
         more.zero_b = C64_CAND_NEED;
         more.zero_c = C64_SLAB;
-        more.stats = c->d_stats.as<uint32_t>();
-        more.stat_words = (uint32_t)(FQD_STAT_SLOTS * sizeof(fqd::PairStats) / 4);
+        if (!c->search_keeps_edges) {
+            more.stats = c->d_stats.as<uint32_t>();
+            more.stat_words = (uint32_t)(FQD_STAT_SLOTS * sizeof(fqd::PairStats) / 4);
+        }
         c->search_zero_pending = false;
     }
     // ---- level 1. Many items (>= 1024 tiles), slabs allowed and a level 2 to follow: slab mode as in the fused
@@ -466,7 +468,15 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
     const bool grouped_first = !edit_general && U >= 2 && (max_distance > 0 || !c->collapsed) && n_shards == 1 &&
                                U < 0xFFFFFF00ull && (pin_path ? !strcmp(pin_path, "grouped") : U >= 65536);
     c->search_zero_pending = false;
-    if (!grouped_first) {
+    // The routed collapse has done pass 0 of exactly this search (fqd::Pass0): its pairs are in the edge list, the
+    // segment hashes it wrote start at segment 1, and the passes below start there too.
+    const bool pass0_held = c->pass0_done && !edit_general && seg_lo == 0 && n_shards == 1 && max_distance >= 1 &&
+                            c->pass0_nseg == (uint32_t)max_distance + 1 && seg_hi == (uint32_t)max_distance + 1 &&
+                            c->seg_hashes_nseg == c->pass0_nseg && c->seg_hashes_first == 1;
+    c->pass0_done = false;
+    if (pass0_held)
+        seg_lo = 1;
+    if (!grouped_first && !pass0_held) {
         FQD_TRY(zero_ctr64(c, C64_EDGES));
         HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
     }
@@ -486,11 +496,12 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         HIP_TRY(c, c->sorted_uid.reserve(U * 4 + 16));
         HIP_TRY(c, c->uid_iota.reserve(U * 4 + 16));
         // (the LDS collapse inside fqd_cluster[_keys] has written them already, on its way out)
-        if (!(c->seg_hashes_nseg == nseg && seg_lo == 0))
+        if (!pass0_held && !(c->seg_hashes_nseg == nseg && c->seg_hashes_first == 0 && seg_lo == 0))
             KTIME(c, FQD_K_SEG_HASH, fqd::launch_segment_hashes(c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), U, sh,
                                                                 nseg, seg_lo, seg_hi, 0, c->seg_hashes.as<uint32_t>(),
                                                                 c->st));
         c->seg_hashes_nseg = 0;
+        c->seg_hashes_first = 0;
         if (c->edge_cap < 1024 || !c->edges.p) {
             c->edge_cap = std::max<uint64_t>(1024, U);
             HIP_TRY(c, c->edges.reserve(c->edge_cap * 8));
@@ -512,6 +523,7 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         if (const char *e = getenv("FQD_GROUP_CAND_BUDGET"))
             cand_budget = strtoull(e, nullptr, 10);
         bool iota_ready = false;
+        c->search_keeps_edges = pass0_held;
         if (grouped_first && grouped)
             c->search_zero_pending = true;           // edges, candidate need, slab flag, statistics: with the partition's first launch
         else
@@ -520,11 +532,12 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         // end. If the passes overflowed the edge buffer (the count still says how many edges there
         // are), the buffer is grown to the known need and the whole search runs again.
         // all passes of a plain search in one (see grouped_pass): positions in the hash array must fit 32 bits
-        const bool fuse_passes = grouped && seg_lo == 0 && seg_hi == nseg && nseg >= 2 && nseg <= 8 &&
-                                 (uint64_t)nseg * U < 0xFFFFFF00ull && !getenv("FQD_GROUP_NO_FUSED_PASSES");
+        const uint32_t n_pass = seg_hi - seg_lo;
+        const bool fuse_passes = grouped && (seg_lo == 0 || pass0_held) && seg_hi == nseg && n_pass >= 2 && nseg <= 8 &&
+                                 (uint64_t)n_pass * U < 0xFFFFFF00ull && !getenv("FQD_GROUP_NO_FUSED_PASSES");
         for (int attempt = 0;; attempt++) {
             if (fuse_passes && grouped) {
-                FQD_TRY(grouped_pass(c, c->seg_hashes.as<uint32_t>(), (uint64_t)nseg * U, d, 0, nseg, (uint32_t)U));
+                FQD_TRY(grouped_pass(c, c->seg_hashes.as<uint32_t>(), (uint64_t)n_pass * U, d, seg_lo, nseg, (uint32_t)U));
             }
             for (uint32_t s = seg_lo; s < seg_hi && !(fuse_passes && grouped); s++) {
                 const uint32_t *pass_hashes = c->seg_hashes.as<uint32_t>() + (size_t)(s - seg_lo) * U;
@@ -586,6 +599,13 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
                 c->edges.release();
                 HIP_TRY(c, c->edges.reserve((size_t)(now + now / 8 + 1024) * 8));
                 c->edge_cap = c->edges.cap / 8;
+            }
+            if (pass0_held) {
+                // the pairs of pass 0 are gone with the counters: the whole search once more, every pass here
+                c->search_keeps_edges = false;
+                c->seg_hashes_nseg = 0;
+                timer.stop();
+                return find_edges_impl(c, max_distance, metric, shard, n_shards, 0, seg_hi, n_edges);
             }
             if (cand_need > c->gp_cand_cap) {
                 if (cand_need > cand_budget) {

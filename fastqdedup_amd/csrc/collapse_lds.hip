@@ -185,12 +185,12 @@ struct SlabSet {
     uint32_t n, cap;
     uint32_t *start, *cursor;
 };
-__global__ void slab_starts3_kernel(SlabSet a, SlabSet b, SlabSet c3, SlabSet d4)
+__global__ void slab_starts3_kernel(SlabSet a, SlabSet b, SlabSet c3, SlabSet d4, SlabSet e5, SlabSet f6)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const SlabSet sets[4] = {a, b, c3, d4};      // (a set of capacity 0 is a table of zeros)
+    const SlabSet sets[6] = {a, b, c3, d4, e5, f6};      // (a set of capacity 0 is a table of zeros)
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 6; k++) {
         if (sets[k].start && i <= sets[k].n) {
             sets[k].start[i] = i * sets[k].cap;
             if (i < sets[k].n)
@@ -444,6 +444,7 @@ struct CompactPolicy {
         const uint4 *in;          // the pack kernel's records: planes + read index
         uint32_t squeeze;
         fqd::SideSlabs side;
+        uint32_t route_mask;      // the key bits the bucket hash looks at (all ones: the whole key; else segment 0)
     };
     static __device__ __forceinline__ uint32_t segment_tag(const Source &, uint32_t) { return 0u; }
     static __device__ __forceinline__ void apply_tag(fqd::Rec12 &, uint32_t) {}
@@ -476,7 +477,7 @@ struct CompactPolicy {
         v.a = squeeze ? r.x | r.z : r.x;
         v.b = squeeze ? r.y | r.z : r.y;
         v.id = rare ? 0xFFFFFFFFu : r.w;
-        return rare ? 0u : fqd::fqd_hash_rec12(v.a, v.b);
+        return rare ? 0u : fqd::fqd_route_hash(v.a, v.b, s.route_mask);
     }
     using KeyRaw = uint4;
     template <bool LEVEL1>
@@ -667,22 +668,44 @@ __device__ __forceinline__ void rec12_planes(uint32_t squeeze, uint32_t a, uint3
     }
 }
 
+constexpr uint32_t P0_ROWS = 512;   // rows of a bucket a wave holds in LDS for search pass 0 (more: the search does that pass)
+constexpr uint32_t P0_WCAP = 256;   // edges buffered per wave (it keeps them across its buckets: one atomic on the job's edge counter per flush,
+                                    // and ONE word takes ~88 atomics per microsecond -- a flush per bucket, 65 536 of them, was 0.6 ms)
+constexpr uint32_t P0_SIDE_WAVES = 64;   // virtual buckets behind the last one: the segment hashes of the side path's keys
+
 // one wave per bucket: tmp[bucket_start[b] + j] -> row side + uoff[b] + j of the unique table, side = *side_unique
 // keys that launch_side_collapse has put at the head of the table already; the waves behind the last bucket
 // write the segment hashes of those keys (their total was not known when they were written)
+template <bool PASS0>
 __global__ __launch_bounds__(256) void bucket_compact12_kernel(
     const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ unique_incl, uint32_t n_buckets,
     const uint4 *__restrict__ tmp, uint32_t squeeze, const uint32_t *__restrict__ side_unique,
     uint4 *__restrict__ urecs, uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst, fqd::SegHashOut sho,
-    const uint32_t *__restrict__ bucket_unique, const uint32_t *__restrict__ group_total)
+    const uint32_t *__restrict__ bucket_unique, const uint32_t *__restrict__ group_total, fqd::Pass0 p0)
 {
-    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // search pass 0 (fqd::Pass0): the wave's rows, counting-sorted by six more bits of their route hash
+    // (PASS0 = false: none of this is compiled in -- p0.mask is 0 then)
+    __shared__ uint32_t s_pa[PASS0 ? 4 : 1][PASS0 ? P0_ROWS : 1], s_pb[PASS0 ? 4 : 1][PASS0 ? P0_ROWS : 1];
+    __shared__ uint16_t s_pj[PASS0 ? 4 : 1][PASS0 ? P0_ROWS : 1];
+    __shared__ uint32_t s_poff[PASS0 ? 4 : 1][66];
+    __shared__ uint2 s_pe[PASS0 ? 4 : 1][PASS0 ? P0_WCAP : 1];
+    __shared__ uint32_t s_pn[4];
+    if (!PASS0)
+        p0.mask = 0;
     const uint32_t side = side_unique ? *side_unique : 0u;
+    const uint32_t lane = fqd_lane(), wave = threadIdx.x >> 6;
+    // With pass 0 the grid is a fixed number of waves, each taking buckets w, w + waves, ...; else one wave per bucket.
+    const uint32_t waves_total = (gridDim.x * blockDim.x) >> 6, wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t side_waves = side_unique && sho.nseg ? (p0.mask ? P0_SIDE_WAVES : waves_total - n_buckets) : 0u;
+    unsigned long long reported = 0;
+    if (p0.mask && lane == 0)
+        s_pn[wave] = 0;
+  for (uint32_t b = wave_global; b < n_buckets + side_waves; b += waves_total) {
     // group_total != NULL: no scan of the bucket counts has run -- the wave adds up the totals of the groups of 256
     // buckets before its own and the counts of the buckets before it inside its group (2 KB of L2-resident words)
     uint32_t g_begin = 0, g_all = 0, g_cnt = 0;
     if (group_total) {
-        const uint32_t lane = fqd_lane(), n_groups = max(n_buckets >> 8, 1u), my_group = min(b, n_buckets - 1) >> 8;
+        const uint32_t n_groups = max(n_buckets >> 8, 1u), my_group = min(b, n_buckets - 1) >> 8;
         for (uint32_t g0 = 0; g0 < n_groups; g0 += 64) {
             const uint32_t g = g0 + lane, t = g < n_groups ? group_total[g] : 0u;
             g_all += t;
@@ -704,43 +727,167 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
     const uint32_t n_unique = side + (group_total ? g_all : unique_incl[n_buckets - 1]);
     if (b >= n_buckets) {
         if (!sho.nseg)
-            return;
-        const uint32_t n_waves = (gridDim.x * blockDim.x >> 6) - n_buckets;
-        for (uint32_t j = (b - n_buckets) * 64 + fqd_lane(); j < side; j += n_waves * 64) {
+            continue;
+        const uint32_t n_waves = side_waves;
+        for (uint32_t j = (b - n_buckets) * 64 + lane; j < side; j += n_waves * 64) {
             const uint4 r = urecs[j];
             const uint32_t w[3] = {r.x, r.y, r.z};
-            for (uint32_t sg = 0; sg < sho.nseg; sg++)
-                sho.out[(size_t)sg * n_unique + j] = fqd_segment_hash(w, sho.planes, sho.kw, sho.len, sg, sho.nseg);
+            for (uint32_t sg = sho.first; sg < sho.nseg; sg++)
+                sho.out[(size_t)(sg - sho.first) * n_unique + j] = fqd_segment_hash(w, sho.planes, sho.kw, sho.len, sg, sho.nseg);
         }
-        return;
+        continue;
     }
     const uint32_t begin = group_total ? g_begin : (b ? unique_incl[b - 1] : 0u);
     const uint32_t cnt = group_total ? g_cnt : unique_incl[b] - begin;
     const uint32_t src = bucket_start[b];
-    for (uint32_t j0 = fqd_lane(); j0 < cnt; j0 += 4 * 64) {
-        uint4 row[4];
+    const bool pass0 = PASS0 && p0.mask != 0 && cnt <= P0_ROWS && cnt > 0;
+    if (p0.mask && cnt > P0_ROWS && lane == 0)
+        atomicOr(p0.flag, 1u);                 // more rows than the wave's LDS holds: the search does pass 0 itself
+    // one row -> the unique table (and the segment hashes of the search passes that follow)
+    auto write_row = [&](const uint4 &row, uint32_t j) {
+        uint32_t w[3];
+        rec12_planes(squeeze, row.x, row.y, w);
+        const uint32_t u = side + begin + j;
+        if (sho.nseg)
+            for (uint32_t sg = sho.first; sg < sho.nseg; sg++)
+                sho.out[(size_t)(sg - sho.first) * n_unique + u] = fqd_segment_hash(w, sho.planes, sho.kw, sho.len, sg, sho.nseg);
+        urecs[u] = make_uint4(w[0], w[1], w[2], 0u);
+        ucounts[u] = row.z;
+        ufirst[u] = row.w;
+    };
+    if (!pass0) {
+        for (uint32_t j0 = lane; j0 < cnt; j0 += 4 * 64) {
+            uint4 row[4];
 #pragma unroll
-        for (uint32_t t = 0; t < 4; t++) {
-            const uint32_t j = j0 + t * 64;
-            row[t] = make_uint4(0, 0, 0, 0);
-            if (j < cnt)
-                row[t] = tmp[src + j];
+            for (uint32_t t = 0; t < 4; t++)       // (clamped, unconditional: the four loads are in flight together)
+                row[t] = tmp[src + min(j0 + t * 64, cnt - 1)];
+#pragma unroll
+            for (uint32_t t = 0; t < 4; t++)
+                if (j0 + t * 64 < cnt)
+                    write_row(row[t], j0 + t * 64);
         }
+        continue;
+    }
+    // ---- with search pass 0 (fqd::Pass0). The wave is a chain of dependent steps, and 65 536 of them run: every
+    // load is requested as early as its address is known -- the rows, the bucket's probe list and the probes' records
+    // -- and the stores of the unique table go out while the edge list's reservation is on its way.
+    constexpr uint32_t RPL = P0_ROWS / 64;      // rows per lane
+    uint4 row[RPL];
 #pragma unroll
-        for (uint32_t t = 0; t < 4; t++) {
-            const uint32_t j = j0 + t * 64;
-            if (j >= cnt)
-                continue;
+    for (uint32_t q = 0; q < RPL; q++)
+        row[q] = tmp[src + min(lane + 64 * q, cnt - 1)];
+    const uint32_t np = p0.probe_n ? min(p0.probe_n[b], fqd::FQD_P0_PROBE_CAP) : 0u;
+    const uint32_t my_probe = p0.probe_n ? p0.probe[(size_t)b * fqd::FQD_P0_PROBE_CAP + (lane & (fqd::FQD_P0_PROBE_CAP - 1))] : 0u;
+    uint4 my_probe_rec = make_uint4(0, 0, 0, 0);      // lane l < np: the record of probe l
+    if ((lane & (fqd::FQD_P0_PROBE_CAP - 1)) < np)
+        my_probe_rec = urecs[my_probe];
+    const uint32_t sub_shift = 32u - p0.bucket_bits - 6u;
+    s_poff[wave][lane] = 0;
+    uint32_t sub_rank[RPL];                     // sub-bin << 16 | rank inside it
+#pragma unroll
+    for (uint32_t q = 0; q < RPL; q++) {
+        sub_rank[q] = 0;
+        if (lane + 64 * q < cnt) {
+            const uint32_t sub = (fqd::fqd_route_hash(row[q].x, row[q].y, p0.mask) >> sub_shift) & 63u;
+            sub_rank[q] = (sub << 16) | atomicAdd(&s_poff[wave][sub], 1u);
+        }
+    }
+    // (the same wave wrote what it now reads: the LDS keeps a wave's accesses in order)
+    {
+        const uint32_t c = s_poff[wave][lane];
+        uint32_t incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if ((int)lane >= o)
+                incl += up;
+        }
+        s_poff[wave][lane] = incl - c;          // start of sub-bin `lane`
+        if (lane == 63)
+            s_poff[wave][64] = incl;            // = cnt
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < RPL; q++) {
+        const uint32_t j = lane + 64 * q;
+        if (j < cnt) {
+            const uint32_t p = s_poff[wave][sub_rank[q] >> 16] + (sub_rank[q] & 0xFFFFu);
+            s_pa[wave][p] = row[q].x;
+            s_pb[wave][p] = row[q].y;
+            s_pj[wave][p] = (uint16_t)j;
+        }
+    }
+    // Pairs go to the wave's LDS buffer; a full buffer is written out by the lanes that are active (converged) at the
+    // call. Pairs behind the edge list's end are counted, not written: the search sees the count and starts over.
+    auto write_out = [&](uint32_t have, uint32_t n, uint32_t rank, int leader) {
+        unsigned long long g = 0;
+        if ((int)lane == leader)
+            g = atomicAdd(p0.edge_count, (unsigned long long)have);
+        g = __shfl(g, leader);
+        for (uint32_t e = rank; e < have; e += n)
+            if (g + e < p0.edge_cap)
+                reinterpret_cast<uint2 *>(p0.edges)[g + e] = s_pe[wave][e];
+        reported += (int)lane == leader ? have : 0u;
+    };
+    auto note = [&](uint32_t u, uint32_t v) {
+        const unsigned long long act = __ballot(1);
+        const uint32_t n = (uint32_t)__popcll(act), rank = (uint32_t)__popcll(act & fqd_lanemask_lt());
+        const int leader = __ffsll((long long)act) - 1;
+        uint32_t have = __hip_atomic_load(&s_pn[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (have + n > P0_WCAP) {
+            write_out(have, n, rank, leader);
+            have = 0;
+        }
+        s_pe[wave][have + rank] = make_uint2(min(u, v), max(u, v));
+        if ((int)lane == leader)
+            __hip_atomic_store(&s_pn[wave], have + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    const uint32_t uid0 = side + begin;
+    // every row against the rows behind it in its sub-bin: same segment 0, at most d mismatches elsewhere
+    for (uint32_t i = lane; i < cnt; i += 64) {
+        const uint32_t ai = s_pa[wave][i], bi = s_pb[wave][i];
+        const uint32_t end = s_poff[wave][((fqd::fqd_route_hash(ai, bi, p0.mask) >> sub_shift) & 63u) + 1];
+        for (uint32_t k = i + 1; k < end; k++) {
+            const uint32_t x = (ai ^ s_pa[wave][k]) | (bi ^ s_pb[wave][k]);     // mismatching positions
+            if (!(x & p0.mask) && (uint32_t)__popc(x) <= p0.d)
+                note(uid0 + s_pj[wave][i], uid0 + s_pj[wave][k]);
+        }
+    }
+    // the keys with an N that were routed here: against every row, and against each other
+    for (uint32_t p = 0; p < np; p++) {
+        const uint32_t sp = __shfl(my_probe, p);
+        const uint4 pr = make_uint4(__shfl(my_probe_rec.x, p), __shfl(my_probe_rec.y, p), __shfl(my_probe_rec.z, p), 0u);
+        for (uint32_t i = lane; i < cnt; i += 64) {
             uint32_t w[3];
-            rec12_planes(squeeze, row[t].x, row[t].y, w);
-            const uint32_t u = side + begin + j;
-            if (sho.nseg)
-                for (uint32_t sg = 0; sg < sho.nseg; sg++)
-                    sho.out[(size_t)sg * n_unique + u] = fqd_segment_hash(w, sho.planes, sho.kw, sho.len, sg, sho.nseg);
-            urecs[u] = make_uint4(w[0], w[1], w[2], 0u);
-            ucounts[u] = row[t].z;
-            ufirst[u] = row[t].w;
+            rec12_planes(squeeze, s_pa[wave][i], s_pb[wave][i], w);
+            const uint32_t x = (pr.x ^ w[0]) | (pr.y ^ w[1]) | (pr.z ^ w[2]);
+            if (!(x & p0.mask) && (uint32_t)__popc(x) <= p0.d)
+                note(sp, uid0 + s_pj[wave][i]);
         }
+        if (lane > p && lane < np) {            // (lane l holds probe l)
+            const uint32_t x = (pr.x ^ my_probe_rec.x) | (pr.y ^ my_probe_rec.y) | (pr.z ^ my_probe_rec.z);
+            if (!(x & p0.mask) && (uint32_t)__popc(x) <= p0.d)
+                note(sp, my_probe);
+        }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < RPL; q++)
+        if (lane + 64 * q < cnt)
+            write_row(row[q], lane + 64 * q);
+  }
+    // what is left in the wave's edge buffer
+    if (p0.mask) {
+        const uint32_t left = __hip_atomic_load(&s_pn[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (left) {
+            unsigned long long g_left = 0;
+            if (lane == 0)
+                g_left = atomicAdd(p0.edge_count, (unsigned long long)left);
+            g_left = __shfl(g_left, 0);
+            for (uint32_t e = lane; e < left; e += 64)
+                if (g_left + e < p0.edge_cap)
+                    reinterpret_cast<uint2 *>(p0.edges)[g_left + e] = s_pe[wave][e];
+            reported += lane == 0 ? left : 0u;
+        }
+        if (p0.stats && lane == 0 && reported)
+            atomicAdd(&p0.stats[wave_global % FQD_STAT_SLOTS].edges, reported);
     }
 }
 
@@ -828,7 +975,7 @@ __global__ __launch_bounds__(SIDE_THREADS) void side_emit_kernel(const uint4 *__
                                                                  const uint32_t *__restrict__ block_counts,
                                                                  uint4 *__restrict__ urecs, uint32_t *__restrict__ ucounts,
                                                                  uint64_t *__restrict__ ufirst,
-                                                                 uint32_t *__restrict__ side_unique)
+                                                                 uint32_t *__restrict__ side_unique, fqd::Pass0 p0)
 {
     __shared__ uint32_t s_part[SIDE_THREADS / 64], s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -869,6 +1016,15 @@ __global__ __launch_bounds__(SIDE_THREADS) void side_emit_kernel(const uint4 *__
             urecs[u] = make_uint4(v.x, v.y, v.z, 0u);
             ucounts[u] = table[table_slots + i];
             ufirst[u] = table[2 * table_slots + i];
+            if (p0.mask) {
+                // search pass 0 happens in the compaction of the bucket this key's segment 0 routes to (fqd::Pass0)
+                const uint32_t bkt = fqd::fqd_route_hash(v.x | v.z, v.y | v.z, p0.mask) >> (32u - p0.bucket_bits);
+                const uint32_t at = atomicAdd(&p0.probe_n[bkt], 1u);
+                if (at < fqd::FQD_P0_PROBE_CAP)
+                    p0.probe[(size_t)bkt * fqd::FQD_P0_PROBE_CAP + at] = u;
+                else
+                    atomicOr(p0.flag, 1u);
+            }
         }
         base += round_total;
     }
@@ -955,14 +1111,19 @@ hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, u
 
 hipError_t launch_slab_starts3(uint32_t n1, uint32_t cap1, uint32_t *start1, uint32_t *cursor1, uint32_t n2, uint32_t cap2,
                                uint32_t *start2, uint32_t *cursor2, uint32_t n3, uint32_t cap3, uint32_t *start3,
-                               uint32_t *cursor3, hipStream_t st, uint32_t n_zero, uint32_t *zero)
+                               uint32_t *cursor3, hipStream_t st, uint32_t n_zero, uint32_t *zero, uint32_t *zero_b,
+                               uint32_t last_b, uint32_t *zero_c, uint32_t last_c)
 {
-    // zero[0 .. n_zero] = 0 on the way (the dedupe's group totals)
-    const uint32_t most = std::max(std::max(n1, zero ? n_zero : 0u), std::max(start2 ? n2 : 0u, start3 ? n3 : 0u));
+    // zero[0 .. n_zero] = 0 on the way (the dedupe's group totals, the probe counts of search pass 0), and two more
+    // small tables of zeros (the edge counter, the search statistics)
+    uint32_t most = std::max(std::max(n1, zero ? n_zero : 0u), std::max(start2 ? n2 : 0u, start3 ? n3 : 0u));
+    most = std::max(most, std::max(zero_b ? last_b : 0u, zero_c ? last_c : 0u));
     slab_starts3_kernel<<<(most + 1 + 255) / 256, 256, 0, st>>>(SlabSet{n1, cap1, start1, cursor1},
                                                                SlabSet{n2, cap2, start2, cursor2},
                                                                SlabSet{n3, cap3, start3, cursor3},
-                                                               SlabSet{zero ? n_zero : 0u, 0u, zero, zero});
+                                                               SlabSet{zero ? n_zero : 0u, 0u, zero, zero},
+                                                               SlabSet{zero_b ? last_b : 0u, 0u, zero_b, zero_b},
+                                                               SlabSet{zero_c ? last_c : 0u, 0u, zero_c, zero_c});
     return hipGetLastError();
 }
 
@@ -998,14 +1159,14 @@ uint32_t part_tile_size12() { return fqd_partition::THREADS * CompactPolicy::EPT
 hipError_t launch_part_scatter12(const uint32_t *in, uint32_t squeeze, SideSlabs side, const uint32_t *seg_start,
                                  const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                  uint32_t n_bins, uint32_t *cursor, Rec12 *out, hipStream_t st, uint32_t slab_cap,
-                                 uint32_t *slab_overflow, const uint32_t *seg_end, uint32_t seg_shift)
+                                 uint32_t *slab_overflow, const uint32_t *seg_end, uint32_t seg_shift, uint32_t route_mask)
 {
     if (n_bins > fqd_partition::MAX_BINS || (squeeze != 1 && squeeze != 2))
         return hipErrorInvalidValue;
     if (squeeze == 1 && (!side.recs || !side.cursor || !side.overflow || !side.cap || !side.n_slabs ||
                          (side.n_slabs & (side.n_slabs - 1))))
         return hipErrorInvalidValue;
-    const CompactPolicy::Source src{reinterpret_cast<const uint4 *>(in), squeeze, side};
+    const CompactPolicy::Source src{reinterpret_cast<const uint4 *>(in), squeeze, side, route_mask ? route_mask : 0xFFFFFFFFu};
     if (n_bins <= 256)
         part_scatter12_kernel<256><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
             src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift);
@@ -1028,13 +1189,22 @@ hipError_t launch_bucket_dedupe12(const Rec12 *part, const uint32_t *bucket_star
 hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                    const uint32_t *tmp_rec, uint32_t squeeze, const uint32_t *side_unique,
                                    uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, hipStream_t st,
-                                   SegHashOut seg_hashes, const uint32_t *bucket_unique, const uint32_t *group_total)
+                                   SegHashOut seg_hashes, const uint32_t *bucket_unique, const uint32_t *group_total,
+                                   Pass0 pass0)
 {
-    // one wave per bucket + 64 waves for the segment hashes of the side path's keys
-    const uint64_t threads = ((uint64_t)n_buckets + (side_unique && seg_hashes.nseg ? 64 : 0)) * 64;
-    bucket_compact12_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
+    // one wave per bucket + 64 waves for the segment hashes of the side path's keys; with search pass 0: as many waves
+    // as the GPU holds at once (256 CUs x 5 workgroups of 4), each taking every waves-th bucket
+    uint64_t threads = ((uint64_t)n_buckets + (side_unique && seg_hashes.nseg ? 64 : 0)) * 64;
+    if (pass0.mask) {
+        threads = std::min<uint64_t>(threads, (uint64_t)256 * 4 * 256);      // (107 VGPRs: four workgroups per CU)
+        bucket_compact12_kernel<true><<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
+            bucket_start, unique_incl, n_buckets, reinterpret_cast<const uint4 *>(tmp_rec), squeeze, side_unique,
+            reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, bucket_unique, group_total, pass0);
+        return hipGetLastError();
+    }
+    bucket_compact12_kernel<false><<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
         bucket_start, unique_incl, n_buckets, reinterpret_cast<const uint4 *>(tmp_rec), squeeze, side_unique,
-        reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, bucket_unique, group_total);
+        reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, bucket_unique, group_total, pass0);
     return hipGetLastError();
 }
 
@@ -1043,7 +1213,7 @@ uint32_t side_table_words(uint32_t table_slots) { return 3 * table_slots + (tabl
 hipError_t launch_side_collapse(const uint4 *side, const uint32_t *cursor, uint32_t first_part, uint32_t subs, uint32_t cap,
                                 const uint32_t *weights, uint32_t *table, uint32_t table_slots, uint32_t *block_counts,
                                 uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, uint32_t *side_unique,
-                                uint32_t *overflow, hipStream_t st)
+                                uint32_t *overflow, hipStream_t st, Pass0 pass0)
 {
     if (!table_slots || (table_slots & (table_slots - 1)) || !subs || !cap)
         return hipErrorInvalidValue;
@@ -1053,7 +1223,7 @@ hipError_t launch_side_collapse(const uint4 *side, const uint32_t *cursor, uint3
                                                                      table_slots, overflow);
     side_count_kernel<<<blocks, SIDE_THREADS, 0, st>>>(table, table_slots, block_counts);
     side_emit_kernel<<<blocks, SIDE_THREADS, 0, st>>>(side, table, table_slots, block_counts,
-                                                    reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, side_unique);
+                                                    reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, side_unique, pass0);
     return hipGetLastError();
 }
 

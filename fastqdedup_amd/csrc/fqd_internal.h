@@ -239,7 +239,15 @@ struct PackScatter {
     // owner-major bins (multi-GPU): bin = owner * owner_hb + top log2(owner_hb) hash bits, owner by the
     // OwnerRule handed to launch_pack; n_bins = owner_parts * owner_hb. 0: plain hash bins.
     uint32_t owner_parts = 0, owner_hb = 0;
+    // != 0: the records are binned by a hash of SEGMENT 0 of the key alone (route_mask: its bits in the 32-base word)
+    // instead of the whole key -- every key sharing segment 0 then ends in one bucket of the collapse, whose
+    // compaction finds the pairs of search pass 0 on the spot (Pass0 below)
+    uint32_t route_mask = 0;
 };
+// The route hash of a one-word key in (a, b) form -- a = p0 | p2, b = p1 | p2 for the three planes of "ACGNT", the two
+// planes themselves for a two-plane alphabet -- over the bits of segment 0: what the fused pack (level 1), level 2
+// and the side path's probe lists must agree on.
+__device__ __forceinline__ uint32_t fqd_route_hash(uint32_t a, uint32_t b, uint32_t route_mask);
 // Compact records of the LDS collapse (collapse_lds.hip; single GPU, one 32-base word per plane): level 2 turns the
 // pack kernel's uint4 records into 12 bytes -- two key words + the read index -- which the dedupe then reads.
 //   squeeze 1: the "ACGNT" code table (A 0, C 1, G 2, N 3, T 4): planes (p0, p1, p2) -> (p0 | p2, p1 | p2), a
@@ -256,6 +264,29 @@ __device__ __forceinline__ uint32_t fqd_hash_rec12(uint32_t a, uint32_t b)
     h = (h ^ b) * 0x85EBCA6Bu;
     return fqd_mix32(h);
 }
+__device__ __forceinline__ uint32_t fqd_route_hash(uint32_t a, uint32_t b, uint32_t route_mask)
+{
+    return fqd_hash_rec12(a & route_mask, b & route_mask);
+}
+// Search pass 0 inside the collapse's compaction (collapse_lds.hip bucket_compact12_kernel): with the reads routed
+// by segment 0, a bucket holds EVERY unique key sharing its segment-0 values, so the pairs that agree on segment 0
+// and lie within distance d are found among the bucket's rows while they are in registers -- no (hash, uid) items,
+// no partition, no candidate list, no record gather for that pass. Keys with an N (side path, head of the unique
+// table) are filed in per-bucket probe lists by side_emit_kernel and compared with the bucket's rows there.
+constexpr uint32_t FQD_P0_PROBE_CAP = 16;     // side keys per bucket (more: *flag, the search runs pass 0 itself)
+struct PairStats;
+struct Pass0 {
+    uint32_t mask = 0;                  // bits of segment 0 in the key word; 0: no pass 0
+    uint32_t d = 0;                     // pairs within this distance
+    uint32_t bucket_bits = 0;           // bucket of a key = route hash >> (32 - bucket_bits)
+    uint32_t *probe_n = nullptr;        // [n_buckets], zeroed before the side path runs
+    uint32_t *probe = nullptr;          // [n_buckets][FQD_P0_PROBE_CAP] uids of side keys
+    uint32_t *edges = nullptr;          // (u, v), u < v, appended behind *edge_count
+    unsigned long long *edge_count = nullptr;
+    uint64_t edge_cap = 0;
+    uint32_t *flag = nullptr;           // |= 1: pass 0 is incomplete (a bucket of more rows than the wave's LDS holds, a full probe list)
+    PairStats *stats = nullptr;         // stats[slot].edges += pairs reported
+};
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
                        uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, const uint8_t *lut_host,
                        uint32_t *recs, uint32_t *lens, uint32_t *hashes, uint32_t *owners, OwnerRule rule,
@@ -306,8 +337,9 @@ hipError_t launch_slab_tile_starts(const uint32_t *seg_start, const uint32_t *se
 uint32_t part_tile_size();
 // bucket_compact_kernel may write the segment hashes of the search that follows (nseg = 0: no)
 struct SegHashOut {
-    uint32_t *out = nullptr;      // [nseg][n_unique]
+    uint32_t *out = nullptr;      // [nseg - first][n_unique]: segments first .. nseg - 1
     uint32_t nseg = 0, planes = 0, kw = 0, len = 0;
+    uint32_t first = 0;           // (1: pass 0 is done by the compaction itself, see Pass0)
 };
 // collapse_pairs.hip -- sort-free collapse for records longer than one uint4
 hipError_t launch_bucket_pairs_dedupe(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
@@ -329,7 +361,9 @@ hipError_t launch_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *bucket
 // up to three slab sets in one launch (start2 / start3 NULL: fewer)
 hipError_t launch_slab_starts3(uint32_t n1, uint32_t cap1, uint32_t *start1, uint32_t *cursor1, uint32_t n2, uint32_t cap2,
                                uint32_t *start2, uint32_t *cursor2, uint32_t n3, uint32_t cap3, uint32_t *start3,
-                               uint32_t *cursor3, hipStream_t st, uint32_t n_zero = 0, uint32_t *zero = nullptr);
+                               uint32_t *cursor3, hipStream_t st, uint32_t n_zero = 0, uint32_t *zero = nullptr,
+                               uint32_t *zero_b = nullptr, uint32_t last_b = 0, uint32_t *zero_c = nullptr,
+                               uint32_t last_c = 0);   // zero[0 .. n_zero], zero_b[0 .. last_b], zero_c[0 .. last_c] = 0
 hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                 uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec, uint32_t *tmp_count,
                                 uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);
@@ -350,7 +384,7 @@ hipError_t launch_part_scatter12(const uint32_t *in /* uint4 records */, uint32_
                                  const uint32_t *seg_start, const uint32_t *tile_start, uint32_t n_seg,
                                  uint32_t max_tiles, uint32_t shift, uint32_t n_bins, uint32_t *cursor, Rec12 *out,
                                  hipStream_t st, uint32_t slab_cap, uint32_t *slab_overflow, const uint32_t *seg_end,
-                                 uint32_t seg_shift);
+                                 uint32_t seg_shift, uint32_t route_mask = 0xFFFFFFFFu);
 uint32_t part_tile_size12();
 hipError_t launch_bucket_dedupe12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                   uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
@@ -360,7 +394,7 @@ hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t 
                                    const uint32_t *tmp_rec, uint32_t squeeze, const uint32_t *side_unique,
                                    uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, hipStream_t st,
                                    SegHashOut seg_hashes = SegHashOut(), const uint32_t *bucket_unique = nullptr,
-                                   const uint32_t *group_total = nullptr);
+                                   const uint32_t *group_total = nullptr, Pass0 pass0 = Pass0());
 // the keys of the side slabs (few: the reads with an N) collapsed through a hash table in global memory and
 // written to the head of the unique table; table: side_table_words(table_slots) words (table_slots a power of
 // two), cleared here; block_counts = table + 3 * table_slots
@@ -369,7 +403,7 @@ hipError_t launch_side_collapse(const uint4 *side, const uint32_t *cursor /* of 
                                 uint32_t first_part /* the cursors started at (first_part + sub) * cap */, uint32_t subs, uint32_t cap,
                                 const uint32_t *weights, uint32_t *table, uint32_t table_slots, uint32_t *block_counts,
                                 uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, uint32_t *side_unique,
-                                uint32_t *overflow, hipStream_t st);
+                                uint32_t *overflow, hipStream_t st, Pass0 pass0 = Pass0());
 
 // edges.hip
 hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t nseg,
@@ -580,7 +614,8 @@ hipError_t launch_transcode_records(const uint32_t *src, const uint32_t *src_len
 // synth.hip
 hipError_t launch_synth(uint8_t *out, uint64_t n_total, uint64_t start, uint64_t count, uint32_t length,
                         uint32_t umi, uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub,
-                        hipStream_t st);
+                        hipStream_t st, uint64_t thr_hot = 0, uint64_t thr_ladder = 0, uint32_t lowc_every = 0,
+                        uint32_t skew = 0);
 hipError_t launch_copy16(const void *src, void *dst, uint64_t bytes, hipStream_t st);
 hipError_t launch_synth_indels(uint64_t n_total, uint64_t start, uint64_t count, uint32_t length, uint32_t umi,
                                uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub, uint64_t thr_indel,

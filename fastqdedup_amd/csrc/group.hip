@@ -470,7 +470,7 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
                         prs[t].y -= fused_U;
                         sy++;
                     }
-                    segs[t] = sx;
+                    segs[t] = seg + sx;                  // (seg: the first pass of the fused ones)
                     lives[t] = lives[t] && sx == sy;     // (hashes of different segments meet only by collision)
                 }
             }
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
                     pr.y -= fused_U;
                     sy++;
                 }
-                my_seg = sx;
+                my_seg = seg + sx;
                 live = sx == sy;             // (hashes of different segments meet only by collision)
             }
         }

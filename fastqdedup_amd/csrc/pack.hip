@@ -342,7 +342,11 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
             if (k < nk) {
                 v[e] = tile4[k];
                 const uint32_t rec[3] = {v[e].x, v[e].y, v[e].z};
-                const uint32_t h = fqd_hash_record(rec, W * K, fixed_len);
+                // (route_mask: the bins follow segment 0 of the key alone, in the (a, b) form level 2 will use)
+                const uint32_t h = fs.route_mask ? fqd::fqd_route_hash(K == 3 ? rec[0] | rec[2] : rec[0],
+                                                                      K == 3 ? rec[1] | rec[2] : (K >= 2 ? rec[1] : 0u),
+                                                                      fs.route_mask)
+                                                 : fqd_hash_record(rec, W * K, fixed_len);
                 v[e].w = (uint32_t)(key0 + k);               // the read index travels with the record
                 if (fs.owner_parts) {
                     // multi-GPU: the bins are owner-major (owner = rank the read goes to, the pigeonhole

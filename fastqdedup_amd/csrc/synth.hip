@@ -21,6 +21,10 @@ __device__ __forceinline__ uint64_t stream_base(uint64_t seed, uint64_t stream)
 struct SynthParams {
     uint64_t n_total, seed, thr_n, thr_sub;
     uint32_t length, umi, copies;
+    // the skewed model of synth.py (all zero: the uniform one): thresholds of the hot molecule and of the ladder,
+    // every lowc_every-th molecule poly-A in its first half
+    uint64_t thr_hot = 0, thr_ladder = 0;
+    uint32_t lowc_every = 0, skew = 0;
 };
 
 // base b of read r of the fixed-length job
@@ -32,9 +36,31 @@ __device__ __forceinline__ uint8_t synth_base(const SynthParams &p, uint64_t r, 
     uint64_t F = M / 4;
     if (F < 1)
         F = 1;
-    const uint64_t mol = splitmix64(stream_base(p.seed, 0) ^ r) % M;
+    uint64_t mol = splitmix64(stream_base(p.seed, 0) ^ r);
+    bool ladder = false;
+    if (p.skew) {
+        // (the same two double multiplications, in the same order, as numpy's: no fused multiply-add can form)
+        const double x = (double)(mol >> 11) * (1.0 / 9007199254740992.0);
+        const double scaled = (double)M * x;
+        mol = (uint64_t)(scaled * x);
+        if (mol > M - 1)
+            mol = M - 1;
+        const uint64_t pick = splitmix64(stream_base(p.seed, 8) ^ r) >> 11;
+        if (pick < p.thr_hot)
+            mol = 0;
+        ladder = pick >= p.thr_hot && pick < p.thr_hot + p.thr_ladder;
+    } else {
+        mol %= M;
+    }
     uint64_t truth;
-    if (b < p.umi) {
+    if (ladder) {
+        if (b + 8 >= p.length)
+            truth = ((splitmix64(stream_base(p.seed, 9) ^ r) & 0xFFFFull) >> (2 * (b + 8 - p.length))) & 3ull;
+        else
+            truth = splitmix64(stream_base(p.seed, 7) ^ (uint64_t)b) & 3ull;
+    } else if (p.lowc_every && b < p.length / 2 && mol % p.lowc_every == p.lowc_every / 2) {
+        truth = 0;
+    } else if (b < p.umi) {
         truth = splitmix64(stream_base(p.seed, 2) ^ (mol * p.umi + b)) & 3ull;
     } else {
         const uint64_t ins = splitmix64(stream_base(p.seed, 1) ^ mol) % F;
@@ -157,7 +183,7 @@ namespace fqd {
 
 hipError_t launch_synth(uint8_t *out, uint64_t n_total, uint64_t start, uint64_t count, uint32_t length,
                         uint32_t umi, uint64_t seed, uint32_t copies, uint64_t thr_n, uint64_t thr_sub,
-                        hipStream_t st)
+                        hipStream_t st, uint64_t thr_hot, uint64_t thr_ladder, uint32_t lowc_every, uint32_t skew)
 {
     const uint64_t total = count * length;
     if (!total)
@@ -167,7 +193,11 @@ hipError_t launch_synth(uint8_t *out, uint64_t n_total, uint64_t start, uint64_t
     uint64_t blocks = (total + 255) / 256;
     if (blocks > (1u << 20))
         blocks = 1u << 20;
-    const SynthParams p{n_total, seed, thr_n, thr_sub, length, umi, copies};
+    SynthParams p{n_total, seed, thr_n, thr_sub, length, umi, copies};
+    p.thr_hot = thr_hot;
+    p.thr_ladder = thr_ladder;
+    p.lowc_every = lowc_every;
+    p.skew = skew;
     synth_kernel<<<(unsigned)blocks, 256, 0, st>>>(out, p, start, count);
     return hipGetLastError();
 }

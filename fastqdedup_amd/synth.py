@@ -47,27 +47,50 @@ def rate_threshold(p: float) -> int:
     return int(p * float(1 << 53))
 
 
+# The SKEWED model (``skew=SKEW`` below; what real libraries look like and the uniform model does not):
+#   * molecule abundance is heavy-tailed: read r copies molecule floor(M * x^2), x uniform in [0, 1) -- molecule m
+#     draws mass ~ 1/sqrt(m) -- and a share ``hot`` of all reads copies molecule 0 (one key with n * hot copies);
+#   * every ``lowc_every``-th molecule is low-complexity: the first half of its key is poly-A, so all of them share
+#     segment 0 of a two-segment split (a crowded bucket of the neighbour search);
+#   * a share ``ladder`` of the reads draws from a LADDER of 4^8 keys: one random prefix followed by every value of
+#     the last eight bases -- 65 536 keys, each with 24 neighbours at Hamming distance 1, ONE connected component.
+SKEW = {"hot": 0.02, "ladder": 0.01, "lowc_every": 100}
+
+
 def synth_keys(n: int, length: int, umi: int, seed: int, *, copies: int = 4,
-               sub_rate: float = 1e-3, n_rate: float = 1e-4) -> np.ndarray:
+               sub_rate: float = 1e-3, n_rate: float = 1e-4, skew=None) -> np.ndarray:
     """Returns an ``(n, length)`` uint8 array of ASCII keys (reads ``0 .. n`` of
     an ``n``-read job). ``umi >= length`` makes every molecule fully random."""
-    return _synth(n, length, umi, seed, copies, sub_rate, n_rate, 0, n)
+    return _synth(n, length, umi, seed, copies, sub_rate, n_rate, 0, n, skew)
 
 
 def synth_keys_range(n_total: int, start: int, count: int, length: int, umi: int, seed: int, *,
-                     copies: int = 4, sub_rate: float = 1e-3, n_rate: float = 1e-4) -> np.ndarray:
+                     copies: int = 4, sub_rate: float = 1e-3, n_rate: float = 1e-4, skew=None) -> np.ndarray:
     """Reads ``start .. start+count`` of an ``n_total``-read job (one rank's shard)."""
-    return _synth(count, length, umi, seed, copies, sub_rate, n_rate, start, n_total)
+    return _synth(count, length, umi, seed, copies, sub_rate, n_rate, start, n_total, skew)
 
 
-def _synth(n, length, umi, seed, copies, sub_rate, n_rate, start, n_total):
+def _synth(n, length, umi, seed, copies, sub_rate, n_rate, start, n_total, skew=None):
     if n == 0:
         return np.zeros((0, length), dtype=np.uint8)
     umi = min(umi, length)
     M = max(1, n_total // copies)
     F = max(1, M // 4)
     r = np.arange(start, start + n, dtype=np.uint64)
-    mol = stream_hash(seed, 0, r) % np.uint64(M)                      # (n,)
+    lowc = ladder = None
+    if skew:
+        x = (stream_hash(seed, 0, r) >> np.uint64(11)).astype(np.float64) * (1.0 / float(1 << 53))
+        mol = np.minimum((np.float64(M) * x * x).astype(np.uint64), np.uint64(M - 1))
+        pick = stream_hash(seed, 8, r) >> np.uint64(11)
+        thr_hot, thr_lad = rate_threshold(skew.get("hot", 0.0)), rate_threshold(skew.get("ladder", 0.0))
+        mol = np.where(pick < np.uint64(thr_hot), np.uint64(0), mol)
+        ladder = (pick >= np.uint64(thr_hot)) & (pick < np.uint64(thr_hot + thr_lad))
+        rung = stream_hash(seed, 9, r) & np.uint64(0xFFFF)
+        every = int(skew.get("lowc_every", 0))
+        if every:
+            lowc = (mol % np.uint64(every)) == np.uint64(every // 2)
+    else:
+        mol = stream_hash(seed, 0, r) % np.uint64(M)                  # (n,)
     ins = stream_hash(seed, 1, mol) % np.uint64(F)                    # (n,)
     out = np.empty((n, length), dtype=np.uint8)
     thr_n = np.uint64(rate_threshold(n_rate))
@@ -78,6 +101,14 @@ def _synth(n, length, umi, seed, copies, sub_rate, n_rate, start, n_total):
             true = stream_hash(seed, 2, mol * np.uint64(umi) + np.uint64(b)) & np.uint64(3)
         else:
             true = stream_hash(seed, 3, ins * np.uint64(rest) + np.uint64(b - umi)) & np.uint64(3)
+        if lowc is not None and b < length // 2:
+            true = np.where(lowc, np.uint64(0), true)
+        if ladder is not None:
+            if b + 8 >= length:
+                rung_base = (rung >> np.uint64(2 * (b + 8 - length))) & np.uint64(3)
+            else:
+                rung_base = np.full(n, stream_hash(seed, 7, np.array([b], dtype=np.uint64))[0] & np.uint64(3), dtype=np.uint64)
+            true = np.where(ladder, rung_base, true)
         e = stream_hash(seed, 4, r * np.uint64(length) + np.uint64(b))
         u = e >> np.uint64(11)
         shift = np.uint64(1) + (e & np.uint64(0x7FF)) % np.uint64(3)

@@ -421,6 +421,15 @@ int fqd_synth_keys(fqd_ctx *ctx, uint8_t *out_device, uint64_t n_total, uint64_t
                    uint64_t count, uint32_t length, uint32_t umi, uint64_t seed, uint32_t copies,
                    uint64_t thr_n, uint64_t thr_sub);
 
+/* The same generator with the SKEWED model of fastqdedup_amd/synth.py (SKEW): heavy-tailed molecule abundance
+ * (molecule floor(M x^2)), a share thr_hot / 2^53 of the reads copying ONE molecule, every lowc_every-th molecule
+ * poly-A in the first half of its key, a share thr_ladder / 2^53 of the reads drawn from a ladder of 4^8 keys that
+ * form one connected component -- crowded buckets, a giant component, a key with a million copies (SURVEY.md 7.4
+ * "Skew"; the reference's trie takes any distribution, _triemodule.c:380-495). Bench/test utility. */
+int fqd_synth_keys_skewed(fqd_ctx *ctx, uint8_t *out_device, uint64_t n_total, uint64_t start, uint64_t count,
+                          uint32_t length, uint32_t umi, uint64_t seed, uint32_t copies, uint64_t thr_n,
+                          uint64_t thr_sub, uint64_t thr_hot, uint64_t thr_ladder, uint32_t lowc_every);
+
 /* Achievable HBM bandwidth on this GPU, now: the best of `reps` device-to-device copies of `bytes`
  * bytes by a 16-byte-per-lane copy kernel on the context's stream, read + write counted, in GB/s
  * (MI355X_MICROARCH.md: 6.29 TB/s for a float4 copy). bench.py's `achievable_peak_gbs`. */
