@@ -48,7 +48,7 @@ EXPORTS = [
     "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_set_timing", "fqd_cluster_keys", "fqd_edge_stats", "fqd_synth_keys",
     "fqd_store_add_keys", "fqd_store_remove", "fqd_store_removed_count", "fqd_get_clusters", "fqd_read_clusters",
     "fqd_trie_order", "fqd_trie_stats", "fqd_store_symbol_events", "fqd_get_stream", "fqd_pack_collapse", "fqd_synth_indel_keys", "fqd_copy_bandwidth",
-    "fqd_synth_keys_skewed", "fqd_cluster_subgraph", "fqd_owner_slab_geometry", "fqd_pack_to_owner_slabs", "fqd_collapse_owner_slabs",
+    "fqd_synth_keys_skewed", "fqd_get_route", "fqd_cluster_subgraph", "fqd_owner_slab_geometry", "fqd_pack_to_owner_slabs", "fqd_collapse_owner_slabs",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -127,6 +127,7 @@ def load() -> C.CDLL:
     L.fqd_edge_stats.argtypes = [vp, u64p, u64p, u64p]
     L.fqd_synth_keys.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                  C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]
+    L.fqd_get_route.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.fqd_synth_keys_skewed.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]
     u32p = C.POINTER(C.c_uint32)
@@ -764,6 +765,16 @@ class Context:
         self._ck(self._L.fqd_synth_keys(self._h, out_tensor.data_ptr(), n_total, start, count, length,
                                         umi, seed, copies, rate_threshold(n_rate),
                                         rate_threshold(sub_rate)))
+
+    ROUTE_BITS = {"fused_pack": 0x1, "compact_records": 0x2, "pass0_in_collapse": 0x4, "restarted": 0x8,
+                  "collapse_lds": 0x10, "collapse_pairs": 0x20, "collapse_sort": 0x40, "search_grouped": 0x100,
+                  "search_sort": 0x200, "search_edit": 0x400, "search_retried": 0x800, "pass0_continued": 0x1000}
+
+    def route(self) -> dict:
+        """Which way the last job took (fqd_get_route): {name: bool} over the FQD_ROUTE_* bits."""
+        v = C.c_uint32(0)
+        self._ck(self._L.fqd_get_route(self._h, C.byref(v)))
+        return {k: bool(v.value & b) for k, b in self.ROUTE_BITS.items()}
 
     def synchronize(self):
         self._ck(self._L.fqd_synchronize(self._h))

@@ -134,7 +134,26 @@ def deduplicate_cluster(input_files: List[str], output_files: List[str], check_s
 
     # ---- pass 1 (reference :242-252): the files are streamed in chunks of records; what stays in host
     # memory is the KEYS (and one weight per record), never a whole file
-    key_parts, off_parts, weight_parts = [], [], []
+    # The keys of all chunks go into ONE buffer that grows geometrically (joining per-chunk arrays at the end held
+    # every key twice for a moment: ~30 GB for 50 M reads of 300 nt); offsets are kept only from the chunk on that
+    # proves the keys ragged (fixed-length keys need none: 8 bytes per read saved).
+    class _Grow:
+        def __init__(self, dtype):
+            self.a, self.n = np.empty(1 << 20, dtype=dtype), 0
+
+        def add(self, part):
+            need = self.n + len(part)
+            if need > len(self.a):
+                bigger = np.empty(max(need, len(self.a) * 2), dtype=self.a.dtype)
+                bigger[: self.n] = self.a[: self.n]
+                self.a = bigger
+            self.a[self.n:need] = part
+            self.n = need
+
+        def view(self):
+            return self.a[: self.n]
+
+    key_buf, weight_buf, off_buf = _Grow(np.uint8), _Grow(np.uint32), None
     n, discarded, key_len, key_bytes = 0, 0, None, 0
     for tables, m, _first in fastq.zip_chunks(input_files, chunk_records):
         fastq.check_mates(tables, m)
@@ -144,12 +163,20 @@ def deduplicate_cluster(input_files: List[str], output_files: List[str], check_s
             data = quals if len(quals) else np.zeros(1, dtype=np.uint8)
             w, _, d = ctx.quality_filter(data, None if qual_len else qual_off, qual_len,
                                          threshold=max_average_error_rate, table=SCORE_TO_ERROR_RATE)
-            weight_parts.append(np.asarray(w, dtype=np.uint32))
+            weight_buf.add(np.asarray(w, dtype=np.uint32))
             discarded += d
-        key_parts.append(keys)
-        off_parts.append(key_off[1:].astype(np.uint64) + np.uint64(key_bytes))
-        key_bytes += len(keys)
+        was_fixed = key_len
         key_len = fixed if key_len is None else (key_len if key_len == fixed else 0)
+        if not key_len:
+            if off_buf is None:
+                # ragged from here on: the offsets of the fixed-length chunks before this one are arithmetic
+                off_buf = _Grow(np.uint64)
+                off_buf.add(np.zeros(1, dtype=np.uint64))
+                if n and was_fixed:
+                    off_buf.add(np.arange(1, n + 1, dtype=np.uint64) * np.uint64(was_fixed))
+            off_buf.add(key_off[1:].astype(np.uint64) + np.uint64(key_bytes))
+        key_buf.add(keys)
+        key_bytes += len(keys)
         n += m
     if filter_on_quality:
         logger.info(f"{discarded} records out of {n} "
@@ -158,16 +185,13 @@ def deduplicate_cluster(input_files: List[str], output_files: List[str], check_s
 
     res = None
     if n:
-        keys = key_parts[0] if len(key_parts) == 1 else np.concatenate(key_parts)
-        del key_parts
-        key_off = None
-        if not key_len:
-            key_off = np.concatenate([np.zeros(1, dtype=np.uint64)] + off_parts)
-        del off_parts
-        weights = (weight_parts[0] if len(weight_parts) == 1 else np.concatenate(weight_parts)) if weight_parts else None
+        keys = key_buf.view()
+        key_off = None if key_len else off_buf.view()
+        weights = weight_buf.view() if filter_on_quality else None
         res = cluster_keys(keys, key_off, key_len or 0, weights, max_distance=max_distance,
                            use_edit_distance=use_edit_distance, method=method, context=ctx)
         del keys, key_off, weights
+    del key_buf, weight_buf, off_buf
     n_counted = res.n_counted if res else 0
     logger.info(f"Processed {n_counted} sequences. ({timer.get_difference()})")
     if logger.level <= logging.DEBUG and res is not None and res.n_unique:

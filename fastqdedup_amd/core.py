@@ -71,6 +71,7 @@ class ClusterResult:
     n_clusters: int                    # == pop_cluster calls in the reference loop
     n_kept: int                        # == len(deduplicated_set)
     stage_ms: Dict[str, float]
+    route: Dict[str, bool] = None      # which way the job took through the library (Context.route)
 
 
 def cluster_keys(keys, offsets=None, key_len: int = 0, weights=None, read_ids=None, *,
@@ -98,7 +99,7 @@ def cluster_keys(keys, offsets=None, key_len: int = 0, weights=None, read_ids=No
             ctx.set_kept_output(None)
     ms = ctx.stage_times()[0] if stage_times else {}     # (resolving the event pairs costs ~20 us of host time)
     return ClusterResult(kept, s["n_reads"], s["n_counted"], s["n_unique"], s["n_edges"],
-                         s["n_clusters"], s["n_kept"], ms)
+                         s["n_clusters"], s["n_kept"], ms, ctx.route())
 
 
 # ---------------------------------------------------------------------------

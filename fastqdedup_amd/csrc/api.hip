@@ -391,7 +391,9 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 c->route_off = true;       // (keys crowding on one segment-0 value: whole-key hashing from now on)
             if (overflow || fused->pack_bad)
                 return FQD_OK;
-            // the compaction did search pass 0 unless it met a bucket too large for that or a full probe list
+            // the compaction does search pass 0 -- unless a probe list was full (known now) or it meets a bucket too
+            // large for that (known when the search reads C_P0 with its own counters: the compaction runs behind
+            // this read-back)
             c->pass0_done = fused->p0.mask != 0 && taken_u32(c, 1 + C_P0) == 0 && sho.first == 1;
             c->pass0_nseg = c->pass0_done ? sho.nseg : 0;
             break;
@@ -644,6 +646,14 @@ void fqd_destroy(fqd_ctx *c)
 
 const char *fqd_last_error(const fqd_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
+int fqd_get_route(const fqd_ctx *c, uint32_t *route)
+{
+    if (!c || !route)
+        return FQD_E_VALUE;
+    *route = c->route;
+    return FQD_OK;
+}
+
 int fqd_synchronize(fqd_ctx *c)
 {
     FQD_TRY(bind(c));
@@ -853,6 +863,7 @@ static int collapse_impl(fqd_ctx *c, const uint32_t *weights, int mem, IdSource 
     FQD_TRY(collapse_lds(c, weights ? d_w : nullptr, ids, &lds_done));
     if (lds_done) {
         timer.stop();
+        c->route |= FQD_ROUTE_COLLAPSE_LDS;
         c->collapse_path = 1;
         c->collapsed = true;
         c->first_distinct = true;
@@ -876,6 +887,7 @@ static int collapse_impl(fqd_ctx *c, const uint32_t *weights, int mem, IdSource 
     FQD_TRY(collapse_pairs(c, weights ? d_w : nullptr, ids, &pairs_done));
     if (pairs_done) {
         timer.stop();
+        c->route |= FQD_ROUTE_COLLAPSE_PAIRS;
         c->collapse_path = 3;
         c->collapsed = true;
         c->first_distinct = true;
@@ -886,6 +898,7 @@ static int collapse_impl(fqd_ctx *c, const uint32_t *weights, int mem, IdSource 
         return FQD_OK;
     }
     c->collapse_path = 2;
+    c->route |= FQD_ROUTE_COLLAPSE_SORT;
     const int bits = hash_bits_from_env();
     const uint32_t mask = bits >= 32 ? ~0u : ((1u << bits) - 1u);
     HIP_TRY(c, c->hs_sorted.reserve(n * 4 + 16));
@@ -1091,10 +1104,16 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
             p0.mask = route_mask;
             p0.d = c->seg_hint - 1;
             p0.bucket_bits = B;
+            p0.max_rows = 512;
+            if (const char *e = getenv("FQD_P0_MAX_ROWS"))         // tests: buckets "too large" for pass 0
+                p0.max_rows = (uint32_t)std::max(1, std::min(512, atoi(e)));
             p0.probe = c->p0_probe.as<uint32_t>();
             p0.edges = c->edges.as<uint32_t>();
             p0.edge_count = c->d_ctr64.as<unsigned long long>() + C64_EDGES;
             p0.edge_cap = c->edge_cap;
+            if (const char *e = getenv("FQD_P0_EDGE_CAP"))         // tests: an edge list too short for pass 0's pairs
+                p0.edge_cap = c->edge_cap = std::min<uint64_t>(c->edge_cap, strtoull(e, nullptr, 10));
+            c->pass0_edge_cap = p0.edge_cap;
             p0.flag = c->d_ctr32.as<uint32_t>() + C_P0;
             p0.stats = c->d_stats.as<fqd::PairStats>();
         }
@@ -1166,8 +1185,12 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     if (getenv("FQD_DEBUG"))
         fprintf(stderr, "[fqd] fused pack + collapse: n=%llu parts=%u cap=%u compact=%u done=%d pack_bad=%u fused_off=%d compact_off=%d\n",
                 (unsigned long long)n, parts, cap1, compact, (int)ok, f.pack_bad, (int)c->fused_off, (int)c->compact_off);
-    if (!ok)
+    if (!ok) {
+        c->route |= FQD_ROUTE_RESTARTED;
         return FQD_OK;
+    }
+    c->route |= FQD_ROUTE_FUSED_PACK | FQD_ROUTE_COLLAPSE_LDS | (compact ? FQD_ROUTE_COMPACT_RECORDS : 0u) |
+                (c->pass0_done ? FQD_ROUTE_PASS0_IN_COLLAPSE : 0u);
     c->collapse_path = 1;
     c->collapsed = true;
     c->first_distinct = true;
@@ -1530,6 +1553,7 @@ int fqd_cluster_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, 
     if (max_distance < 0)
         return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
     bool done = false;
+    c->route = 0;
     c->seg_hint = search_segments_hint(max_distance, metric);
     int rc = FQD_OK;
     if (!offsets && !read_ids)

@@ -108,6 +108,7 @@ struct fqd_ctx {
     bool fused_off = false;        // fqd_cluster_keys: a level-1 slab of the fused pack overflowed once -- plain pack from now on
     bool recs_valid = false;       // c->recs holds the packed reads in read order (not after the fused pack)
     bool pairs_slab_off = false;   // long-record collapse: same, for its (hash, position) partition
+    bool search_is_retry = false;       // find_edges calling itself after pass 0's pairs were lost: the route bits stay
     bool search_keeps_edges = false;    // ... except the edge counter and the statistics: pass 0 of this search has run (fqd::Pass0)
     bool search_zero_pending = false;   // find_edges: the job counters and statistics are zeroed by the partition's first launch
     bool gp_slab_off = false;      // grouped search: same, for the (hash, uid) partition
@@ -128,6 +129,7 @@ struct fqd_ctx {
     DevBuf ld_small, ld_part2, ld_matrix, ld_matrix_incl, ld_seg, ld_side, ld_side_table;
     DevBuf ld_hist, ld_hist_incl, ld_start, ld_cursor, ld_part, ld_tmp_rec, ld_tmp_count, ld_tmp_first, ld_unique,
         ld_unique_incl;
+    uint32_t route = 0;     // FQD_ROUTE_* bits of the job in progress / the last one (fqd_get_route)
     int collapse_path = 0;  // 1: LDS bucket dedupe, 2: sort + verify (last fqd_collapse)
     // stage 3
     uint64_t E = 0, edge_cap = 0;
@@ -141,6 +143,7 @@ struct fqd_ctx {
     // routing (many keys share a segment-0 value) -- this context keeps to whole-key hashing.
     bool pass0_done = false, route_off = false;
     uint32_t pass0_nseg = 0;
+    uint64_t pass0_edge_cap = 0;    // the edge list's capacity pass 0 wrote against (pairs behind it were counted, not written)
     DevBuf p0_probe;
     DevBuf gp_a, gp_b, gp_small, gp_cands;   // grouped search pass: items after level 1 / level 2, small tables, candidate pairs
     uint64_t gp_cand_cap = 0;

@@ -474,14 +474,19 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
                             c->pass0_nseg == (uint32_t)max_distance + 1 && seg_hi == (uint32_t)max_distance + 1 &&
                             c->seg_hashes_nseg == c->pass0_nseg && c->seg_hashes_first == 1;
     c->pass0_done = false;
-    if (pass0_held)
+    if (pass0_held) {
         seg_lo = 1;
+        c->route |= FQD_ROUTE_PASS0_CONTINUED;
+    }
+    if (!c->search_is_retry)
+        c->route &= ~(FQD_ROUTE_SEARCH_GROUPED | FQD_ROUTE_SEARCH_SORT | FQD_ROUTE_SEARCH_EDIT | FQD_ROUTE_SEARCH_RETRIED);
     if (!grouped_first && !pass0_held) {
         FQD_TRY(zero_ctr64(c, C64_EDGES));
         HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
     }
     if (edit_general && U >= 2 && (max_distance > 0 || !c->collapsed)) {
         bool grouped_done = false;
+        c->route |= FQD_ROUTE_SEARCH_EDIT;
         if (n_shards == 1 && c->collapsed)
             FQD_TRY(find_edges_edit_grouped(c, (uint32_t)max_distance, &grouped_done));
         if (!grouped_done)
@@ -507,6 +512,8 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
             HIP_TRY(c, c->edges.reserve(c->edge_cap * 8));
         }
         c->edge_cap = c->edges.cap / 8;
+        if (pass0_held)
+            c->edge_cap = std::min<uint64_t>(c->edge_cap, c->pass0_edge_cap);     // (what pass 0 wrote against)
         unsigned long long have = 0;
         if (n_shards > 1) {
             HIP_TRY(c, c->sel_hash.reserve(U * 4 + 16));
@@ -536,6 +543,7 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         const bool fuse_passes = grouped && (seg_lo == 0 || pass0_held) && seg_hi == nseg && n_pass >= 2 && nseg <= 8 &&
                                  (uint64_t)n_pass * U < 0xFFFFFF00ull && !getenv("FQD_GROUP_NO_FUSED_PASSES");
         for (int attempt = 0;; attempt++) {
+            c->route |= (grouped ? FQD_ROUTE_SEARCH_GROUPED : FQD_ROUTE_SEARCH_SORT) | (attempt ? FQD_ROUTE_SEARCH_RETRIED : 0u);
             if (fuse_passes && grouped) {
                 FQD_TRY(grouped_pass(c, c->seg_hashes.as<uint32_t>(), (uint64_t)n_pass * U, d, seg_lo, nseg, (uint32_t)U));
             }
@@ -576,6 +584,8 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
             // the counters come back while the GPU sets up what fqd_cluster runs next on the unique
             // table (nothing of that depends on the edges)
             FQD_TRY(queue_read_ctr64(c, 0, C64_SLAB + 1));
+            if (pass0_held)          // (the compaction raised it AFTER the collapse's own read-back was queued)
+                FQD_TRY(queue_read_u32(c, c->d_ctr32.as<uint32_t>() + C_P0, 0));
             FQD_TRY(queued_reads_mark(c));
             if (c->preinit_method >= 0) {
                 FQD_TRY(fqd_api_graph_preinit(c, c->preinit_method));
@@ -589,7 +599,9 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
                 c->gp_slab_off = true;
                 FQD_TRY(zero_ctr64(c, C64_SLAB));
             }
-            if (!slab_over && now <= c->edge_cap && cand_need <= c->gp_cand_cap) {
+            // pass 0 by the collapse's compaction, found incomplete now: a bucket of more rows than a wave holds
+            const bool pass0_short = pass0_held && taken_u32(c, 0) != 0;
+            if (!slab_over && now <= c->edge_cap && cand_need <= c->gp_cand_cap && !pass0_short) {
                 have = now;
                 break;
             }
@@ -602,10 +614,14 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
             }
             if (pass0_held) {
                 // the pairs of pass 0 are gone with the counters: the whole search once more, every pass here
+                c->route = (c->route & ~FQD_ROUTE_PASS0_CONTINUED) | FQD_ROUTE_SEARCH_RETRIED;
                 c->search_keeps_edges = false;
                 c->seg_hashes_nseg = 0;
                 timer.stop();
-                return find_edges_impl(c, max_distance, metric, shard, n_shards, 0, seg_hi, n_edges);
+                c->search_is_retry = true;
+                const int rc_again = find_edges_impl(c, max_distance, metric, shard, n_shards, 0, seg_hi, n_edges);
+                c->search_is_retry = false;
+                return rc_again;
             }
             if (cand_need > c->gp_cand_cap) {
                 if (cand_need > cand_budget) {
@@ -625,6 +641,7 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
     }
     if (cross_after && U >= 2) {
         bool cross_done = false;
+        c->route |= FQD_ROUTE_SEARCH_EDIT;
         FQD_TRY(find_edges_edit_grouped(c, 1, &cross_done, true, true));
         if (!cross_done) {           // (cannot happen for d = 1 below 2^26 keys; the sorted search redoes everything)
             FQD_TRY(zero_ctr64(c, C64_EDGES));

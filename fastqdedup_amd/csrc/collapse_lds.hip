@@ -740,8 +740,8 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
     const uint32_t begin = group_total ? g_begin : (b ? unique_incl[b - 1] : 0u);
     const uint32_t cnt = group_total ? g_cnt : unique_incl[b] - begin;
     const uint32_t src = bucket_start[b];
-    const bool pass0 = PASS0 && p0.mask != 0 && cnt <= P0_ROWS && cnt > 0;
-    if (p0.mask && cnt > P0_ROWS && lane == 0)
+    const bool pass0 = PASS0 && p0.mask != 0 && cnt <= p0.max_rows && cnt > 0;
+    if (p0.mask && cnt > p0.max_rows && lane == 0)
         atomicOr(p0.flag, 1u);                 // more rows than the wave's LDS holds: the search does pass 0 itself
     // one row -> the unique table (and the segment hashes of the search passes that follow)
     auto write_row = [&](const uint4 &row, uint32_t j) {
@@ -777,9 +777,9 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
     for (uint32_t q = 0; q < RPL; q++)
         row[q] = tmp[src + min(lane + 64 * q, cnt - 1)];
     const uint32_t np = p0.probe_n ? min(p0.probe_n[b], fqd::FQD_P0_PROBE_CAP) : 0u;
-    const uint32_t my_probe = p0.probe_n ? p0.probe[(size_t)b * fqd::FQD_P0_PROBE_CAP + (lane & (fqd::FQD_P0_PROBE_CAP - 1))] : 0u;
+    const uint32_t my_probe = p0.probe_n ? p0.probe[(size_t)b * fqd::FQD_P0_PROBE_CAP + (lane % fqd::FQD_P0_PROBE_CAP)] : 0u;
     uint4 my_probe_rec = make_uint4(0, 0, 0, 0);      // lane l < np: the record of probe l
-    if ((lane & (fqd::FQD_P0_PROBE_CAP - 1)) < np)
+    if (lane < np)
         my_probe_rec = urecs[my_probe];
     const uint32_t sub_shift = 32u - p0.bucket_bits - 6u;
     s_poff[wave][lane] = 0;

@@ -273,12 +273,14 @@ __device__ __forceinline__ uint32_t fqd_route_hash(uint32_t a, uint32_t b, uint3
 // and lie within distance d are found among the bucket's rows while they are in registers -- no (hash, uid) items,
 // no partition, no candidate list, no record gather for that pass. Keys with an N (side path, head of the unique
 // table) are filed in per-bucket probe lists by side_emit_kernel and compared with the bucket's rows there.
-constexpr uint32_t FQD_P0_PROBE_CAP = 16;     // side keys per bucket (more: *flag, the search runs pass 0 itself)
+constexpr uint32_t FQD_P0_PROBE_CAP = 48;     // side keys per bucket (<= 64; more: *flag, the search runs pass 0 itself). The side
+                                              // slabs hold n / 64 keys, ~12 per bucket of 800 reads: 48 is ten sigma above that
 struct PairStats;
 struct Pass0 {
     uint32_t mask = 0;                  // bits of segment 0 in the key word; 0: no pass 0
     uint32_t d = 0;                     // pairs within this distance
     uint32_t bucket_bits = 0;           // bucket of a key = route hash >> (32 - bucket_bits)
+    uint32_t max_rows = 0;              // buckets of more rows than this raise *flag (<= the 512 a wave holds in LDS)
     uint32_t *probe_n = nullptr;        // [n_buckets], zeroed before the side path runs
     uint32_t *probe = nullptr;          // [n_buckets][FQD_P0_PROBE_CAP] uids of side keys
     uint32_t *edges = nullptr;          // (u, v), u < v, appended behind *edge_count

@@ -764,31 +764,37 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void kept_bin_ker
     const uint64_t v0 = (uint64_t)blockIdx.x * TILE;
     const uint64_t last4 = (U - 1) & ~3ull;      // the last group of four (its tail may lie behind the table: the
                                                  // buffers have the slack, the verdicts are masked)
-    // ---- every load of the tile
-    ulonglong2 idv[GROUPS][2];
-    uint32_t st4[GROUPS];
-#pragma unroll
-    for (uint32_t g = 0; g < GROUPS; g++) {
-        const uint64_t vb = min(v0 + ((uint64_t)g * THREADS + tid) * 4, last4);
-        const ulonglong2 *f2 = reinterpret_cast<const ulonglong2 *>(ufirst + vb);
-        idv[g][0] = f2[0];
-        idv[g][1] = f2[1];
-        st4[g] = METHOD == 3 || METHOD == 1 ? *reinterpret_cast<const uint32_t *>(state + vb) : 0u;
-    }
     for (uint32_t b = tid; b < n_bins; b += THREADS)
         s_hist[b] = 0;
     __syncthreads();
     uint32_t off[KB_KPT], rank[KB_KPT];
     uint32_t total = 0, listed_mask = 0;
+    // two halves of GROUPS / 2 groups: the loads of a half are all in flight before its first verdict (all GROUPS at
+    // once needed 66 VGPRs -- two registers too many for two 1024-thread workgroups per CU)
+    constexpr uint32_t HALF = GROUPS >= 2 ? GROUPS / 2 : 1;
 #pragma unroll
-    for (uint32_t g = 0; g < GROUPS; g++) {
+  for (uint32_t g0 = 0; g0 < GROUPS; g0 += HALF) {
+    ulonglong2 idv[HALF][2];
+    uint32_t st4[HALF];
+#pragma unroll
+    for (uint32_t h = 0; h < HALF; h++) {
+        const uint32_t g = g0 + h;
+        const uint64_t vb = min(v0 + ((uint64_t)g * THREADS + tid) * 4, last4);
+        const ulonglong2 *f2 = reinterpret_cast<const ulonglong2 *>(ufirst + vb);
+        idv[h][0] = f2[0];
+        idv[h][1] = f2[1];
+        st4[h] = METHOD == 3 || METHOD == 1 ? *reinterpret_cast<const uint32_t *>(state + vb) : 0u;
+    }
+#pragma unroll
+    for (uint32_t h = 0; h < HALF; h++) {
+        const uint32_t g = g0 + h;
         const uint64_t vg = v0 + ((uint64_t)g * THREADS + tid) * 4, vb = min(vg, last4);
-        const uint64_t id[4] = {idv[g][0].x, idv[g][0].y, idv[g][1].x, idv[g][1].y};
+        const uint64_t id[4] = {idv[h][0].x, idv[h][0].y, idv[h][1].x, idv[h][1].y};
         bool k[4];
         if (METHOD == 3 || METHOD == 1) {
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t st = (st4[g] >> (8 * j)) & 0xFFu;
+                const uint32_t st = (st4[h] >> (8 * j)) & 0xFFu;
                 k[j] = METHOD == 1 ? st == 1 : st == 0;
                 if (METHOD == 3 && (st & 8) && vb + j < U)     // (few) a member of a set of count-1 keys asks its root
                     k[j] = kept_verdict(3, (uint32_t)(vb + j), labels, best, state, ucounts, parent1, root_taint);
@@ -820,6 +826,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void kept_bin_ker
             }
         }
     }
+  }
     __syncthreads();
     // exclusive scan of the bin counts (n_bins <= KB_MAX_BINS: BPT consecutive bins per thread) + one reservation per bin
     uint32_t cnt[BPT], mine = 0;

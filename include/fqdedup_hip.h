@@ -78,6 +78,24 @@ typedef struct fqd_summary {
     uint64_t n_kept;       /* == len(deduplicated_set)                        */
 } fqd_summary;
 
+/* Which way the last job took through the library -- so that a caller can SEE a fast path that stopped engaging
+ * (unusual data sends a call back to the stage-by-stage way: correct, but up to twice the time). Bits of
+ * fqd_get_route(): */
+#define FQD_ROUTE_FUSED_PACK      0x0001u  /* fqd_cluster_keys: the pack kernel wrote level 1 of the collapse itself     */
+#define FQD_ROUTE_COMPACT_RECORDS 0x0002u  /* ... with 12-byte records behind it (keys with an N on the side path)       */
+#define FQD_ROUTE_PASS0_IN_COLLAPSE 0x0004u /* ... reads binned by segment 0, search pass 0 done by the compaction       */
+#define FQD_ROUTE_RESTARTED       0x0008u  /* a fused attempt was abandoned (foreign byte, full slab or LDS table) and the
+                                            * job started over the stage-by-stage way                                    */
+#define FQD_ROUTE_COLLAPSE_LDS    0x0010u  /* collapse: records of one uint4 partitioned and deduplicated in LDS          */
+#define FQD_ROUTE_COLLAPSE_PAIRS  0x0020u  /* collapse: (hash, position) pairs for longer fixed-length records            */
+#define FQD_ROUTE_COLLAPSE_SORT   0x0040u  /* collapse: radix sort + verification (ragged keys, small inputs, overflow)    */
+#define FQD_ROUTE_SEARCH_GROUPED  0x0100u  /* neighbour search: partition + candidates + verification                     */
+#define FQD_ROUTE_SEARCH_SORT     0x0200u  /* neighbour search: radix sort + pair kernel                                   */
+#define FQD_ROUTE_SEARCH_EDIT     0x0400u  /* the Levenshtein search proper ran (grouped or sorted)                        */
+#define FQD_ROUTE_SEARCH_RETRIED  0x0800u  /* the search ran again: an edge / candidate buffer or a slab was too small     */
+#define FQD_ROUTE_PASS0_CONTINUED 0x1000u  /* the search took pass 0 from the collapse and ran the other passes only       */
+int fqd_get_route(const fqd_ctx *ctx, uint32_t *route);
+
 /* Packed-key geometry chosen by fqd_pack_keys (DESIGN.md "data layout"). */
 typedef struct fqd_shape {
     uint32_t planes;       /* bit planes per base: ceil(log2(alphabet size))  */

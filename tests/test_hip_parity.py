@@ -239,6 +239,68 @@ def test_fused_pack_collapse_matches_oracle(F, oracle, monkeypatch, case):
             ctx.collapse()       # the packed reads were never written: needs fqd_pack_keys first
 
 
+@pytest.mark.parametrize("case", ["plain", "n_keys", "d2", "two_planes", "rows_over_512", "table_overflow",
+                                  "probe_overflow", "edge_overflow", "ladder"])
+def test_routed_collapse_does_search_pass_0(F, oracle, monkeypatch, case):
+    """The routed collapse (fqd::Pass0): for a Hamming search behind fqd_cluster_keys the reads are binned by segment 0
+    of the key, and the compaction of a bucket reports the pairs of search pass 0 itself. Against the oracle, with the
+    route the job took (Context.route) asserted -- also where the shortcut must give way: a bucket with more rows than
+    a wave's LDS holds or a full probe list of keys with an N (the search then runs pass 0 too), a bucket with more
+    keys than the dedupe's LDS table (the job starts over with whole-key hashing, and the context stays with it), an
+    edge list too short for pass 0's pairs (the search grows it and runs every pass)."""
+    from fastqdedup_amd.synth import SKEW, fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_FUSED_MIN_READS", "100000")
+    n, L, d = 300_000, 32, 2 if case == "d2" else 1
+    rng = np.random.default_rng(17)
+    keys = synth_keys(n, L, 12, 171, sub_rate=3e-3, n_rate=0 if case == "two_planes" else 1e-3 if case == "n_keys" else 1e-4,
+                      skew=SKEW if case == "ladder" else None)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    if case == "rows_over_512":
+        monkeypatch.setenv("FQD_P0_MAX_ROWS", "150")      # (as if a wave held 150 rows: most buckets have more)
+    if case == "table_overflow":
+        # 5 000 keys sharing segment 0 (their first 16 bases) and nothing else: more than the dedupe's LDS table holds
+        m = 5000
+        rows = rng.choice(n, size=m, replace=False)
+        keys[rows, :16] = keys[rows[0], :16]
+        keys[rows, 16:] = acgt[rng.integers(0, 4, size=(m, 16))]
+    if case == "probe_overflow":
+        # 90 keys with an N in segment 1 that share segment 0: more than a bucket's probe list holds
+        rows = rng.choice(n, size=90, replace=False)
+        keys[rows] = keys[rows[0]]
+        keys[rows, 16 + (np.arange(90) % 16)] = ord("N")
+        keys[rows, 31 - (np.arange(90) % 15)] = acgt[(np.arange(90) // 15) % 4]
+    if case == "edge_overflow":
+        monkeypatch.setenv("FQD_P0_EDGE_CAP", "2000")
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=d, method="directional")
+    ctx = F.Context(0)
+    if case == "two_planes":
+        present = np.zeros(128, dtype=np.uint8)
+        present[[ord(ch) for ch in "ACGT"]] = 1
+        ctx.configure(present, L, False)
+    for job in range(2):
+        got = F.cluster_keys(raw, key_len=L, max_distance=d, method="directional", context=ctx)
+        assert (got.n_unique, got.n_clusters, got.n_kept) == (want["n_unique"], want["n_clusters"],
+                                                              len(want["kept_read_ids"])), (case, job)
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), (case, job)
+        r = got.route
+        if case == "table_overflow":
+            # job 0: the routed attempt overflows a bucket's table and the job starts over; job 1: whole-key hashing
+            assert r["restarted"] == (job == 0) and not r["pass0_in_collapse"] and not r["pass0_continued"]
+            assert r["fused_pack"] == (job == 1)
+        elif case == "probe_overflow":
+            assert r["fused_pack"] and r["compact_records"] and not r["pass0_in_collapse"] and not r["pass0_continued"]
+        elif case in ("edge_overflow", "rows_over_512"):     # (found out by the search: it runs again, every pass)
+            assert r["pass0_in_collapse"] and r["search_retried"] and not r["pass0_continued"]
+        elif case != "ladder":          # (the skewed model's hot key overfills a slab: the job starts over, see below)
+            assert r["fused_pack"] and r["compact_records"] and r["pass0_in_collapse"] and r["pass0_continued"], (case, r)
+            assert r["search_grouped"] and not r["restarted"]
+    # the same keys the stage-by-stage way, on the same context
+    ctx.pack_keys(raw, None, L)
+    two = ctx.cluster(None, None, max_distance=d, method=2)
+    assert (two["n_unique"], two["n_edges"], two["n_kept"]) == (got.n_unique, got.n_edges, got.n_kept)
+
+
 @pytest.mark.parametrize("L,n_rate,d", [(1, 0.0, 0), (7, 1e-3, 1), (16, 0.05, 1), (17, 1e-4, 2), (31, 1e-3, 1),
                                         (32, 0.003, 2), (24, 0.0, 1)])
 def test_compact_records_over_lengths_and_n_rates(F, oracle, monkeypatch, L, n_rate, d):
