@@ -36,6 +36,12 @@ WORKLOADS = {
                          "Hamming d=2, directional"),
     "config5": dict(n=50_000_000, L=300, umi=300, d=1, edit=True, method="adjacency", seed=1005,
                     name="50M paired 2x150-bp reads, key = R1+R2 (300 nt), --edit d=1, adjacency"),
+    # config 3 under the SKEWED model of fastqdedup_amd/synth.py (what real libraries look like): one key
+    # with a million copies, heavy-tailed molecule abundance, 1 % of the molecules poly-A in segment 0 of the key, and
+    # a ladder of 65 536 keys that form ONE connected component
+    "config3_skew": dict(n=50_000_000, L=32, umi=32, d=1, edit=False, method="directional", seed=1003, skew=True,
+                         name="config 3's shape under the skewed model (a key with 1 M copies, heavy-tailed abundance, "
+                              "1 % low-complexity keys sharing a segment, a 65 536-key component), Hamming d=1, directional"),
     # SURVEY.md 8d's variant of configs[4]: 1 % of the reads are one base short or long, so the keys
     # have three lengths and the Levenshtein search proper runs (equal lengths at d=1 reduce to Hamming)
     "config5v": dict(n=50_000_000, L=300, umi=300, d=1, edit=True, method="adjacency", seed=1005, indel_rate=0.01,
@@ -63,14 +69,17 @@ def cpu_baseline(ctx, wl, sample_reads: int):
         dev, dev_off = ctx.synth_indel_keys(n, 0, n, wl["L"], wl["umi"], wl["seed"], indel_rate=wl["indel_rate"])
         host_off = dev_off.cpu().numpy().astype(np.uint64)
     else:
+        from fastqdedup_amd.synth import SKEW
         dev = torch.empty(n * wl["L"], dtype=torch.uint8, device="cuda:0")
-        ctx.synth_keys(dev, n, 0, n, wl["L"], wl["umi"], wl["seed"])
+        ctx.synth_keys(dev, n, 0, n, wl["L"], wl["umi"], wl["seed"], skew=SKEW if wl.get("skew") else None)
     host = dev.cpu().numpy()
     sample = (f"first {n} reads of the same generator (n_total={n}, L={wl['L']}, umi={wl['umi']}, "
               f"seed={wl['seed']}{', indel tail ' + str(wl['indel_rate']) if wl.get('indel_rate') else ''}), "
               f"d={wl['d']}, {'edit' if wl['edit'] else 'hamming'}, {wl['method']}")
     cores = 1
-    if O.reference_available():
+    # (the skewed model's 65 536-key component: the reference's dissection loops are quadratic PYTHON loops over a
+    # cluster, __init__.py:60-122 -- hours; the oracle's C restatement of the same loops is timed instead)
+    if O.reference_available() and not wl.get("skew"):
         from oracle import ref_driver
         if host_off is not None:
             raw = host.tobytes()
@@ -265,8 +274,9 @@ def main():
         keys, key_offsets = ctx.synth_indel_keys(n_total, rank * n, n, L, wl["umi"], wl["seed"],
                                                  indel_rate=wl["indel_rate"])
     else:
+        from fastqdedup_amd.synth import SKEW
         keys = torch.empty(n * L, dtype=torch.uint8, device=device)
-        ctx.synth_keys(keys, n_total, rank * n, n, L, wl["umi"], wl["seed"])
+        ctx.synth_keys(keys, n_total, rank * n, n, L, wl["umi"], wl["seed"], skew=SKEW if wl.get("skew") else None)
     kept_buf = torch.empty(n, dtype=torch.int64, device=device)
     backend = HipBackend(ctx, device) if sharded else None
 
@@ -475,6 +485,7 @@ def main():
         "roofline": roofline,
         "job_roofline": job_roofline,
         "kernels": kernels,
+        "route": getattr(res, "route", None),
         "kernel_timers": {"timed_steps": args.kernel_timers, "dominant": dominant_name,
                           "note": "HIP event pairs around every kernel launch stop the stream at each record (~0.12 ms of "
                                   "a config-3 step): the timed steps carry the pair of the dominant kernel only -- "
@@ -486,7 +497,7 @@ def main():
         out["sharded_phases_ms_rank0"] = phases
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(ctx, wl, args.cpu_sample or (4_000_000 if L <= 100 else 1_000_000))
+            out["cpu_baseline"] = cpu_baseline(ctx, wl, args.cpu_sample or (1_000_000 if L > 100 or wl.get("skew") else 4_000_000))
         except Exception as exc:  # the GPU numbers stand on their own
             out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:

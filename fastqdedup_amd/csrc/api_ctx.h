@@ -108,6 +108,10 @@ struct fqd_ctx {
     bool fused_off = false;        // fqd_cluster_keys: a level-1 slab of the fused pack overflowed once -- plain pack from now on
     bool recs_valid = false;       // c->recs holds the packed reads in read order (not after the fused pack)
     bool pairs_slab_off = false;   // long-record collapse: same, for its (hash, position) partition
+    // crowded buckets of a distance-1 search (group.hip): flags + list + counters, the fine items, the seen marks
+    DevBuf gp_crowded, gp_fine_hash, gp_fine_val, gp_seen;
+    const uint32_t *gp_last_items = nullptr;   // the partitioned items of the last grouped pass
+    uint32_t gp_crowded_bits = 0;      // != 0: the last grouped pass marked crowded buckets (2^bits buckets) and skipped them
     bool search_is_retry = false;       // find_edges calling itself after pass 0's pairs were lost: the route bits stay
     bool search_keeps_edges = false;    // ... except the edge counter and the statistics: pass 0 of this search has run (fqd::Pass0)
     bool search_zero_pending = false;   // find_edges: the job counters and statistics are zeroed by the partition's first launch

@@ -415,14 +415,91 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
     }
     c->gp_cand_cap = c->gp_cands.cap / 8;
     unsigned long long *ctr = c->d_ctr64.as<unsigned long long>();
+    // Distance 1, every pass in this one partition, exact bucket sizes (a context whose slabs have overflowed before:
+    // data with crowded segment values): buckets of more than 1024 items are marked and SKIPPED here -- all their keys
+    // are pairwise candidates -- and grouped_refine() below matches those keys on finer segments.
+    const uint8_t *skip = nullptr;
+    c->gp_crowded_bits = 0;
+    c->gp_last_items = items;
+    if (d == 1 && fused_U && s == 0 && nseg == 2 && !bucket_end && fused_U < (1u << 28) && !getenv("FQD_GROUP_NO_REFINE")) {
+        HIP_TRY(c, c->gp_crowded.reserve((size_t)n_buckets * 5 + 64));
+        uint8_t *flags = c->gp_crowded.as<uint8_t>();
+        uint32_t *list = reinterpret_cast<uint32_t *>(flags + (((size_t)n_buckets + 63) & ~(size_t)63));
+        unsigned long long *counts = reinterpret_cast<unsigned long long *>(list + n_buckets);
+        HIP_TRY(c, hipMemsetAsync(counts, 0, 32, c->st));
+        uint32_t limit = 1024;
+        if (const char *e = getenv("FQD_GROUP_CROWDED_LIMIT"))
+            limit = (uint32_t)std::max(2, atoi(e));
+        HIP_TRY(c, fqd::launch_group_mark_crowded(c->ld_start.as<uint32_t>(), bucket_end, n_buckets, limit, flags, list, counts,
+                                                  c->st));
+        skip = flags;
+        c->gp_crowded_bits = B;
+    }
     KTIME(c, FQD_K_PAIRS, fqd::launch_grouped_candidates(items, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, B,
                                                          c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,
-                                                         c->st));
+                                                         c->st, 0, skip));
     KTIME(c, FQD_K_VERIFY, fqd::launch_verify_candidates(c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,
                                                          c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, s, nseg,
                                                          c->edges.as<uint32_t>(), ctr + C64_EDGES, c->edge_cap,
                                                          ctr + C64_CAND_NEED, c->d_stats.as<fqd::PairStats>(), c->st,
                                                          fused_U));
+    return FQD_OK;
+}
+
+// Behind a grouped_pass that marked crowded buckets: their keys are matched on finer segments (group.hip "crowded
+// buckets"). One host round trip to learn whether there are any (only contexts that met crowded data get here).
+// *ok = false: more crowded keys than the fine-item buffers hold -- the caller searches again the plain way.
+static int grouped_refine(fqd_ctx *c, const uint32_t *seg_hashes, uint64_t U, uint32_t nseg, bool *ok)
+{
+    *ok = true;
+    const uint32_t B = c->gp_crowded_bits, n_buckets = 1u << B;
+    c->gp_crowded_bits = 0;
+    const KeyShape sh = c->ks;
+    uint8_t *flags = c->gp_crowded.as<uint8_t>();
+    uint32_t *list = reinterpret_cast<uint32_t *>(flags + (((size_t)n_buckets + 63) & ~(size_t)63));
+    unsigned long long *counts = reinterpret_cast<unsigned long long *>(list + n_buckets);
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(h, counts, 16, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, stream_wait(c->st));
+    if (!h[0])
+        return FQD_OK;
+    const uint32_t pieces = fqd::group_fine_pieces();
+    const uint64_t key_cap = std::min<uint64_t>(h[1], U);          // (every crowded item could be a key of its own)
+    if (key_cap * pieces >= 0xFFFFFF00ull) {
+        *ok = false;
+        return FQD_OK;
+    }
+    HIP_TRY(c, c->gp_fine_hash.reserve(key_cap * pieces * 4 + 16));
+    HIP_TRY(c, c->gp_fine_val.reserve(key_cap * pieces * 4 + 16));
+    HIP_TRY(c, c->gp_seen.reserve(U / 8 + 64));          // one bit per key
+    HIP_TRY(c, hipMemsetAsync(c->gp_seen.p, 0, U / 8 + 16, c->st));
+    const uint32_t *items = c->gp_last_items;
+    HIP_TRY(c, fqd::launch_group_refine_items(items, c->ld_start.as<uint32_t>(), nullptr, list, counts, (uint32_t)U,
+                                              c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, c->gp_seen.as<uint32_t>(),
+                                              c->gp_fine_hash.as<uint32_t>(), c->gp_fine_val.as<uint32_t>(), counts + 2,
+                                              key_cap, c->st));
+    HIP_TRY(c, hipMemcpyAsync(h, counts, 24, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, stream_wait(c->st));
+    const uint64_t n_keys = std::min<uint64_t>(h[2], key_cap), N = n_keys * pieces;
+    if (getenv("FQD_DEBUG"))
+        fprintf(stderr, "[fqd] crowded buckets: %llu with %llu items -> %llu keys matched on %u finer segments\n", h[0], h[1],
+                (unsigned long long)n_keys, pieces);
+    if (N < 2)
+        return FQD_OK;
+    uint32_t B2 = 8;
+    while (B2 < 20 && (N >> B2) > 320u)
+        B2++;
+    const uint32_t *items2 = nullptr, *bucket_end2 = nullptr;
+    FQD_TRY(fqd_api_partition_pairs(c, c->gp_fine_hash.as<uint32_t>(), N, B2, false, &items2, &bucket_end2,
+                                    c->gp_fine_val.as<uint32_t>()));
+    unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(c->gp_small.as<uint32_t>() + 4096);
+    unsigned long long *ctr = c->d_ctr64.as<unsigned long long>();
+    HIP_TRY(c, fqd::launch_grouped_candidates(items2, c->ld_start.as<uint32_t>(), bucket_end2, 1u << B2, B2,
+                                              c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap, c->st));
+    HIP_TRY(c, fqd::launch_group_verify_refined(c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap, c->urecs.as<uint32_t>(),
+                                                c->ulens.as<uint32_t>(), sh, nseg, seg_hashes, U, B, flags,
+                                                c->edges.as<uint32_t>(), ctr + C64_EDGES, c->edge_cap, ctr + C64_CAND_NEED,
+                                                c->st));
     return FQD_OK;
 }
 
@@ -546,6 +623,12 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
             c->route |= (grouped ? FQD_ROUTE_SEARCH_GROUPED : FQD_ROUTE_SEARCH_SORT) | (attempt ? FQD_ROUTE_SEARCH_RETRIED : 0u);
             if (fuse_passes && grouped) {
                 FQD_TRY(grouped_pass(c, c->seg_hashes.as<uint32_t>(), (uint64_t)n_pass * U, d, seg_lo, nseg, (uint32_t)U));
+                if (c->gp_crowded_bits) {
+                    bool refined = true;
+                    FQD_TRY(grouped_refine(c, c->seg_hashes.as<uint32_t>(), U, nseg, &refined));
+                    if (!refined)
+                        return fail(c, FQD_E_RUNTIME, "too many keys in crowded buckets for the fine items");
+                }
             }
             for (uint32_t s = seg_lo; s < seg_hi && !(fuse_passes && grouped); s++) {
                 const uint32_t *pass_hashes = c->seg_hashes.as<uint32_t>() + (size_t)(s - seg_lo) * U;

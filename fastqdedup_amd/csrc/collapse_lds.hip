@@ -47,6 +47,7 @@ namespace {
 constexpr uint32_t DD_SLOTS = 1024;        // LDS table slots per bucket (power of two)
 constexpr uint32_t DD_THREADS = 256;
 constexpr uint32_t DD_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t DD_HUGE = 16384;       // reads of a bucket from which on a wave merges its equal records first
 
 // The partition itself (tiles, LDS counting sort, count matrix) is partition.cuh; here is what a
 // 16-byte record looks like to it. LEVEL 1 reads the packed reads and stamps the read index into
@@ -275,6 +276,35 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe_kernel(
           slot[k] = (tag[k] * 0x9E3779B1u) >> 22;  // top 10 bits of a re-mix: DD_SLOTS == 1024
           probes[k] = 0;
           pending[k] = base0 + k * DD_THREADS + tid < hi;
+      }
+      // A HUGE bucket is a key with very many copies (its reads all hash here): the 64 records a wave holds are then
+      // mostly ONE key, and 64 lanes adding to one LDS slot take turns -- one workgroup needed 4.4 ms for a key with
+      // 10^6 copies. There the wave first merges its equal records: the first lane of a key keeps it with the summed
+      // weight and the smallest read index, the others drop out. (A loop per DISTINCT key of the wave: not for
+      // ordinary buckets, whose 64 records are 64 keys.)
+      if (hi - lo > DD_HUGE) {
+#pragma unroll
+          for (uint32_t k = 0; k < DD_AHEAD; k++) {
+              unsigned long long left = __ballot(pending[k]);
+              while (left) {
+                  const int lead = __ffsll((long long)left) - 1;
+                  const uint32_t kx = __shfl(ahead[k].x, lead), ky = __shfl(ahead[k].y, lead), kz = __shfl(ahead[k].z, lead);
+                  const bool mine = pending[k] && ahead[k].x == kx && ahead[k].y == ky && ahead[k].z == kz;
+                  const unsigned long long grp = __ballot(mine);
+                  uint32_t w_sum = mine ? ahead_w[k] : 0u, id_min = mine ? ahead[k].w : 0xFFFFFFFFu;
+                  for (int o = 32; o; o >>= 1) {
+                      w_sum += __shfl_xor(w_sum, o);
+                      id_min = min(id_min, (uint32_t)__shfl_xor(id_min, o));
+                  }
+                  if ((int)lane == lead) {
+                      ahead_w[k] = w_sum;
+                      ahead[k].w = id_min;
+                  } else if (mine) {
+                      pending[k] = false;
+                  }
+                  left &= ~grp;
+              }
+          }
       }
       bool any;
       do {

@@ -491,7 +491,24 @@ hipError_t launch_group_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *
 hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                      uint32_t n_buckets, uint32_t bucket_bits, uint64_t *cands,
                                      unsigned long long *cand_count, uint64_t cand_cap, hipStream_t st,
-                                     uint32_t require_any = 0 /* list only pairs with one of these bits in a value */);
+                                     uint32_t require_any = 0 /* list only pairs with one of these bits in a value */,
+                                     const uint8_t *skip = nullptr /* skip[b] != 0: bucket b is left out */);
+// crowded buckets of a distance-1 search (group.hip "crowded buckets"): marked, skipped by the candidate kernel, their
+// keys matched on finer segments
+uint32_t group_fine_pieces();
+hipError_t launch_group_mark_crowded(const uint32_t *bucket_start, const uint32_t *bucket_end, uint32_t n_buckets,
+                                     uint32_t limit, uint8_t *crowded, uint32_t *list, unsigned long long *counts,
+                                     hipStream_t st);
+hipError_t launch_group_refine_items(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                     const uint32_t *list, const unsigned long long *counts, uint32_t fused_U,
+                                     const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t *seen,
+                                     uint32_t *out_hash, uint32_t *out_val, unsigned long long *n_keys, uint64_t key_cap,
+                                     hipStream_t st);
+hipError_t launch_group_verify_refined(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
+                                       const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t nseg,
+                                       const uint32_t *seg_hashes, uint64_t U, uint32_t bucket_bits,
+                                       const uint8_t *crowded, uint32_t *edges, unsigned long long *edge_count,
+                                       uint64_t edge_cap, unsigned long long *cand_need, hipStream_t st);
 hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
                                     const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d, uint32_t seg,
                                     uint32_t nseg, uint32_t *edges, unsigned long long *edge_count, uint64_t edge_cap,

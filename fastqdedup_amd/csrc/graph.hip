@@ -59,13 +59,23 @@ __global__ void uf_init_kernel(uint32_t *parent, uint64_t U)
         parent[i] = (uint32_t)i;
 }
 
+// FRESH = false: the walk reads through the CU's vector cache (plain loads). A stale parent is still an ancestor --
+// every value a node's parent ever had is one -- so a cached walk ends at a node that WAS a root; whether it still is
+// one is the hooking compare-and-swap's business (it fails, and the caller walks again with FRESH loads, which read
+// the L2 and guarantee progress). With device-scope loads all the way, every find of a giant component (65 536 keys,
+// 786 K edges in the skewed workload) read the one line holding the component's root from its L2 channel: 3 ms.
+template <bool FRESH = true>
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
 {
-    uint32_t p = load_relaxed(&parent[x]);
+    uint32_t p = FRESH ? load_relaxed(&parent[x]) : parent[x];
     while (p != x) {
-        const uint32_t g = load_relaxed(&parent[p]);
+        const uint32_t g = FRESH ? load_relaxed(&parent[p]) : parent[p];
+        // path halving by a plain (relaxed) store: g is an ancestor of x whatever other threads have written to
+        // parent[x] meanwhile (a root is never un-rooted except by hooking it under a smaller node, and every value
+        // ever stored is an ancestor), so the worst a lost race does is keep a longer path. An atomicMin here put
+        // one read-modify-write per step on the few lines at the top of a giant component's tree.
         if (g != p)
-            atomicMin(&parent[x], g);  // path halving; parents only ever decrease
+            __hip_atomic_store(&parent[x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x = p;
         p = g;
     }
@@ -84,7 +94,8 @@ __global__ void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ e
         uint32_t a = uv.x, b = uv.y;
         // the first parent of both ends in flight together (most ends are still their own roots: the two
         // dependent round trips of find(a); find(b) become one)
-        const uint32_t pa = load_relaxed(&parent[a]), pb = load_relaxed(&parent[b]);
+        // (cached loads, like the first walk below: a stale "is its own root" only makes the compare-and-swap fail)
+        const uint32_t pa = parent[a], pb = parent[b];
         if (pa == a && pb == b && a != b) {
             const uint32_t lo = min(a, b), hi = max(a, b);
             if (atomicCAS(&parent[hi], hi, lo) == hi) {
@@ -92,9 +103,10 @@ __global__ void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ e
                 a = b = lo;          // done
             }
         }
-        for (; a != b;) {
-            a = uf_find(parent, a);
-            b = uf_find(parent, b);
+        for (bool fresh = false; a != b; fresh = true) {
+            // the first walk through the CU's cache (see uf_find): a common ancestor found there IS one
+            a = fresh ? uf_find<true>(parent, a) : uf_find<false>(parent, a);
+            b = fresh ? uf_find<true>(parent, b) : uf_find<false>(parent, b);
             if (a == b)
                 break;
             if (a > b) {
@@ -397,9 +409,9 @@ __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *
         const uint32_t u = uu[t], v = vv[t];
         if (cu[t] == 1 && cv[t] == 1) {
             uint32_t a = u, b = v;
-            for (;;) {
-                a = uf_find(parent1, a);
-                b = uf_find(parent1, b);
+            for (bool fresh = false;; fresh = true) {
+                a = fresh ? uf_find<true>(parent1, a) : uf_find<false>(parent1, a);
+                b = fresh ? uf_find<true>(parent1, b) : uf_find<false>(parent1, b);
                 if (a == b)
                     break;
                 if (a > b) {
@@ -413,14 +425,16 @@ __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *
             rank[t] = atomicAdd(&s_n, 1u);
             continue;
         }
+        // (a store only where the byte does not say so yet, as far as this CU's cache knows: the 786 K edges of a
+        // 65 536-key component are 1.5 M byte stores into 64 KB otherwise, queueing on the same lines)
         const long long lu = cu[t], lv = cv[t];
-        if (lv >= 2 && 2 * lv - 1 <= lu)
+        if (lv >= 2 && 2 * lv - 1 <= lu && state[v] != 2)
             state[v] = 2;          // arc u -> v from a key of larger count
-        if (lu >= 2 && 2 * lu - 1 <= lv)
+        if (lu >= 2 && 2 * lu - 1 <= lv && state[u] != 2)
             state[u] = 2;
-        if (lu == 1)
+        if (lu == 1 && state[u] != 3)
             state[u] = 3;          // here cv >= 2: v reaches u and outranks all of u's count-1 set
-        if (lv == 1)
+        if (lv == 1 && state[v] != 3)
             state[v] = 3;
     }
     __syncthreads();

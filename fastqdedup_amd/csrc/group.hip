@@ -241,6 +241,8 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
     const uint2 *__restrict__ items, const uint32_t *__restrict__ bucket_start,
     const uint32_t *__restrict__ bucket_end /* NULL, or slab mode: where each bucket's cursor stopped */,
     uint32_t n_buckets, uint32_t sub_shift, uint2 *__restrict__ cands_all, unsigned long long *__restrict__ cand_counts, uint64_t list_cap,
+    const uint8_t *__restrict__ skip /* NULL, or skip[b] != 0: bucket b is CROWDED -- its keys are matched on finer
+                                      * segments instead (gp_refine_items_kernel) */,
     uint32_t require_any /* != 0: only pairs one of whose values has one of these bits are listed (the Levenshtein
                           * search for pairs of DIFFERENT lengths: a pair of two index items is a pair of one length,
                           * which the Hamming passes have found already -- 11 M of 11.2 M candidates at config 5's
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
         if (bucket_end)
             hi = min(hi, bucket_end[b]);
         const uint32_t m = hi - lo;
-        if (m < 2)
+        if (m < 2 || (skip && skip[b]))
             continue;
         const uint2 *bucket = items + lo;
         const uint32_t m_lds = m < GP_SLICE ? m : GP_SLICE;
@@ -651,6 +653,138 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
     }
 }
 
+
+// ---- crowded buckets: a segment value shared by thousands of keys (low-complexity sequence, a constant prefix, a
+// family of keys that differ in a few positions) makes all of them pairwise candidates -- quadratic, and one wave's
+// work. For distance 1 such keys are matched on FINER segments instead: the key is cut into GP_FINE pieces, a key
+// files one item per piece j, hashed over the whole key with piece j masked out; two keys at distance exactly 1
+// differ inside one piece j* and meet in the items of j* only -- groups are as small as "keys equal outside one
+// piece", every pair is proposed once. The verification keeps a pair iff the FIRST main segment it agrees on falls
+// into a crowded bucket (else the main pass of that segment has reported it).
+constexpr uint32_t GP_FINE = 8;
+
+__global__ void gp_mark_crowded_kernel(const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ bucket_end,
+                                       uint32_t n_buckets, uint32_t limit, uint8_t *__restrict__ crowded,
+                                       uint32_t *__restrict__ list, unsigned long long *__restrict__ counts /* buckets, items */)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_buckets)
+        return;
+    uint32_t hi = bucket_start[b + 1];
+    if (bucket_end)
+        hi = min(hi, bucket_end[b]);
+    const uint32_t m = hi - bucket_start[b];
+    const bool big = m > limit;
+    crowded[b] = big ? 1 : 0;
+    if (big) {
+        list[atomicAdd(&counts[0], 1ull)] = b;
+        atomicAdd(&counts[1], (unsigned long long)m);
+    }
+}
+
+// the hash of a key with piece j of GP_FINE masked out
+__device__ __forceinline__ uint32_t gp_fine_hash(const uint32_t *__restrict__ rec, uint32_t K, uint32_t W, uint32_t len,
+                                                 uint32_t j)
+{
+    const uint32_t lo = len * j / GP_FINE, hi = len * (j + 1) / GP_FINE;
+    uint32_t part = 0;
+    for (uint32_t w = 0; w < W; w++) {
+        const uint32_t keep = ~fqd_range_mask(w, lo, hi);
+        for (uint32_t k = 0; k < K; k++)
+            part += fqd_mix32((rec[w * K + k] & keep) + (w * K + k + 1u) * 0x9E3779B1u);
+    }
+    return fqd_mix32(part + fqd_mix32(len * 0x9E3779B1u + j * 0x85EBCA77u + 0x27D4EB2Fu));
+}
+
+// every key with an item in a crowded bucket files its GP_FINE fine items (once: seen[uid])
+__global__ __launch_bounds__(256) void gp_refine_items_kernel(
+    const uint2 *__restrict__ items, const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ bucket_end,
+    const uint32_t *__restrict__ list, const unsigned long long *__restrict__ counts, uint32_t fused_U,
+    const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t *__restrict__ seen,
+    uint32_t *__restrict__ out_hash, uint32_t *__restrict__ out_val, unsigned long long *__restrict__ n_keys, uint64_t key_cap)
+{
+    // (every workgroup walks the whole list and takes its share of each bucket's items: there may be ONE crowded
+    // bucket with a hundred thousand items)
+    const uint32_t n_list = (uint32_t)counts[0];
+    for (uint32_t li = 0; li < n_list; li++) {
+        const uint32_t b = list[li], lo = bucket_start[b];
+        uint32_t hi = bucket_start[b + 1];
+        if (bucket_end)
+            hi = min(hi, bucket_end[b]);
+        for (uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) {
+            uint32_t uid = items[i].y;
+            if (fused_U)
+                uid %= fused_U;
+            if (atomicOr(&seen[uid >> 5], 1u << (uid & 31u)) & (1u << (uid & 31u)))
+                continue;                              // (a key crowded in both passes files its items once)
+            const unsigned long long at = atomicAdd(n_keys, 1ull);
+            if (at >= key_cap)
+                continue;
+            const uint32_t *rec = urecs + (uint64_t)uid * sh.stride;
+            const uint32_t len = fqd_key_len(sh, ulens, uid);
+            for (uint32_t j = 0; j < GP_FINE; j++) {
+                out_hash[at * GP_FINE + j] = gp_fine_hash(rec, sh.planes, sh.words, len, j);
+                out_val[at * GP_FINE + j] = uid | (j << 28);
+            }
+        }
+    }
+}
+
+// candidates of the fine items -> edges. One thread per candidate (they are few).
+__global__ __launch_bounds__(256) void gp_verify_refined_kernel(
+    const uint2 *__restrict__ cands, const unsigned long long *__restrict__ cand_count, uint64_t cand_cap,
+    const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t nseg,
+    const uint32_t *__restrict__ seg_hashes /* [nseg][U] */, uint64_t U, uint32_t bucket_bits,
+    const uint8_t *__restrict__ crowded, uint32_t *__restrict__ edges, unsigned long long *__restrict__ edge_count,
+    uint64_t edge_cap, unsigned long long *__restrict__ cand_need)
+{
+    const uint32_t list = blockIdx.x % GP_LISTS, part = blockIdx.x / GP_LISTS, parts = gridDim.x / GP_LISTS;
+    const unsigned long long filled = cand_count[(size_t)list * 8];
+    const unsigned long long total = filled < cand_cap ? filled : cand_cap;
+    if (part == 0 && threadIdx.x == 0 && filled > cand_cap)
+        atomicMax(cand_need, filled * GP_LISTS);
+    cands += (size_t)list * cand_cap;
+    for (unsigned long long idx = (unsigned long long)part * blockDim.x + threadIdx.x; idx < total;
+         idx += (unsigned long long)parts * blockDim.x) {
+        const uint2 pr = cands[idx];
+        const uint32_t ja = pr.x >> 28, jb = pr.y >> 28, ua = pr.x & 0x0FFFFFFFu, ub = pr.y & 0x0FFFFFFFu;
+        if (ja != jb || ua == ub)
+            continue;
+        const uint32_t len = fqd_key_len(sh, ulens, ua);
+        if (fqd_key_len(sh, ulens, ub) != len)
+            continue;
+        const uint32_t *ra = urecs + (uint64_t)ua * sh.stride, *rb = urecs + (uint64_t)ub * sh.stride;
+        uint32_t dist = 0, pos = 0;
+        for (uint32_t w = 0; w < sh.words && dist <= 1; w++) {
+            uint32_t dw = 0;
+            for (uint32_t k = 0; k < sh.planes; k++)
+                dw |= ra[w * sh.planes + k] ^ rb[w * sh.planes + k];
+            if (dw) {
+                dist += __popc(dw);
+                pos = w * 32u + (uint32_t)(__ffs((int)dw) - 1);
+            }
+        }
+        if (dist != 1)
+            continue;
+        // the one differing position must lie in the piece both items left out (else: a hash collision)
+        if (!(pos >= len * ja / GP_FINE && pos < len * (ja + 1) / GP_FINE))
+            continue;
+        // the first main segment the pair agrees on: segment 0 unless the difference lies there
+        uint32_t slo, shi;
+        fqd_segment(len, 0, nseg, slo, shi);
+        const uint32_t first = (pos >= slo && pos < shi) ? 1u : 0u;
+        if (first >= nseg)
+            continue;                                  // (nseg == 1: no segment agrees)
+        if (!crowded[seg_hashes[(size_t)first * U + ua] >> (32u - bucket_bits)])
+            continue;                                  // the main pass of that segment has it
+        const unsigned long long at = atomicAdd(edge_count, 1ull);
+        if (at < edge_cap) {
+            edges[2 * at] = min(ua, ub);
+            edges[2 * at + 1] = max(ua, ub);
+        }
+    }
+}
+
 }  // namespace
 
 namespace fqd {
@@ -748,7 +882,7 @@ hipError_t launch_group_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *
 hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                      uint32_t n_buckets, uint32_t bucket_bits, uint64_t *cands,
                                      unsigned long long *cand_count, uint64_t cand_cap, hipStream_t st,
-                                     uint32_t require_any)
+                                     uint32_t require_any, const uint8_t *skip)
 {
     if (!n_buckets)
         return hipSuccess;
@@ -758,7 +892,7 @@ hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *buck
     const unsigned grid = blocks < 8192 ? blocks : 8192;
     grouped_candidates_kernel<<<grid, GP_THREADS, 0, st>>>(reinterpret_cast<const uint2 *>(items), bucket_start,
                                                            bucket_end, n_buckets, sub_shift, reinterpret_cast<uint2 *>(cands),
-                                                           cand_count, cand_cap / GP_LISTS, require_any);
+                                                           cand_count, cand_cap / GP_LISTS, skip, require_any);
     return hipGetLastError();
 }
 
@@ -796,6 +930,41 @@ hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long l
         return hipErrorInvalidValue;
     }
 #undef FQD_GP_CASE
+    return hipGetLastError();
+}
+
+uint32_t group_fine_pieces() { return GP_FINE; }
+
+hipError_t launch_group_mark_crowded(const uint32_t *bucket_start, const uint32_t *bucket_end, uint32_t n_buckets,
+                                     uint32_t limit, uint8_t *crowded, uint32_t *list, unsigned long long *counts,
+                                     hipStream_t st)
+{
+    gp_mark_crowded_kernel<<<(n_buckets + 255) / 256, 256, 0, st>>>(bucket_start, bucket_end, n_buckets, limit, crowded,
+                                                                    list, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_refine_items(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                     const uint32_t *list, const unsigned long long *counts, uint32_t fused_U,
+                                     const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t *seen,
+                                     uint32_t *out_hash, uint32_t *out_val, unsigned long long *n_keys, uint64_t key_cap,
+                                     hipStream_t st)
+{
+    gp_refine_items_kernel<<<1024, 256, 0, st>>>(reinterpret_cast<const uint2 *>(items), bucket_start, bucket_end, list,
+                                                 counts, fused_U, urecs, ulens, sh, seen, out_hash, out_val, n_keys,
+                                                 key_cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_verify_refined(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
+                                       const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t nseg,
+                                       const uint32_t *seg_hashes, uint64_t U, uint32_t bucket_bits,
+                                       const uint8_t *crowded, uint32_t *edges, unsigned long long *edge_count,
+                                       uint64_t edge_cap, unsigned long long *cand_need, hipStream_t st)
+{
+    gp_verify_refined_kernel<<<GP_LISTS * 16, 256, 0, st>>>(reinterpret_cast<const uint2 *>(cands), cand_count,
+                                                            cand_cap / GP_LISTS, urecs, ulens, sh, nseg, seg_hashes, U,
+                                                            bucket_bits, crowded, edges, edge_count, edge_cap, cand_need);
     return hipGetLastError();
 }
 

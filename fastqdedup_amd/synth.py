@@ -55,6 +55,9 @@ def rate_threshold(p: float) -> int:
 #   * a share ``ladder`` of the reads draws from a LADDER of 4^8 keys: one random prefix followed by every value of
 #     the last eight bases -- 65 536 keys, each with 24 neighbours at Hamming distance 1, ONE connected component.
 SKEW = {"hot": 0.02, "ladder": 0.01, "lowc_every": 100}
+if __import__("os").environ.get("FQD_SKEW"):       # experiments: FQD_SKEW="hot=0.02,ladder=0,lowc_every=0"
+    SKEW = {k: (int(v) if k == "lowc_every" else float(v))
+            for k, v in (kv.split("=") for kv in __import__("os").environ["FQD_SKEW"].split(","))}
 
 
 def synth_keys(n: int, length: int, umi: int, seed: int, *, copies: int = 4,

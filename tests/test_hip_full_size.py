@@ -69,7 +69,10 @@ def test_timed_configuration_matches_oracle_at_full_size(full_size, name, monkey
     times = ctx.kernel_times(reset=True)
     if name == "config3":
         # the route bench.py times: pack fused with level 1 (no level-1 scatter launch), 12-byte records through
-        # level 2 and the LDS dedupe (the keys with an N -- 160 K of 50 M reads -- through the side path)
+        # level 2 and the LDS dedupe (the keys with an N -- 160 K of 50 M reads -- through the side path), the reads
+        # binned by segment 0 and search pass 0 done by the compaction
+        assert got.route["fused_pack"] and got.route["compact_records"] and got.route["pass0_in_collapse"], got.route
+        assert got.route["pass0_continued"] and not got.route["restarted"] and not got.route["search_retried"], got.route
         assert times["pack_kernel"][1] and not times["part_scatter_kernel<1>"][1], times
         assert times["part_scatter12_kernel"][1] and times["bucket_dedupe12_kernel"][1], times
         assert not times["part_scatter_kernel<2>"][1] and not times["bucket_dedupe_kernel"][1], times
@@ -79,3 +82,33 @@ def test_timed_configuration_matches_oracle_at_full_size(full_size, name, monkey
     assert got.n_clusters == want["n_clusters"]
     assert got.n_kept == len(want["kept_read_ids"])
     assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+
+
+def test_skewed_workload_matches_oracle(oracle):
+    """SURVEY.md 7.4 "Skew": 4 M reads of config 3's shape under the skewed model of fastqdedup_amd/synth.py -- a key
+    with 80 000 copies, heavy-tailed abundance, 1 % of the molecules poly-A in segment 0 (10 000 keys in one bucket of
+    the search), a ladder of keys that is ONE component of tens of thousands of members -- against the oracle's trie
+    (which takes any distribution, _triemodule.c:380-495). A warm context (it has met the crowded buckets and the
+    overfull slabs on the first job) answers the same, and never with a device-wide sort."""
+    import torch
+    import fastqdedup_amd as F
+    from fastqdedup_amd.synth import SKEW, fixed_offsets
+    n, L = 4_000_000, 32
+    ctx = F.Context(0)
+    dev = torch.empty(n * L, dtype=torch.uint8, device="cuda:0")
+    ctx.synth_keys(dev, n, 0, n, L, L, 1003, skew=SKEW)
+    host = dev.cpu().numpy()
+    run = _OracleRun(oracle, host, n, L, 1, "directional")
+    first = F.cluster_keys(dev, key_len=L, max_distance=1, method="directional", context=ctx)
+    warm = F.cluster_keys(dev, key_len=L, max_distance=1, method="directional", context=ctx)
+    want = run.result()
+    for got in (first, warm):
+        assert (got.n_unique, got.n_clusters) == (want["n_unique"], want["n_clusters"])
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+    assert warm.route["search_grouped"] and not warm.route["search_sort"] and not warm.route["collapse_sort"], warm.route
+    # the same under the adjacency method and at distance 0 (no search at all)
+    for method, d in (("adjacency", 1), ("highest_count", 1), ("directional", 0)):
+        want2 = oracle.dedup(host, fixed_offsets(n, L), max_distance=d, method=method)
+        got2 = F.cluster_keys(dev, key_len=L, max_distance=d, method=method, context=ctx)
+        assert (got2.n_unique, got2.n_clusters) == (want2["n_unique"], want2["n_clusters"]), (method, d)
+        assert np.array_equal(got2.kept_read_ids, want2["kept_read_ids"]), (method, d)
