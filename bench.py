@@ -193,7 +193,7 @@ def copy_peak_gbs(ctx, device, nbytes: int = 2 << 30, reps: int = 5):
     return round(best, 1)
 
 
-def launch_ranks(n_ranks: int) -> int:
+def launch_ranks(n_ranks: int, script: str = None, argv=None) -> int:
     """`python bench.py --gpus N` without torch.distributed.run: start N fresh child processes of this
     script (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on 127.0.0.1) BEFORE this
     process has touched a GPU, pass their output through (rank 0 prints the JSON line) and return the
@@ -208,7 +208,8 @@ def launch_ranks(n_ranks: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
                    LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__),
+                                       *(sys.argv[1:] if argv is None else argv)], env=env))
     codes = [None] * n_ranks
     while any(c is None for c in codes):
         for i, p in enumerate(procs):

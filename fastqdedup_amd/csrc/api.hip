@@ -278,7 +278,9 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 KTIME(c, FQD_K_PART_SCATTER12, fqd::launch_part_scatter12(
                           c->ld_part.as<uint32_t>(), compact, side, f_seg_start, f_tiles, f_parts, f_grid,
                           32 - B, bins2, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<fqd::Rec12>(), c->st, slab_cap,
-                          c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end, fused->sub_bits, fused->route_mask));
+                          c->d_ctr32.as<uint32_t>() + C_BAD, f_seg_end, fused->sub_bits, fused->route_mask,
+                          fused->part_mask, fused->stamp_div, fused->stamp_div ? d_ids.packed_bits : 0u,
+                          fused->stamp_div ? d_ids.stamp_map : nullptr));
                 // the keys with an N: collapsed apart, to the head of the unique table (few: a table in global
                 // memory) -- on the context's second stream, beside the dedupe of the other keys: four short
                 // kernels (0.05 ms in a row) that the compaction, not the dedupe, waits for
@@ -290,7 +292,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                                    fused->side_slots, c->ld_side_table.as<uint32_t>() + 3 * (size_t)fused->side_slots,
                                    c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(),
                                    c->d_ctr32.as<uint32_t>() + C_SIDE, c->d_ctr32.as<uint32_t>() + C_BAD, c->st_side,
-                                   fused->p0));
+                                   fused->p0, fused->stamp_div ? d_ids : IdSource()));
                     HIP_TRY(c, hipEventRecord(c->ev_join, c->st_side));
                     side_pending = true;
                 }
@@ -362,7 +364,8 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                       c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets,
                       c->ld_tmp_rec.as<uint32_t>(), compact, compact == 1 ? c->d_ctr32.as<uint32_t>() + C_SIDE : nullptr,
                       c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho,
-                      c->ld_unique.as<uint32_t>(), group_total, fused ? fused->p0 : fqd::Pass0()));
+                      c->ld_unique.as<uint32_t>(), group_total, fused ? fused->p0 : fqd::Pass0(),
+                      fused && fused->stamp_div ? d_ids : IdSource()));
         else
         KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_compact(
                   c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets, c->ld_tmp_rec.as<uint32_t>(),
@@ -1410,9 +1413,36 @@ int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *
     f.part_mask = hash_bins - 1;
     f.stamp_div = ppo;
     f.tables_ready = true;
+    // compact records as on one GPU (pack_collapse_fused_once): 12-byte items out of level 2, keys with an N on the
+    // side path -- the alphabet must be exactly "ACGNT" (three planes) or have two planes
+    if (!c->compact_off && !getenv("FQD_NO_COMPACT_RECORDS") && c->ks.words == 1) {
+        if (c->ks.planes == 2) {
+            f.compact = 2;
+        } else if (c->ks.planes == 3 && c->shape.alphabet_size == 5 && !memcmp(c->shape.alphabet, "ACGNT", 5)) {
+            f.compact = 1;
+            f.side_slabs = 256;
+            f.side_cap = (uint32_t)((((n_reads >> 6) + 16384) / f.side_slabs + 3) & ~3ull);
+            f.side_slots = 1024;
+            while (f.side_slots < 2ull * f.side_slabs * f.side_cap)
+                f.side_slots *= 2;
+            HIP_TRY(c, c->ld_side.reserve((size_t)f.side_slabs * f.side_cap * 16 + 16));
+            HIP_TRY(c, c->ld_side_table.reserve(((size_t)fqd::side_table_words(f.side_slots) + 2 * f.side_slabs + 4) * 4 + 16));
+            HIP_TRY(c, c->urecs.reserve(n_reads * 16 + 16));
+            HIP_TRY(c, c->ucounts.reserve(n_reads * 4 + 16));
+            HIP_TRY(c, c->ufirst.reserve(n_reads * 8 + 64));
+        }
+    }
     c->seg_hint = search_segments <= 4 ? search_segments : 0;
     bool ok = false;
-    const int rc = collapse_lds(c, nullptr, ids, &ok, &f);
+    const bool compact_was_off = c->compact_off;
+    int rc = collapse_lds(c, nullptr, ids, &ok, &f);
+    if (rc == FQD_OK && !ok && f.compact && !compact_was_off && c->compact_off) {
+        // the side slabs of the compact records overflowed (many keys with an N): once more with uint4 records -- the
+        // received slabs are untouched
+        f.compact = f.side_slabs = f.side_cap = f.side_slots = 0;
+        FQD_TRY(zero_ctr32(c, 0, C_N32));
+        rc = collapse_lds(c, nullptr, ids, &ok, &f);
+    }
     c->seg_hint = 0;
     c->ld_part.unborrow();
     timer.stop();

@@ -86,7 +86,8 @@ struct RecordPolicy {
         return finish<LEVEL1>(s, i, s.in[i], v, true);
     }
     template <bool LEVEL1>
-    static __device__ __forceinline__ uint32_t finish(const Source &s, uint32_t i, const uint4 &raw, uint4 &v, bool)
+    static __device__ __forceinline__ uint32_t finish(const Source &s, uint32_t i, const uint4 &raw, uint4 &v, bool,
+                                                      uint32_t = 0)
     {
         v = raw;
         if (LEVEL1) {
@@ -475,9 +476,20 @@ struct CompactPolicy {
         uint32_t squeeze;
         fqd::SideSlabs side;
         uint32_t route_mask;      // the key bits the bucket hash looks at (all ones: the whole key; else segment 0)
+        // slabs received from several ranks (fqd_collapse_owner_slabs): segment / stamp_div is the sender, whose rank
+        // by id base (stamp_map) is stamped above the read index the record carries, stamp_shift bits up
+        uint32_t stamp_div, stamp_shift;
+        const uint32_t *stamp_map;
     };
-    static __device__ __forceinline__ uint32_t segment_tag(const Source &, uint32_t) { return 0u; }
-    static __device__ __forceinline__ void apply_tag(fqd::Rec12 &, uint32_t) {}
+    static __device__ __forceinline__ uint32_t segment_tag(const Source &s, uint32_t seg)
+    {
+        if (!s.stamp_div)
+            return 0u;
+        const uint32_t sender = seg / s.stamp_div;
+        return (s.stamp_map ? s.stamp_map[sender] : sender) << s.stamp_shift;
+    }
+    // (a record that left through the side slabs has id 0xFFFFFFFF and stays so: it was stamped on its way there)
+    static __device__ __forceinline__ void apply_tag(fqd::Rec12 &v, uint32_t tag) { v.id |= tag; }
     // a record that left through the side slabs: not staged, not written
     static __device__ __forceinline__ bool skip(const fqd::Rec12 &v) { return v.id == 0xFFFFFFFFu; }
     using Raw = uint4;
@@ -489,7 +501,8 @@ struct CompactPolicy {
         return finish<LEVEL1>(s, i, s.in[i], v, true);
     }
     template <bool LEVEL1>
-    static __device__ __forceinline__ uint32_t finish(const Source &s, uint32_t, const uint4 &r, fqd::Rec12 &v, bool valid)
+    static __device__ __forceinline__ uint32_t finish(const Source &s, uint32_t, const uint4 &r, fqd::Rec12 &v, bool valid,
+                                                      uint32_t seg_tag = 0)
     {
         const bool squeeze = s.squeeze == 1;
         const bool rare = squeeze && (r.x & r.y) != 0u;
@@ -498,7 +511,7 @@ struct CompactPolicy {
             const uint32_t slab = blockIdx.x & (s.side.n_slabs - 1);
             const uint32_t pos = atomicAdd(&s.side.cursor[slab], 1u);
             if (pos < (slab + 1) * s.side.cap)
-                s.side.recs[pos] = r;
+                s.side.recs[pos] = make_uint4(r.x, r.y, r.z, r.w | seg_tag);
             else
                 atomicOr(s.side.overflow, 16u);
         }
@@ -533,10 +546,11 @@ template <uint32_t MAXB>
 __global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter12_kernel(
     CompactPolicy::Source src, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ tile_start,
     uint32_t n_seg, uint32_t shift, uint32_t n_bins, uint32_t *__restrict__ cursor, fqd::Rec12 *__restrict__ out,
-    uint32_t slab_cap, uint32_t *__restrict__ slab_overflow, const uint32_t *__restrict__ seg_end, uint32_t seg_shift)
+    uint32_t slab_cap, uint32_t *__restrict__ slab_overflow, const uint32_t *__restrict__ seg_end, uint32_t seg_shift,
+    uint32_t seg_mask)
 {
     fqd_partition::scatter_body<CompactPolicy, false, MAXB>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
-                                                            slab_cap, slab_overflow, seg_end, seg_shift, 0xFFFFFFFFu);
+                                                            slab_cap, slab_overflow, seg_end, seg_shift, seg_mask);
 }
 
 __device__ __forceinline__ uint32_t rec12_tag(uint32_t a, uint32_t b)
@@ -711,7 +725,8 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
     const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ unique_incl, uint32_t n_buckets,
     const uint4 *__restrict__ tmp, uint32_t squeeze, const uint32_t *__restrict__ side_unique,
     uint4 *__restrict__ urecs, uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst, fqd::SegHashOut sho,
-    const uint32_t *__restrict__ bucket_unique, const uint32_t *__restrict__ group_total, fqd::Pass0 p0)
+    const uint32_t *__restrict__ bucket_unique, const uint32_t *__restrict__ group_total, fqd::Pass0 p0,
+    IdSource read_ids /* packed_bits != 0: the rows' index words are (sender rank, read index on the sender) */)
 {
     // search pass 0 (fqd::Pass0): the wave's rows, counting-sorted by six more bits of their route hash
     // (PASS0 = false: none of this is compiled in -- p0.mask is 0 then)
@@ -783,7 +798,7 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
                 sho.out[(size_t)(sg - sho.first) * n_unique + u] = fqd_segment_hash(w, sho.planes, sho.kw, sho.len, sg, sho.nseg);
         urecs[u] = make_uint4(w[0], w[1], w[2], 0u);
         ucounts[u] = row.z;
-        ufirst[u] = row.w;
+        ufirst[u] = read_ids.packed_bits ? read_ids.from_packed(row.w) : (uint64_t)row.w;
     };
     if (!pass0) {
         for (uint32_t j0 = lane; j0 < cnt; j0 += 4 * 64) {
@@ -1005,7 +1020,8 @@ __global__ __launch_bounds__(SIDE_THREADS) void side_emit_kernel(const uint4 *__
                                                                  const uint32_t *__restrict__ block_counts,
                                                                  uint4 *__restrict__ urecs, uint32_t *__restrict__ ucounts,
                                                                  uint64_t *__restrict__ ufirst,
-                                                                 uint32_t *__restrict__ side_unique, fqd::Pass0 p0)
+                                                                 uint32_t *__restrict__ side_unique, fqd::Pass0 p0,
+                                                                 IdSource read_ids)
 {
     __shared__ uint32_t s_part[SIDE_THREADS / 64], s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1045,7 +1061,8 @@ __global__ __launch_bounds__(SIDE_THREADS) void side_emit_kernel(const uint4 *__
             const uint32_t u = base + rank;
             urecs[u] = make_uint4(v.x, v.y, v.z, 0u);
             ucounts[u] = table[table_slots + i];
-            ufirst[u] = table[2 * table_slots + i];
+            const uint32_t first_word = table[2 * table_slots + i];
+            ufirst[u] = read_ids.packed_bits ? read_ids.from_packed(first_word) : (uint64_t)first_word;
             if (p0.mask) {
                 // search pass 0 happens in the compaction of the bucket this key's segment 0 routes to (fqd::Pass0)
                 const uint32_t bkt = fqd::fqd_route_hash(v.x | v.z, v.y | v.z, p0.mask) >> (32u - p0.bucket_bits);
@@ -1189,20 +1206,24 @@ uint32_t part_tile_size12() { return fqd_partition::THREADS * CompactPolicy::EPT
 hipError_t launch_part_scatter12(const uint32_t *in, uint32_t squeeze, SideSlabs side, const uint32_t *seg_start,
                                  const uint32_t *tile_start, uint32_t n_seg, uint32_t max_tiles, uint32_t shift,
                                  uint32_t n_bins, uint32_t *cursor, Rec12 *out, hipStream_t st, uint32_t slab_cap,
-                                 uint32_t *slab_overflow, const uint32_t *seg_end, uint32_t seg_shift, uint32_t route_mask)
+                                 uint32_t *slab_overflow, const uint32_t *seg_end, uint32_t seg_shift, uint32_t route_mask,
+                                 uint32_t seg_mask, uint32_t stamp_div, uint32_t stamp_shift, const uint32_t *stamp_map)
 {
     if (n_bins > fqd_partition::MAX_BINS || (squeeze != 1 && squeeze != 2))
         return hipErrorInvalidValue;
     if (squeeze == 1 && (!side.recs || !side.cursor || !side.overflow || !side.cap || !side.n_slabs ||
                          (side.n_slabs & (side.n_slabs - 1))))
         return hipErrorInvalidValue;
-    const CompactPolicy::Source src{reinterpret_cast<const uint4 *>(in), squeeze, side, route_mask ? route_mask : 0xFFFFFFFFu};
+    const CompactPolicy::Source src{reinterpret_cast<const uint4 *>(in), squeeze, side, route_mask ? route_mask : 0xFFFFFFFFu,
+                                    stamp_div, stamp_shift, stamp_map};
     if (n_bins <= 256)
         part_scatter12_kernel<256><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
-            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift);
+            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift,
+            seg_mask);
     else
         part_scatter12_kernel<fqd_partition::MAX_BINS><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
-            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift);
+            src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift,
+            seg_mask);
     return hipGetLastError();
 }
 
@@ -1220,7 +1241,7 @@ hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t 
                                    const uint32_t *tmp_rec, uint32_t squeeze, const uint32_t *side_unique,
                                    uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, hipStream_t st,
                                    SegHashOut seg_hashes, const uint32_t *bucket_unique, const uint32_t *group_total,
-                                   Pass0 pass0)
+                                   Pass0 pass0, IdSource read_ids)
 {
     // one wave per bucket + 64 waves for the segment hashes of the side path's keys; with search pass 0: as many waves
     // as the GPU holds at once (256 CUs x 5 workgroups of 4), each taking every waves-th bucket
@@ -1229,12 +1250,12 @@ hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t 
         threads = std::min<uint64_t>(threads, (uint64_t)256 * 4 * 256);      // (107 VGPRs: four workgroups per CU)
         bucket_compact12_kernel<true><<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
             bucket_start, unique_incl, n_buckets, reinterpret_cast<const uint4 *>(tmp_rec), squeeze, side_unique,
-            reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, bucket_unique, group_total, pass0);
+            reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, bucket_unique, group_total, pass0, read_ids);
         return hipGetLastError();
     }
     bucket_compact12_kernel<false><<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
         bucket_start, unique_incl, n_buckets, reinterpret_cast<const uint4 *>(tmp_rec), squeeze, side_unique,
-        reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, bucket_unique, group_total, pass0);
+        reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, bucket_unique, group_total, pass0, read_ids);
     return hipGetLastError();
 }
 
@@ -1243,7 +1264,7 @@ uint32_t side_table_words(uint32_t table_slots) { return 3 * table_slots + (tabl
 hipError_t launch_side_collapse(const uint4 *side, const uint32_t *cursor, uint32_t first_part, uint32_t subs, uint32_t cap,
                                 const uint32_t *weights, uint32_t *table, uint32_t table_slots, uint32_t *block_counts,
                                 uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, uint32_t *side_unique,
-                                uint32_t *overflow, hipStream_t st, Pass0 pass0)
+                                uint32_t *overflow, hipStream_t st, Pass0 pass0, IdSource read_ids)
 {
     if (!table_slots || (table_slots & (table_slots - 1)) || !subs || !cap)
         return hipErrorInvalidValue;
@@ -1253,7 +1274,8 @@ hipError_t launch_side_collapse(const uint4 *side, const uint32_t *cursor, uint3
                                                                      table_slots, overflow);
     side_count_kernel<<<blocks, SIDE_THREADS, 0, st>>>(table, table_slots, block_counts);
     side_emit_kernel<<<blocks, SIDE_THREADS, 0, st>>>(side, table, table_slots, block_counts,
-                                                    reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, side_unique, pass0);
+                                                    reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, side_unique, pass0,
+                                                    read_ids);
     return hipGetLastError();
 }
 

@@ -386,7 +386,8 @@ hipError_t launch_part_scatter12(const uint32_t *in /* uint4 records */, uint32_
                                  const uint32_t *seg_start, const uint32_t *tile_start, uint32_t n_seg,
                                  uint32_t max_tiles, uint32_t shift, uint32_t n_bins, uint32_t *cursor, Rec12 *out,
                                  hipStream_t st, uint32_t slab_cap, uint32_t *slab_overflow, const uint32_t *seg_end,
-                                 uint32_t seg_shift, uint32_t route_mask = 0xFFFFFFFFu);
+                                 uint32_t seg_shift, uint32_t route_mask = 0xFFFFFFFFu, uint32_t seg_mask = 0xFFFFFFFFu,
+                                 uint32_t stamp_div = 0, uint32_t stamp_shift = 0, const uint32_t *stamp_map = nullptr);
 uint32_t part_tile_size12();
 hipError_t launch_bucket_dedupe12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                   uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
@@ -396,7 +397,8 @@ hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t 
                                    const uint32_t *tmp_rec, uint32_t squeeze, const uint32_t *side_unique,
                                    uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, hipStream_t st,
                                    SegHashOut seg_hashes = SegHashOut(), const uint32_t *bucket_unique = nullptr,
-                                   const uint32_t *group_total = nullptr, Pass0 pass0 = Pass0());
+                                   const uint32_t *group_total = nullptr, Pass0 pass0 = Pass0(),
+                                   IdSource read_ids = IdSource());
 // the keys of the side slabs (few: the reads with an N) collapsed through a hash table in global memory and
 // written to the head of the unique table; table: side_table_words(table_slots) words (table_slots a power of
 // two), cleared here; block_counts = table + 3 * table_slots
@@ -405,7 +407,7 @@ hipError_t launch_side_collapse(const uint4 *side, const uint32_t *cursor /* of 
                                 uint32_t first_part /* the cursors started at (first_part + sub) * cap */, uint32_t subs, uint32_t cap,
                                 const uint32_t *weights, uint32_t *table, uint32_t table_slots, uint32_t *block_counts,
                                 uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, uint32_t *side_unique,
-                                uint32_t *overflow, hipStream_t st, Pass0 pass0 = Pass0());
+                                uint32_t *overflow, hipStream_t st, Pass0 pass0 = Pass0(), IdSource read_ids = IdSource());
 
 // edges.hip
 hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t nseg,

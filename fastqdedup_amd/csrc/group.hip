@@ -47,7 +47,7 @@ struct PairPolicy {
         return LEVEL1 ? make_uint2(s.hashes[i], s.values ? s.values[i] : i) : s.in[i];
     }
     template <bool LEVEL1>
-    static __device__ __forceinline__ uint32_t finish(const Source &, uint32_t, const uint2 &raw, uint2 &v, bool)
+    static __device__ __forceinline__ uint32_t finish(const Source &, uint32_t, const uint2 &raw, uint2 &v, bool, uint32_t = 0)
     {
         v = raw;
         return v.x;

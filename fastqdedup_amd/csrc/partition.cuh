@@ -18,7 +18,7 @@
 //   using KeyRaw = ...;  key_fetch<LEVEL1>(src, i) -> KeyRaw;  key_finish<LEVEL1>(src, i, raw) -> key   // histogram pass
 //   using Raw = ...;                                                                            // scatter pass, two steps:
 //   template <bool LEVEL1> static __device__ Raw fetch(const Source &, uint32_t i);             //   the loads alone (no branch, no side effect)
-//   template <bool LEVEL1> static __device__ uint32_t finish(const Source &, uint32_t i, const Raw &, Item &, bool valid);  // -> key
+//   template <bool LEVEL1> static __device__ uint32_t finish(const Source &, uint32_t i, const Raw &, Item &, bool valid, uint32_t seg_tag);  // -> key
 //   (the loads of a whole tile must be in flight together: "if (i < hi) { load; hash }" compiles to one branch per
 //   item with s_waitcnt vmcnt(0) inside -- EPT dependent round trips per tile; see tools/isa_skeleton.py. The bodies
 //   below therefore fetch at min(i, hi - 1), unconditionally, and finish afterwards; valid = i < hi)
@@ -187,7 +187,7 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
 #pragma unroll
         for (uint32_t e = 0; e < EPT; e++) {
             const uint32_t i = lo + e * THREADS + tid;
-            h[e] = Policy::template finish<LEVEL1>(src, min(i, hi - 1), raw[e], v[e], i < hi);
+            h[e] = Policy::template finish<LEVEL1>(src, min(i, hi - 1), raw[e], v[e], i < hi, seg_tag);
             Policy::apply_tag(v[e], seg_tag);
         }
     }
