@@ -121,13 +121,13 @@ __global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
                 bool valid[4];
 #pragma unroll
                 for (uint32_t t = 0; t < 4; t++) {
+                    // (clamped and unconditional: "if (valid) load" compiles to a branch with its own wait per round,
+                    // and the four rounds' gathers went out one after the other)
                     const uint32_t e = base + t * groups + gl;
                     valid[t] = gl < groups && e < qn;
-                    xa[t] = xb[t] = make_uint4(0, 0, 0, 0);
-                    if (valid[t]) {
-                        xa[t] = recs4[(size_t)s_qa[wave][e] * q_per_rec + ql];
-                        xb[t] = recs4[(size_t)s_qb[wave][e] * q_per_rec + ql];
-                    }
+                    const uint32_t ec = min(base + t * groups + min(gl, groups - 1), qn - 1);
+                    xa[t] = recs4[(size_t)s_qa[wave][ec] * q_per_rec + ql];
+                    xb[t] = recs4[(size_t)s_qb[wave][ec] * q_per_rec + ql];
                 }
 #pragma unroll
                 for (uint32_t t = 0; t < 4; t++) {

@@ -445,6 +445,7 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
     // words of all 2 * VE records are requested together (clamped, unconditional) -- one candidate per sweep was two
     // dependent round trips and a barrier per 256 candidates.
     constexpr uint32_t VE = COOP ? 1u : 4u;
+    constexpr uint32_t CR = 2;      // COOP: rounds of groups whose record gathers are in flight together (4: 120 VGPRs, no faster)
     const unsigned long long step = (unsigned long long)parts * GP_THREADS * VE;
     for (unsigned long long base = (unsigned long long)part * GP_THREADS * VE; base < total; base += step) {
         bool hits[VE];
@@ -515,29 +516,32 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
             const uint4 *recs4 = reinterpret_cast<const uint4 *>(urecs);
             const uint32_t W = sh.words;
             const unsigned long long have = __ballot(live);
-            for (uint32_t c0 = 0; c0 < 64 && (have >> c0); c0 += 2 * groups) {
-                // two rounds of groups: their four loads per lane are requested together
-                uint4 xs[2];
-                bool on[2];
-                uint32_t lens2[2];     // the pair's key length; keys of different lengths are no Hamming neighbours
+            for (uint32_t c0 = 0; c0 < 64 && (have >> c0); c0 += CR * groups) {
+                // CR rounds of groups: their 2 * CR loads per lane are requested together
+                uint4 xs[CR];
+                bool on[CR];
+                uint32_t lens2[CR];     // the pair's key length; keys of different lengths are no Hamming neighbours
 #pragma unroll
-                for (uint32_t t = 0; t < 2; t++) {
+                for (uint32_t t = 0; t < CR; t++) {
                     const uint32_t cnd = c0 + t * groups + gl;
                     on[t] = gl < groups && cnd < 64 && ((have >> cnd) & 1ull);
+                    // (a lane without a live candidate holds the pair (0, 0): record 0 is readable, so the loads are
+                    // unconditional and both rounds' four gathers are in flight together -- "if (on) load" compiled
+                    // to a branch with its own wait per round)
                     const uint32_t pu = __shfl(pr.x, cnd & 63u), pv = __shfl(pr.y, cnd & 63u);
-                    xs[t] = make_uint4(0, 0, 0, 0);
                     lens2[t] = sh.max_len;
-                    if (on[t]) {
-                        if (sh.ragged) {
-                            lens2[t] = ulens[pu];
-                            on[t] = ulens[pv] == lens2[t];
-                        }
-                        const uint4 a = recs4[(size_t)pu * Q + ql], b = recs4[(size_t)pv * Q + ql];
-                        xs[t] = make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
+                    uint32_t len_v = sh.max_len;
+                    if (sh.ragged) {
+                        lens2[t] = ulens[pu];
+                        len_v = ulens[pv];
                     }
+                    const uint32_t qc = min(ql, Q - 1);
+                    const uint4 a = recs4[(size_t)pu * Q + qc], b = recs4[(size_t)pv * Q + qc];
+                    xs[t] = make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
+                    on[t] = on[t] && len_v == lens2[t];
                 }
 #pragma unroll
-                for (uint32_t t = 0; t < 2; t++) {
+                for (uint32_t t = 0; t < CR; t++) {
                     const uint32_t cnd = c0 + t * groups + gl;
                     const uint32_t cseg = __shfl(my_seg, cnd & 63u);     // the candidate's pass
                     __builtin_amdgcn_wave_barrier();

@@ -112,3 +112,43 @@ def test_skewed_workload_matches_oracle(oracle):
         got2 = F.cluster_keys(dev, key_len=L, max_distance=d, method=method, context=ctx)
         assert (got2.n_unique, got2.n_clusters) == (want2["n_unique"], want2["n_clusters"]), (method, d)
         assert np.array_equal(got2.kept_read_ids, want2["kept_read_ids"]), (method, d)
+
+
+def test_long_keys_match_oracle_at_5m(oracle):
+    """The shapes of BASELINE.json's configs 4 and 5 at 5 M reads of 300 nt, the largest the oracle's trie answers in
+    about two minutes (96 s and 58 s for the reference): Hamming d = 2 directional -- three
+    routed passes' worth of search on 128-byte records, the (hash, position) collapse -- and Levenshtein d = 1
+    adjacency over keys of 299 / 300 / 301 nt (a 1 % indel tail: the ragged pack and collapse, the Hamming passes for
+    pairs of one length and the edit search proper for pairs of different lengths). Both oracle runs start in threads
+    before any GPU work."""
+    import torch
+    import fastqdedup_amd as F
+    n, L = 5_000_000, 300
+    ctx = F.Context(0)
+    dev4 = torch.empty(n * L, dtype=torch.uint8, device="cuda:0")
+    ctx.synth_keys(dev4, n, 0, n, L, L, 1004)
+    host4 = dev4.cpu().numpy()
+    run4 = _OracleRun(oracle, host4, n, L, 2, "directional")
+    dev5, off5 = ctx.synth_indel_keys(n, 0, n, L, L, 1005, indel_rate=0.01)
+    host5, hoff5 = dev5.cpu().numpy(), off5.cpu().numpy().astype(np.uint64)
+    out5, err5 = {}, []
+
+    def work5():
+        try:
+            out5.update(oracle.dedup(host5, hoff5, max_distance=1, use_edit_distance=True, method="adjacency"))
+        except BaseException as exc:
+            err5.append(exc)
+    t5 = threading.Thread(target=work5, daemon=True)
+    t5.start()
+    got4 = F.cluster_keys(dev4, key_len=L, max_distance=2, method="directional", context=ctx)
+    got5 = F.cluster_keys(dev5, off5, 0, max_distance=1, use_edit_distance=True, method="adjacency", context=ctx)
+    assert got4.route["collapse_pairs"] and got4.route["search_grouped"] and not got4.route["search_sort"], got4.route
+    assert got5.route["search_edit"] and not got5.route["collapse_sort"], got5.route
+    want4 = run4.result()
+    assert (got4.n_unique, got4.n_clusters) == (want4["n_unique"], want4["n_clusters"])
+    assert np.array_equal(got4.kept_read_ids, want4["kept_read_ids"])
+    t5.join()
+    if err5:
+        raise err5[0]
+    assert (got5.n_unique, got5.n_clusters) == (out5["n_unique"], out5["n_clusters"])
+    assert np.array_equal(got5.kept_read_ids, out5["kept_read_ids"])
