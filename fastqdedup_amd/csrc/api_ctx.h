@@ -160,6 +160,7 @@ struct fqd_ctx {
     uint64_t n_clusters = 0, roots_seen = 0;
     DevBuf labels, hook_slots;
     bool labels_flat = false;
+    bool pre_zero_tail = false;     // ... and it cleared the kept-bin cursors, C64_SUM and C64_CANDS too (the tail launches no fills)
     bool pre_init = false, pre_init_closed = false;   // fqd_api_graph_preinit ran for this job (its closed-form part too)
     int preinit_method = -1;        // >= 0: the search queues fqd_api_graph_preinit(method) behind its read-back
     // stage 5

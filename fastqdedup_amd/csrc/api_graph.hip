@@ -68,6 +68,7 @@ static int graph_preinit(fqd_ctx *c, int method)
 {
     const uint64_t U = c->U;
     c->pre_init = c->pre_init_closed = false;
+    c->pre_zero_tail = false;
     if (!U)
         return FQD_OK;
     HIP_TRY(c, c->labels.reserve(U * 4 + 16));
@@ -79,11 +80,17 @@ static int graph_preinit(fqd_ctx *c, int method)
         HIP_TRY(c, c->blocked.reserve(U * 4 + 16));
         HIP_TRY(c, c->root_taint.reserve(U + 16));
     }
+    // (the cursor table of the kept-id bins, at the size fqd_dissect will ask for -- no reallocation behind this)
+    HIP_TRY(c, c->kept_u32.reserve(std::max<size_t>(U * 4 + 16, (size_t)512 * fqd::kept_bin_lists() * 4 + 16)));
     // one launch for all of it (graph.hip graph_preinit_kernel)
     HIP_TRY(c, fqd::launch_graph_preinit(c->labels.as<uint32_t>(), c->best.as<uint32_t>(), c->state.as<uint8_t>(),
                                          closed ? c->blocked.as<uint32_t>() : nullptr,
                                          closed ? c->root_taint.as<uint8_t>() : nullptr, U,
-                                         c->hook_slots.as<unsigned long long>(), FQD_HOOK_SLOTS * 8, c->st));
+                                         c->hook_slots.as<unsigned long long>(), FQD_HOOK_SLOTS * 8, c->st,
+                                         c->kept_u32.as<uint32_t>(), 512 * fqd::kept_bin_lists(),
+                                         c->d_ctr64.as<unsigned long long>() + C64_SUM,
+                                         c->d_ctr64.as<unsigned long long>() + C64_CANDS));
+    c->pre_zero_tail = true;
     c->pre_init_closed = closed;
     c->pre_init = true;
     return FQD_OK;
@@ -128,7 +135,10 @@ static int list_kept(fqd_ctx *c, int method)
     }
     const bool by_map = c->first_distinct && window <= 32 * U && window < 0xFFFFFFF0ull &&
                         !getenv("FQD_KEPT_BY_SORT");
-    FQD_TRY(zero_ctr64(c, C64_SUM));
+    const bool tail_zeroed = c->pre_zero_tail;
+    c->pre_zero_tail = false;
+    if (!tail_zeroed)
+        FQD_TRY(zero_ctr64(c, C64_SUM));
     // ... and cheaper still through id bins, without the map (graph.hip kept_bin_kernel): windows of
     // up to 512 bins x 2^18 ids
     if (by_map && window && fqd::kept_bin_shift(window) <= 18 &&
@@ -149,7 +159,7 @@ static int list_kept(fqd_ctx *c, int method)
                   c->ufirst.as<uint64_t>(), c->id_lo, window, U, c->kept.as<uint8_t>(), c->ucounts.as<uint32_t>(),
                   c->blocked.as<uint32_t>(), c->root_taint.as<uint8_t>(), c->kept_u32.as<uint32_t>(),
                   c->kept_lists.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_SUM, base, list_out,
-                  c->kept_scan.as<uint32_t>(), c->st));
+                  c->kept_scan.as<uint32_t>(), c->st, tail_zeroed));
         FQD_TRY(queue_read_u32(c, c->kept_scan.as<uint32_t>(), 0));
         unsigned long long both[2] = {0, 0};      // C64_ROOTS, C64_SUM: one read for fqd_cluster
         FQD_TRY(read_ctr64(c, C64_ROOTS, both, 2));
@@ -279,7 +289,8 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
         if (E) {
             if (E >= 0xFFFFFFFFull)
                 return fail(c, FQD_E_VALUE, "more than 2^32 edges");
-            FQD_TRY(zero_ctr64(c, C64_CANDS));             // (the search's candidate counter, free here)
+            if (!c->pre_zero_tail)
+                FQD_TRY(zero_ctr64(c, C64_CANDS));         // (the search's candidate counter, free here)
             if (!pre_closed) {
                 HIP_TRY(c, hipMemsetAsync(c->root_taint.p, 0, U, c->st));
                 HIP_TRY(c, fqd::launch_uf_init(c->blocked.as<uint32_t>(), U, c->st));

@@ -724,6 +724,7 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
     }
     if (cross_after && U >= 2) {
         bool cross_done = false;
+        c->pre_zero_tail = false;        // (the edit search uses the counters the graph set-up has cleared)
         c->route |= FQD_ROUTE_SEARCH_EDIT;
         FQD_TRY(find_edges_edit_grouped(c, 1, &cross_done, true, true));
         if (!cross_done) {           // (cannot happen for d = 1 below 2^26 keys; the sorted search redoes everything)

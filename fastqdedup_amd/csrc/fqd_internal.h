@@ -551,7 +551,7 @@ hipError_t launch_kept_bins(int method, const uint32_t *labels, const uint32_t *
                             const uint64_t *ufirst, uint64_t id_lo, uint64_t window, uint64_t U, uint8_t *kept,
                             const uint32_t *ucounts, const uint32_t *parent1, const uint8_t *root_taint,
                             uint32_t *cursor, uint32_t *lists, unsigned long long *n_kept_total, uint64_t id_base,
-                            uint64_t *out, uint32_t *n_listed, hipStream_t st);
+                            uint64_t *out, uint32_t *n_listed, hipStream_t st, bool cursors_zeroed = false);
 uint32_t window_blocks(uint64_t n);
 hipError_t launch_window_count(const uint8_t *flags, uint64_t n, uint32_t *block_counts, hipStream_t st);
 hipError_t launch_window_emit(const uint8_t *flags, uint64_t n, const uint32_t *block_incl, uint64_t id_base,
@@ -569,7 +569,9 @@ hipError_t launch_mark_dropped(uint8_t *state, uint64_t U, const uint32_t *dropp
 hipError_t launch_uf_flatten(uint32_t *parent, uint64_t U, unsigned long long *n_roots, hipStream_t st);
 hipError_t launch_dissect_init(uint32_t *best, uint8_t *state, uint64_t U, hipStream_t st);
 hipError_t launch_graph_preinit(uint32_t *parent, uint32_t *best, uint8_t *state, uint32_t *parent1, uint8_t *root_taint,
-                                uint64_t U, unsigned long long *hook_slots, uint32_t hook_words, hipStream_t st);
+                                uint64_t U, unsigned long long *hook_slots, uint32_t hook_words, hipStream_t st,
+                                uint32_t *zero32 = nullptr, uint32_t zero32_words = 0,
+                                unsigned long long *zero64_a = nullptr, unsigned long long *zero64_b = nullptr);
 hipError_t launch_highest_count(const uint32_t *labels, const uint32_t *ucounts, const uint32_t *urecs,
                                 const uint32_t *ulens, KeyShape sh, uint64_t U, uint32_t *best,
                                 hipStream_t st);

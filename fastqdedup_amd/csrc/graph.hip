@@ -275,13 +275,25 @@ __global__ __launch_bounds__(256) void uf_flatten_kernel(uint32_t *parent, uint6
 __global__ void graph_preinit_kernel(uint32_t *__restrict__ parent, uint32_t *__restrict__ best,
                                      uint8_t *__restrict__ state, uint32_t *__restrict__ parent1 /* may be NULL */,
                                      uint8_t *__restrict__ root_taint /* with parent1 */, uint64_t U,
-                                     unsigned long long *__restrict__ hook_slots, uint32_t hook_words)
+                                     unsigned long long *__restrict__ hook_slots, uint32_t hook_words,
+                                     uint32_t *__restrict__ zero32 /* may be NULL */, uint32_t zero32_words,
+                                     unsigned long long *__restrict__ zero64_a, unsigned long long *__restrict__ zero64_b)
 {
     // four keys per thread: 16-byte stores for the word arrays, 4-byte stores for the byte arrays
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = q * 4;
-    if (blockIdx.x == 0)
+    if (blockIdx.x == 0) {
         for (uint32_t w = threadIdx.x; w < hook_words; w += blockDim.x)
             hook_slots[w] = 0ull;
+        // ... and what the tail of the job would clear with launches of its own: the cursors of the kept-id bins, the
+        // counters of the kept keys and of the dissection's edge list
+        if (zero32)
+            for (uint32_t w = threadIdx.x; w < zero32_words; w += blockDim.x)
+                zero32[w] = 0u;
+        if (threadIdx.x == 0 && zero64_a)
+            *zero64_a = 0ull;
+        if (threadIdx.x == 0 && zero64_b)
+            *zero64_b = 0ull;
+    }
     if (i0 + 4 <= U) {
         const uint4 v = make_uint4((uint32_t)i0, (uint32_t)i0 + 1, (uint32_t)i0 + 2, (uint32_t)i0 + 3);
         reinterpret_cast<uint4 *>(parent)[q] = v;
@@ -875,7 +887,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void kept_bin_ker
         gb[q] = 0;
         if (b < n_bins) {
             s_off[b] = run;
-            gb[q] = cnt[q] ? atomicAdd(&cursor[b * KB_SUBS + sub], cnt[q]) : 0u;
+            gb[q] = cnt[q] ? (((b * KB_SUBS + sub) << bin_shift) + atomicAdd(&cursor[b * KB_SUBS + sub], cnt[q])) : 0u;
         }
         run += cnt[q];
     }
@@ -938,7 +950,7 @@ __global__ __launch_bounds__(KE_THREADS) void kept_emit_kernel(uint32_t KB_SUBS,
     for (uint32_t x = tid; x < n_bins; x += KE_THREADS) {
         uint32_t cnt = 0;
         for (uint32_t k = 0; k < KB_SUBS; k++)
-            cnt += cursor[x * KB_SUBS + k] - ((x * KB_SUBS + k) << bin_shift);
+            cnt += cursor[x * KB_SUBS + k];
         all += cnt;
         before += x < b ? cnt : 0u;
     }
@@ -947,7 +959,7 @@ __global__ __launch_bounds__(KE_THREADS) void kept_emit_kernel(uint32_t KB_SUBS,
     const uint32_t q_lo = q * words * 32u, q_hi = q_lo + words * 32u;
     uint32_t below = 0;
     for (uint32_t k = 0; k < KB_SUBS; k++) {
-        const uint32_t slab = (b * KB_SUBS + k) << bin_shift, n = cursor[b * KB_SUBS + k] - slab;
+        const uint32_t slab = (b * KB_SUBS + k) << bin_shift, n = cursor[b * KB_SUBS + k];
         auto mark = [&](uint32_t off) {
             const uint32_t o = off - first;
             below += o < q_lo ? 1u : 0u;
@@ -1030,11 +1042,12 @@ __global__ __launch_bounds__(KE_THREADS) void kept_emit_kernel(uint32_t KB_SUBS,
     }
 }
 
+// (the cursors count from 0: list (b, s) starts at (b * subs + s) << bin_shift)
 __global__ void kept_bin_starts_kernel(uint32_t n_lists, uint32_t bin_shift, uint32_t *__restrict__ cursor)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < n_lists)
-        cursor[b] = b << bin_shift;
+        cursor[b] = 0u;
 }
 
 // ---- ascending id list = compaction of the window's byte map (bytes are 0 or 1) -------------
@@ -1201,12 +1214,13 @@ hipError_t launch_uf_flatten(uint32_t *parent, uint64_t U, unsigned long long *n
 }
 
 hipError_t launch_graph_preinit(uint32_t *parent, uint32_t *best, uint8_t *state, uint32_t *parent1, uint8_t *root_taint,
-                                uint64_t U, unsigned long long *hook_slots, uint32_t hook_words, hipStream_t st)
+                                uint64_t U, unsigned long long *hook_slots, uint32_t hook_words, hipStream_t st,
+                                uint32_t *zero32, uint32_t zero32_words, unsigned long long *zero64_a,
+                                unsigned long long *zero64_b)
 {
     const uint64_t quads = (U + 3) / 4;
-    graph_preinit_kernel<<<(unsigned)std::max<uint64_t>(1, (quads + 255) / 256), 256, 0, st>>>(parent, best, state, parent1,
-                                                                                           root_taint, U, hook_slots,
-                                                                                           hook_words);
+    graph_preinit_kernel<<<(unsigned)std::max<uint64_t>(1, (quads + 255) / 256), 256, 0, st>>>(
+        parent, best, state, parent1, root_taint, U, hook_slots, hook_words, zero32, zero32_words, zero64_a, zero64_b);
     return hipGetLastError();
 }
 
@@ -1312,14 +1326,15 @@ hipError_t launch_kept_bins(int method, const uint32_t *labels, const uint32_t *
                             const uint64_t *ufirst, uint64_t id_lo, uint64_t window, uint64_t U, uint8_t *kept,
                             const uint32_t *ucounts, const uint32_t *parent1, const uint8_t *root_taint,
                             uint32_t *cursor, uint32_t *lists, unsigned long long *n_kept_total, uint64_t id_base,
-                            uint64_t *out, uint32_t *n_listed, hipStream_t st)
+                            uint64_t *out, uint32_t *n_listed, hipStream_t st, bool cursors_zeroed)
 {
     const uint32_t shift = kept_bin_shift(window);
     const uint32_t n_bins = (uint32_t)((window + (1ull << shift) - 1) >> shift);
     const uint32_t KB_SUBS = kb_subs();
     if (!U || !n_bins || shift > 18 || ((uint64_t)n_bins * KB_SUBS << shift) > 0xFFFFFFFFull)   // (a 2^18-bit map is 32 KB of LDS)
         return hipErrorInvalidValue;
-    kept_bin_starts_kernel<<<(n_bins * KB_SUBS + 255) / 256, 256, 0, st>>>(n_bins * KB_SUBS, shift, cursor);
+    if (!cursors_zeroed)       // (else: graph_preinit_kernel has cleared the whole cursor table)
+        kept_bin_starts_kernel<<<(n_bins * KB_SUBS + 255) / 256, 256, 0, st>>>(n_bins * KB_SUBS, shift, cursor);
     // 1024-thread workgroups (16 Ki keys per tile) from 2^22 keys on: runs per (tile, bin) four times as long, a
     // quarter of the cursor atomics; small tables keep 256 threads (more workgroups than CUs)
     static const int kb_threads_env = getenv("FQD_KB_THREADS") ? atoi(getenv("FQD_KB_THREADS")) : 0;
