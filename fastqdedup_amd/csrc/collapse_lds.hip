@@ -80,14 +80,18 @@ struct RecordPolicy {
     using Raw = uint4;
     template <bool LEVEL1>
     static __device__ __forceinline__ uint4 fetch(const Source &s, uint32_t i) { return s.in[i]; }
+    struct Shared {};
+    static __device__ __forceinline__ void init_shared(Shared &, uint32_t) {}
+    static __device__ __forceinline__ void flush(const Source &, Shared &, uint32_t) {}
     template <bool LEVEL1>
     static __device__ __forceinline__ uint32_t load(const Source &s, uint32_t i, uint4 &v)
     {
-        return finish<LEVEL1>(s, i, s.in[i], v, true);
+        Shared none;
+        return finish<LEVEL1>(s, i, s.in[i], v, true, 0u, none);
     }
     template <bool LEVEL1>
     static __device__ __forceinline__ uint32_t finish(const Source &s, uint32_t i, const uint4 &raw, uint4 &v, bool,
-                                                      uint32_t = 0)
+                                                      uint32_t, Shared &)
     {
         v = raw;
         if (LEVEL1) {
@@ -124,7 +128,8 @@ struct RecordPolicy {
         if (LEVEL1 && s.hashes)
             return raw.x;
         uint4 v;
-        return finish<false>(s, i, raw, v, true);
+        Shared none;
+        return finish<false>(s, i, raw, v, true, 0u, none);
     }
 };
 
@@ -495,25 +500,65 @@ struct CompactPolicy {
     using Raw = uint4;
     template <bool LEVEL1>
     static __device__ __forceinline__ uint4 fetch(const Source &s, uint32_t i) { return s.in[i]; }
+    // The keys with an N of a tile (a few of 2048) are parked in LDS and leave for the side slabs behind ONE cursor
+    // reservation per workgroup, after the tile itself has left (flush) -- a global atomic with its answer per rare
+    // record, in the middle of the tile's loads, was a round trip on the critical path of four tiles in five.
+    static constexpr uint32_t RARE_CAP = 64;
+    struct Shared {
+        uint32_t n;
+        uint32_t base;
+        uint4 rec[RARE_CAP];
+    };
+    static __device__ __forceinline__ void init_shared(Shared &sh, uint32_t tid)
+    {
+        if (tid == 0)
+            sh.n = 0;
+    }
+    static __device__ __forceinline__ void flush(const Source &s, Shared &sh, uint32_t tid)
+    {
+        __syncthreads();
+        const uint32_t n = min(sh.n, RARE_CAP);
+        if (!n)
+            return;
+        const uint32_t slab = blockIdx.x & (s.side.n_slabs - 1);
+        if (tid == 0)
+            sh.base = atomicAdd(&s.side.cursor[slab], n);
+        __syncthreads();
+        if (tid < n) {
+            const uint32_t pos = sh.base + tid;
+            if (pos < (slab + 1) * s.side.cap)
+                s.side.recs[pos] = sh.rec[tid];
+            else
+                atomicOr(s.side.overflow, 16u);
+        }
+    }
     template <bool LEVEL1>
     static __device__ __forceinline__ uint32_t load(const Source &s, uint32_t i, fqd::Rec12 &v)
     {
-        return finish<LEVEL1>(s, i, s.in[i], v, true);
+        Shared none;
+        none.n = RARE_CAP;           // (no workgroup state here: straight to the slabs)
+        return finish<LEVEL1>(s, i, s.in[i], v, true, 0u, none);
     }
     template <bool LEVEL1>
     static __device__ __forceinline__ uint32_t finish(const Source &s, uint32_t, const uint4 &r, fqd::Rec12 &v, bool valid,
-                                                      uint32_t seg_tag = 0)
+                                                      uint32_t seg_tag, Shared &sh)
     {
         const bool squeeze = s.squeeze == 1;
         const bool rare = squeeze && (r.x & r.y) != 0u;
         if (rare && valid) {
-            // a key with an N (few: one global atomic each, spread over the side slabs by workgroup)
-            const uint32_t slab = blockIdx.x & (s.side.n_slabs - 1);
-            const uint32_t pos = atomicAdd(&s.side.cursor[slab], 1u);
-            if (pos < (slab + 1) * s.side.cap)
-                s.side.recs[pos] = make_uint4(r.x, r.y, r.z, r.w | seg_tag);
-            else
-                atomicOr(s.side.overflow, 16u);
+            const uint4 stamped = make_uint4(r.x, r.y, r.z, r.w | seg_tag);
+            const uint32_t k = atomicAdd(&sh.n, 1u);
+            if (k < RARE_CAP) {
+                sh.rec[k] = stamped;
+            } else {
+                // (more keys with an N in one tile than the parking space holds: one global atomic each)
+                const uint32_t slab = blockIdx.x & (s.side.n_slabs - 1);
+                const uint32_t pos = atomicAdd(&s.side.cursor[slab], 1u);
+                if (pos < (slab + 1) * s.side.cap)
+                    s.side.recs[pos] = stamped;
+                else
+                    atomicOr(s.side.overflow, 16u);
+            }
         }
         // (the item's words as selects, not as assignments on the two sides of the branch above: with 16 items
         // per thread hipcc 7.2 merged those into "id = 0xFFFFFFFF" for every lane and the kernel skipped all items)
@@ -529,7 +574,8 @@ struct CompactPolicy {
     static __device__ __forceinline__ uint32_t key_finish(const Source &s, uint32_t i, const uint4 &raw)
     {
         fqd::Rec12 v;
-        return finish<false>(s, i, raw, v, false);     // (a histogram pass puts nothing on the side path)
+        Shared none;
+        return finish<false>(s, i, raw, v, false, 0u, none);     // (a histogram pass puts nothing on the side path)
     }
 };
 

@@ -46,8 +46,12 @@ struct PairPolicy {
     {
         return LEVEL1 ? make_uint2(s.hashes[i], s.values ? s.values[i] : i) : s.in[i];
     }
+    struct Shared {};
+    static __device__ __forceinline__ void init_shared(Shared &, uint32_t) {}
+    static __device__ __forceinline__ void flush(const Source &, Shared &, uint32_t) {}
     template <bool LEVEL1>
-    static __device__ __forceinline__ uint32_t finish(const Source &, uint32_t, const uint2 &raw, uint2 &v, bool, uint32_t = 0)
+    static __device__ __forceinline__ uint32_t finish(const Source &, uint32_t, const uint2 &raw, uint2 &v, bool, uint32_t,
+                                                      Shared &)
     {
         v = raw;
         return v.x;

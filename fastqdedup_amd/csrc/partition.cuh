@@ -19,6 +19,8 @@
 //   using Raw = ...;                                                                            // scatter pass, two steps:
 //   template <bool LEVEL1> static __device__ Raw fetch(const Source &, uint32_t i);             //   the loads alone (no branch, no side effect)
 //   template <bool LEVEL1> static __device__ uint32_t finish(const Source &, uint32_t i, const Raw &, Item &, bool valid, uint32_t seg_tag);  // -> key
+//   struct Shared { ... };  per-workgroup LDS state of the scatter pass, handed to finish() and, after the tile has
+//   left, to  static __device__ void flush(const Source &, Shared &, uint32_t tid)   (all threads call it)
 //   (the loads of a whole tile must be in flight together: "if (i < hi) { load; hash }" compiles to one branch per
 //   item with s_waitcnt vmcnt(0) inside -- EPT dependent round trips per tile; see tools/isa_skeleton.py. The bodies
 //   below therefore fetch at min(i, hi - 1), unconditionally, and finish afterwards; valid = i < hi)
@@ -166,9 +168,11 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
     __shared__ uint32_t s_wave[THREADS / 64];
     __shared__ Item s_stage[STAGE];
     __shared__ uint16_t s_stage_bin[STAGE];
+    __shared__ typename Policy::Shared s_policy;
     uint32_t seg, lo, hi;
     if (!tile_of_block<TILE>(seg_start, tile_start, n_seg, seg, lo, hi, seg_end))
         return;
+    Policy::init_shared(s_policy, threadIdx.x);       // (visible after the barrier behind the loads)
     const uint32_t seg_tag = Policy::segment_tag(src, seg);       // (per workgroup: a tile lies in ONE segment)
     seg = (seg >> seg_shift) & seg_mask;
     const bool matrix = LEVEL1 && !l1_subs;
@@ -187,7 +191,7 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
 #pragma unroll
         for (uint32_t e = 0; e < EPT; e++) {
             const uint32_t i = lo + e * THREADS + tid;
-            h[e] = Policy::template finish<LEVEL1>(src, min(i, hi - 1), raw[e], v[e], i < hi, seg_tag);
+            h[e] = Policy::template finish<LEVEL1>(src, min(i, hi - 1), raw[e], v[e], i < hi, seg_tag, s_policy);
             Policy::apply_tag(v[e], seg_tag);
         }
     }
@@ -290,6 +294,7 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
         if (ROUNDS > 1)
             __syncthreads();
     }
+    Policy::flush(src, s_policy, tid);
 }
 
 // tile_start[] for the segments seg_start[0..n_seg] (single block; n_seg <= MAX_BINS)
