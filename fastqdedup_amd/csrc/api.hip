@@ -1107,9 +1107,9 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
             p0.mask = route_mask;
             p0.d = c->seg_hint - 1;
             p0.bucket_bits = B;
-            p0.max_rows = 512;
+            p0.max_rows = fqd::pass0_max_rows();
             if (const char *e = getenv("FQD_P0_MAX_ROWS"))         // tests: buckets "too large" for pass 0
-                p0.max_rows = (uint32_t)std::max(1, std::min(512, atoi(e)));
+                p0.max_rows = (uint32_t)std::max(1, std::min((int)fqd::pass0_max_rows(), atoi(e)));
             p0.probe = c->p0_probe.as<uint32_t>();
             p0.edges = c->edges.as<uint32_t>();
             p0.edge_count = c->d_ctr64.as<unsigned long long>() + C64_EDGES;

@@ -758,7 +758,10 @@ __device__ __forceinline__ void rec12_planes(uint32_t squeeze, uint32_t a, uint3
     }
 }
 
-constexpr uint32_t P0_ROWS = 512;   // rows of a bucket a wave holds in LDS for search pass 0 (more: the search does that pass)
+#ifndef FQD_P0_ROWS
+#define FQD_P0_ROWS 512
+#endif
+constexpr uint32_t P0_ROWS = FQD_P0_ROWS;   // rows of a bucket a wave holds in LDS for search pass 0 (more: the search does that pass)
 constexpr uint32_t P0_WCAP = 256;   // edges buffered per wave (it keeps them across its buckets: one atomic on the job's edge counter per flush,
                                     // and ONE word takes ~88 atomics per microsecond -- a flush per bucket, 65 536 of them, was 0.6 ms)
 constexpr uint32_t P0_SIDE_WAVES = 64;   // virtual buckets behind the last one: the segment hashes of the side path's keys
@@ -1304,6 +1307,8 @@ hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t 
         reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, bucket_unique, group_total, pass0, read_ids);
     return hipGetLastError();
 }
+
+uint32_t pass0_max_rows() { return P0_ROWS; }
 
 uint32_t side_table_words(uint32_t table_slots) { return 3 * table_slots + (table_slots + SIDE_BLOCK - 1) / SIDE_BLOCK; }
 

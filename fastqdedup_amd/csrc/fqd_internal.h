@@ -389,6 +389,7 @@ hipError_t launch_part_scatter12(const uint32_t *in /* uint4 records */, uint32_
                                  uint32_t seg_shift, uint32_t route_mask = 0xFFFFFFFFu, uint32_t seg_mask = 0xFFFFFFFFu,
                                  uint32_t stamp_div = 0, uint32_t stamp_shift = 0, const uint32_t *stamp_map = nullptr);
 uint32_t part_tile_size12();
+uint32_t pass0_max_rows();      // rows of a bucket the compaction's search pass 0 takes (Pass0::max_rows at most)
 hipError_t launch_bucket_dedupe12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                   uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
                                   uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st,

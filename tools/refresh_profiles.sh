@@ -1,26 +1,45 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on a GPU box (run through gpurun from the repo root):
 #   tools/refresh_profiles.sh rNN      -> gpurun_out/profiles_rNN/*, to be copied into profiles/
-# Steps are joined so that a failing GPU step ends the script (no further GPU work after a failure).
+# Steps are joined so that a failing GPU step ends the script (no further GPU work after a failure); every step
+# prints a line, so a long run never looks hung.
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
+PART=${2:-all}        # bench | prof | all (two gpurun calls of <= 20 min each: bench, then prof)
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
+if [ "$PART" != "prof" ]; then
 python3 bench.py > $OUT/${R}_bench_config3.json 2> $OUT/bench_config3.err || exit 1
 echo "config3 done"
-for w in config2 config4 config5 config5v; do
+# the long-key shapes WITH the PMC passes (job_roofline.traffic), config 5 / 5v without (their child passes take minutes)
+for w in config2 config4; do
+    python3 bench.py --workload $w > $OUT/${R}_bench_$w.json 2> $OUT/bench_$w.err || exit 1
+    echo "$w done"
+done
+for w in config5 config5v; do
     python3 bench.py --workload $w --no-pmc > $OUT/${R}_bench_$w.json 2> $OUT/bench_$w.err || exit 1
     echo "$w done"
 done
+python3 bench.py --workload config3_skew --no-pmc --steps 5 --warmup 2 > $OUT/${R}_bench_config3_skew.json 2> $OUT/bench_skew.err || exit 1
+echo "config3_skew done"
 python3 bench.py --force-sharded --no-pmc --no-cpu-baseline --no-host-input --warmup 8 > $OUT/${R}_bench_config3_sharded_world1.json 2> $OUT/bench_sharded.err || exit 1
 echo "sharded done"
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o r -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-input --no-pmc --no-copy-peak > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1) || exit 1
-cp $OUT/prof/r_kernel_stats.csv $OUT/${R}_kernel_stats_bench_config3.csv
-echo "rocprof config3 done"
+fi
+[ "$PART" = "bench" ] && exit 0
+for w in config3 config2 config4 config3_skew; do
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_$w -o r -- python3 $GRAFT_REPO_ROOT/bench.py --workload $w --steps 10 --no-cpu-baseline --no-host-input --no-pmc --no-copy-peak > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_$w.log 2>&1) || exit 1
+    cp $OUT/prof_$w/r_kernel_stats.csv $OUT/${R}_kernel_stats_bench_$w.csv
+    rm -rf $OUT/prof_$w
+    echo "rocprof $w done"
+done
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof5v -o r -- python3 $GRAFT_REPO_ROOT/bench.py --workload config5v --reads-per-gpu 10000000 --no-cpu-baseline --no-host-input --no-pmc --no-copy-peak --steps 5 --warmup 1 > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_5v.log 2>&1) || exit 1
 cp $OUT/prof5v/r_kernel_stats.csv $OUT/${R}_kernel_stats_bench_config5v_10M.csv
+rm -rf $OUT/prof5v
 echo "rocprof config5v (10 M ragged reads) done"
-python3 tools/pmc_per_kernel.py --workload config3 --out $OUT/${R}_pmc_per_kernel_config3.json > /dev/null 2> $OUT/pmc.err || exit 1
-echo "pmc done"
-rm -rf $OUT/prof $OUT/prof5v
+for w in config3 config2 config4; do
+    python3 tools/pmc_per_kernel.py --workload $w --out $OUT/${R}_pmc_per_kernel_$w.json > /dev/null 2> $OUT/pmc_$w.err || exit 1
+    echo "pmc $w done"
+done
+python3 tools/sq_per_kernel.py --workload config3 --out $OUT/${R}_sq_per_kernel_config3.json > /dev/null 2> $OUT/sq.err || exit 1
+echo "sq done"
