@@ -406,8 +406,16 @@ class _Comm:
         if self.alone:
             return
         if self.lib_streams is not None:
+            # Ordering by stream waits alone relies on torch's work being queued on ITS current stream being the
+            # legacy default stream, against which the library's (blocking) stream is ordered as well: temporaries
+            # such as edges.contiguous() handed to an import are then not reused by torch's allocator before the
+            # library's copy has run. A caller inside `with torch.cuda.stream(side)` would break that silently.
+            cur = torch.cuda.current_stream(self.device)
+            if cur.cuda_stream != torch.cuda.default_stream(self.device).cuda_stream:
+                raise RuntimeError("fastqdedup_amd.sharded: run the plan on torch's default stream (the library's "
+                                   "stream is ordered against it; another current stream is not)")
             for st in self.lib_streams():
-                st.wait_stream(torch.cuda.current_stream(self.device))
+                st.wait_stream(cur)
         elif self.device.type == "cuda" and not self.via_host:
             torch.cuda.current_stream(self.device).synchronize()
 
