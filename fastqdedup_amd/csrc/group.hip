@@ -669,7 +669,7 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
 // differ inside one piece j* and meet in the items of j* only -- groups are as small as "keys equal outside one
 // piece", every pair is proposed once. The verification keeps a pair iff the FIRST main segment it agrees on falls
 // into a crowded bucket (else the main pass of that segment has reported it).
-constexpr uint32_t GP_FINE = 8;
+constexpr uint32_t GP_FINE = 16;    // (8: the ladder of the skewed workload made groups of 256 keys, 16.7 M candidates, 3 ms of verification)
 
 __global__ void gp_mark_crowded_kernel(const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ bucket_end,
                                        uint32_t n_buckets, uint32_t limit, uint8_t *__restrict__ crowded,
@@ -752,43 +752,66 @@ __global__ __launch_bounds__(256) void gp_verify_refined_kernel(
     if (part == 0 && threadIdx.x == 0 && filled > cand_cap)
         atomicMax(cand_need, filled * GP_LISTS);
     cands += (size_t)list * cand_cap;
-    for (unsigned long long idx = (unsigned long long)part * blockDim.x + threadIdx.x; idx < total;
-         idx += (unsigned long long)parts * blockDim.x) {
-        const uint2 pr = cands[idx];
-        const uint32_t ja = pr.x >> 28, jb = pr.y >> 28, ua = pr.x & 0x0FFFFFFFu, ub = pr.y & 0x0FFFFFFFu;
-        if (ja != jb || ua == ub)
-            continue;
-        const uint32_t len = fqd_key_len(sh, ulens, ua);
-        if (fqd_key_len(sh, ulens, ub) != len)
-            continue;
-        const uint32_t *ra = urecs + (uint64_t)ua * sh.stride, *rb = urecs + (uint64_t)ub * sh.stride;
-        uint32_t dist = 0, pos = 0;
-        for (uint32_t w = 0; w < sh.words && dist <= 1; w++) {
+    // four candidates per thread and sweep: the candidates, then both records' first words of all four, are requested
+    // together (clamped, unconditional)
+    constexpr uint32_t VR = 4;
+    for (unsigned long long base = (unsigned long long)part * blockDim.x * VR; base < total;
+         base += (unsigned long long)parts * blockDim.x * VR) {
+        uint2 pr[VR];
+        bool live[VR];
+#pragma unroll
+        for (uint32_t t = 0; t < VR; t++) {
+            const unsigned long long idx = base + (unsigned long long)t * blockDim.x + threadIdx.x;
+            live[t] = idx < total;
+            pr[t] = cands[idx < total ? idx : total - 1];
+        }
+        uint32_t dw0[VR];
+#pragma unroll
+        for (uint32_t t = 0; t < VR; t++) {
+            const uint32_t ua = pr[t].x & 0x0FFFFFFFu, ub = pr[t].y & 0x0FFFFFFFu;
+            const uint32_t *ra = urecs + (uint64_t)ua * sh.stride, *rb = urecs + (uint64_t)ub * sh.stride;
             uint32_t dw = 0;
             for (uint32_t k = 0; k < sh.planes; k++)
-                dw |= ra[w * sh.planes + k] ^ rb[w * sh.planes + k];
-            if (dw) {
-                dist += __popc(dw);
-                pos = w * 32u + (uint32_t)(__ffs((int)dw) - 1);
-            }
+                dw |= ra[k] ^ rb[k];
+            dw0[t] = dw;
         }
-        if (dist != 1)
-            continue;
-        // the one differing position must lie in the piece both items left out (else: a hash collision)
-        if (!(pos >= len * ja / GP_FINE && pos < len * (ja + 1) / GP_FINE))
-            continue;
-        // the first main segment the pair agrees on: segment 0 unless the difference lies there
-        uint32_t slo, shi;
-        fqd_segment(len, 0, nseg, slo, shi);
-        const uint32_t first = (pos >= slo && pos < shi) ? 1u : 0u;
-        if (first >= nseg)
-            continue;                                  // (nseg == 1: no segment agrees)
-        if (!crowded[seg_hashes[(size_t)first * U + ua] >> (32u - bucket_bits)])
-            continue;                                  // the main pass of that segment has it
-        const unsigned long long at = atomicAdd(edge_count, 1ull);
-        if (at < edge_cap) {
-            edges[2 * at] = min(ua, ub);
-            edges[2 * at + 1] = max(ua, ub);
+#pragma unroll
+        for (uint32_t t = 0; t < VR; t++) {
+            const uint32_t ja = pr[t].x >> 28, jb = pr[t].y >> 28, ua = pr[t].x & 0x0FFFFFFFu, ub = pr[t].y & 0x0FFFFFFFu;
+            if (!live[t] || ja != jb || ua == ub)
+                continue;
+            const uint32_t len = fqd_key_len(sh, ulens, ua);
+            if (fqd_key_len(sh, ulens, ub) != len)
+                continue;
+            const uint32_t *ra = urecs + (uint64_t)ua * sh.stride, *rb = urecs + (uint64_t)ub * sh.stride;
+            uint32_t dist = __popc(dw0[t]), pos = dw0[t] ? (uint32_t)(__ffs((int)dw0[t]) - 1) : 0u;
+            for (uint32_t w = 1; w < sh.words && dist <= 1; w++) {
+                uint32_t dw = 0;
+                for (uint32_t k = 0; k < sh.planes; k++)
+                    dw |= ra[w * sh.planes + k] ^ rb[w * sh.planes + k];
+                if (dw) {
+                    dist += __popc(dw);
+                    pos = w * 32u + (uint32_t)(__ffs((int)dw) - 1);
+                }
+            }
+            if (dist != 1)
+                continue;
+            // the one differing position must lie in the piece both items left out (else: a hash collision)
+            if (!(pos >= len * ja / GP_FINE && pos < len * (ja + 1) / GP_FINE))
+                continue;
+            // the first main segment the pair agrees on: segment 0 unless the difference lies there
+            uint32_t slo, shi;
+            fqd_segment(len, 0, nseg, slo, shi);
+            const uint32_t first = (pos >= slo && pos < shi) ? 1u : 0u;
+            if (first >= nseg)
+                continue;                                  // (nseg == 1: no segment agrees)
+            if (!crowded[seg_hashes[(size_t)first * U + ua] >> (32u - bucket_bits)])
+                continue;                                  // the main pass of that segment has it
+            const unsigned long long at = atomicAdd(edge_count, 1ull);
+            if (at < edge_cap) {
+                edges[2 * at] = min(ua, ub);
+                edges[2 * at + 1] = max(ua, ub);
+            }
         }
     }
 }
