@@ -321,10 +321,22 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                                                                c->ld_tmp_rec.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
                                                                c->d_ctr32.as<uint32_t>() + C_BAD, c->st, group_total));
         else
-        KTIME(c, FQD_K_DEDUPE, fqd::launch_bucket_dedupe(parted, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
-                                             c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(),
-                                             c->ld_tmp_first.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
-                                             c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+        {
+            // (exact bucket sizes: a key with very many copies is one huge bucket -- cut into chunks, see fqd::HugeBuckets)
+            fqd::HugeBuckets huge;
+            if (!bucket_end && !getenv("FQD_NO_HUGE_BUCKETS")) {
+                const size_t nv = (size_t)FQD_HUGE_MAX * FQD_HUGE_CHUNKS;
+                HIP_TRY(c, c->ld_huge.reserve(((size_t)n_buckets + 63) / 64 * 64 + (3 * nv + 4) * 4 + 64));
+                huge.slot = c->ld_huge.as<uint8_t>();
+                huge.vlo = reinterpret_cast<uint32_t *>(huge.slot + ((size_t)n_buckets + 63) / 64 * 64);
+                huge.vhi = huge.vlo + nv;
+                huge.vunique = huge.vhi + nv;
+            }
+            KTIME(c, FQD_K_DEDUPE, fqd::launch_bucket_dedupe(parted, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
+                                                 c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(),
+                                                 c->ld_tmp_first.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
+                                                 c->d_ctr32.as<uint32_t>() + C_BAD, c->st, huge));
+        }
         if (!group_total)
             FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
         if (side_pending) {                // (the read-back below takes the side path's count and flag too)

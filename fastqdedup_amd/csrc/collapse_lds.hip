@@ -236,19 +236,55 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe_kernel(
     const uint4 *__restrict__ part, const uint32_t *__restrict__ bucket_start /* n_buckets + 1 */,
     const uint32_t *__restrict__ bucket_end /* NULL, or slab mode: where each bucket's cursor stopped */,
     const uint32_t *__restrict__ weights, uint4 *__restrict__ tmp_rec, uint32_t *__restrict__ tmp_count,
-    uint32_t *__restrict__ tmp_first, uint32_t *__restrict__ bucket_unique, uint32_t *__restrict__ overflow)
+    uint32_t *__restrict__ tmp_first, uint32_t *__restrict__ bucket_unique, uint32_t *__restrict__ overflow,
+    fqd::HugeBuckets huge)
 {
     __shared__ uint32_t s_tag[DD_SLOTS], s_x[DD_SLOTS], s_y[DD_SLOTS], s_z[DD_SLOTS], s_cnt[DD_SLOTS], s_min[DD_SLOTS];
     __shared__ uint32_t s_wave_tot[DD_THREADS / 64];
+    __shared__ uint32_t s_chunk[FQD_HUGE_CHUNKS + 1];       // huge bucket, second pass: where each chunk's rows start
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
-    const uint32_t lo = bucket_start[b];
-    uint32_t hi = bucket_start[b + 1];
-    if (bucket_end)
+    // huge.mode 1: the workgroup takes CHUNK b of a huge bucket ([huge.vlo[b], huge.vhi[b]), rows to tmp[vlo ...), their
+    // number to huge.vunique[b]); mode 2: a bucket marked in huge.slot reads the ROWS its chunks left -- (key, count,
+    // first index) triples -- instead of its reads: a key with a million copies is then streamed by FQD_HUGE_CHUNKS
+    // workgroups side by side and merged by one (it was ONE workgroup's 4.4 ms).
+    const bool chunk_pass = huge.mode == 1;
+    uint32_t lo = chunk_pass ? huge.vlo[b] : bucket_start[b];
+    uint32_t hi = chunk_pass ? huge.vhi[b] : bucket_start[b + 1];
+    if (!chunk_pass && bucket_end)
         hi = min(hi, bucket_end[b]);
+    const uint32_t hslot = huge.mode == 2 && huge.slot ? huge.slot[b] : 0u;
+    const uint32_t out_lo = lo;
+    if (hslot) {
+        // logical positions 0 .. rows of all chunks: chunk c's rows lie at tmp[vlo[c] ...)
+        if (tid == 0) {
+            uint32_t acc = 0;
+            for (uint32_t c = 0; c < FQD_HUGE_CHUNKS; c++) {
+                s_chunk[c] = acc;
+                acc += huge.vunique[(hslot - 1) * FQD_HUGE_CHUNKS + c];
+            }
+            s_chunk[FQD_HUGE_CHUNKS] = acc;
+        }
+    }
     for (uint32_t s = tid; s < DD_SLOTS; s += DD_THREADS)
         s_tag[s] = DD_EMPTY;
     __syncthreads();
+    if (hslot) {
+        lo = 0;
+        hi = s_chunk[FQD_HUGE_CHUNKS];
+    }
+    // (second pass over a huge bucket) logical position -> the row's place in tmp
+    auto row_at = [&](uint32_t p) {
+        uint32_t a = 0, z = FQD_HUGE_CHUNKS;        // last chunk with s_chunk[a] <= p
+        while (z - a > 1) {
+            const uint32_t m = (a + z) >> 1;
+            if (s_chunk[m] <= p)
+                a = m;
+            else
+                z = m;
+        }
+        return huge.vlo[(hslot - 1) * FQD_HUGE_CHUNKS + a] + (p - s_chunk[a]);
+    };
 
     bool full = false;
     // Four 256-read chunks are fetched before the first one is hashed: a bucket (~760 reads) then
@@ -262,13 +298,22 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe_kernel(
       for (uint32_t k = 0; k < DD_AHEAD; k++) {
           const uint32_t i = base0 + k * DD_THREADS + tid;
           ahead[k] = make_uint4(0, 0, 0, 0);
-          if (i < hi)
+          ahead_w[k] = 0;
+          if (i < hi && !hslot)
               ahead[k] = part[i];
+          if (i < hi && hslot) {
+              const uint32_t at = row_at(i);
+              ahead[k] = tmp_rec[at];
+              ahead[k].w = tmp_first[at];
+              ahead_w[k] = tmp_count[at];
+          }
       }
+      if (!hslot) {
 #pragma unroll
-      for (uint32_t k = 0; k < DD_AHEAD; k++) {
-          const uint32_t i = base0 + k * DD_THREADS + tid;
-          ahead_w[k] = i < hi ? (weights ? weights[ahead[k].w] : 1u) : 0u;
+          for (uint32_t k = 0; k < DD_AHEAD; k++) {
+              const uint32_t i = base0 + k * DD_THREADS + tid;
+              ahead_w[k] = i < hi ? (weights ? weights[ahead[k].w] : 1u) : 0u;
+          }
       }
       // All DD_AHEAD records of the thread go through the table TOGETHER: a round is "claim an
       // empty slot or stop at a slot whose tag matches" for every pending record, a barrier (the
@@ -288,7 +333,7 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe_kernel(
       // 10^6 copies. There the wave first merges its equal records: the first lane of a key keeps it with the summed
       // weight and the smallest read index, the others drop out. (A loop per DISTINCT key of the wave: not for
       // ordinary buckets, whose 64 records are 64 keys.)
-      if (hi - lo > DD_HUGE) {
+      if (hi - lo > DD_HUGE || chunk_pass) {
 #pragma unroll
           for (uint32_t k = 0; k < DD_AHEAD; k++) {
               unsigned long long left = __ballot(pending[k]);
@@ -368,10 +413,11 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe_kernel(
     __syncthreads();
 
     // compact the live slots (count > 0: a key all of whose holders have weight 0 is not
-    // in the trie) to tmp[lo ...): unique keys <= reads of the bucket, so they fit
+    // in the trie) to tmp[lo ...): unique keys <= reads of the bucket, so they fit. (A CHUNK of a huge bucket keeps
+    // its weight-0 rows: their read index may be the key's first holder -- the merge decides.)
     uint32_t mine = 0;
     for (uint32_t s = tid; s < DD_SLOTS; s += DD_THREADS)
-        mine += (s_tag[s] != DD_EMPTY && s_cnt[s] > 0) ? 1u : 0u;
+        mine += (s_tag[s] != DD_EMPTY && (s_cnt[s] > 0 || chunk_pass)) ? 1u : 0u;
     uint32_t incl = mine;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t up = __shfl_up(incl, o);
@@ -387,16 +433,53 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe_kernel(
     uint32_t total = 0;
     for (uint32_t wv = 0; wv < DD_THREADS / 64; wv++)
         total += s_wave_tot[wv];
-    uint32_t out = lo + before;
+    uint32_t out = out_lo + before;
     for (uint32_t s = tid; s < DD_SLOTS; s += DD_THREADS)
-        if (s_tag[s] != DD_EMPTY && s_cnt[s] > 0) {
+        if (s_tag[s] != DD_EMPTY && (s_cnt[s] > 0 || chunk_pass)) {
             tmp_rec[out] = make_uint4(s_x[s], s_y[s], s_z[s], 0u);
             tmp_count[out] = s_cnt[s];
             tmp_first[out] = s_min[s];
             out++;
         }
     if (tid == 0)
-        bucket_unique[b] = total;
+        (chunk_pass ? huge.vunique : bucket_unique)[b] = total;
+}
+
+// buckets of more than DD_HUGE reads (exact bucket sizes): up to FQD_HUGE_MAX of them are cut into FQD_HUGE_CHUNKS
+// chunks each (multiples of 1024 reads) for bucket_dedupe_kernel's chunk pass
+__global__ void huge_plan_kernel(const uint32_t *__restrict__ bucket_start, uint32_t n_buckets, fqd::HugeBuckets huge,
+                                 uint32_t *__restrict__ n_huge)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_buckets)
+        return;
+    const uint32_t lo = bucket_start[b], hi = bucket_start[b + 1];
+    uint32_t slot = 0;
+    if (hi - lo > DD_HUGE) {
+        const uint32_t h = atomicAdd(n_huge, 1u);
+        if (h < FQD_HUGE_MAX) {
+            slot = h + 1;
+            const uint32_t per = (((hi - lo) + FQD_HUGE_CHUNKS - 1) / FQD_HUGE_CHUNKS + 1023u) & ~1023u;
+            for (uint32_t c = 0; c < FQD_HUGE_CHUNKS; c++) {
+                huge.vlo[h * FQD_HUGE_CHUNKS + c] = min(lo + c * per, hi);
+                huge.vhi[h * FQD_HUGE_CHUNKS + c] = min(lo + (c + 1) * per, hi);
+            }
+        }
+    }
+    huge.slot[b] = (uint8_t)slot;
+}
+
+// (the chunks of slots nobody took: empty)
+__global__ void huge_clear_kernel(fqd::HugeBuckets huge, uint32_t *__restrict__ n_huge)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < FQD_HUGE_MAX * FQD_HUGE_CHUNKS) {
+        huge.vlo[v] = 0;
+        huge.vhi[v] = 0;
+        huge.vunique[v] = 0;
+    }
+    if (v == 0)
+        *n_huge = 0;
 }
 
 // one wave per bucket: tmp[bucket_start[b] + j] -> out[uoff[b] + j], j < unique count
@@ -1241,12 +1324,26 @@ hipError_t launch_slab_tile_starts(const uint32_t *seg_start, const uint32_t *se
 
 hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                 uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec, uint32_t *tmp_count,
-                                uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st)
+                                uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st,
+                                HugeBuckets huge)
 {
-    bucket_dedupe_kernel<<<n_buckets, DD_THREADS, 0, st>>>(reinterpret_cast<const uint4 *>(part), bucket_start, bucket_end,
-                                                           weights,
-                                                           reinterpret_cast<uint4 *>(tmp_rec), tmp_count, tmp_first,
-                                                           bucket_unique, overflow);
+    const uint4 *part4 = reinterpret_cast<const uint4 *>(part);
+    uint4 *tmp4 = reinterpret_cast<uint4 *>(tmp_rec);
+    if (huge.slot && !bucket_end) {
+        // exact bucket sizes (a context that has met overfull slabs): huge buckets in chunks first
+        uint32_t *n_huge = huge.vunique + FQD_HUGE_MAX * FQD_HUGE_CHUNKS;
+        huge_clear_kernel<<<(FQD_HUGE_MAX * FQD_HUGE_CHUNKS + 255) / 256, 256, 0, st>>>(huge, n_huge);
+        huge_plan_kernel<<<(n_buckets + 255) / 256, 256, 0, st>>>(bucket_start, n_buckets, huge, n_huge);
+        huge.mode = 1;
+        bucket_dedupe_kernel<<<FQD_HUGE_MAX * FQD_HUGE_CHUNKS, DD_THREADS, 0, st>>>(part4, bucket_start, nullptr, weights, tmp4,
+                                                                                   tmp_count, tmp_first, bucket_unique,
+                                                                                   overflow, huge);
+        huge.mode = 2;
+    } else {
+        huge = HugeBuckets();
+    }
+    bucket_dedupe_kernel<<<n_buckets, DD_THREADS, 0, st>>>(part4, bucket_start, bucket_end, weights, tmp4, tmp_count,
+                                                           tmp_first, bucket_unique, overflow, huge);
     return hipGetLastError();
 }
 

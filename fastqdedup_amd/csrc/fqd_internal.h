@@ -366,9 +366,19 @@ hipError_t launch_slab_starts3(uint32_t n1, uint32_t cap1, uint32_t *start1, uin
                                uint32_t *cursor3, hipStream_t st, uint32_t n_zero = 0, uint32_t *zero = nullptr,
                                uint32_t *zero_b = nullptr, uint32_t last_b = 0, uint32_t *zero_c = nullptr,
                                uint32_t last_c = 0);   // zero[0 .. n_zero], zero_b[0 .. last_b], zero_c[0 .. last_c] = 0
+// Buckets of the uint4 dedupe that hold tens of thousands of reads and more (ONE key with very many copies): cut into
+// chunks that workgroups reduce side by side, their rows merged by the bucket's own workgroup (collapse_lds.hip)
+#define FQD_HUGE_MAX 32        // huge buckets handled that way per launch (the others: one workgroup each, as before)
+#define FQD_HUGE_CHUNKS 64     // chunks per huge bucket
+struct HugeBuckets {
+    uint8_t *slot = nullptr;       // [n_buckets]: 0, or 1 + the bucket's number among the huge ones
+    uint32_t *vlo = nullptr, *vhi = nullptr, *vunique = nullptr;   // [FQD_HUGE_MAX * FQD_HUGE_CHUNKS] (+ 1 counter behind vunique)
+    uint32_t mode = 0;             // set by launch_bucket_dedupe
+};
 hipError_t launch_bucket_dedupe(const uint32_t *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                 uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec, uint32_t *tmp_count,
-                                uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st);
+                                uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st,
+                                HugeBuckets huge = HugeBuckets());
 hipError_t launch_bucket_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                  const uint32_t *tmp_rec, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                  IdSource read_ids, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
