@@ -74,8 +74,10 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
         // parent[x] meanwhile (a root is never un-rooted except by hooking it under a smaller node, and every value
         // ever stored is an ancestor), so the worst a lost race does is keep a longer path. An atomicMin here put
         // one read-modify-write per step on the few lines at the top of a giant component's tree.
+#ifndef FQD_UF_NO_HALVING
         if (g != p)
             __hip_atomic_store(&parent[x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         x = p;
         p = g;
     }
