@@ -796,7 +796,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void kept_bin_ker
         s_hist[b] = 0;
     __syncthreads();
     uint32_t off[KB_KPT], rank[KB_KPT];
-    uint32_t total = 0, listed_mask = 0;
+    uint32_t total = 0, listed_mask = 0, ask = 0;
     // two halves of GROUPS / 2 groups: the loads of a half are all in flight before its first verdict (all GROUPS at
     // once needed 66 VGPRs -- two registers too many for two 1024-thread workgroups per CU)
     constexpr uint32_t HALF = GROUPS >= 2 ? GROUPS / 2 : 1;
@@ -824,8 +824,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void kept_bin_ker
             for (uint32_t j = 0; j < 4; j++) {
                 const uint32_t st = (st4[h] >> (8 * j)) & 0xFFu;
                 k[j] = METHOD == 1 ? st == 1 : st == 0;
-                if (METHOD == 3 && (st & 8) && vb + j < U)     // (few) a member of a set of count-1 keys asks its root
-                    k[j] = kept_verdict(3, (uint32_t)(vb + j), labels, best, state, ucounts, parent1, root_taint);
+                if (METHOD == 3 && (st & 8) && vg == vb && vb + j < U)
+                    ask |= 1u << (g * 4 + j);      // (few) a member of a set of count-1 keys asks its root: below
             }
         } else {
 #pragma unroll
@@ -855,6 +855,28 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void kept_bin_ker
         }
     }
   }
+    // the keys that have to ask their set's root (directional, closed form: state bit 8), one by one -- their walk's
+    // registers do not ride along in the loop above
+    while (ask) {
+        const uint32_t e = (uint32_t)__ffs((int)ask) - 1u;
+        ask &= ask - 1u;
+        const uint64_t v = v0 + ((uint64_t)(e >> 2) * THREADS + tid) * 4 + (e & 3u);
+        if (kept_verdict(3, (uint32_t)v, labels, best, state, ucounts, parent1, root_taint)) {
+            kept[v] = 1;
+            total++;
+            const uint64_t id = ufirst[v];
+            if (id >= id_lo && id - id_lo < window) {
+                const uint32_t o = (uint32_t)(id - id_lo), r = atomicAdd(&s_hist[o >> bin_shift], 1u);
+#pragma unroll
+                for (uint32_t q = 0; q < KB_KPT; q++)      // (compile-time indices: the arrays stay in registers)
+                    if (q == e) {
+                        off[q] = o;
+                        rank[q] = r;
+                    }
+                listed_mask |= 1u << e;
+            }
+        }
+    }
     __syncthreads();
     // exclusive scan of the bin counts (n_bins <= KB_MAX_BINS: BPT consecutive bins per thread) + one reservation per bin
     uint32_t cnt[BPT], mine = 0;
@@ -889,7 +911,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void kept_bin_ker
         gb[q] = 0;
         if (b < n_bins) {
             s_off[b] = run;
-            gb[q] = cnt[q] ? (((b * KB_SUBS + sub) << bin_shift) + atomicAdd(&cursor[b * KB_SUBS + sub], cnt[q])) : 0u;
+            gb[q] = cnt[q] ? atomicAdd(&cursor[b * KB_SUBS + sub], cnt[q]) : 0u;     // (counts from 0: the list's start is added below)
         }
         run += cnt[q];
     }
@@ -901,7 +923,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void kept_bin_ker
 #pragma unroll
     for (uint32_t q = 0; q < BPT; q++)
         if (tid * BPT + q < n_bins)
-            s_base[tid * BPT + q] = gb[q] - at[q];
+            s_base[tid * BPT + q] = (((tid * BPT + q) * KB_SUBS + sub) << bin_shift) + gb[q] - at[q];
     __syncthreads();
     for (uint32_t p = tid; p < listed; p += THREADS) {
         const uint32_t o = s_stage[p];
