@@ -586,7 +586,7 @@ struct CompactPolicy {
     // The keys with an N of a tile (a few of 2048) are parked in LDS and leave for the side slabs behind ONE cursor
     // reservation per workgroup, after the tile itself has left (flush) -- a global atomic with its answer per rare
     // record, in the middle of the tile's loads, was a round trip on the critical path of four tiles in five.
-    static constexpr uint32_t RARE_CAP = 64;
+    static constexpr uint32_t RARE_CAP = 32;     // (64 made the kernel 32 800 B of LDS: four workgroups per CU instead of five)
     struct Shared {
         uint32_t n;
         uint32_t base;
@@ -671,15 +671,15 @@ __global__ __launch_bounds__(1024) void slab_tile_starts12_kernel(const uint32_t
                                                                                      tile_start);
 }
 
-template <uint32_t MAXB>
+template <uint32_t MAXB, uint32_t NT = 1>
 __global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter12_kernel(
     CompactPolicy::Source src, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ tile_start,
     uint32_t n_seg, uint32_t shift, uint32_t n_bins, uint32_t *__restrict__ cursor, fqd::Rec12 *__restrict__ out,
     uint32_t slab_cap, uint32_t *__restrict__ slab_overflow, const uint32_t *__restrict__ seg_end, uint32_t seg_shift,
     uint32_t seg_mask)
 {
-    fqd_partition::scatter_body<CompactPolicy, false, MAXB>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
-                                                            slab_cap, slab_overflow, seg_end, seg_shift, seg_mask);
+    fqd_partition::scatter_body<CompactPolicy, false, MAXB, NT>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
+                                                                slab_cap, slab_overflow, seg_end, seg_shift, seg_mask);
 }
 
 __device__ __forceinline__ uint32_t rec12_tag(uint32_t a, uint32_t b)
@@ -1362,6 +1362,8 @@ hipError_t launch_part_scatter12(const uint32_t *in, uint32_t squeeze, SideSlabs
         return hipErrorInvalidValue;
     const CompactPolicy::Source src{reinterpret_cast<const uint4 *>(in), squeeze, side, route_mask ? route_mask : 0xFFFFFFFFu,
                                     stamp_div, stamp_shift, stamp_map};
+    // (a workgroup taking TWO consecutive tiles of a slab, both tiles' loads requested up front -- scatter_body's NT --
+    // was measured: 0.426 against 0.390 ms; 98 VGPRs, four workgroups per CU instead of five)
     if (n_bins <= 256)
         part_scatter12_kernel<256><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
             src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end, seg_shift,

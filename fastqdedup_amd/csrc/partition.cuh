@@ -127,7 +127,7 @@ __device__ __forceinline__ void hist_body(const typename Policy::Source &src, co
 
 // LEVEL1: cursor = inclusive scan of the (bin x tile) count matrix. Level 2: cursor[seg * n_bins + b]
 // = next free position of that bucket (one atomic per (tile, bin)).
-template <class Policy, bool LEVEL1, uint32_t MAXB = MAX_BINS>
+template <class Policy, bool LEVEL1, uint32_t MAXB = MAX_BINS, uint32_t NT = 1>
 __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
                                              const uint32_t *__restrict__ seg_start,
                                              const uint32_t *__restrict__ tile_start, uint32_t n_seg, uint32_t shift,
@@ -170,7 +170,7 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
     __shared__ uint16_t s_stage_bin[STAGE];
     __shared__ typename Policy::Shared s_policy;
     uint32_t seg, lo, hi;
-    if (!tile_of_block<TILE>(seg_start, tile_start, n_seg, seg, lo, hi, seg_end))
+    if (!tile_of_block<TILE * NT>(seg_start, tile_start, n_seg, seg, lo, hi, seg_end))
         return;
     Policy::init_shared(s_policy, threadIdx.x);       // (visible after the barrier behind the loads)
     const uint32_t seg_tag = Policy::segment_tag(src, seg);       // (per workgroup: a tile lies in ONE segment)
@@ -179,19 +179,34 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
     if (LEVEL1 && l1_subs)
         seg = blockIdx.x & (l1_subs - 1);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // NT tiles per workgroup (NT = 2: the collapse's level 2): the loads of ALL of them are requested up front, so
+    // the second tile's bytes travel while the first one goes through its LDS phases and its stores -- a workgroup
+    // that loads, sorts and stores one tile has nothing in flight two thirds of the time. Both tiles lie in one
+    // segment: same bins, same cursors.
+    const uint32_t all_lo = lo, all_hi = hi;
+    typename Policy::Raw raw_all[NT][EPT];
+#pragma unroll
+    for (uint32_t k = 0; k < NT; k++)
+#pragma unroll
+        for (uint32_t e = 0; e < EPT; e++)      // every load in flight: clamped indices, no branch
+            raw_all[k][e] = Policy::template fetch<LEVEL1>(src, min(all_lo + (k * EPT + e) * THREADS + threadIdx.x, all_hi - 1));
+#pragma unroll
+  for (uint32_t tile_k = 0; tile_k < NT; tile_k++) {
+    lo = all_lo + tile_k * TILE;
+    if (lo >= all_hi)
+        break;                                   // (the same for every thread of the workgroup)
+    hi = min(lo + TILE, all_hi);
+    if (tile_k)
+        __syncthreads();                         // (the tables of the tile before have been read)
     for (uint32_t b = tid; b < n_bins; b += THREADS)
         s_hist[b] = 0;
     Item v[EPT];
     uint32_t h[EPT], bin[EPT], rank[EPT];
     {
-        typename Policy::Raw raw[EPT];
-#pragma unroll
-        for (uint32_t e = 0; e < EPT; e++)      // every load of the tile in flight: clamped indices, no branch
-            raw[e] = Policy::template fetch<LEVEL1>(src, min(lo + e * THREADS + tid, hi - 1));
 #pragma unroll
         for (uint32_t e = 0; e < EPT; e++) {
             const uint32_t i = lo + e * THREADS + tid;
-            h[e] = Policy::template finish<LEVEL1>(src, min(i, hi - 1), raw[e], v[e], i < hi, seg_tag, s_policy);
+            h[e] = Policy::template finish<LEVEL1>(src, min(i, hi - 1), raw_all[tile_k][e], v[e], i < hi, seg_tag, s_policy);
             Policy::apply_tag(v[e], seg_tag);
         }
     }
@@ -294,6 +309,7 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
         if (ROUNDS > 1)
             __syncthreads();
     }
+  }
     Policy::flush(src, s_policy, tid);
 }
 
