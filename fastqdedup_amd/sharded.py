@@ -41,6 +41,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 
 import os
+import sys
 import time
 
 import numpy as np
@@ -550,6 +551,11 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
                                                                   int(sum(recv_counts)), n_seg)
                     if comm.any_flag(n_unique_local is None):
                         n_unique_local = None      # a bucket overflowed somewhere: once more, the general way
+                        if os.environ.get("FQD_DEBUG") or os.environ.get("FQD_SHARD_TIMING"):
+                            # (at 5-8 ranks an owner's level 2 has 2^15 buckets at most -- ~1500 reads each at 50 M
+                            # received reads: mostly-unique data overfills the dedupe's 1024-slot table)
+                            print(f"[fqd] rank {rank}: the owner-slab collapse gave up (a bucket's table or a slab was "
+                                  f"full somewhere); all ranks repeat the way in the general way", file=sys.stderr)
                     if tick:
                         tick.mark("collapse")
                 del send, scur, recv, rcur
