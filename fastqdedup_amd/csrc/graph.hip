@@ -86,48 +86,64 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
 
 // n_hooks (may be NULL; FQD_HOOK_SLOTS x 8 words, summed by the host) += successful hooks: every hook merges two components, so
 // components = nodes - hooks without a sweep over the nodes.
-__global__ void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ edges, uint64_t E,
-                                unsigned long long *n_hooks)
+__global__ __launch_bounds__(256) void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ edges, uint64_t E,
+                                                       unsigned long long *n_hooks)
 {
+    // The lanes of a wave hook TOGETHER: lanes that are about to hang the same root under the same node send ONE
+    // compare-and-swap (the lowest such lane does; the others read its answer from LDS). In a component of tens of
+    // thousands of keys the last few roots are every lane's target at once, and compare-and-swaps on ONE word are
+    // served at ~88 per microsecond: the 786 K edges of the skewed workload's 65 536-key component took 1.6-3.4 ms.
+    // For ordinary data (components of two or three keys) every lane is its own leader: one round, a few LDS
+    // instructions more than before.
+    __shared__ uint32_t s_slot[4][128], s_res[4][64];
+    const uint32_t lane = fqd_lane(), wave = threadIdx.x >> 6;
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool hooked = false;
+    uint32_t a = 0, b = 0;
     if (e < E) {
         const uint2 uv = reinterpret_cast<const uint2 *>(edges)[e];
-        uint32_t a = uv.x, b = uv.y;
-        // the first parent of both ends in flight together (most ends are still their own roots: the two
-        // dependent round trips of find(a); find(b) become one)
-        // (cached loads, like the first walk below: a stale "is its own root" only makes the compare-and-swap fail)
-        const uint32_t pa = parent[a], pb = parent[b];
-        if (pa == a && pb == b && a != b) {
-            const uint32_t lo = min(a, b), hi = max(a, b);
-            if (atomicCAS(&parent[hi], hi, lo) == hi) {
-                hooked = true;
-                a = b = lo;          // done
-            }
-        }
-        for (bool fresh = false; a != b; fresh = true) {
+        a = uv.x;
+        b = uv.y;
+    }
+    bool active = a != b;
+    for (bool fresh = false; __ballot(active); fresh = true) {
+        if (active) {
             // the first walk through the CU's cache (see uf_find): a common ancestor found there IS one
             a = fresh ? uf_find<true>(parent, a) : uf_find<false>(parent, a);
             b = fresh ? uf_find<true>(parent, b) : uf_find<false>(parent, b);
             if (a == b)
-                break;
+                active = false;
             if (a > b) {
                 const uint32_t t = a;
                 a = b;
                 b = t;
             }
-            // hook the larger root under the smaller one
-            if (atomicCAS(&parent[b], b, a) == b) {
-                hooked = true;
-                break;
-            }
+        }
+        // leaders: per (a, b), the lowest lane that wants to hang root b under a
+        s_slot[wave][lane] = 0xFFFFFFFFu;
+        s_slot[wave][lane + 64] = 0xFFFFFFFFu;
+        const uint32_t h = ((b * 0x9E3779B1u) ^ (a * 0x85EBCA6Bu)) >> 25;
+        if (active)
+            atomicMin(&s_slot[wave][h], lane);
+        const uint32_t owner = active ? s_slot[wave][h] : lane;
+        const uint32_t ob = __shfl(b, owner & 63u), oa = __shfl(a, owner & 63u);
+        const bool follower = active && owner != lane && ob == b && oa == a;
+        uint32_t res = 0xFFFFFFFFu;
+        if (active && !follower)
+            res = atomicCAS(&parent[b], b, a);          // hook the larger root under the smaller one
+        s_res[wave][lane] = res;
+        if (follower)
+            res = s_res[wave][owner];
+        if (active && res == b) {
+            active = false;                               // hung (by this lane or by its leader)
+            hooked = !follower;
         }
     }
     if (n_hooks) {
         // FQD_HOOK_SLOTS counters one cache line apart: tens of thousands of waves adding to ONE
         // word serialise in the L2 (measured: 350 us against 98 us for the unions themselves)
         const unsigned long long m = __ballot(hooked);
-        if (m && fqd_lane() == (uint32_t)(__ffsll((long long)m) - 1))
+        if (m && lane == (uint32_t)(__ffsll((long long)m) - 1))
             atomicAdd(n_hooks + (size_t)(blockIdx.x % FQD_HOOK_SLOTS) * 8, (unsigned long long)__popcll(m));
     }
 }
