@@ -76,7 +76,7 @@ enum Stage { ST_EMPTY = 0, ST_PACKED = 1, ST_UNIQUE = 2, ST_EDGES = 3, ST_LABELS
 
 // small device-side words read back by the host
 enum Ctr { C_BAD = 0, C_COLLISIONS = 1, C_CHANGED = 2, C_MINLEN = 3, C_MAXLEN = 4, C_PACKBAD = 5, C_SIDE = 6, C_P0 = 7, C_N32 = 8 };
-enum Ctr64 { C64_EDGES = 0, C64_ROOTS = 1, C64_SUM = 2, C64_STATS = 3, C64_CANDS = 4, C64_CAND_NEED = 5, C64_SLAB = 6, C64_N = 8 };
+enum Ctr64 { C64_EDGES = 0, C64_ROOTS = 1, C64_SUM = 2, C64_STATS = 3, C64_CANDS = 4, C64_CAND_NEED = 5, C64_SLAB = 6, C64_UF_AGAIN = 7, C64_N = 8 };
 
 }  // namespace
 
@@ -181,6 +181,7 @@ struct fqd_ctx {
 
     // stage timers: one event pair per stage, recorded while the work is queued and resolved when
     // fqd_stage_times asks (a stage end is NOT a host synchronisation point)
+    bool uf_sampled = false;       // the union-find met a giant component on this context: every 16th edge first (graph.hip uf_union_kernel)
     bool join_pending = false;     // the components were queued on st_side: ev_join must be waited for before their counter is read
     hipStream_t st_side = nullptr; // the side path of the compact collapse runs here, beside the dedupe (ev_fork / ev_join order it)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

@@ -47,9 +47,11 @@ static int components_queue(fqd_ctx *c, bool flatten, bool on_side = false)
         st = c->st_side;
     }
     KTIME_ON(c, FQD_K_UF_UNION, st, fqd::launch_uf_union(c->labels.as<uint32_t>(), c->edges.as<uint32_t>(), c->E,
-                                                         c->hook_slots.as<unsigned long long>(), st));
+                                                         c->hook_slots.as<unsigned long long>(), st,
+                                                         c->uf_sampled && !getenv("FQD_UF_NO_SAMPLING")));
     HIP_TRY(c, fqd::launch_hook_total(c->hook_slots.as<unsigned long long>(), U,
-                                      c->d_ctr64.as<unsigned long long>() + C64_ROOTS, st));
+                                      c->d_ctr64.as<unsigned long long>() + C64_ROOTS, st,
+                                      c->d_ctr64.as<unsigned long long>() + C64_UF_AGAIN));
     if (on_side) {
         HIP_TRY(c, hipEventRecord(c->ev_join, c->st_side));
         c->join_pending = true;
@@ -161,11 +163,15 @@ static int list_kept(fqd_ctx *c, int method)
                   c->kept_lists.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_SUM, base, list_out,
                   c->kept_scan.as<uint32_t>(), c->st, tail_zeroed));
         FQD_TRY(queue_read_u32(c, c->kept_scan.as<uint32_t>(), 0));
-        unsigned long long both[2] = {0, 0};      // C64_ROOTS, C64_SUM: one read for fqd_cluster
-        FQD_TRY(read_ctr64(c, C64_ROOTS, both, 2));
+        unsigned long long both[7] = {0, 0, 0, 0, 0, 0, 0};      // C64_ROOTS, C64_SUM ... C64_UF_AGAIN: one read for fqd_cluster
+        FQD_TRY(read_ctr64(c, C64_ROOTS, both, C64_UF_AGAIN - C64_ROOTS + 1));
         c->roots_seen = both[0];
         c->n_kept = both[1];
         c->n_listed = taken_u32(c, 0);
+        // a union-find in which a sixteenth of the edges had to walk twice has met a giant component: from now on
+        // this context hooks every 16th edge first
+        if (!c->uf_sampled && c->E >= 65536 && both[C64_UF_AGAIN - C64_ROOTS] > c->E / 16)
+            c->uf_sampled = true;
         if (getenv("FQD_DEBUG"))
             fprintf(stderr, "[fqd] kept list by id bins: U=%llu base=%llu window=%llu shift=%u kept=%llu listed=%llu\n",
                     (unsigned long long)U, (unsigned long long)base, (unsigned long long)window, shift,

@@ -555,7 +555,7 @@ hipError_t launch_quality(const uint8_t *bytes, uint64_t n_bytes, const uint64_t
 hipError_t launch_uf_init(uint32_t *parent, uint64_t U, hipStream_t st);
 hipError_t launch_mask_dead_edges(uint32_t *edges, uint64_t E, const uint8_t *alive, hipStream_t st);
 hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, unsigned long long *n_hooks,
-                           hipStream_t st);
+                           hipStream_t st, bool sampled_first = false);
 uint32_t kept_bin_shift(uint64_t window);
 uint32_t kept_bin_lists();
 hipError_t launch_kept_bins(int method, const uint32_t *labels, const uint32_t *best, const uint8_t *state,
@@ -568,7 +568,7 @@ hipError_t launch_window_count(const uint8_t *flags, uint64_t n, uint32_t *block
 hipError_t launch_window_emit(const uint8_t *flags, uint64_t n, const uint32_t *block_incl, uint64_t id_base,
                               uint64_t *out, hipStream_t st);
 hipError_t launch_hook_total(const unsigned long long *slots, uint64_t n_nodes, unsigned long long *n_components,
-                             hipStream_t st);
+                             hipStream_t st, unsigned long long *n_second_walks = nullptr);
 hipError_t launch_edge_roots(uint32_t *parent, const uint32_t *edges, uint64_t E, uint32_t *roots, hipStream_t st);
 hipError_t launch_subgraph_mark(const uint32_t *uv, const uint32_t *roots, uint64_t E, uint32_t n_parts, uint32_t part,
                                 uint32_t *flags, uint32_t *sub, unsigned long long *n_sub, hipStream_t st);

@@ -87,8 +87,12 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
 // n_hooks (may be NULL; FQD_HOOK_SLOTS x 8 words, summed by the host) += successful hooks: every hook merges two components, so
 // components = nodes - hooks without a sweep over the nodes.
 __global__ __launch_bounds__(256) void uf_union_kernel(uint32_t *parent, const uint32_t *__restrict__ edges, uint64_t E,
-                                                       unsigned long long *n_hooks)
+                                                       unsigned long long *n_hooks, uint32_t phase)
 {
+    // phase 0: every edge. A context that has met a giant component (many lanes had to walk a second time: word 1 of
+    // the hook slots counts them) runs the unions in two launches: phase 1 takes every 16th edge -- a sixteenth of
+    // the threads pulling at the same roots --, phase 2 the rest, most of which then find both ends under one root
+    // on their first, cached walk and send no compare-and-swap at all.
     // The lanes of a wave hook TOGETHER: lanes that are about to hang the same root under the same node send ONE
     // compare-and-swap (the lowest such lane does; the others read its answer from LDS). In a component of tens of
     // thousands of keys the last few roots are every lane's target at once, and compare-and-swaps on ONE word are
@@ -100,13 +104,14 @@ __global__ __launch_bounds__(256) void uf_union_kernel(uint32_t *parent, const u
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool hooked = false;
     uint32_t a = 0, b = 0;
-    if (e < E) {
+    if (e < E && (phase == 0 || ((e & 15u) == 0) == (phase == 1))) {
         const uint2 uv = reinterpret_cast<const uint2 *>(edges)[e];
         a = uv.x;
         b = uv.y;
     }
-    bool active = a != b;
+    bool active = a != b, again = false;
     for (bool fresh = false; __ballot(active); fresh = true) {
+        again = again || (active && fresh);
         if (active) {
             // the first walk through the CU's cache (see uf_find): a common ancestor found there IS one
             a = fresh ? uf_find<true>(parent, a) : uf_find<false>(parent, a);
@@ -145,6 +150,9 @@ __global__ __launch_bounds__(256) void uf_union_kernel(uint32_t *parent, const u
         const unsigned long long m = __ballot(hooked);
         if (m && lane == (uint32_t)(__ffsll((long long)m) - 1))
             atomicAdd(n_hooks + (size_t)(blockIdx.x % FQD_HOOK_SLOTS) * 8, (unsigned long long)__popcll(m));
+        const unsigned long long r = __ballot(again);
+        if (r && lane == (uint32_t)(__ffsll((long long)r) - 1))
+            atomicAdd(n_hooks + (size_t)(blockIdx.x % FQD_HOOK_SLOTS) * 8 + 1, (unsigned long long)__popcll(r));
     }
 }
 
@@ -163,15 +171,22 @@ __global__ void mask_dead_edges_kernel(uint32_t *edges, uint64_t E, const uint8_
 
 // *n_components = n_nodes - sum of the hook slots (one wave)
 __global__ void hook_total_kernel(const unsigned long long *__restrict__ slots, uint64_t n_nodes,
-                                  unsigned long long *n_components)
+                                  unsigned long long *n_components, unsigned long long *n_second_walks /* may be NULL */)
 {
-    unsigned long long sum = 0;
-    for (uint32_t i = threadIdx.x; i < FQD_HOOK_SLOTS; i += 64)
+    unsigned long long sum = 0, again = 0;
+    for (uint32_t i = threadIdx.x; i < FQD_HOOK_SLOTS; i += 64) {
         sum += slots[(size_t)i * 8];
-    for (int o = 32; o; o >>= 1)
+        again += slots[(size_t)i * 8 + 1];
+    }
+    for (int o = 32; o; o >>= 1) {
         sum += __shfl_xor(sum, o);
-    if (threadIdx.x == 0)
+        again += __shfl_xor(again, o);
+    }
+    if (threadIdx.x == 0) {
         *n_components = n_nodes - sum;
+        if (n_second_walks)
+            *n_second_walks = again;
+    }
 }
 
 // roots[e] = component label (smallest node) of edge e's first end, after all unions are done
@@ -1181,10 +1196,14 @@ hipError_t launch_uf_init(uint32_t *parent, uint64_t U, hipStream_t st)
 }
 
 hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, unsigned long long *n_hooks,
-                           hipStream_t st)
+                           hipStream_t st, bool sampled_first)
 {
-    if (E)
-        uf_union_kernel<<<grid_for(E), 256, 0, st>>>(parent, edges, E, n_hooks);
+    if (E && !sampled_first)
+        uf_union_kernel<<<grid_for(E), 256, 0, st>>>(parent, edges, E, n_hooks, 0u);
+    if (E && sampled_first) {
+        uf_union_kernel<<<grid_for(E), 256, 0, st>>>(parent, edges, E, n_hooks, 1u);
+        uf_union_kernel<<<grid_for(E), 256, 0, st>>>(parent, edges, E, n_hooks, 2u);
+    }
     return hipGetLastError();
 }
 
@@ -1196,9 +1215,9 @@ hipError_t launch_mask_dead_edges(uint32_t *edges, uint64_t E, const uint8_t *al
 }
 
 hipError_t launch_hook_total(const unsigned long long *slots, uint64_t n_nodes, unsigned long long *n_components,
-                             hipStream_t st)
+                             hipStream_t st, unsigned long long *n_second_walks)
 {
-    hook_total_kernel<<<1, 64, 0, st>>>(slots, n_nodes, n_components);
+    hook_total_kernel<<<1, 64, 0, st>>>(slots, n_nodes, n_components, n_second_walks);
     return hipGetLastError();
 }
 
