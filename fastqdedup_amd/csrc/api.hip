@@ -133,6 +133,12 @@ struct FusedLevel1 {
     // the routed collapse: bins by segment 0 (route_mask), search pass 0 in the compaction (p0.mask != 0)
     uint32_t route_mask = 0, group_at = 0;      // group_at: the dedupe's group totals start at c->ld_hist + group_at
     fqd::Pass0 p0;
+    // the spill list (fqd::PackScatter::spill; compact == 1, one sender): spill_cap records behind the side slabs in
+    // c->ld_side, its cursor and the level-1 marks behind the side cursors. can_spill: this attempt could have had one
+    // -- a full slab then turns c->heavy_keys on instead of the fused path off.
+    uint32_t spill_cap = 0;
+    uint32_t *spill_cursor = nullptr, *l1_over = nullptr;
+    bool can_spill = false;
 };
 
 // Bucket bits of the LDS collapse for n reads: ~400-800 reads per bucket (2x fewer workgroups than
@@ -236,7 +242,13 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         side.n_slabs = fused->side_slabs;
         side.cap = fused->side_cap;
         side.overflow = c->d_ctr32.as<uint32_t>() + C_BAD;
+        if (fused->spill_cap) {
+            side.spill_at = side.n_slabs * side.cap;
+            side.spill_cap = fused->spill_cap;
+            side.spill_cursor = fused->spill_cursor;
+        }
     }
+    const bool spill = side.spill_cursor != nullptr;
     const uint32_t *parted = c->ld_part.as<uint32_t>();
     uint32_t U32 = 0, overflow = 0, early_nseg = 0;
     bool side_pending = false;
@@ -284,7 +296,10 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 // the keys with an N: collapsed apart, to the head of the unique table (few: a table in global
                 // memory) -- on the context's second stream, beside the dedupe of the other keys: four short
                 // kernels (0.05 ms in a row) that the compaction, not the dedupe, waits for
-                if (compact == 1) {
+                if (spill) {
+                    // (the dedupe below merges into the table: the side slabs and the spill list go in first)
+                    HIP_TRY(c, fqd::launch_side_begin(side, d_w, c->ld_side_table.as<uint32_t>(), fused->side_slots, c->st));
+                } else if (compact == 1) {
                     HIP_TRY(c, hipEventRecord(c->ev_fork, c->st));
                     HIP_TRY(c, hipStreamWaitEvent(c->st_side, c->ev_fork, 0));
                     HIP_TRY(c, fqd::launch_side_collapse(
@@ -315,7 +330,16 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         const uint32_t n_groups = std::max(n_buckets >> 8, 1u);
         uint32_t *group_total = compact && fused->starts_ready && slab_cap && c->h_pin_big && n_groups <= 4096
                                     ? c->ld_hist.as<uint32_t>() + fused->group_at : nullptr;
-        if (compact)
+        if (compact && spill) {
+            KTIME(c, FQD_K_DEDUPE12, fqd::launch_bucket_dedupe12_merge(
+                      reinterpret_cast<const fqd::Rec12 *>(parted), c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
+                      c->ld_tmp_rec.as<uint32_t>(), c->ld_unique.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st,
+                      group_total, side.recs, c->ld_side_table.as<uint32_t>(), fused->side_slots, fused->l1_over, B2));
+            HIP_TRY(c, fqd::launch_side_finish(side.recs, c->ld_side_table.as<uint32_t>(), fused->side_slots,
+                                               c->ld_side_table.as<uint32_t>() + 3 * (size_t)fused->side_slots,
+                                               c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(),
+                                               c->d_ctr32.as<uint32_t>() + C_SIDE, c->st, fused->p0, IdSource()));
+        } else if (compact)
             KTIME(c, FQD_K_DEDUPE12, fqd::launch_bucket_dedupe12(reinterpret_cast<const fqd::Rec12 *>(parted),
                                                                c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
                                                                c->ld_tmp_rec.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
@@ -396,12 +420,20 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         overflow = taken_u32(c, 1 + C_BAD);
         if (fused) {
             fused->pack_bad = taken_u32(c, 1 + C_PACKBAD);
+            if (overflow && getenv("FQD_DEBUG"))
+                fprintf(stderr, "[fqd] fused collapse: overflow flags 0x%x (1: a bucket's LDS table, 2: a level-2 slab, 4: a level-1 slab or the spill list, 16: the side path)\n", overflow);
             if (overflow & 16u)
                 c->compact_off = true;
-            if (overflow & 4u)
-                c->fused_off = true;
-            if (overflow & 2u)
-                c->slab_off = true;
+            if ((overflow & 6u) && !(overflow & 16u) && fused->can_spill && !spill && !c->heavy_keys) {
+                // a full slab -- a key with hundreds of copies in a bucket, or with a share of all reads in a level-1
+                // part: once more, and from then on, with the spill list
+                c->heavy_keys = true;
+            } else {
+                if (overflow & 4u)
+                    c->fused_off = true;
+                if (overflow & 2u)
+                    c->slab_off = true;
+            }
             if (overflow && fused->route_mask)
                 c->route_off = true;       // (keys crowding on one segment-0 value: whole-key hashing from now on)
             if (overflow || fused->pack_bad)
@@ -1004,10 +1036,15 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
 static int pack_collapse_fused(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uint32_t fixed_len, int mem,
                                const uint32_t *weights, int aux_mem, bool *done)
 {
-    const bool was_off = c->compact_off;
-    FQD_TRY(pack_collapse_fused_once(c, bytes, n, fixed_len, mem, weights, aux_mem, done));
-    if (!*done && !was_off && c->compact_off && !c->fused_off)
+    // ... and when a slab is full -- keys with very many copies -- once more with the spill list (c->heavy_keys: the
+    // routed collapse is off then), and so from then on.
+    for (int attempt = 0; attempt < 3; attempt++) {
+        const bool was_off = c->compact_off, was_heavy = c->heavy_keys;
+        c->route &= ~FQD_ROUTE_RESTARTED;          // (raised by an attempt that ended early; the last one counts)
         FQD_TRY(pack_collapse_fused_once(c, bytes, n, fixed_len, mem, weights, aux_mem, done));
+        if (*done || c->fused_off || (was_off == c->compact_off && was_heavy == c->heavy_keys))
+            break;
+    }
     return FQD_OK;
 }
 
@@ -1076,12 +1113,22 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     // side path of the compact records: 256 slabs for n / 64 + 16 Ki keys with an N in all (more: uint4 records
     // from then on), a hash table of twice as many slots
     uint32_t side_slabs = 0, side_cap = 0, side_slots = 0;
+    // ... and, in a context that has met a full slab before (c->heavy_keys), the spill list behind the side slabs:
+    // room for an eighth of the reads, collapsed through the same table (twice its distinct keys at most: the table
+    // is sized for a sixteenth of the reads on top)
+    const bool can_spill = compact == 1 && !getenv("FQD_NO_SPILL_LIST");
+    const bool heavy = can_spill && c->heavy_keys;
+    uint32_t spill_cap = 0;
     if (compact == 1) {
         side_slabs = 256;
         side_cap = (uint32_t)((((n >> 6) + 16384) / side_slabs + 3) & ~3ull);
+        if (heavy)
+            spill_cap = (uint32_t)(((n >> 3) + 65536 + 3) & ~3ull);
         side_slots = 1024;
-        while (side_slots < 2ull * side_slabs * side_cap)
+        while (side_slots < 2ull * side_slabs * side_cap + (heavy ? (n >> 3) : 0ull))
             side_slots *= 2;
+        if ((uint64_t)side_slabs * side_cap + spill_cap >= 0xFFFFFF00ull)
+            return FQD_OK;
     }
     const uint64_t n_bytes = n * (uint64_t)fixed_len;
     const uint8_t *d_bytes;
@@ -1092,8 +1139,9 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     uint32_t *seg_start = c->ld_seg.as<uint32_t>(), *cursor = seg_start + (parts + 4);
     FQD_TRY(zero_ctr32(c, 0, C_N32));
     if (compact == 1) {
-        HIP_TRY(c, c->ld_side.reserve((size_t)side_slabs * side_cap * 16 + 16));
-        HIP_TRY(c, c->ld_side_table.reserve(((size_t)fqd::side_table_words(side_slots) + 2 * side_slabs + 4) * 4 + 16));
+        HIP_TRY(c, c->ld_side.reserve(((size_t)side_slabs * side_cap + spill_cap) * 16 + 16));
+        // (behind the table: the side cursors, the side starts, 4 spare words | the spill cursor, 3 spare words, 256 level-1 marks)
+        HIP_TRY(c, c->ld_side_table.reserve(((size_t)fqd::side_table_words(side_slots) + 2 * side_slabs + 8 + 256) * 4 + 16));
         // (the side path writes the head of the unique table before the compaction is queued)
         HIP_TRY(c, c->urecs.reserve(n * 16 + 16));
         HIP_TRY(c, c->ucounts.reserve(n * 4 + 16));
@@ -1106,7 +1154,7 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     const uint32_t n_groups = std::max(n_buckets >> 8, 1u);
     uint32_t route_mask = 0;
     fqd::Pass0 p0;
-    if (compact && c->seg_hint >= 2 && !c->route_off && !getenv("FQD_NO_ROUTED_COLLAPSE") && sh.words == 1) {
+    if (compact && c->seg_hint >= 2 && !c->route_off && !heavy && !getenv("FQD_NO_ROUTED_COLLAPSE") && sh.words == 1) {
         const uint32_t seg0_len = fixed_len / c->seg_hint;         // fqd_segment(len, 0, nseg): [0, len / nseg)
         if (seg0_len >= 8) {                                       // (a shorter segment 0 has too few values to spread the reads)
             route_mask = seg0_len >= 32 ? 0xFFFFFFFFu : ((1u << seg0_len) - 1u);
@@ -1163,8 +1211,17 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
             route_mask = 0;
         }
     }
-    const fqd::PackScatter fs{cursor, reinterpret_cast<uint4 *>(c->ld_part.p), c->d_ctr32.as<uint32_t>() + C_BAD,
-                              32 - l1_bits, 1u << l1_bits, 1u << sub_bits, cap1, 0u, 0u, 0u, 0u, route_mask};
+    fqd::PackScatter fs{cursor, reinterpret_cast<uint4 *>(c->ld_part.p), c->d_ctr32.as<uint32_t>() + C_BAD,
+                        32 - l1_bits, 1u << l1_bits, 1u << sub_bits, cap1, 0u, 0u, 0u, 0u, route_mask};
+    uint32_t *spill_words = nullptr;
+    if (heavy) {
+        spill_words = c->ld_side_table.as<uint32_t>() + fqd::side_table_words(side_slots) + 2 * side_slabs + 4;
+        HIP_TRY(c, hipMemsetAsync(spill_words, 0, (4 + 256) * 4, c->st));
+        fs.spill = c->ld_side.as<uint4>() + (size_t)side_slabs * side_cap;
+        fs.spill_cursor = spill_words;
+        fs.spill_cap = spill_cap;
+        fs.l1_over = spill_words + 4;
+    }
     {
         StageTimer kernel_timer(c, FQD_T_PACK_KERNEL);
         KTIME(c, FQD_K_PACK, fqd::launch_pack(d_bytes, n_bytes, nullptr, n, fixed_len, sh, c->d_lut.as<uint8_t>(), lut,
@@ -1194,18 +1251,25 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     f.route_mask = route_mask;
     f.group_at = group_at;
     f.p0 = p0;
+    f.can_spill = can_spill;
+    if (heavy) {
+        f.spill_cap = spill_cap;
+        f.spill_cursor = spill_words;
+        f.l1_over = spill_words + 4;
+    }
     bool ok = false;
     FQD_TRY(collapse_lds(c, weights ? d_w : nullptr, IdSource(), &ok, &f));
     timer.stop();
     if (getenv("FQD_DEBUG"))
-        fprintf(stderr, "[fqd] fused pack + collapse: n=%llu parts=%u cap=%u compact=%u done=%d pack_bad=%u fused_off=%d compact_off=%d\n",
-                (unsigned long long)n, parts, cap1, compact, (int)ok, f.pack_bad, (int)c->fused_off, (int)c->compact_off);
+        fprintf(stderr, "[fqd] fused pack + collapse: n=%llu parts=%u cap=%u compact=%u done=%d pack_bad=%u fused_off=%d compact_off=%d routed=%d spill_list=%d heavy_keys=%d\n",
+                (unsigned long long)n, parts, cap1, compact, (int)ok, f.pack_bad, (int)c->fused_off, (int)c->compact_off,
+                (int)(route_mask != 0), (int)heavy, (int)c->heavy_keys);
     if (!ok) {
         c->route |= FQD_ROUTE_RESTARTED;
         return FQD_OK;
     }
     c->route |= FQD_ROUTE_FUSED_PACK | FQD_ROUTE_COLLAPSE_LDS | (compact ? FQD_ROUTE_COMPACT_RECORDS : 0u) |
-                (c->pass0_done ? FQD_ROUTE_PASS0_IN_COLLAPSE : 0u);
+                (c->pass0_done ? FQD_ROUTE_PASS0_IN_COLLAPSE : 0u) | (heavy ? FQD_ROUTE_SPILL_LIST : 0u);
     c->collapse_path = 1;
     c->collapsed = true;
     c->first_distinct = true;

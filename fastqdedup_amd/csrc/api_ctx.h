@@ -181,6 +181,7 @@ struct fqd_ctx {
 
     // stage timers: one event pair per stage, recorded while the work is queued and resolved when
     // fqd_stage_times asks (a stage end is NOT a host synchronisation point)
+    bool heavy_keys = false;       // a fused attempt ended on a full slab: from now on with the spill list (api.hip pack_collapse_fused_once)
     bool uf_sampled = false;       // the union-find met a giant component on this context: every 16th edge first (graph.hip uf_union_kernel)
     bool join_pending = false;     // the components were queued on st_side: ev_join must be waited for before their counter is read
     hipStream_t st_side = nullptr; // the side path of the compact collapse runs here, beside the dedupe (ev_fork / ev_join order it)

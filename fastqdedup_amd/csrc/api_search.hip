@@ -486,6 +486,7 @@ static int grouped_refine(fqd_ctx *c, const uint32_t *seg_hashes, uint64_t U, ui
                 (unsigned long long)n_keys, pieces);
     if (N < 2)
         return FQD_OK;
+    c->route |= FQD_ROUTE_SEARCH_REFINED;
     uint32_t B2 = 8;
     while (B2 < 20 && (N >> B2) > 320u)
         B2++;

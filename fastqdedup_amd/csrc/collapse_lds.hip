@@ -60,6 +60,7 @@ struct RecordPolicy {
     static constexpr uint32_t EPT = 8;          // 2048-record tiles
     static constexpr uint32_t ROUNDS = 1;
     static constexpr bool MAY_SKIP = false;
+    static constexpr bool CAN_SPILL = false;
     static __device__ __forceinline__ bool skip(const uint4 &) { return false; }
     struct Source {
         const uint32_t *hashes;   // level 1 only, may be NULL
@@ -554,11 +555,26 @@ __global__ void bucket_starts_kernel(const uint32_t *__restrict__ hist_incl, uin
 // (The pack kernel itself writing Rec12 items into level 1 was measured: 0.98 ms instead of 0.57 -- its 4-record
 // runs become 48 bytes at any 4-byte offset, and such writes cost more than the quarter of the bytes saves;
 // level 2 writes 8-record runs.)
-struct CompactPolicy {
+// SPILL: an item that finds its bucket's slab full goes, as the uint4 record it came from, to the spill list behind
+// the side slabs (fqd::SideSlabs) instead of ending the attempt -- a context that has met keys with hundreds of
+// copies (api.hip heavy_keys); the list is collapsed with the side path's keys.
+template <bool SPILL>
+struct CompactPolicyT {
     using Item = fqd::Rec12;
     static constexpr uint32_t EPT = FQD_SCATTER12_EPT;
     static constexpr uint32_t ROUNDS = FQD_SCATTER12_ROUNDS;
     static constexpr bool MAY_SKIP = true;
+    static constexpr bool CAN_SPILL = SPILL;
+    struct Source;
+    static __device__ __forceinline__ uint32_t spill_reserve(const Source &s, uint32_t n) { return atomicAdd(s.side.spill_cursor, n); }
+    static __device__ __forceinline__ void spill_write(const Source &s, uint32_t at, const fqd::Rec12 &v)
+    {
+        // (squeeze 1, a key without an N: back to its three planes, see rec12_planes)
+        if (at < s.side.spill_cap)
+            s.side.recs[(size_t)s.side.spill_at + at] = make_uint4(v.a & ~v.b, v.b & ~v.a, v.a & v.b, v.id);
+        else
+            atomicOr(s.side.overflow, 4u);           // (the spill list is full as well: the attempt ends)
+    }
     struct Source {
         const uint4 *in;          // the pack kernel's records: planes + read index
         uint32_t squeeze;
@@ -661,6 +677,7 @@ struct CompactPolicy {
         return finish<false>(s, i, raw, v, false, 0u, none);     // (a histogram pass puts nothing on the side path)
     }
 };
+using CompactPolicy = CompactPolicyT<false>;
 
 // (the tiles of part_scatter12_kernel)
 __global__ __launch_bounds__(1024) void slab_tile_starts12_kernel(const uint32_t *__restrict__ seg_start,
@@ -671,15 +688,16 @@ __global__ __launch_bounds__(1024) void slab_tile_starts12_kernel(const uint32_t
                                                                                      tile_start);
 }
 
-template <uint32_t MAXB, uint32_t NT = 1>
+template <uint32_t MAXB, uint32_t NT = 1, bool SPILL = false>
 __global__ __launch_bounds__(fqd_partition::THREADS) void part_scatter12_kernel(
-    CompactPolicy::Source src, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ tile_start,
+    typename CompactPolicyT<SPILL>::Source src, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ tile_start,
     uint32_t n_seg, uint32_t shift, uint32_t n_bins, uint32_t *__restrict__ cursor, fqd::Rec12 *__restrict__ out,
     uint32_t slab_cap, uint32_t *__restrict__ slab_overflow, const uint32_t *__restrict__ seg_end, uint32_t seg_shift,
     uint32_t seg_mask)
 {
-    fqd_partition::scatter_body<CompactPolicy, false, MAXB, NT>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out,
-                                                                slab_cap, slab_overflow, seg_end, seg_shift, seg_mask);
+    fqd_partition::scatter_body<CompactPolicyT<SPILL>, false, MAXB, NT>(src, seg_start, tile_start, n_seg, shift, n_bins, cursor,
+                                                                        out, slab_cap, slab_overflow, seg_end, seg_shift,
+                                                                        seg_mask);
 }
 
 __device__ __forceinline__ uint32_t rec12_tag(uint32_t a, uint32_t b)
@@ -691,6 +709,76 @@ __device__ __forceinline__ uint32_t rec12_tag(uint32_t a, uint32_t b)
     return h == DD_EMPTY ? 0u : h;
 }
 
+
+// ---- the side table (see "the side path" below): helpers shared by its kernels and by the merging dedupe ----
+constexpr uint32_t SIDE_EMPTY = 0xFFFFFFFFu, SIDE_BLOCK = 1024;
+constexpr uint32_t SIDE_MAX_PROBES = 8192;     // (a table that full is given up: overflow bit 16)
+
+__device__ __forceinline__ uint32_t side_hash(uint32_t x, uint32_t y, uint32_t z)
+{
+    uint32_t h = (x ^ 0x9E3779B9u) * 0x85EBCA6Bu;
+    h = (h ^ (h >> 15) ^ y) * 0xC2B2AE35u;
+    h = (h ^ (h >> 13) ^ z) * 0x27D4EB2Fu;
+    return h ^ (h >> 16);
+}
+
+// one record (planes x, y, z; weight w, read index id) into the table; pos: the position in `side` of a record with
+// this key, which claims the slot if the key is new
+__device__ __forceinline__ void side_insert_one(const uint4 *__restrict__ side, uint32_t *table, uint32_t table_slots,
+                                                uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t id, uint32_t pos,
+                                                uint32_t *__restrict__ overflow)
+{
+    uint32_t slot = side_hash(x, y, z) & (table_slots - 1);
+    const uint32_t max_probes = min(table_slots, SIDE_MAX_PROBES);
+    for (uint32_t probes = 0; probes < max_probes; probes++) {
+        uint32_t owner = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (owner == SIDE_EMPTY) {
+            owner = atomicCAS(&table[slot], SIDE_EMPTY, pos);
+            if (owner == SIDE_EMPTY)
+                owner = pos;
+        }
+        bool same = owner == pos;
+        if (!same) {
+            const uint4 o = side[owner];
+            same = o.x == x && o.y == y && o.z == z;
+        }
+        if (same) {
+            atomicAdd(&table[table_slots + slot], w);
+            atomicMin(&table[2 * table_slots + slot], id);
+            return;
+        }
+        slot = (slot + 1) & (table_slots - 1);
+    }
+    atomicOr(overflow, 16u);
+}
+
+// the slot of a key in the COMPLETE table (no insert runs beside this), or SIDE_EMPTY
+__device__ __forceinline__ uint32_t side_find(const uint4 *__restrict__ side, const uint32_t *__restrict__ table,
+                                              uint32_t table_slots, uint32_t x, uint32_t y, uint32_t z)
+{
+    uint32_t slot = side_hash(x, y, z) & (table_slots - 1);
+    const uint32_t max_probes = min(table_slots, SIDE_MAX_PROBES);
+    for (uint32_t probes = 0; probes < max_probes; probes++) {
+        const uint32_t owner = table[slot];
+        if (owner == SIDE_EMPTY)
+            return SIDE_EMPTY;
+        const uint4 o = side[owner];
+        if (o.x == x && o.y == y && o.z == z)
+            return slot;
+        slot = (slot + 1) & (table_slots - 1);
+    }
+    return SIDE_EMPTY;
+}
+
+// what the merging dedupe needs to know (bucket_dedupe12_kernel<true>)
+struct SideMerge {
+    const uint4 *side;
+    uint32_t *table;
+    uint32_t table_slots;
+    const uint32_t *l1_over;     // [bucket >> l1_shift] != 0: a level-1 slab of the bucket's bin spilled
+    uint32_t l1_shift;
+};
+
 // bucket_dedupe_kernel for Rec12 items. The two key words of an item ARE the key, so a slot is one 64-bit word
 // and ONE 64-bit LDS compare-and-swap both claims an empty slot and recognises the key in a taken one: no tag,
 // no parked record to verify against, hence no workgroup barrier between claiming and verifying -- the rounds of
@@ -700,12 +788,18 @@ __device__ __forceinline__ uint32_t rec12_tag(uint32_t a, uint32_t b)
 // (a, b, count, first index) at tmp[lo + rank].
 constexpr unsigned long long DD_EMPTY64 = ~0ull;
 
+// MERGE (a context with a spill list, squeeze 1): copies of this bucket's keys may lie in the side table -- the spill
+// list has been collapsed into it BEFORE this kernel -- when the bucket's slab overflowed at level 2 or a slab of its
+// level-1 bin did in the pack kernel. Such a bucket looks every one of its keys up there; a key that is found adds its
+// count and first index to the table's entry and leaves no row of its own.
+template <bool MERGE>
 __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
     const fqd::Rec12 *__restrict__ part, const uint32_t *__restrict__ bucket_start,
     const uint32_t *__restrict__ bucket_end, const uint32_t *__restrict__ weights, uint4 *__restrict__ tmp,
     uint32_t *__restrict__ bucket_unique, uint32_t *__restrict__ overflow,
     uint32_t *__restrict__ group_total /* NULL, or [b >> 8] += unique keys of bucket b: with it the compaction finds
-                                        * its offsets itself (bucket_compact12_kernel) and no scan runs in between */)
+                                        * its offsets itself (bucket_compact12_kernel) and no scan runs in between */,
+    SideMerge merge)
 {
     __shared__ unsigned long long s_key[DD_SLOTS + 1];
     __shared__ uint32_t s_cnt[DD_SLOTS + 1], s_min[DD_SLOTS + 1];
@@ -786,10 +880,31 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
     if (full)
         atomicOr(overflow, 1u);
     __syncthreads();
+    constexpr uint32_t PER = (DD_SLOTS + DD_THREADS) / DD_THREADS;     // slots per thread, table + 1
+    if constexpr (MERGE) {
+        const bool spilled = (bucket_end && bucket_end[b] > bucket_start[b + 1]) || merge.l1_over[b >> merge.l1_shift];
+        if (spilled) {                              // (the same for every thread of the workgroup)
+#pragma unroll
+            for (uint32_t k = 0; k < PER; k++) {
+                const uint32_t sl = tid + k * DD_THREADS;
+                // (a taken slot, whatever its count: the first index of a weight-0 holder counts as well)
+                if (sl <= DD_SLOTS && (sl == DD_SLOTS ? s_min[sl] != 0xFFFFFFFFu : s_key[sl] != DD_EMPTY64)) {
+                    const unsigned long long kk = s_key[sl];      // (a, b) -> the three planes (rec12_planes, squeeze 1)
+                    const uint32_t ka = (uint32_t)kk, kb = (uint32_t)(kk >> 32);
+                    const uint32_t at = side_find(merge.side, merge.table, merge.table_slots, ka & ~kb, kb & ~ka, ka & kb);
+                    if (at != SIDE_EMPTY) {
+                        atomicAdd(&merge.table[merge.table_slots + at], s_cnt[sl]);
+                        atomicMin(&merge.table[2 * merge.table_slots + at], s_min[sl]);
+                        s_cnt[sl] = 0u;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
 
     // live slots (count > 0: a key all of whose holders have weight 0 is not in the trie), the slot behind the
     // table included
-    constexpr uint32_t PER = (DD_SLOTS + DD_THREADS) / DD_THREADS;     // slots per thread, table + 1
     uint32_t mine = 0;
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
@@ -1074,8 +1189,6 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
 // the slabs (written by an earlier kernel) -- no record is parked in the table, so nothing can be read half
 // written. Then the live slots are counted per block of 1024 and written, in table order, to the head of the
 // unique table.
-constexpr uint32_t SIDE_EMPTY = 0xFFFFFFFFu, SIDE_BLOCK = 1024;
-
 __global__ void side_clear_kernel(uint32_t *__restrict__ table, uint32_t table_slots)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1099,25 +1212,71 @@ __global__ void side_insert_kernel(const uint4 *__restrict__ side, const uint32_
         return;
     const uint32_t pos = sub * cap + i;
     const uint4 v = side[pos];
-    const uint32_t w = weights ? weights[v.w] : 1u;
-    uint32_t h = (v.x ^ 0x9E3779B9u) * 0x85EBCA6Bu;
-    h = (h ^ (h >> 15) ^ v.y) * 0xC2B2AE35u;
-    h = (h ^ (h >> 13) ^ v.z) * 0x27D4EB2Fu;
-    h ^= h >> 16;
-    uint32_t slot = h & (table_slots - 1);
-    for (uint32_t probes = 0; probes < table_slots; probes++) {
-        uint32_t owner = atomicCAS(&table[slot], SIDE_EMPTY, pos);
-        if (owner == SIDE_EMPTY)
-            owner = pos;
-        const uint4 o = owner == pos ? v : side[owner];
-        if (o.x == v.x && o.y == v.y && o.z == v.z) {
-            atomicAdd(&table[table_slots + slot], w);
-            atomicMin(&table[2 * table_slots + slot], v.w);
-            return;
+    side_insert_one(side, table, table_slots, v.x, v.y, v.z, weights ? weights[v.w] : 1u, v.w, pos, overflow);
+}
+
+// The spill list (SideSlabs::spill_at ..): records the pack kernel or level 2 could not place because a slab was full
+// -- mostly copies of a few keys with very many holders. A workgroup collapses chunks of 1024 records in an LDS table
+// first (64-bit compare-and-swap on the two key words, like bucket_dedupe12_kernel) and sends one insert per distinct
+// key of the chunk to the table in global memory: a record each would queue a million additions on one word for a
+// key with a million copies (~88 per microsecond). Keys with an N and the all-T key (the LDS table's EMPTY pattern) go
+// straight to the global table.
+constexpr uint32_t SP_THREADS = 256, SP_R = 4, SP_CHUNK = SP_THREADS * SP_R, SP_SLOTS = 2 * SP_CHUNK;
+
+__global__ __launch_bounds__(SP_THREADS) void side_insert_spill_kernel(
+    const uint4 *__restrict__ side, uint32_t spill_at, uint32_t spill_cap, const uint32_t *__restrict__ spill_cursor,
+    const uint32_t *__restrict__ weights, uint32_t *table, uint32_t table_slots, uint32_t *__restrict__ overflow)
+{
+    __shared__ unsigned long long s_key[SP_SLOTS];
+    __shared__ uint32_t s_cnt[SP_SLOTS], s_min[SP_SLOTS], s_pos[SP_SLOTS];
+    const uint32_t filled = min(*spill_cursor, spill_cap), tid = threadIdx.x;
+    for (uint32_t lo = blockIdx.x * SP_CHUNK; lo < filled; lo += gridDim.x * SP_CHUNK) {
+        uint4 v[SP_R];
+#pragma unroll
+        for (uint32_t r = 0; r < SP_R; r++)            // clamped, unconditional: in flight together
+            v[r] = side[(size_t)spill_at + min(lo + r * SP_THREADS + tid, filled - 1)];
+        for (uint32_t sl = tid; sl < SP_SLOTS; sl += SP_THREADS) {
+            s_key[sl] = DD_EMPTY64;
+            s_cnt[sl] = 0u;
+            s_min[sl] = 0xFFFFFFFFu;
         }
-        slot = (slot + 1) & (table_slots - 1);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < SP_R; r++) {
+            const uint32_t i = lo + r * SP_THREADS + tid;
+            if (i >= filled)
+                continue;
+            const uint32_t w = weights ? weights[v[r].w] : 1u;
+            const uint32_t a = v[r].x | v[r].z, b = v[r].y | v[r].z;
+            const unsigned long long key = ((unsigned long long)b << 32) | a;
+            if ((v[r].x & v[r].y) != 0u || key == DD_EMPTY64) {
+                side_insert_one(side, table, table_slots, v[r].x, v[r].y, v[r].z, w, v[r].w, spill_at + i, overflow);
+                continue;
+            }
+            uint32_t slot = (rec12_tag(a, b) * 0x9E3779B1u) >> 21;           // top 11 bits: SP_SLOTS == 2048
+            for (;;) {                                 // (half as many records as slots: a free one is found)
+                const unsigned long long old = atomicCAS(&s_key[slot], DD_EMPTY64, key);
+                if (old == DD_EMPTY64)
+                    s_pos[slot] = spill_at + i;        // (one winner per slot; read behind the barrier)
+                if (old == DD_EMPTY64 || old == key) {
+                    atomicAdd(&s_cnt[slot], w);
+                    atomicMin(&s_min[slot], v[r].w);
+                    break;
+                }
+                slot = (slot + 1) & (SP_SLOTS - 1);
+            }
+        }
+        __syncthreads();
+        for (uint32_t sl = tid; sl < SP_SLOTS; sl += SP_THREADS) {
+            const unsigned long long kk = s_key[sl];
+            if (kk != DD_EMPTY64) {
+                const uint32_t ka = (uint32_t)kk, kb = (uint32_t)(kk >> 32);
+                side_insert_one(side, table, table_slots, ka & ~kb, kb & ~ka, ka & kb, s_cnt[sl], s_min[sl], s_pos[sl],
+                                overflow);
+            }
+        }
+        __syncthreads();
     }
-    atomicOr(overflow, 16u);
 }
 
 // (256 threads for 1024 slots: these kernels run beside the dedupe kernel, whose workgroups fill every CU -- a
@@ -1362,6 +1521,21 @@ hipError_t launch_part_scatter12(const uint32_t *in, uint32_t squeeze, SideSlabs
         return hipErrorInvalidValue;
     const CompactPolicy::Source src{reinterpret_cast<const uint4 *>(in), squeeze, side, route_mask ? route_mask : 0xFFFFFFFFu,
                                     stamp_div, stamp_shift, stamp_map};
+    if (side.spill_cursor) {
+        if (squeeze != 1 || !slab_cap || !side.spill_cap || stamp_div)
+            return hipErrorInvalidValue;
+        const CompactPolicyT<true>::Source spill_src{reinterpret_cast<const uint4 *>(in), squeeze, side,
+                                                     route_mask ? route_mask : 0xFFFFFFFFu, stamp_div, stamp_shift, stamp_map};
+        if (n_bins <= 256)
+            part_scatter12_kernel<256, 1, true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
+                spill_src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end,
+                seg_shift, seg_mask);
+        else
+            part_scatter12_kernel<fqd_partition::MAX_BINS, 1, true><<<max_tiles, fqd_partition::THREADS, 0, st>>>(
+                spill_src, seg_start, tile_start, n_seg, shift, n_bins, cursor, out, slab_cap, slab_overflow, seg_end,
+                seg_shift, seg_mask);
+        return hipGetLastError();
+    }
     // (a workgroup taking TWO consecutive tiles of a slab, both tiles' loads requested up front -- scatter_body's NT --
     // was measured: 0.426 against 0.390 ms; 98 VGPRs, four workgroups per CU instead of five)
     if (n_bins <= 256)
@@ -1379,9 +1553,25 @@ hipError_t launch_bucket_dedupe12(const Rec12 *part, const uint32_t *bucket_star
                                   uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
                                   uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st, uint32_t *group_total)
 {
-    bucket_dedupe12_kernel<<<n_buckets, DD_THREADS, 0, st>>>(part, bucket_start, bucket_end, weights,
-                                                             reinterpret_cast<uint4 *>(tmp_rec), bucket_unique, overflow,
-                                                             group_total);
+    bucket_dedupe12_kernel<false><<<n_buckets, DD_THREADS, 0, st>>>(part, bucket_start, bucket_end, weights,
+                                                                    reinterpret_cast<uint4 *>(tmp_rec), bucket_unique,
+                                                                    overflow, group_total, SideMerge{});
+    return hipGetLastError();
+}
+
+// ... in a context with a spill list: behind launch_side_begin, before launch_side_finish
+hipError_t launch_bucket_dedupe12_merge(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                        uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
+                                        uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st, uint32_t *group_total,
+                                        const uint4 *side, uint32_t *table, uint32_t table_slots, const uint32_t *l1_over,
+                                        uint32_t l1_shift)
+{
+    if (!side || !table || !table_slots || !l1_over)
+        return hipErrorInvalidValue;
+    bucket_dedupe12_kernel<true><<<n_buckets, DD_THREADS, 0, st>>>(part, bucket_start, bucket_end, weights,
+                                                                   reinterpret_cast<uint4 *>(tmp_rec), bucket_unique,
+                                                                   overflow, group_total,
+                                                                   SideMerge{side, table, table_slots, l1_over, l1_shift});
     return hipGetLastError();
 }
 
@@ -1422,6 +1612,34 @@ hipError_t launch_side_collapse(const uint4 *side, const uint32_t *cursor, uint3
     side_clear_kernel<<<(table_slots + 255) / 256, 256, 0, st>>>(table, table_slots);
     side_insert_kernel<<<dim3((cap + 255) / 256, subs), 256, 0, st>>>(side, cursor, first_part, cap, weights, table,
                                                                      table_slots, overflow);
+    side_count_kernel<<<blocks, SIDE_THREADS, 0, st>>>(table, table_slots, block_counts);
+    side_emit_kernel<<<blocks, SIDE_THREADS, 0, st>>>(side, table, table_slots, block_counts,
+                                                    reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, side_unique, pass0,
+                                                    read_ids);
+    return hipGetLastError();
+}
+
+// The side path in two halves around the dedupe of a context with a spill list (SideSlabs::spill_cursor): the keys of
+// the side slabs and the spill list into the table -- then the dedupe merges what it finds there (MERGE) -- then the
+// table's live slots to the head of the unique table.
+hipError_t launch_side_begin(SideSlabs side, const uint32_t *weights, uint32_t *table, uint32_t table_slots, hipStream_t st)
+{
+    if (!table_slots || (table_slots & (table_slots - 1)) || !side.n_slabs || !side.cap || !side.spill_cursor)
+        return hipErrorInvalidValue;
+    side_clear_kernel<<<(table_slots + 255) / 256, 256, 0, st>>>(table, table_slots);
+    side_insert_kernel<<<dim3((side.cap + 255) / 256, side.n_slabs), 256, 0, st>>>(side.recs, side.cursor, 0, side.cap, weights,
+                                                                                 table, table_slots, side.overflow);
+    const uint32_t chunks = (side.spill_cap + SP_CHUNK - 1) / SP_CHUNK;
+    side_insert_spill_kernel<<<std::max(1u, std::min(chunks, 4096u)), SP_THREADS, 0, st>>>(
+        side.recs, side.spill_at, side.spill_cap, side.spill_cursor, weights, table, table_slots, side.overflow);
+    return hipGetLastError();
+}
+
+hipError_t launch_side_finish(const uint4 *side, uint32_t *table, uint32_t table_slots, uint32_t *block_counts,
+                              uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, uint32_t *side_unique, hipStream_t st,
+                              Pass0 pass0, IdSource read_ids)
+{
+    const uint32_t blocks = (table_slots + SIDE_BLOCK - 1) / SIDE_BLOCK;
     side_count_kernel<<<blocks, SIDE_THREADS, 0, st>>>(table, table_slots, block_counts);
     side_emit_kernel<<<blocks, SIDE_THREADS, 0, st>>>(side, table, table_slots, block_counts,
                                                     reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, side_unique, pass0,

@@ -243,6 +243,14 @@ struct PackScatter {
     // instead of the whole key -- every key sharing segment 0 then ends in one bucket of the collapse, whose
     // compaction finds the pairs of search pass 0 on the spot (Pass0 below)
     uint32_t route_mask = 0;
+    // the SPILL list (pack_kernel<.., 2>; a context that has met keys with very many copies, api.hip heavy_keys): a
+    // record that finds its part's slab full goes to spill[atomicAdd(spill_cursor, ..)] instead of ending the
+    // attempt, and the bin is marked in l1_over[bin]; the list is collapsed with the side path's keys
+    // (launch_side_insert_spill) and the dedupe of the bin's buckets merges its rows into those (bucket_dedupe12 MERGE)
+    uint4 *spill = nullptr;
+    uint32_t *spill_cursor = nullptr;
+    uint32_t spill_cap = 0;
+    uint32_t *l1_over = nullptr;
 };
 // The route hash of a one-word key in (a, b) form -- a = p0 | p2, b = p1 | p2 for the three planes of "ACGNT", the two
 // planes themselves for a two-plane alphabet -- over the bits of segment 0: what the fused pack (level 1), level 2
@@ -391,6 +399,11 @@ struct SideSlabs {
     uint32_t *cursor = nullptr;    // cursor[s] starts at s * cap (launch_slab_starts)
     uint32_t n_slabs = 0, cap = 0; // n_slabs: a power of two
     uint32_t *overflow = nullptr;  // bit 16: a side slab was full
+    // the spill list (PackScatter::spill): recs[spill_at, spill_at + spill_cap), filled up to *spill_cursor; level 2
+    // appends the items that find their bucket's slab full (as uint4 records again). spill_cursor == NULL: no list,
+    // a full slab ends the attempt.
+    uint32_t spill_at = 0, spill_cap = 0;
+    uint32_t *spill_cursor = nullptr;
 };
 hipError_t launch_part_scatter12(const uint32_t *in /* uint4 records */, uint32_t squeeze, SideSlabs side,
                                  const uint32_t *seg_start, const uint32_t *tile_start, uint32_t n_seg,
@@ -419,6 +432,19 @@ hipError_t launch_side_collapse(const uint4 *side, const uint32_t *cursor /* of 
                                 const uint32_t *weights, uint32_t *table, uint32_t table_slots, uint32_t *block_counts,
                                 uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, uint32_t *side_unique,
                                 uint32_t *overflow, hipStream_t st, Pass0 pass0 = Pass0(), IdSource read_ids = IdSource());
+
+// a context with a spill list (SideSlabs::spill_cursor, PackScatter::spill): launch_side_begin (side slabs + spill
+// list -> table), launch_bucket_dedupe12_merge (rows whose key is in the table merge into it), launch_side_finish
+// (table -> head of the unique table)
+hipError_t launch_side_begin(SideSlabs side, const uint32_t *weights, uint32_t *table, uint32_t table_slots, hipStream_t st);
+hipError_t launch_bucket_dedupe12_merge(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                        uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
+                                        uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st, uint32_t *group_total,
+                                        const uint4 *side, uint32_t *table, uint32_t table_slots, const uint32_t *l1_over,
+                                        uint32_t l1_shift);
+hipError_t launch_side_finish(const uint4 *side, uint32_t *table, uint32_t table_slots, uint32_t *block_counts,
+                              uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, uint32_t *side_unique, hipStream_t st,
+                              Pass0 pass0 = Pass0(), IdSource read_ids = IdSource());
 
 // edges.hip
 hipError_t launch_segment_hashes(const uint32_t *urecs, const uint32_t *ulens, uint64_t U, KeyShape sh, uint32_t nseg,

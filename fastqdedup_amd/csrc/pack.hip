@@ -122,7 +122,7 @@ struct PackHash {
 // tile reserves its share of a bin with ONE atomic on that part's cursor. `subs` parts per bin
 // (tile t feeds sub t % subs) spread those atomics: with one cursor per bin the 48 K tiles of a
 // 50 M-read job queue up on a few hundred addresses.
-template <int K, bool SWAR, bool FUSED = false>
+template <int K, bool SWAR, int FUSED = 0 /* 1: partitioned output; 2: ... with the spill list (PackScatter::spill) */>
 __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     const uint8_t *__restrict__ bytes, uint64_t n_bytes, const uint64_t *__restrict__ offsets, uint64_t n,
     uint32_t fixed_len, KeyShape sh, uint32_t kpb, uint32_t plane_words, const uint8_t *__restrict__ lut_g,
@@ -412,8 +412,18 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
             if (mine) {
                 const uint32_t part = tid * fs.subs + my_sub;
                 const uint32_t g = atomicAdd(&fs.cursor[part], mine);
-                if ((uint64_t)g + mine > ((uint64_t)part + 1) * fs.cap)
-                    atomicOr(fs.overflow, 4u);    // the part's slab is full: the caller packs the plain way
+                const uint64_t end = ((uint64_t)part + 1) * fs.cap;
+                if ((uint64_t)g + mine > end) {
+                    if (FUSED == 2) {
+                        // the part's slab is full: the records behind its end go to the spill list, position pos to
+                        // spill[s_hist[bin] + pos] (the bin's count has been read: its word is free)
+                        const uint32_t first = (uint32_t)max((uint64_t)g, end);
+                        s_hist[tid] = atomicAdd(fs.spill_cursor, g + mine - first) - first;
+                        fs.l1_over[tid] = 1u;
+                    } else {
+                        atomicOr(fs.overflow, 4u);    // the part's slab is full: the caller packs the plain way
+                    }
+                }
                 base = g - excl;
             }
             s_base[tid] = base;
@@ -441,8 +451,15 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
                     const uint32_t pos = s_base[bn] + round0 + p;
                     // (non-temporal stores here: 0.89 ms instead of 0.56 -- the runs of consecutive tiles complete
                     // each other's partial lines in the XCD's L2, which a non-temporal store forgoes)
-                    if (pos < (bn * fs.subs + my_sub + 1) * fs.cap)
+                    if (pos < (bn * fs.subs + my_sub + 1) * fs.cap) {
                         fs.out[pos] = tile4[p];
+                    } else if (FUSED == 2) {
+                        const uint32_t at = s_hist[bn] + pos;
+                        if (at < fs.spill_cap)
+                            fs.spill[at] = tile4[p];
+                        else
+                            atomicOr(fs.overflow, 4u);     // (the spill list is full as well)
+                    }
                 }
             }
             __syncthreads();
@@ -602,9 +619,23 @@ hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *o
                                                                      kpb, plane_words, lut_dev, ph, recs, lens, \
                                                                      hashes, owners, rule, bad_flag, fs)
 #define FQD_PACK_FUSED(KK, SW)                                                                             \
-    pack_kernel<KK, SW, true><<<(unsigned)blocks, PACK_THREADS, lds, st>>>(bytes, n_bytes, offsets, n, fixed_len, \
-                                                                           sh, kpb, plane_words, lut_dev, ph, recs, \
-                                                                           lens, hashes, owners, rule, bad_flag, fs)
+    pack_kernel<KK, SW, 1><<<(unsigned)blocks, PACK_THREADS, lds, st>>>(bytes, n_bytes, offsets, n, fixed_len, \
+                                                                        sh, kpb, plane_words, lut_dev, ph, recs, \
+                                                                        lens, hashes, owners, rule, bad_flag, fs)
+    if (fused && fused->spill) {
+        // (the spill list exists for the compact records of "ACGNT" keys alone: three planes)
+        if (sh.planes != 3 || !fused->spill_cursor || !fused->l1_over || fused->owner_parts)
+            return hipErrorInvalidValue;
+        if (swar)
+            pack_kernel<3, true, 2><<<(unsigned)blocks, PACK_THREADS, lds, st>>>(bytes, n_bytes, offsets, n, fixed_len, sh, kpb,
+                                                                                 plane_words, lut_dev, ph, recs, lens, hashes,
+                                                                                 owners, rule, bad_flag, fs);
+        else
+            pack_kernel<3, false, 2><<<(unsigned)blocks, PACK_THREADS, lds, st>>>(bytes, n_bytes, offsets, n, fixed_len, sh, kpb,
+                                                                                  plane_words, lut_dev, ph, recs, lens, hashes,
+                                                                                  owners, rule, bad_flag, fs);
+        return hipGetLastError();
+    }
     if (fused) {
         if (swar) {
             switch (sh.planes) {

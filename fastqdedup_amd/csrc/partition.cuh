@@ -27,6 +27,8 @@
 //   static __device__ uint32_t segment_tag(const Source &, uint32_t segment);  static __device__ void apply_tag(Item &, uint32_t tag);
 //   static constexpr bool MAY_SKIP;  static __device__ bool skip(const Item &);   // scatter pass: an item load() has disposed of otherwise
 //   static constexpr uint32_t EPT, ROUNDS;   // items per thread (tile = 256 * EPT); staging rounds of the scatter pass
+//   static constexpr bool CAN_SPILL;   // slab mode: items behind a full slab's end go to a list of the Policy's --
+//   spill_reserve(src, n) -> first index, spill_write(src, index, item) -- instead of raising the overflow flag
 #pragma once
 #include "fqd_internal.h"
 
@@ -287,8 +289,16 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
             s_base[b] = g_base[k] - g_run[k];
             if (!matrix && slab_cap && g_cnt[k]) {
                 const uint64_t end = ((uint64_t)seg * n_bins + b + 1) * slab_cap;
-                if ((uint64_t)g_base[k] + g_cnt[k] > end)
-                    atomicOr(slab_overflow, 2u);
+                if ((uint64_t)g_base[k] + g_cnt[k] > end) {
+                    if constexpr (Policy::CAN_SPILL) {
+                        // the items behind the slab's end go to the Policy's spill list: position pos to
+                        // spill[s_hist[bin] + pos] (the bin's count is in g_cnt by now: its word is free)
+                        const uint32_t first = (uint32_t)max((uint64_t)g_base[k], end);
+                        s_hist[b] = Policy::spill_reserve(src, g_base[k] + g_cnt[k] - first) - first;
+                    } else {
+                        atomicOr(slab_overflow, 2u);
+                    }
+                }
             }
         }
     }
@@ -304,6 +314,8 @@ __device__ __forceinline__ void scatter_body(const typename Policy::Source &src,
                 const uint32_t pos = s_base[bn] + r0 + p;   // consecutive p of one bin: consecutive addresses
                 if (matrix || !slab_cap || pos < (seg * n_bins + bn + 1) * slab_cap)
                     out[pos] = s_stage[p];
+                else if constexpr (Policy::CAN_SPILL)
+                    Policy::spill_write(src, s_hist[bn] + pos, s_stage[p]);
             }
         }
         if (ROUNDS > 1)

@@ -94,6 +94,10 @@ typedef struct fqd_summary {
 #define FQD_ROUTE_SEARCH_EDIT     0x0400u  /* the Levenshtein search proper ran (grouped or sorted)                        */
 #define FQD_ROUTE_SEARCH_RETRIED  0x0800u  /* the search ran again: an edge / candidate buffer or a slab was too small     */
 #define FQD_ROUTE_PASS0_CONTINUED 0x1000u  /* the search took pass 0 from the collapse and ran the other passes only       */
+#define FQD_ROUTE_SPILL_LIST      0x2000u  /* the fused collapse ran with its spill list: the context has met keys with
+                                            * hundreds of copies (full slabs); no search pass 0 in the compaction then     */
+#define FQD_ROUTE_SEARCH_REFINED  0x4000u  /* crowded segment values (thousands of keys sharing one) were matched on finer
+                                            * segments instead of pairwise                                                 */
 int fqd_get_route(const fqd_ctx *ctx, uint32_t *route);
 
 /* Packed-key geometry chosen by fqd_pack_keys (DESIGN.md "data layout"). */

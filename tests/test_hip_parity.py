@@ -285,20 +285,76 @@ def test_routed_collapse_does_search_pass_0(F, oracle, monkeypatch, case):
         assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), (case, job)
         r = got.route
         if case == "table_overflow":
-            # job 0: the routed attempt overflows a bucket's table and the job starts over; job 1: whole-key hashing
-            assert r["restarted"] == (job == 0) and not r["pass0_in_collapse"] and not r["pass0_continued"]
-            assert r["fused_pack"] == (job == 1)
+            # job 0: the routed attempt overflows a bucket's table and slab -- once more with whole-key hashing and the
+            # spill list (a full slab looks like a key with very many copies); job 1 starts that way
+            assert not r["restarted"] and not r["pass0_in_collapse"] and not r["pass0_continued"]
+            assert r["fused_pack"] and r["spill_list"]
         elif case == "probe_overflow":
             assert r["fused_pack"] and r["compact_records"] and not r["pass0_in_collapse"] and not r["pass0_continued"]
         elif case in ("edge_overflow", "rows_over_512"):     # (found out by the search: it runs again, every pass)
             assert r["pass0_in_collapse"] and r["search_retried"] and not r["pass0_continued"]
-        elif case != "ladder":          # (the skewed model's hot key overfills a slab: the job starts over, see below)
+        elif case == "ladder":          # (the skewed model's hot key overfills a slab: with the spill list from then on)
+            assert r["fused_pack"] and r["compact_records"] and r["spill_list"] and not r["restarted"], r
+            assert r["search_refined"], r       # (the ladder shares one segment-0 value: matched on finer segments)
+        else:
             assert r["fused_pack"] and r["compact_records"] and r["pass0_in_collapse"] and r["pass0_continued"], (case, r)
             assert r["search_grouped"] and not r["restarted"]
     # the same keys the stage-by-stage way, on the same context
     ctx.pack_keys(raw, None, L)
     two = ctx.cluster(None, None, max_distance=d, method=2)
     assert (two["n_unique"], two["n_edges"], two["n_kept"]) == (got.n_unique, got.n_edges, got.n_kept)
+
+
+@pytest.mark.parametrize("case", ["one_hot_key", "zipf", "hot_all_t", "hot_with_n", "weights", "spill_full"])
+def test_spill_list_takes_keys_with_many_copies(F, oracle, monkeypatch, case):
+    """Keys with hundreds of copies -- or a share of ALL reads -- overfill the slabs of the fused collapse. The first
+    such job of a context runs again with the SPILL LIST (records that find a slab full are collapsed through the side
+    path's table, and the dedupe merges its rows into that), later jobs start that way. Against the oracle, with the
+    route asserted; a full spill list sends the job the stage-by-stage way."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_FUSED_MIN_READS", "100000")
+    n, L = 400_000, 32
+    rng = np.random.default_rng(23)
+    keys = synth_keys(n, L, 12, 99, sub_rate=3e-3, n_rate=1e-3)
+    weights = None
+    if case in ("one_hot_key", "weights", "spill_full"):
+        share = 0.6 if case == "spill_full" else 0.1            # (the spill list holds an eighth of the reads + 65 536)
+        rows = rng.choice(n, size=int(n * share), replace=False)
+        keys[rows] = keys[rows[0]]
+        near = rows[: len(rows) // 50]                          # ... and its one-error cloud
+        keys[near, rng.integers(0, L, size=len(near))] = ord("A")
+    if case == "zipf":
+        # copies ~ 1 / rank: a few keys with thousands of copies, hundreds with more than a slab holds
+        # (sources without an N: thousands of copies of a key with an N fill the side slabs -- case hot_with_n)
+        src = rng.choice(np.flatnonzero(~(keys == ord("N")).any(axis=1)), size=4000, replace=False)
+        p = 1.0 / np.arange(1, 4001)
+        pick = rng.choice(4000, size=n // 4, p=p / p.sum())
+        rows = rng.choice(n, size=n // 4, replace=False)
+        keys[rows] = keys[src[pick]]
+    if case == "hot_all_t":
+        rows = rng.choice(n, size=n // 10, replace=False)
+        keys[rows] = ord("T")                                   # (the all-ones pattern of the LDS tables)
+    if case == "hot_with_n":
+        rows = rng.choice(n, size=n // 10, replace=False)
+        keys[rows] = keys[rows[0]]
+        keys[rows, 5] = ord("N")
+    if case == "weights":
+        weights = rng.integers(0, 3, size=n).astype(np.uint32)
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=1, method="directional", weights=weights)
+    ctx = F.Context(0)
+    for job in range(2):
+        got = F.cluster_keys(raw, key_len=L, max_distance=1, method="directional", weights=weights, context=ctx)
+        assert (got.n_unique, got.n_clusters, got.n_kept) == (want["n_unique"], want["n_clusters"],
+                                                              len(want["kept_read_ids"])), (case, job)
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), (case, job)
+        r = got.route
+        if case == "spill_full":
+            assert r["restarted"] == (job == 0) and not r["spill_list"] and r["fused_pack"] == False, r
+        elif case == "hot_with_n":
+            pass        # (keys with an N fill the side slabs: uint4 records, stage by stage -- just the result counts)
+        else:
+            assert r["fused_pack"] and r["compact_records"] and r["spill_list"] and not r["restarted"], (case, job, r)
 
 
 @pytest.mark.parametrize("L,n_rate,d", [(1, 0.0, 0), (7, 1e-3, 1), (16, 0.05, 1), (17, 1e-4, 2), (31, 1e-3, 1),
@@ -317,8 +373,10 @@ def test_compact_records_over_lengths_and_n_rates(F, oracle, monkeypatch, L, n_r
     got = F.cluster_keys(raw, key_len=L, max_distance=d, method="directional", context=ctx)
     kt = ctx.kernel_times(reset=True)
     assert kt["pack_kernel"][1] >= 1
-    assert kt["part_scatter12_kernel"][1] == 1                                        # 12-byte records (tried first)
-    if L >= 16:    # (very short keys -- 5 or 16 384 distinct ones -- overfill their slabs: the plain way takes over)
+    assert kt["part_scatter12_kernel"][1] >= 1                                        # 12-byte records (tried first)
+    if L >= 16:    # (very short keys -- 5 or 16 384 distinct ones -- overfill their slabs: once more with the spill
+                   # list, and if that is full as well the plain way takes over)
+        assert kt["part_scatter12_kernel"][1] == 1
         assert kt["part_scatter_kernel<1>"][1] == 0                                   # ... the fused way in
     assert (got.n_unique, got.n_clusters) == (want["n_unique"], want["n_clusters"])
     assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
