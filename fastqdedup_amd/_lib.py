@@ -48,7 +48,7 @@ EXPORTS = [
     "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_set_timing", "fqd_cluster_keys", "fqd_edge_stats", "fqd_synth_keys",
     "fqd_store_add_keys", "fqd_store_remove", "fqd_store_removed_count", "fqd_get_clusters", "fqd_read_clusters",
     "fqd_trie_order", "fqd_trie_stats", "fqd_store_symbol_events", "fqd_get_stream", "fqd_pack_collapse", "fqd_synth_indel_keys", "fqd_copy_bandwidth",
-    "fqd_synth_keys_skewed", "fqd_get_route", "fqd_cluster_subgraph", "fqd_owner_slab_geometry", "fqd_pack_to_owner_slabs", "fqd_collapse_owner_slabs",
+    "fqd_synth_keys_skewed", "fqd_get_route", "fqd_cluster_subgraph", "fqd_cluster_subgraph_home", "fqd_dissect_except", "fqd_owner_slab_geometry", "fqd_pack_to_owner_slabs", "fqd_collapse_owner_slabs",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -112,6 +112,9 @@ def load() -> C.CDLL:
     L.fqd_edge_labels.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, u64p, C.c_int]
     L.fqd_cluster_subgraph.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, u64p, u64p,
                                        C.c_int]
+    L.fqd_cluster_subgraph_home.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p, vp, vp, vp,
+                                            u64p, u64p, u64p, u64p, C.c_int]
+    L.fqd_dissect_except.argtypes = [vp, C.c_int, vp, C.c_uint64, C.c_int, u64p]
     L.fqd_list_kept_except.argtypes = [vp, vp, C.c_uint64, C.c_int, u64p]
     L.fqd_export_unique.argtypes = [vp, vp, vp, vp, vp, C.c_int]
     L.fqd_import_unique.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_int]
@@ -503,6 +506,28 @@ class Context:
         self._ck(self._L.fqd_cluster_subgraph(self._h, ep, rp, int(n_edges), int(n_nodes), int(n_parts), int(part), tp,
                                               sp, C.byref(nt), C.byref(ns), DEVICE))
         return int(nt.value), int(ns.value)
+
+    def cluster_subgraph_home(self, uv, roots, n_edges: int, n_nodes: int, n_parts: int, part: int, uid_bounds,
+                              touched_out, sub_out, home_out):
+        """fqd_cluster_subgraph_home -> (touched nodes, edges of this part's spanning clusters, home edges, edges of
+        ALL parts' spanning clusters)."""
+        ep, _m, _0 = _ptr_mem(uv)
+        rp, _m, _1 = _ptr_mem(roots)
+        tp, _m, _2 = _ptr_mem(touched_out)
+        sp, _m, _3 = _ptr_mem(sub_out)
+        hp, _m, _4 = _ptr_mem(home_out)
+        bounds = (C.c_uint64 * (n_parts + 1))(*[int(b) for b in uid_bounds])
+        nt, ns, nh, nsp = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._L.fqd_cluster_subgraph_home(self._h, ep, rp, int(n_edges), int(n_nodes), int(n_parts), int(part),
+                                                   bounds, tp, sp, hp, C.byref(nt), C.byref(ns), C.byref(nh),
+                                                   C.byref(nsp), DEVICE))
+        return int(nt.value), int(ns.value), int(nh.value), int(nsp.value)
+
+    def dissect_except(self, method: int, dropped, n_dropped: int) -> int:
+        dp, _m, _0 = _ptr_mem(dropped)
+        nk = C.c_uint64(0)
+        self._ck(self._L.fqd_dissect_except(self._h, int(method), dp, int(n_dropped), DEVICE, C.byref(nk)))
+        return int(nk.value)
 
     def list_kept_except(self, dropped, n_dropped: int) -> int:
         dp, dm, _0 = _ptr_mem(dropped)

@@ -178,6 +178,9 @@ struct fqd_ctx {
     uint64_t store_removed = 0, store_table_U = 0, store_next_id = 0;
     // scratch
     DevBuf tmp, stage_a, stage_b, stage_c, stage_d;
+    DevBuf span;                   // fqd_cluster_subgraph_home: one byte per node, 1 = its cluster has keys on two ranks
+    const uint32_t *drop_after = nullptr;   // fqd_dissect_except: rows whose verdict came from elsewhere (device)
+    uint64_t drop_after_n = 0;
 
     // stage timers: one event pair per stage, recorded while the work is queued and resolved when
     // fqd_stage_times asks (a stage end is NOT a host synchronisation point)

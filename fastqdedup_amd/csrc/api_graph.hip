@@ -371,12 +371,39 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
         HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join, 0));
         c->join_pending = false;
     }
+    if (c->drop_after_n) {
+        // (fqd_dissect_except: keys whose cluster was dissected elsewhere stood alone in this graph)
+        FQD_TRY(zero_ctr32(c, C_BAD));
+        HIP_TRY(c, fqd::launch_mark_dropped_after(c->state.as<uint8_t>(), c->best.as<uint32_t>(), U, c->drop_after,
+                                                  c->drop_after_n, c->d_ctr32.as<uint32_t>() + C_BAD, c->st));
+    }
     FQD_TRY(list_kept(c, list_method));
+    if (c->drop_after_n) {
+        uint32_t bad = 0;
+        FQD_TRY(read_ctr32(c, C_BAD, &bad));
+        if (bad)
+            return fail(c, FQD_E_VALUE, "dropped row outside the unique table");
+    }
     timer.stop();
     c->stage = ST_KEPT;
     if (n_kept)
         *n_kept = c->n_kept;
     return FQD_OK;
+}
+
+// fqd_dissect for a rank of a sharded job (sharded.py, home clusters): the edges in the context are those of the
+// clusters that live on this rank alone; `dropped` (device) lists the rows that the dissection of the OTHER clusters
+// -- done elsewhere -- dropped. Those rows have no edge here, so they are kept by this dissection and then overruled.
+int fqd_dissect_except(fqd_ctx *c, int method, const uint32_t *dropped, uint64_t n_dropped, int mem, uint64_t *n_kept)
+{
+    if (mem != FQD_DEVICE && n_dropped)
+        return fail(c, FQD_E_VALUE, "fqd_dissect_except works on device buffers");
+    c->drop_after = dropped;
+    c->drop_after_n = n_dropped;
+    const int rc = fqd_dissect(c, method, n_kept);
+    c->drop_after = nullptr;
+    c->drop_after_n = 0;
+    return rc;
 }
 
 int fqd_set_id_window(fqd_ctx *c, uint64_t lo, uint64_t hi)
@@ -469,14 +496,13 @@ int fqd_edge_labels(fqd_ctx *c, const uint32_t *uv, uint64_t E, uint64_t n_nodes
     HIP_TRY(c, fqd::launch_uf_init(parent, n_nodes, c->st));
     HIP_TRY(c, fqd::launch_uf_union(parent, uv, E, c->stage_b.as<unsigned long long>(), c->st));
     HIP_TRY(c, fqd::launch_edge_roots(parent, uv, E, roots, c->st));
-    std::vector<unsigned long long> slots((size_t)FQD_HOOK_SLOTS * 8);
-    HIP_TRY(c, hipMemcpyAsync(slots.data(), c->stage_b.p, FQD_HOOK_SLOTS * 64, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, stream_wait(c->st));
-    unsigned long long hooks = 0;
-    for (size_t i = 0; i < slots.size(); i += 8)
-        hooks += slots[i];
+    // (the slots added up on the device: one 8-byte read instead of FQD_HOOK_SLOTS x 64 bytes into pageable memory)
+    HIP_TRY(c, fqd::launch_hook_total(c->stage_b.as<unsigned long long>(), n_nodes,
+                                      c->d_ctr64.as<unsigned long long>() + C64_ROOTS, c->st));
+    unsigned long long comps = 0;
+    FQD_TRY(read_ctr64(c, C64_ROOTS, &comps));
     if (n_components)
-        *n_components = n_nodes - hooks;
+        *n_components = comps;
     return FQD_OK;
 }
 
@@ -516,6 +542,65 @@ int fqd_cluster_subgraph(fqd_ctx *c, const uint32_t *uv, const uint32_t *roots, 
         *n_touched = taken_u32(c, 0);
     if (n_sub)
         *n_sub = ns;
+    return FQD_OK;
+}
+
+// fqd_cluster_subgraph with HOME clusters apart (graph.hip): uid_bounds[r] .. uid_bounds[r + 1] is rank r's range of the
+// job-wide key numbering (n_parts + 1 host values, n_parts <= FQD_MAX_HOME_RANKS). home_edges_out (device, 2 E words):
+// the edges of the clusters that live on this rank alone, ends as rows of ITS table; touched_out / sub_edges_out: this
+// rank's share of the clusters that span ranks.
+int fqd_cluster_subgraph_home(fqd_ctx *c, const uint32_t *uv, const uint32_t *roots, uint64_t E, uint64_t n_nodes,
+                              uint32_t n_parts, uint32_t part, const uint64_t *uid_bounds, uint32_t *touched_out,
+                              uint32_t *sub_edges_out, uint32_t *home_edges_out, uint64_t *n_touched, uint64_t *n_sub,
+                              uint64_t *n_home, uint64_t *n_spanning_edges, int mem)
+{
+    FQD_TRY(bind(c));
+    if (mem != FQD_DEVICE)
+        return fail(c, FQD_E_VALUE, "fqd_cluster_subgraph_home works on device buffers");
+    if (!n_parts || part >= n_parts || n_parts > FQD_MAX_HOME_RANKS || n_nodes >= 0xFFFFFFF0ull || !uid_bounds ||
+        ((uintptr_t)uv & 7u))
+        return fail(c, FQD_E_VALUE, "fqd_cluster_subgraph_home: bad arguments");
+    fqd::UidBounds bounds{};
+    bounds.n = n_parts;
+    for (uint32_t r = 0; r <= n_parts; r++) {
+        if (uid_bounds[r] > n_nodes || (r && uid_bounds[r] < uid_bounds[r - 1]))
+            return fail(c, FQD_E_VALUE, "fqd_cluster_subgraph_home: bad key ranges");
+        bounds.lo[r] = (uint32_t)uid_bounds[r];
+    }
+    if (n_touched)
+        *n_touched = 0;
+    if (n_sub)
+        *n_sub = 0;
+    if (n_home)
+        *n_home = 0;
+    if (n_spanning_edges)
+        *n_spanning_edges = 0;
+    if (!E || !n_nodes)
+        return FQD_OK;
+    HIP_TRY(c, c->stage_a.reserve(n_nodes * 4 + 16));       // flags
+    HIP_TRY(c, c->stage_b.reserve(n_nodes * 4 + 16));       // their inclusive scan
+    HIP_TRY(c, c->span.reserve(n_nodes + 16));
+    HIP_TRY(c, hipMemsetAsync(c->stage_a.p, 0, n_nodes * 4, c->st));
+    HIP_TRY(c, hipMemsetAsync(c->span.p, 0, n_nodes, c->st));
+    FQD_TRY(zero_ctr64(c, C64_SUM, 3));     // C64_SUM: edges of my share, + 1: home edges, + 2: edges of spanning clusters
+    unsigned long long *d_n = c->d_ctr64.as<unsigned long long>() + C64_SUM;
+    HIP_TRY(c, fqd::launch_subgraph_mark_home(uv, roots, E, n_parts, part, bounds, c->span.as<uint8_t>(),
+                                              c->stage_a.as<uint32_t>(), sub_edges_out, d_n, home_edges_out, d_n + 1, d_n + 2,
+                                              c->st));
+    FQD_TRY(scan_u32(c, c->stage_a.as<uint32_t>(), c->stage_b.as<uint32_t>(), n_nodes));
+    HIP_TRY(c, fqd::launch_subgraph_finish(c->stage_a.as<uint32_t>(), c->stage_b.as<uint32_t>(), n_nodes, E, touched_out,
+                                           sub_edges_out, d_n, c->st));
+    FQD_TRY(queue_read_u32(c, c->stage_b.as<uint32_t>() + (n_nodes - 1), 0));
+    unsigned long long both[3] = {0, 0, 0};
+    FQD_TRY(read_ctr64(c, C64_SUM, both, 3));
+    if (n_touched)
+        *n_touched = taken_u32(c, 0);
+    if (n_sub)
+        *n_sub = both[0];
+    if (n_home)
+        *n_home = both[1];
+    if (n_spanning_edges)
+        *n_spanning_edges = both[2];
     return FQD_OK;
 }
 

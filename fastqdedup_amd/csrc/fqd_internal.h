@@ -598,6 +598,18 @@ hipError_t launch_hook_total(const unsigned long long *slots, uint64_t n_nodes, 
 hipError_t launch_edge_roots(uint32_t *parent, const uint32_t *edges, uint64_t E, uint32_t *roots, hipStream_t st);
 hipError_t launch_subgraph_mark(const uint32_t *uv, const uint32_t *roots, uint64_t E, uint32_t n_parts, uint32_t part,
                                 uint32_t *flags, uint32_t *sub, unsigned long long *n_sub, hipStream_t st);
+// home clusters (graph.hip): rank r holds the unique keys [lo[r], lo[r + 1]) of the job-wide numbering
+#define FQD_MAX_HOME_RANKS 16
+struct UidBounds {
+    uint32_t n;                                 // ranks
+    uint32_t lo[FQD_MAX_HOME_RANKS + 1];
+};
+hipError_t launch_subgraph_mark_home(const uint32_t *uv, const uint32_t *roots, uint64_t E, uint32_t n_parts, uint32_t part,
+                                     UidBounds bounds, uint8_t *span, uint32_t *flags, uint32_t *sub,
+                                     unsigned long long *n_sub, uint32_t *home, unsigned long long *n_home,
+                                     unsigned long long *n_span, hipStream_t st);
+hipError_t launch_mark_dropped_after(uint8_t *state, uint32_t *best, uint64_t U, const uint32_t *dropped, uint64_t n,
+                                     uint32_t *bad, hipStream_t st);
 hipError_t launch_subgraph_finish(const uint32_t *flags, const uint32_t *flags_incl, uint64_t n_nodes, uint64_t E,
                                   uint32_t *touched, uint32_t *sub, const unsigned long long *n_sub, hipStream_t st);
 hipError_t launch_check_indices(const uint32_t *idx, uint64_t n, uint64_t limit, uint32_t *bad, hipStream_t st);

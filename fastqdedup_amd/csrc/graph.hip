@@ -242,6 +242,108 @@ __global__ __launch_bounds__(1024) void subgraph_mark_kernel(const uint32_t *__r
     }
 }
 
+// ---- ... with HOME clusters apart (sharded.py step 4, the in-place dissection): a cluster all of whose keys live in
+// ONE rank's range of the unique table is dissected by that rank on the table it holds -- no key travels, no verdict
+// comes back. span[root] = 1 for a cluster with an edge between two ranks' ranges (a connected cluster with keys on
+// two ranks has one); this rank then takes (a) the edges of its home clusters, ends renumbered to rows of its own
+// table, and (b) its share (root % n_parts == part) of the spanning clusters, as above.
+__device__ __forceinline__ uint32_t uid_rank(const fqd::UidBounds &b, uint32_t u)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < FQD_MAX_HOME_RANKS; k++)
+        r += (k < b.n && u >= b.lo[k]) ? 1u : 0u;
+    return r;
+}
+
+__global__ void span_mark_kernel(const uint32_t *__restrict__ uv, const uint32_t *__restrict__ roots, uint64_t E,
+                                 fqd::UidBounds bounds, uint8_t *__restrict__ span)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E)
+        return;
+    const uint2 ends = reinterpret_cast<const uint2 *>(uv)[e];
+    if (uid_rank(bounds, ends.x) != uid_rank(bounds, ends.y))
+        span[roots[e]] = 1;
+}
+
+__global__ __launch_bounds__(1024) void subgraph_mark_home_kernel(
+    const uint32_t *__restrict__ uv, const uint32_t *__restrict__ roots, uint64_t E, uint32_t n_parts, uint32_t part,
+    fqd::UidBounds bounds, const uint8_t *__restrict__ span, uint32_t *__restrict__ flags, uint32_t *__restrict__ sub,
+    unsigned long long *__restrict__ n_sub, uint32_t *__restrict__ home, unsigned long long *__restrict__ n_home,
+    unsigned long long *__restrict__ n_span /* edges of spanning clusters, whoever dissects them: the same on every rank */)
+{
+    __shared__ uint32_t s_wave[2][16];
+    __shared__ unsigned long long s_base[2];
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t u = 0, v = 0;
+    bool mine = false, at_home = false, spanning = false;
+    if (e < E) {
+        const uint2 ends = reinterpret_cast<const uint2 *>(uv)[e];
+        u = ends.x;
+        v = ends.y;
+        const uint32_t root = roots[e];
+        spanning = span[root] != 0;
+        if (spanning)
+            mine = root % n_parts == part;
+        else
+            at_home = uid_rank(bounds, u) == part;
+    }
+    {
+        const unsigned long long bs = __ballot(spanning);
+        if (bs && fqd_lane() == 0)
+            atomicAdd(n_span, (unsigned long long)__popcll(bs));
+    }
+    if (mine) {
+        flags[u] = 1u;
+        flags[v] = 1u;
+    }
+    const unsigned long long b0 = __ballot(mine), b1 = __ballot(at_home);
+    if (fqd_lane() == 0) {
+        s_wave[0][wave] = (uint32_t)__popcll(b0);
+        s_wave[1][wave] = (uint32_t)__popcll(b1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            const uint32_t c = s_wave[threadIdx.x][w];
+            s_wave[threadIdx.x][w] = total;
+            total += c;
+        }
+        s_base[threadIdx.x] = total ? atomicAdd(threadIdx.x ? n_home : n_sub, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    if (mine) {
+        const uint64_t at = s_base[0] + s_wave[0][wave] + __popcll(b0 & fqd_lanemask_lt());
+        sub[2 * at] = u;
+        sub[2 * at + 1] = v;
+    }
+    if (at_home) {
+        const uint64_t at = s_base[1] + s_wave[1][wave] + __popcll(b1 & fqd_lanemask_lt());
+        home[2 * at] = u - bounds.lo[part];
+        home[2 * at + 1] = v - bounds.lo[part];
+    }
+}
+
+// the verdicts of clusters dissected elsewhere, over a dissection of this table in which those keys stood alone:
+// "dropped" in every method's reading of best / state (kept_verdict)
+__global__ void mark_dropped_after_kernel(uint8_t *state, uint32_t *best, uint64_t U, const uint32_t *__restrict__ dropped,
+                                          uint64_t n, uint32_t *bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t v = dropped[i];
+    if (v < U) {
+        state[v] = 2;
+        best[v] = 0xFFFFFFFFu;
+    } else {
+        *bad = 1;
+    }
+}
+
 __global__ void subgraph_nodes_kernel(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ flags_incl,
                                       uint64_t n_nodes, uint32_t *__restrict__ touched)
 {
@@ -1233,6 +1335,27 @@ hipError_t launch_subgraph_mark(const uint32_t *uv, const uint32_t *roots, uint6
 {
     if (E)
         subgraph_mark_kernel<<<(unsigned)((E + 1023) / 1024), 1024, 0, st>>>(uv, roots, E, n_parts, part, flags, sub, n_sub);
+    return hipGetLastError();
+}
+
+hipError_t launch_subgraph_mark_home(const uint32_t *uv, const uint32_t *roots, uint64_t E, uint32_t n_parts, uint32_t part,
+                                     UidBounds bounds, uint8_t *span, uint32_t *flags, uint32_t *sub,
+                                     unsigned long long *n_sub, uint32_t *home, unsigned long long *n_home,
+                                     unsigned long long *n_span, hipStream_t st)
+{
+    if (E) {
+        span_mark_kernel<<<grid_for(E), 256, 0, st>>>(uv, roots, E, bounds, span);
+        subgraph_mark_home_kernel<<<(unsigned)((E + 1023) / 1024), 1024, 0, st>>>(uv, roots, E, n_parts, part, bounds, span,
+                                                                                  flags, sub, n_sub, home, n_home, n_span);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_dropped_after(uint8_t *state, uint32_t *best, uint64_t U, const uint32_t *dropped, uint64_t n,
+                                     uint32_t *bad, hipStream_t st)
+{
+    if (n)
+        mark_dropped_after_kernel<<<grid_for(n), 256, 0, st>>>(state, best, U, dropped, n, bad);
     return hipGetLastError();
 }
 

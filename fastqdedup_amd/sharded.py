@@ -221,6 +221,37 @@ class HipBackend:
         nt, ns = self.ctx.cluster_subgraph(edges, roots, n_edges, n_nodes, n_parts, part, touched, sub)
         return touched[:nt], sub[:ns]
 
+    MAX_HOME_RANKS = 16
+
+    def cluster_subgraph_home(self, edges, roots, n_nodes, n_parts, part, uid_bounds):
+        """... with the clusters that live on this rank alone apart (fqd_cluster_subgraph_home): (touched nodes of
+        this rank's share of the SPANNING clusters, their edges renumbered, the edges of its HOME clusters as rows of
+        its own table, the number of edges in spanning clusters job-wide -- every rank computes the same number)."""
+        n_edges = int(edges.shape[0])
+        touched = torch.empty(min(2 * n_edges, n_nodes), dtype=torch.int32, device=self.device)
+        sub = torch.empty((n_edges, 2), dtype=torch.int32, device=self.device)
+        home = torch.empty((n_edges, 2), dtype=torch.int32, device=self.device)
+        if not n_edges:
+            return touched, sub, home, 0
+        nt, ns, nh, n_span = self.ctx.cluster_subgraph_home(edges, roots, n_edges, n_nodes, n_parts, part, uid_bounds,
+                                                            touched, sub, home)
+        return touched[:nt], sub[:ns], home[:nh], n_span
+
+    def finish_owner_home(self, home_edges, method, dropped_rows, id_hi):
+        """The home clusters dissected on the table this rank holds, the rows dropped elsewhere dropped as well ->
+        (ascending kept first-holder ids, count)."""
+        self.ctx.import_edges(home_edges.contiguous(), home_edges.shape[0])
+        self.ctx.components()
+        self.ctx.set_id_window(0, id_hi)
+        try:
+            self.ctx.dissect_except(method, dropped_rows.to(torch.int32).contiguous(), dropped_rows.shape[0])
+        finally:
+            self.ctx.set_id_window()
+        n_kept, n_listed = self.ctx.kept_count()
+        kept = torch.empty(n_listed, dtype=torch.int64, device=self.device)
+        self.ctx.kept_read_ids(n_listed, kept)
+        return kept, n_kept
+
     def gather_unique(self, rows):
         n = rows.shape[0]
         recs, lens = self._rows(n)
@@ -639,7 +670,28 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
     g_edges = comm.all_gather_rows(mine).contiguous()
     n_edges = int(g_edges.shape[0])
     labels, n_clusters = backend.edge_labels(g_edges, n_unique)
-    if hasattr(backend, "cluster_subgraph"):
+    # HOME clusters: a cluster all of whose keys one rank holds (every cluster of a one-rank job; at G ranks the
+    # clusters whose pairs all agree on segment 0) is dissected by that rank on the table it holds -- no key is
+    # fetched, no verdict sent back. The other clusters ("spanning") are dealt out by root as before.
+    home_edges, any_spanning = None, True
+    use_home = (hasattr(backend, "finish_owner_home") and world <= getattr(backend, "MAX_HOME_RANKS", 16)
+                and not os.environ.get("FQD_NO_HOME_CLUSTERS"))
+    if use_home and hasattr(backend, "cluster_subgraph_home"):
+        touched, sub_edges, home_edges, n_span = backend.cluster_subgraph_home(g_edges, labels, n_unique, world, rank,
+                                                                               uid_bounds)
+        any_spanning = n_span > 0        # (computed from the job-wide edge list: the same on every rank)
+    elif use_home:
+        inner = torch.tensor(uid_bounds[1:-1], dtype=torch.int64, device=g_edges.device)
+        owner = torch.bucketize(g_edges.to(torch.int64), inner, right=True)
+        cross = owner[:, 0] != owner[:, 1]
+        spanning = torch.isin(labels, torch.unique(labels[cross]))
+        any_spanning = bool(spanning.any())
+        home_edges = (g_edges[~spanning & (owner[:, 0] == rank)] - uid0).to(torch.int32)
+        my_edges = g_edges[spanning & ((labels % world) == rank)]
+        touched, inverse = torch.unique(my_edges.reshape(-1), return_inverse=True)     # ascending uids
+        sub_edges = inverse.reshape(-1, 2).to(torch.int32)
+        del my_edges
+    elif hasattr(backend, "cluster_subgraph"):
         touched, sub_edges = backend.cluster_subgraph(g_edges, labels, n_unique, world, rank)
     else:
         my_edges = g_edges[(labels % world) == rank]
@@ -651,25 +703,37 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
         tick.mark("gather-edges+label")
 
     # ---- 5. key data of my clusters from their owners; dissect; verdicts back ----------
-    ask_counts = _split_by_bounds(touched, uid_bounds)            # ascending uids are grouped by owner
-    asked_counts = comm.exchange_counts(ask_counts)
-    asked = comm.all_to_all_rows(touched, ask_counts, asked_counts)
-    a_recs, a_lens, a_counts = backend.gather_unique(asked - uid0)
-    t_recs = comm.all_to_all_rows(a_recs, asked_counts, ask_counts)
-    t_counts = comm.all_to_all_rows(a_counts, asked_counts, ask_counts)
-    t_lens = comm.all_to_all_rows(a_lens, asked_counts, ask_counts) if g_ragged else None
-    del a_recs, a_lens, a_counts, asked
-    if tick:
-        tick.mark("fetch-cluster-keys")
-    verdict = backend.dissect_subgraph(t_recs, t_lens, t_counts, sub_edges, method_id)
-    dropped = touched[verdict == 0]
-    del t_recs, t_lens, t_counts, sub_edges
-    if tick:
-        tick.mark("dissect")
-    drop_counts = _split_by_bounds(dropped, uid_bounds)
-    dropped_counts = comm.exchange_counts(drop_counts)
-    dropped_here = comm.all_to_all_rows(dropped, drop_counts, dropped_counts)
-    kept_owned, n_kept_owned = backend.finish_owner(dropped_here - uid0, max(n_total, 1))
+    # (no cluster spans ranks -- a one-rank job, or every pair agrees on segment 0: nothing to fetch or send back,
+    # and every rank knows)
+    if any_spanning:
+        ask_counts = _split_by_bounds(touched, uid_bounds)            # ascending uids are grouped by owner
+        asked_counts = comm.exchange_counts(ask_counts)
+        asked = comm.all_to_all_rows(touched, ask_counts, asked_counts)
+        a_recs, a_lens, a_counts = backend.gather_unique(asked - uid0)
+        t_recs = comm.all_to_all_rows(a_recs, asked_counts, ask_counts)
+        t_counts = comm.all_to_all_rows(a_counts, asked_counts, ask_counts)
+        t_lens = comm.all_to_all_rows(a_lens, asked_counts, ask_counts) if g_ragged else None
+        del a_recs, a_lens, a_counts, asked
+        if tick:
+            tick.mark("fetch-cluster-keys")
+        verdict = backend.dissect_subgraph(t_recs, t_lens, t_counts, sub_edges, method_id)
+        dropped = touched[verdict == 0]
+        del t_recs, t_lens, t_counts, sub_edges
+        if tick:
+            tick.mark("dissect")
+        drop_counts = _split_by_bounds(dropped, uid_bounds)
+        dropped_counts = comm.exchange_counts(drop_counts)
+        dropped_here = comm.all_to_all_rows(dropped, drop_counts, dropped_counts)
+    else:
+        dropped_here = touched[:0]
+        del sub_edges
+        if tick:
+            for name in ("fetch-cluster-keys", "dissect"):
+                tick.mark(name)
+    if home_edges is not None:
+        kept_owned, n_kept_owned = backend.finish_owner_home(home_edges, method_id, dropped_here - uid0, max(n_total, 1))
+    else:
+        kept_owned, n_kept_owned = backend.finish_owner(dropped_here - uid0, max(n_total, 1))
     if tick:
         tick.mark("verdicts-home")
 

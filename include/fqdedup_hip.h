@@ -297,6 +297,19 @@ int fqd_edge_labels(fqd_ctx *ctx, const uint32_t *uv, uint64_t n_edges, uint64_t
 int fqd_cluster_subgraph(fqd_ctx *ctx, const uint32_t *uv, const uint32_t *roots, uint64_t n_edges, uint64_t n_nodes,
                          uint32_t n_parts, uint32_t part, uint32_t *touched_out, uint32_t *sub_edges_out,
                          uint64_t *n_touched, uint64_t *n_sub, int mem);
+/* ... with HOME clusters apart: a cluster all of whose keys lie in ONE rank's range of the job-wide key numbering
+ * (uid_bounds[r] .. uid_bounds[r + 1], n_parts + 1 host values, n_parts <= 16) is dissected by that rank on the
+ * unique table it holds (fqd_import_edges(home edges) + fqd_components + fqd_dissect_except). home_edges_out (2 E
+ * words): the edges of this rank's home clusters, ends as rows of its own table; touched_out / sub_edges_out as
+ * above, over the clusters that span ranks only. */
+int fqd_cluster_subgraph_home(fqd_ctx *ctx, const uint32_t *uv, const uint32_t *roots, uint64_t n_edges, uint64_t n_nodes,
+                              uint32_t n_parts, uint32_t part, const uint64_t *uid_bounds, uint32_t *touched_out,
+                              uint32_t *sub_edges_out, uint32_t *home_edges_out, uint64_t *n_touched, uint64_t *n_sub,
+                              uint64_t *n_home, uint64_t *n_spanning_edges /* of ALL ranks' shares: the same everywhere */,
+                              int mem);
+/* fqd_dissect over the edges in the context (the home clusters), then rows dropped[0..n_dropped) (DEVICE; keys of
+ * clusters dissected on other ranks, which have no edge here) are dropped as well. */
+int fqd_dissect_except(fqd_ctx *ctx, int method, const uint32_t *dropped, uint64_t n_dropped, int mem, uint64_t *n_kept);
 /* Kept list when the verdicts were computed on other ranks: every key of the unique table is
  * kept except rows dropped[0..n_dropped) (DEVICE). Afterwards fqd_get_kept_count /
  * fqd_get_kept_read_ids / fqd_get_unique_table(kept) answer as after fqd_dissect. */

@@ -155,6 +155,17 @@ class NumpyBackend:
         kept = sorted(f for i, f in enumerate(self.table_first) if i not in gone)
         return torch.tensor(kept, dtype=torch.int64), len(kept)
 
+    def finish_owner_home(self, home_edges, method, dropped_rows, id_hi):
+        """Home clusters (edges over rows of this rank's table) dissected in place; rows dropped elsewhere go too."""
+        self.keys = [k.decode("latin-1") for k in self.table]
+        self.counts, self.first = list(self.table_counts), list(range(len(self.table)))
+        self.d, self.edit = self.max_distance, False
+        kept_rows, _, _ = self.finish(home_edges, method, 0, len(self.table))
+        gone = set(dropped_rows.tolist())
+        assert not (gone & set(home_edges.reshape(-1).tolist())), "a dropped key has an edge at home"
+        kept = sorted(self.table_first[i] for i in kept_rows.tolist() if i not in gone)
+        return torch.tensor(kept, dtype=torch.int64), len(kept)
+
     def collapse_packed(self, recs, lens, weights, read_ids):
         ks = self._decode(recs, lens)
         first, count = {}, {}
@@ -236,8 +247,15 @@ def _worker(rank, world, port, shards, d, method, weights, plan, q):
 @pytest.mark.parametrize("plan", ["segment-routed", "gathered"])
 @pytest.mark.parametrize("world,d,method,ragged", [(2, 1, "directional", True), (2, 2, "adjacency", False),
                                                    (3, 1, "highest_count", True)])
-def test_sharded_job_equals_single_job(oracle, world, d, method, ragged, plan):
+@pytest.mark.parametrize("home", [True, False])
+def test_sharded_job_equals_single_job(oracle, monkeypatch, world, d, method, ragged, plan, home):
+    """(home: clusters that live on one rank are dissected there in place -- sharded.py step 4; False: every cluster
+    is dealt out by its root and its keys fetched, the way before)"""
     from fastqdedup_amd.synth import synth_keys
+    if not home:
+        if plan == "gathered":
+            pytest.skip("the gathered plan has no home clusters")
+        monkeypatch.setenv("FQD_NO_HOME_CLUSTERS", "1")      # (inherited by the spawned ranks)
     n, L = 240, 12
     allk = [bytes(r) for r in synth_keys(n, L, 4, 5 + world, sub_rate=0.02, n_rate=0.01)]
     if ragged:
