@@ -48,7 +48,8 @@ EXPORTS = [
     "fqd_within_distance", "fqd_contains", "fqd_quality_filter", "fqd_stage_times", "fqd_kernel_times", "fqd_set_timing", "fqd_cluster_keys", "fqd_edge_stats", "fqd_synth_keys",
     "fqd_store_add_keys", "fqd_store_remove", "fqd_store_removed_count", "fqd_get_clusters", "fqd_read_clusters",
     "fqd_trie_order", "fqd_trie_stats", "fqd_store_symbol_events", "fqd_get_stream", "fqd_pack_collapse", "fqd_synth_indel_keys", "fqd_copy_bandwidth",
-    "fqd_synth_keys_skewed", "fqd_get_route", "fqd_cluster_subgraph", "fqd_cluster_subgraph_home", "fqd_dissect_except", "fqd_owner_slab_geometry", "fqd_pack_to_owner_slabs", "fqd_collapse_owner_slabs",
+    "fqd_synth_keys_skewed", "fqd_get_route", "fqd_cluster_subgraph", "fqd_cluster_subgraph_home", "fqd_dissect_except",
+    "fqd_owner_routing_possible", "fqd_set_owner_routing", "fqd_owner_slab_geometry", "fqd_pack_to_owner_slabs", "fqd_collapse_owner_slabs",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -115,6 +116,8 @@ def load() -> C.CDLL:
     L.fqd_cluster_subgraph_home.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p, vp, vp, vp,
                                             u64p, u64p, u64p, u64p, C.c_int]
     L.fqd_dissect_except.argtypes = [vp, C.c_int, vp, C.c_uint64, C.c_int, u64p]
+    L.fqd_owner_routing_possible.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]
+    L.fqd_set_owner_routing.argtypes = [vp, C.c_int]
     L.fqd_list_kept_except.argtypes = [vp, vp, C.c_uint64, C.c_int, u64p]
     L.fqd_export_unique.argtypes = [vp, vp, vp, vp, vp, C.c_int]
     L.fqd_import_unique.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_int]
@@ -258,6 +261,14 @@ class Context:
         if rc:
             raise ValueError("bad owner slab geometry")
         return int(hb.value), int(subs.value), int(cap.value)
+
+    def owner_routing_possible(self, key_len: int, n_segments: int) -> bool:
+        v = C.c_int(0)
+        self._ck(self._L.fqd_owner_routing_possible(self._h, int(key_len), int(n_segments), C.byref(v)))
+        return bool(v.value)
+
+    def set_owner_routing(self, enable: bool):
+        self._ck(self._L.fqd_set_owner_routing(self._h, 1 if enable else 0))
 
     def pack_to_owner_slabs(self, keys, key_len: int, n_parts: int, n_segments: int, segment: int, geometry,
                             slabs_out, cursors_out):

@@ -1287,6 +1287,35 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
 // at level 2, reading the slabs of all senders in place. Per read and rank: one pass over the key
 // bytes and one partition pass, like the single-GPU path (the general way -- fqd_pack_keys, grouping
 // by owner, level 1 and level 2 at the receiver -- makes four).
+// The routed collapse across ranks: every sender bins its owner slabs by a hash of SEGMENT 0 of the key (the segment
+// the owner rule looks at anyway) instead of the whole key, so that the owner's compaction does search pass 0 on the
+// spot as on one GPU (fqd::Pass0). All ranks must bin alike: the caller asks every rank (fqd_owner_routing_possible)
+// and switches it on everywhere or nowhere (fqd_set_owner_routing).
+static uint32_t owner_route_mask(uint32_t key_len, uint32_t n_segments)
+{
+    if (n_segments < 2 || n_segments > 4 || !key_len || key_len > 32)
+        return 0;
+    const uint32_t seg0_len = key_len / n_segments;            // fqd_segment(len, 0, nseg): [0, len / nseg)
+    if (seg0_len < 8)
+        return 0;
+    return seg0_len >= 32 ? 0xFFFFFFFFu : ((1u << seg0_len) - 1u);
+}
+
+int fqd_owner_routing_possible(const fqd_ctx *c, uint32_t key_len, uint32_t n_segments, int *possible)
+{
+    if (!possible)
+        return FQD_E_VALUE;
+    *possible = !c->route_off && !c->compact_off && !getenv("FQD_NO_ROUTED_COLLAPSE") && !getenv("FQD_NO_COMPACT_RECORDS") &&
+                owner_route_mask(key_len, n_segments) != 0;
+    return FQD_OK;
+}
+
+int fqd_set_owner_routing(fqd_ctx *c, int enable)
+{
+    c->owner_routed = enable != 0;
+    return FQD_OK;
+}
+
 int fqd_owner_slab_geometry(uint64_t n_max, uint32_t n_parts, uint32_t *hash_bins, uint32_t *subs, uint32_t *cap)
 {
     if (!n_parts || n_parts > 256 || !hash_bins || !subs || !cap)
@@ -1351,6 +1380,8 @@ int fqd_pack_to_owner_slabs(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uint32
                         32 - hb_bits, n_bins, subs, cap};
     fs.owner_parts = n_parts;
     fs.owner_hb = hash_bins;
+    if (c->owner_routed && segment == 0)
+        fs.route_mask = owner_route_mask(fixed_len, n_segments);      // (the hash bins follow segment 0 too)
     const fqd::OwnerRule rule{n_parts, n_segments, segment};
     if (n) {
         StageTimer kernel_timer(c, FQD_T_PACK_KERNEL);
@@ -1509,6 +1540,42 @@ int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *
         }
     }
     c->seg_hint = search_segments <= 4 ? search_segments : 0;
+    // the senders binned by segment 0 (fqd_set_owner_routing, on every rank): level 2 does too, and the compaction
+    // reports the pairs of search pass 0 (as pack_collapse_fused_once sets it up on one GPU)
+    if (c->owner_routed && f.compact && c->seg_hint >= 2) {
+        const uint32_t mask = owner_route_mask(c->ks.max_len, c->seg_hint);
+        if (!mask)
+            return fail(c, FQD_E_STATE, "fqd_set_owner_routing is on, but keys of this length cannot be routed");
+        const uint32_t n_buckets = 1u << B;
+        HIP_TRY(c, c->p0_probe.reserve((size_t)n_buckets * fqd::FQD_P0_PROBE_CAP * 4 + 16));
+        HIP_TRY(c, c->ld_hist.reserve(((size_t)n_buckets + std::max(n_buckets >> 8, 1u)) * 4 + 1024 * 4));   // (collapse_lds asks for less)
+        const uint64_t want_edges = std::max<uint64_t>(c->edges.cap / 8, std::max<uint64_t>(1u << 20, n_reads / 8));
+        if (c->edge_cap < want_edges || !c->edges.p) {
+            HIP_TRY(c, c->edges.reserve(want_edges * 8));
+            c->edge_cap = c->edges.cap / 8;
+        }
+        fqd::Pass0 &p0 = f.p0;
+        p0.mask = mask;
+        p0.d = c->seg_hint - 1;
+        p0.bucket_bits = B;
+        p0.max_rows = fqd::pass0_max_rows();
+        if (const char *e = getenv("FQD_P0_MAX_ROWS"))
+            p0.max_rows = (uint32_t)std::max(1, std::min((int)fqd::pass0_max_rows(), atoi(e)));
+        p0.probe = c->p0_probe.as<uint32_t>();
+        p0.probe_n = c->ld_hist.as<uint32_t>();
+        p0.edges = c->edges.as<uint32_t>();
+        p0.edge_count = c->d_ctr64.as<unsigned long long>() + C64_EDGES;
+        p0.edge_cap = c->edge_cap;
+        c->pass0_edge_cap = p0.edge_cap;
+        p0.flag = c->d_ctr32.as<uint32_t>() + C_P0;
+        p0.stats = c->d_stats.as<fqd::PairStats>();
+        HIP_TRY(c, hipMemsetAsync(p0.probe_n, 0, (size_t)n_buckets * 4, c->st));
+        FQD_TRY(zero_ctr64(c, C64_EDGES));
+        HIP_TRY(c, hipMemsetAsync(c->d_stats.p, 0, FQD_STAT_SLOTS * sizeof(fqd::PairStats), c->st));
+        f.route_mask = mask;
+    }
+    // (routing on but no compact records here: the senders' level-1 bins follow the segment-0 hash, level 2 hashes the
+    // whole record -- every copy of a key still meets in one bucket: correct, just without pass 0)
     bool ok = false;
     const bool compact_was_off = c->compact_off;
     int rc = collapse_lds(c, nullptr, ids, &ok, &f);
@@ -1516,6 +1583,8 @@ int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *
         // the side slabs of the compact records overflowed (many keys with an N): once more with uint4 records -- the
         // received slabs are untouched
         f.compact = f.side_slabs = f.side_cap = f.side_slots = 0;
+        f.route_mask = 0;
+        f.p0 = fqd::Pass0();
         FQD_TRY(zero_ctr32(c, 0, C_N32));
         rc = collapse_lds(c, nullptr, ids, &ok, &f);
     }
@@ -1525,6 +1594,8 @@ int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *
     FQD_TRY(rc);
     if (!ok)
         return FQD_OK;
+    c->route = FQD_ROUTE_COLLAPSE_LDS | (f.compact ? FQD_ROUTE_COMPACT_RECORDS : 0u) |
+               (c->pass0_done ? FQD_ROUTE_PASS0_IN_COLLAPSE : 0u);
     c->collapse_path = 1;
     c->collapsed = true;
     c->first_distinct = true;

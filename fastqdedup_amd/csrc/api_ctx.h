@@ -146,6 +146,7 @@ struct fqd_ctx {
     // segments, for the next fqd_find_edges to continue; route_off: a bucket's LDS table overflowed under the
     // routing (many keys share a segment-0 value) -- this context keeps to whole-key hashing.
     bool pass0_done = false, route_off = false;
+    bool owner_routed = false;     // fqd_set_owner_routing: the owner slabs are binned by segment 0 on EVERY rank of the job
     uint32_t pass0_nseg = 0;
     uint64_t pass0_edge_cap = 0;    // the edge list's capacity pass 0 wrote against (pairs behind it were counted, not written)
     DevBuf p0_probe;

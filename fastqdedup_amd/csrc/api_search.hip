@@ -548,8 +548,11 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
     c->search_zero_pending = false;
     // The routed collapse has done pass 0 of exactly this search (fqd::Pass0): its pairs are in the edge list, the
     // segment hashes it wrote start at segment 1, and the passes below start there too.
+    // (seg_hi == 1: a rank of a sharded job asks for pass 0 alone -- fqd_find_edges_segments(0, 1) behind
+    // fqd_collapse_owner_slabs with owner routing: nothing is left to search, the counters are read and that is it)
     const bool pass0_held = c->pass0_done && !edit_general && seg_lo == 0 && n_shards == 1 && max_distance >= 1 &&
-                            c->pass0_nseg == (uint32_t)max_distance + 1 && seg_hi == (uint32_t)max_distance + 1 &&
+                            c->pass0_nseg == (uint32_t)max_distance + 1 &&
+                            (seg_hi == (uint32_t)max_distance + 1 || seg_hi == 1) &&
                             c->seg_hashes_nseg == c->pass0_nseg && c->seg_hashes_first == 1;
     c->pass0_done = false;
     if (pass0_held) {
@@ -609,7 +612,7 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
             cand_budget = strtoull(e, nullptr, 10);
         bool iota_ready = false;
         c->search_keeps_edges = pass0_held;
-        if (grouped_first && grouped)
+        if (grouped_first && grouped && seg_hi > seg_lo)
             c->search_zero_pending = true;           // edges, candidate need, slab flag, statistics: with the partition's first launch
         else
             FQD_TRY(zero_ctr64(c, C64_CAND_NEED, 2));    // ... and C64_SLAB

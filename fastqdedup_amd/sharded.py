@@ -139,6 +139,12 @@ class HipBackend:
         return recs, lens, ids, w_out, [int(c) for c in counts]
 
     # ---- reads -> owner, the fused way (short fixed-length keys, no weights) -------------------
+    def owner_routing_possible(self, key_len, n_segments):
+        return self.ctx.owner_routing_possible(key_len, n_segments)
+
+    def set_owner_routing(self, enable):
+        self.ctx.set_owner_routing(enable)
+
     def pack_into_owner_slabs(self, keys, key_len, n_parts, n_segments, geometry, slabs_out, cursors_out):
         """One chunk of this rank's reads into the caller's slab buffers (rows of 4 words; cursors): reads per
         owner, or None when the general way must be taken."""
@@ -529,6 +535,10 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
                      and n_max >= int(os.environ.get("FQD_OWNER_SLABS_MIN_READS", 1 << 20))
                      and not os.environ.get("FQD_NO_OWNER_SLABS"))
         want_slabs = not comm.any_flag(not can_slabs)      # (weights, switches: every rank must agree)
+        if want_slabs and hasattr(backend, "set_owner_routing"):
+            # the slabs binned by segment 0 on every rank (search pass 0 then happens in the owner's collapse,
+            # fqd_set_owner_routing) -- or on none
+            backend.set_owner_routing(not comm.any_flag(not backend.owner_routing_possible(fixed, n_seg)))
         if want_slabs:
             # FQD_SHARD_CHUNKS=n: the reads leave in n pieces -- while chunk k travels (the all-to-all runs on
             # torch's / RCCL's stream, ordered behind the pack of chunk k only), the library packs chunk k + 1 on

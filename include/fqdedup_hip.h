@@ -243,6 +243,14 @@ int fqd_collapse_received(fqd_ctx *ctx, const uint32_t *weights, const uint64_t 
  * fqd_owner_slab_geometry gives (hash_bins, subs, cap) for ranks that pack at most n_max reads each;
  * all ranks of a job must use the same values. Replaces, per batch and rank, the reference's insert
  * loop __init__.py:242-252 like fqd_pack_keys + fqd_collapse do. */
+/* Owner slabs binned by SEGMENT 0 of the key (what the owner rule looks at) instead of the whole key: the owner's
+ * compaction then reports the pairs of search pass 0 itself, as fqd_cluster_keys does on one GPU, and
+ * fqd_find_edges_segments(0, 1) has nothing left to search. Every rank of the job must bin alike: ask every rank
+ * (possible: keys of <= 32 symbols with a segment 0 of >= 8, compact records, no crowded segment value met before)
+ * and switch it on everywhere or nowhere; the setting holds for the fqd_pack_to_owner_slabs /
+ * fqd_collapse_owner_slabs calls that follow. */
+int fqd_owner_routing_possible(const fqd_ctx *ctx, uint32_t key_len, uint32_t n_segments, int *possible);
+int fqd_set_owner_routing(fqd_ctx *ctx, int enable);
 int fqd_owner_slab_geometry(uint64_t n_max, uint32_t n_parts, uint32_t *hash_bins, uint32_t *subs, uint32_t *cap);
 int fqd_pack_to_owner_slabs(fqd_ctx *ctx, const uint8_t *bytes, uint64_t n, uint32_t fixed_len, int mem, uint32_t n_parts,
                             uint32_t n_segments, uint32_t segment, uint32_t hash_bins, uint32_t subs, uint32_t cap,

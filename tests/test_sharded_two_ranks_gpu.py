@@ -239,3 +239,66 @@ def test_two_ranks_at_scale_equal_the_single_gpu_job():
         assert (count, total, mixed) == (int(mine.shape[0]), int(mine.sum().item()),
                                          int((mine * (mine % 1009 + 1)).sum().item())), rank
         assert (n_clusters, n_unique, n_kept) == (want.n_clusters, want.n_unique, want.n_kept)
+
+
+@pytest.mark.parametrize("routed", [False, True])
+def test_eight_owners_geometry_in_one_process(routed):
+    """The way in of an 8-rank job -- 8 senders x 8 owners, 32 hash bins per owner (config 4's geometry), ids stamped
+    with 8 sender ranks -- on ONE process (a GPU box admits 6 processes): every "rank" packs its shard into owner-major
+    slabs, every "owner" gets the slab ranges an all-to-all would deliver and collapses them. The union of the owners'
+    unique tables must be the single-GPU job's table; with owner routing (fqd_set_owner_routing) the owners' collapse
+    reports search pass 0, whose pairs must be the ones the search finds without it."""
+    import fastqdedup_amd as F
+    world, n_per_rank, L, seed, d = 8, 400_000, 32, 4242, 1
+    n = world * n_per_rank
+    gpu = torch.device("cuda", 0)
+    ctx = F.Context(0)
+    dna = np.zeros(128, dtype=np.uint8)
+    dna[[ord(ch) for ch in "ACGNT"]] = 1
+    ctx.configure(dna, L, False)
+    assert ctx.owner_routing_possible(L, d + 1)
+    ctx.set_owner_routing(routed)
+    geometry = F.Context.owner_slab_geometry(n_per_rank, world)
+    hb, subs, cap = geometry
+    assert hb == 32                                              # 256 level-1 bins over 8 owners
+    parts = world * hb * subs
+    keys = torch.empty(n * L, dtype=torch.uint8, device=gpu)
+    ctx.synth_keys(keys, n, 0, n, L, 12, seed, sub_rate=3e-3, n_rate=1e-3)
+    send = torch.empty((world, parts * cap, 4), dtype=torch.int32, device=gpu)
+    scur = torch.empty((world, parts), dtype=torch.int32, device=gpu)
+    per_owner = np.zeros(world, dtype=np.int64)
+    for s in range(world):
+        counts = ctx.pack_to_owner_slabs(keys[s * n_per_rank * L:(s + 1) * n_per_rank * L], L, world, d + 1, 0, geometry,
+                                         send[s], scur[s])
+        assert counts is not None and sum(counts) == n_per_rank
+        per_owner += np.array(counts)
+    ppo = hb * subs                                              # slabs per (sender, owner)
+    first_all, count_all, pass0_pairs = [], [], set()
+    for p in range(world):
+        recv = torch.stack([send[s].reshape(world, ppo * cap, 4)[p] for s in range(world)]).reshape(-1, 4).contiguous()
+        rcur = torch.stack([scur[s].reshape(world, ppo)[p] for s in range(world)]).reshape(-1).contiguous()
+        nu = ctx.collapse_owner_slabs(recv, rcur, world, p, geometry, [s * n_per_rank for s in range(world)], n,
+                                      int(per_owner[p]), d + 1)
+        assert nu is not None, p
+        ne = ctx.find_edges_segments(d, 0, 1)
+        assert ctx.route()["pass0_continued"] == routed, (p, ctx.route())
+        first, counts, _, _ = ctx.unique_table(nu, labels=False, kept=False)
+        edges = np.empty((ne, 2), dtype=np.int32)
+        ctx.export_edges(edges)
+        a, b = first[edges[:, 0]], first[edges[:, 1]]
+        pass0_pairs |= set(zip(np.minimum(a, b).tolist(), np.maximum(a, b).tolist()))
+        first_all.append(first)
+        count_all.append(counts)
+    first_all, count_all = np.concatenate(first_all), np.concatenate(count_all)
+    order = np.argsort(first_all)
+    one = F.Context(0)
+    want = F.cluster_keys(keys, key_len=L, max_distance=d, method="directional", context=one)
+    w_first, w_counts, _, _ = one.unique_table(want.n_unique, labels=False, kept=False)
+    w_order = np.argsort(w_first)
+    assert np.array_equal(first_all[order], w_first[w_order])
+    assert np.array_equal(count_all[order], w_counts[w_order])
+    # pass 0 = the pairs within distance d that agree on segment 0: the same set either way (kept for the other run)
+    seen = test_eight_owners_geometry_in_one_process.__dict__.setdefault("pairs", {})
+    seen[routed] = pass0_pairs
+    if len(seen) == 2:
+        assert seen[False] == seen[True] and len(seen[True]) > 1000
