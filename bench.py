@@ -469,11 +469,33 @@ def main():
                 "input_gb_per_s_incl_compute": round(in_bytes / dt / 1e9, 1),
                 "input_gb_per_s_excl_compute": round(in_bytes / max(dt - ms_per_step * 1e-3, 1e-9) / 1e9, 1),
                 "pinned_h2d_gb_per_s": pinned_h2d_gbs(device),
-                "note": "keys start in pageable host memory, kept ids end in host memory. pinned_h2d_gb_per_s: the "
-                        "link's rate in this run (a 1 GiB copy out of pinned memory). Staging the pageable keys "
-                        "through two pinned buffers filled by 8 host threads was measured and dropped: 42.1 ms against "
-                        "40.5 ms for the driver's own pageable path"}
+                "note": "keys start in pageable host memory, kept ids end in host memory (a page-locked array out of "
+                        "torch's caching host allocator: into a fresh pageable array the 100 MB of ids took 9.8 ms, "
+                        "tools/diag_e2e.py). pinned_h2d_gb_per_s: the link's rate in this run (a 1 GiB copy out of pinned "
+                        "memory); the driver's own pageable path moves the keys at that rate too, so staging them through "
+                        "pinned buffers filled by host threads only added time (42.1 ms against 40.5)"}
         del host_keys
+        # ... and with the keys in PINNED host memory (what a reader that decodes into page-locked buffers hands over):
+        # the copy then runs at the link's rate and the step behind it
+        if in_bytes <= (4 << 30) and pcie["pinned_h2d_gb_per_s"]:
+            try:
+                pinned = torch.empty(in_bytes, dtype=torch.uint8).pin_memory()
+                pinned.copy_(keys.reshape(-1)[:in_bytes])
+                torch.cuda.synchronize(device)
+                pk = pinned.numpy()
+                F.cluster_keys(pk, host_offsets, host_len, max_distance=wl["d"], use_edit_distance=wl["edit"],
+                               method=wl["method"], context=ctx)
+                t1 = time.perf_counter()
+                F.cluster_keys(pk, host_offsets, host_len, max_distance=wl["d"], use_edit_distance=wl["edit"],
+                               method=wl["method"], context=ctx)
+                dtp = time.perf_counter() - t1
+                link_ms = in_bytes / (pcie["pinned_h2d_gb_per_s"] * 1e9) * 1e3
+                pcie["pinned_input"] = {"ms": round(dtp * 1e3, 3), "reads_per_s": round(n / dtp, 1),
+                                        "bytes_over_link_rate_ms": round(link_ms, 3),
+                                        "ratio_to_link_time": round(dtp * 1e3 / link_ms, 3)}
+                del pinned, pk
+            except Exception as exc:          # (no page-locked memory to be had: the pageable figure stands alone)
+                pcie["pinned_input"] = {"error": str(exc)[:200]}
 
     # whole-job algorithmic traffic as SURVEY.md section 8d defines it (ALG_BYTES_V1): pack + collapse
     # + (d+1) search passes + edges + dissection, with N, U, E of this run
@@ -496,6 +518,7 @@ def main():
                         "(value = reads / t_dev); t_e2e (pageable host keys -> host ids, PCIe-inclusive) is "
                         "reported as t_e2e_ms / host_input and is never `value`",
         "t_dev_ms": round(ms_per_step, 3), "t_e2e_ms": None if pcie is None else pcie["ms"],
+        "t_e2e_pinned_ms": None if pcie is None else pcie.get("pinned_input", {}).get("ms"),
         "data": "synthetic keys generated in HBM (fqd_synth_keys, fastqdedup_amd/synth.py)",
         "config": {"workload": wl["name"], "reads_per_gpu": n, "reads_total": n_total, "key_len": L,
                    "max_distance": wl["d"], "metric": "edit" if wl["edit"] else "hamming",
