@@ -225,46 +225,88 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
     // four record quarters per lane and step: the four position loads go out together, then the four record
     // gathers (one after the other, every step waited for a chain of two dependent round trips -- 25-50 steps per
     // wave: 1.3 ms for 12.9 M records of 128 bytes, config 4)
-    constexpr uint32_t CP = 4;
+    // (clamped indices, unconditional loads: "x < total ? load : 0" compiles to a branch per load with a wait inside,
+    // and the CP gathers then go out one after the other -- DESIGN.md section 0, item 2)
+#ifndef FQD_PAIRS_COMPACT_CP
+#define FQD_PAIRS_COMPACT_CP 4
+#endif
+    constexpr uint32_t CP = FQD_PAIRS_COMPACT_CP;
     const uint32_t total = cnt * q_per_rec;
+    // q_per_rec a power of two (always when hashes are asked for): x / q and x % q are a shift and a mask, and a lane
+    // keeps its quarter q across its steps (64 is a multiple of q_per_rec) -- for keys of one length the segment masks
+    // of its four words are computed once per wave, not once per record quarter
+    const bool pow2 = (q_per_rec & (q_per_rec - 1)) == 0;
+    const uint32_t q_shift = pow2 ? (uint32_t)__ffs((int)q_per_rec) - 1u : 0u;
+    constexpr uint32_t MAX_SEG = 4;
+    uint32_t seg_mask[MAX_SEG][4];
+    const bool fixed_masks = sho.nseg && sho.nseg <= MAX_SEG && !lens && pow2;
+    if (fixed_masks) {
+        const uint32_t q = fqd_lane() & (q_per_rec - 1);
+        for (uint32_t sg = 0; sg < MAX_SEG; sg++) {
+            uint32_t lo = 0, hi = 0;
+            if (sg < sho.nseg)
+                fqd_segment(sho.len, sg, sho.nseg, lo, hi);
+#pragma unroll
+            for (uint32_t e = 0; e < 4; e++) {
+                const uint32_t jw = q * 4 + e;
+                seg_mask[sg][e] = sg < sho.nseg && jw < sho.kw ? fqd_range_mask(jw / sho.planes, lo, hi) : 0u;
+            }
+        }
+    }
     for (uint32_t x0 = fqd_lane(); x0 < total; x0 += CP * 64) {
-        uint32_t rep[CP];
+        uint32_t rep[CP], klen_of[CP];
         uint4 v[CP];
 #pragma unroll
         for (uint32_t t = 0; t < CP; t++) {
-            const uint32_t x = x0 + t * 64;
-            rep[t] = x < total ? tmp_rep[src + x / q_per_rec] : 0u;
+            const uint32_t xc = min(x0 + t * 64, total - 1);
+            rep[t] = tmp_rep[src + (pow2 ? xc >> q_shift : xc / q_per_rec)];
         }
 #pragma unroll
         for (uint32_t t = 0; t < CP; t++) {
-            const uint32_t x = x0 + t * 64;
-            v[t] = make_uint4(0, 0, 0, 0);
-            if (x < total)
-                v[t] = recs4[(size_t)rep[t] * q_per_rec + x % q_per_rec];
+            const uint32_t xc = min(x0 + t * 64, total - 1);
+            v[t] = recs4[(size_t)rep[t] * q_per_rec + (pow2 ? xc & (q_per_rec - 1) : xc % q_per_rec)];
+        }
+        if (sho.nseg && lens) {              // (ragged keys: segments of the key's own length; one branch for the CP loads)
+#pragma unroll
+            for (uint32_t t = 0; t < CP; t++)
+                klen_of[t] = lens[rep[t]];
+        } else {
+#pragma unroll
+            for (uint32_t t = 0; t < CP; t++)
+                klen_of[t] = sho.len;
         }
 #pragma unroll
         for (uint32_t t = 0; t < CP; t++) {
             const uint32_t x = x0 + t * 64;
             if (x >= total)
                 continue;              // (a record's q_per_rec lanes stay or leave together: 64 is a multiple of it when hashes are asked for)
-            const uint32_t j = x / q_per_rec, q = x - j * q_per_rec;
+            const uint32_t j = pow2 ? x >> q_shift : x / q_per_rec, q = x - j * q_per_rec;
             urecs4[(size_t)(begin + j) * q_per_rec + q] = v[t];
             if (sho.nseg) {
                 // as segment_hashes_kernel (edges.hip): the record's q_per_rec lanes sit side by side in
                 // the wave (q_per_rec divides 64), each sums its four words' share of a segment
                 const uint32_t word[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
-                const uint32_t klen = lens ? lens[rep[t]] : sho.len;       // (ragged keys: segments of the key's own length)
+                const uint32_t klen = klen_of[t];
                 for (uint32_t sg = 0; sg < sho.nseg; sg++) {
-                    uint32_t lo, hi;
-                    fqd_segment(klen, sg, sho.nseg, lo, hi);
                     uint32_t part = 0;
+                    if (fixed_masks) {
 #pragma unroll
-                    for (uint32_t e = 0; e < 4; e++) {
-                        const uint32_t jw = q * 4 + e;             // word index in the record
-                        if (jw < sho.kw) {
-                            const uint32_t m = fqd_range_mask(jw / sho.planes, lo, hi);
+                        for (uint32_t e = 0; e < 4; e++) {
+                            const uint32_t m = seg_mask[sg < MAX_SEG ? sg : 0][e];
                             if (m)
-                                part += fqd_mix32((word[e] & m) + (jw + 1u) * 0x9E3779B1u);
+                                part += fqd_mix32((word[e] & m) + (q * 4 + e + 1u) * 0x9E3779B1u);
+                        }
+                    } else {
+                        uint32_t lo, hi;
+                        fqd_segment(klen, sg, sho.nseg, lo, hi);
+#pragma unroll
+                        for (uint32_t e = 0; e < 4; e++) {
+                            const uint32_t jw = q * 4 + e;             // word index in the record
+                            if (jw < sho.kw) {
+                                const uint32_t m = fqd_range_mask(jw / sho.planes, lo, hi);
+                                if (m)
+                                    part += fqd_mix32((word[e] & m) + (jw + 1u) * 0x9E3779B1u);
+                            }
                         }
                     }
                     for (uint32_t off = 1; off < q_per_rec; off <<= 1) {

@@ -5,6 +5,5 @@ run() {
         python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$w $*'.ljust(44), d['ms_per_step'], d['stage_ms_per_step'], d.get('job_roofline',{}).get('frac')); print('    ', {k['kernel'].replace('_kernel','')[:26]: k['ms_per_step'] for k in d['kernels']})"
 }
 run config4 FQD_AB=base
-run config4 FQD_UF_NO_SAMPLING=1
-run config4 FQD_NO_GRAPH_OVERLAP=1
-run config4 FQD_NO_GRAPH_OVERLAP=1 FQD_UF_NO_SAMPLING=1
+run config5v FQD_AB=base
+run config2 FQD_AB=base
