@@ -168,14 +168,17 @@ static int list_kept(fqd_ctx *c, int method)
         c->roots_seen = both[0];
         c->n_kept = both[1];
         c->n_listed = taken_u32(c, 0);
-        // a union-find in which a sixteenth of the edges had to walk twice has met a giant component: from now on
-        // this context hooks every 16th edge first
-        if (!c->uf_sampled && c->E >= 65536 && both[C64_UF_AGAIN - C64_ROOTS] > c->E / 16)
+        // a union-find with a second walk for every fifth edge has met a giant component: from now on this context
+        // hooks every 16th edge first. (Measured, walks per edge: config 3 0.013, config 2 0.035, config 4 -- d = 2,
+        // millions of clusters of 3-4 keys whose neighbours hook first -- 0.16, where the two launches cost 0.03 ms
+        // and gain nothing; the skewed model with its 65 536-key component 0.27-0.29, where they gain 0.7 ms.)
+        if (!c->uf_sampled && c->E >= 65536 && both[C64_UF_AGAIN - C64_ROOTS] > c->E / 5)
             c->uf_sampled = true;
         if (getenv("FQD_DEBUG"))
-            fprintf(stderr, "[fqd] kept list by id bins: U=%llu base=%llu window=%llu shift=%u kept=%llu listed=%llu\n",
+            fprintf(stderr, "[fqd] kept list by id bins: U=%llu base=%llu window=%llu shift=%u kept=%llu listed=%llu; union-find: %llu second walks for %llu edges, sampled=%d\n",
                     (unsigned long long)U, (unsigned long long)base, (unsigned long long)window, shift,
-                    (unsigned long long)c->n_kept, (unsigned long long)c->n_listed);
+                    (unsigned long long)c->n_kept, (unsigned long long)c->n_listed,
+                    (unsigned long long)both[C64_UF_AGAIN - C64_ROOTS], (unsigned long long)c->E, (int)c->uf_sampled);
         return FQD_OK;
     }
     if (by_map) {

@@ -109,9 +109,13 @@ __global__ __launch_bounds__(256) void uf_union_kernel(uint32_t *parent, const u
         a = uv.x;
         b = uv.y;
     }
-    bool active = a != b, again = false;
+    // (second and later walks of the wave's lanes, counted per walk: a lane of a giant component retries many times,
+    // a lane of a small cluster whose neighbour hooked first retries once)
+    bool active = a != b;
+    uint32_t walks_again = 0;
     for (bool fresh = false; __ballot(active); fresh = true) {
-        again = again || (active && fresh);
+        if (fresh)
+            walks_again += (uint32_t)__popcll(__ballot(active));
         if (active) {
             // the first walk through the CU's cache (see uf_find): a common ancestor found there IS one
             a = fresh ? uf_find<true>(parent, a) : uf_find<false>(parent, a);
@@ -150,9 +154,8 @@ __global__ __launch_bounds__(256) void uf_union_kernel(uint32_t *parent, const u
         const unsigned long long m = __ballot(hooked);
         if (m && lane == (uint32_t)(__ffsll((long long)m) - 1))
             atomicAdd(n_hooks + (size_t)(blockIdx.x % FQD_HOOK_SLOTS) * 8, (unsigned long long)__popcll(m));
-        const unsigned long long r = __ballot(again);
-        if (r && lane == (uint32_t)(__ffsll((long long)r) - 1))
-            atomicAdd(n_hooks + (size_t)(blockIdx.x % FQD_HOOK_SLOTS) * 8 + 1, (unsigned long long)__popcll(r));
+        if (walks_again && lane == 0)
+            atomicAdd(n_hooks + (size_t)(blockIdx.x % FQD_HOOK_SLOTS) * 8 + 1, (unsigned long long)walks_again);
     }
 }
 
