@@ -1542,7 +1542,10 @@ int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *
     c->seg_hint = search_segments <= 4 ? search_segments : 0;
     // the senders binned by segment 0 (fqd_set_owner_routing, on every rank): level 2 does too, and the compaction
     // reports the pairs of search pass 0 (as pack_collapse_fused_once sets it up on one GPU)
-    if (c->owner_routed && f.compact && c->seg_hint >= 2) {
+    // (not where a bucket holds more reads than pass 0 is good for -- 5 to 8 ranks at 50 M reads each leave ~1500 reads
+    // in each of the 2^15 buckets level 2 can make: a wave holds 512 unique rows, and a bucket beyond that sends the
+    // whole pass back to the search. The senders' bins still follow segment 0; level 2 then hashes whole keys.)
+    if (c->owner_routed && f.compact && c->seg_hint >= 2 && (n_reads >> B) <= 1200) {
         const uint32_t mask = owner_route_mask(c->ks.max_len, c->seg_hint);
         if (!mask)
             return fail(c, FQD_E_STATE, "fqd_set_owner_routing is on, but keys of this length cannot be routed");

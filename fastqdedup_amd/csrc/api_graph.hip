@@ -91,7 +91,8 @@ static int graph_preinit(fqd_ctx *c, int method)
                                          c->hook_slots.as<unsigned long long>(), FQD_HOOK_SLOTS * 8, c->st,
                                          c->kept_u32.as<uint32_t>(), 512 * fqd::kept_bin_lists(),
                                          c->d_ctr64.as<unsigned long long>() + C64_SUM,
-                                         c->d_ctr64.as<unsigned long long>() + C64_CANDS));
+                                         c->d_ctr64.as<unsigned long long>() + C64_CANDS,
+                                         closed ? c->ucounts.as<uint32_t>() : nullptr));
     c->pre_zero_tail = true;
     c->pre_init_closed = closed;
     c->pre_init = true;
@@ -280,6 +281,9 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
     c->pre_init = c->pre_init_closed = false;          // (one job's worth)
     if (!pre)
         HIP_TRY(c, fqd::launch_dissect_init(c->best.as<uint32_t>(), c->state.as<uint8_t>(), U, c->st));
+    const bool closed_form = method == FQD_METHOD_DIRECTIONAL && c->collapsed && !getenv("FQD_DIRECTIONAL_ROUNDS") && E;
+    if (pre_closed && !closed_form)      // (the set-up launch wrote count nibbles into the state bytes: not for these)
+        HIP_TRY(c, hipMemsetAsync(c->state.p, 0, U, c->st));
     uint32_t *d_changed = c->d_ctr32.as<uint32_t>() + C_CHANGED;
     int list_method = method;      // how list_kept reads the verdicts
     if (method == FQD_METHOD_HIGHEST_COUNT) {
@@ -303,6 +307,8 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
             if (!pre_closed) {
                 HIP_TRY(c, hipMemsetAsync(c->root_taint.p, 0, U, c->st));
                 HIP_TRY(c, fqd::launch_uf_init(c->blocked.as<uint32_t>(), U, c->st));
+                // (the state byte of this dissection starts as the key's count nibble, graph.hip dstate_init)
+                HIP_TRY(c, fqd::launch_dstate_init(c->state.as<uint8_t>(), c->ucounts.as<uint32_t>(), U, c->st));
             }
             for (int pass = 1; pass <= 2; pass++)
                 KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_directional_closed(

@@ -620,7 +620,10 @@ hipError_t launch_dissect_init(uint32_t *best, uint8_t *state, uint64_t U, hipSt
 hipError_t launch_graph_preinit(uint32_t *parent, uint32_t *best, uint8_t *state, uint32_t *parent1, uint8_t *root_taint,
                                 uint64_t U, unsigned long long *hook_slots, uint32_t hook_words, hipStream_t st,
                                 uint32_t *zero32 = nullptr, uint32_t zero32_words = 0,
-                                unsigned long long *zero64_a = nullptr, unsigned long long *zero64_b = nullptr);
+                                unsigned long long *zero64_a = nullptr, unsigned long long *zero64_b = nullptr,
+                                const uint32_t *ucounts = nullptr /* with parent1: state[i] starts as the count nibble of
+                                                                   * the closed-form directional dissection */);
+hipError_t launch_dstate_init(uint8_t *state, const uint32_t *ucounts, uint64_t U, hipStream_t st);
 hipError_t launch_highest_count(const uint32_t *labels, const uint32_t *ucounts, const uint32_t *urecs,
                                 const uint32_t *ulens, KeyShape sh, uint64_t U, uint32_t *best,
                                 hipStream_t st);

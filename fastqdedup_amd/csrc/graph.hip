@@ -406,6 +406,24 @@ __global__ __launch_bounds__(256) void uf_flatten_kernel(uint32_t *parent, uint6
 }
 
 // ---- dissection ------------------------------------------------------------------
+// The state byte of the closed-form directional dissection carries the key's COUNT in its high nibble (15: "15 or
+// more, look it up"), its verdict bits in the low one (0 kept so far, 2, 3, bit 8: see directional_edges_kernel). One
+// random byte per end of an edge then answers both "how many copies" and "what do we know": the pass over the edges
+// fetched a count sector AND a state sector per end before (3.9 GB for the 9.3 M edges of config 4).
+__device__ __forceinline__ uint32_t dstate_init(uint32_t count) { return (count < 15u ? count : 15u) << 4; }
+// verdict bits into the low nibble of state[v], whatever the other bytes of its word are doing
+__device__ __forceinline__ void dstate_or(uint8_t *state, uint32_t v, uint32_t bits)
+{
+    atomicOr(reinterpret_cast<uint32_t *>(state) + (v >> 2), bits << (8u * (v & 3u)));
+}
+
+__global__ void dstate_init_kernel(uint8_t *__restrict__ state, const uint32_t *__restrict__ ucounts, uint64_t U)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < U)
+        state[i] = (uint8_t)dstate_init(ucounts[i]);
+}
+
 // Everything stages 4 and 5 set up over the unique table, in ONE launch (fqd_api_graph_preinit: five
 // launches and two fills of ~5 us each, plus the gaps between them, were 70 us of a 2.9 ms job):
 // parent[i] = i (components), best[i] = i, state[i] = 0 (dissection), and for the closed-form
@@ -415,7 +433,8 @@ __global__ void graph_preinit_kernel(uint32_t *__restrict__ parent, uint32_t *__
                                      uint8_t *__restrict__ root_taint /* with parent1 */, uint64_t U,
                                      unsigned long long *__restrict__ hook_slots, uint32_t hook_words,
                                      uint32_t *__restrict__ zero32 /* may be NULL */, uint32_t zero32_words,
-                                     unsigned long long *__restrict__ zero64_a, unsigned long long *__restrict__ zero64_b)
+                                     unsigned long long *__restrict__ zero64_a, unsigned long long *__restrict__ zero64_b,
+                                     const uint32_t *__restrict__ ucounts /* with parent1: state[i] = count nibble (dstate_init) */)
 {
     // four keys per thread: 16-byte stores for the word arrays, 4-byte stores for the byte arrays
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = q * 4;
@@ -436,7 +455,12 @@ __global__ void graph_preinit_kernel(uint32_t *__restrict__ parent, uint32_t *__
         const uint4 v = make_uint4((uint32_t)i0, (uint32_t)i0 + 1, (uint32_t)i0 + 2, (uint32_t)i0 + 3);
         reinterpret_cast<uint4 *>(parent)[q] = v;
         reinterpret_cast<uint4 *>(best)[q] = v;
-        reinterpret_cast<uint32_t *>(state)[q] = 0u;
+        uint32_t st4 = 0u;
+        if (parent1 && ucounts) {
+            const uint4 c4 = reinterpret_cast<const uint4 *>(ucounts)[q];
+            st4 = dstate_init(c4.x) | dstate_init(c4.y) << 8 | dstate_init(c4.z) << 16 | dstate_init(c4.w) << 24;
+        }
+        reinterpret_cast<uint32_t *>(state)[q] = st4;
         if (parent1) {
             reinterpret_cast<uint4 *>(parent1)[q] = v;
             reinterpret_cast<uint32_t *>(root_taint)[q] = 0u;
@@ -445,7 +469,7 @@ __global__ void graph_preinit_kernel(uint32_t *__restrict__ parent, uint32_t *__
         for (uint64_t i = i0; i < U; i++) {
             parent[i] = (uint32_t)i;
             best[i] = (uint32_t)i;
-            state[i] = 0;
+            state[i] = parent1 && ucounts ? (uint8_t)dstate_init(ucounts[i]) : (uint8_t)0;
             if (parent1) {
                 parent1[i] = (uint32_t)i;
                 root_taint[i] = 0;
@@ -544,11 +568,21 @@ __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *
         uu[t] = uv.x;
         vv[t] = uv.y;
     }
+    uint8_t su[DE_EPT], sv[DE_EPT];
 #pragma unroll
     for (uint32_t t = 0; t < DE_EPT; t++) {
         live[t] = live[t] && uu[t] != vv[t];
-        cu[t] = ucounts[uu[t]];
-        cv[t] = ucounts[vv[t]];
+        su[t] = state[uu[t]];                       // count nibble + what is known of the key so far: ONE byte per end
+        sv[t] = state[vv[t]];
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < DE_EPT; t++) {
+        cu[t] = su[t] >> 4;
+        cv[t] = sv[t] >> 4;
+        if (cu[t] == 15u)                           // (15 or more copies: the count itself -- few keys)
+            cu[t] = ucounts[uu[t]];
+        if (cv[t] == 15u)
+            cv[t] = ucounts[vv[t]];
     }
     uint32_t rank[DE_EPT];
 #pragma unroll
@@ -575,17 +609,18 @@ __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *
             rank[t] = atomicAdd(&s_n, 1u);
             continue;
         }
-        // (a store only where the byte does not say so yet, as far as this CU's cache knows: the 786 K edges of a
-        // 65 536-key component are 1.5 M byte stores into 64 KB otherwise, queueing on the same lines)
+        // (an OR only where the byte -- as fetched above -- does not say so yet: the 786 K edges of a 65 536-key
+        // component are 1.5 M updates of 64 KB otherwise, queueing on the same lines)
         const long long lu = cu[t], lv = cv[t];
-        if (lv >= 2 && 2 * lv - 1 <= lu && state[v] != 2)
-            state[v] = 2;          // arc u -> v from a key of larger count
-        if (lu >= 2 && 2 * lu - 1 <= lv && state[u] != 2)
-            state[u] = 2;
-        if (lu == 1 && state[u] != 3)
-            state[u] = 3;          // here cv >= 2: v reaches u and outranks all of u's count-1 set
-        if (lv == 1 && state[v] != 3)
-            state[v] = 3;
+        const uint32_t ku = su[t] & 15u, kv = sv[t] & 15u;
+        if (lv >= 2 && 2 * lv - 1 <= lu && kv != 2)
+            dstate_or(state, v, 2u);          // arc u -> v from a key of larger count
+        if (lu >= 2 && 2 * lu - 1 <= lv && ku != 2)
+            dstate_or(state, u, 2u);
+        if (lu == 1 && ku != 3)
+            dstate_or(state, u, 3u);          // here cv >= 2: v reaches u and outranks all of u's count-1 set
+        if (lv == 1 && kv != 3)
+            dstate_or(state, v, 3u);
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_n)
@@ -627,7 +662,7 @@ __global__ void directional_roots_kernel(const uint32_t *__restrict__ edges,
                 pr = parent1[r];
             }
             roots[2 * i + k] = r;
-            const uint8_t sx = state[x];
+            const uint8_t sx = state[x];              // (high nibble: the count, see dstate_init)
             if ((sx & 7) == 3)
                 root_taint[r] = 1;
             if (!(sx & 8))
@@ -756,7 +791,7 @@ __device__ __forceinline__ bool kept_verdict(int method, uint32_t v, const uint3
     if (method == 2)
         return best[v] == v;
     if (method == 3) {
-        const uint8_t st = state[v];
+        const uint8_t st = state[v] & 15u;        // (the high nibble is the key's count, see dstate_init)
         if (!(st & 8))
             return st == 0;        // 2: in-arc from a bigger key, 3: count 1 next to a bigger key
         if ((st & 7) == 3)
@@ -791,6 +826,7 @@ __device__ __forceinline__ void kept_verdicts(int method, const uint32_t (&v)[N]
             st[t] = state[v[t]];
 #pragma unroll
         for (uint32_t t = 0; t < N; t++) {
+            st[t] &= 15u;                     // (the high nibble is the key's count)
             if (!valid[t])
                 st[t] = 2;
             k[t] = st[t] == 0;
@@ -958,7 +994,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void kept_bin_ker
         if (METHOD == 3 || METHOD == 1) {
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t st = (st4[h] >> (8 * j)) & 0xFFu;
+                const uint32_t st = (st4[h] >> (8 * j)) & (METHOD == 3 ? 0x0Fu : 0xFFu);   // (3: the high nibble is the count)
                 k[j] = METHOD == 1 ? st == 1 : st == 0;
                 if (METHOD == 3 && (st & 8) && vg == vb && vb + j < U)
                     ask |= 1u << (g * 4 + j);      // (few) a member of a set of count-1 keys asks its root: below
@@ -1401,11 +1437,19 @@ hipError_t launch_uf_flatten(uint32_t *parent, uint64_t U, unsigned long long *n
 hipError_t launch_graph_preinit(uint32_t *parent, uint32_t *best, uint8_t *state, uint32_t *parent1, uint8_t *root_taint,
                                 uint64_t U, unsigned long long *hook_slots, uint32_t hook_words, hipStream_t st,
                                 uint32_t *zero32, uint32_t zero32_words, unsigned long long *zero64_a,
-                                unsigned long long *zero64_b)
+                                unsigned long long *zero64_b, const uint32_t *ucounts)
 {
     const uint64_t quads = (U + 3) / 4;
     graph_preinit_kernel<<<(unsigned)std::max<uint64_t>(1, (quads + 255) / 256), 256, 0, st>>>(
-        parent, best, state, parent1, root_taint, U, hook_slots, hook_words, zero32, zero32_words, zero64_a, zero64_b);
+        parent, best, state, parent1, root_taint, U, hook_slots, hook_words, zero32, zero32_words, zero64_a, zero64_b,
+        ucounts);
+    return hipGetLastError();
+}
+
+hipError_t launch_dstate_init(uint8_t *state, const uint32_t *ucounts, uint64_t U, hipStream_t st)
+{
+    if (U)
+        dstate_init_kernel<<<grid_for(U), 256, 0, st>>>(state, ucounts, U);
     return hipGetLastError();
 }
 
