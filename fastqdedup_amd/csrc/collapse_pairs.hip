@@ -239,13 +239,16 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
     const uint32_t q_shift = pow2 ? (uint32_t)__ffs((int)q_per_rec) - 1u : 0u;
     constexpr uint32_t MAX_SEG = 4;
     uint32_t seg_mask[MAX_SEG][4];
-    const bool fixed_masks = sho.nseg && sho.nseg <= MAX_SEG && !lens && pow2;
+    // (ragged keys: the masks of the bucket's first key's length -- nearly every key of a FASTQ file has the modal
+    // length --, a key of another length computes its own)
+    const bool fixed_masks = sho.nseg && sho.nseg <= MAX_SEG && pow2 && cnt;
+    const uint32_t mask_len = fixed_masks && lens ? lens[tmp_rep[src]] : sho.len;
     if (fixed_masks) {
         const uint32_t q = fqd_lane() & (q_per_rec - 1);
         for (uint32_t sg = 0; sg < MAX_SEG; sg++) {
             uint32_t lo = 0, hi = 0;
             if (sg < sho.nseg)
-                fqd_segment(sho.len, sg, sho.nseg, lo, hi);
+                fqd_segment(mask_len, sg, sho.nseg, lo, hi);
 #pragma unroll
             for (uint32_t e = 0; e < 4; e++) {
                 const uint32_t jw = q * 4 + e;
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
                 const uint32_t klen = klen_of[t];
                 for (uint32_t sg = 0; sg < sho.nseg; sg++) {
                     uint32_t part = 0;
-                    if (fixed_masks) {
+                    if (fixed_masks && klen == mask_len) {
 #pragma unroll
                         for (uint32_t e = 0; e < 4; e++) {
                             const uint32_t m = seg_mask[sg < MAX_SEG ? sg : 0][e];
