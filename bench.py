@@ -472,8 +472,9 @@ def main():
                 "note": "keys start in pageable host memory, kept ids end in host memory (a page-locked array out of "
                         "torch's caching host allocator: into a fresh pageable array the 100 MB of ids took 9.8 ms, "
                         "tools/diag_e2e.py). pinned_h2d_gb_per_s: the link's rate in this run (a 1 GiB copy out of pinned "
-                        "memory); the driver's own pageable path moves the keys at that rate too, so staging them through "
-                        "pinned buffers filled by host threads only added time (42.1 ms against 40.5)"}
+                        "memory); the driver's own pageable path moves the keys at that rate too (staging them through "
+                        "pinned buffers filled by host threads only added time). The keys travel in 8 pieces with the "
+                        "pack kernel of a piece under the copy of the next (FQD_NO_CHUNKED_UPLOAD=1: one copy)"}
         del host_keys
         # ... and with the keys in PINNED host memory (what a reader that decodes into page-locked buffers hands over):
         # the copy then runs at the link's rate and the step behind it

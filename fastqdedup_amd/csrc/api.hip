@@ -1133,7 +1133,20 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     const uint64_t n_bytes = n * (uint64_t)fixed_len;
     const uint8_t *d_bytes;
     StageTimer pack_timer(c, FQD_T_PACK);
-    FQD_TRY(to_device(c, bytes, (size_t)n_bytes, mem, c->in_bytes, &d_bytes));
+    // Keys in HOST memory, a large job: the bytes come over in pieces on the second stream and the pack kernel of
+    // piece k runs under the copy of piece k + 1 (it is the one part of the step that needs nothing but the bytes:
+    // 0.5 ms of a 32 ms PCIe-inclusive step at config 3).
+    uint32_t pieces = 1;
+    if (mem == FQD_HOST && n_bytes >= (256ull << 20) && n >= (1u << 20) && !getenv("FQD_NO_CHUNKED_UPLOAD"))
+        pieces = 8;
+    if (const char *e = getenv("FQD_UPLOAD_PIECES"))
+        pieces = mem == FQD_HOST ? (uint32_t)std::max(1, std::min(64, atoi(e))) : 1u;
+    if (pieces > 1) {
+        HIP_TRY(c, c->in_bytes.reserve((size_t)n_bytes + 16));
+        d_bytes = c->in_bytes.as<uint8_t>();
+    } else {
+        FQD_TRY(to_device(c, bytes, (size_t)n_bytes, mem, c->in_bytes, &d_bytes));
+    }
     HIP_TRY(c, c->ld_part.reserve((size_t)parts * cap1 * 16 + 16));
     HIP_TRY(c, c->ld_seg.reserve((size_t)3 * (parts + 4) * 4));
     uint32_t *seg_start = c->ld_seg.as<uint32_t>(), *cursor = seg_start + (parts + 4);
@@ -1222,7 +1235,21 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
         fs.spill_cap = spill_cap;
         fs.l1_over = spill_words + 4;
     }
-    {
+    if (pieces > 1) {
+        // piece boundaries on multiples of 8192 reads: whole workgroups of the pack kernel, 16-byte aligned bytes
+        const uint64_t per = ((n + pieces - 1) / pieces + 8191) & ~8191ull;
+        for (uint64_t r0 = 0; r0 < n; r0 += per) {
+            const uint64_t r1 = std::min<uint64_t>(n, r0 + per);
+            HIP_TRY(c, hipMemcpyAsync(const_cast<uint8_t *>(d_bytes) + r0 * fixed_len, bytes + r0 * fixed_len,
+                                      (size_t)((r1 - r0) * fixed_len), hipMemcpyHostToDevice, c->st_side));
+            HIP_TRY(c, hipEventRecord(c->ev_fork, c->st_side));
+            HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_fork, 0));
+            fs.id_base = (uint32_t)r0;
+            KTIME(c, FQD_K_PACK, fqd::launch_pack(d_bytes + r0 * fixed_len, (r1 - r0) * fixed_len, nullptr, r1 - r0, fixed_len,
+                                                  sh, c->d_lut.as<uint8_t>(), lut, nullptr, nullptr, nullptr, nullptr,
+                                                  fqd::OwnerRule{}, c->d_ctr32.as<uint32_t>() + C_PACKBAD, c->st, &fs));
+        }
+    } else {
         StageTimer kernel_timer(c, FQD_T_PACK_KERNEL);
         KTIME(c, FQD_K_PACK, fqd::launch_pack(d_bytes, n_bytes, nullptr, n, fixed_len, sh, c->d_lut.as<uint8_t>(), lut,
                                               nullptr, nullptr, nullptr, nullptr, fqd::OwnerRule{},

@@ -251,6 +251,10 @@ struct PackScatter {
     uint32_t *spill_cursor = nullptr;
     uint32_t spill_cap = 0;
     uint32_t *l1_over = nullptr;
+    // the reads of this launch are reads id_base .. of the job (a job packed in pieces, each behind its own
+    // host-to-device copy: the cursors go on from piece to piece)
+    uint32_t id_base = 0;
+    uint32_t sub_rot = 0;      // set by launch_pack: the job-wide number of this launch's first workgroup (sub-part = workgroup % subs)
 };
 // The route hash of a one-word key in (a, b) form -- a = p0 | p2, b = p1 | p2 for the three planes of "ACGNT", the two
 // planes themselves for a two-plane alphabet -- over the bits of segment 0: what the fused pack (level 1), level 2

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
                                                                       K == 3 ? rec[1] | rec[2] : (K >= 2 ? rec[1] : 0u),
                                                                       fs.route_mask)
                                                  : fqd_hash_record(rec, W * K, fixed_len);
-                v[e].w = (uint32_t)(key0 + k);               // the read index travels with the record
+                v[e].w = (uint32_t)(key0 + k) + fs.id_base;   // the read index travels with the record
                 if (fs.owner_parts) {
                     // multi-GPU: the bins are owner-major (owner = rank the read goes to, the pigeonhole
                     // rule of fqd_set_owner_rule), hash bins inside -- an owner's reads leave as ONE
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
         uint32_t excl = incl - mine;
         for (uint32_t wv = 0; wv < wave; wv++)
             excl += s_wave[wv];
-        const uint32_t my_sub = blockIdx.x & (fs.subs - 1);
+        const uint32_t my_sub = (blockIdx.x + fs.sub_rot) & (fs.subs - 1);
         if (tid < fs.n_bins) {
             s_off[tid] = excl;
             uint32_t base = 0;
@@ -609,6 +609,7 @@ hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *o
             return hipErrorInvalidValue;
     }
     const uint64_t tiles_per_block = fused ? FQD_PACK_NSUB : 1;      // (pack_kernel NSUB)
+    fs.sub_rot = (uint32_t)(fs.id_base / (kpb * tiles_per_block));
     const uint64_t blocks = (n + kpb * tiles_per_block - 1) / (kpb * tiles_per_block);
     if (blocks > 0x7FFFFFFFull)
         return hipErrorInvalidValue;

@@ -1276,3 +1276,24 @@ def test_ragged_keys_collapse_without_a_sort(F, oracle, monkeypatch):
         times = ctx.kernel_times(reset=True)
         if path == "pairs":
             assert times["bucket_dedupe_kernel"][1] and not times["head_flags_kernel"][1], times
+
+
+def test_host_keys_uploaded_in_pieces_under_the_pack(F, oracle, monkeypatch):
+    """Keys in host memory, the fused way in: the bytes travel in pieces on the second stream and the pack kernel of a
+    piece runs under the copy of the next (large jobs by default; FQD_UPLOAD_PIECES pins the number). The read indices
+    of the later pieces start at their first read (PackScatter::id_base)."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_FUSED_MIN_READS", "100000")
+    n, L = 300_001, 32                      # (not a multiple of anything: the last piece is short)
+    keys = synth_keys(n, L, 12, 4711, sub_rate=3e-3, n_rate=1e-3)
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=1, method="directional")
+    for pieces in ("1", "3", "16"):
+        monkeypatch.setenv("FQD_UPLOAD_PIECES", pieces)
+        ctx = F.Context(0)
+        got = F.cluster_keys(raw, key_len=L, max_distance=1, method="directional", context=ctx)
+        assert got.route["fused_pack"], got.route
+        per = (-(-n // int(pieces)) + 8191) // 8192 * 8192          # (pieces end on multiples of 8192 reads)
+        assert ctx.kernel_times(reset=True)["pack_kernel"][1] == (1 if pieces == "1" else -(-n // per))
+        assert (got.n_unique, got.n_clusters) == (want["n_unique"], want["n_clusters"]), pieces
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), pieces
