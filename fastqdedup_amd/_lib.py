@@ -49,7 +49,7 @@ EXPORTS = [
     "fqd_store_add_keys", "fqd_store_remove", "fqd_store_removed_count", "fqd_get_clusters", "fqd_read_clusters",
     "fqd_trie_order", "fqd_trie_stats", "fqd_store_symbol_events", "fqd_get_stream", "fqd_pack_collapse", "fqd_synth_indel_keys", "fqd_copy_bandwidth",
     "fqd_synth_keys_skewed", "fqd_get_route", "fqd_cluster_subgraph", "fqd_cluster_subgraph_home", "fqd_dissect_except",
-    "fqd_owner_routing_possible", "fqd_set_owner_routing", "fqd_owner_slab_geometry", "fqd_pack_to_owner_slabs", "fqd_collapse_owner_slabs",
+    "fqd_owner_routing_possible", "fqd_set_owner_routing", "fqd_dense_owner_slabs", "fqd_owner_slab_geometry", "fqd_pack_to_owner_slabs", "fqd_collapse_owner_slabs",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -131,6 +131,7 @@ def load() -> C.CDLL:
     L.fqd_cluster_subgraph_home.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p, vp, vp, vp,
                                             u64p, u64p, u64p, u64p, C.c_int]
     L.fqd_dissect_except.argtypes = [vp, C.c_int, vp, C.c_uint64, C.c_int, u64p]
+    L.fqd_dense_owner_slabs.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.fqd_owner_routing_possible.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]
     L.fqd_set_owner_routing.argtypes = [vp, C.c_int]
     L.fqd_list_kept_except.argtypes = [vp, vp, C.c_uint64, C.c_int, u64p]
@@ -299,6 +300,15 @@ class Context:
         self._ck(self._L.fqd_pack_to_owner_slabs(self._h, kp, n, int(key_len), km, int(n_parts), int(n_segments),
                                                  int(segment), hb, subs, cap, sp, cp, counts, C.byref(done)))
         return [int(x) for x in counts] if done.value else None
+
+    def dense_owner_slabs(self, slabs, cursors, n_parts: int, geometry, rows_out, fills_out):
+        """fqd_dense_owner_slabs: the filled prefixes of the slabs back to back + every slab's fill (device buffers)."""
+        sp, _m, _0 = _ptr_mem(slabs)
+        cp, _m, _1 = _ptr_mem(cursors)
+        rp, _m, _2 = _ptr_mem(rows_out)
+        fp, _m, _3 = _ptr_mem(fills_out)
+        hb, subs, cap = geometry
+        self._ck(self._L.fqd_dense_owner_slabs(self._h, sp, cp, int(n_parts), hb, subs, cap, rp, fp))
 
     def collapse_owner_slabs(self, slabs, cursors, n_senders: int, my_part: int, geometry, sender_id0, id_limit: int,
                              n_reads: int, search_segments: int = 0):

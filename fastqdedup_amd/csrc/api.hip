@@ -1448,6 +1448,26 @@ int fqd_pack_to_owner_slabs(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uint32
     return FQD_OK;
 }
 
+// The filled prefixes of a sender's owner slabs, back to back: what travels when the slack shall stay home (an
+// all-to-all-v by rows instead of equal slab ranges: 1.16 x fewer bytes at 50 M reads, 1.35 x at four chunks).
+// rows_out (device): room for the n reads packed; fills_out (device, n_parts * hash_bins * subs words): every slab's
+// fill -- the owner needs the fills of its slabs (they are equal splits of this array) to find the slabs in the rows.
+int fqd_dense_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *cursors, uint32_t n_parts, uint32_t hash_bins,
+                          uint32_t subs, uint32_t cap, uint32_t *rows_out, uint32_t *fills_out)
+{
+    FQD_TRY(bind(c));
+    const uint64_t parts64 = (uint64_t)n_parts * hash_bins * subs;
+    if (!slabs || !cursors || !rows_out || !fills_out || !n_parts || !hash_bins || subs != 32 || !cap || parts64 > 65536 ||
+        parts64 * cap >= 0xFFFFFF00ull || ((uintptr_t)slabs & 15u) || ((uintptr_t)rows_out & 15u))
+        return fail(c, FQD_E_VALUE, "fqd_dense_owner_slabs: bad arguments");
+    const uint32_t parts = (uint32_t)parts64;
+    HIP_TRY(c, c->ld_seg.reserve((size_t)3 * (parts + 4) * 4));
+    uint32_t *start = c->ld_seg.as<uint32_t>();
+    HIP_TRY(c, fqd::launch_fill_scan(cursors, parts, cap, fills_out, start, nullptr, c->st));
+    HIP_TRY(c, fqd::launch_slab_dense_rows(slabs, start, parts, cap, rows_out, c->st));
+    return FQD_OK;
+}
+
 int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *cursors, uint32_t n_senders,
                              uint32_t my_part, uint32_t hash_bins, uint32_t subs, uint32_t cap, const uint64_t *sender_id0,
                              uint64_t id_limit, uint64_t n_reads, uint32_t search_segments, uint64_t *n_unique, int *done)
@@ -1458,13 +1478,16 @@ int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *
     *done = 0;
     const uint32_t ppo = hash_bins * subs;              // slabs per (sender, owner)
     const uint64_t parts64 = (uint64_t)n_senders * ppo;
-    if (!n_senders || !hash_bins || (hash_bins & (hash_bins - 1)) || subs != 32 || !cap || parts64 > 65536 ||
+    // cap == 0: DENSE rows (fqd_dense_owner_slabs on every sender): `slabs` holds the senders' filled prefixes back to
+    // back, `cursors` the fill of every slab
+    const bool dense = cap == 0;
+    if (!n_senders || !hash_bins || (hash_bins & (hash_bins - 1)) || subs != 32 || parts64 > 65536 ||
         ((uintptr_t)slabs & 15u))
         return fail(c, FQD_E_VALUE, "fqd_collapse_owner_slabs: bad geometry");
     if (!c->shape.planes || c->ks.stride != 4 || c->ks.ragged || c->ks.planes * c->ks.words > 3)
         return fail(c, FQD_E_STATE, "fqd_collapse_owner_slabs needs the geometry of one-uint4 records");
     const uint32_t parts = (uint32_t)parts64;
-    if (parts64 * cap + n_reads >= 0xFFFFFF00ull || n_reads >= 0xFFFFFF00ull)
+    if ((dense ? n_reads : parts64 * cap) + n_reads >= 0xFFFFFF00ull || n_reads >= 0xFFFFFF00ull)
         return FQD_OK;
     // (sender, read index on the sender) must fit the record's spare word
     // (senders in ANY order -- a rank's reads may arrive as several senders, chunk by chunk: a sender's reads lie
@@ -1518,8 +1541,13 @@ int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *
     // segment tables: seg_start (parts + 1) | seg_end (parts) | tile_start (parts + 1), 4 words apart
     HIP_TRY(c, c->ld_seg.reserve((size_t)3 * (parts + 4) * 4));
     uint32_t *seg_start = c->ld_seg.as<uint32_t>(), *seg_end = seg_start + (parts + 4);
-    HIP_TRY(c, fqd::launch_owner_slab_bounds(cursors, n_senders, ppo, my_part, cap, seg_start, seg_end, c->st));
-    c->ld_part.borrow(slabs, (size_t)parts * cap * 16);
+    if (dense) {
+        HIP_TRY(c, fqd::launch_fill_scan(cursors, parts, 0u, nullptr, seg_start, seg_end, c->st));
+        c->ld_part.borrow(slabs, (size_t)n_reads * 16);
+    } else {
+        HIP_TRY(c, fqd::launch_owner_slab_bounds(cursors, n_senders, ppo, my_part, cap, seg_start, seg_end, c->st));
+        c->ld_part.borrow(slabs, (size_t)parts * cap * 16);
+    }
     // id bases of the senders on the device, in ascending order, and every sender's rank in that order: the rank is
     // what level 2 stamps above the read index, so stamped words compare like the ids they stand for
     std::vector<uint32_t> order(n_senders), rank_of(n_senders);

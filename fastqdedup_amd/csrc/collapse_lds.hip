@@ -178,6 +178,71 @@ __global__ void owner_slab_bounds_kernel(const uint32_t *__restrict__ cursors, u
     }
 }
 
+// ---- owner slabs without their slack on the wire (multi-GPU, sharded.py) ------------------------------
+// fill[i] of n slabs and its exclusive prefix sum, ONE block: cap != 0: in[] are the cursors of slabs that start at
+// i * cap (a sender's own slabs); cap == 0: in[] ARE the fills (what a sender told the owner). start has n + 1 entries.
+__global__ __launch_bounds__(1024) void fill_scan_kernel(const uint32_t *__restrict__ in, uint32_t n, uint32_t cap,
+                                                         uint32_t *__restrict__ fills /* may be NULL */,
+                                                         uint32_t *__restrict__ start, uint32_t *__restrict__ end /* may be NULL */)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t per = (n + 1023u) / 1024u, i0 = tid * per, i1 = min(i0 + per, n);
+    auto fill_of = [&](uint32_t i) {
+        const uint32_t v = in[i];
+        if (!cap)
+            return v;
+        const uint32_t first = i * cap;
+        return v > first ? min(v - first, cap) : 0u;
+    };
+    uint32_t mine = 0;
+    for (uint32_t i = i0; i < i1; i++)
+        mine += fill_of(i);
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if ((int)lane >= o)
+            incl += up;
+    }
+    if (lane == 63)
+        s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (uint32_t w = 0; w < wave; w++)
+        run += s_wave[w];
+    for (uint32_t i = i0; i < i1; i++) {
+        const uint32_t f = fill_of(i);
+        start[i] = run;
+        if (fills)
+            fills[i] = f;
+        if (end)
+            end[i] = run + f;
+        run += f;
+    }
+    if ((i0 < n && i1 == n) || (n == 0 && tid == 0))      // (the one thread whose range reaches the end)
+        start[n] = run;
+}
+
+// rows [p * cap, p * cap + fill[p]) of every slab -> dense[start[p] ..): one workgroup per 1024 rows of a slab
+__global__ __launch_bounds__(256) void slab_dense_rows_kernel(const uint4 *__restrict__ slabs, const uint32_t *__restrict__ start,
+                                                              uint32_t cap, uint32_t chunks_per_slab, uint4 *__restrict__ dense)
+{
+    const uint32_t p = blockIdx.x / chunks_per_slab, chunk = blockIdx.x - p * chunks_per_slab;
+    const uint32_t lo = start[p], fill = start[p + 1] - lo;
+    if (chunk * 1024u >= fill)
+        return;
+    uint4 v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)      // (clamped, unconditional: in flight together)
+        v[k] = slabs[(size_t)p * cap + min(chunk * 1024u + k * 256u + threadIdx.x, fill - 1)];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t r = chunk * 1024u + k * 256u + threadIdx.x;
+        if (r < fill)
+            dense[(size_t)lo + r] = v[k];
+    }
+}
+
 __global__ __launch_bounds__(1024) void slab_tile_starts_kernel(const uint32_t *__restrict__ seg_start,
                                                                 const uint32_t *__restrict__ seg_end, uint32_t n_seg,
                                                                 uint32_t *__restrict__ tile_start)
@@ -1430,6 +1495,25 @@ hipError_t launch_owner_slab_bounds(const uint32_t *cursors, uint32_t n_senders,
     const uint32_t n = n_senders * parts_per_owner + 1;
     owner_slab_bounds_kernel<<<(n + 255) / 256, 256, 0, st>>>(cursors, n_senders, parts_per_owner, my_part, cap, seg_start,
                                                              seg_end);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_scan(const uint32_t *in, uint32_t n, uint32_t cap, uint32_t *fills, uint32_t *start, uint32_t *end,
+                            hipStream_t st)
+{
+    fill_scan_kernel<<<1, 1024, 0, st>>>(in, n, cap, fills, start, end);
+    return hipGetLastError();
+}
+
+hipError_t launch_slab_dense_rows(const uint32_t *slabs, const uint32_t *start, uint32_t n_slabs, uint32_t cap,
+                                  uint32_t *dense, hipStream_t st)
+{
+    const uint32_t chunks = (cap + 1023u) / 1024u;
+    if ((uint64_t)n_slabs * chunks > 0x7FFFFFFFull)
+        return hipErrorInvalidValue;
+    if (n_slabs)
+        slab_dense_rows_kernel<<<n_slabs * chunks, 256, 0, st>>>(reinterpret_cast<const uint4 *>(slabs), start, cap, chunks,
+                                                                reinterpret_cast<uint4 *>(dense));
     return hipGetLastError();
 }
 

@@ -614,6 +614,12 @@ hipError_t launch_subgraph_mark_home(const uint32_t *uv, const uint32_t *roots, 
                                      unsigned long long *n_span, hipStream_t st);
 hipError_t launch_mark_dropped_after(uint8_t *state, uint32_t *best, uint64_t U, const uint32_t *dropped, uint64_t n,
                                      uint32_t *bad, hipStream_t st);
+// owner slabs without their slack (collapse_lds.hip): fills + exclusive starts of n slabs (cap == 0: `in` holds fills),
+// and the filled prefixes of the slabs copied to dense[start[p] ..)
+hipError_t launch_fill_scan(const uint32_t *in, uint32_t n, uint32_t cap, uint32_t *fills, uint32_t *start, uint32_t *end,
+                            hipStream_t st);
+hipError_t launch_slab_dense_rows(const uint32_t *slabs, const uint32_t *start, uint32_t n_slabs, uint32_t cap,
+                                  uint32_t *dense, hipStream_t st);
 hipError_t launch_subgraph_finish(const uint32_t *flags, const uint32_t *flags_incl, uint64_t n_nodes, uint64_t E,
                                   uint32_t *touched, uint32_t *sub, const unsigned long long *n_sub, hipStream_t st);
 hipError_t launch_check_indices(const uint32_t *idx, uint64_t n, uint64_t limit, uint32_t *bad, hipStream_t st);

@@ -156,6 +156,14 @@ class HipBackend:
         self.ragged = bool(sh.ragged)
         return counts
 
+    def dense_owner_slabs(self, slabs, cursors, n_parts, geometry, n_rows):
+        """The filled prefixes of the slabs back to back (n_rows x 4 words) and every slab's fill (fqd_dense_owner_slabs)."""
+        hb, subs, _cap = geometry
+        rows = torch.empty((max(int(n_rows), 1), 4), dtype=torch.int32, device=self.device)
+        fills = torch.empty(n_parts * hb * subs, dtype=torch.int32, device=self.device)
+        self.ctx.dense_owner_slabs(slabs, cursors, n_parts, geometry, rows, fills)
+        return rows[: int(n_rows)], fills
+
     def collapse_owner_slabs(self, slabs, cursors, n_senders, my_part, geometry, sender_id0, id_limit, n_reads,
                              search_segments):
         """The receiving side (fqd_collapse_owner_slabs): unique keys of this rank, or None."""
@@ -561,35 +569,61 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
             parts = world * hb * subs
             n_unique_local = None
             if chunks * parts * cap * 16 <= (64 << 30):
-                send = torch.empty((chunks, parts * cap, 4), dtype=torch.int32, device=dev)
+                # Slabs WITHOUT their slack on the wire (more than one rank): every chunk's filled prefixes back to back
+                # (fqd_dense_owner_slabs), moved by an all-to-all-v, the fills by an equal-split one; the owner finds the
+                # slabs in the rows by the fills. With one rank nothing travels and the slabs are read where they lie.
+                dense = (not comm.alone and hasattr(backend, "dense_owner_slabs")
+                         and not os.environ.get("FQD_NO_DENSE_SLABS"))
+                send = torch.empty((1 if dense else chunks, parts * cap, 4), dtype=torch.int32, device=dev)
                 scur = torch.empty((chunks, parts), dtype=torch.int32, device=dev)
-                recv, rcur = (send, scur) if comm.alone else (torch.empty_like(send), torch.empty_like(scur))
+                recv, rcur = (send, scur) if comm.alone else (None if dense else torch.empty_like(send),
+                                                              torch.empty_like(scur))
+                got_rows, got_counts = [], []
                 ok, totals = True, [0] * world
                 mine = all_bounds[rank]
                 for k in range(chunks):
                     lo, hi = mine[k] * key_len, mine[k + 1] * key_len
+                    slab_k = send[0] if dense else send[k]
                     try:
                         counts = backend.pack_into_owner_slabs(keys if chunks == 1 else keys[lo:hi], key_len, world, n_seg,
-                                                               geometry, send[k], scur[k])
+                                                               geometry, slab_k, scur[k])
                     except ValueError:
                         counts = None
                     if counts is None:
                         ok = False                 # (the buffers still travel: every rank takes part in every collective)
                     else:
                         totals = [a + b for a, b in zip(totals, counts)]
-                    comm.all_to_all_into(recv[k], send[k])
-                    comm.all_to_all_into(rcur[k], scur[k])
+                    if dense:
+                        out_counts = counts if counts is not None else [0] * world
+                        rows_k, fills_k = backend.dense_owner_slabs(slab_k, scur[k], world, geometry, sum(out_counts))
+                        if counts is None:
+                            fills_k = torch.zeros_like(fills_k)
+                        in_counts = comm.exchange_counts(out_counts)
+                        got_rows.append(comm.all_to_all_rows(rows_k, out_counts, in_counts))
+                        got_counts.append(in_counts)
+                        comm.all_to_all_into(rcur[k], fills_k)
+                        del rows_k, fills_k
+                    else:
+                        comm.all_to_all_into(recv[k], send[k])
+                        comm.all_to_all_into(rcur[k], scur[k])
                 comm.settle()
                 if tick:
                     tick.mark("pack-to-owner-slabs")        # (with the exchange of all chunks but the last under it)
                 if not comm.any_flag(not ok):               # somebody cannot: everybody takes the general way
-                    recv_counts = comm.exchange_counts(totals)
+                    if dense:
+                        recv_counts = [sum(c[s_] for c in got_counts) for s_ in range(world)]
+                        recv_rows = got_rows[0] if chunks == 1 else torch.cat(got_rows, dim=0)
+                        recv_geometry = (hb, subs, 0)       # (cap 0: dense rows, the "cursors" are fills)
+                    else:
+                        recv_counts = comm.exchange_counts(totals)
+                        recv_rows, recv_geometry = recv.reshape(-1, 4), geometry
                     if tick:
                         tick.mark("all-to-all-slabs")
                     sender_id0 = [id_bounds[s_] + all_bounds[s_][k] for k in range(chunks) for s_ in range(world)]
-                    n_unique_local = backend.collapse_owner_slabs(recv.reshape(-1, 4), rcur.reshape(-1), world * chunks, rank,
-                                                                  geometry, sender_id0, max(n_total, 1),
+                    n_unique_local = backend.collapse_owner_slabs(recv_rows.contiguous(), rcur.reshape(-1), world * chunks,
+                                                                  rank, recv_geometry, sender_id0, max(n_total, 1),
                                                                   int(sum(recv_counts)), n_seg)
+                    del recv_rows
                     if comm.any_flag(n_unique_local is None):
                         n_unique_local = None      # a bucket overflowed somewhere: once more, the general way
                         if os.environ.get("FQD_DEBUG") or os.environ.get("FQD_SHARD_TIMING"):
@@ -599,7 +633,7 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
                                   f"full somewhere); all ranks repeat the way in the general way", file=sys.stderr)
                     if tick:
                         tick.mark("collapse")
-                del send, scur, recv, rcur
+                del send, scur, recv, rcur, got_rows
         if n_unique_local is None:
             foreign = 0
             try:

@@ -255,6 +255,13 @@ int fqd_owner_slab_geometry(uint64_t n_max, uint32_t n_parts, uint32_t *hash_bin
 int fqd_pack_to_owner_slabs(fqd_ctx *ctx, const uint8_t *bytes, uint64_t n, uint32_t fixed_len, int mem, uint32_t n_parts,
                             uint32_t n_segments, uint32_t segment, uint32_t hash_bins, uint32_t subs, uint32_t cap,
                             uint32_t *slabs_out, uint32_t *cursors_out, uint64_t *counts, int *done);
+/* Owner slabs WITHOUT their slack on the wire: the filled prefixes of a sender's slabs back to back (rows_out, device,
+ * room for the reads packed) and every slab's fill (fills_out, device, n_parts * hash_bins * subs words). The caller
+ * moves rows by an all-to-all-v (reads per owner: fqd_pack_to_owner_slabs' counts) and the fills by an equal-split
+ * all-to-all; the owner then calls fqd_collapse_owner_slabs with cap = 0, `slabs` = the received rows (sender by
+ * sender), `cursors` = the received fills. */
+int fqd_dense_owner_slabs(fqd_ctx *ctx, const uint32_t *slabs, const uint32_t *cursors, uint32_t n_parts, uint32_t hash_bins,
+                          uint32_t subs, uint32_t cap, uint32_t *rows_out, uint32_t *fills_out);
 int fqd_collapse_owner_slabs(fqd_ctx *ctx, const uint32_t *slabs, const uint32_t *cursors, uint32_t n_senders,
                              uint32_t my_part, uint32_t hash_bins, uint32_t subs, uint32_t cap,
                              const uint64_t *sender_id0, uint64_t id_limit, uint64_t n_reads, uint32_t search_segments,

@@ -25,6 +25,10 @@ def _worker(rank, world, port, case, plan, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if plan.endswith("+padded"):
+        # whole slabs on the wire, slack included (equal-split all-to-all) instead of their filled prefixes (all-to-all-v)
+        plan = plan[: -len("+padded")]
+        os.environ["FQD_NO_DENSE_SLABS"] = "1"
     if plan.endswith("+chunks3"):
         # ... leaving in three chunks per rank (the exchange of a chunk runs under the pack of the next)
         plan = plan[: -len("+chunks3")]
@@ -59,6 +63,8 @@ def _worker(rank, world, port, case, plan, q):
 @pytest.mark.parametrize("shape,plan", [("fixed32", "segment-routed"), ("fixed32", "gathered"),
                                         ("fixed32", "segment-routed+slabs"), ("fixed32_3ranks", "segment-routed+slabs"),
                                         ("fixed32_5ranks", "segment-routed+slabs"),
+                                        ("fixed32", "segment-routed+slabs+padded"),
+                                        ("fixed32_3ranks", "segment-routed+slabs+chunks3+padded"),
                                         ("fixed32", "segment-routed+slabs+chunks3"),
                                         ("fixed32_3ranks", "segment-routed+slabs+chunks3"),
                                         ("fixed32_foreign", "segment-routed+slabs"),
