@@ -139,6 +139,7 @@ struct FusedLevel1 {
     uint32_t spill_cap = 0;
     uint32_t *spill_cursor = nullptr, *l1_over = nullptr;
     bool can_spill = false;
+    uint32_t spill_used = 0;   // out: records that went to the spill list
 };
 
 // Bucket bits of the LDS collapse for n reads: ~400-800 reads per bucket (2x fewer workgroups than
@@ -378,6 +379,8 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         else
             FQD_TRY(queue_read_u32(c, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 0));
         FQD_TRY(queue_read_u32n(c, c->d_ctr32.as<uint32_t>(), C_P0 + 1, 1));
+        if (spill)
+            FQD_TRY(queue_read_u32(c, side.spill_cursor, 12));
         FQD_TRY(queued_reads_mark(c));
         HIP_TRY(c, c->urecs.reserve(n * 16 + 16));
         HIP_TRY(c, c->ucounts.reserve(n * 4 + 16));
@@ -420,6 +423,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         overflow = taken_u32(c, 1 + C_BAD);
         if (fused) {
             fused->pack_bad = taken_u32(c, 1 + C_PACKBAD);
+            fused->spill_used = spill ? taken_u32(c, 12) : 0u;
             if (overflow && getenv("FQD_DEBUG"))
                 fprintf(stderr, "[fqd] fused collapse: overflow flags 0x%x (1: a bucket's LDS table, 2: a level-2 slab, 4: a level-1 slab or the spill list, 16: the side path)\n", overflow);
             if (overflow & 16u)
@@ -1038,6 +1042,17 @@ static int pack_collapse_fused(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uin
 {
     // ... and when a slab is full -- keys with very many copies -- once more with the spill list (c->heavy_keys: the
     // routed collapse is off then), and so from then on.
+    // A context that gave up a fast path (heavy_keys, route_off) tries it again after fast_retry_after jobs that did
+    // not need the slow one -- a file with PCR jackpots or a poly-A library should not cost every later file of a
+    // long-lived context 0.3-0.6 ms per step; a retry that fails doubles the wait (8, 16, ... 1024 jobs).
+    const bool gave_up_before = c->heavy_keys || c->route_off;
+    if (gave_up_before && c->clean_jobs >= c->fast_retry_after && !getenv("FQD_NO_FAST_PATH_RETRY")) {
+        c->heavy_keys = c->route_off = false;
+        c->clean_jobs = 0;
+        c->fast_probe = true;
+    }
+    const bool heavy_at_start = c->heavy_keys, route_off_at_start = c->route_off;
+    c->last_spill_used = 0;
     for (int attempt = 0; attempt < 3; attempt++) {
         const bool was_off = c->compact_off, was_heavy = c->heavy_keys;
         c->route &= ~FQD_ROUTE_RESTARTED;          // (raised by an attempt that ended early; the last one counts)
@@ -1045,6 +1060,16 @@ static int pack_collapse_fused(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uin
         if (*done || c->fused_off || (was_off == c->compact_off && was_heavy == c->heavy_keys))
             break;
     }
+    if ((c->heavy_keys && !heavy_at_start) || (c->route_off && !route_off_at_start)) {
+        // the data of this job needed the slow way (again)
+        if (c->fast_probe)
+            c->fast_retry_after = std::min<uint32_t>(c->fast_retry_after * 2, 1024u);
+        c->clean_jobs = 0;
+    } else if (c->heavy_keys || c->route_off) {
+        // (with the spill list: clean when nothing was spilled; route_off alone: the collapse cannot tell, every job counts)
+        c->clean_jobs = (c->heavy_keys && c->last_spill_used) ? 0u : c->clean_jobs + 1u;
+    }
+    c->fast_probe = false;
     return FQD_OK;
 }
 
@@ -1286,6 +1311,7 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     }
     bool ok = false;
     FQD_TRY(collapse_lds(c, weights ? d_w : nullptr, IdSource(), &ok, &f));
+    c->last_spill_used = f.spill_used;
     timer.stop();
     if (getenv("FQD_DEBUG"))
         fprintf(stderr, "[fqd] fused pack + collapse: n=%llu parts=%u cap=%u compact=%u done=%d pack_bad=%u fused_off=%d compact_off=%d routed=%d spill_list=%d heavy_keys=%d\n",

@@ -185,6 +185,11 @@ struct fqd_ctx {
 
     // stage timers: one event pair per stage, recorded while the work is queued and resolved when
     // fqd_stage_times asks (a stage end is NOT a host synchronisation point)
+    // the fast paths a context has given up (heavy_keys: spill list, no routing; route_off) are tried again after
+    // fast_retry_after jobs that did not need them (api.hip pack_collapse_fused); a retry that fails doubles the wait
+    uint32_t clean_jobs = 0, fast_retry_after = 8;
+    bool fast_probe = false;
+    uint32_t last_spill_used = 0;  // records the last fused job sent to its spill list
     bool heavy_keys = false;       // a fused attempt ended on a full slab: from now on with the spill list (api.hip pack_collapse_fused_once)
     bool uf_sampled = false;       // the union-find met a giant component on this context: every 16th edge first (graph.hip uf_union_kernel)
     bool join_pending = false;     // the components were queued on st_side: ev_join must be waited for before their counter is read

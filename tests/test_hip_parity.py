@@ -1297,3 +1297,38 @@ def test_host_keys_uploaded_in_pieces_under_the_pack(F, oracle, monkeypatch):
         assert ctx.kernel_times(reset=True)["pack_kernel"][1] == (1 if pieces == "1" else -(-n // per))
         assert (got.n_unique, got.n_clusters) == (want["n_unique"], want["n_clusters"]), pieces
         assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), pieces
+
+
+def test_a_context_tries_its_fast_path_again(F, oracle, monkeypatch):
+    """A file with a jackpot key makes the context run the fused collapse with its spill list and without routing.
+    After eight jobs that spilled nothing it tries the routed collapse again (and keeps it when the data allows);
+    a retry that fails doubles the wait."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_FUSED_MIN_READS", "100000")
+    n, L = 300_000, 32
+    plain = synth_keys(n, L, 12, 77, sub_rate=3e-3, n_rate=1e-4)
+    hot = plain.copy()
+    rows = np.random.default_rng(5).choice(n, size=n // 8, replace=False)
+    hot[rows] = hot[rows[0]]
+    raws = {"plain": np.ascontiguousarray(plain).reshape(-1), "hot": np.ascontiguousarray(hot).reshape(-1)}
+    want = {k: oracle.dedup(v, fixed_offsets(n, L), max_distance=1, method="directional") for k, v in raws.items()}
+    ctx = F.Context(0)
+
+    def job(kind):
+        got = F.cluster_keys(raws[kind], key_len=L, max_distance=1, method="directional", context=ctx)
+        assert np.array_equal(got.kept_read_ids, want[kind]["kept_read_ids"]), kind
+        return got.route
+    assert job("plain")["pass0_in_collapse"]
+    r = job("hot")
+    assert r["spill_list"] and not r["pass0_in_collapse"]
+    for i in range(8):                       # eight jobs that spill nothing: still the careful way ...
+        r = job("plain")
+        assert r["spill_list"] and not r["pass0_in_collapse"], i
+    r = job("plain")                         # ... then the fast one again
+    assert r["pass0_in_collapse"] and not r["spill_list"] and not r["restarted"], r
+    r = job("hot")                           # (and back, as before)
+    assert r["spill_list"] and not r["restarted"], r
+    monkeypatch.setenv("FQD_NO_FAST_PATH_RETRY", "1")
+    for i in range(10):
+        r = job("plain")
+        assert r["spill_list"], i
