@@ -68,6 +68,7 @@ def _worker(rank, world, port, case, plan, q):
                                         ("fixed32", "segment-routed+slabs+chunks3"),
                                         ("fixed32_3ranks", "segment-routed+slabs+chunks3"),
                                         ("fixed32_foreign", "segment-routed+slabs"),
+                                        ("fixed32_hot", "segment-routed+slabs"), ("fixed32_hot", "segment-routed"),
                                         ("fixed32_foreign", "segment-routed"),
                                         ("fixed100_weights", "segment-routed"), ("fixed100_weights", "gathered"),
                                         ("fixed300_d2", "segment-routed"),
@@ -92,10 +93,17 @@ def test_ranks_on_one_gpu(oracle, shape, plan):
         cuts = [0, 80_000, 81_000, n]
         case = [(allk[cuts[r]:cuts[r + 1]].reshape(-1), None, L, None, d, edit, method) for r in range(3)]
         raw, off, w = allk.reshape(-1), fixed_offsets(n, L), None
-    elif shape in ("fixed32", "fixed32_foreign"):
+    elif shape in ("fixed32", "fixed32_foreign", "fixed32_hot"):
         n, L, d, edit, method = 120_000, 32, 1, False, "directional"
         allk = synth_keys(n, L, L, 5, sub_rate=3e-3, n_rate=3e-4)
         cut = 70_000
+        if shape == "fixed32_hot":
+            # a key with a sixth of all reads (and its one-error cloud), spread over both ranks: the owner's slabs of
+            # the fused way in overflow -- every rank repeats the way in the general way
+            rows = np.random.default_rng(11).choice(n, size=n // 6, replace=False)
+            allk[rows] = allk[rows[0]]
+            near = rows[: len(rows) // 30]
+            allk[near, np.random.default_rng(12).integers(0, L, size=len(near))] = ord("G")
         if shape == "fixed32_foreign":
             # a symbol outside "ACGNT" on rank 1 only: the optimistic pack fails there, every
             # rank must fall back to the scanned, merged symbol table
