@@ -344,7 +344,8 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
             KTIME(c, FQD_K_DEDUPE12, fqd::launch_bucket_dedupe12(reinterpret_cast<const fqd::Rec12 *>(parted),
                                                                c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
                                                                c->ld_tmp_rec.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
-                                                               c->d_ctr32.as<uint32_t>() + C_BAD, c->st, group_total));
+                                                               c->d_ctr32.as<uint32_t>() + C_BAD, c->st, group_total,
+                                                               (n >> B) > 1000 /* (an owner's buckets at 5-8 ranks) */));
         else
         {
             // (exact bucket sizes: a key with very many copies is one huge bucket -- cut into chunks, see fqd::HugeBuckets)

@@ -857,7 +857,10 @@ constexpr unsigned long long DD_EMPTY64 = ~0ull;
 // list has been collapsed into it BEFORE this kernel -- when the bucket's slab overflowed at level 2 or a slab of its
 // level-1 bin did in the pack kernel. Such a bucket looks every one of its keys up there; a key that is found adds its
 // count and first index to the table's entry and leaves no row of its own.
-template <bool MERGE>
+// SLOTS: 1024, or 2048 for buckets of more than ~1000 reads (the owner's collapse of a 5-8 rank job: 2^15 buckets at
+// most for 50 M received reads, ~1500 reads each -- mostly-unique data overfilled the 1024-slot table there and sent
+// every rank back to the general way)
+template <bool MERGE, uint32_t SLOTS = DD_SLOTS>
 __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
     const fqd::Rec12 *__restrict__ part, const uint32_t *__restrict__ bucket_start,
     const uint32_t *__restrict__ bucket_end, const uint32_t *__restrict__ weights, uint4 *__restrict__ tmp,
@@ -866,8 +869,8 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
                                         * its offsets itself (bucket_compact12_kernel) and no scan runs in between */,
     SideMerge merge)
 {
-    __shared__ unsigned long long s_key[DD_SLOTS + 1];
-    __shared__ uint32_t s_cnt[DD_SLOTS + 1], s_min[DD_SLOTS + 1];
+    __shared__ unsigned long long s_key[SLOTS + 1];
+    __shared__ uint32_t s_cnt[SLOTS + 1], s_min[SLOTS + 1];
     __shared__ uint32_t s_wave_tot[DD_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // With group totals, consecutive workgroups take buckets of DIFFERENT groups (workgroup i: group i % G): the 256
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
             ahead[k] = part[min(base0 + k * DD_THREADS + tid, last)];
     };
     fetch(lo);                                // (the table is cleared while the first items are on their way)
-    for (uint32_t s = tid; s <= DD_SLOTS; s += DD_THREADS) {
+    for (uint32_t s = tid; s <= SLOTS; s += DD_THREADS) {
         s_key[s] = DD_EMPTY64;
         s_cnt[s] = 0u;
         s_min[s] = 0xFFFFFFFFu;
@@ -912,17 +915,17 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
 #pragma unroll
         for (uint32_t k = 0; k < DD_AHEAD; k++) {
             key[k] = ((unsigned long long)ahead[k].b << 32) | ahead[k].a;
-            slot[k] = (rec12_tag(ahead[k].a, ahead[k].b) * 0x9E3779B1u) >> 22;   // top 10 bits of a re-mix: DD_SLOTS == 1024
+            slot[k] = (rec12_tag(ahead[k].a, ahead[k].b) * 0x9E3779B1u) >> (SLOTS == 2048 ? 21 : 22);   // top 10 / 11 bits of a re-mix
             if (base0 + k * DD_THREADS + tid < hi) {
                 if (key[k] == DD_EMPTY64) {
-                    atomicAdd(&s_cnt[DD_SLOTS], ahead_w[k]);
-                    atomicMin(&s_min[DD_SLOTS], ahead[k].id);
+                    atomicAdd(&s_cnt[SLOTS], ahead_w[k]);
+                    atomicMin(&s_min[SLOTS], ahead[k].id);
                 } else {
                     pend |= 1u << k;
                 }
             }
         }
-        for (uint32_t probes = 0; pend && probes < DD_SLOTS; probes++) {
+        for (uint32_t probes = 0; pend && probes < SLOTS; probes++) {
             unsigned long long old[DD_AHEAD];
 #pragma unroll
             for (uint32_t k = 0; k < DD_AHEAD; k++)       // the compare-and-swaps of all pending items in flight together
@@ -936,7 +939,7 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
                         atomicMin(&s_min[slot[k]], ahead[k].id);
                         pend &= ~(1u << k);
                     } else {
-                        slot[k] = (slot[k] + 1) & (DD_SLOTS - 1);
+                        slot[k] = (slot[k] + 1) & (SLOTS - 1);
                     }
                 }
         }
@@ -945,7 +948,7 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
     if (full)
         atomicOr(overflow, 1u);
     __syncthreads();
-    constexpr uint32_t PER = (DD_SLOTS + DD_THREADS) / DD_THREADS;     // slots per thread, table + 1
+    constexpr uint32_t PER = (SLOTS + DD_THREADS) / DD_THREADS;     // slots per thread, table + 1
     if constexpr (MERGE) {
         const bool spilled = (bucket_end && bucket_end[b] > bucket_start[b + 1]) || merge.l1_over[b >> merge.l1_shift];
         if (spilled) {                              // (the same for every thread of the workgroup)
@@ -953,7 +956,7 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
             for (uint32_t k = 0; k < PER; k++) {
                 const uint32_t sl = tid + k * DD_THREADS;
                 // (a taken slot, whatever its count: the first index of a weight-0 holder counts as well)
-                if (sl <= DD_SLOTS && (sl == DD_SLOTS ? s_min[sl] != 0xFFFFFFFFu : s_key[sl] != DD_EMPTY64)) {
+                if (sl <= SLOTS && (sl == SLOTS ? s_min[sl] != 0xFFFFFFFFu : s_key[sl] != DD_EMPTY64)) {
                     const unsigned long long kk = s_key[sl];      // (a, b) -> the three planes (rec12_planes, squeeze 1)
                     const uint32_t ka = (uint32_t)kk, kb = (uint32_t)(kk >> 32);
                     const uint32_t at = side_find(merge.side, merge.table, merge.table_slots, ka & ~kb, kb & ~ka, ka & kb);
@@ -974,7 +977,7 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t s = tid + k * DD_THREADS;
-        mine += (s <= DD_SLOTS && s_cnt[s] > 0) ? 1u : 0u;
+        mine += (s <= SLOTS && s_cnt[s] > 0) ? 1u : 0u;
     }
     uint32_t incl = mine;
     for (int o = 1; o < 64; o <<= 1) {
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(DD_THREADS) void bucket_dedupe12_kernel(
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t s = tid + k * DD_THREADS;
-        if (s <= DD_SLOTS && s_cnt[s] > 0) {
+        if (s <= SLOTS && s_cnt[s] > 0) {
             const unsigned long long kk = s_key[s];     // (the extra slot's key was never written: it IS the EMPTY pattern)
             tmp[out++] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), s_cnt[s], s_min[s]);
         }
@@ -1635,11 +1638,18 @@ hipError_t launch_part_scatter12(const uint32_t *in, uint32_t squeeze, SideSlabs
 
 hipError_t launch_bucket_dedupe12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                   uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
-                                  uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st, uint32_t *group_total)
+                                  uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st, uint32_t *group_total,
+                                  bool big_table)
 {
-    bucket_dedupe12_kernel<false><<<n_buckets, DD_THREADS, 0, st>>>(part, bucket_start, bucket_end, weights,
-                                                                    reinterpret_cast<uint4 *>(tmp_rec), bucket_unique,
-                                                                    overflow, group_total, SideMerge{});
+    if (big_table)
+        bucket_dedupe12_kernel<false, 2048><<<n_buckets, DD_THREADS, 0, st>>>(part, bucket_start, bucket_end, weights,
+                                                                              reinterpret_cast<uint4 *>(tmp_rec),
+                                                                              bucket_unique, overflow, group_total,
+                                                                              SideMerge{});
+    else
+        bucket_dedupe12_kernel<false><<<n_buckets, DD_THREADS, 0, st>>>(part, bucket_start, bucket_end, weights,
+                                                                        reinterpret_cast<uint4 *>(tmp_rec), bucket_unique,
+                                                                        overflow, group_total, SideMerge{});
     return hipGetLastError();
 }
 

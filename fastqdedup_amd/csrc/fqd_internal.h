@@ -420,7 +420,7 @@ uint32_t pass0_max_rows();      // rows of a bucket the compaction's search pass
 hipError_t launch_bucket_dedupe12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                   uint32_t n_buckets, const uint32_t *weights, uint32_t *tmp_rec,
                                   uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st,
-                                  uint32_t *group_total = nullptr);
+                                  uint32_t *group_total = nullptr, bool big_table = false /* 2048 slots per bucket */);
 hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                    const uint32_t *tmp_rec, uint32_t squeeze, const uint32_t *side_unique,
                                    uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst, hipStream_t st,
