@@ -1049,6 +1049,8 @@ static int pack_collapse_fused(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uin
     const bool gave_up_before = c->heavy_keys || c->route_off;
     if (gave_up_before && c->clean_jobs >= c->fast_retry_after && !getenv("FQD_NO_FAST_PATH_RETRY")) {
         c->heavy_keys = c->route_off = false;
+        c->gp_slab_off = false;        // (the search's slabs and the one-launch union-find with it: each finds out
+        c->uf_sampled = false;         //  again within the job if the data still needs the careful way)
         c->clean_jobs = 0;
         c->fast_probe = true;
     }
