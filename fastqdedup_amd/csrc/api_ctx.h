@@ -191,6 +191,7 @@ struct fqd_ctx {
     bool fast_probe = false;
     uint32_t last_spill_used = 0;  // records the last fused job sent to its spill list
     bool heavy_keys = false;       // a fused attempt ended on a full slab: from now on with the spill list (api.hip pack_collapse_fused_once)
+    int last_search_d = 0;         // max_distance of the last neighbour search (the closed-form dissection: pass 1b from d = 2 on)
     bool uf_sampled = false;       // the union-find met a giant component on this context: every 16th edge first (graph.hip uf_union_kernel)
     bool join_pending = false;     // the components were queued on st_side: ev_join must be waited for before their counter is read
     hipStream_t st_side = nullptr; // the side path of the compact collapse runs here, beside the dedupe (ev_fork / ev_join order it)

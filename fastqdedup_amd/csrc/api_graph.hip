@@ -92,7 +92,8 @@ static int graph_preinit(fqd_ctx *c, int method)
                                          c->kept_u32.as<uint32_t>(), 512 * fqd::kept_bin_lists(),
                                          c->d_ctr64.as<unsigned long long>() + C64_SUM,
                                          c->d_ctr64.as<unsigned long long>() + C64_CANDS,
-                                         closed ? c->ucounts.as<uint32_t>() : nullptr));
+                                         closed ? c->ucounts.as<uint32_t>() : nullptr,
+                                         c->d_ctr64.as<unsigned long long>() + C64_CAND_NEED));
     c->pre_zero_tail = true;
     c->pre_init_closed = closed;
     c->pre_init = true;
@@ -296,26 +297,31 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
         // relies on a strict order of the keys, so a caller's list with repeated keys
         // (fqd_import_unique) takes the relaxation rounds below.
         HIP_TRY(c, c->blocked.reserve(U * 4 + 16));   // here: union-find over the count-1 keys
-        HIP_TRY(c, c->taint.reserve(E * 4 + 16));       // here: the edges between count-1 keys (edge indices)
+        HIP_TRY(c, c->taint.reserve(E * 8 + 16));       // here: the edges between count-1 keys (edge indices), and behind them those pass 2 looks at
         HIP_TRY(c, c->stage_a.reserve(E * 8 + 16));     // ... and the roots of their ends
         HIP_TRY(c, c->root_taint.reserve(U + 16));
         if (E) {
             if (E >= 0xFFFFFFFFull)
                 return fail(c, FQD_E_VALUE, "more than 2^32 edges");
             if (!c->pre_zero_tail)
-                FQD_TRY(zero_ctr64(c, C64_CANDS));         // (the search's candidate counter, free here)
+                FQD_TRY(zero_ctr64(c, C64_CANDS, 2));      // (the search's candidate counters, free here: the two lists' lengths)
             if (!pre_closed) {
                 HIP_TRY(c, hipMemsetAsync(c->root_taint.p, 0, U, c->st));
                 HIP_TRY(c, fqd::launch_uf_init(c->blocked.as<uint32_t>(), U, c->st));
                 // (the state byte of this dissection starts as the key's count nibble, graph.hip dstate_init)
                 HIP_TRY(c, fqd::launch_dstate_init(c->state.as<uint8_t>(), c->ucounts.as<uint32_t>(), U, c->st));
             }
+            // (pass 1b -- graph.hip directional_unions_kernel -- from distance 2 on, or when the edges came from elsewhere)
+            const bool split_unions = (c->last_search_d >= 2 || getenv("FQD_DIRECTIONAL_SPLIT_UNIONS")) &&
+                                      !getenv("FQD_DIRECTIONAL_NO_SPLIT_UNIONS");
             for (int pass = 1; pass <= 2; pass++)
                 KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_directional_closed(
                           c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(), c->urecs.as<uint32_t>(),
                           c->ulens.as<uint32_t>(), sh, c->blocked.as<uint32_t>(), c->state.as<uint8_t>(),
                           c->taint.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_CANDS,
-                          c->root_taint.as<uint8_t>(), c->best.as<uint32_t>(), pass, c->st, c->stage_a.as<uint32_t>()));
+                          c->root_taint.as<uint8_t>(), c->best.as<uint32_t>(), pass, c->st, c->stage_a.as<uint32_t>(),
+                          split_unions ? c->taint.as<uint32_t>() + E : nullptr,
+                          c->d_ctr64.as<unsigned long long>() + C64_CAND_NEED));
             list_method = 3;
         }
     } else if (method == FQD_METHOD_DIRECTIONAL) {

@@ -514,6 +514,7 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         return fail(c, FQD_E_STATE, "fqd_find_edges before fqd_collapse/fqd_import_unique");
     if (max_distance < 0)
         return fail(c, FQD_E_VALUE, "max_distance should be non-negative");
+    c->last_search_d = max_distance;
     if (n_shards == 0 || shard >= n_shards)
         return fail(c, FQD_E_VALUE, "bad shard");
     const KeyShape sh = c->ks;

@@ -632,7 +632,8 @@ hipError_t launch_graph_preinit(uint32_t *parent, uint32_t *best, uint8_t *state
                                 uint32_t *zero32 = nullptr, uint32_t zero32_words = 0,
                                 unsigned long long *zero64_a = nullptr, unsigned long long *zero64_b = nullptr,
                                 const uint32_t *ucounts = nullptr /* with parent1: state[i] starts as the count nibble of
-                                                                   * the closed-form directional dissection */);
+                                                                   * the closed-form directional dissection */,
+                                unsigned long long *zero64_c = nullptr);
 hipError_t launch_dstate_init(uint8_t *state, const uint32_t *ucounts, uint64_t U, hipStream_t st);
 hipError_t launch_highest_count(const uint32_t *labels, const uint32_t *ucounts, const uint32_t *urecs,
                                 const uint32_t *ulens, KeyShape sh, uint64_t U, uint32_t *best,
@@ -657,7 +658,8 @@ hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t 
 hipError_t launch_directional_closed(const uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
                                      const uint32_t *ulens, KeyShape sh, uint32_t *parent1, uint8_t *state,
                                      uint32_t *list11, unsigned long long *list11_count, uint8_t *root_taint,
-                                     uint32_t *best, int pass, hipStream_t st, uint32_t *roots /* 2 E words */);
+                                     uint32_t *best, int pass, hipStream_t st, uint32_t *roots, uint32_t *list2,
+                                     unsigned long long *list2_count);
 hipError_t launch_gather_kept(const uint32_t *kept_u32, const uint32_t *kept_scan, const uint64_t *ufirst,
                               uint64_t U, uint64_t *out, hipStream_t st);
 

@@ -434,6 +434,7 @@ __global__ void graph_preinit_kernel(uint32_t *__restrict__ parent, uint32_t *__
                                      unsigned long long *__restrict__ hook_slots, uint32_t hook_words,
                                      uint32_t *__restrict__ zero32 /* may be NULL */, uint32_t zero32_words,
                                      unsigned long long *__restrict__ zero64_a, unsigned long long *__restrict__ zero64_b,
+                                     unsigned long long *__restrict__ zero64_c,
                                      const uint32_t *__restrict__ ucounts /* with parent1: state[i] = count nibble (dstate_init) */)
 {
     // four keys per thread: 16-byte stores for the word arrays, 4-byte stores for the byte arrays
@@ -450,6 +451,8 @@ __global__ void graph_preinit_kernel(uint32_t *__restrict__ parent, uint32_t *__
             *zero64_a = 0ull;
         if (threadIdx.x == 0 && zero64_b)
             *zero64_b = 0ull;
+        if (threadIdx.x == 0 && zero64_c)
+            *zero64_c = 0ull;
     }
     if (i0 + 4 <= U) {
         const uint4 v = make_uint4((uint32_t)i0, (uint32_t)i0 + 1, (uint32_t)i0 + 2, (uint32_t)i0 + 3);
@@ -548,6 +551,7 @@ __global__ void directional_round_kernel(const uint32_t *__restrict__ edges, uin
 // those edges (few) are listed for pass 2. Four edges per thread, one list reservation per workgroup.
 constexpr uint32_t DE_EPT = 4;
 
+template <bool UNION_HERE>      // false: the listed edges are united by directional_unions_kernel (pass 1b)
 __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *__restrict__ edges, uint64_t E,
                                                                 const uint32_t *__restrict__ ucounts,
                                                                 uint32_t *parent1, uint8_t *state,
@@ -592,21 +596,23 @@ __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *
             continue;
         const uint32_t u = uu[t], v = vv[t];
         if (cu[t] == 1 && cv[t] == 1) {
-            uint32_t a = u, b = v;
-            for (bool fresh = false;; fresh = true) {
-                a = fresh ? uf_find<true>(parent1, a) : uf_find<false>(parent1, a);
-                b = fresh ? uf_find<true>(parent1, b) : uf_find<false>(parent1, b);
-                if (a == b)
-                    break;
-                if (a > b) {
-                    const uint32_t x = a;
-                    a = b;
-                    b = x;
+            if (UNION_HERE) {
+                uint32_t a = u, b = v;
+                for (bool fresh = false;; fresh = true) {
+                    a = fresh ? uf_find<true>(parent1, a) : uf_find<false>(parent1, a);
+                    b = fresh ? uf_find<true>(parent1, b) : uf_find<false>(parent1, b);
+                    if (a == b)
+                        break;
+                    if (a > b) {
+                        const uint32_t x = a;
+                        a = b;
+                        b = x;
+                    }
+                    if (atomicCAS(&parent1[b], b, a) == b)
+                        break;
                 }
-                if (atomicCAS(&parent1[b], b, a) == b)
-                    break;
             }
-            rank[t] = atomicAdd(&s_n, 1u);
+            rank[t] = atomicAdd(&s_n, 1u);      // (an edge between count-1 keys: listed)
             continue;
         }
         // (an OR only where the byte -- as fetched above -- does not say so yet: the 786 K edges of a 65 536-key
@@ -631,6 +637,80 @@ __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *
         if (rank[t] != 0xFFFFFFFFu)
             list11[s_base + rank[t]] =
                 (uint32_t)(((uint64_t)blockIdx.x * DE_EPT + t) * blockDim.x + threadIdx.x);
+}
+
+// Pass 1b, over the listed edges (both ends count 1), AFTER pass 1 has marked every count-1 key that touches a bigger
+// one (state 3, "tainted": dropped whatever its set looks like): the ends are united, and the edge stays on the list of
+// pass 2 only if one of its ends is NOT tainted. An edge between two tainted keys has nothing more to say -- both are
+// dropped -- and the taint of a set reaches its root through the listed edges: a set with a tainted and an untainted
+// member has an edge between such a pair on the path that joins them. With d = 2 most listed edges join two error
+// variants of one molecule, both next to the molecule's key (config 4: 3.4 M edges listed, a tenth of them left for
+// pass 2, whose two launches moved 4.5 GB before).
+__global__ __launch_bounds__(256) void directional_unions_kernel(const uint32_t *__restrict__ edges,
+                                                                 const uint32_t *__restrict__ list11,
+                                                                 const unsigned long long *__restrict__ list11_count,
+                                                                 uint32_t *parent1, const uint8_t *__restrict__ state,
+                                                                 uint32_t *__restrict__ list_out,
+                                                                 unsigned long long *__restrict__ list_out_count)
+{
+    __shared__ uint32_t s_n, s_base;
+    const uint64_t n = *list11_count;
+    constexpr uint32_t UE = 4;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x * UE; base < n; base += (uint64_t)gridDim.x * blockDim.x * UE) {
+        if (threadIdx.x == 0)
+            s_n = 0;
+        __syncthreads();
+        uint32_t e[UE];
+        uint2 uv[UE];
+        uint8_t su[UE], sv[UE];
+        bool live[UE];
+#pragma unroll
+        for (uint32_t t = 0; t < UE; t++) {           // (clamped, unconditional: in flight together)
+            const uint64_t i = base + (uint64_t)t * blockDim.x + threadIdx.x;
+            live[t] = i < n;
+            e[t] = list11[min(i, n - 1)];
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < UE; t++)
+            uv[t] = reinterpret_cast<const uint2 *>(edges)[e[t]];
+#pragma unroll
+        for (uint32_t t = 0; t < UE; t++) {
+            su[t] = state[uv[t].x];
+            sv[t] = state[uv[t].y];
+        }
+        uint32_t rank[UE];
+#pragma unroll
+        for (uint32_t t = 0; t < UE; t++) {
+            rank[t] = 0xFFFFFFFFu;
+            if (!live[t])
+                continue;
+            uint32_t a = uv[t].x, b = uv[t].y;
+            for (bool fresh = false;; fresh = true) {
+                a = fresh ? uf_find<true>(parent1, a) : uf_find<false>(parent1, a);
+                b = fresh ? uf_find<true>(parent1, b) : uf_find<false>(parent1, b);
+                if (a == b)
+                    break;
+                if (a > b) {
+                    const uint32_t x = a;
+                    a = b;
+                    b = x;
+                }
+                if (atomicCAS(&parent1[b], b, a) == b)
+                    break;
+            }
+            if ((su[t] & 15u) != 3u || (sv[t] & 15u) != 3u)
+                rank[t] = atomicAdd(&s_n, 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_n)
+            s_base = (uint32_t)atomicAdd(list_out_count, (unsigned long long)s_n);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t t = 0; t < UE; t++)
+            if (rank[t] != 0xFFFFFFFFu)
+                list_out[s_base + rank[t]] = e[t];
+        __syncthreads();
+    }
 }
 
 // Pass 2 (after every union of pass 1), over the edges between count-1 keys only, in two launches.
@@ -1437,12 +1517,12 @@ hipError_t launch_uf_flatten(uint32_t *parent, uint64_t U, unsigned long long *n
 hipError_t launch_graph_preinit(uint32_t *parent, uint32_t *best, uint8_t *state, uint32_t *parent1, uint8_t *root_taint,
                                 uint64_t U, unsigned long long *hook_slots, uint32_t hook_words, hipStream_t st,
                                 uint32_t *zero32, uint32_t zero32_words, unsigned long long *zero64_a,
-                                unsigned long long *zero64_b, const uint32_t *ucounts)
+                                unsigned long long *zero64_b, const uint32_t *ucounts, unsigned long long *zero64_c)
 {
     const uint64_t quads = (U + 3) / 4;
     graph_preinit_kernel<<<(unsigned)std::max<uint64_t>(1, (quads + 255) / 256), 256, 0, st>>>(
         parent, best, state, parent1, root_taint, U, hook_slots, hook_words, zero32, zero32_words, zero64_a, zero64_b,
-        ucounts);
+        zero64_c, ucounts);
     return hipGetLastError();
 }
 
@@ -1481,19 +1561,30 @@ hipError_t launch_directional_round(const uint32_t *edges, uint64_t E, const uin
 hipError_t launch_directional_closed(const uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
                                      const uint32_t *ulens, KeyShape sh, uint32_t *parent1, uint8_t *state,
                                      uint32_t *list11, unsigned long long *list11_count, uint8_t *root_taint,
-                                     uint32_t *best, int pass, hipStream_t st, uint32_t *roots)
+                                     uint32_t *best, int pass, hipStream_t st, uint32_t *roots, uint32_t *list2,
+                                     unsigned long long *list2_count)
 {
     if (!E)
         return hipSuccess;
     const unsigned list_grid = (unsigned)std::min<uint64_t>(grid_for(E), 8192);   // (the list's length is on the device)
+    // list2 != NULL: pass 1 only lists the edges between count-1 keys, pass 1b unites them and keeps those pass 2 must
+    // look at (worth its launch where such edges are many: d >= 2, error variants of one molecule next to each other);
+    // else pass 1 unites them itself and pass 2 walks the whole list
     if (pass == 1) {
-        directional_edges_kernel<<<(unsigned)((E + 256 * DE_EPT - 1) / (256 * DE_EPT)), 256, 0, st>>>(
-            edges, E, ucounts, parent1, state, list11, list11_count);
+        const unsigned grid = (unsigned)((E + 256 * DE_EPT - 1) / (256 * DE_EPT));
+        if (list2)
+            directional_edges_kernel<false><<<grid, 256, 0, st>>>(edges, E, ucounts, parent1, state, list11, list11_count);
+        else
+            directional_edges_kernel<true><<<grid, 256, 0, st>>>(edges, E, ucounts, parent1, state, list11, list11_count);
     } else {
-        directional_roots_kernel<<<list_grid, 256, 0, st>>>(edges, list11, list11_count, parent1, state, root_taint,
-                                                            roots);
-        directional_best_kernel<<<list_grid, 256, 0, st>>>(edges, list11, list11_count, ucounts, urecs, ulens, sh, roots,
-                                                           root_taint, best);
+        if (list2)
+            directional_unions_kernel<<<(unsigned)std::min<uint64_t>(grid_for((E + 3) / 4), 8192), 256, 0, st>>>(
+                edges, list11, list11_count, parent1, state, list2, list2_count);
+        const uint32_t *list = list2 ? list2 : list11;
+        const unsigned long long *count = list2 ? list2_count : list11_count;
+        directional_roots_kernel<<<list_grid, 256, 0, st>>>(edges, list, count, parent1, state, root_taint, roots);
+        directional_best_kernel<<<list_grid, 256, 0, st>>>(edges, list, count, ucounts, urecs, ulens, sh, roots, root_taint,
+                                                           best);
     }
     return hipGetLastError();
 }

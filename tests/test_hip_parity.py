@@ -1332,3 +1332,24 @@ def test_a_context_tries_its_fast_path_again(F, oracle, monkeypatch):
     for i in range(10):
         r = job("plain")
         assert r["spill_list"], i
+
+
+@pytest.mark.parametrize("d,switch", [(1, "FQD_DIRECTIONAL_SPLIT_UNIONS"), (2, "FQD_DIRECTIONAL_NO_SPLIT_UNIONS"), (2, None),
+                                      (1, None)])
+def test_directional_unions_in_pass_1_or_1b(F, oracle, monkeypatch, d, switch):
+    """The closed-form directional dissection unites the edges between count-1 keys either in its first pass over the
+    edges or (distance >= 2 by default) in a pass of its own that also drops the edges between two tainted keys from
+    the list of pass 2: same verdicts either way, against the oracle -- many count-1 variants next to each other
+    (sub_rate 1 %), keys with several copies, weights that make count-1 keys out of popular ones."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    if switch:
+        monkeypatch.setenv(switch, "1")
+    n, L = 120_000, 32
+    keys = synth_keys(n, L, 10, 99 + d, copies=6, sub_rate=1e-2, n_rate=1e-4)
+    weights = (np.random.default_rng(d).random(n) < 0.6).astype(np.uint32)
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    for w in (None, weights):
+        want = oracle.dedup(raw, fixed_offsets(n, L), w, max_distance=d, method="directional")
+        got = F.cluster_keys(raw, key_len=L, weights=w, max_distance=d, method="directional", context=F.Context(0))
+        assert (got.n_unique, got.n_clusters, got.n_kept) == (want["n_unique"], want["n_clusters"], len(want["kept_read_ids"]))
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
