@@ -1592,7 +1592,13 @@ int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *
     uint32_t *d_rank_of = reinterpret_cast<uint32_t *>(c->seg_tab.as<uint64_t>() + n_senders);
     HIP_TRY(c, hipMemcpyAsync(c->seg_tab.p, sorted_id0.data(), (size_t)n_senders * 8, hipMemcpyHostToDevice, c->st));
     HIP_TRY(c, hipMemcpyAsync(d_rank_of, rank_of.data(), (size_t)n_senders * 4, hipMemcpyHostToDevice, c->st));
+    if (dense)       // (the fills the senders told us must add up to the rows the caller received: level 2 walks them)
+        FQD_TRY(queue_read_u32(c, seg_start + parts, 13));
     HIP_TRY(c, stream_wait(c->st));          // (host vectors)
+    if (dense && taken_u32(c, 13) != n_reads) {
+        c->ld_part.unborrow();
+        return fail(c, FQD_E_VALUE, "fqd_collapse_owner_slabs: the slabs' fills do not add up to n_reads");
+    }
     IdSource ids;
     ids.seg_id0 = c->seg_tab.as<uint64_t>();
     ids.n_seg = n_senders;
