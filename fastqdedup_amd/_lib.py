@@ -131,7 +131,7 @@ def load() -> C.CDLL:
     L.fqd_cluster_subgraph_home.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p, vp, vp, vp,
                                             u64p, u64p, u64p, u64p, C.c_int]
     L.fqd_dissect_except.argtypes = [vp, C.c_int, vp, C.c_uint64, C.c_int, u64p]
-    L.fqd_dense_owner_slabs.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    L.fqd_dense_owner_slabs.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp]
     L.fqd_owner_routing_possible.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]
     L.fqd_set_owner_routing.argtypes = [vp, C.c_int]
     L.fqd_list_kept_except.argtypes = [vp, vp, C.c_uint64, C.c_int, u64p]
@@ -308,7 +308,8 @@ class Context:
         rp, _m, _2 = _ptr_mem(rows_out)
         fp, _m, _3 = _ptr_mem(fills_out)
         hb, subs, cap = geometry
-        self._ck(self._L.fqd_dense_owner_slabs(self._h, sp, cp, int(n_parts), hb, subs, cap, rp, fp))
+        room = int(rows_out.shape[0]) if hasattr(rows_out, "shape") and len(rows_out.shape) == 2 else int(rows_out.numel()) // 4
+        self._ck(self._L.fqd_dense_owner_slabs(self._h, sp, cp, int(n_parts), hb, subs, cap, rp, room, fp))
 
     def collapse_owner_slabs(self, slabs, cursors, n_senders: int, my_part: int, geometry, sender_id0, id_limit: int,
                              n_reads: int, search_segments: int = 0):

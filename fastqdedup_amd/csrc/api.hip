@@ -433,6 +433,10 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 // a full slab -- a key with hundreds of copies in a bucket, or with a share of all reads in a level-1
                 // part: once more, and from then on, with the spill list
                 c->heavy_keys = true;
+            } else if ((overflow & 6u) && !(overflow & 16u) && fused->route_mask && !c->route_off) {
+                // a ROUTED attempt without a spill list to turn to (two-plane alphabets): the slab may be full of keys
+                // that share a segment-0 value, not of copies of one key -- whole-key hashing gets one attempt
+                // (route_off below) before the fused path is given up for the context
             } else {
                 if (overflow & 4u)
                     c->fused_off = true;
@@ -1056,11 +1060,12 @@ static int pack_collapse_fused(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uin
     }
     const bool heavy_at_start = c->heavy_keys, route_off_at_start = c->route_off;
     c->last_spill_used = 0;
-    for (int attempt = 0; attempt < 3; attempt++) {
-        const bool was_off = c->compact_off, was_heavy = c->heavy_keys;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        const bool was_off = c->compact_off, was_heavy = c->heavy_keys, was_routed = !c->route_off;
         c->route &= ~FQD_ROUTE_RESTARTED;          // (raised by an attempt that ended early; the last one counts)
         FQD_TRY(pack_collapse_fused_once(c, bytes, n, fixed_len, mem, weights, aux_mem, done));
-        if (*done || c->fused_off || (was_off == c->compact_off && was_heavy == c->heavy_keys))
+        if (*done || c->fused_off ||
+            (was_off == c->compact_off && was_heavy == c->heavy_keys && was_routed == !c->route_off))
             break;
     }
     if ((c->heavy_keys && !heavy_at_start) || (c->route_off && !route_off_at_start)) {
@@ -1481,8 +1486,11 @@ int fqd_pack_to_owner_slabs(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uint32
 // all-to-all-v by rows instead of equal slab ranges: 1.16 x fewer bytes at 50 M reads, 1.35 x at four chunks).
 // rows_out (device): room for the n reads packed; fills_out (device, n_parts * hash_bins * subs words): every slab's
 // fill -- the owner needs the fills of its slabs (they are equal splits of this array) to find the slabs in the rows.
+// rows_capacity: rows_out's room in rows. The fills come from the cursors, not from the caller's count: rows behind the
+// capacity are not written (cursors of a pack that gave up -- the rows are not used then -- must not reach past the
+// caller's buffer).
 int fqd_dense_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *cursors, uint32_t n_parts, uint32_t hash_bins,
-                          uint32_t subs, uint32_t cap, uint32_t *rows_out, uint32_t *fills_out)
+                          uint32_t subs, uint32_t cap, uint32_t *rows_out, uint64_t rows_capacity, uint32_t *fills_out)
 {
     FQD_TRY(bind(c));
     const uint64_t parts64 = (uint64_t)n_parts * hash_bins * subs;
@@ -1493,7 +1501,7 @@ int fqd_dense_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *cur
     HIP_TRY(c, c->ld_seg.reserve((size_t)3 * (parts + 4) * 4));
     uint32_t *start = c->ld_seg.as<uint32_t>();
     HIP_TRY(c, fqd::launch_fill_scan(cursors, parts, cap, fills_out, start, nullptr, c->st));
-    HIP_TRY(c, fqd::launch_slab_dense_rows(slabs, start, parts, cap, rows_out, c->st));
+    HIP_TRY(c, fqd::launch_slab_dense_rows(slabs, start, parts, cap, rows_out, c->st, rows_capacity));
     return FQD_OK;
 }
 

@@ -223,9 +223,12 @@ __global__ __launch_bounds__(1024) void fill_scan_kernel(const uint32_t *__restr
         start[n] = run;
 }
 
-// rows [p * cap, p * cap + fill[p]) of every slab -> dense[start[p] ..): one workgroup per 1024 rows of a slab
+// rows [p * cap, p * cap + fill[p]) of every slab -> dense[start[p] ..): one workgroup per 1024 rows of a slab.
+// dense has room for dense_rows rows: a row behind that is not written (the caller's count and the cursors
+// disagree -- cursors of a pack that gave up, say; the rows are not used then) and *over is raised.
 __global__ __launch_bounds__(256) void slab_dense_rows_kernel(const uint4 *__restrict__ slabs, const uint32_t *__restrict__ start,
-                                                              uint32_t cap, uint32_t chunks_per_slab, uint4 *__restrict__ dense)
+                                                              uint32_t cap, uint32_t chunks_per_slab, uint4 *__restrict__ dense,
+                                                              uint64_t dense_rows, uint32_t *__restrict__ over)
 {
     const uint32_t p = blockIdx.x / chunks_per_slab, chunk = blockIdx.x - p * chunks_per_slab;
     const uint32_t lo = start[p], fill = start[p + 1] - lo;
@@ -238,8 +241,12 @@ __global__ __launch_bounds__(256) void slab_dense_rows_kernel(const uint4 *__res
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
         const uint32_t r = chunk * 1024u + k * 256u + threadIdx.x;
-        if (r < fill)
-            dense[(size_t)lo + r] = v[k];
+        if (r < fill) {
+            if ((uint64_t)lo + r < dense_rows)
+                dense[(size_t)lo + r] = v[k];
+            else if (over)
+                *over = 1u;          // (the same value from every thread that gets here)
+        }
     }
 }
 
@@ -1509,14 +1516,14 @@ hipError_t launch_fill_scan(const uint32_t *in, uint32_t n, uint32_t cap, uint32
 }
 
 hipError_t launch_slab_dense_rows(const uint32_t *slabs, const uint32_t *start, uint32_t n_slabs, uint32_t cap,
-                                  uint32_t *dense, hipStream_t st)
+                                  uint32_t *dense, hipStream_t st, uint64_t dense_rows, uint32_t *over)
 {
     const uint32_t chunks = (cap + 1023u) / 1024u;
     if ((uint64_t)n_slabs * chunks > 0x7FFFFFFFull)
         return hipErrorInvalidValue;
     if (n_slabs)
         slab_dense_rows_kernel<<<n_slabs * chunks, 256, 0, st>>>(reinterpret_cast<const uint4 *>(slabs), start, cap, chunks,
-                                                                reinterpret_cast<uint4 *>(dense));
+                                                                reinterpret_cast<uint4 *>(dense), dense_rows, over);
     return hipGetLastError();
 }
 

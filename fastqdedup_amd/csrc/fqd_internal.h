@@ -619,7 +619,8 @@ hipError_t launch_mark_dropped_after(uint8_t *state, uint32_t *best, uint64_t U,
 hipError_t launch_fill_scan(const uint32_t *in, uint32_t n, uint32_t cap, uint32_t *fills, uint32_t *start, uint32_t *end,
                             hipStream_t st);
 hipError_t launch_slab_dense_rows(const uint32_t *slabs, const uint32_t *start, uint32_t n_slabs, uint32_t cap,
-                                  uint32_t *dense, hipStream_t st);
+                                  uint32_t *dense, hipStream_t st, uint64_t dense_rows = ~0ull /* room in dense: rows behind it are
+                                  * dropped */, uint32_t *over = nullptr /* set to 1 when a row was dropped */);
 hipError_t launch_subgraph_finish(const uint32_t *flags, const uint32_t *flags_incl, uint64_t n_nodes, uint64_t E,
                                   uint32_t *touched, uint32_t *sub, const unsigned long long *n_sub, hipStream_t st);
 hipError_t launch_check_indices(const uint32_t *idx, uint64_t n, uint64_t limit, uint32_t *bad, hipStream_t st);

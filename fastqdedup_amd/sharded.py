@@ -572,8 +572,10 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
                 # Slabs WITHOUT their slack on the wire (more than one rank): every chunk's filled prefixes back to back
                 # (fqd_dense_owner_slabs), moved by an all-to-all-v, the fills by an equal-split one; the owner finds the
                 # slabs in the rows by the fills. With one rank nothing travels and the slabs are read where they lie.
-                dense = (not comm.alone and hasattr(backend, "dense_owner_slabs")
-                         and not os.environ.get("FQD_NO_DENSE_SLABS"))
+                # (every rank must take the same exchange -- all-to-all-v + counts against equal splits: one vote,
+                # like want_slabs; ranks that disagreed would issue different collectives and hang)
+                dense = not comm.alone and not comm.any_flag(not (hasattr(backend, "dense_owner_slabs")
+                                                                  and not os.environ.get("FQD_NO_DENSE_SLABS")))
                 send = torch.empty((1 if dense else chunks, parts * cap, 4), dtype=torch.int32, device=dev)
                 scur = torch.empty((chunks, parts), dtype=torch.int32, device=dev)
                 recv, rcur = (send, scur) if comm.alone else (None if dense else torch.empty_like(send),
@@ -595,9 +597,13 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
                         totals = [a + b for a, b in zip(totals, counts)]
                     if dense:
                         out_counts = counts if counts is not None else [0] * world
-                        rows_k, fills_k = backend.dense_owner_slabs(slab_k, scur[k], world, geometry, sum(out_counts))
                         if counts is None:
-                            fills_k = torch.zeros_like(fills_k)
+                            # the pack gave up (a full slab, a foreign byte): its cursors say nothing about what lies in
+                            # the slabs -- no dense copy; zero rows and zero fills travel so that the collectives match
+                            rows_k = torch.empty((0, 4), dtype=torch.int32, device=dev)
+                            fills_k = torch.zeros(parts, dtype=torch.int32, device=dev)
+                        else:
+                            rows_k, fills_k = backend.dense_owner_slabs(slab_k, scur[k], world, geometry, sum(out_counts))
                         in_counts = comm.exchange_counts(out_counts)
                         got_rows.append(comm.all_to_all_rows(rows_k, out_counts, in_counts))
                         got_counts.append(in_counts)
@@ -620,9 +626,19 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
                     if tick:
                         tick.mark("all-to-all-slabs")
                     sender_id0 = [id_bounds[s_] + all_bounds[s_][k] for k in range(chunks) for s_ in range(world)]
-                    n_unique_local = backend.collapse_owner_slabs(recv_rows.contiguous(), rcur.reshape(-1), world * chunks,
-                                                                  rank, recv_geometry, sender_id0, max(n_total, 1),
-                                                                  int(sum(recv_counts)), n_seg)
+                    # a failure on ONE rank (fills that do not add up, a rank that received nothing) must not raise
+                    # here: the others would wait in the vote below for ever. It counts as "this rank cannot".
+                    n_recv = int(sum(recv_counts))
+                    try:
+                        if dense and n_recv == 0:
+                            recv_rows = torch.zeros((1, 4), dtype=torch.int32, device=dev)     # (never a null buffer)
+                        n_unique_local = backend.collapse_owner_slabs(recv_rows.contiguous(), rcur.reshape(-1),
+                                                                      world * chunks, rank, recv_geometry, sender_id0,
+                                                                      max(n_total, 1), n_recv, n_seg)
+                    except (ValueError, RuntimeError) as e:
+                        n_unique_local = None
+                        if os.environ.get("FQD_DEBUG") or os.environ.get("FQD_SHARD_TIMING"):
+                            print(f"[fqd] rank {rank}: the owner-slab collapse failed ({e}); general way", file=sys.stderr)
                     del recv_rows
                     if comm.any_flag(n_unique_local is None):
                         n_unique_local = None      # a bucket overflowed somewhere: once more, the general way

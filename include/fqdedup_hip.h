@@ -259,9 +259,10 @@ int fqd_pack_to_owner_slabs(fqd_ctx *ctx, const uint8_t *bytes, uint64_t n, uint
  * room for the reads packed) and every slab's fill (fills_out, device, n_parts * hash_bins * subs words). The caller
  * moves rows by an all-to-all-v (reads per owner: fqd_pack_to_owner_slabs' counts) and the fills by an equal-split
  * all-to-all; the owner then calls fqd_collapse_owner_slabs with cap = 0, `slabs` = the received rows (sender by
- * sender), `cursors` = the received fills. */
+ * sender), `cursors` = the received fills. rows_capacity: rows_out's room in rows -- the fills come from the cursors, and
+ * rows behind the capacity are dropped, never written (a caller whose pack gave up passes cursors it cannot trust). */
 int fqd_dense_owner_slabs(fqd_ctx *ctx, const uint32_t *slabs, const uint32_t *cursors, uint32_t n_parts, uint32_t hash_bins,
-                          uint32_t subs, uint32_t cap, uint32_t *rows_out, uint32_t *fills_out);
+                          uint32_t subs, uint32_t cap, uint32_t *rows_out, uint64_t rows_capacity, uint32_t *fills_out);
 int fqd_collapse_owner_slabs(fqd_ctx *ctx, const uint32_t *slabs, const uint32_t *cursors, uint32_t n_senders,
                              uint32_t my_part, uint32_t hash_bins, uint32_t subs, uint32_t cap,
                              const uint64_t *sender_id0, uint64_t id_limit, uint64_t n_reads, uint32_t search_segments,
