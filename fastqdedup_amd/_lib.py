@@ -86,7 +86,14 @@ def load() -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    # FQD_LIB_VARIANT=name: fastqdedup_amd/libfqdedup_hip.name.so instead (tools/ab_variants.sh: the same library built with
+    # other compile-time switches, timed side by side on ONE box); a variant that is missing is an error, never a fallback
+    path = LIB_PATH
+    if os.environ.get("FQD_LIB_VARIANT"):
+        path = LIB_PATH[:-3] + "." + os.environ["FQD_LIB_VARIANT"] + ".so"
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing (FQD_LIB_VARIANT)")
+    L = C.CDLL(path)
     vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
     L.fqd_device_count.restype = C.c_int
     L.fqd_global_error.restype = C.c_char_p
@@ -831,7 +838,7 @@ class Context:
     ROUTE_BITS = {"fused_pack": 0x1, "compact_records": 0x2, "pass0_in_collapse": 0x4, "restarted": 0x8,
                   "collapse_lds": 0x10, "collapse_pairs": 0x20, "collapse_sort": 0x40, "search_grouped": 0x100,
                   "search_sort": 0x200, "search_edit": 0x400, "search_retried": 0x800, "pass0_continued": 0x1000,
-                  "spill_list": 0x2000, "search_refined": 0x4000}
+                  "spill_list": 0x2000, "search_refined": 0x4000, "one_kernel_collapse": 0x8000}
 
     def route(self) -> dict:
         """Which way the last job took (fqd_get_route): {name: bool} over the FQD_ROUTE_* bits."""

@@ -331,7 +331,61 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         const uint32_t n_groups = std::max(n_buckets >> 8, 1u);
         uint32_t *group_total = compact && fused->starts_ready && slab_cap && c->h_pin_big && n_groups <= 4096
                                     ? c->ld_hist.as<uint32_t>() + fused->group_at : nullptr;
-        if (compact && spill) {
+        // ---- dedupe + compaction (+ search pass 0) in ONE persistent kernel (collapse_lds.hip bucket_collapse12_kernel):
+        // compact records behind a routed fused pack on one GPU, no spill list, buckets of the usual size, and at
+        // most one array of segment hashes to write (its stride would be the unique count, which nobody knows yet).
+        // The side path's keys lie at the head of the unique table and its probe lists feed pass 0: it must have
+        // finished before the kernel starts.
+        fqd::SegHashOut sho1;
+        bool one_kernel = false;
+        fqd::CollapseSync csync;
+        if (compact && fused && !spill && group_total && fused->p0.mask != 0 && !fused->stamp_div && !d_w &&
+            !c->one_kernel_off && (n >> B) <= 1000 && (n_buckets & 63u) == 0 && !getenv("FQD_NO_ONE_KERNEL_COLLAPSE")) {
+            const bool want_hashes = c->seg_hint != 0;
+            const uint32_t teams_fit = fqd::collapse12_teams();
+            if (teams_fit && (!want_hashes || c->seg_hint - 1u <= 1u)) {
+                uint32_t T = std::min<uint32_t>(teams_fit, n_buckets >> 6);
+                if (const char *e = getenv("FQD_ONE_KERNEL_TEAMS"))       // (experiments / tests: fewer resident workgroups)
+                    T = (uint32_t)std::max(1, std::min((int)T, atoi(e)));
+                const uint32_t G = T * 64u, R = (n_buckets + G - 1) / G;
+                const size_t words = (size_t)R * T + 4;
+                HIP_TRY(c, c->ld_sync.reserve(words * 8 + 64));
+                HIP_TRY(c, hipMemsetAsync(c->ld_sync.p, 0, words * 8, c->st));
+                csync.team = c->ld_sync.as<unsigned long long>();
+                csync.done = csync.team + (size_t)R * T;
+                csync.abort = reinterpret_cast<uint32_t *>(csync.done + 1);
+                csync.result = csync.abort + 1;
+                csync.teams_per_round = T;
+                csync.n_rounds = R;
+                csync.wait_ticks = 20000000ull;                  // 0.2 s of the 100 MHz wall clock
+                if (const char *e = getenv("FQD_ONE_KERNEL_WAIT_TICKS"))
+                    csync.wait_ticks = strtoull(e, nullptr, 10);
+                one_kernel = true;
+            }
+        }
+        if (one_kernel) {
+            if (side_pending) {
+                HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join, 0));
+                side_pending = false;
+            }
+            HIP_TRY(c, c->urecs.reserve(n * 16 + 16));
+            HIP_TRY(c, c->ucounts.reserve(n * 4 + 16));
+            HIP_TRY(c, c->ufirst.reserve(n * 8 + 64));
+            if (c->seg_hint) {
+                HIP_TRY(c, c->seg_hashes.reserve((size_t)c->seg_hint * n * 4 + 16));
+                sho1.out = c->seg_hashes.as<uint32_t>();
+                sho1.nseg = c->seg_hint;
+                sho1.planes = sh.planes;
+                sho1.kw = kw;
+                sho1.len = sh.max_len;
+                sho1.first = 1u;                     // (pass 0 happens in the kernel itself)
+            }
+            KTIME(c, FQD_K_DEDUPE12, fqd::launch_bucket_collapse12(
+                      reinterpret_cast<const fqd::Rec12 *>(parted), c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
+                      compact, compact == 1 ? c->d_ctr32.as<uint32_t>() + C_SIDE : nullptr, c->urecs.as<uint32_t>(),
+                      c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho1, fused->p0, IdSource(), csync,
+                      c->d_ctr32.as<uint32_t>() + C_BAD));
+        } else if (compact && spill) {
             KTIME(c, FQD_K_DEDUPE12, fqd::launch_bucket_dedupe12_merge(
                       reinterpret_cast<const fqd::Rec12 *>(parted), c->ld_start.as<uint32_t>(), bucket_end, n_buckets, d_w,
                       c->ld_tmp_rec.as<uint32_t>(), c->ld_unique.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st,
@@ -363,7 +417,7 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                                                  c->ld_tmp_first.as<uint32_t>(), c->ld_unique.as<uint32_t>(),
                                                  c->d_ctr32.as<uint32_t>() + C_BAD, c->st, huge));
         }
-        if (!group_total)
+        if (!group_total && !one_kernel)
             FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
         if (side_pending) {                // (the read-back below takes the side path's count and flag too)
             HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join, 0));
@@ -375,7 +429,9 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         // reads the unique count on the device and writes into tables sized for the worst case (as
         // many unique keys as reads), so the GPU works through the ~50 us the host needs to see the
         // numbers and react. If a flag says the attempt failed, what it wrote is simply not used.
-        if (group_total)       // (the unique count is the sum of the group totals: the host adds them up)
+        if (one_kernel)        // (result, abort: the two words behind the team words)
+            FQD_TRY(queue_read_u32n(c, csync.abort, 2, 13));
+        else if (group_total)       // (the unique count is the sum of the group totals: the host adds them up)
             HIP_TRY(c, hipMemcpyAsync(c->h_pin_big, group_total, (size_t)n_groups * 4, hipMemcpyDeviceToHost, c->st));
         else
             FQD_TRY(queue_read_u32(c, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 0));
@@ -390,7 +446,9 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         // segment hashes on the way (the records are fixed-length here)
         fqd::SegHashOut sho;
         const bool routed = fused && fused->p0.mask != 0;
-        if (c->seg_hint && (routed || !getenv("FQD_NO_EARLY_SEG_HASHES"))) {
+        if (one_kernel) {
+            sho = sho1;
+        } else if (c->seg_hint && (routed || !getenv("FQD_NO_EARLY_SEG_HASHES"))) {
             HIP_TRY(c, c->seg_hashes.reserve((size_t)c->seg_hint * n * 4 + 16));
             sho.out = c->seg_hashes.as<uint32_t>();
             sho.nseg = c->seg_hint;
@@ -399,7 +457,9 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
             sho.len = sh.max_len;
             sho.first = routed ? 1u : 0u;        // (pass 0 happens in the compaction itself)
         }
-        if (compact)
+        if (one_kernel)
+            ;                  // (the rows are in the unique table already)
+        else if (compact)
             KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_compact12(
                       c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets,
                       c->ld_tmp_rec.as<uint32_t>(), compact, compact == 1 ? c->d_ctr32.as<uint32_t>() + C_SIDE : nullptr,
@@ -415,7 +475,18 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         c->seg_hashes_first = sho.first;
         FQD_TRY(queued_reads_wait(c));
         uint32_t main_unique = 0;
-        if (group_total)
+        if (one_kernel) {
+            if (taken_u32(c, 13) != 0) {
+                // a wait inside the kernel ran into its limit (workgroups that were not resident: another process on
+                // the GPU?): nothing it wrote counts -- once more, and from now on, with the two kernels
+                c->one_kernel_off = true;
+                if (getenv("FQD_DEBUG"))
+                    fprintf(stderr, "[fqd] one-kernel collapse: a wait ran into its limit; two kernels from now on\n");
+                return FQD_OK;             // (pack_collapse_fused sees one_kernel_off change and runs the attempt again)
+            }
+            main_unique = taken_u32(c, 14);
+            c->route |= FQD_ROUTE_ONE_KERNEL_COLLAPSE;
+        } else if (group_total)
             for (uint32_t g = 0; g < n_groups; g++)
                 main_unique += static_cast<const uint32_t *>(c->h_pin_big)[g];
         else
@@ -1061,11 +1132,12 @@ static int pack_collapse_fused(fqd_ctx *c, const uint8_t *bytes, uint64_t n, uin
     const bool heavy_at_start = c->heavy_keys, route_off_at_start = c->route_off;
     c->last_spill_used = 0;
     for (int attempt = 0; attempt < 4; attempt++) {
-        const bool was_off = c->compact_off, was_heavy = c->heavy_keys, was_routed = !c->route_off;
+        const bool was_off = c->compact_off, was_heavy = c->heavy_keys, was_routed = !c->route_off, was_one = !c->one_kernel_off;
         c->route &= ~FQD_ROUTE_RESTARTED;          // (raised by an attempt that ended early; the last one counts)
         FQD_TRY(pack_collapse_fused_once(c, bytes, n, fixed_len, mem, weights, aux_mem, done));
         if (*done || c->fused_off ||
-            (was_off == c->compact_off && was_heavy == c->heavy_keys && was_routed == !c->route_off))
+            (was_off == c->compact_off && was_heavy == c->heavy_keys && was_routed == !c->route_off &&
+             was_one == !c->one_kernel_off))
             break;
     }
     if ((c->heavy_keys && !heavy_at_start) || (c->route_off && !route_off_at_start)) {

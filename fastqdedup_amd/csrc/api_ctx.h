@@ -150,6 +150,8 @@ struct fqd_ctx {
     uint32_t pass0_nseg = 0;
     uint64_t pass0_edge_cap = 0;    // the edge list's capacity pass 0 wrote against (pairs behind it were counted, not written)
     DevBuf p0_probe;
+    DevBuf ld_sync;                 // the words the workgroups of the one-kernel dedupe + compaction meet on (fqd::CollapseSync)
+    bool one_kernel_off = false;    // ... a wait of that kernel ran into its limit once (CUs held by another process?): two kernels from now on
     DevBuf ld_huge;                 // the uint4 dedupe's huge-bucket plan (fqd::HugeBuckets)
     DevBuf gp_a, gp_b, gp_small, gp_cands;   // grouped search pass: items after level 1 / level 2, small tables, candidate pairs
     uint64_t gp_cand_cap = 0;

@@ -1258,6 +1258,425 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
     }
 }
 
+// ---- dedupe + compaction (+ search pass 0) of compact records in ONE kernel (fqd::CollapseSync) ----------------
+// bucket_dedupe12_kernel and bucket_compact12_kernel<true> fused: a bucket's unique rows never leave the workgroup
+// between the LDS table and the unique table -- no tmp rows (16 B written and read back per unique key), no second
+// launch of 65 536 latency chains. What stood in the way is the row's place in the unique table, a prefix sum over
+// ALL buckets. Here:
+//   * The grid is PERSISTENT and resident at once: G = 64 * T workgroups (T <= 32 teams of 64), workgroup w taking
+//     buckets w, w + G, w + 2 G, ... -- "round" r is the buckets [r G, (r + 1) G).
+//   * Having counted a bucket's unique keys, a workgroup adds (1 << 32 | count) to its team's word of the round with ONE
+//     64-bit atomic: the old value's low half is its offset inside the team (arrival order -- any order will do, rows of
+//     a bucket stay together), the high half tells the last arriver that the team is complete.
+//   * The rows of round r are WRITTEN half a round later, behind the insert phase of round r + 1 (they wait in
+//     registers): by then the teams before the workgroup's own have all but always arrived, so the wait for
+//     base = side keys + rounds before r + teams before mine in r + my offset is one L2 round trip of 64 lanes, not a
+//     queue behind slower predecessors (what a decoupled look-back cost in round 1: 0.77 ms).
+//   * The next bucket's items are requested as soon as the current ones are in the table, so no wave waits for HBM.
+//   * Search pass 0 runs on the rows while they are in LDS, as in bucket_compact12_kernel<true> but with one ROW per
+//     thread instead of eight per lane; a pair is buffered with bucket-local row numbers (bit 31) until base is known.
+// Every wait is bounded (a wall-clock limit, then *abort: all workgroups leave and the host runs the two kernels
+// instead) -- a workgroup that is not resident (another process holding CUs) must not hang the others.
+constexpr uint32_t FC_ECAP = 384, FC_FLUSH_AT = 128;     // pair buffer of a workgroup / flushed when more than that many are final
+constexpr uint32_t FC_LOCAL = 0x80000000u;               // a pair's end that is still a bucket-local row number
+constexpr uint32_t FC_AHEAD = 4;                         // 256-item chunks of a bucket held in registers (more: fetched in place)
+#ifndef FQD_FC_SLOTS
+#define FQD_FC_SLOTS 1024
+#endif
+#ifndef FQD_FC_WAVES
+#define FQD_FC_WAVES 5
+#endif
+constexpr uint32_t FC_SLOTS = FQD_FC_SLOTS;              // slots of the LDS table (512: 20 KB of LDS per workgroup instead of 28)
+constexpr uint32_t FC_ROWS = P0_ROWS;                    // unique keys of a bucket the kernel takes (more: *abort |= 2, the two kernels run)
+__global__ __launch_bounds__(DD_THREADS, FQD_FC_WAVES) void bucket_collapse12_kernel(
+    const fqd::Rec12 *__restrict__ part, const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ bucket_end,
+    const uint32_t *__restrict__ weights, uint32_t n_buckets, uint32_t squeeze, const uint32_t *__restrict__ side_unique,
+    uint4 *__restrict__ urecs, uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst, fqd::SegHashOut sho,
+    fqd::Pass0 p0, IdSource read_ids, fqd::CollapseSync sync, uint32_t *__restrict__ overflow)
+{
+    constexpr uint32_t SLOTS = FC_SLOTS, PER = (SLOTS + DD_THREADS) / DD_THREADS;
+    static_assert(SLOTS == 1024 || SLOTS == 512, "slot = top 10 / 9 bits");
+    __shared__ unsigned long long s_key[SLOTS + 1];
+    __shared__ uint32_t s_cnt[SLOTS + 1], s_min[SLOTS + 1];
+    // a bucket's rows, densely and in pass 0's order: they wait here until their place in the unique table is known
+    __shared__ uint32_t s_ra[FC_ROWS], s_rb[FC_ROWS], s_rc[FC_ROWS], s_rm[FC_ROWS];
+    __shared__ uint4 s_probe[fqd::FQD_P0_PROBE_CAP];
+    __shared__ uint2 s_edge[FC_ECAP];
+    __shared__ uint32_t s_poff[66];
+    __shared__ uint32_t s_wave_tot[DD_THREADS / 64];
+    __shared__ uint32_t s_en, s_base, s_off, s_g;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t T = sync.teams_per_round, G = T * 64u, R = sync.n_rounds, w = blockIdx.x, my_team = w >> 6;
+    const uint32_t side = side_unique ? *side_unique : 0u;
+    const uint32_t sub_shift = 32u - p0.bucket_bits - 6u;
+
+    auto bounds = [&](uint32_t b, uint32_t &lo, uint32_t &hi) {
+        lo = hi = 0;
+        if (b < n_buckets) {
+            lo = bucket_start[b];
+            hi = bucket_start[b + 1];
+            if (bucket_end)
+                hi = min(hi, bucket_end[b]);
+        }
+    };
+    fqd::Rec12 cur[FC_AHEAD];
+    auto fetch = [&](uint32_t lo, uint32_t hi) {
+        const uint32_t last = max(hi, lo + 1) - 1;       // (an empty bucket still owns its slab: part[lo] is readable)
+#pragma unroll
+        for (uint32_t k = 0; k < FC_AHEAD; k++)          // clamped, not conditional: the loads are in flight together
+            cur[k] = part[min(lo + k * DD_THREADS + tid, last)];
+    };
+    auto clear_table = [&]() {
+        for (uint32_t sl = tid; sl <= SLOTS; sl += DD_THREADS) {
+            s_key[sl] = DD_EMPTY64;
+            s_cnt[sl] = 0u;
+            s_min[sl] = 0xFFFFFFFFu;
+        }
+    };
+    // FC_AHEAD items per thread into the table (bucket_dedupe12_kernel's probe loop)
+    // (returns != 0 when an item found no slot)
+    auto insert_chunk = [&](const fqd::Rec12 (&it)[FC_AHEAD], uint32_t base0, uint32_t hi) -> uint32_t {
+        uint32_t wgt[FC_AHEAD];
+        uint32_t slot[FC_AHEAD];
+        uint32_t pend = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < FC_AHEAD; k++) {
+            const bool valid = base0 + k * DD_THREADS + tid < hi;
+            wgt[k] = valid ? (weights ? weights[it[k].id] : 1u) : 0u;
+            slot[k] = (rec12_tag(it[k].a, it[k].b) * 0x9E3779B1u) >> (SLOTS == 1024 ? 22 : 23);   // top 10 / 9 bits of a re-mix
+            if (valid) {
+                if ((it[k].a & it[k].b) == 0xFFFFFFFFu) {      // the all-ones key IS the EMPTY pattern: a slot of its own
+                    atomicAdd(&s_cnt[SLOTS], wgt[k]);
+                    atomicMin(&s_min[SLOTS], it[k].id);
+                } else {
+                    pend |= 1u << k;
+                }
+            }
+        }
+        for (uint32_t probes = 0; pend && probes < SLOTS; probes++) {
+            unsigned long long old[FC_AHEAD];
+#pragma unroll
+            for (uint32_t k = 0; k < FC_AHEAD; k++)       // the compare-and-swaps of all pending items in flight together
+                if (pend >> k & 1u)
+                    old[k] = atomicCAS(&s_key[slot[k]], DD_EMPTY64, ((unsigned long long)it[k].b << 32) | it[k].a);
+#pragma unroll
+            for (uint32_t k = 0; k < FC_AHEAD; k++)
+                if (pend >> k & 1u) {
+                    if (old[k] == DD_EMPTY64 || old[k] == (((unsigned long long)it[k].b << 32) | it[k].a)) {
+                        atomicAdd(&s_cnt[slot[k]], wgt[k]);
+                        atomicMin(&s_min[slot[k]], it[k].id);
+                        pend &= ~(1u << k);
+                    } else {
+                        slot[k] = (slot[k] + 1) & (SLOTS - 1);
+                    }
+                }
+        }
+        return pend;
+    };
+
+    // the rows that wait for their place (round prev_r) are s_ra .. s_rm[0, prev_total)
+    uint32_t prev_total = 0, prev_off = 0, prev_r = 0;
+    uint32_t have_prev = 0;
+    uint32_t P = 0;                   // (wave 0) unique keys of the rounds before prev_r
+    uint32_t n_final = 0;             // pairs [0, n_final) of s_edge are job-wide uids; [n_final, s_en) wait for prev's base
+    unsigned long long reported = 0;
+    if (tid == 0)
+        s_en = 0;
+
+    // the pairs whose ends are final leave: one addition to the job's edge counter for all of them
+    // (all threads, between barriers; n_final == s_en here)
+    auto flush_edges = [&]() {
+        if (tid == 0) {
+            const unsigned long long g0 = atomicAdd(p0.edge_count, (unsigned long long)n_final);
+            reported += n_final;
+            s_g = (uint32_t)g0;                   // (64 bits through two LDS words; s_base has been read by everybody)
+            s_base = (uint32_t)(g0 >> 32);
+        }
+        __syncthreads();
+        const unsigned long long g = ((unsigned long long)s_base << 32) | s_g;
+        for (uint32_t e = tid; e < n_final; e += DD_THREADS)
+            if (g + e < p0.edge_cap)
+                reinterpret_cast<uint2 *>(p0.edges)[g + e] = s_edge[e];
+        __syncthreads();
+        if (tid == 0)
+            s_en = 0;
+        n_final = 0;
+        __syncthreads();
+    };
+
+    // rows of round prev_r -> the unique table; its pairs get their uids (returns false when a wait ran into its limit)
+    auto write_prev = [&]() -> bool {
+        if (wave == 0) {
+            const uint32_t q = prev_r;
+            unsigned long long v1 = 64ull << 32, v2 = 64ull << 32;
+            const bool need1 = q >= 1 && lane < T, need2 = lane >= 32 && lane - 32 < my_team;
+            const unsigned long long *a1 = sync.team + (size_t)(q ? q - 1 : 0) * T + (lane < T ? lane : 0u);
+            const unsigned long long *a2 = sync.team + (size_t)q * T + (need2 ? lane - 32 : 0u);
+            const long long t0 = wall_clock64();
+            bool aborted = false;
+            for (uint32_t spin = 0;; spin++) {
+                if (need1)
+                    v1 = __hip_atomic_load(a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (need2)
+                    v2 = __hip_atomic_load(a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = (uint32_t)(v1 >> 32) == 64u && (uint32_t)(v2 >> 32) == 64u;
+                if (__ballot(!ok) == 0ull)
+                    break;
+                if ((spin & 15u) == 15u) {
+                    const bool late = wall_clock64() - t0 > (long long)sync.wait_ticks;
+                    if (late && lane == 0)
+                        atomicOr(sync.abort, 1u);
+                    if (__hip_atomic_load(sync.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                        aborted = true;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            uint32_t tot1 = need1 ? (uint32_t)v1 : 0u, tot2 = need2 ? (uint32_t)v2 : 0u;
+            for (int o = 32; o; o >>= 1) {
+                tot1 += __shfl_xor(tot1, o);
+                tot2 += __shfl_xor(tot2, o);
+            }
+            P += tot1;
+            if (lane == 0)
+                s_base = aborted ? 0xFFFFFFFFu : side + P + tot2 + prev_off;
+        }
+        __syncthreads();
+        const uint32_t base = s_base;
+        if (base == 0xFFFFFFFFu)
+            return false;
+        for (uint32_t j = tid; j < prev_total; j += DD_THREADS) {
+            const uint32_t u = base + j;
+            uint32_t wv[3];
+            rec12_planes(squeeze, s_ra[j], s_rb[j], wv);
+            if (sho.nseg)
+                for (uint32_t sg = sho.first; sg < sho.nseg; sg++)      // (one array at most: the host saw to it)
+                    sho.out[u] = fqd_segment_hash(wv, sho.planes, sho.kw, sho.len, sg, sho.nseg);
+            urecs[u] = make_uint4(wv[0], wv[1], wv[2], 0u);
+            ucounts[u] = s_rc[j];
+            const uint32_t first_word = s_rm[j];
+            ufirst[u] = read_ids.packed_bits ? read_ids.from_packed(first_word) : (uint64_t)first_word;
+        }
+        // the pairs of that bucket: bucket-local row numbers -> uids, smaller first
+        const uint32_t en = min(s_en, FC_ECAP);
+        for (uint32_t e = n_final + tid; e < en; e += DD_THREADS) {
+            uint2 pr = s_edge[e];
+            if (pr.x & FC_LOCAL)
+                pr.x = base + (pr.x & ~FC_LOCAL);
+            if (pr.y & FC_LOCAL)
+                pr.y = base + (pr.y & ~FC_LOCAL);
+            s_edge[e] = make_uint2(min(pr.x, pr.y), max(pr.x, pr.y));
+        }
+        n_final = en;
+        __syncthreads();
+        if (tid == 0 && s_en != en)
+            s_en = en;
+        if (n_final > FC_FLUSH_AT)
+            flush_edges();
+        return true;
+    };
+
+    auto note = [&](uint32_t x, uint32_t y) {
+        const uint32_t at = atomicAdd(&s_en, 1u);
+        if (at < FC_ECAP)
+            s_edge[at] = make_uint2(x, y);
+        else
+            atomicOr(p0.flag, 1u);          // more pairs in one bucket than the buffer holds: the search does pass 0 itself
+    };
+
+    uint32_t np_next = 0, probe_next = 0;
+    auto load_probes = [&](uint32_t b) {
+        np_next = 0;
+        if (p0.probe_n && b < n_buckets) {
+            np_next = min(p0.probe_n[b], fqd::FQD_P0_PROBE_CAP);
+            probe_next = p0.probe[(size_t)b * fqd::FQD_P0_PROBE_CAP + (tid % fqd::FQD_P0_PROBE_CAP)];   // (unconditional: no wait for the count)
+        }
+    };
+    uint32_t lo, hi;
+    bounds(w, lo, hi);
+    fetch(lo, hi);
+    load_probes(w);
+    clear_table();
+    uint32_t aborted = 0;
+    for (uint32_t r = 0; r < R; r++) {
+        const uint32_t b = r * G + w;
+        uint32_t lo_n, hi_n;
+        bounds(r + 1 < R ? b + G : n_buckets, lo_n, hi_n);
+        // the keys with an N that were routed to this bucket (fqd::Pass0 probe lists; the side path has finished): their
+        // uids were requested a round ago
+        const uint32_t np = np_next, my_probe = probe_next;
+        load_probes(r + 1 < R ? b + G : n_buckets);
+        __syncthreads();                          // the table is clear; pass 0 of the bucket before is over
+        if (tid < 66)
+            s_poff[tid] = 0;                      // (the sub-bin counters: used behind the next barrier)
+        // ---- the bucket's items into the table
+        uint32_t full = insert_chunk(cur, lo, hi);
+        for (uint32_t base0 = lo + FC_AHEAD * DD_THREADS; base0 < hi; base0 += FC_AHEAD * DD_THREADS) {
+            fqd::Rec12 more[FC_AHEAD];             // (a bucket of more than 1024 items: the rest where it lies)
+            const uint32_t last = hi - 1;
+#pragma unroll
+            for (uint32_t k = 0; k < FC_AHEAD; k++)
+                more[k] = part[min(base0 + k * DD_THREADS + tid, last)];
+            full |= insert_chunk(more, base0, hi);
+        }
+        // ---- the next bucket's items and this bucket's probe records are on their way while the bucket is finished
+        fetch(lo_n, hi_n);
+        uint4 my_probe_rec = make_uint4(0, 0, 0, 0);
+        if (tid < np)
+            my_probe_rec = urecs[my_probe];
+        __syncthreads();                          // every item of the bucket is in the table
+        // ---- the rows of the round before leave the row arrays: their place is known by now
+        if (have_prev && !write_prev()) {
+            aborted = 1;
+            break;
+        }
+        // ---- live slots (count > 0: a key all of whose holders have weight 0 is not in the trie): counted, and ranked
+        // inside the sub-bins pass 0 sorts them by (six more bits of the route hash; LDS atomics)
+        const bool sorted = p0.mask != 0;
+        uint32_t live = 0, sub_rank[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t sl = tid + k * DD_THREADS;
+            sub_rank[k] = 0;
+            if (sl <= SLOTS && s_cnt[sl] > 0) {
+                live |= 1u << k;
+                if (sorted) {
+                    const unsigned long long kk = s_key[sl];       // (the slot behind the table: never written, it IS the EMPTY pattern)
+                    const uint32_t sub = (fqd::fqd_route_hash((uint32_t)kk, (uint32_t)(kk >> 32), p0.mask) >> sub_shift) & 63u;
+                    sub_rank[k] = (sub << 16) | atomicAdd(&s_poff[sub], 1u);
+                }
+            }
+        }
+        const uint32_t mine = (uint32_t)__popc(live);
+        uint32_t incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if ((int)lane >= o)
+                incl += up;
+        }
+        if (lane == 63)
+            s_wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine, total = 0;
+        for (uint32_t wv = 0; wv < DD_THREADS / 64; wv++) {
+            before += wv < wave ? s_wave_tot[wv] : 0u;
+            total += s_wave_tot[wv];
+        }
+        // ---- the bucket's count to its team: my offset inside the team comes back
+        if (tid == 0) {
+            const unsigned long long old = __hip_atomic_fetch_add(sync.team + (size_t)r * T + my_team,
+                                                                  (1ull << 32) | total, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_AGENT);
+            s_off = (uint32_t)old;
+            if ((uint32_t)(old >> 32) == 63u) {
+                // the team is complete: its sum to the job's total; the last team's closer leaves the total for the host
+                const uint32_t team_sum = (uint32_t)old + total;
+                const unsigned long long old2 = __hip_atomic_fetch_add(sync.done, (1ull << 32) | team_sum, __ATOMIC_RELAXED,
+                                                                       __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(old2 >> 32) == R * T - 1u)
+                    *sync.result = (uint32_t)old2 + team_sum;
+            }
+            if (total > FC_ROWS)
+                atomicOr(sync.abort, 2u);         // more unique keys than the row arrays hold: the two kernels run instead
+        }
+        if (full)
+            atomicOr(overflow, 1u);               // more distinct keys than slots: the caller takes another way
+        if (sorted && wave == 0) {
+            const uint32_t c = s_poff[lane];
+            uint32_t in2 = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(in2, o);
+                if ((int)lane >= o)
+                    in2 += up;
+            }
+            s_poff[lane] = in2 - c;                // start of sub-bin `lane`
+            if (lane == 63)
+                s_poff[64] = in2;                  // = total
+        }
+        __syncthreads();
+        // ---- the rows densely into the row arrays, in pass 0's order (or in slot order)
+        {
+            uint32_t j = before;
+#pragma unroll
+            for (uint32_t k = 0; k < PER; k++)
+                if (live >> k & 1u) {
+                    const uint32_t sl = tid + k * DD_THREADS;
+                    const uint32_t pp = sorted ? s_poff[sub_rank[k] >> 16] + (sub_rank[k] & 0xFFFFu) : j;
+                    if (pp < FC_ROWS) {
+                        const unsigned long long kk = s_key[sl];
+                        s_ra[pp] = (uint32_t)kk;
+                        s_rb[pp] = (uint32_t)(kk >> 32);
+                        s_rc[pp] = s_cnt[sl];
+                        s_rm[pp] = s_min[sl];
+                    }
+                    j++;
+                }
+        }
+        const bool pass0 = p0.mask != 0 && total > 0 && total <= min(p0.max_rows, FC_ROWS);
+        if (p0.mask && total > p0.max_rows && tid == 0)
+            atomicOr(p0.flag, 1u);                // more rows than pass 0 takes: the search does that pass itself
+        if (pass0 && tid < np)
+            s_probe[tid] = make_uint4(my_probe_rec.x, my_probe_rec.y, my_probe_rec.z, my_probe);
+        __syncthreads();                          // the table's slots have been read: it can be cleared
+        clear_table();
+        // ---- search pass 0: every row against the rows behind it in its sub-bin (same segment 0, at most d mismatches elsewhere)
+        if (pass0) {
+            for (uint32_t i = tid; i < total; i += DD_THREADS) {
+                const uint32_t ai = s_ra[i], bi = s_rb[i];
+                const uint32_t end = s_poff[((fqd::fqd_route_hash(ai, bi, p0.mask) >> sub_shift) & 63u) + 1];
+                for (uint32_t k = i + 1; k < end; k++) {
+                    const uint32_t x = (ai ^ s_ra[k]) | (bi ^ s_rb[k]);     // mismatching positions
+                    if (!(x & p0.mask) && (uint32_t)__popc(x) <= p0.d)
+                        note(FC_LOCAL | i, FC_LOCAL | k);
+                }
+            }
+            // the keys with an N that were routed here: against every row, and against each other
+            for (uint32_t p = 0; p < np; p++) {
+                const uint4 pr = s_probe[p];
+                for (uint32_t i = tid; i < total; i += DD_THREADS) {
+                    uint32_t wv[3];
+                    rec12_planes(squeeze, s_ra[i], s_rb[i], wv);
+                    const uint32_t x = (pr.x ^ wv[0]) | (pr.y ^ wv[1]) | (pr.z ^ wv[2]);
+                    if (!(x & p0.mask) && (uint32_t)__popc(x) <= p0.d)
+                        note(pr.w, FC_LOCAL | i);
+                }
+                if (tid > p && tid < np) {          // (thread t holds probe t)
+                    const uint32_t x = (pr.x ^ my_probe_rec.x) | (pr.y ^ my_probe_rec.y) | (pr.z ^ my_probe_rec.z);
+                    if (!(x & p0.mask) && (uint32_t)__popc(x) <= p0.d)
+                        note(pr.w, my_probe);
+                }
+            }
+        }
+        prev_total = min(total, FC_ROWS);
+        prev_r = r;
+        have_prev = 1;
+        prev_off = s_off;                         // (written before the barrier behind the count)
+        lo = lo_n;
+        hi = hi_n;
+    }
+    if (have_prev && !aborted) {
+        __syncthreads();                          // pass 0 of the last bucket is over
+        if (!write_prev())
+            aborted = 1;
+    }
+    if (!aborted && p0.mask) {
+        __syncthreads();
+        if (n_final)
+            flush_edges();
+        if (p0.stats && tid == 0 && reported)
+            atomicAdd(&p0.stats[w % FQD_STAT_SLOTS].edges, reported);
+    }
+    // the segment hashes of the side path's keys (head of the unique table; one array: its stride does not matter)
+    if (!aborted && sho.nseg && side)
+        for (uint32_t j = w * DD_THREADS + tid; j < side; j += G * DD_THREADS) {
+            const uint4 rr = urecs[j];
+            const uint32_t wv[3] = {rr.x, rr.y, rr.z};
+            for (uint32_t sg = sho.first; sg < sho.nseg; sg++)
+                sho.out[j] = fqd_segment_hash(wv, sho.planes, sho.kw, sho.len, sg, sho.nseg);
+        }
+}
+
 // ---- the side path: keys with the rare symbol (uint4 records in `subs` slabs) -----------------------------
 // An open-addressing table in global memory, one word triple per slot: the POSITION of the record that claimed
 // the slot, the count and the smallest read index. A later record compares itself with the claimer's record in
@@ -1701,6 +2120,38 @@ hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t 
 uint32_t pass0_max_rows() { return P0_ROWS; }
 
 uint32_t side_table_words(uint32_t table_slots) { return 3 * table_slots + (table_slots + SIDE_BLOCK - 1) / SIDE_BLOCK; }
+
+uint32_t collapse12_teams()
+{
+    static int teams = -1;          // (one kind of device per process: gfx950)
+    if (teams < 0) {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bucket_collapse12_kernel, DD_THREADS, 0) != hipSuccess)
+            return 0;
+        const long resident = (long)per_cu * prop.multiProcessorCount;
+        teams = (int)std::min<long>(32, resident / 64);
+    }
+    return (uint32_t)std::max(teams, 0);
+}
+
+hipError_t launch_bucket_collapse12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                    uint32_t n_buckets, const uint32_t *weights, uint32_t squeeze,
+                                    const uint32_t *side_unique, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
+                                    hipStream_t st, SegHashOut seg_hashes, Pass0 pass0, IdSource read_ids,
+                                    CollapseSync sync, uint32_t *overflow)
+{
+    if (!sync.teams_per_round || sync.teams_per_round > 32 || sync.teams_per_round > collapse12_teams() ||
+        (uint64_t)sync.n_rounds * sync.teams_per_round * 64 < n_buckets ||
+        (seg_hashes.nseg && seg_hashes.nseg - seg_hashes.first > 1))
+        return hipErrorInvalidValue;
+    bucket_collapse12_kernel<<<sync.teams_per_round * 64, DD_THREADS, 0, st>>>(
+        part, bucket_start, bucket_end, weights, n_buckets, squeeze, side_unique, reinterpret_cast<uint4 *>(urecs), ucounts,
+        ufirst, seg_hashes, pass0, read_ids, sync, overflow);
+    return hipGetLastError();
+}
+
 
 hipError_t launch_side_collapse(const uint4 *side, const uint32_t *cursor, uint32_t first_part, uint32_t subs, uint32_t cap,
                                 const uint32_t *weights, uint32_t *table, uint32_t table_slots, uint32_t *block_counts,

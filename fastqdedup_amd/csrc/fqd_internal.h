@@ -301,6 +301,17 @@ struct Pass0 {
     uint32_t *flag = nullptr;           // |= 1: pass 0 is incomplete (a bucket of more rows than the wave's LDS holds, a full probe list)
     PairStats *stats = nullptr;         // stats[slot].edges += pairs reported
 };
+// Dedupe + compaction of compact records in one persistent kernel (collapse_lds.hip bucket_collapse12_kernel): the
+// words its workgroups meet on. Grid = 64 * teams_per_round workgroups, all resident at once; round r = buckets
+// [r * grid, (r + 1) * grid).
+struct CollapseSync {
+    unsigned long long *team = nullptr;   // [n_rounds * teams_per_round], zeroed: arrived workgroups << 32 | their unique keys
+    unsigned long long *done = nullptr;   // zeroed: complete teams << 32 | their unique keys
+    uint32_t *abort = nullptr;            // zeroed; != 0 afterwards: a wait ran into its limit, nothing of the output counts
+    uint32_t *result = nullptr;           // the job's unique keys without the side path's (written by the last team's closer)
+    uint32_t teams_per_round = 0, n_rounds = 0;
+    uint64_t wait_ticks = 0;              // limit of one wait in wall_clock64 ticks (100 MHz)
+};
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
                        uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, const uint8_t *lut_host,
                        uint32_t *recs, uint32_t *lens, uint32_t *hashes, uint32_t *owners, OwnerRule rule,
@@ -427,6 +438,16 @@ hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t 
                                    SegHashOut seg_hashes = SegHashOut(), const uint32_t *bucket_unique = nullptr,
                                    const uint32_t *group_total = nullptr, Pass0 pass0 = Pass0(),
                                    IdSource read_ids = IdSource());
+// dedupe + compaction (+ search pass 0) in one persistent kernel (CollapseSync above). collapse12_teams(): teams of 64
+// workgroups the device holds at once (<= 32; 0: the kernel cannot be used) -- the launch takes sync.teams_per_round
+// of them, and sync.n_rounds * 64 * sync.teams_per_round >= n_buckets. The side path must have finished (*side_unique,
+// the probe lists of pass0); at most ONE array of segment hashes (seg_hashes.nseg - seg_hashes.first <= 1).
+uint32_t collapse12_teams();
+hipError_t launch_bucket_collapse12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                    uint32_t n_buckets, const uint32_t *weights, uint32_t squeeze,
+                                    const uint32_t *side_unique, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
+                                    hipStream_t st, SegHashOut seg_hashes, Pass0 pass0, IdSource read_ids,
+                                    CollapseSync sync, uint32_t *overflow);
 // the keys of the side slabs (few: the reads with an N) collapsed through a hash table in global memory and
 // written to the head of the unique table; table: side_table_words(table_slots) words (table_slots a power of
 // two), cleared here; block_counts = table + 3 * table_slots

@@ -98,6 +98,8 @@ typedef struct fqd_summary {
                                             * hundreds of copies (full slabs); no search pass 0 in the compaction then     */
 #define FQD_ROUTE_SEARCH_REFINED  0x4000u  /* crowded segment values (thousands of keys sharing one) were matched on finer
                                             * segments instead of pairwise                                                 */
+#define FQD_ROUTE_ONE_KERNEL_COLLAPSE 0x8000u /* dedupe + compaction (+ search pass 0) of the compact records ran as ONE
+                                            * persistent kernel: no tmp rows between the LDS table and the unique table   */
 int fqd_get_route(const fqd_ctx *ctx, uint32_t *route);
 
 /* Packed-key geometry chosen by fqd_pack_keys (DESIGN.md "data layout"). */
