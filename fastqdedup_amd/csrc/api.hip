@@ -140,6 +140,8 @@ struct FusedLevel1 {
     uint32_t *spill_cursor = nullptr, *l1_over = nullptr;
     bool can_spill = false;
     uint32_t spill_used = 0;   // out: records that went to the spill list
+    bool side_parked = false;  // the pack kernel has sent the keys with an N to the side slabs itself (PackScatter::side_recs):
+                               // the side path is queued BEFORE level 2 and runs beside it
 };
 
 // Bucket bits of the LDS collapse for n reads: ~400-800 reads per bucket (2x fewer workgroups than
@@ -288,6 +290,23 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 if (compact == 1 && !fused->starts_ready)
                     HIP_TRY(c, fqd::launch_slab_starts(side.n_slabs, side.cap, side.cursor + side.n_slabs, side.cursor,
                                                        c->st));
+                const bool side_early = compact == 1 && !spill && fused->side_parked;
+                auto queue_side_path = [&]() -> int {
+                    HIP_TRY(c, hipEventRecord(c->ev_fork, c->st));
+                    HIP_TRY(c, hipStreamWaitEvent(c->st_side, c->ev_fork, 0));
+                    HIP_TRY(c, fqd::launch_side_collapse(
+                                   side.recs, side.cursor, 0, side.n_slabs, side.cap, d_w, c->ld_side_table.as<uint32_t>(),
+                                   fused->side_slots, c->ld_side_table.as<uint32_t>() + 3 * (size_t)fused->side_slots,
+                                   c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(),
+                                   c->d_ctr32.as<uint32_t>() + C_SIDE, c->d_ctr32.as<uint32_t>() + C_BAD, c->st_side,
+                                   fused->p0, fused->stamp_div ? d_ids : IdSource()));
+                    HIP_TRY(c, hipEventRecord(c->ev_join, c->st_side));
+                    side_pending = true;
+                    return FQD_OK;
+                };
+                // (the pack kernel has filled the side slabs: their keys are collapsed beside level 2)
+                if (side_early)
+                    FQD_TRY(queue_side_path());
                 KTIME(c, FQD_K_PART_SCATTER12, fqd::launch_part_scatter12(
                           c->ld_part.as<uint32_t>(), compact, side, f_seg_start, f_tiles, f_parts, f_grid,
                           32 - B, bins2, c->ld_cursor.as<uint32_t>(), c->ld_part2.as<fqd::Rec12>(), c->st, slab_cap,
@@ -300,17 +319,8 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
                 if (spill) {
                     // (the dedupe below merges into the table: the side slabs and the spill list go in first)
                     HIP_TRY(c, fqd::launch_side_begin(side, d_w, c->ld_side_table.as<uint32_t>(), fused->side_slots, c->st));
-                } else if (compact == 1) {
-                    HIP_TRY(c, hipEventRecord(c->ev_fork, c->st));
-                    HIP_TRY(c, hipStreamWaitEvent(c->st_side, c->ev_fork, 0));
-                    HIP_TRY(c, fqd::launch_side_collapse(
-                                   side.recs, side.cursor, 0, side.n_slabs, side.cap, d_w, c->ld_side_table.as<uint32_t>(),
-                                   fused->side_slots, c->ld_side_table.as<uint32_t>() + 3 * (size_t)fused->side_slots,
-                                   c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(),
-                                   c->d_ctr32.as<uint32_t>() + C_SIDE, c->d_ctr32.as<uint32_t>() + C_BAD, c->st_side,
-                                   fused->p0, fused->stamp_div ? d_ids : IdSource()));
-                    HIP_TRY(c, hipEventRecord(c->ev_join, c->st_side));
-                    side_pending = true;
+                } else if (compact == 1 && !side_early) {
+                    FQD_TRY(queue_side_path());
                 }
             } else if (fused)
                 KTIME(c, FQD_K_PART_SCATTER2, fqd::launch_part_scatter(
@@ -1331,6 +1341,15 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     }
     fqd::PackScatter fs{cursor, reinterpret_cast<uint4 *>(c->ld_part.p), c->d_ctr32.as<uint32_t>() + C_BAD,
                         32 - l1_bits, 1u << l1_bits, 1u << sub_bits, cap1, 0u, 0u, 0u, 0u, route_mask};
+    // compact records, one GPU: the pack kernel takes the keys with an N out itself (FQD_NO_PACK_PARKING=1: level 2 does)
+    const bool side_parked = compact == 1 && starts_ready && !getenv("FQD_NO_PACK_PARKING");
+    if (side_parked) {
+        uint32_t *tail = c->ld_side_table.as<uint32_t>() + fqd::side_table_words(side_slots);
+        fs.side_recs = c->ld_side.as<uint4>();
+        fs.side_cursor = tail;
+        fs.side_slabs = side_slabs;
+        fs.side_cap = side_cap;
+    }
     uint32_t *spill_words = nullptr;
     if (heavy) {
         spill_words = c->ld_side_table.as<uint32_t>() + fqd::side_table_words(side_slots) + 2 * side_slabs + 4;
@@ -1384,6 +1403,7 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     f.group_at = group_at;
     f.p0 = p0;
     f.can_spill = can_spill;
+    f.side_parked = side_parked;
     if (heavy) {
         f.spill_cap = spill_cap;
         f.spill_cursor = spill_words;

@@ -255,6 +255,15 @@ struct PackScatter {
     // host-to-device copy: the cursors go on from piece to piece)
     uint32_t id_base = 0;
     uint32_t sub_rot = 0;      // set by launch_pack: the job-wide number of this launch's first workgroup (sub-part = workgroup % subs)
+    // compact records (Rec12, squeeze 1): a key with an N leaves HERE for the side slabs (SideSlabs below: side_slabs
+    // slabs of side_cap records, cursor[s] starting at s * side_cap; a full slab raises bit 16 of *overflow) instead
+    // of travelling through level 1 to be taken out by level 2 -- the side path then runs beside level 2 and has
+    // finished (the head of the unique table, the probe lists of search pass 0) before the dedupe starts.
+    // NULL: every record goes to its bin.
+    uint4 *side_recs = nullptr;
+    uint32_t *side_cursor = nullptr;
+    uint32_t side_slabs = 0, side_cap = 0;
+    uint32_t rare_at = 0;      // set by launch_pack: LDS word offset of the parked keys with an N
 };
 // The route hash of a one-word key in (a, b) form -- a = p0 | p2, b = p1 | p2 for the three planes of "ACGNT", the two
 // planes themselves for a two-plane alphabet -- over the bits of segment 0: what the fused pack (level 1), level 2

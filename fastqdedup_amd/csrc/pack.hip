@@ -106,6 +106,7 @@ __global__ void scan_lens_kernel(const uint64_t *__restrict__ offsets, uint64_t 
 // hold, per slot, the code of its symbol and the symbol itself (0x80 for an empty slot,
 // which no ASCII byte equals).
 constexpr uint32_t PACK_NO_SHIFT = 0xFFFFFFFFu;
+constexpr uint32_t PACK_RARE_CAP = 32;      // keys with an N a workgroup parks in LDS (2048 keys hold ~7 at an N rate of 1e-4 per base)
 struct PackHash {
     uint32_t s1, s2;
     uint64_t code_tbl, char_tbl;
@@ -148,7 +149,13 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     uint4 v[NSUB * R];
     uint32_t bin[NSUB * R], rank[NSUB * R];
     uint32_t n_block = 0;                                // keys of this workgroup
+    // keys with an N (fs.side_recs): parked here, then appended to a side slab behind ONE cursor reservation
+    uint32_t *s_rare_n = smem + fs.rare_at;              // [0] parked so far, [1] their place in the slab
+    uint4 *s_rare = reinterpret_cast<uint4 *>(s_rare_n + 4);
+    const bool park = FUSED && K == 3 && fs.side_recs != nullptr;
     if (FUSED) {
+        if (park && tid == 0)
+            s_rare_n[0] = 0;
         for (uint32_t b = tid; b < fs.n_bins; b += PACK_THREADS)
             s_hist[b] = 0;                               // (visible after the first barrier below)
 #pragma unroll
@@ -342,12 +349,27 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
             if (k < nk) {
                 v[e] = tile4[k];
                 const uint32_t rec[3] = {v[e].x, v[e].y, v[e].z};
+                v[e].w = (uint32_t)(key0 + k) + fs.id_base;   // the read index travels with the record
+                if (park && (rec[0] & rec[1]) != 0u) {
+                    // a key with an N (code 3): to the side slabs, not into a bin (bin[e] stays "none")
+                    const uint32_t at = atomicAdd(&s_rare_n[0], 1u);
+                    if (at < PACK_RARE_CAP) {
+                        s_rare[at] = v[e];
+                    } else {                              // (more of them than the parking space holds: one global atomic each)
+                        const uint32_t slab = blockIdx.x & (fs.side_slabs - 1);
+                        const uint32_t pos = atomicAdd(&fs.side_cursor[slab], 1u);
+                        if (pos < (slab + 1) * fs.side_cap)
+                            fs.side_recs[pos] = v[e];
+                        else
+                            atomicOr(fs.overflow, 16u);
+                    }
+                    continue;
+                }
                 // (route_mask: the bins follow segment 0 of the key alone, in the (a, b) form level 2 will use)
                 const uint32_t h = fs.route_mask ? fqd::fqd_route_hash(K == 3 ? rec[0] | rec[2] : rec[0],
                                                                       K == 3 ? rec[1] | rec[2] : (K >= 2 ? rec[1] : 0u),
                                                                       fs.route_mask)
                                                  : fqd_hash_record(rec, W * K, fixed_len);
-                v[e].w = (uint32_t)(key0 + k) + fs.id_base;   // the read index travels with the record
                 if (fs.owner_parts) {
                     // multi-GPU: the bins are owner-major (owner = rank the read goes to, the pigeonhole
                     // rule of fqd_set_owner_rule), hash bins inside -- an owner's reads leave as ONE
@@ -391,6 +413,12 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
         // ---- phase D, second half: the workgroup's tiles leave partitioned by hash bin ------------
         // tables: hist[n_bins] | off[n_bins] | base[n_bins] | wave[4] | bin16[kpb], behind the record tile
         __syncthreads();
+        // the parked keys with an N: one reservation in this workgroup's side slab (their answer is used behind the next
+        // barrier); what is left of the block is what the bins hold
+        const uint32_t n_rare = park ? s_rare_n[0] : 0u;
+        if (n_rare && tid == 0)
+            s_rare_n[1] = atomicAdd(&fs.side_cursor[blockIdx.x & (fs.side_slabs - 1)], min(n_rare, PACK_RARE_CAP));
+        n_block -= n_rare;
         // exclusive scan of the bin counts: n_bins <= 256, one bin per thread
         const uint32_t mine = tid < fs.n_bins ? s_hist[tid] : 0u;
         uint32_t incl = mine;
@@ -429,6 +457,14 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
             s_base[tid] = base;
         }
         __syncthreads();
+        if (tid < min(n_rare, PACK_RARE_CAP)) {
+            const uint32_t slab = blockIdx.x & (fs.side_slabs - 1);
+            const uint32_t pos = s_rare_n[1] + tid;
+            if (pos < (slab + 1) * fs.side_cap)
+                fs.side_recs[pos] = s_rare[tid];
+            else
+                atomicOr(fs.overflow, 16u);
+        }
         // the records leave in rounds of kpb sorted positions through the one-tile staging area
         for (uint32_t round0 = 0; round0 < n_block; round0 += kpb) {
 #pragma unroll
@@ -604,6 +640,14 @@ hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *o
         if (!(sh.planes <= 3 && find_pack_hash(lut_host, ph_probe)) || fs.n_bins > PACK_WAVES * 64) {
             fs.hist_at = lds / 4;
             lds += fs.n_bins * 4;
+        }
+        // (the parking space of the keys with an N: behind everything; 30.7 -> 31.3 KB at 32-nt keys, still five workgroups per CU)
+        lds = (lds + 15u) & ~15u;
+        fs.rare_at = lds / 4;
+        if (fs.side_recs) {
+            if (!fs.side_cursor || !fs.side_slabs || (fs.side_slabs & (fs.side_slabs - 1)) || fs.owner_parts || sh.planes != 3)
+                return hipErrorInvalidValue;
+            lds += 16 + PACK_RARE_CAP * 16;
         }
         if (lds > 64 * 1024)
             return hipErrorInvalidValue;
