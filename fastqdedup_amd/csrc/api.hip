@@ -352,20 +352,27 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         if (compact && fused && !spill && group_total && fused->p0.mask != 0 && !fused->stamp_div && !d_w &&
             !c->one_kernel_off && (n >> B) <= 1000 && (n_buckets & 63u) == 0 && !getenv("FQD_NO_ONE_KERNEL_COLLAPSE")) {
             const bool want_hashes = c->seg_hint != 0;
-            const uint32_t teams_fit = fqd::collapse12_teams();
-            if (teams_fit && (!want_hashes || c->seg_hint - 1u <= 1u)) {
-                uint32_t T = std::min<uint32_t>(teams_fit, n_buckets >> 6);
-                if (const char *e = getenv("FQD_ONE_KERNEL_TEAMS"))       // (experiments / tests: fewer resident workgroups)
-                    T = (uint32_t)std::max(1, std::min((int)T, atoi(e)));
-                const uint32_t G = T * 64u, R = (n_buckets + G - 1) / G;
-                const size_t words = (size_t)R * T + 4;
-                HIP_TRY(c, c->ld_sync.reserve(words * 8 + 64));
-                HIP_TRY(c, hipMemsetAsync(c->ld_sync.p, 0, words * 8, c->st));
+            const uint32_t resident = fqd::collapse12_resident();
+            uint32_t team = 16;                                       // workgroups that share one reservation of rows
+            if (const char *e = getenv("FQD_ONE_KERNEL_TEAM"))
+                team = (uint32_t)std::max(1, std::min(64, atoi(e)));
+            if (resident >= team && (!want_hashes || c->seg_hint - 1u <= 1u)) {
+                uint32_t G = std::min<uint32_t>(resident, n_buckets);
+                if (const char *e = getenv("FQD_ONE_KERNEL_GRID"))     // (experiments / tests: fewer resident workgroups)
+                    G = (uint32_t)std::max(1, std::min((int)G, atoi(e)));
+                G -= G % team;
+                const uint32_t TPR = G / team, R = (n_buckets + G - 1) / G;
+                const size_t n_teams = (size_t)R * TPR;
+                const size_t bytes = n_teams * 8 + ((n_teams * 4 + 7) & ~(size_t)7) + 16 + 16 * 8;
+                HIP_TRY(c, c->ld_sync.reserve(bytes + 64));
+                HIP_TRY(c, hipMemsetAsync(c->ld_sync.p, 0, bytes, c->st));
                 csync.team = c->ld_sync.as<unsigned long long>();
-                csync.done = csync.team + (size_t)R * T;
-                csync.abort = reinterpret_cast<uint32_t *>(csync.done + 1);
+                csync.base = reinterpret_cast<uint32_t *>(csync.team + n_teams);
+                csync.abort = csync.base + ((n_teams + 1) & ~(size_t)1);
                 csync.result = csync.abort + 1;
-                csync.teams_per_round = T;
+                csync.prof = reinterpret_cast<unsigned long long *>(csync.abort + 4);      // (16 words; only a -DFQD_FC_PROF build writes them)
+                csync.team_size = team;
+                csync.teams_per_round = TPR;
                 csync.n_rounds = R;
                 csync.wait_ticks = 20000000ull;                  // 0.2 s of the 100 MHz wall clock
                 if (const char *e = getenv("FQD_ONE_KERNEL_WAIT_TICKS"))
@@ -496,6 +503,17 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
             }
             main_unique = taken_u32(c, 14);
             c->route |= FQD_ROUTE_ONE_KERNEL_COLLAPSE;
+            if (getenv("FQD_FC_PROF")) {       // (a -DFQD_FC_PROF build: thread 0's ticks per phase, summed over the workgroups)
+                unsigned long long prof[16];
+                HIP_TRY(c, hipMemcpyAsync(prof, csync.prof, sizeof prof, hipMemcpyDeviceToHost, c->st));
+                HIP_TRY(c, stream_wait(c->st));
+                const double per = 1.0 / (100.0 * csync.teams_per_round * csync.team_size);      // ticks of 10 ns -> microseconds per workgroup
+                fprintf(stderr, "[fqd] one-kernel collapse, us per workgroup (%u rounds of %u workgroups):", csync.n_rounds,
+                        csync.teams_per_round * csync.team_size);
+                for (int i = 0; i < 11; i++)
+                    fprintf(stderr, " p%d=%.1f", i, prof[i] * per);
+                fprintf(stderr, "\n");
+            }
         } else if (group_total)
             for (uint32_t g = 0; g < n_groups; g++)
                 main_unique += static_cast<const uint32_t *>(c->h_pin_big)[g];

@@ -1263,15 +1263,17 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
 // between the LDS table and the unique table -- no tmp rows (16 B written and read back per unique key), no second
 // launch of 65 536 latency chains. What stood in the way is the row's place in the unique table, a prefix sum over
 // ALL buckets. Here:
-//   * The grid is PERSISTENT and resident at once: G = 64 * T workgroups (T <= 32 teams of 64), workgroup w taking
-//     buckets w, w + G, w + 2 G, ... -- "round" r is the buckets [r G, (r + 1) G).
+//   * The grid is PERSISTENT and resident at once: G workgroups in teams of TEAM, workgroup w taking buckets w, w + G,
+//     w + 2 G, ... -- "round" r is the buckets [r G, (r + 1) G).
 //   * Having counted a bucket's unique keys, a workgroup adds (1 << 32 | count) to its team's word of the round with ONE
 //     64-bit atomic: the old value's low half is its offset inside the team (arrival order -- any order will do, rows of
-//     a bucket stay together), the high half tells the last arriver that the team is complete.
-//   * The rows of round r are WRITTEN half a round later, behind the insert phase of round r + 1 (they wait in
-//     registers): by then the teams before the workgroup's own have all but always arrived, so the wait for
-//     base = side keys + rounds before r + teams before mine in r + my offset is one L2 round trip of 64 lanes, not a
-//     queue behind slower predecessors (what a decoupled look-back cost in round 1: 0.77 ms).
+//     a bucket stay together), the high half tells the last arriver that the team is complete. That one reserves the
+//     team's rows with ONE addition to the job's row counter (G / TEAM per round: a few thousand on that word in all,
+//     where one per bucket would be 65 536 -- 0.7 ms at ~88 per microsecond) and leaves the base for the others.
+//     Teams take their place in the order they complete: no workgroup waits for any but the TEAM - 1 others of its team
+//     (a prefix over the teams of a round made every round a barrier across all resident workgroups: 9 of 29 us).
+//   * The rows of round r are WRITTEN half a round later, behind the insert phase of round r + 1 (they wait in LDS):
+//     by then the team's base has all but always been written, and the word was requested at the top of the round.
 //   * The next bucket's items are requested as soon as the current ones are in the table, so no wave waits for HBM.
 //   * Search pass 0 runs on the rows while they are in LDS, as in bucket_compact12_kernel<true> but with one ROW per
 //     thread instead of eight per lane; a pair is buffered with bucket-local row numbers (bit 31) until base is known.
@@ -1304,9 +1306,10 @@ __global__ __launch_bounds__(DD_THREADS, FQD_FC_WAVES) void bucket_collapse12_ke
     __shared__ uint2 s_edge[FC_ECAP];
     __shared__ uint32_t s_poff[66];
     __shared__ uint32_t s_wave_tot[DD_THREADS / 64];
-    __shared__ uint32_t s_en, s_base, s_off, s_g;
+    __shared__ uint32_t s_en, s_base, s_g;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t T = sync.teams_per_round, G = T * 64u, R = sync.n_rounds, w = blockIdx.x, my_team = w >> 6;
+    const uint32_t TPR = sync.teams_per_round, TEAM = sync.team_size, G = TPR * TEAM, R = sync.n_rounds, w = blockIdx.x,
+                   my_team = w / TEAM;
     const uint32_t side = side_unique ? *side_unique : 0u;
     const uint32_t sub_shift = 32u - p0.bucket_bits - 6u;
 
@@ -1377,7 +1380,6 @@ __global__ __launch_bounds__(DD_THREADS, FQD_FC_WAVES) void bucket_collapse12_ke
     // the rows that wait for their place (round prev_r) are s_ra .. s_rm[0, prev_total)
     uint32_t prev_total = 0, prev_off = 0, prev_r = 0;
     uint32_t have_prev = 0;
-    uint32_t P = 0;                   // (wave 0) unique keys of the rounds before prev_r
     uint32_t n_final = 0;             // pairs [0, n_final) of s_edge are job-wide uids; [n_final, s_en) wait for prev's base
     unsigned long long reported = 0;
     if (tid == 0)
@@ -1404,43 +1406,39 @@ __global__ __launch_bounds__(DD_THREADS, FQD_FC_WAVES) void bucket_collapse12_ke
         __syncthreads();
     };
 
-    // rows of round prev_r -> the unique table; its pairs get their uids (returns false when a wait ran into its limit)
-    auto write_prev = [&]() -> bool {
-        if (wave == 0) {
-            const uint32_t q = prev_r;
-            unsigned long long v1 = 64ull << 32, v2 = 64ull << 32;
-            const bool need1 = q >= 1 && lane < T, need2 = lane >= 32 && lane - 32 < my_team;
-            const unsigned long long *a1 = sync.team + (size_t)(q ? q - 1 : 0) * T + (lane < T ? lane : 0u);
-            const unsigned long long *a2 = sync.team + (size_t)q * T + (need2 ? lane - 32 : 0u);
-            const long long t0 = wall_clock64();
+    // rows of round prev_r -> the unique table; its pairs get their uids (returns false when a wait ran into its limit).
+    // pre_v: the team's base word as it was at the top of this round (requested there, so that its round trip lies under
+    // the insert phase); 0: the team's closer has not written it yet -- wait for it.
+    auto write_prev = [&](uint32_t pre_v) -> bool {
+        if (tid == 0) {
+            const uint32_t *at = sync.base + (size_t)prev_r * TPR + my_team;
+            uint32_t v = pre_v;
             bool aborted = false;
-            for (uint32_t spin = 0;; spin++) {
-                if (need1)
-                    v1 = __hip_atomic_load(a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (need2)
-                    v2 = __hip_atomic_load(a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool ok = (uint32_t)(v1 >> 32) == 64u && (uint32_t)(v2 >> 32) == 64u;
-                if (__ballot(!ok) == 0ull)
-                    break;
-                if ((spin & 15u) == 15u) {
-                    const bool late = wall_clock64() - t0 > (long long)sync.wait_ticks;
-                    if (late && lane == 0)
-                        atomicOr(sync.abort, 1u);
-                    if (__hip_atomic_load(sync.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                        aborted = true;
+#ifdef FQD_FC_PROF
+            const long long t00 = wall_clock64();
+#endif
+            if (!v) {
+                const long long t0 = wall_clock64();
+                for (uint32_t spin = 0;; spin++) {
+                    v = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v)
                         break;
+                    if ((spin & 15u) == 15u) {
+                        if (wall_clock64() - t0 > (long long)sync.wait_ticks)
+                            atomicOr(sync.abort, 1u);
+                        if (__hip_atomic_load(sync.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                            aborted = true;
+                            break;
+                        }
                     }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                __builtin_amdgcn_s_sleep(2);
             }
-            uint32_t tot1 = need1 ? (uint32_t)v1 : 0u, tot2 = need2 ? (uint32_t)v2 : 0u;
-            for (int o = 32; o; o >>= 1) {
-                tot1 += __shfl_xor(tot1, o);
-                tot2 += __shfl_xor(tot2, o);
-            }
-            P += tot1;
-            if (lane == 0)
-                s_base = aborted ? 0xFFFFFFFFu : side + P + tot2 + prev_off;
+#ifdef FQD_FC_PROF
+            if (sync.prof)
+                atomicAdd(&sync.prof[10], (unsigned long long)(wall_clock64() - t00));
+#endif
+            s_base = aborted ? 0xFFFFFFFFu : side + (v - 1u) + prev_off;
         }
         __syncthreads();
         const uint32_t base = s_base;
@@ -1499,6 +1497,14 @@ __global__ __launch_bounds__(DD_THREADS, FQD_FC_WAVES) void bucket_collapse12_ke
     load_probes(w);
     clear_table();
     uint32_t aborted = 0;
+#ifdef FQD_FC_PROF
+    // (a diagnostic build: thread 0's wall-clock ticks per phase of the round, summed over the workgroups into sync.prof)
+    unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_last = wall_clock64();
+#define FC_PROF(i) do { if (tid == 0) { const long long t_ = wall_clock64(); prof_acc[i] += (unsigned long long)(t_ - prof_last); prof_last = t_; } } while (0)
+#else
+#define FC_PROF(i) do { } while (0)
+#endif
     for (uint32_t r = 0; r < R; r++) {
         const uint32_t b = r * G + w;
         uint32_t lo_n, hi_n;
@@ -1507,7 +1513,11 @@ __global__ __launch_bounds__(DD_THREADS, FQD_FC_WAVES) void bucket_collapse12_ke
         // uids were requested a round ago
         const uint32_t np = np_next, my_probe = probe_next;
         load_probes(r + 1 < R ? b + G : n_buckets);
+        uint32_t pre_v = 0;                       // (thread 0: has my team of the round before got its base yet?)
+        if (have_prev && tid == 0)
+            pre_v = __hip_atomic_load(sync.base + (size_t)prev_r * TPR + my_team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();                          // the table is clear; pass 0 of the bucket before is over
+        FC_PROF(0);
         if (tid < 66)
             s_poff[tid] = 0;                      // (the sub-bin counters: used behind the next barrier)
         // ---- the bucket's items into the table
@@ -1525,12 +1535,15 @@ __global__ __launch_bounds__(DD_THREADS, FQD_FC_WAVES) void bucket_collapse12_ke
         uint4 my_probe_rec = make_uint4(0, 0, 0, 0);
         if (tid < np)
             my_probe_rec = urecs[my_probe];
+        FC_PROF(1);
         __syncthreads();                          // every item of the bucket is in the table
+        FC_PROF(2);
         // ---- the rows of the round before leave the row arrays: their place is known by now
-        if (have_prev && !write_prev()) {
+        if (have_prev && !write_prev(pre_v)) {
             aborted = 1;
             break;
         }
+        FC_PROF(3);
         // ---- live slots (count > 0: a key all of whose holders have weight 0 is not in the trie): counted, and ranked
         // inside the sub-bins pass 0 sorts them by (six more bits of the route hash; LDS atomics)
         const bool sorted = p0.mask != 0;
@@ -1558,28 +1571,22 @@ __global__ __launch_bounds__(DD_THREADS, FQD_FC_WAVES) void bucket_collapse12_ke
         if (lane == 63)
             s_wave_tot[wave] = incl;
         __syncthreads();
+        FC_PROF(4);
         uint32_t before = incl - mine, total = 0;
         for (uint32_t wv = 0; wv < DD_THREADS / 64; wv++) {
             before += wv < wave ? s_wave_tot[wv] : 0u;
             total += s_wave_tot[wv];
         }
-        // ---- the bucket's count to its team: my offset inside the team comes back
+        // ---- the bucket's count to its team; what comes back (my offset inside the team; am I the last?) is looked at
+        // at the END of the round: the atomic's round trip lies under pass 0
+        unsigned long long pub_old = 0;
         if (tid == 0) {
-            const unsigned long long old = __hip_atomic_fetch_add(sync.team + (size_t)r * T + my_team,
-                                                                  (1ull << 32) | total, __ATOMIC_RELAXED,
-                                                                  __HIP_MEMORY_SCOPE_AGENT);
-            s_off = (uint32_t)old;
-            if ((uint32_t)(old >> 32) == 63u) {
-                // the team is complete: its sum to the job's total; the last team's closer leaves the total for the host
-                const uint32_t team_sum = (uint32_t)old + total;
-                const unsigned long long old2 = __hip_atomic_fetch_add(sync.done, (1ull << 32) | team_sum, __ATOMIC_RELAXED,
-                                                                       __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)(old2 >> 32) == R * T - 1u)
-                    *sync.result = (uint32_t)old2 + team_sum;
-            }
+            pub_old = __hip_atomic_fetch_add(sync.team + (size_t)r * TPR + my_team, (1ull << 32) | total, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
             if (total > FC_ROWS)
                 atomicOr(sync.abort, 2u);         // more unique keys than the row arrays hold: the two kernels run instead
         }
+        FC_PROF(5);
         if (full)
             atomicOr(overflow, 1u);               // more distinct keys than slots: the caller takes another way
         if (sorted && wave == 0) {
@@ -1595,6 +1602,7 @@ __global__ __launch_bounds__(DD_THREADS, FQD_FC_WAVES) void bucket_collapse12_ke
                 s_poff[64] = in2;                  // = total
         }
         __syncthreads();
+        FC_PROF(6);
         // ---- the rows densely into the row arrays, in pass 0's order (or in slot order)
         {
             uint32_t j = before;
@@ -1619,6 +1627,7 @@ __global__ __launch_bounds__(DD_THREADS, FQD_FC_WAVES) void bucket_collapse12_ke
         if (pass0 && tid < np)
             s_probe[tid] = make_uint4(my_probe_rec.x, my_probe_rec.y, my_probe_rec.z, my_probe);
         __syncthreads();                          // the table's slots have been read: it can be cleared
+        FC_PROF(7);
         clear_table();
         // ---- search pass 0: every row against the rows behind it in its sub-bin (same segment 0, at most d mismatches elsewhere)
         if (pass0) {
@@ -1648,16 +1657,26 @@ __global__ __launch_bounds__(DD_THREADS, FQD_FC_WAVES) void bucket_collapse12_ke
                 }
             }
         }
+        FC_PROF(8);
         prev_total = min(total, FC_ROWS);
         prev_r = r;
         have_prev = 1;
-        prev_off = s_off;                         // (written before the barrier behind the count)
+        if (tid == 0) {
+            prev_off = (uint32_t)pub_old;
+            if ((uint32_t)(pub_old >> 32) == TEAM - 1u) {
+                // the team is complete and I am its closer: ONE reservation in the unique table for all of it (teams in
+                // the order they complete -- any order will do), then the base for the team to read
+                const uint32_t team_sum = (uint32_t)pub_old + total;
+                const uint32_t at = __hip_atomic_fetch_add(sync.result, team_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sync.base + (size_t)r * TPR + my_team, at + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         lo = lo_n;
         hi = hi_n;
     }
     if (have_prev && !aborted) {
         __syncthreads();                          // pass 0 of the last bucket is over
-        if (!write_prev())
+        if (!write_prev(0u))
             aborted = 1;
     }
     if (!aborted && p0.mask) {
@@ -1667,6 +1686,11 @@ __global__ __launch_bounds__(DD_THREADS, FQD_FC_WAVES) void bucket_collapse12_ke
         if (p0.stats && tid == 0 && reported)
             atomicAdd(&p0.stats[w % FQD_STAT_SLOTS].edges, reported);
     }
+#ifdef FQD_FC_PROF
+    if (tid == 0 && sync.prof)
+        for (int i = 0; i < 10; i++)
+            atomicAdd(&sync.prof[i], prof_acc[i]);
+#endif
     // the segment hashes of the side path's keys (head of the unique table; one array: its stride does not matter)
     if (!aborted && sho.nseg && side)
         for (uint32_t j = w * DD_THREADS + tid; j < side; j += G * DD_THREADS) {
@@ -2121,19 +2145,18 @@ uint32_t pass0_max_rows() { return P0_ROWS; }
 
 uint32_t side_table_words(uint32_t table_slots) { return 3 * table_slots + (table_slots + SIDE_BLOCK - 1) / SIDE_BLOCK; }
 
-uint32_t collapse12_teams()
+uint32_t collapse12_resident()
 {
-    static int teams = -1;          // (one kind of device per process: gfx950)
-    if (teams < 0) {
+    static long resident = -1;          // (one kind of device per process: gfx950)
+    if (resident < 0) {
         int dev = 0, per_cu = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bucket_collapse12_kernel, DD_THREADS, 0) != hipSuccess)
             return 0;
-        const long resident = (long)per_cu * prop.multiProcessorCount;
-        teams = (int)std::min<long>(32, resident / 64);
+        resident = (long)per_cu * prop.multiProcessorCount;
     }
-    return (uint32_t)std::max(teams, 0);
+    return (uint32_t)std::max<long>(resident, 0);
 }
 
 hipError_t launch_bucket_collapse12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
@@ -2142,11 +2165,11 @@ hipError_t launch_bucket_collapse12(const Rec12 *part, const uint32_t *bucket_st
                                     hipStream_t st, SegHashOut seg_hashes, Pass0 pass0, IdSource read_ids,
                                     CollapseSync sync, uint32_t *overflow)
 {
-    if (!sync.teams_per_round || sync.teams_per_round > 32 || sync.teams_per_round > collapse12_teams() ||
-        (uint64_t)sync.n_rounds * sync.teams_per_round * 64 < n_buckets ||
+    const uint64_t grid = (uint64_t)sync.team_size * sync.teams_per_round;
+    if (!grid || grid > collapse12_resident() || (uint64_t)sync.n_rounds * grid < n_buckets ||
         (seg_hashes.nseg && seg_hashes.nseg - seg_hashes.first > 1))
         return hipErrorInvalidValue;
-    bucket_collapse12_kernel<<<sync.teams_per_round * 64, DD_THREADS, 0, st>>>(
+    bucket_collapse12_kernel<<<(unsigned)grid, DD_THREADS, 0, st>>>(
         part, bucket_start, bucket_end, weights, n_buckets, squeeze, side_unique, reinterpret_cast<uint4 *>(urecs), ucounts,
         ufirst, seg_hashes, pass0, read_ids, sync, overflow);
     return hipGetLastError();

@@ -315,11 +315,13 @@ struct Pass0 {
 // [r * grid, (r + 1) * grid).
 struct CollapseSync {
     unsigned long long *team = nullptr;   // [n_rounds * teams_per_round], zeroed: arrived workgroups << 32 | their unique keys
-    unsigned long long *done = nullptr;   // zeroed: complete teams << 32 | their unique keys
-    uint32_t *abort = nullptr;            // zeroed; != 0 afterwards: a wait ran into its limit, nothing of the output counts
-    uint32_t *result = nullptr;           // the job's unique keys without the side path's (written by the last team's closer)
-    uint32_t teams_per_round = 0, n_rounds = 0;
+    uint32_t *base = nullptr;             // [n_rounds * teams_per_round], zeroed: 1 + the first row of the team's keys (0: not known yet)
+    uint32_t *abort = nullptr;            // zeroed; != 0 afterwards: a wait ran into its limit (1) or a bucket had more unique
+                                          // keys than the kernel takes (2): nothing of the output counts
+    uint32_t *result = nullptr;           // zeroed: the row counter -- afterwards the job's unique keys without the side path's
+    uint32_t team_size = 0, teams_per_round = 0, n_rounds = 0;      // grid = team_size * teams_per_round workgroups
     uint64_t wait_ticks = 0;              // limit of one wait in wall_clock64 ticks (100 MHz)
+    unsigned long long *prof = nullptr;   // (diagnostic builds, -DFQD_FC_PROF: 16 words of per-phase ticks, zeroed)
 };
 hipError_t launch_pack(const uint8_t *bytes, uint64_t n_bytes, const uint64_t *offsets, uint64_t n,
                        uint32_t fixed_len, KeyShape sh, const uint8_t *lut_dev, const uint8_t *lut_host,
@@ -447,11 +449,11 @@ hipError_t launch_bucket_compact12(const uint32_t *bucket_start, const uint32_t 
                                    SegHashOut seg_hashes = SegHashOut(), const uint32_t *bucket_unique = nullptr,
                                    const uint32_t *group_total = nullptr, Pass0 pass0 = Pass0(),
                                    IdSource read_ids = IdSource());
-// dedupe + compaction (+ search pass 0) in one persistent kernel (CollapseSync above). collapse12_teams(): teams of 64
-// workgroups the device holds at once (<= 32; 0: the kernel cannot be used) -- the launch takes sync.teams_per_round
-// of them, and sync.n_rounds * 64 * sync.teams_per_round >= n_buckets. The side path must have finished (*side_unique,
+// dedupe + compaction (+ search pass 0) in one persistent kernel (CollapseSync above). collapse12_resident(): workgroups
+// of it the device holds at once (0: the kernel cannot be used) -- the grid must not be larger, and
+// sync.n_rounds * grid >= n_buckets. The side path must have finished (*side_unique,
 // the probe lists of pass0); at most ONE array of segment hashes (seg_hashes.nseg - seg_hashes.first <= 1).
-uint32_t collapse12_teams();
+uint32_t collapse12_resident();
 hipError_t launch_bucket_collapse12(const Rec12 *part, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                     uint32_t n_buckets, const uint32_t *weights, uint32_t squeeze,
                                     const uint32_t *side_unique, uint32_t *urecs, uint32_t *ucounts, uint64_t *ufirst,
