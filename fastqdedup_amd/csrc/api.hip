@@ -350,7 +350,9 @@ int collapse_lds(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done, Fu
         bool one_kernel = false;
         fqd::CollapseSync csync;
         if (compact && fused && !spill && group_total && fused->p0.mask != 0 && !fused->stamp_div && !d_w &&
-            !c->one_kernel_off && (n >> B) <= 1000 && (n_buckets & 63u) == 0 && !getenv("FQD_NO_ONE_KERNEL_COLLAPSE")) {
+            !c->one_kernel_off && (n >> B) <= 1000 && (n_buckets & 63u) == 0 && getenv("FQD_ONE_KERNEL_COLLAPSE")) {
+            // (OFF unless asked for: measured at config 3 it takes 0.63-0.67 ms where the two kernels take 0.22 + 0.30 --
+            // DESIGN "the one-kernel collapse")
             const bool want_hashes = c->seg_hint != 0;
             const uint32_t resident = fqd::collapse12_resident();
             uint32_t team = 16;                                       // workgroups that share one reservation of rows

@@ -239,6 +239,55 @@ def test_fused_pack_collapse_matches_oracle(F, oracle, monkeypatch, case):
             ctx.collapse()       # the packed reads were never written: needs fqd_pack_keys first
 
 
+@pytest.mark.parametrize("case", ["plain", "n_keys", "two_planes", "rows_over_150", "probe_overflow", "edge_overflow",
+                                  "no_patience", "small_grid"])
+def test_one_kernel_collapse_equals_the_two_kernels(F, oracle, monkeypatch, case):
+    """FQD_ONE_KERNEL_COLLAPSE=1: dedupe + compaction + search pass 0 of the compact records as ONE persistent kernel
+    (collapse_lds.hip bucket_collapse12_kernel; off by default -- it is slower than the two kernels, DESIGN "the one-kernel
+    collapse") must give what the oracle gives, also where pass 0 gives way (a bucket with more rows than pass 0 takes, a
+    full probe list, an edge list too short) and when its waits run into their limit at once (the host then runs the two
+    kernels). What it replaces: `TrieNode_AddSequence` counting (`_triemodule.c:222-288`)."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_FUSED_MIN_READS", "100000")
+    monkeypatch.setenv("FQD_ONE_KERNEL_COLLAPSE", "1")
+    n, L, d = 400_000, 32, 1
+    rng = np.random.default_rng(23)
+    keys = synth_keys(n, L, 12, 231, sub_rate=3e-3, n_rate=0 if case == "two_planes" else 1e-3 if case == "n_keys" else 1e-4)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    if case == "rows_over_150":
+        monkeypatch.setenv("FQD_P0_MAX_ROWS", "150")
+    if case == "probe_overflow":
+        rows = rng.choice(n, size=90, replace=False)
+        keys[rows] = keys[rows[0]]
+        keys[rows, 16 + (np.arange(90) % 16)] = ord("N")
+        keys[rows, 31 - (np.arange(90) % 15)] = acgt[(np.arange(90) // 15) % 4]
+    if case == "edge_overflow":
+        monkeypatch.setenv("FQD_P0_EDGE_CAP", "2000")
+    if case == "no_patience":
+        monkeypatch.setenv("FQD_ONE_KERNEL_WAIT_TICKS", "0")
+    if case == "small_grid":            # (many rounds per workgroup, teams of 4)
+        monkeypatch.setenv("FQD_ONE_KERNEL_GRID", "64")
+        monkeypatch.setenv("FQD_ONE_KERNEL_TEAM", "4")
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=d, method="directional")
+    ctx = F.Context(0)
+    if case == "two_planes":
+        present = np.zeros(128, dtype=np.uint8)
+        present[[ord(ch) for ch in "ACGT"]] = 1
+        ctx.configure(present, L, False)
+    for job in range(2):
+        got = F.cluster_keys(raw, key_len=L, max_distance=d, method="directional", context=ctx)
+        assert (got.n_unique, got.n_clusters, got.n_kept) == (want["n_unique"], want["n_clusters"],
+                                                              len(want["kept_read_ids"])), (case, job)
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), (case, job)
+        r = got.route
+        assert r["fused_pack"] and r["compact_records"], (case, r)
+        if case != "no_patience":       # (there the kernel may or may not have had to wait)
+            assert r["one_kernel_collapse"], (case, r)
+        if case in ("plain", "n_keys", "two_planes", "small_grid"):
+            assert r["pass0_in_collapse"] and r["pass0_continued"] and not r["restarted"], (case, r)
+
+
 @pytest.mark.parametrize("case", ["plain", "n_keys", "d2", "two_planes", "rows_over_512", "table_overflow",
                                   "probe_overflow", "edge_overflow", "ladder"])
 def test_routed_collapse_does_search_pass_0(F, oracle, monkeypatch, case):

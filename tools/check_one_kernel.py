@@ -17,9 +17,9 @@ ctx.synth_keys(keys, n, 0, n, L, L, 1003)
 out = {}
 for mode in ("two", "one", "one"):
     if mode == "two":
-        os.environ["FQD_NO_ONE_KERNEL_COLLAPSE"] = "1"
+        os.environ.pop("FQD_ONE_KERNEL_COLLAPSE", None)
     else:
-        os.environ.pop("FQD_NO_ONE_KERNEL_COLLAPSE", None)
+        os.environ["FQD_ONE_KERNEL_COLLAPSE"] = "1"
     for method in ("directional", "adjacency"):
         t0 = time.perf_counter()
         r = F.cluster_keys(keys, key_len=L, max_distance=d, method=method, context=ctx)
