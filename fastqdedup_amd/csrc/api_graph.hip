@@ -78,15 +78,12 @@ static int graph_preinit(fqd_ctx *c, int method)
     HIP_TRY(c, c->best.reserve(U * 4 + 16));
     HIP_TRY(c, c->state.reserve(U + 16));
     const bool closed = method == FQD_METHOD_DIRECTIONAL && c->collapsed && !getenv("FQD_DIRECTIONAL_ROUNDS");
-    if (closed) {
-        HIP_TRY(c, c->blocked.reserve(U * 4 + 16));
+    if (closed)
         HIP_TRY(c, c->root_taint.reserve(U + 16));
-    }
     // (the cursor table of the kept-id bins, at the size fqd_dissect will ask for -- no reallocation behind this)
     HIP_TRY(c, c->kept_u32.reserve(std::max<size_t>(U * 4 + 16, (size_t)512 * fqd::kept_bin_lists() * 4 + 16)));
     // one launch for all of it (graph.hip graph_preinit_kernel)
     HIP_TRY(c, fqd::launch_graph_preinit(c->labels.as<uint32_t>(), c->best.as<uint32_t>(), c->state.as<uint8_t>(),
-                                         closed ? c->blocked.as<uint32_t>() : nullptr,
                                          closed ? c->root_taint.as<uint8_t>() : nullptr, U,
                                          c->hook_slots.as<unsigned long long>(), FQD_HOOK_SLOTS * 8, c->st,
                                          c->kept_u32.as<uint32_t>(), 512 * fqd::kept_bin_lists(),
@@ -161,7 +158,7 @@ static int list_kept(fqd_ctx *c, int method)
         KTIME(c, FQD_K_KEPT_FLAGS, fqd::launch_kept_bins(
                   method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(), c->state.as<uint8_t>(),
                   c->ufirst.as<uint64_t>(), c->id_lo, window, U, c->kept.as<uint8_t>(), c->ucounts.as<uint32_t>(),
-                  c->blocked.as<uint32_t>(), c->root_taint.as<uint8_t>(), c->kept_u32.as<uint32_t>(),
+                  c->labels.as<uint32_t>(), c->root_taint.as<uint8_t>(), c->kept_u32.as<uint32_t>(),
                   c->kept_lists.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_SUM, base, list_out,
                   c->kept_scan.as<uint32_t>(), c->st, tail_zeroed));
         FQD_TRY(queue_read_u32(c, c->kept_scan.as<uint32_t>(), 0));
@@ -190,7 +187,7 @@ static int list_kept(fqd_ctx *c, int method)
         KTIME(c, FQD_K_KEPT_FLAGS, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
                                           c->state.as<uint8_t>(), c->ufirst.as<uint64_t>(), c->id_lo, c->id_hi, U,
                                           c->kept.as<uint8_t>(), nullptr, c->stage_c.as<uint8_t>(), window,
-                                          c->ucounts.as<uint32_t>(), c->blocked.as<uint32_t>(),
+                                          c->ucounts.as<uint32_t>(), c->labels.as<uint32_t>(),
                                           c->root_taint.as<uint8_t>(),
                                           c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
         // the list goes straight into the caller's buffer when one was announced and is large enough
@@ -229,7 +226,7 @@ static int list_kept(fqd_ctx *c, int method)
     KTIME(c, FQD_K_KEPT_FLAGS, fqd::launch_kept_flags(method, c->labels.as<uint32_t>(), c->best.as<uint32_t>(),
                                       c->state.as<uint8_t>(), c->ufirst.as<uint64_t>(), c->id_lo, c->id_hi, U,
                                       c->kept.as<uint8_t>(), c->kept_u32.as<uint32_t>(), nullptr, 0,
-                                      c->ucounts.as<uint32_t>(), c->blocked.as<uint32_t>(), c->root_taint.as<uint8_t>(),
+                                      c->ucounts.as<uint32_t>(), c->labels.as<uint32_t>(), c->root_taint.as<uint8_t>(),
                                       c->d_ctr64.as<unsigned long long>() + C64_SUM, c->st));
     c->kept_in_out = false;
     FQD_TRY(scan_u32(c, c->kept_u32.as<uint32_t>(), c->kept_scan.as<uint32_t>(), U));
@@ -296,7 +293,7 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
         // closed form (graph.hip): two passes over the edges, no rounds, no host round trips. It
         // relies on a strict order of the keys, so a caller's list with repeated keys
         // (fqd_import_unique) takes the relaxation rounds below.
-        HIP_TRY(c, c->blocked.reserve(U * 4 + 16));   // here: union-find over the count-1 keys
+        // (the sets of count-1 keys are whole components: their parents are the components' -- c->labels)
         HIP_TRY(c, c->taint.reserve(E * 8 + 16));       // here: the edges between count-1 keys (edge indices), and behind them those pass 2 looks at
         HIP_TRY(c, c->stage_a.reserve(E * 8 + 16));     // ... and the roots of their ends
         HIP_TRY(c, c->root_taint.reserve(U + 16));
@@ -307,21 +304,26 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
                 FQD_TRY(zero_ctr64(c, C64_CANDS, 2));      // (the search's candidate counters, free here: the two lists' lengths)
             if (!pre_closed) {
                 HIP_TRY(c, hipMemsetAsync(c->root_taint.p, 0, U, c->st));
-                HIP_TRY(c, fqd::launch_uf_init(c->blocked.as<uint32_t>(), U, c->st));
                 // (the state byte of this dissection starts as the key's count nibble, graph.hip dstate_init)
                 HIP_TRY(c, fqd::launch_dstate_init(c->state.as<uint8_t>(), c->ucounts.as<uint32_t>(), U, c->st));
             }
             // (pass 1b -- graph.hip directional_unions_kernel -- from distance 2 on, or when the edges came from elsewhere)
             const bool split_unions = (c->last_search_d >= 2 || getenv("FQD_DIRECTIONAL_SPLIT_UNIONS")) &&
                                       !getenv("FQD_DIRECTIONAL_NO_SPLIT_UNIONS");
-            for (int pass = 1; pass <= 2; pass++)
+            for (int pass = 1; pass <= 2; pass++) {
+                if (pass == 2 && c->join_pending) {
+                    // pass 2 walks the components' parents: the union-find that ran beside pass 1 must be through
+                    HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join, 0));
+                    c->join_pending = false;
+                }
                 KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_directional_closed(
                           c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(), c->urecs.as<uint32_t>(),
-                          c->ulens.as<uint32_t>(), sh, c->blocked.as<uint32_t>(), c->state.as<uint8_t>(),
+                          c->ulens.as<uint32_t>(), sh, c->labels.as<uint32_t>(), c->state.as<uint8_t>(),
                           c->taint.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_CANDS,
                           c->root_taint.as<uint8_t>(), c->best.as<uint32_t>(), pass, c->st, c->stage_a.as<uint32_t>(),
                           split_unions ? c->taint.as<uint32_t>() + E : nullptr,
                           c->d_ctr64.as<unsigned long long>() + C64_CAND_NEED));
+            }
             list_method = 3;
         }
     } else if (method == FQD_METHOD_DIRECTIONAL) {

@@ -660,11 +660,12 @@ hipError_t launch_mark_dropped(uint8_t *state, uint64_t U, const uint32_t *dropp
                                hipStream_t st);
 hipError_t launch_uf_flatten(uint32_t *parent, uint64_t U, unsigned long long *n_roots, hipStream_t st);
 hipError_t launch_dissect_init(uint32_t *best, uint8_t *state, uint64_t U, hipStream_t st);
-hipError_t launch_graph_preinit(uint32_t *parent, uint32_t *best, uint8_t *state, uint32_t *parent1, uint8_t *root_taint,
+hipError_t launch_graph_preinit(uint32_t *parent, uint32_t *best, uint8_t *state, uint8_t *root_taint /* != NULL: the closed-form
+                                directional dissection follows */,
                                 uint64_t U, unsigned long long *hook_slots, uint32_t hook_words, hipStream_t st,
                                 uint32_t *zero32 = nullptr, uint32_t zero32_words = 0,
                                 unsigned long long *zero64_a = nullptr, unsigned long long *zero64_b = nullptr,
-                                const uint32_t *ucounts = nullptr /* with parent1: state[i] starts as the count nibble of
+                                const uint32_t *ucounts = nullptr /* with root_taint: state[i] starts as the count nibble of
                                                                    * the closed-form directional dissection */,
                                 unsigned long long *zero64_c = nullptr);
 hipError_t launch_dstate_init(uint8_t *state, const uint32_t *ucounts, uint64_t U, hipStream_t st);
@@ -689,7 +690,8 @@ hipError_t launch_kept_flags(int method, const uint32_t *labels, const uint32_t 
 // directional dissection without rounds: pass 1 (edges: in-arcs, taint, unions of count-1 keys), pass 2
 // (count-1 keys report to their set's root); method 3 of launch_kept_flags reads the verdicts
 hipError_t launch_directional_closed(const uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
-                                     const uint32_t *ulens, KeyShape sh, uint32_t *parent1, uint8_t *state,
+                                     const uint32_t *ulens, KeyShape sh, const uint32_t *parent /* the components' (complete
+                                     before pass 2) */, uint8_t *state,
                                      uint32_t *list11, unsigned long long *list11_count, uint8_t *root_taint,
                                      uint32_t *best, int pass, hipStream_t st, uint32_t *roots, uint32_t *list2,
                                      unsigned long long *list2_count);

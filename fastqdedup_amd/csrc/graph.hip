@@ -427,15 +427,15 @@ __global__ void dstate_init_kernel(uint8_t *__restrict__ state, const uint32_t *
 // Everything stages 4 and 5 set up over the unique table, in ONE launch (fqd_api_graph_preinit: five
 // launches and two fills of ~5 us each, plus the gaps between them, were 70 us of a 2.9 ms job):
 // parent[i] = i (components), best[i] = i, state[i] = 0 (dissection), and for the closed-form
-// directional dissection parent1[i] = i, root_taint[i] = 0; block 0 also clears the hook counters.
+// directional dissection (root_taint != NULL) root_taint[i] = 0 and state[i] = the key's count nibble; block 0 also
+// clears the hook counters.
 __global__ void graph_preinit_kernel(uint32_t *__restrict__ parent, uint32_t *__restrict__ best,
-                                     uint8_t *__restrict__ state, uint32_t *__restrict__ parent1 /* may be NULL */,
-                                     uint8_t *__restrict__ root_taint /* with parent1 */, uint64_t U,
+                                     uint8_t *__restrict__ state, uint8_t *__restrict__ root_taint /* may be NULL */, uint64_t U,
                                      unsigned long long *__restrict__ hook_slots, uint32_t hook_words,
                                      uint32_t *__restrict__ zero32 /* may be NULL */, uint32_t zero32_words,
                                      unsigned long long *__restrict__ zero64_a, unsigned long long *__restrict__ zero64_b,
                                      unsigned long long *__restrict__ zero64_c,
-                                     const uint32_t *__restrict__ ucounts /* with parent1: state[i] = count nibble (dstate_init) */)
+                                     const uint32_t *__restrict__ ucounts /* with root_taint: state[i] = count nibble (dstate_init) */)
 {
     // four keys per thread: 16-byte stores for the word arrays, 4-byte stores for the byte arrays
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = q * 4;
@@ -459,24 +459,20 @@ __global__ void graph_preinit_kernel(uint32_t *__restrict__ parent, uint32_t *__
         reinterpret_cast<uint4 *>(parent)[q] = v;
         reinterpret_cast<uint4 *>(best)[q] = v;
         uint32_t st4 = 0u;
-        if (parent1 && ucounts) {
+        if (root_taint && ucounts) {
             const uint4 c4 = reinterpret_cast<const uint4 *>(ucounts)[q];
             st4 = dstate_init(c4.x) | dstate_init(c4.y) << 8 | dstate_init(c4.z) << 16 | dstate_init(c4.w) << 24;
         }
         reinterpret_cast<uint32_t *>(state)[q] = st4;
-        if (parent1) {
-            reinterpret_cast<uint4 *>(parent1)[q] = v;
+        if (root_taint)
             reinterpret_cast<uint32_t *>(root_taint)[q] = 0u;
-        }
     } else {
         for (uint64_t i = i0; i < U; i++) {
             parent[i] = (uint32_t)i;
             best[i] = (uint32_t)i;
-            state[i] = parent1 && ucounts ? (uint8_t)dstate_init(ucounts[i]) : (uint8_t)0;
-            if (parent1) {
-                parent1[i] = (uint32_t)i;
+            state[i] = root_taint && ucounts ? (uint8_t)dstate_init(ucounts[i]) : (uint8_t)0;
+            if (root_taint)
                 root_taint[i] = 0;
-            }
         }
     }
 }
@@ -546,15 +542,19 @@ __global__ void directional_round_kernel(const uint32_t *__restrict__ edges, uin
 }
 
 // ---- directional, closed form -------------------------------------------------------
+// A count-1 key is kept iff its COMPONENT holds count-1 keys only and it is the component's largest key: a maximal
+// connected set S of count-1 keys that touches no bigger key has no edge leaving it at all (a neighbour outside S would
+// be a count-1 key, hence in S, or a bigger key), so S is a whole component -- and a set that does touch one is dropped
+// entirely. The sets therefore need no union-find of their own: the components' parents (uf_union_kernel, which runs
+// beside pass 1 and must have finished before pass 2) are their parents. (Rounds 1-3 kept a second union-find over the
+// edges between count-1 keys: 3.4 M unions of config 4's 9.35 M edges, 0.32 ms, and 52 MB of parents to set up.)
 // Pass 1 over the edges: in-arcs of keys with count >= 2 (state = 2: dropped), count-1 keys that
-// touch a bigger key (state = 3: tainted), and a union-find over the edges between count-1 keys --
-// those edges (few) are listed for pass 2. Four edges per thread, one list reservation per workgroup.
+// touch a bigger key (state = 3: tainted); the edges between count-1 keys (few) are listed for pass 2. Four edges per
+// thread, one list reservation per workgroup.
 constexpr uint32_t DE_EPT = 4;
 
-template <bool UNION_HERE>      // false: the listed edges are united by directional_unions_kernel (pass 1b)
 __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *__restrict__ edges, uint64_t E,
-                                                                const uint32_t *__restrict__ ucounts,
-                                                                uint32_t *parent1, uint8_t *state,
+                                                                const uint32_t *__restrict__ ucounts, uint8_t *state,
                                                                 uint32_t *__restrict__ list11,
                                                                 unsigned long long *__restrict__ list11_count)
 {
@@ -596,22 +596,6 @@ __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *
             continue;
         const uint32_t u = uu[t], v = vv[t];
         if (cu[t] == 1 && cv[t] == 1) {
-            if (UNION_HERE) {
-                uint32_t a = u, b = v;
-                for (bool fresh = false;; fresh = true) {
-                    a = fresh ? uf_find<true>(parent1, a) : uf_find<false>(parent1, a);
-                    b = fresh ? uf_find<true>(parent1, b) : uf_find<false>(parent1, b);
-                    if (a == b)
-                        break;
-                    if (a > b) {
-                        const uint32_t x = a;
-                        a = b;
-                        b = x;
-                    }
-                    if (atomicCAS(&parent1[b], b, a) == b)
-                        break;
-                }
-            }
             rank[t] = atomicAdd(&s_n, 1u);      // (an edge between count-1 keys: listed)
             continue;
         }
@@ -640,16 +624,15 @@ __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *
 }
 
 // Pass 1b, over the listed edges (both ends count 1), AFTER pass 1 has marked every count-1 key that touches a bigger
-// one (state 3, "tainted": dropped whatever its set looks like): the ends are united, and the edge stays on the list of
-// pass 2 only if one of its ends is NOT tainted. An edge between two tainted keys has nothing more to say -- both are
-// dropped -- and the taint of a set reaches its root through the listed edges: a set with a tainted and an untainted
-// member has an edge between such a pair on the path that joins them. With d = 2 most listed edges join two error
-// variants of one molecule, both next to the molecule's key (config 4: 3.4 M edges listed, a tenth of them left for
-// pass 2, whose two launches moved 4.5 GB before).
-__global__ __launch_bounds__(256) void directional_unions_kernel(const uint32_t *__restrict__ edges,
+// one (state 3, "tainted": dropped whatever its set looks like): the edge stays on the list of pass 2 only if one of its
+// ends is NOT tainted. An edge between two tainted keys has nothing more to say -- both are dropped -- and the taint of
+// a set reaches its root through the listed edges: a set with a tainted and an untainted member has an edge between
+// such a pair on the path that joins them. With d = 2 most listed edges join two error variants of one molecule, both
+// next to the molecule's key (config 4: 3.4 M edges listed, a tenth of them left for pass 2).
+__global__ __launch_bounds__(256) void directional_filter_kernel(const uint32_t *__restrict__ edges,
                                                                  const uint32_t *__restrict__ list11,
                                                                  const unsigned long long *__restrict__ list11_count,
-                                                                 uint32_t *parent1, const uint8_t *__restrict__ state,
+                                                                 const uint8_t *__restrict__ state,
                                                                  uint32_t *__restrict__ list_out,
                                                                  unsigned long long *__restrict__ list_out_count)
 {
@@ -682,23 +665,7 @@ __global__ __launch_bounds__(256) void directional_unions_kernel(const uint32_t 
 #pragma unroll
         for (uint32_t t = 0; t < UE; t++) {
             rank[t] = 0xFFFFFFFFu;
-            if (!live[t])
-                continue;
-            uint32_t a = uv[t].x, b = uv[t].y;
-            for (bool fresh = false;; fresh = true) {
-                a = fresh ? uf_find<true>(parent1, a) : uf_find<false>(parent1, a);
-                b = fresh ? uf_find<true>(parent1, b) : uf_find<false>(parent1, b);
-                if (a == b)
-                    break;
-                if (a > b) {
-                    const uint32_t x = a;
-                    a = b;
-                    b = x;
-                }
-                if (atomicCAS(&parent1[b], b, a) == b)
-                    break;
-            }
-            if ((su[t] & 15u) != 3u || (sv[t] & 15u) != 3u)
+            if (live[t] && ((su[t] & 15u) != 3u || (sv[t] & 15u) != 3u))
                 rank[t] = atomicAdd(&s_n, 1u);
         }
         __syncthreads();
@@ -752,6 +719,46 @@ __global__ void directional_roots_kernel(const uint32_t *__restrict__ edges,
     }
 }
 
+// a > b for two DIFFERENT keys of one count, every word of both records requested before the first is looked at
+// (fqd_key_cmp walks the words one dependent round trip after the other -- ten for two 300-nt keys that differ near
+// their ends, and neighbours differ anywhere). Records of up to 8 uint4; longer ones: the walk.
+__device__ __forceinline__ bool key_greater_inflight(uint32_t a, uint32_t b, const uint32_t *__restrict__ urecs,
+                                                     const uint32_t *__restrict__ ulens, const KeyShape &sh)
+{
+    const uint32_t q4 = sh.stride / 4u;
+    const uint32_t *ra = urecs + (uint64_t)a * sh.stride, *rb = urecs + (uint64_t)b * sh.stride;
+    if (q4 > 8u || (sh.stride & 3u))
+        return fqd_key_cmp(ra, fqd_key_len(sh, ulens, a), rb, fqd_key_len(sh, ulens, b), sh.planes, sh.words) > 0;
+    uint4 va[8], vb[8];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) {              // (clamped, unconditional: in flight together)
+        va[q] = reinterpret_cast<const uint4 *>(ra)[min(q, q4 - 1u)];
+        vb[q] = reinterpret_cast<const uint4 *>(rb)[min(q, q4 - 1u)];
+    }
+    // the first record word (of stride) in which they differ; word j belongs to 32-base word j / K
+    uint32_t first = 0xFFFFFFFFu;
+#pragma unroll
+    for (int q = 7; q >= 0; q--) {
+        if ((uint32_t)q < q4) {
+            if (va[q].w != vb[q].w) first = 4u * q + 3u;
+            if (va[q].z != vb[q].z) first = 4u * q + 2u;
+            if (va[q].y != vb[q].y) first = 4u * q + 1u;
+            if (va[q].x != vb[q].x) first = 4u * q + 0u;
+        }
+    }
+    const uint32_t la = fqd_key_len(sh, ulens, a), lb = fqd_key_len(sh, ulens, b);
+    if (first == 0xFFFFFFFFu || first >= sh.planes * sh.words)
+        return la > lb;                              // (equal records: one is a prefix of the other, or padding differs -- never)
+    // (the words of that 32-base word again, from the cache: no register array indexed by a run-time value)
+    const uint32_t w = first / sh.planes;
+    const uint32_t d = fqd_diff_word_dyn(ra, rb, w, sh.planes);
+    const uint32_t bit = (uint32_t)__ffs((int)d) - 1u, pos = w * 32u + bit;
+    if (pos >= la || pos >= lb)
+        return la > lb;
+    return fqd_code_at(ra, w, bit, sh.planes) > fqd_code_at(rb, w, bit, sh.planes);
+}
+
+// best[root] = the largest key among the ends of the listed edges of an untainted set (all of count 1)
 __global__ void directional_best_kernel(const uint32_t *__restrict__ edges, const uint32_t *__restrict__ list11,
                                         const unsigned long long *__restrict__ list11_count,
                                         const uint32_t *__restrict__ ucounts, const uint32_t *__restrict__ urecs,
@@ -762,14 +769,21 @@ __global__ void directional_best_kernel(const uint32_t *__restrict__ edges, cons
     const uint64_t n = *list11_count;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t e = list11[i];
+        const uint2 rr = reinterpret_cast<const uint2 *>(roots)[i];
+        const uint2 xx = reinterpret_cast<const uint2 *>(edges)[e];
+        const uint8_t t0 = root_taint[rr.x], t1 = root_taint[rr.y];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const uint32_t r = roots[2 * i + k];
-            if (root_taint[r])
+            const uint32_t r = k ? rr.y : rr.x, x = k ? xx.y : xx.x;
+            if ((k ? t1 : t0) || r == x)
                 continue;
-            const uint32_t x = edges[2 * e + k];
-            if (r != x)
-                raise_best(best, r, x, ucounts, urecs, ulens, sh);
+            for (;;) {                               // (raise_best for two keys of count 1: the keys alone decide)
+                const uint32_t old = load_relaxed(&best[r]);
+                if (old == x || !key_greater_inflight(x, old, urecs, ulens, sh))
+                    break;
+                if (atomicCAS(&best[r], old, x) == old)
+                    break;
+            }
         }
     }
 }
@@ -1514,14 +1528,14 @@ hipError_t launch_uf_flatten(uint32_t *parent, uint64_t U, unsigned long long *n
     return hipGetLastError();
 }
 
-hipError_t launch_graph_preinit(uint32_t *parent, uint32_t *best, uint8_t *state, uint32_t *parent1, uint8_t *root_taint,
+hipError_t launch_graph_preinit(uint32_t *parent, uint32_t *best, uint8_t *state, uint8_t *root_taint,
                                 uint64_t U, unsigned long long *hook_slots, uint32_t hook_words, hipStream_t st,
                                 uint32_t *zero32, uint32_t zero32_words, unsigned long long *zero64_a,
                                 unsigned long long *zero64_b, const uint32_t *ucounts, unsigned long long *zero64_c)
 {
     const uint64_t quads = (U + 3) / 4;
     graph_preinit_kernel<<<(unsigned)std::max<uint64_t>(1, (quads + 255) / 256), 256, 0, st>>>(
-        parent, best, state, parent1, root_taint, U, hook_slots, hook_words, zero32, zero32_words, zero64_a, zero64_b,
+        parent, best, state, root_taint, U, hook_slots, hook_words, zero32, zero32_words, zero64_a, zero64_b,
         zero64_c, ucounts);
     return hipGetLastError();
 }
@@ -1559,7 +1573,7 @@ hipError_t launch_directional_round(const uint32_t *edges, uint64_t E, const uin
 }
 
 hipError_t launch_directional_closed(const uint32_t *edges, uint64_t E, const uint32_t *ucounts, const uint32_t *urecs,
-                                     const uint32_t *ulens, KeyShape sh, uint32_t *parent1, uint8_t *state,
+                                     const uint32_t *ulens, KeyShape sh, const uint32_t *parent, uint8_t *state,
                                      uint32_t *list11, unsigned long long *list11_count, uint8_t *root_taint,
                                      uint32_t *best, int pass, hipStream_t st, uint32_t *roots, uint32_t *list2,
                                      unsigned long long *list2_count)
@@ -1567,22 +1581,19 @@ hipError_t launch_directional_closed(const uint32_t *edges, uint64_t E, const ui
     if (!E)
         return hipSuccess;
     const unsigned list_grid = (unsigned)std::min<uint64_t>(grid_for(E), 8192);   // (the list's length is on the device)
-    // list2 != NULL: pass 1 only lists the edges between count-1 keys, pass 1b unites them and keeps those pass 2 must
-    // look at (worth its launch where such edges are many: d >= 2, error variants of one molecule next to each other);
-    // else pass 1 unites them itself and pass 2 walks the whole list
+    // parent: the COMPONENTS' union-find (uf_union_kernel), complete before pass 2 -- pass 1 does not look at it.
+    // list2 != NULL: pass 1b keeps the listed edges pass 2 must look at (worth its launch where the edges between
+    // count-1 keys are many: d >= 2, error variants of one molecule next to each other); else pass 2 walks the whole list
     if (pass == 1) {
         const unsigned grid = (unsigned)((E + 256 * DE_EPT - 1) / (256 * DE_EPT));
-        if (list2)
-            directional_edges_kernel<false><<<grid, 256, 0, st>>>(edges, E, ucounts, parent1, state, list11, list11_count);
-        else
-            directional_edges_kernel<true><<<grid, 256, 0, st>>>(edges, E, ucounts, parent1, state, list11, list11_count);
+        directional_edges_kernel<<<grid, 256, 0, st>>>(edges, E, ucounts, state, list11, list11_count);
     } else {
         if (list2)
-            directional_unions_kernel<<<(unsigned)std::min<uint64_t>(grid_for((E + 3) / 4), 8192), 256, 0, st>>>(
-                edges, list11, list11_count, parent1, state, list2, list2_count);
+            directional_filter_kernel<<<(unsigned)std::min<uint64_t>(grid_for((E + 3) / 4), 8192), 256, 0, st>>>(
+                edges, list11, list11_count, state, list2, list2_count);
         const uint32_t *list = list2 ? list2 : list11;
         const unsigned long long *count = list2 ? list2_count : list11_count;
-        directional_roots_kernel<<<list_grid, 256, 0, st>>>(edges, list, count, parent1, state, root_taint, roots);
+        directional_roots_kernel<<<list_grid, 256, 0, st>>>(edges, list, count, parent, state, root_taint, roots);
         directional_best_kernel<<<list_grid, 256, 0, st>>>(edges, list, count, ucounts, urecs, ulens, sh, roots, root_taint,
                                                            best);
     }

@@ -521,6 +521,22 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
             const uint4 *recs4 = reinterpret_cast<const uint4 *>(urecs);
             const uint32_t W = sh.words;
             const unsigned long long have = __ballot(live);
+            // Keys of ONE length: which bits of this lane's 32-base words (ql, ql + Q: W <= 2 Q for records of up to
+            // 16 uint4... else the general loop) lie in segment s2 does not depend on the candidate -- worked out once
+            // per sweep, not per word, segment and candidate (two divisions by nseg each: the inner loop was mostly that)
+            const bool fixed = !sh.ragged && nseg <= 4 && W <= 2 * Q;
+            uint32_t fm0[4] = {0, 0, 0, 0}, fm1[4] = {0, 0, 0, 0};
+            if (fixed) {
+#pragma unroll
+                for (uint32_t s2 = 0; s2 < 4; s2++)
+                    if (s2 < nseg) {
+                        uint32_t slo, shi;
+                        fqd_segment(sh.max_len, s2, nseg, slo, shi);
+                        fm0[s2] = ql < W ? fqd_range_mask(ql, slo, shi) : 0u;
+                        fm1[s2] = ql + Q < W ? fqd_range_mask(ql + Q, slo, shi) : 0u;
+                    }
+            }
+            const bool pow2 = (Q & (Q - 1)) == 0;       // (groups that a butterfly of shuffles adds up)
             for (uint32_t c0 = 0; c0 < 64 && (have >> c0); c0 += CR * groups) {
                 // CR rounds of groups: their 2 * CR loads per lane are requested together
                 uint4 xs[CR];
@@ -554,7 +570,25 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
                         *reinterpret_cast<uint4 *>(&s_x[wave][(gl * Q + ql) * 4]) = xs[t];
                     __builtin_amdgcn_wave_barrier();
                     uint32_t dist = 0, seg_mis = 0;
-                    if (on[t]) {
+                    if (on[t] && fixed) {
+                        const uint32_t *x = &s_x[wave][gl * Q * 4];
+                        uint32_t dw0 = 0, dw1 = 0;
+                        if (ql < W) {
+#pragma unroll
+                            for (int k = 0; k < K; k++)
+                                dw0 |= x[ql * K + k];
+                        }
+                        if (ql + Q < W) {
+#pragma unroll
+                            for (int k = 0; k < K; k++)
+                                dw1 |= x[(ql + Q) * K + k];
+                        }
+                        dist = __popc(dw0) + __popc(dw1);
+#pragma unroll
+                        for (uint32_t s2 = 0; s2 < 4; s2++)
+                            if (s2 < cseg && ((dw0 & fm0[s2]) | (dw1 & fm1[s2])))
+                                seg_mis |= 1u << s2;
+                    } else if (on[t]) {
                         const uint32_t *x = &s_x[wave][gl * Q * 4];
                         for (uint32_t w = ql; w < W; w += Q) {
                             uint32_t dw = 0;
@@ -570,16 +604,28 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
                             }
                         }
                     }
-                    s_part[wave][lane][0] = dist;
-                    s_part[wave][lane][1] = seg_mis;
-                    __builtin_amdgcn_wave_barrier();
+                    if (pow2) {
+                        // (the Q lanes of a group: a butterfly; lanes of groups that are off hold zeros)
+                        for (uint32_t o = Q >> 1; o; o >>= 1) {
+                            dist += __shfl_xor(dist, o);
+                            seg_mis |= __shfl_xor(seg_mis, o);
+                        }
+                    } else {
+                        s_part[wave][lane][0] = dist;
+                        s_part[wave][lane][1] = seg_mis;
+                        __builtin_amdgcn_wave_barrier();
+                    }
                     if (gl < groups && cnd < 64 && ql == 0)
                         s_hit[wave][cnd] = 0;          // (a pair of different lengths stays a miss)
                     if (on[t] && ql == 0) {
-                        uint32_t dsum = 0, mis = 0;
-                        for (uint32_t q = 0; q < Q; q++) {
-                            dsum += s_part[wave][lane + q][0];
-                            mis |= s_part[wave][lane + q][1];
+                        uint32_t dsum = dist, mis = seg_mis;
+                        if (!pow2) {
+                            dsum = 0;
+                            mis = 0;
+                            for (uint32_t q = 0; q < Q; q++) {
+                                dsum += s_part[wave][lane + q][0];
+                                mis |= s_part[wave][lane + q][1];
+                            }
                         }
                         // a neighbour, reported in the pass of the FIRST segment the pair agrees on: all
                         // earlier segments must disagree (an empty segment agrees trivially, as in gp_verify)

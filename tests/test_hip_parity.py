@@ -216,13 +216,18 @@ def test_fused_pack_collapse_matches_oracle(F, oracle, monkeypatch, case):
         got = F.cluster_keys(raw, key_len=L, weights=weights, max_distance=1, method="directional", context=ctx)
         kt = ctx.kernel_times(reset=True)
         # which way in: the plain level-1 scatter runs only when the fused attempt was given up
-        fused_only = case not in ("foreign_byte", "crowded_part")
+        fused_only = case != "foreign_byte"
         assert kt["part_scatter_kernel<1>"][1] == (0 if fused_only else 1)
-        assert kt["pack_kernel"][1] == (2 if case == "many_n" and job == 0 else
-                                        1 if fused_only or (case == "crowded_part" and job == 1) else
-                                        3 if case == "foreign_byte" else 2)
+        # (crowded_part: the key with 40 000 copies fills a level-1 slab -- once more, and from then on, with the spill
+        # list. Until round 4 its 3 600 copies with an N then overfilled the side slabs of the few level-2 tiles they sat
+        # in and the fused way in was given up for the context; the pack kernel now takes keys with an N out itself, a
+        # workgroup's share into its own slab, and the attempt with the spill list goes through.)
+        assert kt["pack_kernel"][1] == (2 if case in ("many_n", "crowded_part") and job == 0 else
+                                        1 if fused_only else 3)
+        if case == "crowded_part":
+            assert got.route["fused_pack"] and got.route["spill_list"] and got.route["compact_records"], got.route
         # ... and which records: 12-byte ones unless pinned or given up
-        if fused_only:
+        if fused_only and case != "crowded_part":
             compact = case != "uint4_records" and not (case == "many_n" and job == 1)
             assert kt["part_scatter12_kernel"][1] == (1 if compact else 0)
             assert kt["part_scatter_kernel<2>"][1] == (0 if compact and case != "many_n" else 1)
