@@ -43,6 +43,12 @@ int set_geometry(fqd_ctx *c, uint32_t max_len, int ragged)
     if (kw > 14000)
         return fail(c, FQD_E_VALUE, "key of " + std::to_string(max_len) + " bases is too long for the LDS pack tile");
     c->shape.stride_words = (uint32_t)((kw + 3) & ~3ull);
+    // Records of 3 uint4 (keys of 65-128 nt over "ACGNT": 48 bytes) take a 64-byte stride: a record gather is then ONE
+    // 64-byte sector instead of 1.75 on average, and the record is a power-of-two number of uint4 -- the cooperative
+    // verification and the segment hashes inside the compaction apply (config 2: 10 M x 100 nt). 16 bytes more per
+    // read out of the pack kernel; records of 5-7 uint4 are left alone (up to 60 % more bytes for the same effect).
+    if (c->shape.stride_words == 12 && !getenv("FQD_NO_STRIDE_PADDING"))
+        c->shape.stride_words = 16;
     c->ks.planes = c->shape.planes;
     c->ks.words = c->shape.words;
     c->ks.stride = c->shape.stride_words;

@@ -257,7 +257,8 @@ def test_one_kernel_collapse_equals_the_two_kernels(F, oracle, monkeypatch, case
     monkeypatch.setenv("FQD_ONE_KERNEL_COLLAPSE", "1")
     n, L, d = 400_000, 32, 1
     rng = np.random.default_rng(23)
-    keys = synth_keys(n, L, 12, 231, sub_rate=3e-3, n_rate=0 if case == "two_planes" else 1e-3 if case == "n_keys" else 1e-4)
+    # (n_keys: 1 % of the keys with an N -- the side slabs hold 1.5 %; more and the job takes uint4 records)
+    keys = synth_keys(n, L, 12, 231, sub_rate=3e-3, n_rate=0 if case == "two_planes" else 3e-4 if case == "n_keys" else 1e-4)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     if case == "rows_over_150":
         monkeypatch.setenv("FQD_P0_MAX_ROWS", "150")
