@@ -472,6 +472,11 @@ class Context:
             lab.ctypes.data if labels else None, kp.ctypes.data if kept else None, HOST))
         return first, counts, lab, kp
 
+    def labels_into(self, labels):
+        """The component label (smallest row of its component) of every unique key (uint32) into a caller's buffer."""
+        lp, lm, _0 = _ptr_mem(labels)
+        self._ck(self._L.fqd_get_unique_table(self._h, None, None, lp, None, lm))
+
     def kept_flags_into(self, kept):
         """The dissection's verdict per unique key (uint8) into a caller's buffer."""
         kp, km, _0 = _ptr_mem(kept)

@@ -113,6 +113,7 @@ struct fqd_ctx {
     const uint32_t *gp_last_items = nullptr;   // the partitioned items of the last grouped pass
     uint32_t gp_crowded_bits = 0;      // != 0: the last grouped pass marked crowded buckets (2^bits buckets) and skipped them
     bool search_is_retry = false;       // find_edges calling itself after pass 0's pairs were lost: the route bits stay
+    bool search_force_sort = false;     // ... or after the crowded-bucket refinement gave up: that run takes the sort path
     bool search_keeps_edges = false;    // ... except the edge counter and the statistics: pass 0 of this search has run (fqd::Pass0)
     bool search_zero_pending = false;   // find_edges: the job counters and statistics are zeroed by the partition's first launch
     bool gp_slab_off = false;      // grouped search: same, for the (hash, uid) partition

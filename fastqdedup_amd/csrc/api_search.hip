@@ -465,7 +465,10 @@ static int grouped_refine(fqd_ctx *c, const uint32_t *seg_hashes, uint64_t U, ui
         return FQD_OK;
     const uint32_t pieces = fqd::group_fine_pieces();
     const uint64_t key_cap = std::min<uint64_t>(h[1], U);          // (every crowded item could be a key of its own)
-    if (key_cap * pieces >= 0xFFFFFF00ull) {
+    uint64_t fine_limit = 0xFFFFFF00ull;            // (positions in the fine-item arrays are 32-bit)
+    if (const char *e = getenv("FQD_GROUP_FINE_LIMIT"))      // tests: as if the crowded keys were too many
+        fine_limit = strtoull(e, nullptr, 10);
+    if (key_cap * pieces >= fine_limit) {
         *ok = false;
         return FQD_OK;
     }
@@ -545,7 +548,8 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
     // (zeroed by the first launch of the partitioned Hamming search when that is what runs: see search_zero_pending)
     const char *pin_path = getenv("FQD_EDGES");
     const bool grouped_first = !edit_general && U >= 2 && (max_distance > 0 || !c->collapsed) && n_shards == 1 &&
-                               U < 0xFFFFFF00ull && (pin_path ? !strcmp(pin_path, "grouped") : U >= 65536);
+                               U < 0xFFFFFF00ull && (pin_path ? !strcmp(pin_path, "grouped") : U >= 65536) &&
+                               !c->search_force_sort;
     c->search_zero_pending = false;
     // The routed collapse has done pass 0 of exactly this search (fqd::Pass0): its pairs are in the edge list, the
     // segment hashes it wrote start at segment 1, and the passes below start there too.
@@ -604,7 +608,8 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         // Grouping by partition (group.hip) unless a bucket shard was asked for or the table is small
         // (FQD_EDGES=sort|grouped pins the path for tests).
         const char *pin = getenv("FQD_EDGES");
-        bool grouped = n_shards == 1 && U < 0xFFFFFF00ull && (pin ? !strcmp(pin, "grouped") : U >= 65536);
+        bool grouped = n_shards == 1 && U < 0xFFFFFF00ull && (pin ? !strcmp(pin, "grouped") : U >= 65536) &&
+                       !c->search_force_sort;
         // Candidate pairs are listed before they are verified; a segment value shared by very many
         // keys (all of them pairwise candidates) would need a list beyond this budget: the search
         // then runs again on the sort path, which verifies in place and needs no list.
@@ -631,8 +636,24 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
                 if (c->gp_crowded_bits) {
                     bool refined = true;
                     FQD_TRY(grouped_refine(c, c->seg_hashes.as<uint32_t>(), U, nseg, &refined));
-                    if (!refined)
-                        return fail(c, FQD_E_RUNTIME, "too many keys in crowded buckets for the fine items");
+                    if (!refined) {
+                        // more crowded keys than the fine items can address: the whole search once more on the sort path,
+                        // which compares a crowded bucket's keys in place and needs no items at all (the reference's trie
+                        // takes any distribution, _triemodule.c:380-495: this must never be an error)
+                        if (getenv("FQD_DEBUG"))
+                            fprintf(stderr, "[fqd] crowded buckets: too many keys for the fine items; the search runs again on the sort path\n");
+                        c->route = (c->route & ~FQD_ROUTE_PASS0_CONTINUED) | FQD_ROUTE_SEARCH_RETRIED;
+                        c->search_keeps_edges = false;
+                        c->seg_hashes_nseg = 0;
+                        timer.stop();
+                        c->search_is_retry = true;
+                        c->search_force_sort = true;
+                        const int rc_again = find_edges_impl(c, max_distance, metric, shard, n_shards,
+                                                             pass0_held ? 0u : seg_lo, seg_hi, n_edges);
+                        c->search_force_sort = false;
+                        c->search_is_retry = false;
+                        return rc_again;
+                    }
                 }
             }
             for (uint32_t s = seg_lo; s < seg_hi && !(fuse_passes && grouped); s++) {

@@ -999,7 +999,9 @@ hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long l
     // config 2: 0.119 ms against 0.092 one thread per candidate -- most candidates there are no
     // neighbours and are out after one word; 128-byte records, config 5: 0.44 against 1.46 ms), and at
     // most 32 segments: the per-lane notes are a bit mask
-    const bool coop = sh.stride >= 16 && sh.stride <= 256 && !(sh.stride & 3u) && nseg <= 32 &&
+    // (records of ONE 64-byte sector -- keys of 65-128 nt, padded to a 64-byte stride since round 4 -- take the
+    // one-thread way again: 0.159 against 0.174 ms at config 2)
+    const bool coop = sh.stride >= 20 && sh.stride <= 256 && !(sh.stride & 3u) && nseg <= 32 &&
                       !getenv("FQD_VERIFY_NO_COOP");
 #define FQD_GP_CASE(KK)                                                                                              \
     case KK:                                                                                                         \

@@ -175,6 +175,14 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     const uint32_t span = (uint32_t)(b1 - a0);
     const uint32_t n_rows = (span + 2047u) / 2048u;
     uint32_t bad = 0;
+    // ragged keys: the block's key offsets (relative to a0) once into LDS -- the byte scratch of the LUT path, free
+    // under the SWAR conversion -- instead of two 8-byte global loads per (key, word) item of phase B: with 64 keys
+    // of 300 nt per block those loads were a dependent round trip in each of its three sweeps
+    uint32_t *s_koff = scratch;
+    const bool koff_lds = SWAR && !FUSED && offsets != nullptr && nk + 1 <= PACK_WAVES * 64;
+    if (koff_lds)
+        for (uint32_t t = tid; t <= nk; t += PACK_THREADS)
+            s_koff[t] = (uint32_t)(offsets[key0 + t] - a0);     // (visible behind the barrier that ends phase A)
 
     // ---- phase A: byte range -> K bit streams in LDS ------------------------
     // Bits of bytes outside [b0, b1) are never read by phase B; bytes past the END OF THE
@@ -310,7 +318,10 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     for (uint32_t item = tid; item < nk * W; item += PACK_THREADS) {
         const uint32_t k = item / W, w = item - k * W;
         uint64_t kb, ke;
-        if (offsets) {
+        if (koff_lds) {
+            kb = a0 + s_koff[k];
+            ke = a0 + s_koff[k + 1];
+        } else if (offsets) {
             kb = offsets[key0 + k];
             ke = offsets[key0 + k + 1];
         } else {
@@ -355,8 +366,9 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
                     const uint32_t at = atomicAdd(&s_rare_n[0], 1u);
                     if (at < PACK_RARE_CAP) {
                         s_rare[at] = v[e];
-                    } else {                              // (more of them than the parking space holds: one global atomic each)
-                        const uint32_t slab = blockIdx.x & (fs.side_slabs - 1);
+                    } else {                              // (more of them than the parking space holds: one global atomic each,
+                                                          //  spread over the slabs)
+                        const uint32_t slab = (blockIdx.x + fs.sub_rot + at) & (fs.side_slabs - 1);
                         const uint32_t pos = atomicAdd(&fs.side_cursor[slab], 1u);
                         if (pos < (slab + 1) * fs.side_cap)
                             fs.side_recs[pos] = v[e];
@@ -397,7 +409,8 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     }
     // ---- phase C: hash per key, then stream the tile out ---------------------
     for (uint32_t k = tid; k < nk; k += PACK_THREADS) {
-        const uint32_t len = offsets ? (uint32_t)(offsets[key0 + k + 1] - offsets[key0 + k]) : fixed_len;
+        const uint32_t len = koff_lds ? s_koff[k + 1] - s_koff[k]
+                                      : offsets ? (uint32_t)(offsets[key0 + k + 1] - offsets[key0 + k]) : fixed_len;
         hashes[key0 + k] = fqd_hash_record(tile + k * stride, W * K, len);
         if (lens)
             lens[key0 + k] = len;
@@ -415,9 +428,17 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
         __syncthreads();
         // the parked keys with an N: one reservation in this workgroup's side slab (their answer is used behind the next
         // barrier); what is left of the block is what the bins hold
+        // (two slabs per workgroup, half a table apart, the job-wide workgroup number deciding -- a job packed in
+        // pieces starts every launch at block 0, and a job of fewer workgroups than slabs must not leave half of
+        // them empty: 300 K reads with 3 % keys with an N overfilled the slabs of its 147 workgroups)
         const uint32_t n_rare = park ? s_rare_n[0] : 0u;
+        const uint32_t n_parked = min(n_rare, PACK_RARE_CAP), n_first = (n_parked + 1u) / 2u;
+        const uint32_t slab_a = (blockIdx.x + fs.sub_rot) & (fs.side_slabs - 1);
+        const uint32_t slab_b = (slab_a + fs.side_slabs / 2u) & (fs.side_slabs - 1);
         if (n_rare && tid == 0)
-            s_rare_n[1] = atomicAdd(&fs.side_cursor[blockIdx.x & (fs.side_slabs - 1)], min(n_rare, PACK_RARE_CAP));
+            s_rare_n[1] = atomicAdd(&fs.side_cursor[slab_a], n_first);
+        if (n_parked > n_first && tid == 1)
+            s_rare_n[2] = atomicAdd(&fs.side_cursor[slab_b], n_parked - n_first);
         n_block -= n_rare;
         // exclusive scan of the bin counts: n_bins <= 256, one bin per thread
         const uint32_t mine = tid < fs.n_bins ? s_hist[tid] : 0u;
@@ -457,9 +478,9 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
             s_base[tid] = base;
         }
         __syncthreads();
-        if (tid < min(n_rare, PACK_RARE_CAP)) {
-            const uint32_t slab = blockIdx.x & (fs.side_slabs - 1);
-            const uint32_t pos = s_rare_n[1] + tid;
+        if (tid < n_parked) {
+            const uint32_t slab = tid < n_first ? slab_a : slab_b;
+            const uint32_t pos = tid < n_first ? s_rare_n[1] + tid : s_rare_n[2] + (tid - n_first);
             if (pos < (slab + 1) * fs.side_cap)
                 fs.side_recs[pos] = s_rare[tid];
             else

@@ -237,6 +237,16 @@ class HipBackend:
 
     MAX_HOME_RANKS = 16
 
+    def local_labels(self, edges):
+        """Union-find over the rows of THIS rank's table and edges between them (row pairs): (label of every row -- the
+        smallest row of its component --, number of components)."""
+        nu = self.n_unique_local
+        self.ctx.import_edges(edges.contiguous(), edges.shape[0])
+        n_components = self.ctx.components()
+        labels = torch.empty(max(nu, 1), dtype=torch.int32, device=self.device)
+        self.ctx.labels_into(labels)
+        return labels[:nu], n_components
+
     def cluster_subgraph_home(self, edges, roots, n_nodes, n_parts, part, uid_bounds):
         """... with the clusters that live on this rank alone apart (fqd_cluster_subgraph_home): (touched nodes of
         this rank's share of the SPANNING clusters, their edges renumbered, the edges of its HOME clusters as rows of
@@ -255,7 +265,7 @@ class HipBackend:
         """The home clusters dissected on the table this rank holds, the rows dropped elsewhere dropped as well ->
         (ascending kept first-holder ids, count)."""
         self.ctx.import_edges(home_edges.contiguous(), home_edges.shape[0])
-        self.ctx.components()
+        self.home_components = self.ctx.components()      # (components of the table under the home edges)
         self.ctx.set_id_window(0, id_hi)
         try:
             self.ctx.dissect_except(method, dropped_rows.to(torch.int32).contiguous(), dropped_rows.shape[0])
@@ -726,76 +736,139 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
                 tick.mark("search-routed")
     mine = torch.cat(found, dim=0) if found else torch.empty((0, 2), dtype=torch.int32, device=dev)
 
-    # ---- 4. all edges everywhere (8 B each); label; take this rank's clusters ----------
-    g_edges = comm.all_gather_rows(mine).contiguous()
-    n_edges = int(g_edges.shape[0])
-    labels, n_clusters = backend.edge_labels(g_edges, n_unique)
-    # HOME clusters: a cluster all of whose keys one rank holds (every cluster of a one-rank job; at G ranks the
-    # clusters whose pairs all agree on segment 0) is dissected by that rank on the table it holds -- no key is
-    # fetched, no verdict sent back. The other clusters ("spanning") are dealt out by root as before.
-    home_edges, any_spanning = None, True
-    use_home = (hasattr(backend, "finish_owner_home") and world <= getattr(backend, "MAX_HOME_RANKS", 16)
-                and not os.environ.get("FQD_NO_HOME_CLUSTERS"))
-    if use_home and hasattr(backend, "cluster_subgraph_home"):
-        touched, sub_edges, home_edges, n_span = backend.cluster_subgraph_home(g_edges, labels, n_unique, world, rank,
-                                                                               uid_bounds)
-        any_spanning = n_span > 0        # (computed from the job-wide edge list: the same on every rank)
-    elif use_home:
-        inner = torch.tensor(uid_bounds[1:-1], dtype=torch.int64, device=g_edges.device)
-        owner = torch.bucketize(g_edges.to(torch.int64), inner, right=True)
-        cross = owner[:, 0] != owner[:, 1]
-        spanning = torch.isin(labels, torch.unique(labels[cross]))
-        any_spanning = bool(spanning.any())
-        home_edges = (g_edges[~spanning & (owner[:, 0] == rank)] - uid0).to(torch.int32)
-        my_edges = g_edges[spanning & ((labels % world) == rank)]
-        touched, inverse = torch.unique(my_edges.reshape(-1), return_inverse=True)     # ascending uids
-        sub_edges = inverse.reshape(-1, 2).to(torch.int32)
-        del my_edges
-    elif hasattr(backend, "cluster_subgraph"):
-        touched, sub_edges = backend.cluster_subgraph(g_edges, labels, n_unique, world, rank)
-    else:
-        my_edges = g_edges[(labels % world) == rank]
-        touched, inverse = torch.unique(my_edges.reshape(-1), return_inverse=True)     # ascending uids
-        sub_edges = inverse.reshape(-1, 2).to(torch.int32)
-        del my_edges
-    del g_edges, labels
-    if tick:
-        tick.mark("gather-edges+label")
-
-    # ---- 5. key data of my clusters from their owners; dissect; verdicts back ----------
-    # (no cluster spans ranks -- a one-rank job, or every pair agrees on segment 0: nothing to fetch or send back,
-    # and every rank knows)
-    if any_spanning:
-        ask_counts = _split_by_bounds(touched, uid_bounds)            # ascending uids are grouped by owner
-        asked_counts = comm.exchange_counts(ask_counts)
-        asked = comm.all_to_all_rows(touched, ask_counts, asked_counts)
-        a_recs, a_lens, a_counts = backend.gather_unique(asked - uid0)
-        t_recs = comm.all_to_all_rows(a_recs, asked_counts, ask_counts)
-        t_counts = comm.all_to_all_rows(a_counts, asked_counts, ask_counts)
-        t_lens = comm.all_to_all_rows(a_lens, asked_counts, ask_counts) if g_ragged else None
-        del a_recs, a_lens, a_counts, asked
+    # ---- 4. every edge to the owner of its ends; union-find at home; labels across ranks --------------
+    # No rank ever holds the job's edge list, and no rank runs a union-find over the job's keys (rounds 1-3 all-gathered
+    # every edge and labelled all U keys on EVERY rank: per-rank work that grew with the number of ranks -- 600 MB and
+    # ~75 M edges per rank at 8 x 25 M reads of 300 nt). Per rank and step now: its own share of the edges.
+    #   4a  an edge (u, v) goes to the owner of u (uids are contiguous per rank); there it is a HOME edge (v is its
+    #       own as well) or a CROSS edge
+    #   4b  union-find over the rank's own rows and home edges: local components, named by their smallest row
+    #   4c  a cross edge becomes an edge between LOCAL COMPONENTS: u -> its component at home, then on to the owner of v,
+    #       v -> its component there; both owners keep a copy (mine, theirs)
+    #   4d  the smallest uid of a cluster reaches all of its local components by min-label rounds over those copies
+    #       (a message per cross edge and round, until no label moves anywhere: clusters are a handful of keys, the
+    #       rounds as many as a cluster has ranks in a row)
+    #   4e  clusters = local components whose label is their own uid, summed over the ranks
+    n_edges = int(comm.all_gather_ints([int(mine.shape[0])])[:, 0].sum())
+    no_home = bool(os.environ.get("FQD_NO_HOME_CLUSTERS"))
+    dev_t = mine.device
+    if comm.alone and not no_home:
+        # one rank: every edge is a home edge, every cluster a home cluster
+        home_edges = mine
+        dropped_here = torch.empty(0, dtype=torch.int64, device=dev_t)
+        kept_owned, n_kept_owned = backend.finish_owner_home(home_edges, method_id, dropped_here, max(n_total, 1))
+        n_clusters = int(backend.home_components)
         if tick:
-            tick.mark("fetch-cluster-keys")
-        verdict = backend.dissect_subgraph(t_recs, t_lens, t_counts, sub_edges, method_id)
-        dropped = touched[verdict == 0]
-        del t_recs, t_lens, t_counts, sub_edges
-        if tick:
-            tick.mark("dissect")
-        drop_counts = _split_by_bounds(dropped, uid_bounds)
-        dropped_counts = comm.exchange_counts(drop_counts)
-        dropped_here = comm.all_to_all_rows(dropped, drop_counts, dropped_counts)
-    else:
-        dropped_here = touched[:0]
-        del sub_edges
-        if tick:
-            for name in ("fetch-cluster-keys", "dissect"):
+            for name in ("gather-edges+label", "fetch-cluster-keys", "dissect", "verdicts-home"):
                 tick.mark(name)
-    if home_edges is not None:
-        kept_owned, n_kept_owned = backend.finish_owner_home(home_edges, method_id, dropped_here - uid0, max(n_total, 1))
     else:
-        kept_owned, n_kept_owned = backend.finish_owner(dropped_here - uid0, max(n_total, 1))
-    if tick:
-        tick.mark("verdicts-home")
+        inner = torch.tensor(uid_bounds[1:-1], dtype=torch.int64, device=dev_t)
+
+        def owner_of(uids):
+            return torch.bucketize(uids.to(torch.int64), inner, right=True)
+
+        def to_owners(rows, dest):
+            """rows grouped by destination rank (stable) and moved: what this rank receives."""
+            order = torch.sort(dest, stable=True)[1]
+            counts = torch.bincount(dest, minlength=world).tolist()
+            got_counts = comm.exchange_counts(counts)
+            return comm.all_to_all_rows(rows[order].contiguous(), counts, got_counts)
+
+        # 4a
+        at_u = to_owners(mine.to(torch.int32), owner_of(mine[:, 0]))
+        v_owner = owner_of(at_u[:, 1])
+        is_home = v_owner == rank
+        home_local = (at_u[is_home] - uid0).to(torch.int32)
+        cross = at_u[~is_home]                                        # u is mine, v is not
+        cross_dest = v_owner[~is_home]
+        del at_u
+        # 4b
+        lab, _n_local = backend.local_labels(home_local)
+        lab = lab.to(torch.int64)
+        n_rows = int(lab.shape[0])
+        # 4c: (component of u at home as a uid, v) -> owner of v -> (component of u, component of v)
+        cu = lab[(cross[:, 0] - uid0).long()] + uid0
+        there = to_owners(torch.stack([cu.to(torch.int32), cross[:, 1]], dim=1), cross_dest)
+        cv = lab[(there[:, 1] - uid0).long()] + uid0                 # (there: [component elsewhere, v mine])
+        mine_theirs = torch.stack([cv, there[:, 0].to(torch.int64)], dim=1)
+        back = to_owners(torch.stack([there[:, 0], cv.to(torch.int32)], dim=1), owner_of(there[:, 0]))
+        pairs = torch.cat([mine_theirs, back.to(torch.int64)], dim=0)   # (my component, a component elsewhere) per cross edge end
+        del there, back, mine_theirs
+        touched = torch.zeros(max(n_rows, 1), dtype=torch.bool, device=dev_t)
+        touched[(pairs[:, 0] - uid0).long()] = True
+        if no_home:                    # (tests: every cluster with an edge is dealt out, none dissected in place)
+            touched[lab[home_local.reshape(-1).long()]] = True
+        # 4d
+        label = torch.arange(n_rows, dtype=torch.int64, device=dev_t) + uid0     # (of component roots; other rows unused)
+        pair_dest = owner_of(pairs[:, 1])
+        pair_order = torch.sort(pair_dest, stable=True)[1]
+        pair_counts = torch.bincount(pair_dest, minlength=world).tolist()
+        pair_got = comm.exchange_counts(pair_counts)
+        theirs_sorted = pairs[pair_order, 1]
+        mine_sorted = (pairs[pair_order, 0] - uid0).long()
+        while True:
+            msg = torch.stack([theirs_sorted, label[mine_sorted]], dim=1)         # (their component, my label)
+            got = comm.all_to_all_rows(msg, pair_counts, pair_got)
+            before = label.clone()
+            if got.shape[0]:
+                label.scatter_reduce_(0, (got[:, 0] - uid0).long(), got[:, 1], reduce="amin", include_self=True)
+            if not comm.any_flag(bool((label != before).any())):
+                break
+        del before
+        # 4e
+        is_root = lab == torch.arange(n_rows, dtype=torch.int64, device=dev_t)
+        mine_clusters = int((is_root & (label == torch.arange(n_rows, dtype=torch.int64, device=dev_t) + uid0)).sum())
+        n_clusters = int(comm.all_gather_ints([mine_clusters])[:, 0].sum())
+        if tick:
+            tick.mark("gather-edges+label")
+
+        # ---- 5. clusters with keys on several ranks: keys and edges to the cluster's host; dissect; verdicts back ----
+        # host = label mod ranks. Every rank PUSHES what it holds of such clusters (rows and edges; no request, no
+        # list of clusters anywhere); clusters that live on one rank (no cross edge) are dissected there, in place.
+        row_label = label[lab]                                          # every row's cluster
+        row_spans = touched[lab]
+        span_rows = torch.nonzero(row_spans).reshape(-1)               # ascending rows
+        any_spanning = comm.any_flag(bool(span_rows.shape[0]))
+        home_keep = ~row_spans[home_local[:, 0].long()] if home_local.shape[0] else torch.zeros(0, dtype=torch.bool, device=dev_t)
+        home_edges = home_local[home_keep]
+        if any_spanning:
+            row_host = (row_label[span_rows] % world)
+            a_recs, a_lens, a_counts = backend.gather_unique(span_rows.to(torch.int32))
+            order = torch.sort(row_host, stable=True)[1]
+            r_counts = torch.bincount(row_host, minlength=world).tolist()
+            r_got = comm.exchange_counts(r_counts)
+            t_uids = comm.all_to_all_rows((span_rows[order] + uid0).to(torch.int64), r_counts, r_got)
+            t_recs = comm.all_to_all_rows(a_recs[order], r_counts, r_got)
+            t_counts = comm.all_to_all_rows(a_counts[order], r_counts, r_got)
+            t_lens = comm.all_to_all_rows(a_lens[order], r_counts, r_got) if g_ragged else None
+            del a_recs, a_lens, a_counts
+            # the clusters' edges: home edges of spanning clusters and the cross edges (each held once, at the owner of u)
+            e_home = home_local[~home_keep].to(torch.int64) + uid0
+            e_all = torch.cat([e_home, cross.to(torch.int64)], dim=0)
+            e_host = row_label[(e_all[:, 0] - uid0).long()] % world
+            t_edges = to_owners(e_all, e_host)
+            if tick:
+                tick.mark("fetch-cluster-keys")
+            # rows by uid; the edges' ends become positions in that order
+            t_sorted, t_perm = torch.sort(t_uids)
+            sub_edges = torch.searchsorted(t_sorted, t_edges.reshape(-1)).reshape(-1, 2).to(torch.int32)
+            verdict = backend.dissect_subgraph(t_recs[t_perm].contiguous(), t_lens[t_perm].contiguous() if t_lens is not None else None,
+                                               t_counts[t_perm].contiguous(), sub_edges, method_id)
+            dropped = t_sorted[verdict == 0]
+            del t_recs, t_lens, t_counts, sub_edges, t_edges
+            if tick:
+                tick.mark("dissect")
+            drop_counts = _split_by_bounds(dropped, uid_bounds)
+            dropped_counts = comm.exchange_counts(drop_counts)
+            dropped_here = comm.all_to_all_rows(dropped, drop_counts, dropped_counts)
+        else:
+            dropped_here = torch.empty(0, dtype=torch.int64, device=dev_t)
+            if tick:
+                for name in ("fetch-cluster-keys", "dissect"):
+                    tick.mark(name)
+        kept_owned, n_kept_owned = backend.finish_owner_home(home_edges, method_id, dropped_here - uid0, max(n_total, 1))
+        if tick:
+            tick.mark("verdicts-home")
 
     # ---- 6. kept ids to the rank that read them ------------------------------------------
     out_counts = _split_by_bounds(kept_owned, id_bounds)

@@ -244,6 +244,26 @@ def test_fused_pack_collapse_matches_oracle(F, oracle, monkeypatch, case):
             ctx.collapse()       # the packed reads were never written: needs fqd_pack_keys first
 
 
+def test_crowded_buckets_beyond_the_fine_items_take_the_sort_path(F, oracle, monkeypatch):
+    """A segment value shared by thousands of keys is matched on finer segments (group.hip "crowded buckets"); when the
+    crowded keys are more than the fine items can address the search must run again on the sort path -- never an error:
+    the reference's trie takes any distribution (`_triemodule.c:380-495`). FQD_GROUP_FINE_LIMIT makes "too many" small."""
+    from fastqdedup_amd.synth import SKEW, fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_FUSED_MIN_READS", "100000")
+    n, L = 300_000, 32
+    keys = synth_keys(n, L, 12, 171, sub_rate=3e-3, n_rate=1e-4, skew=SKEW)
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=1, method="directional")
+    ctx = F.Context(0)
+    got = F.cluster_keys(raw, key_len=L, max_distance=1, method="directional", context=ctx)      # (the context meets the skew)
+    assert got.route["search_refined"], got.route
+    monkeypatch.setenv("FQD_GROUP_FINE_LIMIT", "1000")
+    got = F.cluster_keys(raw, key_len=L, max_distance=1, method="directional", context=ctx)
+    assert not got.route["search_refined"] and got.route["search_sort"] and got.route["search_retried"], got.route
+    assert (got.n_unique, got.n_clusters, got.n_kept) == (want["n_unique"], want["n_clusters"], len(want["kept_read_ids"]))
+    assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+
+
 @pytest.mark.parametrize("case", ["plain", "n_keys", "two_planes", "rows_over_150", "probe_overflow", "edge_overflow",
                                   "no_patience", "small_grid"])
 def test_one_kernel_collapse_equals_the_two_kernels(F, oracle, monkeypatch, case):

@@ -136,6 +136,24 @@ class NumpyBackend:
                 hooks += 1
         return torch.tensor([find(u) for u, _ in edges.tolist()], dtype=torch.int32), n_nodes - hooks
 
+    def local_labels(self, edges):
+        """Union-find over this rank's table and edges between its rows: (smallest row of every row's component, components)."""
+        n = len(self.table)
+        parent = list(range(n))
+
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        hooks = 0
+        for u, v in edges.tolist():
+            ru, rv = find(u), find(v)
+            if ru != rv:
+                parent[max(ru, rv)] = min(ru, rv)
+                hooks += 1
+        return torch.tensor([find(i) for i in range(n)], dtype=torch.int32), n - hooks
+
     def gather_unique(self, rows):
         sel = rows.tolist()
         recs, lens = self._rows_of([self.table[i] for i in sel])
@@ -160,7 +178,7 @@ class NumpyBackend:
         self.keys = [k.decode("latin-1") for k in self.table]
         self.counts, self.first = list(self.table_counts), list(range(len(self.table)))
         self.d, self.edit = self.max_distance, False
-        kept_rows, _, _ = self.finish(home_edges, method, 0, len(self.table))
+        kept_rows, self.home_components, _ = self.finish(home_edges, method, 0, len(self.table))
         gone = set(dropped_rows.tolist())
         assert not (gone & set(home_edges.reshape(-1).tolist())), "a dropped key has an edge at home"
         kept = sorted(self.table_first[i] for i in kept_rows.tolist() if i not in gone)
