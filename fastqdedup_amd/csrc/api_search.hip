@@ -415,13 +415,14 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
     }
     c->gp_cand_cap = c->gp_cands.cap / 8;
     unsigned long long *ctr = c->d_ctr64.as<unsigned long long>();
-    // Distance 1, every pass in this one partition, exact bucket sizes (a context whose slabs have overflowed before:
+    // Distance 1 to 3, every pass in this one partition, exact bucket sizes (a context whose slabs have overflowed before:
     // data with crowded segment values): buckets of more than 1024 items are marked and SKIPPED here -- all their keys
     // are pairwise candidates -- and grouped_refine() below matches those keys on finer segments.
     const uint8_t *skip = nullptr;
     c->gp_crowded_bits = 0;
     c->gp_last_items = items;
-    if (d == 1 && fused_U && s == 0 && nseg == 2 && !bucket_end && fused_U < (1u << 28) && !getenv("FQD_GROUP_NO_REFINE")) {
+    if (fqd::group_fine_items(d) && fused_U && s == 0 && nseg == d + 1 && !bucket_end &&
+        fused_U < (1u << fqd::group_fine_uid_bits()) && !getenv("FQD_GROUP_NO_REFINE")) {
         HIP_TRY(c, c->gp_crowded.reserve((size_t)n_buckets * 5 + 64));
         uint8_t *flags = c->gp_crowded.as<uint8_t>();
         uint32_t *list = reinterpret_cast<uint32_t *>(flags + (((size_t)n_buckets + 63) & ~(size_t)63));
@@ -451,6 +452,7 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
 // *ok = false: more crowded keys than the fine-item buffers hold -- the caller searches again the plain way.
 static int grouped_refine(fqd_ctx *c, const uint32_t *seg_hashes, uint64_t U, uint32_t nseg, bool *ok)
 {
+    const uint32_t d = nseg - 1;         // (the refinement runs behind a search whose d + 1 passes were all in one partition)
     *ok = true;
     const uint32_t B = c->gp_crowded_bits, n_buckets = 1u << B;
     c->gp_crowded_bits = 0;
@@ -463,7 +465,7 @@ static int grouped_refine(fqd_ctx *c, const uint32_t *seg_hashes, uint64_t U, ui
     HIP_TRY(c, stream_wait(c->st));
     if (!h[0])
         return FQD_OK;
-    const uint32_t pieces = fqd::group_fine_pieces();
+    const uint32_t pieces = fqd::group_fine_items(d);      // fine items per crowded key
     const uint64_t key_cap = std::min<uint64_t>(h[1], U);          // (every crowded item could be a key of its own)
     uint64_t fine_limit = 0xFFFFFF00ull;            // (positions in the fine-item arrays are 32-bit)
     if (const char *e = getenv("FQD_GROUP_FINE_LIMIT"))      // tests: as if the crowded keys were too many
@@ -480,7 +482,7 @@ static int grouped_refine(fqd_ctx *c, const uint32_t *seg_hashes, uint64_t U, ui
     HIP_TRY(c, fqd::launch_group_refine_items(items, c->ld_start.as<uint32_t>(), nullptr, list, counts, (uint32_t)U,
                                               c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, c->gp_seen.as<uint32_t>(),
                                               c->gp_fine_hash.as<uint32_t>(), c->gp_fine_val.as<uint32_t>(), counts + 2,
-                                              key_cap, c->st));
+                                              key_cap, c->st, d));
     HIP_TRY(c, hipMemcpyAsync(h, counts, 24, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(c, stream_wait(c->st));
     const uint64_t n_keys = std::min<uint64_t>(h[2], key_cap), N = n_keys * pieces;
@@ -503,7 +505,7 @@ static int grouped_refine(fqd_ctx *c, const uint32_t *seg_hashes, uint64_t U, ui
     HIP_TRY(c, fqd::launch_group_verify_refined(c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap, c->urecs.as<uint32_t>(),
                                                 c->ulens.as<uint32_t>(), sh, nseg, seg_hashes, U, B, flags,
                                                 c->edges.as<uint32_t>(), ctr + C64_EDGES, c->edge_cap, ctr + C64_CAND_NEED,
-                                                c->st));
+                                                c->st, d));
     return FQD_OK;
 }
 

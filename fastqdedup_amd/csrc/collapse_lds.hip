@@ -1067,16 +1067,46 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
     unsigned long long reported = 0;
     if (p0.mask && lane == 0)
         s_pn[wave] = 0;
-  for (uint32_t b = wave_global; b < n_buckets + side_waves; b += waves_total) {
-    // group_total != NULL: no scan of the bucket counts has run -- the wave adds up the totals of the groups of 256
-    // buckets before its own and the counts of the buckets before it inside its group (2 KB of L2-resident words)
-    uint32_t g_begin = 0, g_all = 0, g_cnt = 0;
+    // (group_total != NULL) the job's unique keys and, per lane, the totals of up to 256 groups: once per wave, not once
+    // per bucket -- and a bucket's row count and slab start are requested one bucket AHEAD, so that its rows can be
+    // requested at the top of its turn instead of behind a round trip for the count
+    const uint32_t n_groups = max(n_buckets >> 8, 1u);
+    uint32_t g_all = 0, gt[4] = {0, 0, 0, 0};
     if (group_total) {
-        const uint32_t n_groups = max(n_buckets >> 8, 1u), my_group = min(b, n_buckets - 1) >> 8;
         for (uint32_t g0 = 0; g0 < n_groups; g0 += 64) {
             const uint32_t g = g0 + lane, t = g < n_groups ? group_total[g] : 0u;
             g_all += t;
-            g_begin += g < my_group ? t : 0u;
+            if (g0 < 256)
+                gt[g0 >> 6] = t;
+        }
+        for (int o = 32; o; o >>= 1)
+            g_all += __shfl_xor(g_all, o);
+    }
+    uint32_t nxt_cnt = 0, nxt_src = 0;
+    if (group_total && wave_global < n_buckets) {
+        nxt_cnt = bucket_unique[wave_global];
+        nxt_src = bucket_start[wave_global];
+    }
+  for (uint32_t b = wave_global; b < n_buckets + side_waves; b += waves_total) {
+    // group_total != NULL: no scan of the bucket counts has run -- the wave adds up the totals of the groups of 256
+    // buckets before its own and the counts of the buckets before it inside its group (2 KB of L2-resident words)
+    uint32_t g_begin = 0;
+    const uint32_t g_cnt = nxt_cnt, g_src = nxt_src;
+    if (group_total) {
+        const uint32_t my_group = min(b, n_buckets - 1) >> 8;
+        if (b + waves_total < n_buckets) {
+            nxt_cnt = bucket_unique[b + waves_total];
+            nxt_src = bucket_start[b + waves_total];
+        }
+        if (n_groups <= 256) {
+#pragma unroll
+            for (uint32_t c4 = 0; c4 < 4; c4++)
+                g_begin += c4 * 64 + lane < my_group ? gt[c4] : 0u;
+        } else {
+            for (uint32_t g0 = 0; g0 < n_groups; g0 += 64) {
+                const uint32_t g = g0 + lane;
+                g_begin += g < my_group ? group_total[g] : 0u;
+            }
         }
         if (b < n_buckets) {
 #pragma unroll
@@ -1084,11 +1114,6 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
                 const uint32_t x = (my_group << 8) + j0 + lane;
                 g_begin += x < b ? bucket_unique[x] : 0u;
             }
-            g_cnt = bucket_unique[b];
-        }
-        for (int o = 32; o; o >>= 1) {
-            g_begin += __shfl_xor(g_begin, o);
-            g_all += __shfl_xor(g_all, o);
         }
     }
     const uint32_t n_unique = side + (group_total ? g_all : unique_incl[n_buckets - 1]);
@@ -1104,12 +1129,20 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
         }
         continue;
     }
-    const uint32_t begin = group_total ? g_begin : (b ? unique_incl[b - 1] : 0u);
-    const uint32_t cnt = group_total ? g_cnt : unique_incl[b] - begin;
-    const uint32_t src = bucket_start[b];
+    // (g_begin: still a per-lane share here -- added up BEHIND the row loads below, which need the count alone)
+    const uint32_t begin_part = group_total ? g_begin : (b ? unique_incl[b - 1] : 0u);
+    const uint32_t cnt = group_total ? g_cnt : unique_incl[b] - begin_part;
+    const uint32_t src = group_total ? g_src : bucket_start[b];
     const bool pass0 = PASS0 && p0.mask != 0 && cnt <= p0.max_rows && cnt > 0;
     if (p0.mask && cnt > p0.max_rows && lane == 0)
         atomicOr(p0.flag, 1u);                 // more rows than the wave's LDS holds: the search does pass 0 itself
+    // the bucket's first row: the lanes' shares added up (called behind the row loads: it needs their count alone)
+    uint32_t begin = begin_part;
+    auto sum_begin = [&]() {
+        if (group_total)
+            for (int o = 32; o; o >>= 1)
+                begin += __shfl_xor(begin, o);
+    };
     // one row -> the unique table (and the segment hashes of the search passes that follow)
     auto write_row = [&](const uint4 &row, uint32_t j) {
         uint32_t w[3];
@@ -1123,6 +1156,7 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
         ufirst[u] = read_ids.packed_bits ? read_ids.from_packed(row.w) : (uint64_t)row.w;
     };
     if (!pass0) {
+        sum_begin();
         for (uint32_t j0 = lane; j0 < cnt; j0 += 4 * 64) {
             uint4 row[4];
 #pragma unroll
@@ -1148,6 +1182,7 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
     uint4 my_probe_rec = make_uint4(0, 0, 0, 0);      // lane l < np: the record of probe l
     if (lane < np)
         my_probe_rec = urecs[my_probe];
+    sum_begin();
     const uint32_t sub_shift = 32u - p0.bucket_bits - 6u;
     s_poff[wave][lane] = 0;
     uint32_t sub_rank[RPL];                     // sub-bin << 16 | rank inside it
@@ -1179,9 +1214,10 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
             const uint32_t p = s_poff[wave][sub_rank[q] >> 16] + (sub_rank[q] & 0xFFFFu);
             s_pa[wave][p] = row[q].x;
             s_pb[wave][p] = row[q].y;
-            s_pj[wave][p] = (uint16_t)j;
+            s_pj[wave][p] = (uint16_t)(j | (sub_rank[q] >> 16) << 9);      // (row number < 512 | sub-bin: no second hash in the compare loop)
         }
     }
+    static_assert(P0_ROWS <= 512, "s_pj: nine bits of row number");
     // Pairs go to the wave's LDS buffer; a full buffer is written out by the lanes that are active (converged) at the
     // call. Pairs behind the edge list's end are counted, not written: the search sees the count and starts over.
     auto write_out = [&](uint32_t have, uint32_t n, uint32_t rank, int leader) {
@@ -1210,12 +1246,12 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
     const uint32_t uid0 = side + begin;
     // every row against the rows behind it in its sub-bin: same segment 0, at most d mismatches elsewhere
     for (uint32_t i = lane; i < cnt; i += 64) {
-        const uint32_t ai = s_pa[wave][i], bi = s_pb[wave][i];
-        const uint32_t end = s_poff[wave][((fqd::fqd_route_hash(ai, bi, p0.mask) >> sub_shift) & 63u) + 1];
+        const uint32_t ai = s_pa[wave][i], bi = s_pb[wave][i], ji = s_pj[wave][i];
+        const uint32_t end = s_poff[wave][(ji >> 9) + 1];
         for (uint32_t k = i + 1; k < end; k++) {
             const uint32_t x = (ai ^ s_pa[wave][k]) | (bi ^ s_pb[wave][k]);     // mismatching positions
             if (!(x & p0.mask) && (uint32_t)__popc(x) <= p0.d)
-                note(uid0 + s_pj[wave][i], uid0 + s_pj[wave][k]);
+                note(uid0 + (ji & 511u), uid0 + (s_pj[wave][k] & 511u));
         }
     }
     // the keys with an N that were routed here: against every row, and against each other
@@ -1227,7 +1263,7 @@ __global__ __launch_bounds__(256) void bucket_compact12_kernel(
             rec12_planes(squeeze, s_pa[wave][i], s_pb[wave][i], w);
             const uint32_t x = (pr.x ^ w[0]) | (pr.y ^ w[1]) | (pr.z ^ w[2]);
             if (!(x & p0.mask) && (uint32_t)__popc(x) <= p0.d)
-                note(sp, uid0 + s_pj[wave][i]);
+                note(sp, uid0 + (s_pj[wave][i] & 511u));
         }
         if (lane > p && lane < np) {            // (lane l holds probe l)
             const uint32_t x = (pr.x ^ my_probe_rec.x) | (pr.y ^ my_probe_rec.y) | (pr.z ^ my_probe_rec.z);

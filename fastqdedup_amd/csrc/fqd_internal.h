@@ -568,9 +568,11 @@ hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *buck
                                      unsigned long long *cand_count, uint64_t cand_cap, hipStream_t st,
                                      uint32_t require_any = 0 /* list only pairs with one of these bits in a value */,
                                      const uint8_t *skip = nullptr /* skip[b] != 0: bucket b is left out */);
-// crowded buckets of a distance-1 search (group.hip "crowded buckets"): marked, skipped by the candidate kernel, their
-// keys matched on finer segments
-uint32_t group_fine_pieces();
+// crowded buckets of a search at distance d <= 3 (group.hip "crowded buckets"): marked, skipped by the candidate kernel,
+// their keys matched on finer pieces. group_fine_items(d): items a crowded key files (0: no refinement at that distance);
+// uids must fit group_fine_uid_bits() bits
+uint32_t group_fine_items(uint32_t d);
+uint32_t group_fine_uid_bits();
 hipError_t launch_group_mark_crowded(const uint32_t *bucket_start, const uint32_t *bucket_end, uint32_t n_buckets,
                                      uint32_t limit, uint8_t *crowded, uint32_t *list, unsigned long long *counts,
                                      hipStream_t st);
@@ -578,12 +580,12 @@ hipError_t launch_group_refine_items(const uint32_t *items, const uint32_t *buck
                                      const uint32_t *list, const unsigned long long *counts, uint32_t fused_U,
                                      const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t *seen,
                                      uint32_t *out_hash, uint32_t *out_val, unsigned long long *n_keys, uint64_t key_cap,
-                                     hipStream_t st);
+                                     hipStream_t st, uint32_t d);
 hipError_t launch_group_verify_refined(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
                                        const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t nseg,
                                        const uint32_t *seg_hashes, uint64_t U, uint32_t bucket_bits,
                                        const uint8_t *crowded, uint32_t *edges, unsigned long long *edge_count,
-                                       uint64_t edge_cap, unsigned long long *cand_need, hipStream_t st);
+                                       uint64_t edge_cap, unsigned long long *cand_need, hipStream_t st, uint32_t d);
 hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
                                     const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d, uint32_t seg,
                                     uint32_t nseg, uint32_t *edges, unsigned long long *edge_count, uint64_t edge_cap,

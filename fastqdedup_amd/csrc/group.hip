@@ -711,12 +711,31 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
 
 // ---- crowded buckets: a segment value shared by thousands of keys (low-complexity sequence, a constant prefix, a
 // family of keys that differ in a few positions) makes all of them pairwise candidates -- quadratic, and one wave's
-// work. For distance 1 such keys are matched on FINER segments instead: the key is cut into GP_FINE pieces, a key
-// files one item per piece j, hashed over the whole key with piece j masked out; two keys at distance exactly 1
-// differ inside one piece j* and meet in the items of j* only -- groups are as small as "keys equal outside one
-// piece", every pair is proposed once. The verification keeps a pair iff the FIRST main segment it agrees on falls
-// into a crowded bucket (else the main pass of that segment has reported it).
-constexpr uint32_t GP_FINE = 16;    // (8: the ladder of the skewed workload made groups of 256 keys, 16.7 M candidates, 3 ms of verification)
+// work. Such keys are matched on FINER pieces instead: the key is cut into k pieces, and a key files one item per
+// set M of d pieces, hashed over the whole key with the pieces of M masked out. Two keys within distance d differ
+// inside at most d pieces -- the set D -- and meet in the items of every M that contains D; the pair is reported under
+// ONE of them, the numerically smallest such M (D plus the lowest pieces outside it). Groups are as small as "keys
+// equal outside d pieces". d = 1: k = 16 pieces, 16 items per key (8 pieces made groups of 256 keys of the skewed
+// workload's ladder: 16.7 M candidates, 3 ms of verification); d = 2: k = 8, 28 items; d = 3: k = 8, 56 items.
+// The verification keeps a pair iff the FIRST main segment it agrees on falls into a crowded bucket (else the main
+// pass of that segment has reported it).
+constexpr uint32_t GP_FINE_MAX_D = 3, GP_FINE_MAX_SETS = 56, GP_FINE_SET_SHIFT = 26;      // (a set's index rides above 26 uid bits)
+__host__ __device__ constexpr uint32_t gp_fine_k(uint32_t d) { return d == 1 ? 16u : 8u; }
+__host__ __device__ constexpr uint32_t gp_fine_sets(uint32_t d) { return d == 1 ? 16u : d == 2 ? 28u : d == 3 ? 56u : 0u; }
+
+// the idx-th set of d pieces out of k, as a bit mask: sets in increasing numeric order of their masks
+__device__ __forceinline__ uint32_t gp_fine_set(uint32_t d, uint32_t idx)
+{
+    const uint32_t k = gp_fine_k(d);
+    uint32_t seen = 0;
+    for (uint32_t m = 1; m < (1u << k); m++)
+        if ((uint32_t)__popc(m) == d) {
+            if (seen == idx)
+                return m;
+            seen++;
+        }
+    return 0;
+}
 
 __global__ void gp_mark_crowded_kernel(const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ bucket_end,
                                        uint32_t n_buckets, uint32_t limit, uint8_t *__restrict__ crowded,
@@ -737,27 +756,35 @@ __global__ void gp_mark_crowded_kernel(const uint32_t *__restrict__ bucket_start
     }
 }
 
-// the hash of a key with piece j of GP_FINE masked out
+// the hash of a key with the pieces of `set` (bits over k pieces) masked out
 __device__ __forceinline__ uint32_t gp_fine_hash(const uint32_t *__restrict__ rec, uint32_t K, uint32_t W, uint32_t len,
-                                                 uint32_t j)
+                                                 uint32_t set, uint32_t k)
 {
-    const uint32_t lo = len * j / GP_FINE, hi = len * (j + 1) / GP_FINE;
     uint32_t part = 0;
     for (uint32_t w = 0; w < W; w++) {
-        const uint32_t keep = ~fqd_range_mask(w, lo, hi);
-        for (uint32_t k = 0; k < K; k++)
-            part += fqd_mix32((rec[w * K + k] & keep) + (w * K + k + 1u) * 0x9E3779B1u);
+        uint32_t gone = 0;
+        for (uint32_t j = 0; j < k; j++)
+            if (set >> j & 1u)
+                gone |= fqd_range_mask(w, len * j / k, len * (j + 1) / k);
+        for (uint32_t kk = 0; kk < K; kk++)
+            part += fqd_mix32((rec[w * K + kk] & ~gone) + (w * K + kk + 1u) * 0x9E3779B1u);
     }
-    return fqd_mix32(part + fqd_mix32(len * 0x9E3779B1u + j * 0x85EBCA77u + 0x27D4EB2Fu));
+    return fqd_mix32(part + fqd_mix32(len * 0x9E3779B1u + set * 0x85EBCA77u + 0x27D4EB2Fu));
 }
 
-// every key with an item in a crowded bucket files its GP_FINE fine items (once: seen[uid])
+// every key with an item in a crowded bucket files its fine items (once: seen[uid])
 __global__ __launch_bounds__(256) void gp_refine_items_kernel(
     const uint2 *__restrict__ items, const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ bucket_end,
     const uint32_t *__restrict__ list, const unsigned long long *__restrict__ counts, uint32_t fused_U,
     const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t *__restrict__ seen,
-    uint32_t *__restrict__ out_hash, uint32_t *__restrict__ out_val, unsigned long long *__restrict__ n_keys, uint64_t key_cap)
+    uint32_t *__restrict__ out_hash, uint32_t *__restrict__ out_val, unsigned long long *__restrict__ n_keys, uint64_t key_cap,
+    uint32_t d)
 {
+    __shared__ uint32_t s_set[GP_FINE_MAX_SETS];
+    const uint32_t n_sets = gp_fine_sets(d), k = gp_fine_k(d);
+    if (threadIdx.x < n_sets)
+        s_set[threadIdx.x] = gp_fine_set(d, threadIdx.x);
+    __syncthreads();
     // (every workgroup walks the whole list and takes its share of each bucket's items: there may be ONE crowded
     // bucket with a hundred thousand items)
     const uint32_t n_list = (uint32_t)counts[0];
@@ -771,15 +798,15 @@ __global__ __launch_bounds__(256) void gp_refine_items_kernel(
             if (fused_U)
                 uid %= fused_U;
             if (atomicOr(&seen[uid >> 5], 1u << (uid & 31u)) & (1u << (uid & 31u)))
-                continue;                              // (a key crowded in both passes files its items once)
+                continue;                              // (a key crowded in several passes files its items once)
             const unsigned long long at = atomicAdd(n_keys, 1ull);
             if (at >= key_cap)
                 continue;
             const uint32_t *rec = urecs + (uint64_t)uid * sh.stride;
             const uint32_t len = fqd_key_len(sh, ulens, uid);
-            for (uint32_t j = 0; j < GP_FINE; j++) {
-                out_hash[at * GP_FINE + j] = gp_fine_hash(rec, sh.planes, sh.words, len, j);
-                out_val[at * GP_FINE + j] = uid | (j << 28);
+            for (uint32_t j = 0; j < n_sets; j++) {
+                out_hash[at * n_sets + j] = gp_fine_hash(rec, sh.planes, sh.words, len, s_set[j], k);
+                out_val[at * n_sets + j] = uid | (j << GP_FINE_SET_SHIFT);
             }
         }
     }
@@ -791,7 +818,7 @@ __global__ __launch_bounds__(256) void gp_verify_refined_kernel(
     const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t nseg,
     const uint32_t *__restrict__ seg_hashes /* [nseg][U] */, uint64_t U, uint32_t bucket_bits,
     const uint8_t *__restrict__ crowded, uint32_t *__restrict__ edges, unsigned long long *__restrict__ edge_count,
-    uint64_t edge_cap, unsigned long long *__restrict__ cand_need)
+    uint64_t edge_cap, unsigned long long *__restrict__ cand_need, uint32_t d)
 {
     const uint32_t list = blockIdx.x % GP_LISTS, part = blockIdx.x / GP_LISTS, parts = gridDim.x / GP_LISTS;
     const unsigned long long filled = cand_count[(size_t)list * 8];
@@ -805,9 +832,14 @@ __global__ __launch_bounds__(256) void gp_verify_refined_kernel(
     // addition per hit -- which the compiler turns into one per wave and sweep -- queued 31 000 additions on one address
     // for the ladder of the skewed workload: 0.38 ms for 2 M candidates).
     constexpr uint32_t VR = 4;
+    constexpr uint32_t UID_MASK = (1u << GP_FINE_SET_SHIFT) - 1u;
     __shared__ uint2 s_edge[256 * VR];
     __shared__ uint32_t s_n;
     __shared__ unsigned long long s_at;
+    __shared__ uint32_t s_set[GP_FINE_MAX_SETS];
+    const uint32_t k = gp_fine_k(d);
+    if (threadIdx.x < gp_fine_sets(d))
+        s_set[threadIdx.x] = gp_fine_set(d, threadIdx.x);
     for (unsigned long long base = (unsigned long long)part * blockDim.x * VR; base < total;
          base += (unsigned long long)parts * blockDim.x * VR) {
         if (threadIdx.x == 0)
@@ -824,43 +856,70 @@ __global__ __launch_bounds__(256) void gp_verify_refined_kernel(
         uint32_t dw0[VR];
 #pragma unroll
         for (uint32_t t = 0; t < VR; t++) {
-            const uint32_t ua = pr[t].x & 0x0FFFFFFFu, ub = pr[t].y & 0x0FFFFFFFu;
+            const uint32_t ua = pr[t].x & UID_MASK, ub = pr[t].y & UID_MASK;
             const uint32_t *ra = urecs + (uint64_t)ua * sh.stride, *rb = urecs + (uint64_t)ub * sh.stride;
             uint32_t dw = 0;
-            for (uint32_t k = 0; k < sh.planes; k++)
-                dw |= ra[k] ^ rb[k];
+            for (uint32_t kk = 0; kk < sh.planes; kk++)
+                dw |= ra[kk] ^ rb[kk];
             dw0[t] = dw;
         }
 #pragma unroll
         for (uint32_t t = 0; t < VR; t++) {
-            const uint32_t ja = pr[t].x >> 28, jb = pr[t].y >> 28, ua = pr[t].x & 0x0FFFFFFFu, ub = pr[t].y & 0x0FFFFFFFu;
+            const uint32_t ja = pr[t].x >> GP_FINE_SET_SHIFT, jb = pr[t].y >> GP_FINE_SET_SHIFT;
+            const uint32_t ua = pr[t].x & UID_MASK, ub = pr[t].y & UID_MASK;
             if (!live[t] || ja != jb || ua == ub)
                 continue;
             const uint32_t len = fqd_key_len(sh, ulens, ua);
             if (fqd_key_len(sh, ulens, ub) != len)
                 continue;
             const uint32_t *ra = urecs + (uint64_t)ua * sh.stride, *rb = urecs + (uint64_t)ub * sh.stride;
-            uint32_t dist = __popc(dw0[t]), pos = dw0[t] ? (uint32_t)(__ffs((int)dw0[t]) - 1) : 0u;
-            for (uint32_t w = 1; w < sh.words && dist <= 1; w++) {
-                uint32_t dw = 0;
-                for (uint32_t k = 0; k < sh.planes; k++)
-                    dw |= ra[w * sh.planes + k] ^ rb[w * sh.planes + k];
-                if (dw) {
-                    dist += __popc(dw);
-                    pos = w * 32u + (uint32_t)(__ffs((int)dw) - 1);
+            // the mismatching positions (at most d, else out): their pieces, and the main segments they fall into
+            uint32_t dist = 0, pieces = 0, seg_mis = 0;
+            for (uint32_t w = 0; w < sh.words && dist <= d; w++) {
+                uint32_t dw = dw0[t];
+                if (w) {
+                    dw = 0;
+                    for (uint32_t kk = 0; kk < sh.planes; kk++)
+                        dw |= ra[w * sh.planes + kk] ^ rb[w * sh.planes + kk];
+                }
+                dist += __popc(dw);
+                while (dw && dist <= d) {
+                    const uint32_t pos = w * 32u + (uint32_t)(__ffs((int)dw) - 1);
+                    dw &= dw - 1u;
+                    uint32_t j = (uint32_t)((uint64_t)pos * k / len);         // the piece [len j / k, len (j + 1) / k) of pos
+                    while (j && pos < len * j / k)
+                        j--;
+                    while (j + 1 < k && pos >= len * (j + 1) / k)
+                        j++;
+                    pieces |= 1u << j;
+                    for (uint32_t s2 = 0; s2 < nseg; s2++) {
+                        uint32_t slo, shi;
+                        fqd_segment(len, s2, nseg, slo, shi);
+                        if (pos >= slo && pos < shi)
+                            seg_mis |= 1u << s2;
+                    }
                 }
             }
-            if (dist != 1)
+            if (dist == 0 || dist > d)
                 continue;
-            // the one differing position must lie in the piece both items left out (else: a hash collision)
-            if (!(pos >= len * ja / GP_FINE && pos < len * (ja + 1) / GP_FINE))
+            // the set both items left out must be THE set of this pair: its pieces and the lowest others (else the
+            // pair is reported under another set, or the hashes collided)
+            const uint32_t set = s_set[ja];
+            if (pieces & ~set)
                 continue;
-            // the first main segment the pair agrees on: segment 0 unless the difference lies there
-            uint32_t slo, shi;
-            fqd_segment(len, 0, nseg, slo, shi);
-            const uint32_t first = (pos >= slo && pos < shi) ? 1u : 0u;
+            uint32_t want = pieces, others = ~pieces & ((1u << k) - 1u);
+            for (uint32_t need = d - (uint32_t)__popc(pieces); need; need--) {
+                want |= others & (0u - others);
+                others &= others - 1u;
+            }
+            if (want != set)
+                continue;
+            // the first main segment the pair agrees on (an empty segment agrees trivially)
+            uint32_t first = 0;
+            while (first < nseg && (seg_mis >> first & 1u))
+                first++;
             if (first >= nseg)
-                continue;                                  // (nseg == 1: no segment agrees)
+                continue;                                  // (no segment agrees: cannot be within d of d + 1 segments)
             if (!crowded[seg_hashes[(size_t)first * U + ua] >> (32u - bucket_bits)])
                 continue;                                  // the main pass of that segment has it
             s_edge[atomicAdd(&s_n, 1u)] = make_uint2(min(ua, ub), max(ua, ub));
@@ -1029,7 +1088,8 @@ hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long l
     return hipGetLastError();
 }
 
-uint32_t group_fine_pieces() { return GP_FINE; }
+uint32_t group_fine_items(uint32_t d) { return gp_fine_sets(d); }       // fine items a crowded key files (0: no refinement at d)
+uint32_t group_fine_uid_bits() { return GP_FINE_SET_SHIFT; }
 
 hipError_t launch_group_mark_crowded(const uint32_t *bucket_start, const uint32_t *bucket_end, uint32_t n_buckets,
                                      uint32_t limit, uint8_t *crowded, uint32_t *list, unsigned long long *counts,
@@ -1044,11 +1104,13 @@ hipError_t launch_group_refine_items(const uint32_t *items, const uint32_t *buck
                                      const uint32_t *list, const unsigned long long *counts, uint32_t fused_U,
                                      const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t *seen,
                                      uint32_t *out_hash, uint32_t *out_val, unsigned long long *n_keys, uint64_t key_cap,
-                                     hipStream_t st)
+                                     hipStream_t st, uint32_t d)
 {
+    if (!gp_fine_sets(d))
+        return hipErrorInvalidValue;
     gp_refine_items_kernel<<<1024, 256, 0, st>>>(reinterpret_cast<const uint2 *>(items), bucket_start, bucket_end, list,
                                                  counts, fused_U, urecs, ulens, sh, seen, out_hash, out_val, n_keys,
-                                                 key_cap);
+                                                 key_cap, d);
     return hipGetLastError();
 }
 
@@ -1056,11 +1118,13 @@ hipError_t launch_group_verify_refined(const uint64_t *cands, const unsigned lon
                                        const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t nseg,
                                        const uint32_t *seg_hashes, uint64_t U, uint32_t bucket_bits,
                                        const uint8_t *crowded, uint32_t *edges, unsigned long long *edge_count,
-                                       uint64_t edge_cap, unsigned long long *cand_need, hipStream_t st)
+                                       uint64_t edge_cap, unsigned long long *cand_need, hipStream_t st, uint32_t d)
 {
+    if (!gp_fine_sets(d))
+        return hipErrorInvalidValue;
     gp_verify_refined_kernel<<<GP_LISTS * 16, 256, 0, st>>>(reinterpret_cast<const uint2 *>(cands), cand_count,
                                                             cand_cap / GP_LISTS, urecs, ulens, sh, nseg, seg_hashes, U,
-                                                            bucket_bits, crowded, edges, edge_count, edge_cap, cand_need);
+                                                            bucket_bits, crowded, edges, edge_count, edge_cap, cand_need, d);
     return hipGetLastError();
 }
 

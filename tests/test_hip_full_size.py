@@ -114,6 +114,35 @@ def test_skewed_workload_matches_oracle(oracle):
         assert np.array_equal(got2.kept_read_ids, want2["kept_read_ids"]), (method, d)
 
 
+def test_skewed_workload_at_distance_2_matches_oracle(oracle):
+    """The skewed model at Hamming d = 2 (BASELINE config 4's distance; 2 M reads of 32 nt): crowded segment values are
+    matched on finer pieces -- every set of 2 of 8 pieces masked out, a pair reported under the smallest set that holds
+    its differences (group.hip "crowded buckets") -- instead of pairwise on the sort path, which rounds 2-3 fell back to
+    from d = 2 on. Against the oracle's trie (`TrieNode_FindNearest`, `_triemodule.c:380-495`, takes any distribution);
+    the warm context must not sort."""
+    import torch
+    import fastqdedup_amd as F
+    from fastqdedup_amd.synth import SKEW
+    n, L, d = 2_000_000, 32, 2
+    ctx = F.Context(0)
+    dev = torch.empty(n * L, dtype=torch.uint8, device="cuda:0")
+    ctx.synth_keys(dev, n, 0, n, L, L, 1004, skew=SKEW)
+    host = dev.cpu().numpy()
+    runs = {m: _OracleRun(oracle, host, n, L, d, m) for m in ("directional", "adjacency")}
+    first = F.cluster_keys(dev, key_len=L, max_distance=d, method="directional", context=ctx)
+    warm = F.cluster_keys(dev, key_len=L, max_distance=d, method="directional", context=ctx)
+    want = runs["directional"].result()
+    for got in (first, warm):
+        assert (got.n_unique, got.n_clusters) == (want["n_unique"], want["n_clusters"])
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+    assert warm.route["search_grouped"] and warm.route["search_refined"] and not warm.route["search_sort"], warm.route
+    want2 = runs["adjacency"].result()
+    got2 = F.cluster_keys(dev, key_len=L, max_distance=d, method="adjacency", context=ctx)
+    assert (got2.n_unique, got2.n_clusters) == (want2["n_unique"], want2["n_clusters"])
+    assert np.array_equal(got2.kept_read_ids, want2["kept_read_ids"])
+    assert not got2.route["search_sort"], got2.route
+
+
 def test_long_keys_match_oracle_at_5m(oracle):
     """The shapes of BASELINE.json's configs 4 and 5 at 5 M reads of 300 nt, the largest the oracle's trie answers in
     about two minutes (96 s and 58 s for the reference): Hamming d = 2 directional -- three
