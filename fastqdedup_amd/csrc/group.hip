@@ -716,25 +716,33 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
 // inside at most d pieces -- the set D -- and meet in the items of every M that contains D; the pair is reported under
 // ONE of them, the numerically smallest such M (D plus the lowest pieces outside it). Groups are as small as "keys
 // equal outside d pieces". d = 1: k = 16 pieces, 16 items per key (8 pieces made groups of 256 keys of the skewed
-// workload's ladder: 16.7 M candidates, 3 ms of verification); d = 2: k = 8, 28 items; d = 3: k = 8, 56 items.
+// workload's ladder: 16.7 M candidates, 3 ms of verification); d = 2: k = 16, 120 items; d = 3: k = 8, 56 items.
 // The verification keeps a pair iff the FIRST main segment it agrees on falls into a crowded bucket (else the main
 // pass of that segment has reported it).
-constexpr uint32_t GP_FINE_MAX_D = 3, GP_FINE_MAX_SETS = 56, GP_FINE_SET_SHIFT = 26;      // (a set's index rides above 26 uid bits)
-__host__ __device__ constexpr uint32_t gp_fine_k(uint32_t d) { return d == 1 ? 16u : 8u; }
-__host__ __device__ constexpr uint32_t gp_fine_sets(uint32_t d) { return d == 1 ? 16u : d == 2 ? 28u : d == 3 ? 56u : 0u; }
+// (d = 2 with 8 pieces of a 32-nt key: the skewed workload's ladder -- every value of the last eight bases -- is ONE
+// group under the set of its two pieces, 17 000 keys, 150 M candidates, and the search fell back to the sort path;
+// with 16 pieces its groups are 256 keys)
+constexpr uint32_t GP_FINE_MAX_D = 3, GP_FINE_MAX_SETS = 120, GP_FINE_SET_SHIFT = 25;      // (a set's index rides above 25 uid bits)
+__host__ __device__ constexpr uint32_t gp_fine_k(uint32_t d) { return d <= 2 ? 16u : 8u; }
+__host__ __device__ constexpr uint32_t gp_fine_sets(uint32_t d) { return d == 1 ? 16u : d == 2 ? 120u : d == 3 ? 56u : 0u; }
 
-// the idx-th set of d pieces out of k, as a bit mask: sets in increasing numeric order of their masks
+// the idx-th set of d pieces out of k, as a bit mask: sets in increasing numeric order of their masks (the combinatorial
+// number system: idx = C(c_d, d) + ... + C(c_1, 1), c_d > ... > c_1)
+__device__ __forceinline__ uint32_t gp_choose(uint32_t c, uint32_t t)
+{
+    return t == 1 ? c : t == 2 ? c * (c - 1u) / 2u : c * (c - 1u) * (c - 2u) / 6u;      // (c < t: 0 -- c - 1, c - 2 wrap only when a factor is 0)
+}
 __device__ __forceinline__ uint32_t gp_fine_set(uint32_t d, uint32_t idx)
 {
-    const uint32_t k = gp_fine_k(d);
-    uint32_t seen = 0;
-    for (uint32_t m = 1; m < (1u << k); m++)
-        if ((uint32_t)__popc(m) == d) {
-            if (seen == idx)
-                return m;
-            seen++;
-        }
-    return 0;
+    uint32_t set = 0;
+    for (uint32_t t = d; t >= 1; t--) {
+        uint32_t c = t - 1;                         // (C(t - 1, t) = 0 <= idx)
+        while (c + 1 < 32 && (c + 1 >= t ? gp_choose(c + 1, t) : 0u) <= idx)
+            c++;
+        idx -= c >= t ? gp_choose(c, t) : 0u;
+        set |= 1u << c;
+    }
+    return set;
 }
 
 __global__ void gp_mark_crowded_kernel(const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ bucket_end,

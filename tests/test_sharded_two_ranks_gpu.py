@@ -323,3 +323,45 @@ def test_eight_owners_geometry_in_one_process(routed, mostly_unique, monkeypatch
     seen[routed] = pass0_pairs
     if len(seen) == 2:
         assert seen[False] == seen[True] and len(seen[True]) > 1000
+
+
+def test_dense_owner_slabs_never_write_past_the_rows_they_were_given():
+    """fqd_dense_owner_slabs derives the fills from the cursors, not from the caller's count: rows behind the capacity
+    it was told must be dropped, never written (round 3's advisor: after a pack that gave up, cursors of whatever value
+    drove the copy past a 16-byte buffer). A canary behind a deliberately short buffer stays intact; with room for
+    every row the rows are the slabs' filled prefixes, back to back."""
+    import fastqdedup_amd as F
+    world, n, L, d = 2, 300_000, 32, 1
+    gpu = torch.device("cuda", 0)
+    ctx = F.Context(0)
+    dna = np.zeros(128, dtype=np.uint8)
+    dna[[ord(ch) for ch in "ACGNT"]] = 1
+    ctx.configure(dna, L, False)
+    geometry = F.Context.owner_slab_geometry(n, world)
+    hb, subs, cap = geometry
+    parts = world * hb * subs
+    keys = torch.empty(n * L, dtype=torch.uint8, device=gpu)
+    ctx.synth_keys(keys, n, 0, n, L, 12, 99)
+    slabs = torch.empty((parts * cap, 4), dtype=torch.int32, device=gpu)
+    cursors = torch.empty(parts, dtype=torch.int32, device=gpu)
+    counts = ctx.pack_to_owner_slabs(keys, L, world, d + 1, 0, geometry, slabs, cursors)
+    assert counts is not None and sum(counts) == n
+    fills = torch.empty(parts, dtype=torch.int32, device=gpu)
+    # room for every row: the filled prefixes, back to back
+    rows = torch.empty((n, 4), dtype=torch.int32, device=gpu)
+    ctx.dense_owner_slabs(slabs, cursors, world, geometry, rows, fills)
+    ctx.synchronize()
+    f = fills.cpu().numpy().astype(np.int64)
+    assert int(f.sum()) == n
+    starts = np.concatenate([[0], np.cumsum(f)])
+    sl = slabs.cpu().numpy().reshape(parts, cap, 4)
+    got = rows.cpu().numpy()
+    for p in (0, 1, parts // 2, parts - 1):
+        assert np.array_equal(got[starts[p]:starts[p + 1]], sl[p, :f[p]]), p
+    # room for a tenth: nothing behind it may change
+    short = n // 10
+    big = torch.full((n + 64, 4), 0x5A5A5A5A, dtype=torch.int32, device=gpu)
+    ctx.dense_owner_slabs(slabs, cursors, world, geometry, big[:short], fills)
+    ctx.synchronize()
+    assert bool((big[short:] == 0x5A5A5A5A).all()), "rows were written behind the capacity"
+    assert np.array_equal(big[:short].cpu().numpy(), got[:short])
