@@ -534,6 +534,40 @@ __global__ __launch_bounds__(256) void hash_records_kernel(const uint32_t *__res
     hashes[i] = fqd_hash_record(recs + i * sh.stride, sh.words * sh.planes, fqd_key_len(sh, lens, i));
 }
 
+// The same for records of several uint4 (reads received from other ranks have no hashes: fqd_import_packed): a
+// workgroup's HR_RECS records come in as one coalesced stream of uint4 into LDS rows one word longer than the record
+// (lanes then walk THEIR record without bank conflicts); a thread per record walking its 128 bytes in global memory
+// took 3.8 ms for 10 M records of 128 bytes -- 0.34 TB/s, the longest kernel of the one-rank plan on config 4's shape.
+constexpr uint32_t HR_RECS = 128;
+__global__ __launch_bounds__(256) void hash_records_staged_kernel(const uint32_t *__restrict__ recs,
+                                                                  const uint32_t *__restrict__ lens, uint64_t n,
+                                                                  KeyShape sh, uint32_t *__restrict__ hashes)
+{
+    extern __shared__ uint32_t s_rows[];                  // HR_RECS x (stride + 1) words
+    const uint64_t r0 = (uint64_t)blockIdx.x * HR_RECS;
+    const uint32_t nr = (uint32_t)min((uint64_t)HR_RECS, n - r0), q4 = sh.stride / 4u, row = sh.stride + 1u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(recs + r0 * sh.stride);
+    const uint32_t total = nr * q4;
+    for (uint32_t x0 = threadIdx.x; x0 < total; x0 += 4 * 256) {
+        uint4 v[4];
+#pragma unroll
+        for (uint32_t t = 0; t < 4; t++)                   // (clamped, unconditional: in flight together)
+            v[t] = src[min(x0 + t * 256, total - 1)];
+#pragma unroll
+        for (uint32_t t = 0; t < 4; t++) {
+            const uint32_t x = x0 + t * 256;
+            if (x < total) {
+                uint32_t *dst = s_rows + (x / q4) * row + (x % q4) * 4u;
+                dst[0] = v[t].x; dst[1] = v[t].y; dst[2] = v[t].z; dst[3] = v[t].w;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nr)
+        hashes[r0 + threadIdx.x] = fqd_hash_record(s_rows + threadIdx.x * row, sh.words * sh.planes,
+                                                   fqd_key_len(sh, lens, r0 + threadIdx.x));
+}
+
 }  // namespace
 
 namespace fqd {
@@ -746,7 +780,11 @@ hipError_t launch_hash_records(const uint32_t *recs, const uint32_t *lens, uint6
 {
     if (!n)
         return hipSuccess;
-    hash_records_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(recs, lens, n, sh, hashes);
+    const size_t lds = (size_t)HR_RECS * (sh.stride + 1) * 4;
+    if (sh.stride >= 8 && !(sh.stride & 3u) && lds <= 60 * 1024 && ((uintptr_t)recs & 15u) == 0)
+        hash_records_staged_kernel<<<(unsigned)((n + HR_RECS - 1) / HR_RECS), 256, lds, st>>>(recs, lens, n, sh, hashes);
+    else
+        hash_records_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(recs, lens, n, sh, hashes);
     return hipGetLastError();
 }
 
