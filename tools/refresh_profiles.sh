@@ -4,7 +4,7 @@
 # Steps are joined so that a failing GPU step ends the script (no further GPU work after a failure); every step
 # prints a line, so a long run never looks hung.
 set -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 PART=${2:-all}        # bench | prof | all (two gpurun calls of <= 20 min each: bench, then prof)
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
@@ -24,10 +24,19 @@ done
 python3 bench.py --workload config3_skew --no-pmc --steps 5 --warmup 2 > $OUT/${R}_bench_config3_skew.json 2> $OUT/bench_skew.err || exit 1
 echo "config3_skew done"
 python3 bench.py --force-sharded --no-pmc --no-cpu-baseline --no-host-input --warmup 8 > $OUT/${R}_bench_config3_sharded_world1.json 2> $OUT/bench_sharded.err || exit 1
+python3 bench.py --force-sharded --workload config4 --steps 10 --warmup 3 --no-pmc --no-cpu-baseline --no-host-input > $OUT/${R}_bench_config4_sharded_world1.json 2> $OUT/bench_sharded4.err || exit 1
 echo "sharded done"
+# the skewed model: adjacency, and at distance 2 beside the uniform job of that shape (no CPU baseline: the oracle's
+# quadratic dissection of the 65 536-key component takes minutes at d = 2)
+python3 bench.py --workload config3_skew_adj --no-pmc --steps 5 --warmup 2 --no-cpu-baseline --no-host-input > $OUT/${R}_bench_config3_skew_adj.json 2> $OUT/bench_skew_adj.err || exit 1
+python3 bench.py --workload config3_skew_d2 --no-pmc --steps 5 --warmup 2 --no-cpu-baseline --no-host-input > $OUT/${R}_bench_config3_skew_d2.json 2> $OUT/bench_skew_d2.err || exit 1
+python3 bench.py --workload config3_d2 --no-pmc --steps 5 --warmup 2 --no-cpu-baseline --no-host-input > $OUT/${R}_bench_config3_d2.json 2> $OUT/bench_d2.err || exit 1
+echo "skew variants done"
+hipcc --offload-arch=gfx950 -O3 -o /tmp/mb tools/microbench_patterns.hip 2> /dev/null && /tmp/mb > $OUT/${R}_microbench_patterns.json || exit 1
+echo "microbench done"
 fi
 [ "$PART" = "bench" ] && exit 0
-for w in config3 config2 config4 config3_skew; do
+for w in config3 config2 config4 config3_skew config3_skew_d2; do
     (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_$w -o r -- python3 $GRAFT_REPO_ROOT/bench.py --workload $w --steps 10 --no-cpu-baseline --no-host-input --no-pmc --no-copy-peak > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_$w.log 2>&1) || exit 1
     cp $OUT/prof_$w/r_kernel_stats.csv $OUT/${R}_kernel_stats_bench_$w.csv
     rm -rf $OUT/prof_$w
