@@ -244,6 +244,28 @@ def test_fused_pack_collapse_matches_oracle(F, oracle, monkeypatch, case):
             ctx.collapse()       # the packed reads were never written: needs fqd_pack_keys first
 
 
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_crowded_buckets_are_matched_on_finer_pieces(F, oracle, monkeypatch, d):
+    """Crowded segment values at distances 1, 2 and 3 (group.hip "crowded buckets": sets of d pieces masked out, a pair
+    reported under the smallest set that holds its differing pieces, and only if the first main segment it agrees on is
+    a crowded one): the skewed model at 300 K reads with the crowding limit lowered to 64 items, so that hundreds of
+    buckets take that way. Against the oracle's trie (`TrieNode_FindNearest`, `_triemodule.c:380-495`), two methods."""
+    from fastqdedup_amd.synth import SKEW, fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_GROUP_CROWDED_LIMIT", "64")
+    n, L = 300_000, 32
+    keys = synth_keys(n, L, 12, 900 + d, sub_rate=4e-3, n_rate=1e-4, skew=SKEW)
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    ctx = F.Context(0)
+    for method in ("directional", "adjacency"):
+        want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=d, method=method)
+        for job in range(2):        # (the first job meets the overfull slabs; from the second on: exact sizes, refinement)
+            got = F.cluster_keys(raw, key_len=L, max_distance=d, method=method, context=ctx)
+            assert (got.n_unique, got.n_clusters, got.n_kept) == (want["n_unique"], want["n_clusters"],
+                                                                  len(want["kept_read_ids"])), (d, method, job)
+            assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), (d, method, job)
+    assert got.route["search_refined"] and got.route["search_grouped"], got.route
+
+
 def test_crowded_buckets_beyond_the_fine_items_take_the_sort_path(F, oracle, monkeypatch):
     """A segment value shared by thousands of keys is matched on finer segments (group.hip "crowded buckets"); when the
     crowded keys are more than the fine items can address the search must run again on the sort path -- never an error:
