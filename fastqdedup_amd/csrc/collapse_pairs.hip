@@ -256,14 +256,25 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
             }
         }
     }
+    // (the positions of a step's records are requested a step AHEAD: a step was two dependent round trips -- positions,
+    // then the record gathers -- six to twelve steps per bucket)
+    uint32_t rep_next[CP];
+    auto request_reps = [&](uint32_t x0) {
+#pragma unroll
+        for (uint32_t t = 0; t < CP; t++) {
+            const uint32_t xc = min(x0 + t * 64, total ? total - 1 : 0u);
+            rep_next[t] = tmp_rep[src + (pow2 ? xc >> q_shift : xc / q_per_rec)];
+        }
+    };
+    if (total)
+        request_reps(fqd_lane());
     for (uint32_t x0 = fqd_lane(); x0 < total; x0 += CP * 64) {
         uint32_t rep[CP], klen_of[CP];
         uint4 v[CP];
 #pragma unroll
-        for (uint32_t t = 0; t < CP; t++) {
-            const uint32_t xc = min(x0 + t * 64, total - 1);
-            rep[t] = tmp_rep[src + (pow2 ? xc >> q_shift : xc / q_per_rec)];
-        }
+        for (uint32_t t = 0; t < CP; t++)
+            rep[t] = rep_next[t];
+        request_reps(x0 + CP * 64);
 #pragma unroll
         for (uint32_t t = 0; t < CP; t++) {
             const uint32_t xc = min(x0 + t * 64, total - 1);
