@@ -167,6 +167,9 @@ struct fqd_ctx {
     bool labels_flat = false;
     bool pre_zero_tail = false;     // ... and it cleared the kept-bin cursors, C64_SUM and C64_CANDS too (the tail launches no fills)
     bool pre_init = false, pre_init_closed = false;   // fqd_api_graph_preinit ran for this job (its closed-form part too)
+    DevBuf nodes;                   // node records (parent, state byte) of the one-sweep components + directional pass 1
+    bool pre_nodes = false;         // ... the set-up wrote THEM (not the labels / state arrays): components_queue runs the one sweep
+    bool pass1_done = false;        // ... which did pass 1 of the closed-form directional dissection: fqd_dissect starts at pass 2
     int preinit_method = -1;        // >= 0: the search queues fqd_api_graph_preinit(method) behind its read-back
     // stage 5
     uint64_t n_kept = 0, n_listed = 0;          // kept keys; kept keys whose first holder is in the id window

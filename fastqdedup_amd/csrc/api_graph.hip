@@ -31,6 +31,33 @@ static int ensure_flat_labels(fqd_ctx *c)
 static int components_queue(fqd_ctx *c, bool flatten, bool on_side = false)
 {
     const uint64_t U = c->U;
+    c->pass1_done = false;
+    if (c->pre_init && c->pre_nodes) {
+        // The set-up wrote node records (parent, state byte): components AND pass 1 of the closed-form directional
+        // dissection in one sweep over the edges (graph.hip union_directional_kernel), then the records are taken apart
+        // into the labels and state arrays everything downstream reads. On the context's own stream: there is nothing
+        // left to run beside it.
+        c->pre_nodes = false;
+        const uint64_t E = c->E;
+        if (E >= 0xFFFFFFFFull)
+            return fail(c, FQD_E_VALUE, "more than 2^32 edges");
+        HIP_TRY(c, c->taint.reserve(E * 8 + 16));          // the edges between count-1 keys, and behind them those pass 2 looks at
+        if (c->store_removed && c->store_table_U == U)
+            HIP_TRY(c, fqd::launch_mask_dead_edges(c->edges.as<uint32_t>(), E, c->store_alive.as<uint8_t>(), c->st));
+        KTIME(c, FQD_K_UF_UNION, fqd::launch_union_directional(
+                  c->nodes.as<uint32_t>(), c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(), c->taint.as<uint32_t>(),
+                  c->d_ctr64.as<unsigned long long>() + C64_CANDS, c->hook_slots.as<unsigned long long>(), c->st,
+                  c->uf_sampled && !getenv("FQD_UF_NO_SAMPLING")));
+        HIP_TRY(c, fqd::launch_unzip_nodes(c->nodes.as<uint32_t>(), c->labels.as<uint32_t>(), c->state.as<uint8_t>(), U, c->st));
+        HIP_TRY(c, fqd::launch_hook_total(c->hook_slots.as<unsigned long long>(), U,
+                                          c->d_ctr64.as<unsigned long long>() + C64_ROOTS, c->st,
+                                          c->d_ctr64.as<unsigned long long>() + C64_UF_AGAIN));
+        c->pass1_done = E != 0;
+        c->labels_flat = false;
+        if (flatten)
+            FQD_TRY(ensure_flat_labels(c));
+        return FQD_OK;
+    }
     if (!c->pre_init) {                // (else: queued by fqd_api_graph_preinit while the host waited for the edge count)
         HIP_TRY(c, c->labels.reserve(U * 4 + 16));
         HIP_TRY(c, c->hook_slots.reserve(FQD_HOOK_SLOTS * 64));
@@ -80,6 +107,23 @@ static int graph_preinit(fqd_ctx *c, int method)
     const bool closed = method == FQD_METHOD_DIRECTIONAL && c->collapsed && !getenv("FQD_DIRECTIONAL_ROUNDS");
     if (closed)
         HIP_TRY(c, c->root_taint.reserve(U + 16));
+    c->pre_nodes = false;
+    if (closed && !getenv("FQD_NO_NODE_RECORDS") && !getenv("FQD_NO_GRAPH_OVERLAP")) {
+        // components and pass 1 will run as ONE sweep on node records (components_queue): the set-up writes those
+        HIP_TRY(c, c->nodes.reserve(U * 8 + 64));
+        HIP_TRY(c, c->kept_u32.reserve(std::max<size_t>(U * 4 + 16, (size_t)512 * fqd::kept_bin_lists() * 4 + 16)));
+        HIP_TRY(c, fqd::launch_graph_preinit_nodes(c->nodes.as<uint32_t>(), c->best.as<uint32_t>(), c->root_taint.as<uint8_t>(),
+                                                   c->ucounts.as<uint32_t>(), U, c->hook_slots.as<unsigned long long>(),
+                                                   FQD_HOOK_SLOTS * 8, c->st, c->kept_u32.as<uint32_t>(),
+                                                   512 * fqd::kept_bin_lists(), c->d_ctr64.as<unsigned long long>() + C64_SUM,
+                                                   c->d_ctr64.as<unsigned long long>() + C64_CANDS,
+                                                   c->d_ctr64.as<unsigned long long>() + C64_CAND_NEED));
+        c->pre_zero_tail = true;
+        c->pre_init_closed = true;
+        c->pre_init = true;
+        c->pre_nodes = true;
+        return FQD_OK;
+    }
     // (the cursor table of the kept-id bins, at the size fqd_dissect will ask for -- no reallocation behind this)
     HIP_TRY(c, c->kept_u32.reserve(std::max<size_t>(U * 4 + 16, (size_t)512 * fqd::kept_bin_lists() * 4 + 16)));
     // one launch for all of it (graph.hip graph_preinit_kernel)
@@ -277,6 +321,8 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
     HIP_TRY(c, c->kept_scan.reserve(U * 4 + 16));
     const bool pre = c->pre_init, pre_closed = c->pre_init && c->pre_init_closed;
     c->pre_init = c->pre_init_closed = false;          // (one job's worth)
+    const bool pass1_done = c->pass1_done && pre_closed;      // (components_queue did pass 1 of THIS dissection, on node records)
+    c->pass1_done = false;
     if (!pre)
         HIP_TRY(c, fqd::launch_dissect_init(c->best.as<uint32_t>(), c->state.as<uint8_t>(), U, c->st));
     const bool closed_form = method == FQD_METHOD_DIRECTIONAL && c->collapsed && !getenv("FQD_DIRECTIONAL_ROUNDS") && E;
@@ -310,7 +356,7 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
             // (pass 1b -- graph.hip directional_unions_kernel -- from distance 2 on, or when the edges came from elsewhere)
             const bool split_unions = (c->last_search_d >= 2 || getenv("FQD_DIRECTIONAL_SPLIT_UNIONS")) &&
                                       !getenv("FQD_DIRECTIONAL_NO_SPLIT_UNIONS");
-            for (int pass = 1; pass <= 2; pass++) {
+            for (int pass = pass1_done ? 2 : 1; pass <= 2; pass++) {
                 if (pass == 2 && c->join_pending) {
                     // pass 2 walks the components' parents: the union-find that ran beside pass 1 must be through
                     HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join, 0));

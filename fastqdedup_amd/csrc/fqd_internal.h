@@ -617,6 +617,16 @@ hipError_t launch_quality(const uint8_t *bytes, uint64_t n_bytes, const uint64_t
 
 // graph.hip -- union-find + dissection
 hipError_t launch_uf_init(uint32_t *parent, uint64_t U, hipStream_t st);
+// components and pass 1 of the closed-form directional dissection in one sweep over the edges, on node records
+// node[x] = (parent, state byte) -- graph.hip union_directional_kernel; then the records taken apart again
+hipError_t launch_graph_preinit_nodes(uint32_t *node, uint32_t *best, uint8_t *root_taint, const uint32_t *ucounts, uint64_t U,
+                                      unsigned long long *hook_slots, uint32_t hook_words, hipStream_t st, uint32_t *zero32,
+                                      uint32_t zero32_words, unsigned long long *zero64_a, unsigned long long *zero64_b,
+                                      unsigned long long *zero64_c);
+hipError_t launch_union_directional(uint32_t *node, const uint32_t *edges, uint64_t E, const uint32_t *ucounts, uint32_t *list11,
+                                    unsigned long long *list11_count, unsigned long long *n_hooks, hipStream_t st,
+                                    bool sampled_first);
+hipError_t launch_unzip_nodes(const uint32_t *node, uint32_t *parent, uint8_t *state, uint64_t U, hipStream_t st);
 hipError_t launch_mask_dead_edges(uint32_t *edges, uint64_t E, const uint8_t *alive, hipStream_t st);
 hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, unsigned long long *n_hooks,
                            hipStream_t st, bool sampled_first = false);

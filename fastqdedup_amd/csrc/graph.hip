@@ -623,6 +623,204 @@ __global__ __launch_bounds__(256) void directional_edges_kernel(const uint32_t *
                 (uint32_t)(((uint64_t)blockIdx.x * DE_EPT + t) * blockDim.x + threadIdx.x);
 }
 
+// ---- components AND pass 1 of the closed-form directional dissection in ONE sweep over the edges, on NODE RECORDS ----
+// node[x] = (parent of x, state byte of x): what uf_union_kernel and directional_edges_kernel fetch per end of an edge
+// -- a parent word here, a state byte there, two random sectors per end -- lies in ONE 8-byte record, one sector per
+// end. Both kernels sit on the memory system's random-access rate (57.7 G sectors/s, microbench row 3: four sectors per
+// edge are 0.65 ms for config 4's 9.35 M edges, and the two kernels side by side took 0.8); the sectors halve. The
+// records are taken apart again (unzip_nodes_kernel: parents to the labels array, states to the state array) for
+// everything downstream, which is unchanged. fqd_cluster[_keys] with the closed-form directional dissection takes this
+// way (FQD_NO_NODE_RECORDS=1: the two kernels on their arrays, as the stage-by-stage calls do).
+template <bool FRESH>
+__device__ __forceinline__ uint32_t uf_find2(uint32_t *node, uint32_t x)
+{
+    uint32_t p = FRESH ? load_relaxed(&node[2 * (size_t)x]) : node[2 * (size_t)x];
+    while (p != x) {
+        const uint32_t g = FRESH ? load_relaxed(&node[2 * (size_t)p]) : node[2 * (size_t)p];
+        if (g != p)
+            __hip_atomic_store(&node[2 * (size_t)x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (path halving, see uf_find)
+        x = p;
+        p = g;
+    }
+    return x;
+}
+
+constexpr uint32_t UD_EPT = 4;
+
+__global__ __launch_bounds__(256) void union_directional_kernel(uint32_t *node /* [U][2] */, const uint32_t *__restrict__ edges,
+                                                                uint64_t E, const uint32_t *__restrict__ ucounts,
+                                                                uint32_t *__restrict__ list11,
+                                                                unsigned long long *__restrict__ list11_count,
+                                                                unsigned long long *n_hooks, uint32_t phase)
+{
+    __shared__ uint32_t s_slot[4][128], s_res[4][64];
+    __shared__ uint32_t s_n, s_base;
+    const uint32_t lane = fqd_lane(), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        s_n = 0;
+    __syncthreads();
+    uint32_t uu[UD_EPT], vv[UD_EPT];
+    bool live[UD_EPT];
+#pragma unroll
+    for (uint32_t t = 0; t < UD_EPT; t++) {           // the edges, then both ends' records of all four, in flight together
+        const uint64_t e = ((uint64_t)blockIdx.x * UD_EPT + t) * blockDim.x + threadIdx.x;
+        // (phases as in uf_union_kernel: 0 every edge; 1 every 16th, 2 the rest -- a context that has met a giant component)
+        live[t] = e < E && (phase == 0 || ((e & 15u) == 0) == (phase == 1));
+        const uint2 uv = reinterpret_cast<const uint2 *>(edges)[min(e, E - 1)];
+        uu[t] = uv.x;
+        vv[t] = uv.y;
+    }
+    uint2 nu[UD_EPT], nv[UD_EPT];
+#pragma unroll
+    for (uint32_t t = 0; t < UD_EPT; t++) {
+        live[t] = live[t] && uu[t] != vv[t];
+        nu[t] = reinterpret_cast<const uint2 *>(node)[uu[t]];
+        nv[t] = reinterpret_cast<const uint2 *>(node)[vv[t]];
+    }
+    // ---- pass 1 of the dissection (directional_edges_kernel on the records' state bytes)
+    uint32_t rank[UD_EPT];
+#pragma unroll
+    for (uint32_t t = 0; t < UD_EPT; t++) {
+        rank[t] = 0xFFFFFFFFu;
+        if (!live[t])
+            continue;
+        const uint32_t su = nu[t].y & 0xFFu, sv = nv[t].y & 0xFFu;
+        uint32_t cu = su >> 4, cv = sv >> 4;
+        if (cu == 15u)                              // (15 or more copies: the count itself -- few keys)
+            cu = ucounts[uu[t]];
+        if (cv == 15u)
+            cv = ucounts[vv[t]];
+        if (cu == 1 && cv == 1) {
+            rank[t] = atomicAdd(&s_n, 1u);          // (an edge between count-1 keys: listed)
+            continue;
+        }
+        const long long lu = cu, lv = cv;
+        const uint32_t ku = su & 15u, kv = sv & 15u;
+        if (lv >= 2 && 2 * lv - 1 <= lu && kv != 2)
+            atomicOr(&node[2 * (size_t)vv[t] + 1], 2u);      // arc u -> v from a key of larger count
+        if (lu >= 2 && 2 * lu - 1 <= lv && ku != 2)
+            atomicOr(&node[2 * (size_t)uu[t] + 1], 2u);
+        if (lu == 1 && ku != 3)
+            atomicOr(&node[2 * (size_t)uu[t] + 1], 3u);      // here cv >= 2: v reaches u and outranks all of u's count-1 set
+        if (lv == 1 && kv != 3)
+            atomicOr(&node[2 * (size_t)vv[t] + 1], 3u);
+    }
+    // ---- the unions (uf_union_kernel: lanes that hang the same root under the same node send ONE compare-and-swap)
+    uint32_t hooks = 0, walks_again = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < UD_EPT; t++) {
+        // the first step of either walk is in hand: the record's parent word
+        uint32_t a = nu[t].x, b = nv[t].x;
+        bool active = live[t];
+        bool hooked = false;
+        for (bool fresh = false; __ballot(active); fresh = true) {
+            if (fresh)
+                walks_again += (uint32_t)__popcll(__ballot(active));
+            if (active) {
+                a = fresh ? uf_find2<true>(node, a) : uf_find2<false>(node, a);
+                b = fresh ? uf_find2<true>(node, b) : uf_find2<false>(node, b);
+                if (a == b)
+                    active = false;
+                if (a > b) {
+                    const uint32_t x = a;
+                    a = b;
+                    b = x;
+                }
+            }
+            s_slot[wave][lane] = 0xFFFFFFFFu;
+            s_slot[wave][lane + 64] = 0xFFFFFFFFu;
+            const uint32_t h = ((b * 0x9E3779B1u) ^ (a * 0x85EBCA6Bu)) >> 25;
+            if (active)
+                atomicMin(&s_slot[wave][h], lane);
+            const uint32_t owner = active ? s_slot[wave][h] : lane;
+            const uint32_t ob = __shfl(b, owner & 63u), oa = __shfl(a, owner & 63u);
+            const bool follower = active && owner != lane && ob == b && oa == a;
+            uint32_t res = 0xFFFFFFFFu;
+            if (active && !follower)
+                res = atomicCAS(&node[2 * (size_t)b], b, a);        // hook the larger root under the smaller one
+            s_res[wave][lane] = res;
+            if (follower)
+                res = s_res[wave][owner];
+            if (active && res == b) {
+                active = false;
+                hooked = !follower;
+            }
+        }
+        hooks += (uint32_t)__popcll(__ballot(hooked));
+    }
+    if (n_hooks && lane == 0) {
+        if (hooks)
+            atomicAdd(n_hooks + (size_t)(blockIdx.x % FQD_HOOK_SLOTS) * 8, (unsigned long long)hooks);
+        if (walks_again)
+            atomicAdd(n_hooks + (size_t)(blockIdx.x % FQD_HOOK_SLOTS) * 8 + 1, (unsigned long long)walks_again);
+    }
+    // ---- the listed edges: one reservation per workgroup
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n)
+        s_base = (uint32_t)atomicAdd(list11_count, (unsigned long long)s_n);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t t = 0; t < UD_EPT; t++)
+        if (rank[t] != 0xFFFFFFFFu)
+            list11[s_base + rank[t]] = (uint32_t)(((uint64_t)blockIdx.x * UD_EPT + t) * blockDim.x + threadIdx.x);
+}
+
+// node records -> the parents (labels array) and the state bytes: four keys per thread
+__global__ void unzip_nodes_kernel(const uint32_t *__restrict__ node, uint32_t *__restrict__ parent, uint8_t *__restrict__ state,
+                                   uint64_t U)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = q * 4;
+    if (i0 + 4 <= U) {
+        const uint4 lo = reinterpret_cast<const uint4 *>(node)[2 * q], hi = reinterpret_cast<const uint4 *>(node)[2 * q + 1];
+        reinterpret_cast<uint4 *>(parent)[q] = make_uint4(lo.x, lo.z, hi.x, hi.z);
+        reinterpret_cast<uint32_t *>(state)[q] = (lo.y & 0xFFu) | (lo.w & 0xFFu) << 8 | (hi.y & 0xFFu) << 16 | (hi.w & 0xFFu) << 24;
+    } else {
+        for (uint64_t i = i0; i < U; i++) {
+            parent[i] = node[2 * i];
+            state[i] = (uint8_t)node[2 * i + 1];
+        }
+    }
+}
+
+// node[i] = (i, the count nibble of key i); with best[i] = i, root_taint[i] = 0 and the counters graph_preinit_kernel clears
+__global__ void graph_preinit_nodes_kernel(uint32_t *__restrict__ node, uint32_t *__restrict__ best, uint8_t *__restrict__ root_taint,
+                                           const uint32_t *__restrict__ ucounts, uint64_t U,
+                                           unsigned long long *__restrict__ hook_slots, uint32_t hook_words,
+                                           uint32_t *__restrict__ zero32, uint32_t zero32_words,
+                                           unsigned long long *__restrict__ zero64_a, unsigned long long *__restrict__ zero64_b,
+                                           unsigned long long *__restrict__ zero64_c)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = q * 4;
+    if (blockIdx.x == 0) {
+        for (uint32_t w = threadIdx.x; w < hook_words; w += blockDim.x)
+            hook_slots[w] = 0ull;
+        if (zero32)
+            for (uint32_t w = threadIdx.x; w < zero32_words; w += blockDim.x)
+                zero32[w] = 0u;
+        if (threadIdx.x == 0 && zero64_a)
+            *zero64_a = 0ull;
+        if (threadIdx.x == 0 && zero64_b)
+            *zero64_b = 0ull;
+        if (threadIdx.x == 0 && zero64_c)
+            *zero64_c = 0ull;
+    }
+    if (i0 + 4 <= U) {
+        const uint4 c4 = reinterpret_cast<const uint4 *>(ucounts)[q];
+        const uint32_t i = (uint32_t)i0;
+        reinterpret_cast<uint4 *>(node)[2 * q] = make_uint4(i, dstate_init(c4.x), i + 1, dstate_init(c4.y));
+        reinterpret_cast<uint4 *>(node)[2 * q + 1] = make_uint4(i + 2, dstate_init(c4.z), i + 3, dstate_init(c4.w));
+        reinterpret_cast<uint4 *>(best)[q] = make_uint4(i, i + 1, i + 2, i + 3);
+        reinterpret_cast<uint32_t *>(root_taint)[q] = 0u;
+    } else {
+        for (uint64_t i = i0; i < U; i++) {
+            node[2 * i] = (uint32_t)i;
+            node[2 * i + 1] = dstate_init(ucounts[i]);
+            best[i] = (uint32_t)i;
+            root_taint[i] = 0;
+        }
+    }
+}
+
 // Pass 1b, over the listed edges (both ends count 1), AFTER pass 1 has marked every count-1 key that touches a bigger
 // one (state 3, "tainted": dropped whatever its set looks like): the edge stays on the list of pass 2 only if one of its
 // ends is NOT tainted. An edge between two tainted keys has nothing more to say -- both are dropped -- and the taint of
@@ -1444,6 +1642,40 @@ hipError_t launch_uf_union(uint32_t *parent, const uint32_t *edges, uint64_t E, 
         uf_union_kernel<<<grid_for(E), 256, 0, st>>>(parent, edges, E, n_hooks, 1u);
         uf_union_kernel<<<grid_for(E), 256, 0, st>>>(parent, edges, E, n_hooks, 2u);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_union_directional(uint32_t *node, const uint32_t *edges, uint64_t E, const uint32_t *ucounts, uint32_t *list11,
+                                    unsigned long long *list11_count, unsigned long long *n_hooks, hipStream_t st,
+                                    bool sampled_first)
+{
+    if (!E)
+        return hipSuccess;
+    const unsigned grid = (unsigned)((E + 256 * UD_EPT - 1) / (256 * UD_EPT));
+    if (!sampled_first) {
+        union_directional_kernel<<<grid, 256, 0, st>>>(node, edges, E, ucounts, list11, list11_count, n_hooks, 0u);
+    } else {
+        union_directional_kernel<<<grid, 256, 0, st>>>(node, edges, E, ucounts, list11, list11_count, n_hooks, 1u);
+        union_directional_kernel<<<grid, 256, 0, st>>>(node, edges, E, ucounts, list11, list11_count, n_hooks, 2u);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_unzip_nodes(const uint32_t *node, uint32_t *parent, uint8_t *state, uint64_t U, hipStream_t st)
+{
+    if (U)
+        unzip_nodes_kernel<<<(unsigned)std::max<uint64_t>(1, ((U + 3) / 4 + 255) / 256), 256, 0, st>>>(node, parent, state, U);
+    return hipGetLastError();
+}
+
+hipError_t launch_graph_preinit_nodes(uint32_t *node, uint32_t *best, uint8_t *root_taint, const uint32_t *ucounts, uint64_t U,
+                                      unsigned long long *hook_slots, uint32_t hook_words, hipStream_t st, uint32_t *zero32,
+                                      uint32_t zero32_words, unsigned long long *zero64_a, unsigned long long *zero64_b,
+                                      unsigned long long *zero64_c)
+{
+    const uint64_t quads = (U + 3) / 4;
+    graph_preinit_nodes_kernel<<<(unsigned)std::max<uint64_t>(1, (quads + 255) / 256), 256, 0, st>>>(
+        node, best, root_taint, ucounts, U, hook_slots, hook_words, zero32, zero32_words, zero64_a, zero64_b, zero64_c);
     return hipGetLastError();
 }
 
