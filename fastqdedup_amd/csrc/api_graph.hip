@@ -108,7 +108,11 @@ static int graph_preinit(fqd_ctx *c, int method)
     if (closed)
         HIP_TRY(c, c->root_taint.reserve(U + 16));
     c->pre_nodes = false;
-    if (closed && !getenv("FQD_NO_NODE_RECORDS") && !getenv("FQD_NO_GRAPH_OVERLAP")) {
+    // (from distance 2 on -- edges are many per key there: config 4 has 0.72 per key and the one sweep takes 0.76 ms where
+    // the two kernels side by side took 0.80, step 7.07 -> 7.00 ms; at distance 1, config 3 with 0.12 edges per key, taking
+    // the records apart again costs more than the sweep saves: 2.16 against 2.11 ms. FQD_NODE_RECORDS=1 / FQD_NO_NODE_RECORDS=1 pin it)
+    const bool want_nodes = getenv("FQD_NODE_RECORDS") || (c->last_search_d >= 2 && !getenv("FQD_NO_NODE_RECORDS"));
+    if (closed && want_nodes && !getenv("FQD_NO_GRAPH_OVERLAP")) {
         // components and pass 1 will run as ONE sweep on node records (components_queue): the set-up writes those
         HIP_TRY(c, c->nodes.reserve(U * 8 + 64));
         HIP_TRY(c, c->kept_u32.reserve(std::max<size_t>(U * 4 + 16, (size_t)512 * fqd::kept_bin_lists() * 4 + 16)));

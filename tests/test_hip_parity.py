@@ -244,6 +244,32 @@ def test_fused_pack_collapse_matches_oracle(F, oracle, monkeypatch, case):
             ctx.collapse()       # the packed reads were never written: needs fqd_pack_keys first
 
 
+@pytest.mark.parametrize("switch", ["FQD_NODE_RECORDS", "FQD_NO_NODE_RECORDS"])
+@pytest.mark.parametrize("d", [1, 2])
+def test_components_and_pass_1_on_node_records(F, oracle, monkeypatch, switch, d):
+    """The closed-form directional dissection behind fqd_cluster_keys: components and pass 1 in ONE sweep over the edges
+    on node records (parent, state byte) -- the default from distance 2 on -- or as the union-find beside pass 1 on
+    their own arrays; both pinned at both distances, with keys of 15 and more copies (the state byte's count nibble
+    saturates) and a giant component (the union-find's two phases on the second job). Against the oracle
+    (`cluster_dissection_directional`, `__init__.py:60-91`; `Trie.pop_cluster`, `_triemodule.c:778-897`)."""
+    from fastqdedup_amd.synth import SKEW, fixed_offsets, synth_keys
+    monkeypatch.setenv(switch, "1")
+    n, L = 400_000, 32
+    keys = synth_keys(n, L, 12, 77 + d, sub_rate=4e-3, n_rate=1e-4, skew=SKEW)
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=d, method="directional")
+    ctx = F.Context(0)
+    for job in range(2):
+        got = F.cluster_keys(raw, key_len=L, max_distance=d, method="directional", context=ctx)
+        assert (got.n_unique, got.n_clusters, got.n_kept) == (want["n_unique"], want["n_clusters"],
+                                                              len(want["kept_read_ids"])), (switch, d, job)
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), (switch, d, job)
+    # another method on the same context afterwards (the state bytes of the sweep must not leak into it)
+    want2 = oracle.dedup(raw, fixed_offsets(n, L), max_distance=d, method="adjacency")
+    got2 = F.cluster_keys(raw, key_len=L, max_distance=d, method="adjacency", context=ctx)
+    assert np.array_equal(got2.kept_read_ids, want2["kept_read_ids"]), (switch, d)
+
+
 @pytest.mark.parametrize("d", [1, 2, 3])
 def test_crowded_buckets_are_matched_on_finer_pieces(F, oracle, monkeypatch, d):
     """Crowded segment values at distances 1, 2 and 3 (group.hip "crowded buckets": sets of d pieces masked out, a pair
