@@ -5,11 +5,11 @@
 # prints a line, so a long run never looks hung.
 set -o pipefail
 R=${1:-r04}
-PART=${2:-all}        # bench | prof | all (two gpurun calls of <= 20 min each: bench, then prof)
+PART=${2:-all}        # bench1 | bench2 | prof | all (three gpurun calls of <= 20 min each)
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
-if [ "$PART" != "prof" ]; then
+if [ "$PART" = "bench1" ] || [ "$PART" = "all" ]; then
 python3 bench.py > $OUT/${R}_bench_config3.json 2> $OUT/bench_config3.err || exit 1
 echo "config3 done"
 # the long-key shapes WITH the PMC passes (job_roofline.traffic), config 5 / 5v without (their child passes take minutes)
@@ -17,6 +17,8 @@ for w in config2 config4; do
     python3 bench.py --workload $w > $OUT/${R}_bench_$w.json 2> $OUT/bench_$w.err || exit 1
     echo "$w done"
 done
+fi
+if [ "$PART" = "bench2" ] || [ "$PART" = "all" ]; then
 for w in config5 config5v; do
     python3 bench.py --workload $w --no-pmc > $OUT/${R}_bench_$w.json 2> $OUT/bench_$w.err || exit 1
     echo "$w done"
@@ -35,7 +37,8 @@ echo "skew variants done"
 hipcc --offload-arch=gfx950 -O3 -o /tmp/mb tools/microbench_patterns.hip 2> /dev/null && /tmp/mb > $OUT/${R}_microbench_patterns.json || exit 1
 echo "microbench done"
 fi
-[ "$PART" = "bench" ] && exit 0
+[ "$PART" = "bench1" ] && exit 0
+[ "$PART" = "bench2" ] && exit 0
 for w in config3 config2 config4 config3_skew config3_skew_d2; do
     (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_$w -o r -- python3 $GRAFT_REPO_ROOT/bench.py --workload $w --steps 10 --no-cpu-baseline --no-host-input --no-pmc --no-copy-peak > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_$w.log 2>&1) || exit 1
     cp $OUT/prof_$w/r_kernel_stats.csv $OUT/${R}_kernel_stats_bench_$w.csv
