@@ -806,12 +806,18 @@ def cluster_keys_sharded(backend, keys, offsets=None, key_len: int = 0, weights=
         pair_got = comm.exchange_counts(pair_counts)
         theirs_sorted = pairs[pair_order, 1]
         mine_sorted = (pairs[pair_order, 0] - uid0).long()
+        # (three rounds between two looks at "did anything move": a look is an all-reduce and a host round trip, a round
+        # costs little -- and a cluster of a handful of keys spans two or three ranks in a row)
         while True:
-            msg = torch.stack([theirs_sorted, label[mine_sorted]], dim=1)         # (their component, my label)
-            got = comm.all_to_all_rows(msg, pair_counts, pair_got)
-            before = label.clone()
-            if got.shape[0]:
-                label.scatter_reduce_(0, (got[:, 0] - uid0).long(), got[:, 1], reduce="amin", include_self=True)
+            for k in range(3):
+                if k == 2:
+                    before = label.clone()
+                msg = torch.stack([theirs_sorted, label[mine_sorted]], dim=1)     # (their component, my label)
+                got = comm.all_to_all_rows(msg, pair_counts, pair_got)
+                if got.shape[0]:
+                    label.scatter_reduce_(0, (got[:, 0] - uid0).long(), got[:, 1], reduce="amin", include_self=True)
+            # converged when the LAST round of a batch moved nothing anywhere (a round that moves nothing on any rank
+            # sends the same messages as the round before it: every later round is idle too)
             if not comm.any_flag(bool((label != before).any())):
                 break
         del before
