@@ -45,11 +45,9 @@ WORKLOADS = {
     # ... and dissected by adjacency (the 65 536-key component through host-checked rounds; reference __init__.py:105-122)
     "config3_skew_adj": dict(n=50_000_000, L=32, umi=32, d=1, edit=False, method="adjacency", seed=1003, skew=True,
                              name="config 3's shape under the skewed model, Hamming d=1, adjacency"),
-    # the skewed model at config 4's distance (d = 2): crowded segment values matched on 120 finer items per key
-    "config3_skew_d2": dict(n=50_000_000, L=32, umi=32, d=2, edit=False, method="directional", seed=1003, skew=True,
-                            name="config 3's shape under the skewed model, Hamming d=2, directional"),
-    "config3_d2": dict(n=50_000_000, L=32, umi=32, d=2, edit=False, method="directional", seed=1003,
-                       name="config 3's shape (uniform model), Hamming d=2, directional"),
+    # config 4's shape (300-nt keys, d = 2) under the skewed model: crowded segment values matched on 120 finer items per key
+    "config4_skew": dict(n=25_000_000, L=300, umi=300, d=2, edit=False, method="directional", seed=1004, skew=True,
+                         name="config 4's shape (25M per GPU, 300-nt keys) under the skewed model, Hamming d=2, directional"),
     # SURVEY.md 8d's variant of configs[4]: 1 % of the reads are one base short or long, so the keys
     # have three lengths and the Levenshtein search proper runs (equal lengths at d=1 reduce to Hamming)
     "config5v": dict(n=50_000_000, L=300, umi=300, d=1, edit=True, method="adjacency", seed=1005, indel_rate=0.01,

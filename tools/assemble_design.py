@@ -36,8 +36,7 @@ def workloads():
             ("config 5v: the same with a 1 % indel tail", "bench_config5v.json"),
             ("config 3 under the skewed model (`config3_skew`)", "bench_config3_skew.json"),
             ("… dissected by adjacency (`config3_skew_adj`)", "bench_config3_skew_adj.json"),
-            ("config 3's shape at d = 2, uniform (`config3_d2`)", "bench_config3_d2.json"),
-            ("… under the skewed model (`config3_skew_d2`)", "bench_config3_skew_d2.json"),
+            ("config 4's shape under the skewed model (`config4_skew`)", "bench_config4_skew.json"),
             ("config 3 through the multi-GPU plan, one rank", "bench_config3_sharded_world1.json"),
             ("config 4's shape through the multi-GPU plan, one rank", "bench_config4_sharded_world1.json")]
     out = ["| workload | ms / step | reads/s (`t_dev`) | whole-job fraction of 8 TB/s | PMC traffic per step | `t_e2e` ms | first call ms | CPU reference reads/s (sample) |",

@@ -31,15 +31,14 @@ echo "sharded done"
 # the skewed model: adjacency, and at distance 2 beside the uniform job of that shape (no CPU baseline: the oracle's
 # quadratic dissection of the 65 536-key component takes minutes at d = 2)
 python3 bench.py --workload config3_skew_adj --no-pmc --steps 5 --warmup 2 --no-cpu-baseline --no-host-input > $OUT/${R}_bench_config3_skew_adj.json 2> $OUT/bench_skew_adj.err || exit 1
-python3 bench.py --workload config3_skew_d2 --no-pmc --steps 5 --warmup 2 --no-cpu-baseline --no-host-input > $OUT/${R}_bench_config3_skew_d2.json 2> $OUT/bench_skew_d2.err || exit 1
-python3 bench.py --workload config3_d2 --no-pmc --steps 5 --warmup 2 --no-cpu-baseline --no-host-input > $OUT/${R}_bench_config3_d2.json 2> $OUT/bench_d2.err || exit 1
+python3 bench.py --workload config4_skew --no-pmc --steps 5 --warmup 2 --no-cpu-baseline --no-host-input > $OUT/${R}_bench_config4_skew.json 2> $OUT/bench_skew4.err || exit 1
 echo "skew variants done"
 hipcc --offload-arch=gfx950 -O3 -o /tmp/mb tools/microbench_patterns.hip 2> /dev/null && /tmp/mb > $OUT/${R}_microbench_patterns.json || exit 1
 echo "microbench done"
 fi
 [ "$PART" = "bench1" ] && exit 0
 [ "$PART" = "bench2" ] && exit 0
-for w in config3 config2 config4 config3_skew config3_skew_d2; do
+for w in config3 config2 config4 config3_skew config4_skew; do
     (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_$w -o r -- python3 $GRAFT_REPO_ROOT/bench.py --workload $w --steps 10 --no-cpu-baseline --no-host-input --no-pmc --no-copy-peak > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_$w.log 2>&1) || exit 1
     cp $OUT/prof_$w/r_kernel_stats.csv $OUT/${R}_kernel_stats_bench_$w.csv
     rm -rf $OUT/prof_$w
