@@ -46,8 +46,13 @@ WORKLOADS = {
     "config3_skew_adj": dict(n=50_000_000, L=32, umi=32, d=1, edit=False, method="adjacency", seed=1003, skew=True,
                              name="config 3's shape under the skewed model, Hamming d=1, adjacency"),
     # config 4's shape (300-nt keys, d = 2) under the skewed model: crowded segment values matched on 120 finer items per key
-    "config4_skew": dict(n=25_000_000, L=300, umi=300, d=2, edit=False, method="directional", seed=1004, skew=True,
-                         name="config 4's shape (25M per GPU, 300-nt keys) under the skewed model, Hamming d=2, directional"),
+    # (without the model's LADDER: all 4^8 values of eight adjacent bases lie inside ONE of the 16 fine pieces of a 300-nt
+    # key, the 65 536 keys stay one group of the refinement and the search takes the quadratic sort path -- 19 s)
+    "config4_skew": dict(n=25_000_000, L=300, umi=300, d=2, edit=False, method="directional", seed=1004,
+                         skew={"hot": 0.02, "ladder": 0.0, "lowc_every": 100},
+                         name="config 4's shape (25M per GPU, 300-nt keys) under the skewed model without its ladder "
+                              "(a key with 500 K copies, heavy-tailed abundance, 1 % of the molecules poly-A in their "
+                              "first half), Hamming d=2, directional"),
     # SURVEY.md 8d's variant of configs[4]: 1 % of the reads are one base short or long, so the keys
     # have three lengths and the Levenshtein search proper runs (equal lengths at d=1 reduce to Hamming)
     "config5v": dict(n=50_000_000, L=300, umi=300, d=1, edit=True, method="adjacency", seed=1005, indel_rate=0.01,
@@ -77,7 +82,7 @@ def cpu_baseline(ctx, wl, sample_reads: int):
     else:
         from fastqdedup_amd.synth import SKEW
         dev = torch.empty(n * wl["L"], dtype=torch.uint8, device="cuda:0")
-        ctx.synth_keys(dev, n, 0, n, wl["L"], wl["umi"], wl["seed"], skew=SKEW if wl.get("skew") else None)
+        ctx.synth_keys(dev, n, 0, n, wl["L"], wl["umi"], wl["seed"], skew=(wl["skew"] if isinstance(wl.get("skew"), dict) else SKEW) if wl.get("skew") else None)
     host = dev.cpu().numpy()
     sample = (f"first {n} reads of the same generator (n_total={n}, L={wl['L']}, umi={wl['umi']}, "
               f"seed={wl['seed']}{', indel tail ' + str(wl['indel_rate']) if wl.get('indel_rate') else ''}), "
@@ -302,7 +307,7 @@ def main():
     else:
         from fastqdedup_amd.synth import SKEW
         keys = torch.empty(n * L, dtype=torch.uint8, device=device)
-        ctx.synth_keys(keys, n_total, rank * n, n, L, wl["umi"], wl["seed"], skew=SKEW if wl.get("skew") else None)
+        ctx.synth_keys(keys, n_total, rank * n, n, L, wl["umi"], wl["seed"], skew=(wl["skew"] if isinstance(wl.get("skew"), dict) else SKEW) if wl.get("skew") else None)
     kept_buf = torch.empty(n, dtype=torch.int64, device=device)
     backend = HipBackend(ctx, device) if sharded else None
 
