@@ -843,7 +843,7 @@ class Context:
     ROUTE_BITS = {"fused_pack": 0x1, "compact_records": 0x2, "pass0_in_collapse": 0x4, "restarted": 0x8,
                   "collapse_lds": 0x10, "collapse_pairs": 0x20, "collapse_sort": 0x40, "search_grouped": 0x100,
                   "search_sort": 0x200, "search_edit": 0x400, "search_retried": 0x800, "pass0_continued": 0x1000,
-                  "spill_list": 0x2000, "search_refined": 0x4000, "one_kernel_collapse": 0x8000}
+                  "spill_list": 0x2000, "search_refined": 0x4000, "one_kernel_collapse": 0x8000, "search_tiles": 0x10000}
 
     def route(self) -> dict:
         """Which way the last job took (fqd_get_route): {name: bool} over the FQD_ROUTE_* bits."""

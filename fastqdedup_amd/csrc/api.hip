@@ -612,7 +612,7 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
     for (int attempt = 0; attempt < 2; attempt++) {
         const bool slabs = attempt == 0 && !c->pairs_slab_off && !getenv("FQD_LDS_NO_SLABS");
         const uint32_t *items = nullptr, *bucket_end = nullptr;
-        FQD_TRY(zero_ctr32(c, C_BAD));
+        FQD_TRY(zero_ctr32(c, C_BAD, 3));         // ... C_COLLISIONS, C_CHANGED: the slices' counters below
         FQD_TRY(zero_ctr64(c, C64_SLAB));
         FQD_TRY(fqd_api_partition_pairs(c, c->hashes.as<uint32_t>(), n, B, slabs, &items, &bucket_end, nullptr));
         // tmp rows of a bucket start where its items start (unique keys <= reads of the bucket)
@@ -622,10 +622,22 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
         HIP_TRY(c, c->ld_tmp_first.reserve(slots * 4 + 16));
         HIP_TRY(c, c->ld_unique.reserve((size_t)n_buckets * 4 + 16));
         HIP_TRY(c, c->ld_unique_incl.reserve((size_t)n_buckets * 4 + 16));
+        // a bucket of very many pairs (one key with 100 000 copies) is cut into slices, each a workgroup of its own
+        fqd::PairsSlices sl;
+        sl.slice = fqd::pairs_slice_items();
+        if (sl.slice) {
+            sl.cap = (uint32_t)(n / sl.slice + 1);
+            HIP_TRY(c, c->pairs_slices.reserve((size_t)sl.cap * 24 + 64));
+            sl.extra = c->pairs_slices.as<uint2>();
+            sl.extra_unique = reinterpret_cast<uint32_t *>(sl.extra + sl.cap);
+            sl.big = sl.extra_unique + sl.cap;
+            sl.ctr = c->d_ctr32.as<uint32_t>() + C_COLLISIONS;       // (and C_CHANGED: neither has another user during a collapse)
+            sl.tags = const_cast<uint32_t *>(items);
+        }
         KTIME(c, FQD_K_DEDUPE, fqd::launch_bucket_pairs_dedupe(
                   items, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, c->recs.as<uint32_t>(), sh.stride, d_w,
                   c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(), c->ld_tmp_first.as<uint32_t>(),
-                  c->ld_unique.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st, d_lens));
+                  c->ld_unique.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st, d_lens, sl));
         FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
         FQD_TRY(queue_read_u32(c, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 0));
         FQD_TRY(queue_read_u32(c, c->d_ctr32.as<uint32_t>() + C_BAD, 1));

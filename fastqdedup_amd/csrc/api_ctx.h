@@ -111,11 +111,15 @@ struct fqd_ctx {
     // crowded buckets of a distance-1 search (group.hip): flags + list + counters, the fine items, the seen marks
     DevBuf gp_crowded, gp_fine_hash, gp_fine_val, gp_seen;
     const uint32_t *gp_last_items = nullptr;   // the partitioned items of the last grouped pass
+    uint32_t gp_crowded_bits_last = 0;
     uint32_t gp_crowded_bits = 0;      // != 0: the last grouped pass marked crowded buckets (2^bits buckets) and skipped them
     bool search_is_retry = false;       // find_edges calling itself after pass 0's pairs were lost: the route bits stay
     bool search_force_sort = false;     // ... or after the crowded-bucket refinement gave up: that run takes the sort path
     bool search_keeps_edges = false;    // ... except the edge counter and the statistics: pass 0 of this search has run (fqd::Pass0)
     bool search_zero_pending = false;   // find_edges: the job counters and statistics are zeroed by the partition's first launch
+    DevBuf pairs_slices;           // collapse_pairs: the slices of very long buckets (fqd::PairsSlices)
+    bool gp_fine_ok = false;       // the last grouped pass: its crowded keys can be matched on finer pieces
+    bool gp_tiles = false;         // grouped search: crowded buckets go all pairs in tiles (the finer pieces did not split them)
     bool gp_slab_off = false;      // grouped search: same, for the (hash, uid) partition
     bool slab_off = false;         // LDS collapse: a slab of level 2 overflowed once, use exact bucket sizes
     bool hashes_valid = false;     // `hashes` holds the record hashes of the packed reads (lazy after an import)

@@ -389,6 +389,7 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
 // one partition, one candidate kernel and one verification for the whole search (the hash of a
 // segment mixes its number in, so items of different passes do not meet; a candidate's pass is its
 // position / fused_U). Half the launches of two passes, and kernels twice as long.
+static bool tiles_possible(const fqd_ctx *c, uint32_t nseg);
 static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t d, uint32_t s, uint32_t nseg,
                         uint32_t fused_U = 0)
 {
@@ -421,14 +422,16 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
     const uint8_t *skip = nullptr;
     c->gp_crowded_bits = 0;
     c->gp_last_items = items;
-    if (fqd::group_fine_items(d) && fused_U && s == 0 && nseg == d + 1 && !bucket_end &&
-        fused_U < (1u << fqd::group_fine_uid_bits()) && !getenv("FQD_GROUP_NO_REFINE")) {
+    c->gp_fine_ok = fqd::group_fine_items(d) && fused_U < (1u << fqd::group_fine_uid_bits());
+    if ((c->gp_fine_ok || tiles_possible(c, nseg)) && fused_U && s == 0 && nseg == d + 1 && !bucket_end &&
+        !getenv("FQD_GROUP_NO_REFINE")) {
         HIP_TRY(c, c->gp_crowded.reserve((size_t)n_buckets * 5 + 64));
         uint8_t *flags = c->gp_crowded.as<uint8_t>();
         uint32_t *list = reinterpret_cast<uint32_t *>(flags + (((size_t)n_buckets + 63) & ~(size_t)63));
         unsigned long long *counts = reinterpret_cast<unsigned long long *>(list + n_buckets);
         HIP_TRY(c, hipMemsetAsync(counts, 0, 32, c->st));
-        uint32_t limit = 1024;
+        uint32_t limit = 512;           // (buckets hold <= 320 items on average; round 4: 1024 -- a family of 1000 keys sharing a
+                                        // segment is 500 K pairs for ONE wave of grouped_candidates)
         if (const char *e = getenv("FQD_GROUP_CROWDED_LIMIT"))
             limit = (uint32_t)std::max(2, atoi(e));
         HIP_TRY(c, fqd::launch_group_mark_crowded(c->ld_start.as<uint32_t>(), bucket_end, n_buckets, limit, flags, list, counts,
@@ -447,6 +450,30 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
     return FQD_OK;
 }
 
+// The other way behind a grouped_pass that marked crowded buckets (group.hip "the last resort"): all pairs of each
+// crowded bucket, tiled. No host round trip; nothing to do is a launch of empty workgroups.
+static bool tiles_possible(const fqd_ctx *c, uint32_t nseg)
+{
+    return c->ks.stride <= 32 && !(c->ks.stride & 3u) && nseg <= 8 && !getenv("FQD_GROUP_NO_TILES");
+}
+
+static int grouped_tiles(fqd_ctx *c, uint64_t U, uint32_t d, uint32_t seg0, uint32_t nseg)
+{
+    const uint32_t B = c->gp_crowded_bits, n_buckets = 1u << B;
+    c->gp_crowded_bits = 0;
+    uint8_t *flags = c->gp_crowded.as<uint8_t>();
+    uint32_t *list = reinterpret_cast<uint32_t *>(flags + (((size_t)n_buckets + 63) & ~(size_t)63));
+    unsigned long long *counts = reinterpret_cast<unsigned long long *>(list + n_buckets);
+    HIP_TRY(c, c->gp_fine_hash.reserve(((size_t)n_buckets + 2) * 8));
+    unsigned long long *ctr = c->d_ctr64.as<unsigned long long>();
+    c->route |= FQD_ROUTE_SEARCH_TILES;
+    KTIME(c, FQD_K_PAIRS, fqd::launch_group_crowded_tiles(c->gp_last_items, c->ld_start.as<uint32_t>(), nullptr, list, counts,
+                                                          c->gp_fine_hash.as<unsigned long long>(), (uint32_t)U, seg0,
+                                                          c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), c->ks, d, nseg,
+                                                          c->edges.as<uint32_t>(), ctr + C64_EDGES, c->edge_cap, c->st));
+    return FQD_OK;
+}
+
 // Behind a grouped_pass that marked crowded buckets: their keys are matched on finer segments (group.hip "crowded
 // buckets"). One host round trip to learn whether there are any (only contexts that met crowded data get here).
 // *ok = false: more crowded keys than the fine-item buffers hold -- the caller searches again the plain way.
@@ -455,16 +482,29 @@ static int grouped_refine(fqd_ctx *c, const uint32_t *seg_hashes, uint64_t U, ui
     const uint32_t d = nseg - 1;         // (the refinement runs behind a search whose d + 1 passes were all in one partition)
     *ok = true;
     const uint32_t B = c->gp_crowded_bits, n_buckets = 1u << B;
+    c->gp_crowded_bits_last = B;
     c->gp_crowded_bits = 0;
     const KeyShape sh = c->ks;
     uint8_t *flags = c->gp_crowded.as<uint8_t>();
     uint32_t *list = reinterpret_cast<uint32_t *>(flags + (((size_t)n_buckets + 63) & ~(size_t)63));
     unsigned long long *counts = reinterpret_cast<unsigned long long *>(list + n_buckets);
     unsigned long long h[4] = {0, 0, 0, 0};
-    HIP_TRY(c, hipMemcpyAsync(h, counts, 16, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipMemcpyAsync(h, counts, 32, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(c, stream_wait(c->st));
     if (!h[0])
         return FQD_OK;
+    // few enough pairs: all of them, in tiles over the whole GPU (no items, no lists; a bucket of 62 K poly-A keys of
+    // 300 nt is 1.9 G compares, about what filing and matching 120 fine items per key costs); beyond that the fine items,
+    // whose cost grows with the keys and not with their square
+    unsigned long long tile_budget = 8000000000ull;
+    if (const char *e = getenv("FQD_GROUP_TILE_BUDGET"))
+        tile_budget = strtoull(e, nullptr, 10);
+    if (tiles_possible(c, nseg) && h[3] <= tile_budget) {
+        if (getenv("FQD_DEBUG"))
+            fprintf(stderr, "[fqd] crowded buckets: %llu with %llu items, %llu pairs twice over: all pairs in tiles\n", h[0], h[1], h[3]);
+        c->gp_crowded_bits = B;
+        return grouped_tiles(c, U, d, 0, nseg);
+    }
     const uint32_t pieces = fqd::group_fine_items(d);      // fine items per crowded key
     const uint64_t key_cap = std::min<uint64_t>(h[1], U);          // (every crowded item could be a key of its own)
     uint64_t fine_limit = 0xFFFFFF00ull;            // (positions in the fine-item arrays are 32-bit)
@@ -631,14 +671,22 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
         const uint32_t n_pass = seg_hi - seg_lo;
         const bool fuse_passes = grouped && (seg_lo == 0 || pass0_held) && seg_hi == nseg && n_pass >= 2 && nseg <= 8 &&
                                  (uint64_t)n_pass * U < 0xFFFFFF00ull && !getenv("FQD_GROUP_NO_FUSED_PASSES");
+        bool used_refine = false;
         for (int attempt = 0;; attempt++) {
             c->route |= (grouped ? FQD_ROUTE_SEARCH_GROUPED : FQD_ROUTE_SEARCH_SORT) | (attempt ? FQD_ROUTE_SEARCH_RETRIED : 0u);
             if (fuse_passes && grouped) {
                 FQD_TRY(grouped_pass(c, c->seg_hashes.as<uint32_t>(), (uint64_t)n_pass * U, d, seg_lo, nseg, (uint32_t)U));
-                if (c->gp_crowded_bits) {
+                if (c->gp_crowded_bits && (c->gp_tiles || !c->gp_fine_ok) && tiles_possible(c, nseg)) {
+                    FQD_TRY(grouped_tiles(c, U, d, seg_lo, nseg));
+                } else if (c->gp_crowded_bits) {
                     bool refined = true;
                     FQD_TRY(grouped_refine(c, c->seg_hashes.as<uint32_t>(), U, nseg, &refined));
-                    if (!refined) {
+                    used_refine = true;
+                    if (!refined && tiles_possible(c, nseg)) {
+                        // more crowded keys than the fine items can address: all pairs of the crowded buckets, in tiles
+                        c->gp_crowded_bits = c->gp_crowded_bits_last;
+                        FQD_TRY(grouped_tiles(c, U, d, seg_lo, nseg));
+                    } else if (!refined) {
                         // more crowded keys than the fine items can address: the whole search once more on the sort path,
                         // which compares a crowded bucket's keys in place and needs no items at all (the reference's trie
                         // takes any distribution, _triemodule.c:380-495: this must never be an error)
@@ -735,7 +783,11 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
                 return rc_again;
             }
             if (cand_need > c->gp_cand_cap) {
-                if (cand_need > cand_budget) {
+                if (cand_need > cand_budget && used_refine && !c->gp_tiles && tiles_possible(c, nseg)) {
+                    // the finer pieces left a crowded family in one piece (its candidate pairs are beyond every
+                    // budget): from now on this context compares crowded buckets all pairs, tiled
+                    c->gp_tiles = true;
+                } else if (cand_need > cand_budget) {
                     grouped = false;
                 } else {
                     c->gp_cands.release();

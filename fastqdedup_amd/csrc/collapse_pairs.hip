@@ -15,6 +15,7 @@
 // read: 8 bytes through the partition twice and, for a read that is not the first of its key, two
 // record gathers (its own and the parked one, which the reads before it have pulled into L2).
 // bucket_pairs_compact_kernel then gathers one record per unique key into the unique table.
+#include <algorithm>
 #include <cstdlib>
 #include "fqd_internal.h"
 
@@ -33,7 +34,10 @@ __global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
     uint32_t *__restrict__ bucket_unique, uint32_t *__restrict__ overflow,
     uint32_t tag_mask /* ~0; tests: few bits => different keys share a tag */,
     const uint32_t *__restrict__ lens /* ragged keys: equal records of different length are different keys (the
-                                         bases past a key's end hold code 0, like its first symbol might); else NULL */)
+                                         bases past a key's end hold code 0, like its first symbol might); else NULL */,
+    fqd::PairsSlices sl /* slice != 0: a bucket's first `slice` items only; workgroups past n_buckets take the further
+                           SLICES of longer buckets (pairs_slices_kernel), pairs_merge_kernel joins their rows */,
+    uint32_t n_buckets)
 {
     __shared__ uint32_t s_tag[PD_SLOTS], s_rep[PD_SLOTS], s_cnt[PD_SLOTS], s_min[PD_SLOTS];
     __shared__ uint32_t s_wave_tot[PD_THREADS / 64];
@@ -44,10 +48,24 @@ __global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
     const uint32_t groups = 64u / q_per_rec;            // comparisons a wave does at once (q_per_rec <= 64)
     const uint32_t gl = lane / q_per_rec, ql = lane - gl * q_per_rec;
     const uint32_t b = blockIdx.x;
-    const uint32_t lo = bucket_start[b];
-    uint32_t hi = bucket_start[b + 1];
-    if (bucket_end)
-        hi = min(hi, bucket_end[b]);
+    uint32_t lo, hi;
+    bool sliced = b >= n_buckets;
+    if (sliced) {
+        if (b - n_buckets >= sl.ctr[1])
+            return;
+        const uint2 piece = sl.extra[b - n_buckets];
+        lo = piece.x;
+        hi = piece.y;
+    } else {
+        lo = bucket_start[b];
+        hi = bucket_start[b + 1];
+        if (bucket_end)
+            hi = min(hi, bucket_end[b]);
+        if (sl.slice && hi - lo > sl.slice) {
+            hi = lo + sl.slice;
+            sliced = true;
+        }
+    }
     for (uint32_t s = tid; s < PD_SLOTS; s += PD_THREADS)
         s_tag[s] = PD_EMPTY;
     __syncthreads();
@@ -170,10 +188,11 @@ __global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
         atomicOr(overflow, 1u);
     __syncthreads();
 
-    // live slots (count > 0: a key all of whose holders have weight 0 is not in the trie) -> tmp[lo ...)
+    // live slots (count > 0: a key all of whose holders have weight 0 is not in the trie; a SLICE keeps such rows -- their
+    // first position counts if another slice holds the key with a weight -- and the merge drops them) -> tmp[lo ...)
     uint32_t mine = 0;
     for (uint32_t s = tid; s < PD_SLOTS; s += PD_THREADS)
-        mine += (s_tag[s] != PD_EMPTY && s_cnt[s] > 0) ? 1u : 0u;
+        mine += (s_tag[s] != PD_EMPTY && (s_cnt[s] > 0 || sliced)) ? 1u : 0u;
     uint32_t incl = mine;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t up = __shfl_up(incl, o);
@@ -191,14 +210,168 @@ __global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
         total += s_wave_tot[wv];
     uint32_t out = lo + before;
     for (uint32_t s = tid; s < PD_SLOTS; s += PD_THREADS)
-        if (s_tag[s] != PD_EMPTY && s_cnt[s] > 0) {
+        if (s_tag[s] != PD_EMPTY && (s_cnt[s] > 0 || sliced)) {
             tmp_rep[out] = s_rep[s];
             tmp_count[out] = s_cnt[s];
             tmp_first[out] = s_min[s];
+            if (sliced)                     // (the slice's items are done with: a row's tag rides where they were)
+                sl.tags[(size_t)out * 2] = s_tag[s];
             out++;
         }
     if (tid == 0)
-        bucket_unique[b] = total;
+        (b >= n_buckets ? sl.extra_unique[b - n_buckets] : bucket_unique[b]) = total;
+}
+
+// ---- a bucket of very many pairs (ONE key with half a million copies: the skewed model's hot molecule) -------------
+// One workgroup walked it alone -- 500 K record comparisons at what 4 waves keep in flight: 5.4 ms of a 7 ms job. Such a
+// bucket is cut into SLICES of PD_SLICE items, each a workgroup of the dedupe kernel above with its own LDS table and its
+// rows where its items were; this kernel then joins the rows of a bucket's slices (a few hundred: the other keys of the
+// bucket + one row of the hot key per slice) through one more LDS table, keyed by (tag, parked position) in ONE 64-bit
+// word so that a claim and its position appear together, and leaves them where the compaction expects them.
+constexpr uint32_t PD_SLICE = 4096;
+
+__global__ void pairs_slices_kernel(const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ bucket_end,
+                                    uint32_t n_buckets, fqd::PairsSlices sl)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_buckets)
+        return;
+    const uint32_t lo = bucket_start[b];
+    uint32_t hi = bucket_start[b + 1];
+    if (bucket_end)
+        hi = min(hi, bucket_end[b]);
+    if (hi - lo <= sl.slice)
+        return;
+    const uint32_t k = (hi - lo + sl.slice - 1) / sl.slice - 1;        // slices beyond the first
+    const uint32_t g = atomicAdd(&sl.ctr[0], 1u), base = atomicAdd(&sl.ctr[1], k);     // (sum of k <= items / slice <= cap)
+    sl.big[g * 3] = b;
+    sl.big[g * 3 + 1] = base;
+    sl.big[g * 3 + 2] = k;
+    for (uint32_t t = 0; t < k; t++)
+        sl.extra[base + t] = make_uint2(lo + (t + 1) * sl.slice, min(hi, lo + (t + 2) * sl.slice));
+}
+
+__global__ __launch_bounds__(PD_THREADS) void pairs_merge_kernel(
+    const uint32_t *__restrict__ bucket_start, const uint4 *__restrict__ recs4, uint32_t q_per_rec,
+    uint32_t *__restrict__ tmp_rep, uint32_t *__restrict__ tmp_count, uint32_t *__restrict__ tmp_first,
+    uint32_t *__restrict__ bucket_unique, uint32_t *__restrict__ overflow, const uint32_t *__restrict__ lens,
+    fqd::PairsSlices sl)
+{
+    constexpr uint32_t PM_CHUNK = 1024;
+    __shared__ unsigned long long s_key[PD_SLOTS];
+    __shared__ uint32_t s_cnt[PD_SLOTS], s_min[PD_SLOTS];
+    __shared__ uint32_t s_slo[PM_CHUNK], s_row0[PM_CHUNK + 1];
+    __shared__ uint32_t s_wave_tot[PD_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_big = sl.ctr[0];
+    for (uint32_t g = blockIdx.x; g < n_big; g += gridDim.x) {
+        const uint32_t b = sl.big[g * 3], base = sl.big[g * 3 + 1], k = sl.big[g * 3 + 2], lo = bucket_start[b];
+        __syncthreads();
+        for (uint32_t s = tid; s < PD_SLOTS; s += PD_THREADS) {
+            s_key[s] = ~0ull;
+            s_cnt[s] = 0;
+            s_min[s] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        bool full = false;
+        // the slices' rows as one list (a slice leaves a handful of rows; walking the slices one after the other was a
+        // chain of dependent round trips per slice: 0.28 ms for the 122 slices of a key with 500 K copies)
+        for (uint32_t t0 = 0; t0 <= k; t0 += PM_CHUNK) {
+            const uint32_t nt = min(PM_CHUNK, k + 1 - t0);
+            __syncthreads();
+            for (uint32_t x = tid; x < nt; x += PD_THREADS) {
+                const uint32_t t = t0 + x;
+                s_slo[x] = t ? sl.extra[base + t - 1].x : lo;
+                s_row0[x] = t ? sl.extra_unique[base + t - 1] : bucket_unique[b];
+            }
+            __syncthreads();
+            if (wave == 0) {                       // exclusive prefix of the row counts (nt <= PM_CHUNK, 64 lanes)
+                uint32_t run = 0;
+                for (uint32_t x0 = 0; x0 < nt; x0 += 64) {
+                    const uint32_t v = x0 + lane < nt ? s_row0[x0 + lane] : 0u;
+                    uint32_t inc = v;
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t up = __shfl_up(inc, o);
+                        if ((int)lane >= o)
+                            inc += up;
+                    }
+                    if (x0 + lane < nt)
+                        s_row0[x0 + lane] = run + inc - v;
+                    run += __shfl(inc, 63);
+                }
+                if (lane == 0)
+                    s_row0[nt] = run;
+            }
+            __syncthreads();
+            const uint32_t n_rows = s_row0[nt];
+            for (uint32_t r = tid; r < n_rows; r += PD_THREADS) {
+                uint32_t a = 0, z = nt;
+                while (z - a > 1) {
+                    const uint32_t mid = (a + z) >> 1;
+                    if (s_row0[mid] <= r)
+                        a = mid;
+                    else
+                        z = mid;
+                }
+                const uint32_t at = s_slo[a] + (r - s_row0[a]);
+                const uint32_t tag = sl.tags[(size_t)at * 2], rep = tmp_rep[at];
+                const uint32_t cnt = tmp_count[at], first = tmp_first[at];
+                uint32_t slot = (tag * 0x9E3779B1u) >> 22, probes = 0;
+                for (;;) {
+                    const unsigned long long mine = (unsigned long long)tag << 32 | rep;
+                    const unsigned long long old = atomicCAS(&s_key[slot], ~0ull, mine);
+                    bool same = old == ~0ull;
+                    if (!same && (uint32_t)(old >> 32) == tag) {
+                        const uint32_t park = (uint32_t)old;
+                        same = !lens || lens[park] == lens[rep];
+                        for (uint32_t q = 0; q < q_per_rec && same; q++) {
+                            const uint4 x = recs4[(size_t)rep * q_per_rec + q], y = recs4[(size_t)park * q_per_rec + q];
+                            same = ((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w)) == 0;
+                        }
+                    }
+                    if (same) {
+                        atomicAdd(&s_cnt[slot], cnt);
+                        atomicMin(&s_min[slot], first);
+                        break;
+                    }
+                    slot = (slot + 1) & (PD_SLOTS - 1);
+                    if (++probes >= PD_SLOTS) {
+                        full = true;
+                        break;
+                    }
+                }
+            }
+        }
+        if (full)
+            atomicOr(overflow, 1u);
+        __syncthreads();                         // (every row of every slice has been read: the bucket's rows may be overwritten)
+        uint32_t mine = 0;
+        for (uint32_t s = tid; s < PD_SLOTS; s += PD_THREADS)
+            mine += (s_key[s] != ~0ull && s_cnt[s] > 0) ? 1u : 0u;
+        uint32_t incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if ((int)lane >= o)
+                incl += up;
+        }
+        if (lane == 63)
+            s_wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t out = lo + incl - mine, total = 0;
+        for (uint32_t wv = 0; wv < PD_THREADS / 64; wv++) {
+            out += wv < wave ? s_wave_tot[wv] : 0u;
+            total += s_wave_tot[wv];
+        }
+        for (uint32_t s = tid; s < PD_SLOTS; s += PD_THREADS)
+            if (s_key[s] != ~0ull && s_cnt[s] > 0) {
+                tmp_rep[out] = (uint32_t)s_key[s];
+                tmp_count[out] = s_cnt[s];
+                tmp_first[out] = s_min[s];
+                out++;
+            }
+        if (tid == 0)
+            bucket_unique[b] = total;
+    }
 }
 
 // one wave per bucket: the record at tmp_rep[bucket_start[b] + j] -> urecs[unique offset of b + j]
@@ -345,15 +518,29 @@ hipError_t launch_bucket_pairs_dedupe(const uint32_t *items, const uint32_t *buc
                                       uint32_t n_buckets, const uint32_t *recs, uint32_t stride_words,
                                       const uint32_t *weights, uint32_t *tmp_rep, uint32_t *tmp_count,
                                       uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st,
-                                      const uint32_t *lens)
+                                      const uint32_t *lens, PairsSlices sl)
 {
     if (!n_buckets || (stride_words & 3u))
         return n_buckets ? hipErrorInvalidValue : hipSuccess;
-    bucket_pairs_dedupe_kernel<<<n_buckets, PD_THREADS, 0, st>>>(
+    if (sl.slice)
+        pairs_slices_kernel<<<(n_buckets + 255) / 256, 256, 0, st>>>(bucket_start, bucket_end, n_buckets, sl);
+    bucket_pairs_dedupe_kernel<<<n_buckets + (sl.slice ? sl.cap : 0u), PD_THREADS, 0, st>>>(
         reinterpret_cast<const uint2 *>(items), bucket_start, bucket_end, reinterpret_cast<const uint4 *>(recs),
         stride_words / 4, weights, tmp_rep, tmp_count, tmp_first, bucket_unique, overflow,
-        getenv("FQD_PAIRS_TAG_MASK") ? (uint32_t)strtoul(getenv("FQD_PAIRS_TAG_MASK"), nullptr, 0) : 0xFFFFFFFFu, lens);
+        getenv("FQD_PAIRS_TAG_MASK") ? (uint32_t)strtoul(getenv("FQD_PAIRS_TAG_MASK"), nullptr, 0) : 0xFFFFFFFFu, lens, sl,
+        n_buckets);
+    if (sl.slice)
+        pairs_merge_kernel<<<std::min(sl.cap, 256u), PD_THREADS, 0, st>>>(bucket_start, reinterpret_cast<const uint4 *>(recs),
+                                                                         stride_words / 4, tmp_rep, tmp_count, tmp_first,
+                                                                         bucket_unique, overflow, lens, sl);
     return hipGetLastError();
+}
+
+uint32_t pairs_slice_items()
+{
+    if (const char *e = getenv("FQD_PAIRS_SLICE"))       // tests: small slices; 0 = one workgroup per bucket whatever its size
+        return (uint32_t)strtoul(e, nullptr, 10);
+    return PD_SLICE;
 }
 
 hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,

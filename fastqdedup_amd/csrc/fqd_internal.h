@@ -378,11 +378,21 @@ struct SegHashOut {
     uint32_t first = 0;           // (1: pass 0 is done by the compaction itself, see Pass0)
 };
 // collapse_pairs.hip -- sort-free collapse for records longer than one uint4
+// buckets of more than `slice` pairs are cut into slices (0: never)
+struct PairsSlices {
+    uint32_t slice = 0, cap = 0;       // items per slice; slices beyond the buckets' first (and long buckets) there is room for
+    uint2 *extra = nullptr;            // [cap] (first item, end) of each further slice
+    uint32_t *extra_unique = nullptr;  // [cap] rows each of them left
+    uint32_t *big = nullptr;           // [cap][3] bucket, its first further slice, how many
+    uint32_t *ctr = nullptr;           // [2] long buckets, further slices (zero at launch)
+    uint32_t *tags = nullptr;          // the items' array: a row's tag is written over the hash of item (slice start + row)
+};
 hipError_t launch_bucket_pairs_dedupe(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                       uint32_t n_buckets, const uint32_t *recs, uint32_t stride_words,
                                       const uint32_t *weights, uint32_t *tmp_rep, uint32_t *tmp_count,
                                       uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st,
-                                      const uint32_t *lens = nullptr);
+                                      const uint32_t *lens = nullptr, PairsSlices sl = PairsSlices());
+uint32_t pairs_slice_items();
 hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                        const uint32_t *tmp_rep, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                        const uint32_t *recs, uint32_t stride_words, IdSource read_ids, uint32_t *urecs,
@@ -581,6 +591,11 @@ hipError_t launch_group_refine_items(const uint32_t *items, const uint32_t *buck
                                      const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t *seen,
                                      uint32_t *out_hash, uint32_t *out_val, unsigned long long *n_keys, uint64_t key_cap,
                                      hipStream_t st, uint32_t d);
+hipError_t launch_group_crowded_tiles(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                      const uint32_t *list, const unsigned long long *counts, unsigned long long *tile_prefix,
+                                      uint32_t fused_U, uint32_t seg0, const uint32_t *urecs, const uint32_t *ulens, KeyShape sh,
+                                      uint32_t d, uint32_t nseg, uint32_t *edges, unsigned long long *edge_count,
+                                      uint64_t edge_cap, hipStream_t st);
 hipError_t launch_group_verify_refined(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
                                        const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t nseg,
                                        const uint32_t *seg_hashes, uint64_t U, uint32_t bucket_bits,

@@ -761,24 +761,16 @@ __global__ void gp_mark_crowded_kernel(const uint32_t *__restrict__ bucket_start
     if (big) {
         list[atomicAdd(&counts[0], 1ull)] = b;
         atomicAdd(&counts[1], (unsigned long long)m);
+        atomicAdd(&counts[3], (unsigned long long)m * m);      // (all pairs in tiles: that many compares, twice)
     }
 }
 
-// the hash of a key with the pieces of `set` (bits over k pieces) masked out
-__device__ __forceinline__ uint32_t gp_fine_hash(const uint32_t *__restrict__ rec, uint32_t K, uint32_t W, uint32_t len,
-                                                 uint32_t set, uint32_t k)
-{
-    uint32_t part = 0;
-    for (uint32_t w = 0; w < W; w++) {
-        uint32_t gone = 0;
-        for (uint32_t j = 0; j < k; j++)
-            if (set >> j & 1u)
-                gone |= fqd_range_mask(w, len * j / k, len * (j + 1) / k);
-        for (uint32_t kk = 0; kk < K; kk++)
-            part += fqd_mix32((rec[w * K + kk] & ~gone) + (w * K + kk + 1u) * 0x9E3779B1u);
-    }
-    return fqd_mix32(part + fqd_mix32(len * 0x9E3779B1u + set * 0x85EBCA77u + 0x27D4EB2Fu));
-}
+// The hash of a key with the pieces of `set` (bits over k pieces) masked out = a mix of the SUM of the hashes of the
+// pieces left in (each piece hashed with its words' numbers, so the sum is position-aware): a key's k piece hashes are
+// worked out once, one pass over its record, and each of its 16 / 120 / 56 items is the total minus d of them. (Round 4's
+// first version hashed the whole masked record per item: 120 passes over a 120-byte record per key, 5.4 ms for the 62 K
+// crowded keys of the skewed config 4.)
+constexpr uint32_t GP_FINE_K_MAX = 16;
 
 // every key with an item in a crowded bucket files its fine items (once: seen[uid])
 __global__ __launch_bounds__(256) void gp_refine_items_kernel(
@@ -789,10 +781,12 @@ __global__ __launch_bounds__(256) void gp_refine_items_kernel(
     uint32_t d)
 {
     __shared__ uint32_t s_set[GP_FINE_MAX_SETS];
-    const uint32_t n_sets = gp_fine_sets(d), k = gp_fine_k(d);
+    __shared__ uint32_t s_ph[256][GP_FINE_K_MAX + 1];
+    const uint32_t n_sets = gp_fine_sets(d), k = gp_fine_k(d), K = sh.planes;
     if (threadIdx.x < n_sets)
         s_set[threadIdx.x] = gp_fine_set(d, threadIdx.x);
     __syncthreads();
+    uint32_t *ph = s_ph[threadIdx.x];
     // (every workgroup walks the whole list and takes its share of each bucket's items: there may be ONE crowded
     // bucket with a hundred thousand items)
     const uint32_t n_list = (uint32_t)counts[0];
@@ -812,8 +806,25 @@ __global__ __launch_bounds__(256) void gp_refine_items_kernel(
                 continue;
             const uint32_t *rec = urecs + (uint64_t)uid * sh.stride;
             const uint32_t len = fqd_key_len(sh, ulens, uid);
+            uint32_t total = 0;
+            for (uint32_t p = 0; p < k; p++) {
+                const uint32_t plo = len * p / k, phi = len * (p + 1) / k;
+                uint32_t h = 0;
+                for (uint32_t w = plo >> 5; plo < phi && w <= (phi - 1u) >> 5; w++) {
+                    const uint32_t m = fqd_range_mask(w, plo, phi);
+                    for (uint32_t kk = 0; kk < K; kk++)
+                        h += fqd_mix32((rec[w * K + kk] & m) + ((w * K + kk) * GP_FINE_K_MAX + p + 1u) * 0x9E3779B1u);
+                }
+                ph[p] = h;
+                total += h;
+            }
+            const uint32_t len_mix = len * 0x9E3779B1u + 0x27D4EB2Fu;
             for (uint32_t j = 0; j < n_sets; j++) {
-                out_hash[at * n_sets + j] = gp_fine_hash(rec, sh.planes, sh.words, len, s_set[j], k);
+                const uint32_t set = s_set[j];
+                uint32_t part = total;
+                for (uint32_t rest = set; rest; rest &= rest - 1u)
+                    part -= ph[__ffs(rest) - 1];
+                out_hash[at * n_sets + j] = fqd_mix32(part + fqd_mix32(len_mix + set * 0x85EBCA77u));
                 out_val[at * n_sets + j] = uid | (j << GP_FINE_SET_SHIFT);
             }
         }
@@ -944,6 +955,191 @@ __global__ __launch_bounds__(256) void gp_verify_refined_kernel(
                     reinterpret_cast<uint2 *>(edges)[at + e] = s_edge[e];
         }
     }
+}
+
+// ---- crowded buckets, the last resort: ALL PAIRS of a bucket, tiled over the whole GPU ---------------------------
+// The fine pieces above split a crowded bucket only when its keys differ OUTSIDE a few pieces; a family that varies
+// inside one piece (all 4^8 values of eight adjacent bases of a 300-nt key: 65 536 keys, each with 276 neighbours
+// within distance 2) stays one group, its candidate pairs outgrow every budget, and until round 4 the search then took
+// the sort path -- which walks such a run in ONE wave: 19 s for 25 M reads. All pairs of m keys are m^2 / 2 cheap
+// compares when they are spread over the GPU: tiles of 128 x 128 rows, both tiles' records staged in LDS, a row per
+// thread against every row of the other tile (a broadcast read per word), hash first (a bucket holds many segment
+// values), then the exact distance and the first-agreeing-segment rule -- 2 G pairs of 128-byte records in a few ms.
+constexpr uint32_t CT_TS = 128, CT_WCAP = 192;
+
+__global__ void gp_tile_prefix_kernel(const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ bucket_end,
+                                      const uint32_t *__restrict__ list, const unsigned long long *__restrict__ counts,
+                                      unsigned long long *__restrict__ tile_prefix /* [n_list + 1] */)
+{
+    if (blockIdx.x || threadIdx.x)
+        return;
+    const uint32_t n_list = (uint32_t)counts[0];
+    unsigned long long run = 0;
+    for (uint32_t li = 0; li < n_list; li++) {
+        const uint32_t b = list[li];
+        uint32_t hi = bucket_start[b + 1];
+        if (bucket_end)
+            hi = min(hi, bucket_end[b]);
+        const unsigned long long T = (hi - bucket_start[b] + CT_TS - 1) / CT_TS;
+        tile_prefix[li] = run;
+        run += T * (T + 1) / 2;
+    }
+    tile_prefix[n_list] = run;
+}
+
+__global__ __launch_bounds__(CT_TS) void gp_crowded_tiles_kernel(
+    const uint2 *__restrict__ items, const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ bucket_end,
+    const uint32_t *__restrict__ list, const unsigned long long *__restrict__ counts,
+    const unsigned long long *__restrict__ tile_prefix, uint32_t fused_U, uint32_t seg0,
+    const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t d, uint32_t nseg,
+    uint32_t *__restrict__ edges, unsigned long long *__restrict__ edge_count, uint64_t edge_cap)
+{
+    extern __shared__ uint32_t ct_smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t row = sh.stride + 1u, q4 = sh.stride / 4u, K = sh.planes, W = sh.words;
+    uint32_t *rec_i = ct_smem, *rec_j = rec_i + CT_TS * row;
+    uint32_t *h_j = rec_j + CT_TS * row, *uid_j = h_j + CT_TS, *uid_i = uid_j + CT_TS, *seg_j = uid_i + CT_TS;
+    uint32_t *seg_masks = seg_j + CT_TS;                    // [W][8]: bits of word w inside main segment s (keys of ONE length)
+    uint2 *wbuf = reinterpret_cast<uint2 *>(seg_masks + W * 8u + (W & 1u ? 8u : 0u));      // [waves][CT_WCAP]
+    __shared__ uint32_t s_wn[CT_TS / 64];
+    if (lane == 0)
+        s_wn[wave] = 0;
+    for (uint32_t x = tid; x < W * 8u; x += CT_TS) {
+        const uint32_t w = x >> 3, s2 = x & 7u;
+        uint32_t slo = 0, shi = 0;
+        if (s2 < nseg)
+            fqd_segment(sh.max_len, s2, nseg, slo, shi);
+        seg_masks[x] = s2 < nseg ? fqd_range_mask(w, slo, shi) : 0u;
+    }
+    const uint32_t n_list = (uint32_t)counts[0];
+    const unsigned long long total = tile_prefix[n_list];
+    auto flush = [&](uint32_t have) {
+        unsigned long long g = 0;
+        if (lane == 0)
+            g = atomicAdd(edge_count, (unsigned long long)have);
+        g = __shfl(g, 0);
+        for (uint32_t e = lane; e < have; e += 64)
+            if (g + e < edge_cap)
+                reinterpret_cast<uint2 *>(edges)[g + e] = wbuf[wave * CT_WCAP + e];
+    };
+    auto note = [&](bool hit, uint32_t u, uint32_t v) {          // (all lanes of the wave, converged)
+        const unsigned long long m = __ballot(hit);
+        if (!m)
+            return;
+        const uint32_t n = (uint32_t)__popcll(m);
+        uint32_t have = s_wn[wave];
+        if (have + n > CT_WCAP) {
+            flush(have);
+            have = 0;
+        }
+        if (hit)
+            wbuf[wave * CT_WCAP + have + (uint32_t)__popcll(m & fqd_lanemask_lt())] = make_uint2(min(u, v), max(u, v));
+        if (lane == 0)
+            s_wn[wave] = have + n;
+    };
+    for (unsigned long long g = blockIdx.x; g < total; g += gridDim.x) {
+        // which bucket, which pair of tiles
+        uint32_t a = 0, z = n_list;
+        while (z - a > 1) {
+            const uint32_t mid = (a + z) >> 1;
+            if (tile_prefix[mid] <= g)
+                a = mid;
+            else
+                z = mid;
+        }
+        const uint32_t b = list[a], lo = bucket_start[b];
+        uint32_t hi = bucket_start[b + 1];
+        if (bucket_end)
+            hi = min(hi, bucket_end[b]);
+        const uint32_t m = hi - lo, T = (m + CT_TS - 1) / CT_TS;
+        const unsigned long long idx = g - tile_prefix[a];
+        // row-major over the upper triangle: row ti holds T - ti pairs (ti, ti .. T - 1)
+        uint32_t ti = (uint32_t)(((2.0 * T + 1.0) - sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)idx)) * 0.5);
+        auto row_start = [&](uint32_t r) { return (unsigned long long)r * T - (unsigned long long)r * (r - 1) / 2; };
+        while (ti > 0 && row_start(ti) > idx)
+            ti--;
+        while (ti + 1 < T && row_start(ti + 1) <= idx)
+            ti++;
+        const uint32_t tj = ti + (uint32_t)(idx - row_start(ti));
+        const uint32_t ni = min(CT_TS, m - ti * CT_TS), nj = min(CT_TS, m - tj * CT_TS);
+        __syncthreads();                                  // (the tiles of the pair before are done with)
+        // the rows' items, then their records as one coalesced stream of uint4 per tile
+        uint32_t my_h = 0, my_uid = 0, my_seg = 0;
+        if (tid < ni) {
+            const uint2 it = items[lo + ti * CT_TS + tid];
+            my_h = it.x;
+            my_uid = fused_U ? it.y % fused_U : it.y;
+            my_seg = seg0 + (fused_U ? it.y / fused_U : 0u);
+            uid_i[tid] = my_uid;
+        }
+        if (tid < nj) {
+            const uint2 it = items[lo + tj * CT_TS + tid];
+            h_j[tid] = it.x;
+            uid_j[tid] = fused_U ? it.y % fused_U : it.y;
+            seg_j[tid] = seg0 + (fused_U ? it.y / fused_U : 0u);
+        }
+        __syncthreads();
+        const uint4 *recs4 = reinterpret_cast<const uint4 *>(urecs);
+        for (uint32_t x0 = tid; x0 < CT_TS * q4; x0 += 4 * CT_TS) {
+            uint4 vi[4], vj[4];
+#pragma unroll
+            for (uint32_t t = 0; t < 4; t++) {             // (clamped, unconditional: in flight together)
+                const uint32_t x = x0 + t * CT_TS, r = x / q4, q = x - r * q4;
+                vi[t] = recs4[(size_t)uid_i[min(r, ni - 1)] * q4 + q];
+                vj[t] = recs4[(size_t)uid_j[min(r, nj - 1)] * q4 + q];
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < 4; t++) {
+                const uint32_t x = x0 + t * CT_TS, r = x / q4, q = x - r * q4;
+                if (x < CT_TS * q4) {
+                    uint32_t *di = rec_i + r * row + q * 4u, *dj = rec_j + r * row + q * 4u;
+                    if (r < ni) { di[0] = vi[t].x; di[1] = vi[t].y; di[2] = vi[t].z; di[3] = vi[t].w; }
+                    if (r < nj) { dj[0] = vj[t].x; dj[1] = vj[t].y; dj[2] = vj[t].z; dj[3] = vj[t].w; }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t my_len = tid < ni ? fqd_key_len(sh, ulens, my_uid) : 0u;
+        const uint32_t *mine = rec_i + tid * row;
+        for (uint32_t k = 0; k < nj; k++) {
+            bool hit = false;
+            const uint32_t uk = uid_j[k];
+            if (tid < ni && h_j[k] == my_h && seg_j[k] == my_seg && (ti != tj || k > tid) && uk != my_uid &&
+                (!sh.ragged || fqd_key_len(sh, ulens, uk) == my_len)) {
+                const uint32_t *other = rec_j + k * row;
+                uint32_t dist = 0, seg_mis = 0;
+                for (uint32_t w = 0; w < W && dist <= d; w++) {
+                    uint32_t dw = 0;
+                    for (uint32_t kk = 0; kk < K; kk++)
+                        dw |= mine[w * K + kk] ^ other[w * K + kk];
+                    if (dw) {
+                        dist += __popc(dw);
+                        if (!sh.ragged) {
+                            for (uint32_t s2 = 0; s2 < nseg && s2 < 8; s2++)
+                                seg_mis |= (dw & seg_masks[w * 8u + s2]) ? 1u << s2 : 0u;
+                        } else {
+                            for (uint32_t s2 = 0; s2 < nseg; s2++) {
+                                uint32_t slo, shi;
+                                fqd_segment(my_len, s2, nseg, slo, shi);
+                                seg_mis |= (dw & fqd_range_mask(w, slo, shi)) ? 1u << s2 : 0u;
+                            }
+                        }
+                    }
+                }
+                if (dist && dist <= d) {
+                    uint32_t first = 0;
+                    while (first < nseg && (seg_mis >> first & 1u))
+                        first++;
+                    hit = first == my_seg;               // reported in the pass of the FIRST segment the pair agrees on
+                }
+            }
+            note(hit, my_uid, uk);
+        }
+    }
+    __syncthreads();
+    const uint32_t left = s_wn[wave];
+    if (left)
+        flush(left);
 }
 
 }  // namespace
@@ -1119,6 +1315,25 @@ hipError_t launch_group_refine_items(const uint32_t *items, const uint32_t *buck
     gp_refine_items_kernel<<<1024, 256, 0, st>>>(reinterpret_cast<const uint2 *>(items), bucket_start, bucket_end, list,
                                                  counts, fused_U, urecs, ulens, sh, seen, out_hash, out_val, n_keys,
                                                  key_cap, d);
+    return hipGetLastError();
+}
+
+// all pairs of the crowded buckets (marked by launch_group_mark_crowded; list / counts from there), tiled:
+// tile_prefix has room for n_buckets + 1 words of 8 bytes. Records of up to 32 words; nseg <= 8.
+hipError_t launch_group_crowded_tiles(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
+                                      const uint32_t *list, const unsigned long long *counts, unsigned long long *tile_prefix,
+                                      uint32_t fused_U, uint32_t seg0, const uint32_t *urecs, const uint32_t *ulens, KeyShape sh,
+                                      uint32_t d, uint32_t nseg, uint32_t *edges, unsigned long long *edge_count,
+                                      uint64_t edge_cap, hipStream_t st)
+{
+    if (sh.stride > 32 || (sh.stride & 3u) || nseg > 8)
+        return hipErrorInvalidValue;
+    gp_tile_prefix_kernel<<<1, 64, 0, st>>>(bucket_start, bucket_end, list, counts, tile_prefix);
+    const size_t lds = ((size_t)2 * CT_TS * (sh.stride + 1) + 4 * CT_TS + (size_t)sh.words * 8 + 8) * 4 +
+                       (size_t)(CT_TS / 64) * CT_WCAP * 8;
+    gp_crowded_tiles_kernel<<<4096, CT_TS, lds, st>>>(reinterpret_cast<const uint2 *>(items), bucket_start, bucket_end, list,
+                                                      counts, tile_prefix, fused_U, seg0, urecs, ulens, sh, d, nseg, edges,
+                                                      edge_count, edge_cap);
     return hipGetLastError();
 }
 

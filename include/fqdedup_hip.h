@@ -100,6 +100,8 @@ typedef struct fqd_summary {
                                             * segments instead of pairwise                                                 */
 #define FQD_ROUTE_ONE_KERNEL_COLLAPSE 0x8000u /* dedupe + compaction (+ search pass 0) of the compact records ran as ONE
                                             * persistent kernel: no tmp rows between the LDS table and the unique table   */
+#define FQD_ROUTE_SEARCH_TILES    0x10000u /* crowded segment values that the finer segments could not split (a family
+                                            * varying inside one piece) were compared ALL PAIRS, tiled over the GPU         */
 int fqd_get_route(const fqd_ctx *ctx, uint32_t *route);
 
 /* Packed-key geometry chosen by fqd_pack_keys (DESIGN.md "data layout"). */

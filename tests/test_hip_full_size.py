@@ -114,8 +114,8 @@ def test_skewed_workload_matches_oracle(oracle):
         assert np.array_equal(got2.kept_read_ids, want2["kept_read_ids"]), (method, d)
 
 
-@pytest.mark.parametrize("n,L", [(2_000_000, 32), (1_000_000, 300)])
-def test_skewed_workload_at_distance_2_matches_oracle(oracle, n, L):
+@pytest.mark.parametrize("n,L,ladder", [(2_000_000, 32, True), (1_000_000, 300, False), (1_000_000, 300, True)])
+def test_skewed_workload_at_distance_2_matches_oracle(oracle, n, L, ladder):
     """The skewed model at Hamming d = 2 (BASELINE config 4's distance; 2 M reads of 32 nt, and config 4's own key length:
     1 M reads of 300 nt -- the (hash, position) collapse, 128-byte records, the cooperative verification): crowded segment values are
     matched on finer pieces -- every set of 2 of 8 pieces masked out, a pair reported under the smallest set that holds
@@ -128,10 +128,11 @@ def test_skewed_workload_at_distance_2_matches_oracle(oracle, n, L):
     d = 2
     ctx = F.Context(0)
     dev = torch.empty(n * L, dtype=torch.uint8, device="cuda:0")
-    # (300-nt keys: without the model's ladder -- its 4^8 keys vary inside ONE of the 16 fine pieces of a 300-nt key and
-    # stay one group of the refinement, which then gives way to the sort path: correct, quadratic, and not this test's
-    # subject; at 32 nt a piece is two bases and the ladder splits into groups of 256)
-    skew = SKEW if L == 32 else {"hot": 0.02, "ladder": 0.0, "lowc_every": 100}
+    # (300-nt keys without the model's ladder: the refinement alone; with it: the ladder's 4^8 keys vary inside ONE of the
+    # 16 fine pieces of a 300-nt key and stay one group of the refinement -- the context then compares its crowded buckets
+    # all pairs in tiles (group.hip "the last resort"; until round 4 this case fell to the sort path, quadratic in one
+    # wave); at 32 nt a piece is two bases and the ladder splits into groups of 256)
+    skew = SKEW if ladder else {"hot": 0.02, "ladder": 0.0, "lowc_every": 100}
     ctx.synth_keys(dev, n, 0, n, L, L, 1004, skew=skew)
     host = dev.cpu().numpy()
     runs = {m: _OracleRun(oracle, host, n, L, d, m) for m in ("directional", "adjacency")}
@@ -143,9 +144,10 @@ def test_skewed_workload_at_distance_2_matches_oracle(oracle, n, L):
         assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
     # (32-nt keys at d = 2: a third of a key is 10-11 bases -- even uniform keys share segment values by the dozen, the
     # candidate lists outgrow their budget and the search takes the sort path, skew or not; 300-nt keys must not sort)
-    assert warm.route["search_refined"], warm.route
+    assert warm.route["search_refined"] or warm.route["search_tiles"], warm.route
     if L == 300:
         assert warm.route["search_grouped"] and not warm.route["search_sort"], warm.route
+        assert warm.route["search_tiles"], warm.route       # (few enough crowded pairs to take them all, with or without the ladder)
     want2 = runs["adjacency"].result()
     got2 = F.cluster_keys(dev, key_len=L, max_distance=d, method="adjacency", context=ctx)
     assert (got2.n_unique, got2.n_clusters) == (want2["n_unique"], want2["n_clusters"])

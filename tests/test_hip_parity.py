@@ -278,6 +278,7 @@ def test_crowded_buckets_are_matched_on_finer_pieces(F, oracle, monkeypatch, d):
     buckets take that way. Against the oracle's trie (`TrieNode_FindNearest`, `_triemodule.c:380-495`), two methods."""
     from fastqdedup_amd.synth import SKEW, fixed_offsets, synth_keys
     monkeypatch.setenv("FQD_GROUP_CROWDED_LIMIT", "64")
+    monkeypatch.setenv("FQD_GROUP_TILE_BUDGET", "0")          # (so few crowded keys would go all pairs in tiles by default)
     n, L = 300_000, 32
     keys = synth_keys(n, L, 12, 900 + d, sub_rate=4e-3, n_rate=1e-4, skew=SKEW)
     raw = np.ascontiguousarray(keys).reshape(-1)
@@ -289,13 +290,17 @@ def test_crowded_buckets_are_matched_on_finer_pieces(F, oracle, monkeypatch, d):
             assert (got.n_unique, got.n_clusters, got.n_kept) == (want["n_unique"], want["n_clusters"],
                                                                   len(want["kept_read_ids"])), (d, method, job)
             assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), (d, method, job)
-    assert got.route["search_refined"] and got.route["search_grouped"], got.route
+    # (d = 3 on 32-nt keys: the candidates of the fine groups outgrow the budget and the context turns to all pairs in tiles)
+    assert (got.route["search_refined"] or got.route["search_tiles"]) and got.route["search_grouped"], got.route
+    assert not got.route["search_sort"], got.route
 
 
-def test_crowded_buckets_beyond_the_fine_items_take_the_sort_path(F, oracle, monkeypatch):
+def test_crowded_buckets_beyond_the_fine_items_go_all_pairs(F, oracle, monkeypatch):
     """A segment value shared by thousands of keys is matched on finer segments (group.hip "crowded buckets"); when the
-    crowded keys are more than the fine items can address the search must run again on the sort path -- never an error:
-    the reference's trie takes any distribution (`_triemodule.c:380-495`). FQD_GROUP_FINE_LIMIT makes "too many" small."""
+    crowded keys are more than the fine items can address, the crowded buckets are compared ALL PAIRS in tiles (group.hip
+    "the last resort"), and where that is switched off (or the records are too long for its LDS tiles) the search runs
+    again on the sort path -- never an error: the reference's trie takes any distribution (`_triemodule.c:380-495`).
+    FQD_GROUP_FINE_LIMIT makes "too many" small."""
     from fastqdedup_amd.synth import SKEW, fixed_offsets, synth_keys
     monkeypatch.setenv("FQD_FUSED_MIN_READS", "100000")
     n, L = 300_000, 32
@@ -303,13 +308,44 @@ def test_crowded_buckets_beyond_the_fine_items_take_the_sort_path(F, oracle, mon
     raw = np.ascontiguousarray(keys).reshape(-1)
     want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=1, method="directional")
     ctx = F.Context(0)
+    monkeypatch.setenv("FQD_GROUP_TILE_BUDGET", "0")          # (so few crowded keys would go all pairs in tiles by default)
     got = F.cluster_keys(raw, key_len=L, max_distance=1, method="directional", context=ctx)      # (the context meets the skew)
-    assert got.route["search_refined"], got.route
+    assert got.route["search_refined"] and not got.route["search_tiles"], got.route
     monkeypatch.setenv("FQD_GROUP_FINE_LIMIT", "1000")
     got = F.cluster_keys(raw, key_len=L, max_distance=1, method="directional", context=ctx)
-    assert not got.route["search_refined"] and got.route["search_sort"] and got.route["search_retried"], got.route
+    assert got.route["search_tiles"] and got.route["search_grouped"] and not got.route["search_sort"], got.route
     assert (got.n_unique, got.n_clusters, got.n_kept) == (want["n_unique"], want["n_clusters"], len(want["kept_read_ids"]))
     assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+    monkeypatch.setenv("FQD_GROUP_NO_TILES", "1")
+    got = F.cluster_keys(raw, key_len=L, max_distance=1, method="directional", context=ctx)
+    assert not got.route["search_tiles"] and got.route["search_sort"] and got.route["search_retried"], got.route
+    assert (got.n_unique, got.n_clusters, got.n_kept) == (want["n_unique"], want["n_clusters"], len(want["kept_read_ids"]))
+    assert np.array_equal(got.kept_read_ids, want["kept_read_ids"])
+
+
+@pytest.mark.parametrize("L,d,budget", [(300, 1, "0"), (100, 2, "0"), (300, 2, None), (100, 4, None)])
+def test_a_family_inside_one_piece_goes_all_pairs(F, oracle, monkeypatch, L, d, budget):
+    """The skewed model's LADDER -- every value of eight adjacent bases behind one prefix -- varies inside ONE fine piece
+    of a long key: the refinement cannot split it, its candidate pairs outgrow the budget, and the context then compares
+    crowded buckets all pairs in tiles (`gp_crowded_tiles_kernel`) instead of walking them on the sort path. d = 4 has no
+    fine pieces at all and goes to the tiles at once, and so do crowded buckets of few enough pairs (budget None: the
+    default; "0": the fine pieces first, as for a job with millions of crowded keys). Against the oracle's trie
+    (`TrieNode_FindNearest`, `_triemodule.c:380-495`)."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_EDGES", "grouped")
+    if budget is not None:
+        monkeypatch.setenv("FQD_GROUP_TILE_BUDGET", budget)
+    n = 120_000
+    keys = synth_keys(n, L, 12, 177, sub_rate=3e-3, n_rate=1e-4, skew={"hot": 0.02, "ladder": 0.15, "lowc_every": 100})
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    ctx = F.Context(0)
+    for method in ("directional", "adjacency"):
+        want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=d, method=method)
+        got = F.cluster_keys(raw, key_len=L, max_distance=d, method=method, context=ctx)
+        assert (got.n_unique, got.n_clusters, got.n_kept) == (want["n_unique"], want["n_clusters"],
+                                                              len(want["kept_read_ids"])), (method, got.route)
+        assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), method
+        assert got.route["search_tiles"] and not got.route["search_sort"], (method, got.route)
 
 
 @pytest.mark.parametrize("case", ["plain", "n_keys", "two_planes", "rows_over_150", "probe_overflow", "edge_overflow",
@@ -418,7 +454,7 @@ def test_routed_collapse_does_search_pass_0(F, oracle, monkeypatch, case):
             assert r["pass0_in_collapse"] and r["search_retried"] and not r["pass0_continued"]
         elif case == "ladder":          # (the skewed model's hot key overfills a slab: with the spill list from then on)
             assert r["fused_pack"] and r["compact_records"] and r["spill_list"] and not r["restarted"], r
-            assert r["search_refined"], r       # (the ladder shares one segment-0 value: matched on finer segments)
+            assert r["search_refined"] or r["search_tiles"], r       # (the ladder shares one segment-0 value: matched on finer segments, or all pairs in tiles)
         else:
             assert r["fused_pack"] and r["compact_records"] and r["pass0_in_collapse"] and r["pass0_continued"], (case, r)
             assert r["search_grouped"] and not r["restarted"]
@@ -509,15 +545,21 @@ def test_compact_records_over_lengths_and_n_rates(F, oracle, monkeypatch, L, n_r
     assert np.array_equal(other.kept_read_ids, got.kept_read_ids)
 
 
-@pytest.mark.parametrize("case", ["plain", "weights", "tag_collisions", "heavy_key", "few_buckets", "len300_d2"])
+@pytest.mark.parametrize("case", ["plain", "weights", "tag_collisions", "heavy_key", "few_buckets", "len300_d2",
+                                  "slices", "slices_weights", "slices_tag_collisions", "slices_heavy_key"])
 def test_long_record_collapse_without_sort_matches_oracle(F, oracle, monkeypatch, case):
     """Keys above 32 nt (records longer than one uint4) collapse through (hash, position) pairs: the
     pairs are partitioned, an LDS table per bucket matches them, records are compared where they
     lie (collapse_pairs.hip). Same answer as the oracle and as the sort-based collapse -- with
     weights, with different keys sharing a tag (masked tags), with a key whose copies overfill a
-    slab (exact bucket sizes then), and when a bucket overflows the table (sort-based path then)."""
+    slab (exact bucket sizes then), and when a bucket overflows the table (sort-based path then). `slices*`: every
+    bucket cut into slices of 64 pairs, a workgroup each, their rows joined by `pairs_merge_kernel` (what a bucket of
+    more than 4096 pairs gets by default: `heavy_key`'s 5000 copies are two slices)."""
     from fastqdedup_amd.synth import fixed_offsets, synth_keys
     n, L, d = (120_000, 100, 1) if case != "len300_d2" else (70_000, 300, 2)
+    if case.startswith("slices"):
+        monkeypatch.setenv("FQD_PAIRS_SLICE", "64")
+        case = case[7:] or "plain"
     if case == "heavy_key":
         n = 300_000                      # two partition levels: the second one works on slabs
     keys = synth_keys(n, L, 12, 61, sub_rate=2e-3, n_rate=2e-4)
@@ -1390,14 +1432,16 @@ def test_ragged_keys_collapse_without_a_sort(F, oracle, monkeypatch):
     strs += ["A" * k for k in range(1, 70)] * 3 + ["AC", "ACA", "ACAA", "AC"]
     raw, off = _pack(strs)
     want = oracle.dedup(raw, off, max_distance=1, method="directional")
-    for path in ("pairs", "sort"):
-        monkeypatch.setenv("FQD_COLLAPSE", path)
+    for path in ("pairs", "pairs in slices of 64", "sort"):
+        monkeypatch.setenv("FQD_COLLAPSE", path.split()[0])
+        if "slices" in path:
+            monkeypatch.setenv("FQD_PAIRS_SLICE", "64")       # (the rows of a bucket's slices joined by pairs_merge_kernel)
         ctx = F.Context(0)
         got = F.cluster_keys(raw, off, max_distance=1, method="directional", context=ctx)
         assert got.n_unique == want["n_unique"], path
         assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), path
         times = ctx.kernel_times(reset=True)
-        if path == "pairs":
+        if path != "sort":
             assert times["bucket_dedupe_kernel"][1] and not times["head_flags_kernel"][1], times
 
 
