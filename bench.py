@@ -46,13 +46,13 @@ WORKLOADS = {
     "config3_skew_adj": dict(n=50_000_000, L=32, umi=32, d=1, edit=False, method="adjacency", seed=1003, skew=True,
                              name="config 3's shape under the skewed model, Hamming d=1, adjacency"),
     # config 4's shape (300-nt keys, d = 2) under the skewed model: crowded segment values matched on 120 finer items per key
-    # (without the model's LADDER: all 4^8 values of eight adjacent bases lie inside ONE of the 16 fine pieces of a 300-nt
-    # key, the 65 536 keys stay one group of the refinement and the search takes the quadratic sort path -- 19 s)
-    "config4_skew": dict(n=25_000_000, L=300, umi=300, d=2, edit=False, method="directional", seed=1004,
-                         skew={"hot": 0.02, "ladder": 0.0, "lowc_every": 100},
-                         name="config 4's shape (25M per GPU, 300-nt keys) under the skewed model without its ladder "
-                              "(a key with 500 K copies, heavy-tailed abundance, 1 % of the molecules poly-A in their "
-                              "first half), Hamming d=2, directional"),
+    # (round 4, first version: without the model's LADDER -- all 4^8 values of eight adjacent bases lie inside ONE of the 16
+    # fine pieces of a 300-nt key, the keys stayed one group of the refinement and the search took the quadratic sort path,
+    # 19 s; crowded buckets now go all pairs in tiles, group.hip "the last resort", and the ladder is back in)
+    "config4_skew": dict(n=25_000_000, L=300, umi=300, d=2, edit=False, method="directional", seed=1004, skew=True,
+                         name="config 4's shape (25M per GPU, 300-nt keys) under the skewed model (a key with 500 K "
+                              "copies, heavy-tailed abundance, 1 % of the molecules poly-A in their first half, 1 % of "
+                              "the reads on a ladder of 4^8 keys), Hamming d=2, directional"),
     # SURVEY.md 8d's variant of configs[4]: 1 % of the reads are one base short or long, so the keys
     # have three lengths and the Levenshtein search proper runs (equal lengths at d=1 reduce to Hamming)
     "config5v": dict(n=50_000_000, L=300, umi=300, d=1, edit=True, method="adjacency", seed=1005, indel_rate=0.01,

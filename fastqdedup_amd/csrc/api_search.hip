@@ -430,8 +430,10 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
         uint32_t *list = reinterpret_cast<uint32_t *>(flags + (((size_t)n_buckets + 63) & ~(size_t)63));
         unsigned long long *counts = reinterpret_cast<unsigned long long *>(list + n_buckets);
         HIP_TRY(c, hipMemsetAsync(counts, 0, 32, c->st));
-        uint32_t limit = 512;           // (buckets hold <= 320 items on average; round 4: 1024 -- a family of 1000 keys sharing a
-                                        // segment is 500 K pairs for ONE wave of grouped_candidates)
+        // twice the average bucket, between 512 and 1024 (round 4 began with 1024 throughout: at config 4's skewed shape a
+        // family of 1000 keys sharing a segment is 500 K pairs for ONE wave of grouped_candidates -- 1.6 ms against 0.65
+        // with 566; 512 throughout marked ordinary buckets of config 3's 430-item average: 4.7 ms against 3.4)
+        uint32_t limit = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(512, 2 * (U >> B)));
         if (const char *e = getenv("FQD_GROUP_CROWDED_LIMIT"))
             limit = (uint32_t)std::max(2, atoi(e));
         HIP_TRY(c, fqd::launch_group_mark_crowded(c->ld_start.as<uint32_t>(), bucket_end, n_buckets, limit, flags, list, counts,
@@ -454,7 +456,7 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
 // crowded bucket, tiled. No host round trip; nothing to do is a launch of empty workgroups.
 static bool tiles_possible(const fqd_ctx *c, uint32_t nseg)
 {
-    return c->ks.stride <= 32 && !(c->ks.stride & 3u) && nseg <= 8 && !getenv("FQD_GROUP_NO_TILES");
+    return fqd::group_tiles_possible(c->ks, nseg) && !getenv("FQD_GROUP_NO_TILES");
 }
 
 static int grouped_tiles(fqd_ctx *c, uint64_t U, uint32_t d, uint32_t seg0, uint32_t nseg)
@@ -540,8 +542,11 @@ static int grouped_refine(fqd_ctx *c, const uint32_t *seg_hashes, uint64_t U, ui
                                     c->gp_fine_val.as<uint32_t>()));
     unsigned long long *cand_ctr = reinterpret_cast<unsigned long long *>(c->gp_small.as<uint32_t>() + 4096);
     unsigned long long *ctr = c->d_ctr64.as<unsigned long long>();
+    // (a fine bucket of thousands of items is a family the pieces do not split: not walked by its one wave when the
+    // tiles can take it -- the need it reports sends this context to them)
     HIP_TRY(c, fqd::launch_grouped_candidates(items2, c->ld_start.as<uint32_t>(), bucket_end2, 1u << B2, B2,
-                                              c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap, c->st));
+                                              c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap, c->st, 0, nullptr,
+                                              tiles_possible(c, nseg) ? 8192u : 0u, ctr + C64_CAND_NEED));
     HIP_TRY(c, fqd::launch_group_verify_refined(c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap, c->urecs.as<uint32_t>(),
                                                 c->ulens.as<uint32_t>(), sh, nseg, seg_hashes, U, B, flags,
                                                 c->edges.as<uint32_t>(), ctr + C64_EDGES, c->edge_cap, ctr + C64_CAND_NEED,

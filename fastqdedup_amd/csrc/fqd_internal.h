@@ -577,7 +577,10 @@ hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *buck
                                      uint32_t n_buckets, uint32_t bucket_bits, uint64_t *cands,
                                      unsigned long long *cand_count, uint64_t cand_cap, hipStream_t st,
                                      uint32_t require_any = 0 /* list only pairs with one of these bits in a value */,
-                                     const uint8_t *skip = nullptr /* skip[b] != 0: bucket b is left out */);
+                                     const uint8_t *skip = nullptr /* skip[b] != 0: bucket b is left out */,
+                                     uint32_t give_up_over = 0, unsigned long long *cand_need = nullptr /* a bucket of more
+                                     items is not walked; *cand_need is raised beyond every budget instead */);
+bool group_tiles_possible(KeyShape sh, uint32_t nseg);
 // crowded buckets of a search at distance d <= 3 (group.hip "crowded buckets"): marked, skipped by the candidate kernel,
 // their keys matched on finer pieces. group_fine_items(d): items a crowded key files (0: no refinement at that distance);
 // uids must fit group_fine_uid_bits() bits

@@ -248,6 +248,10 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
     uint32_t n_buckets, uint32_t sub_shift, uint2 *__restrict__ cands_all, unsigned long long *__restrict__ cand_counts, uint64_t list_cap,
     const uint8_t *__restrict__ skip /* NULL, or skip[b] != 0: bucket b is CROWDED -- its keys are matched on finer
                                       * segments instead (gp_refine_items_kernel) */,
+    uint32_t give_up_over, unsigned long long *__restrict__ cand_need /* give_up_over != 0: a bucket of more items (the
+                          * fine items of a family the pieces do not split) is not walked -- millions of pairs by ONE
+                          * wave, 16 s for the 65 536-key ladder -- but reported as a need beyond every budget: the host
+                          * then takes the crowded buckets all pairs in tiles */,
     uint32_t require_any /* != 0: only pairs one of whose values has one of these bits are listed (the Levenshtein
                           * search for pairs of DIFFERENT lengths: a pair of two index items is a pair of one length,
                           * which the Hamming passes have found already -- 11 M of 11.2 M candidates at config 5's
@@ -320,6 +324,11 @@ __global__ __launch_bounds__(GP_THREADS) void grouped_candidates_kernel(
         const uint32_t m = hi - lo;
         if (m < 2 || (skip && skip[b]))
             continue;
+        if (give_up_over && m > give_up_over) {
+            if (lane == 0)
+                atomicMax(cand_need, 1ull << 62);
+            continue;
+        }
         const uint2 *bucket = items + lo;
         const uint32_t m_lds = m < GP_SLICE ? m : GP_SLICE;
         // ---- load (all of the lane's loads in flight before anything else), rank, scan, place
@@ -987,6 +996,11 @@ __global__ void gp_tile_prefix_kernel(const uint32_t *__restrict__ bucket_start,
     tile_prefix[n_list] = run;
 }
 
+// K planes, Q4 uint4 per record (1, 2, 4 or 8): a thread's own record sits in registers, the other tile's rows in LDS at
+// a stride of Q4 * 4 + 4 words (16-byte aligned: a row is read by Q4 broadcast ds_read_b128, all in flight together).
+// (First version: both tiles in LDS, word-by-word loops with run-time bounds and an early exit -- every word a dependent
+// LDS round trip, two waves per SIMD to hide it: 450 ms for the skewed config 4 where this one takes __TILES_MS__.)
+template <uint32_t K, uint32_t Q4>
 __global__ __launch_bounds__(CT_TS) void gp_crowded_tiles_kernel(
     const uint2 *__restrict__ items, const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ bucket_end,
     const uint32_t *__restrict__ list, const unsigned long long *__restrict__ counts,
@@ -994,22 +1008,21 @@ __global__ __launch_bounds__(CT_TS) void gp_crowded_tiles_kernel(
     const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t d, uint32_t nseg,
     uint32_t *__restrict__ edges, unsigned long long *__restrict__ edge_count, uint64_t edge_cap)
 {
-    extern __shared__ uint32_t ct_smem[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t row = sh.stride + 1u, q4 = sh.stride / 4u, K = sh.planes, W = sh.words;
-    uint32_t *rec_i = ct_smem, *rec_j = rec_i + CT_TS * row;
-    uint32_t *h_j = rec_j + CT_TS * row, *uid_j = h_j + CT_TS, *uid_i = uid_j + CT_TS, *seg_j = uid_i + CT_TS;
-    uint32_t *seg_masks = seg_j + CT_TS;                    // [W][8]: bits of word w inside main segment s (keys of ONE length)
-    uint2 *wbuf = reinterpret_cast<uint2 *>(seg_masks + W * 8u + (W & 1u ? 8u : 0u));      // [waves][CT_WCAP]
+    constexpr uint32_t ROW4 = Q4 + 1, WMAX = Q4 * 4 / K;        // (words of 32 bases a record of Q4 uint4 can hold)
+    __shared__ uint4 rec_j[CT_TS * ROW4];
+    __shared__ uint32_t h_j[CT_TS], uid_j[CT_TS], seg_j[CT_TS];
+    __shared__ uint2 wbuf[CT_TS / 64][CT_WCAP];
     __shared__ uint32_t s_wn[CT_TS / 64];
+    __shared__ uint32_t s_mask[WMAX][8];                  // keys of ONE length: the bits of word w inside main segment s
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t W = sh.words;
     if (lane == 0)
         s_wn[wave] = 0;
-    for (uint32_t x = tid; x < W * 8u; x += CT_TS) {
-        const uint32_t w = x >> 3, s2 = x & 7u;
+    for (uint32_t x = tid; x < WMAX * 8u; x += CT_TS) {
         uint32_t slo = 0, shi = 0;
-        if (s2 < nseg)
-            fqd_segment(sh.max_len, s2, nseg, slo, shi);
-        seg_masks[x] = s2 < nseg ? fqd_range_mask(w, slo, shi) : 0u;
+        if ((x & 7u) < nseg)
+            fqd_segment(sh.max_len, x & 7u, nseg, slo, shi);
+        s_mask[x >> 3][x & 7u] = (x & 7u) < nseg ? fqd_range_mask(x >> 3, slo, shi) : 0u;
     }
     const uint32_t n_list = (uint32_t)counts[0];
     const unsigned long long total = tile_prefix[n_list];
@@ -1020,23 +1033,9 @@ __global__ __launch_bounds__(CT_TS) void gp_crowded_tiles_kernel(
         g = __shfl(g, 0);
         for (uint32_t e = lane; e < have; e += 64)
             if (g + e < edge_cap)
-                reinterpret_cast<uint2 *>(edges)[g + e] = wbuf[wave * CT_WCAP + e];
+                reinterpret_cast<uint2 *>(edges)[g + e] = wbuf[wave][e];
     };
-    auto note = [&](bool hit, uint32_t u, uint32_t v) {          // (all lanes of the wave, converged)
-        const unsigned long long m = __ballot(hit);
-        if (!m)
-            return;
-        const uint32_t n = (uint32_t)__popcll(m);
-        uint32_t have = s_wn[wave];
-        if (have + n > CT_WCAP) {
-            flush(have);
-            have = 0;
-        }
-        if (hit)
-            wbuf[wave * CT_WCAP + have + (uint32_t)__popcll(m & fqd_lanemask_lt())] = make_uint2(min(u, v), max(u, v));
-        if (lane == 0)
-            s_wn[wave] = have + n;
-    };
+    const uint4 *recs4 = reinterpret_cast<const uint4 *>(urecs);
     for (unsigned long long g = blockIdx.x; g < total; g += gridDim.x) {
         // which bucket, which pair of tiles
         uint32_t a = 0, z = n_list;
@@ -1056,22 +1055,22 @@ __global__ __launch_bounds__(CT_TS) void gp_crowded_tiles_kernel(
         // row-major over the upper triangle: row ti holds T - ti pairs (ti, ti .. T - 1)
         uint32_t ti = (uint32_t)(((2.0 * T + 1.0) - sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)idx)) * 0.5);
         auto row_start = [&](uint32_t r) { return (unsigned long long)r * T - (unsigned long long)r * (r - 1) / 2; };
+        ti = min(ti, T - 1);
         while (ti > 0 && row_start(ti) > idx)
             ti--;
         while (ti + 1 < T && row_start(ti + 1) <= idx)
             ti++;
         const uint32_t tj = ti + (uint32_t)(idx - row_start(ti));
         const uint32_t ni = min(CT_TS, m - ti * CT_TS), nj = min(CT_TS, m - tj * CT_TS);
-        __syncthreads();                                  // (the tiles of the pair before are done with)
-        // the rows' items, then their records as one coalesced stream of uint4 per tile
-        uint32_t my_h = 0, my_uid = 0, my_seg = 0;
-        if (tid < ni) {
-            const uint2 it = items[lo + ti * CT_TS + tid];
-            my_h = it.x;
-            my_uid = fused_U ? it.y % fused_U : it.y;
-            my_seg = seg0 + (fused_U ? it.y / fused_U : 0u);
-            uid_i[tid] = my_uid;
-        }
+        __syncthreads();                                  // (the tile of the pair before is done with)
+        // my row of tile i: item and record (registers); row tid of tile j: item (LDS)
+        const uint2 it_i = items[lo + ti * CT_TS + min(tid, ni - 1)];
+        const uint32_t my_h = it_i.x, my_uid = fused_U ? it_i.y % fused_U : it_i.y;
+        const uint32_t my_seg = seg0 + (fused_U ? it_i.y / fused_U : 0u);
+        uint4 mine[Q4];
+#pragma unroll
+        for (uint32_t q = 0; q < Q4; q++)
+            mine[q] = recs4[(size_t)my_uid * Q4 + q];
         if (tid < nj) {
             const uint2 it = items[lo + tj * CT_TS + tid];
             h_j[tid] = it.x;
@@ -1079,44 +1078,56 @@ __global__ __launch_bounds__(CT_TS) void gp_crowded_tiles_kernel(
             seg_j[tid] = seg0 + (fused_U ? it.y / fused_U : 0u);
         }
         __syncthreads();
-        const uint4 *recs4 = reinterpret_cast<const uint4 *>(urecs);
-        for (uint32_t x0 = tid; x0 < CT_TS * q4; x0 += 4 * CT_TS) {
-            uint4 vi[4], vj[4];
+        // tile j's records as one coalesced stream of uint4
+        for (uint32_t x0 = tid; x0 < CT_TS * Q4; x0 += 4 * CT_TS) {
+            uint4 vj[4];
 #pragma unroll
             for (uint32_t t = 0; t < 4; t++) {             // (clamped, unconditional: in flight together)
-                const uint32_t x = x0 + t * CT_TS, r = x / q4, q = x - r * q4;
-                vi[t] = recs4[(size_t)uid_i[min(r, ni - 1)] * q4 + q];
-                vj[t] = recs4[(size_t)uid_j[min(r, nj - 1)] * q4 + q];
+                const uint32_t x = x0 + t * CT_TS, r = min(x / Q4, nj - 1), q = x % Q4;
+                vj[t] = recs4[(size_t)uid_j[r] * Q4 + q];
             }
 #pragma unroll
             for (uint32_t t = 0; t < 4; t++) {
-                const uint32_t x = x0 + t * CT_TS, r = x / q4, q = x - r * q4;
-                if (x < CT_TS * q4) {
-                    uint32_t *di = rec_i + r * row + q * 4u, *dj = rec_j + r * row + q * 4u;
-                    if (r < ni) { di[0] = vi[t].x; di[1] = vi[t].y; di[2] = vi[t].z; di[3] = vi[t].w; }
-                    if (r < nj) { dj[0] = vj[t].x; dj[1] = vj[t].y; dj[2] = vj[t].z; dj[3] = vj[t].w; }
-                }
+                const uint32_t x = x0 + t * CT_TS, r = x / Q4, q = x % Q4;
+                if (x < CT_TS * Q4 && r < nj)
+                    rec_j[r * ROW4 + q] = vj[t];
             }
         }
         __syncthreads();
-        const uint32_t my_len = tid < ni ? fqd_key_len(sh, ulens, my_uid) : 0u;
-        const uint32_t *mine = rec_i + tid * row;
+        const uint32_t my_len = sh.ragged ? fqd_key_len(sh, ulens, my_uid) : sh.max_len;
+        const uint32_t *mw = reinterpret_cast<const uint32_t *>(mine);
         for (uint32_t k = 0; k < nj; k++) {
-            bool hit = false;
             const uint32_t uk = uid_j[k];
-            if (tid < ni && h_j[k] == my_h && seg_j[k] == my_seg && (ti != tj || k > tid) && uk != my_uid &&
-                (!sh.ragged || fqd_key_len(sh, ulens, uk) == my_len)) {
-                const uint32_t *other = rec_j + k * row;
-                uint32_t dist = 0, seg_mis = 0;
-                for (uint32_t w = 0; w < W && dist <= d; w++) {
+            const bool cand = tid < ni && h_j[k] == my_h && seg_j[k] == my_seg && (ti != tj || k > tid) && uk != my_uid;
+            if (!__ballot(cand))
+                continue;                                  // (nobody in the wave: the row is not even read)
+            uint4 other[Q4];
+#pragma unroll
+            for (uint32_t q = 0; q < Q4; q++)
+                other[q] = rec_j[k * ROW4 + q];
+            const uint32_t *ow = reinterpret_cast<const uint32_t *>(other);
+            uint32_t dist = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < WMAX; w++) {
+                uint32_t dw = 0;
+#pragma unroll
+                for (uint32_t kk = 0; kk < K; kk++)
+                    dw |= mw[w * K + kk] ^ ow[w * K + kk];
+                dist += w < W ? __popc(dw) : 0u;
+            }
+            bool hit = cand && dist && dist <= d && (!sh.ragged || fqd_key_len(sh, ulens, uk) == my_len);
+            if (hit) {                                      // (rare: which main segments hold the differences)
+                uint32_t seg_mis = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < WMAX; w++) {
                     uint32_t dw = 0;
+#pragma unroll
                     for (uint32_t kk = 0; kk < K; kk++)
-                        dw |= mine[w * K + kk] ^ other[w * K + kk];
-                    if (dw) {
-                        dist += __popc(dw);
+                        dw |= mw[w * K + kk] ^ ow[w * K + kk];
+                    if (w < W && dw) {
                         if (!sh.ragged) {
-                            for (uint32_t s2 = 0; s2 < nseg && s2 < 8; s2++)
-                                seg_mis |= (dw & seg_masks[w * 8u + s2]) ? 1u << s2 : 0u;
+                            for (uint32_t s2 = 0; s2 < nseg; s2++)
+                                seg_mis |= (dw & s_mask[w][s2]) ? 1u << s2 : 0u;
                         } else {
                             for (uint32_t s2 = 0; s2 < nseg; s2++) {
                                 uint32_t slo, shi;
@@ -1126,14 +1137,24 @@ __global__ __launch_bounds__(CT_TS) void gp_crowded_tiles_kernel(
                         }
                     }
                 }
-                if (dist && dist <= d) {
-                    uint32_t first = 0;
-                    while (first < nseg && (seg_mis >> first & 1u))
-                        first++;
-                    hit = first == my_seg;               // reported in the pass of the FIRST segment the pair agrees on
-                }
+                uint32_t first = 0;
+                while (first < nseg && (seg_mis >> first & 1u))
+                    first++;
+                hit = first == my_seg;                   // reported in the pass of the FIRST segment the pair agrees on
             }
-            note(hit, my_uid, uk);
+            const unsigned long long hm = __ballot(hit);
+            if (hm) {
+                const uint32_t n = (uint32_t)__popcll(hm);
+                uint32_t have = s_wn[wave];
+                if (have + n > CT_WCAP) {
+                    flush(have);
+                    have = 0;
+                }
+                if (hit)
+                    wbuf[wave][have + (uint32_t)__popcll(hm & fqd_lanemask_lt())] = make_uint2(min(my_uid, uk), max(my_uid, uk));
+                if (lane == 0)
+                    s_wn[wave] = have + n;
+            }
         }
     }
     __syncthreads();
@@ -1239,7 +1260,8 @@ hipError_t launch_group_slab_starts(uint32_t n_buckets, uint32_t cap, uint32_t *
 hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                      uint32_t n_buckets, uint32_t bucket_bits, uint64_t *cands,
                                      unsigned long long *cand_count, uint64_t cand_cap, hipStream_t st,
-                                     uint32_t require_any, const uint8_t *skip)
+                                     uint32_t require_any, const uint8_t *skip, uint32_t give_up_over,
+                                     unsigned long long *cand_need)
 {
     if (!n_buckets)
         return hipSuccess;
@@ -1249,7 +1271,8 @@ hipError_t launch_grouped_candidates(const uint32_t *items, const uint32_t *buck
     const unsigned grid = blocks < 8192 ? blocks : 8192;
     grouped_candidates_kernel<<<grid, GP_THREADS, 0, st>>>(reinterpret_cast<const uint2 *>(items), bucket_start,
                                                            bucket_end, n_buckets, sub_shift, reinterpret_cast<uint2 *>(cands),
-                                                           cand_count, cand_cap / GP_LISTS, skip, require_any);
+                                                           cand_count, cand_cap / GP_LISTS, skip,
+                                                           cand_need ? give_up_over : 0u, cand_need, require_any);
     return hipGetLastError();
 }
 
@@ -1326,15 +1349,28 @@ hipError_t launch_group_crowded_tiles(const uint32_t *items, const uint32_t *buc
                                       uint32_t d, uint32_t nseg, uint32_t *edges, unsigned long long *edge_count,
                                       uint64_t edge_cap, hipStream_t st)
 {
-    if (sh.stride > 32 || (sh.stride & 3u) || nseg > 8)
+    const uint32_t q4 = sh.stride / 4;
+    if (sh.stride > 32 || (sh.stride & 3u) || (q4 & (q4 - 1)) || nseg > 8 || sh.planes < 2 || sh.planes > 3)
         return hipErrorInvalidValue;
     gp_tile_prefix_kernel<<<1, 64, 0, st>>>(bucket_start, bucket_end, list, counts, tile_prefix);
-    const size_t lds = ((size_t)2 * CT_TS * (sh.stride + 1) + 4 * CT_TS + (size_t)sh.words * 8 + 8) * 4 +
-                       (size_t)(CT_TS / 64) * CT_WCAP * 8;
-    gp_crowded_tiles_kernel<<<4096, CT_TS, lds, st>>>(reinterpret_cast<const uint2 *>(items), bucket_start, bucket_end, list,
-                                                      counts, tile_prefix, fused_U, seg0, urecs, ulens, sh, d, nseg, edges,
-                                                      edge_count, edge_cap);
+#define FQD_TILES(KK, QQ)                                                                                               \
+    gp_crowded_tiles_kernel<KK, QQ><<<8192, CT_TS, 0, st>>>(reinterpret_cast<const uint2 *>(items), bucket_start,      \
+                                                            bucket_end, list, counts, tile_prefix, fused_U, seg0, urecs, \
+                                                            ulens, sh, d, nseg, edges, edge_count, edge_cap)
+    if (sh.planes == 3) {
+        if (q4 == 1) FQD_TILES(3, 1); else if (q4 == 2) FQD_TILES(3, 2); else if (q4 == 4) FQD_TILES(3, 4); else FQD_TILES(3, 8);
+    } else {
+        if (q4 == 1) FQD_TILES(2, 1); else if (q4 == 2) FQD_TILES(2, 2); else if (q4 == 4) FQD_TILES(2, 4); else FQD_TILES(2, 8);
+    }
+#undef FQD_TILES
     return hipGetLastError();
+}
+
+// (what the launcher above takes)
+bool group_tiles_possible(KeyShape sh, uint32_t nseg)
+{
+    const uint32_t q4 = sh.stride / 4;
+    return sh.stride <= 32 && !(sh.stride & 3u) && !(q4 & (q4 - 1)) && nseg <= 8 && sh.planes >= 2 && sh.planes <= 3;
 }
 
 hipError_t launch_group_verify_refined(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
