@@ -348,6 +348,61 @@ def test_a_family_inside_one_piece_goes_all_pairs(F, oracle, monkeypatch, L, d, 
         assert got.route["search_tiles"] and not got.route["search_sort"], (method, got.route)
 
 
+@pytest.mark.parametrize("d", [1, 2])
+@pytest.mark.parametrize("route", ["tiles", "fine pieces"])
+def test_crowded_buckets_of_ragged_keys(F, oracle, monkeypatch, d, route):
+    """Keys of SEVERAL lengths (58-62 nt) that share their first 40 bases by the thousand: crowded buckets of a ragged
+    search -- equal records of different lengths are different keys, the segments of a pair are those of ITS length --
+    through the tiles and through the fine pieces. Against the oracle's trie (`_triemodule.c:380-495`)."""
+    import random
+    rng = random.Random(40 + d)
+    monkeypatch.setenv("FQD_EDGES", "grouped")
+    monkeypatch.setenv("FQD_GROUP_TILE_BUDGET", "0" if route == "fine pieces" else "1000000000000")
+    stem = "".join(rng.choice("ACGT") for _ in range(40))
+    mols = [stem + "".join(rng.choice("ACGT") for _ in range(rng.randint(18, 22))) for _ in range(6000)]
+    mols += ["".join(rng.choice("ACGT") for _ in range(rng.randint(58, 62))) for _ in range(30_000)]
+    strs = []
+    for _ in range(150_000):
+        m = list(rng.choice(mols))
+        for _ in range(rng.choice((0, 0, 0, 1, 1, 2))):
+            m[rng.randrange(len(m))] = rng.choice("ACGT")
+        strs.append("".join(m))
+    strs += [stem[:k] for k in range(30, 41)] * 2 + [stem + "A" * k for k in range(0, 20)]
+    raw, off = _pack(strs)
+    ctx = F.Context(0)
+    for method in ("directional", "adjacency"):
+        want = oracle.dedup(raw, off, max_distance=d, method=method)
+        for job in range(2):
+            got = F.cluster_keys(raw, off, max_distance=d, method=method, context=ctx)
+            assert (got.n_unique, got.n_clusters, got.n_kept) == (want["n_unique"], want["n_clusters"],
+                                                                  len(want["kept_read_ids"])), (method, job, got.route)
+            assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), (method, job)
+    assert got.route["search_tiles" if route == "tiles" else "search_refined"] and not got.route["search_sort"], got.route
+
+
+def test_crowded_buckets_on_a_two_plane_alphabet_go_all_pairs(F, oracle, monkeypatch):
+    """ACGT only (two bit planes, `gp_crowded_tiles_kernel<2, 1>`): the skewed model without its N, crowded buckets all
+    pairs in tiles."""
+    from fastqdedup_amd.synth import SKEW, fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_EDGES", "grouped")
+    monkeypatch.setenv("FQD_GROUP_TILE_BUDGET", "1000000000000")
+    n, L = 200_000, 32
+    keys = synth_keys(n, L, 12, 178, sub_rate=3e-3, n_rate=0, skew=SKEW)
+    raw = np.ascontiguousarray(keys).reshape(-1)
+    present = np.zeros(128, dtype=np.uint8)
+    present[[ord(ch) for ch in "ACGT"]] = 1
+    for d in (1, 2):
+        ctx = F.Context(0)
+        ctx.configure(present, L, False)
+        want = oracle.dedup(raw, fixed_offsets(n, L), max_distance=d, method="directional")
+        for job in range(2):
+            got = F.cluster_keys(raw, key_len=L, max_distance=d, method="directional", context=ctx)
+            assert (got.n_unique, got.n_clusters, got.n_kept) == (want["n_unique"], want["n_clusters"],
+                                                                  len(want["kept_read_ids"])), (d, job, got.route)
+            assert np.array_equal(got.kept_read_ids, want["kept_read_ids"]), (d, job)
+        assert got.route["search_tiles"], got.route
+
+
 @pytest.mark.parametrize("case", ["plain", "n_keys", "two_planes", "rows_over_150", "probe_overflow", "edge_overflow",
                                   "no_patience", "small_grid"])
 def test_one_kernel_collapse_equals_the_two_kernels(F, oracle, monkeypatch, case):
