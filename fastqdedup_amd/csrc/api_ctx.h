@@ -119,6 +119,7 @@ struct fqd_ctx {
     bool search_zero_pending = false;   // find_edges: the job counters and statistics are zeroed by the partition's first launch
     DevBuf pairs_slices;           // collapse_pairs: the slices of very long buckets (fqd::PairsSlices)
     bool gp_fine_ok = false;       // the last grouped pass: its crowded keys can be matched on finer pieces
+    bool gp_fine_used = false;     // the last grouped_refine filed fine items (its candidates count towards the budget)
     bool gp_tiles = false;         // grouped search: crowded buckets go all pairs in tiles (the finer pieces did not split them)
     bool gp_slab_off = false;      // grouped search: same, for the (hash, uid) partition
     bool slab_off = false;         // LDS collapse: a slab of level 2 overflowed once, use exact bucket sizes

@@ -390,6 +390,26 @@ int fqd_api_partition_pairs(fqd_ctx *c, const uint32_t *keys, uint64_t N, uint32
 // segment mixes its number in, so items of different passes do not meet; a candidate's pass is its
 // position / fused_U). Half the launches of two passes, and kernels twice as long.
 static bool tiles_possible(const fqd_ctx *c, uint32_t nseg);
+
+// what a grouped_pass leaves about its crowded buckets (one buffer: fqd_ctx::gp_crowded)
+struct CrowdedBuf {
+    uint8_t *flags;                     // [n_buckets] 0 / 1 (fine pieces) / 2 (small: tiles)
+    uint32_t *list, *list2;             // the buckets flagged 1, flagged 2
+    unsigned long long *counts;         // [8] see gp_mark_crowded_kernel
+    unsigned long long *tile_prefix;    // [n_buckets + 2] scratch of the tiles
+    static size_t bytes(uint32_t n_buckets) { return (size_t)n_buckets * 17 + 256; }
+};
+static CrowdedBuf crowded_buf(fqd_ctx *c, uint32_t n_buckets)
+{
+    CrowdedBuf b;
+    b.flags = c->gp_crowded.as<uint8_t>();
+    b.list = reinterpret_cast<uint32_t *>(b.flags + (((size_t)n_buckets + 63) & ~(size_t)63));
+    b.list2 = b.list + n_buckets;
+    b.counts = reinterpret_cast<unsigned long long *>(b.list2 + n_buckets + (n_buckets & 1u));
+    b.tile_prefix = b.counts + 8;
+    return b;
+}
+
 static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t d, uint32_t s, uint32_t nseg,
                         uint32_t fused_U = 0)
 {
@@ -425,19 +445,23 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
     c->gp_fine_ok = fqd::group_fine_items(d) && fused_U < (1u << fqd::group_fine_uid_bits());
     if ((c->gp_fine_ok || tiles_possible(c, nseg)) && fused_U && s == 0 && nseg == d + 1 && !bucket_end &&
         !getenv("FQD_GROUP_NO_REFINE")) {
-        HIP_TRY(c, c->gp_crowded.reserve((size_t)n_buckets * 5 + 64));
-        uint8_t *flags = c->gp_crowded.as<uint8_t>();
-        uint32_t *list = reinterpret_cast<uint32_t *>(flags + (((size_t)n_buckets + 63) & ~(size_t)63));
-        unsigned long long *counts = reinterpret_cast<unsigned long long *>(list + n_buckets);
-        HIP_TRY(c, hipMemsetAsync(counts, 0, 32, c->st));
+        HIP_TRY(c, c->gp_crowded.reserve(CrowdedBuf::bytes(n_buckets)));
+        const CrowdedBuf cb = crowded_buf(c, n_buckets);
+        uint8_t *flags = cb.flags;
+        HIP_TRY(c, hipMemsetAsync(cb.counts, 0, 64, c->st));
         // twice the average bucket, between 512 and 1024 (round 4 began with 1024 throughout: at config 4's skewed shape a
         // family of 1000 keys sharing a segment is 500 K pairs for ONE wave of grouped_candidates -- 1.6 ms against 0.65
         // with 566; 512 throughout marked ordinary buckets of config 3's 430-item average: 4.7 ms against 3.4)
         uint32_t limit = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(512, 2 * (U >> B)));
         if (const char *e = getenv("FQD_GROUP_CROWDED_LIMIT"))
             limit = (uint32_t)std::max(2, atoi(e));
-        HIP_TRY(c, fqd::launch_group_mark_crowded(c->ld_start.as<uint32_t>(), bucket_end, n_buckets, limit, flags, list, counts,
-                                                  c->st));
+        // crowded buckets of up to 16 K items go all pairs in tiles whatever the others do (a context that has given up
+        // on the fine pieces, or has none at this distance: every crowded bucket)
+        uint32_t tile_max = !tiles_possible(c, nseg) ? 0u : (c->gp_tiles || !c->gp_fine_ok) ? 0xFFFFFFFFu : 16384u;
+        if (const char *e = getenv("FQD_GROUP_TILE_MAX_BUCKET"))
+            tile_max = tiles_possible(c, nseg) ? (uint32_t)strtoul(e, nullptr, 10) : 0u;
+        HIP_TRY(c, fqd::launch_group_mark_crowded(c->ld_start.as<uint32_t>(), bucket_end, n_buckets, limit, tile_max, flags,
+                                                  cb.list, cb.list2, cb.counts, c->st));
         skip = flags;
         c->gp_crowded_bits = B;
     }
@@ -459,20 +483,16 @@ static bool tiles_possible(const fqd_ctx *c, uint32_t nseg)
     return fqd::group_tiles_possible(c->ks, nseg) && !getenv("FQD_GROUP_NO_TILES");
 }
 
-static int grouped_tiles(fqd_ctx *c, uint64_t U, uint32_t d, uint32_t seg0, uint32_t nseg)
+static int grouped_tiles(fqd_ctx *c, uint64_t U, uint32_t d, uint32_t seg0, uint32_t nseg, uint32_t B, int which)
 {
-    const uint32_t B = c->gp_crowded_bits, n_buckets = 1u << B;
-    c->gp_crowded_bits = 0;
-    uint8_t *flags = c->gp_crowded.as<uint8_t>();
-    uint32_t *list = reinterpret_cast<uint32_t *>(flags + (((size_t)n_buckets + 63) & ~(size_t)63));
-    unsigned long long *counts = reinterpret_cast<unsigned long long *>(list + n_buckets);
-    HIP_TRY(c, c->gp_fine_hash.reserve(((size_t)n_buckets + 2) * 8));
+    const CrowdedBuf cb = crowded_buf(c, 1u << B);
     unsigned long long *ctr = c->d_ctr64.as<unsigned long long>();
     c->route |= FQD_ROUTE_SEARCH_TILES;
-    KTIME(c, FQD_K_PAIRS, fqd::launch_group_crowded_tiles(c->gp_last_items, c->ld_start.as<uint32_t>(), nullptr, list, counts,
-                                                          c->gp_fine_hash.as<unsigned long long>(), (uint32_t)U, seg0,
-                                                          c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), c->ks, d, nseg,
-                                                          c->edges.as<uint32_t>(), ctr + C64_EDGES, c->edge_cap, c->st));
+    KTIME(c, FQD_K_PAIRS, fqd::launch_group_crowded_tiles(c->gp_last_items, c->ld_start.as<uint32_t>(), nullptr,
+                                                          which == 2 ? cb.list2 : cb.list, cb.counts + (which == 2 ? 4 : 0),
+                                                          cb.tile_prefix, (uint32_t)U, seg0, c->urecs.as<uint32_t>(),
+                                                          c->ulens.as<uint32_t>(), c->ks, d, nseg, c->edges.as<uint32_t>(),
+                                                          ctr + C64_EDGES, c->edge_cap, c->st));
     return FQD_OK;
 }
 
@@ -487,33 +507,51 @@ static int grouped_refine(fqd_ctx *c, const uint32_t *seg_hashes, uint64_t U, ui
     c->gp_crowded_bits_last = B;
     c->gp_crowded_bits = 0;
     const KeyShape sh = c->ks;
-    uint8_t *flags = c->gp_crowded.as<uint8_t>();
-    uint32_t *list = reinterpret_cast<uint32_t *>(flags + (((size_t)n_buckets + 63) & ~(size_t)63));
-    unsigned long long *counts = reinterpret_cast<unsigned long long *>(list + n_buckets);
-    unsigned long long h[4] = {0, 0, 0, 0};
-    HIP_TRY(c, hipMemcpyAsync(h, counts, 32, hipMemcpyDeviceToHost, c->st));
+    const CrowdedBuf cb = crowded_buf(c, n_buckets);
+    uint8_t *flags = cb.flags;
+    unsigned long long *counts = cb.counts;
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(h, counts, 64, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(c, stream_wait(c->st));
-    if (!h[0])
+    if (!h[0] && !h[4])
         return FQD_OK;
-    // few enough pairs: all of them, in tiles over the whole GPU (no items, no lists; a bucket of 62 K poly-A keys of
-    // 300 nt is 1.9 G compares, about what filing and matching 120 fine items per key costs); beyond that the fine items,
-    // whose cost grows with the keys and not with their square
+    // The small crowded buckets (list 2) go all pairs in tiles; so do the others when their pairs are few (no items, no
+    // lists: a bucket of 62 K poly-A keys of 300 nt is 1.9 G compares, about what filing and matching 120 fine items per
+    // key costs); beyond that the fine items, whose cost grows with the keys and not with their square. (The tiles read
+    // the partition this pass left in ld_start: they are queued BEFORE the refinement partitions its items.)
     unsigned long long tile_budget = 8000000000ull;
     if (const char *e = getenv("FQD_GROUP_TILE_BUDGET"))
         tile_budget = strtoull(e, nullptr, 10);
-    if (tiles_possible(c, nseg) && h[3] <= tile_budget) {
-        if (getenv("FQD_DEBUG"))
-            fprintf(stderr, "[fqd] crowded buckets: %llu with %llu items, %llu pairs twice over: all pairs in tiles\n", h[0], h[1], h[3]);
-        c->gp_crowded_bits = B;
-        return grouped_tiles(c, U, d, 0, nseg);
-    }
+    const bool tiles_ok = tiles_possible(c, nseg);
+    const bool small_tiles = tiles_ok && h[4] && (h[6] <= tile_budget || !c->gp_fine_ok || c->gp_tiles);
+    const bool fine_tiles = tiles_ok && h[0] && h[3] + (small_tiles ? h[6] : 0) <= tile_budget;
+    if (getenv("FQD_DEBUG"))
+        fprintf(stderr, "[fqd] crowded buckets: %llu with %llu items (%llu pairs twice over)%s; small ones: %llu with %llu items "
+                        "(%llu)%s\n", h[0], h[1], h[3], fine_tiles ? " in tiles" : "", h[4], h[5], h[6],
+                small_tiles ? " in tiles" : "");
+    if (small_tiles)
+        FQD_TRY(grouped_tiles(c, U, d, 0, nseg, B, 2));
+    if (fine_tiles)
+        FQD_TRY(grouped_tiles(c, U, d, 0, nseg, B, 1));
+    const uint32_t accept = (h[0] && !fine_tiles ? 1u : 0u) | (h[4] && !small_tiles ? 2u : 0u);
+    if (!accept)
+        return FQD_OK;
     const uint32_t pieces = fqd::group_fine_items(d);      // fine items per crowded key
-    const uint64_t key_cap = std::min<uint64_t>(h[1], U);          // (every crowded item could be a key of its own)
+    // (every crowded item could be a key of its own)
+    const uint64_t key_cap = std::min<uint64_t>((accept & 1u ? h[1] : 0) + (accept & 2u ? h[5] : 0), U);
     uint64_t fine_limit = 0xFFFFFF00ull;            // (positions in the fine-item arrays are 32-bit)
     if (const char *e = getenv("FQD_GROUP_FINE_LIMIT"))      // tests: as if the crowded keys were too many
         fine_limit = strtoull(e, nullptr, 10);
-    if (key_cap * pieces >= fine_limit) {
-        *ok = false;
+    if (!c->gp_fine_ok || !pieces || key_cap * pieces >= fine_limit) {
+        if (!tiles_ok) {
+            *ok = false;
+            return FQD_OK;
+        }
+        // more crowded keys than the fine items can address: all pairs of those buckets too, in tiles
+        if (accept & 2u)
+            FQD_TRY(grouped_tiles(c, U, d, 0, nseg, B, 2));
+        if (accept & 1u)
+            FQD_TRY(grouped_tiles(c, U, d, 0, nseg, B, 1));
         return FQD_OK;
     }
     HIP_TRY(c, c->gp_fine_hash.reserve(key_cap * pieces * 4 + 16));
@@ -521,19 +559,22 @@ static int grouped_refine(fqd_ctx *c, const uint32_t *seg_hashes, uint64_t U, ui
     HIP_TRY(c, c->gp_seen.reserve(U / 8 + 64));          // one bit per key
     HIP_TRY(c, hipMemsetAsync(c->gp_seen.p, 0, U / 8 + 16, c->st));
     const uint32_t *items = c->gp_last_items;
-    HIP_TRY(c, fqd::launch_group_refine_items(items, c->ld_start.as<uint32_t>(), nullptr, list, counts, (uint32_t)U,
-                                              c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, c->gp_seen.as<uint32_t>(),
-                                              c->gp_fine_hash.as<uint32_t>(), c->gp_fine_val.as<uint32_t>(), counts + 2,
-                                              key_cap, c->st, d));
-    HIP_TRY(c, hipMemcpyAsync(h, counts, 24, hipMemcpyDeviceToHost, c->st));
+    for (int which = 1; which <= 2; which++)
+        if (accept & (uint32_t)which)
+            HIP_TRY(c, fqd::launch_group_refine_items(items, c->ld_start.as<uint32_t>(), nullptr, which == 2 ? cb.list2 : cb.list,
+                                                      counts + (which == 2 ? 4 : 0), (uint32_t)U, c->urecs.as<uint32_t>(),
+                                                      c->ulens.as<uint32_t>(), sh, c->gp_seen.as<uint32_t>(),
+                                                      c->gp_fine_hash.as<uint32_t>(), c->gp_fine_val.as<uint32_t>(),
+                                                      counts + 7, key_cap, c->st, d));
+    HIP_TRY(c, hipMemcpyAsync(h, counts, 64, hipMemcpyDeviceToHost, c->st));
     HIP_TRY(c, stream_wait(c->st));
-    const uint64_t n_keys = std::min<uint64_t>(h[2], key_cap), N = n_keys * pieces;
+    const uint64_t n_keys = std::min<uint64_t>(h[7], key_cap), N = n_keys * pieces;
     if (getenv("FQD_DEBUG"))
-        fprintf(stderr, "[fqd] crowded buckets: %llu with %llu items -> %llu keys matched on %u finer segments\n", h[0], h[1],
-                (unsigned long long)n_keys, pieces);
+        fprintf(stderr, "[fqd] crowded buckets: %llu keys matched on %u finer segments\n", (unsigned long long)n_keys, pieces);
     if (N < 2)
         return FQD_OK;
     c->route |= FQD_ROUTE_SEARCH_REFINED;
+    c->gp_fine_used = true;
     uint32_t B2 = 8;
     while (B2 < 20 && (N >> B2) > 320u)
         B2++;
@@ -550,7 +591,7 @@ static int grouped_refine(fqd_ctx *c, const uint32_t *seg_hashes, uint64_t U, ui
     HIP_TRY(c, fqd::launch_group_verify_refined(c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap, c->urecs.as<uint32_t>(),
                                                 c->ulens.as<uint32_t>(), sh, nseg, seg_hashes, U, B, flags,
                                                 c->edges.as<uint32_t>(), ctr + C64_EDGES, c->edge_cap, ctr + C64_CAND_NEED,
-                                                c->st, d));
+                                                c->st, d, accept));
     return FQD_OK;
 }
 
@@ -681,17 +722,18 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
             c->route |= (grouped ? FQD_ROUTE_SEARCH_GROUPED : FQD_ROUTE_SEARCH_SORT) | (attempt ? FQD_ROUTE_SEARCH_RETRIED : 0u);
             if (fuse_passes && grouped) {
                 FQD_TRY(grouped_pass(c, c->seg_hashes.as<uint32_t>(), (uint64_t)n_pass * U, d, seg_lo, nseg, (uint32_t)U));
-                if (c->gp_crowded_bits && (c->gp_tiles || !c->gp_fine_ok) && tiles_possible(c, nseg)) {
-                    FQD_TRY(grouped_tiles(c, U, d, seg_lo, nseg));
+                if (c->gp_crowded_bits && (c->gp_tiles || !c->gp_fine_ok) && tiles_possible(c, nseg) &&
+                    !getenv("FQD_GROUP_TILE_MAX_BUCKET")) {
+                    // (every crowded bucket was put on list 2: no host round trip)
+                    const uint32_t B_marked = c->gp_crowded_bits;
+                    c->gp_crowded_bits = 0;
+                    FQD_TRY(grouped_tiles(c, U, d, seg_lo, nseg, B_marked, 2));
                 } else if (c->gp_crowded_bits) {
                     bool refined = true;
+                    c->gp_fine_used = false;
                     FQD_TRY(grouped_refine(c, c->seg_hashes.as<uint32_t>(), U, nseg, &refined));
-                    used_refine = true;
-                    if (!refined && tiles_possible(c, nseg)) {
-                        // more crowded keys than the fine items can address: all pairs of the crowded buckets, in tiles
-                        c->gp_crowded_bits = c->gp_crowded_bits_last;
-                        FQD_TRY(grouped_tiles(c, U, d, seg_lo, nseg));
-                    } else if (!refined) {
+                    used_refine = used_refine || c->gp_fine_used;
+                    if (!refined) {
                         // more crowded keys than the fine items can address: the whole search once more on the sort path,
                         // which compares a crowded bucket's keys in place and needs no items at all (the reference's trie
                         // takes any distribution, _triemodule.c:380-495: this must never be an error)

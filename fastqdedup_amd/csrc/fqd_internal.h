@@ -587,8 +587,8 @@ bool group_tiles_possible(KeyShape sh, uint32_t nseg);
 uint32_t group_fine_items(uint32_t d);
 uint32_t group_fine_uid_bits();
 hipError_t launch_group_mark_crowded(const uint32_t *bucket_start, const uint32_t *bucket_end, uint32_t n_buckets,
-                                     uint32_t limit, uint8_t *crowded, uint32_t *list, unsigned long long *counts,
-                                     hipStream_t st);
+                                     uint32_t limit, uint32_t tile_max, uint8_t *crowded, uint32_t *list, uint32_t *list2,
+                                     unsigned long long *counts /* [8] */, hipStream_t st);
 hipError_t launch_group_refine_items(const uint32_t *items, const uint32_t *bucket_start, const uint32_t *bucket_end,
                                      const uint32_t *list, const unsigned long long *counts, uint32_t fused_U,
                                      const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t *seen,
@@ -603,7 +603,7 @@ hipError_t launch_group_verify_refined(const uint64_t *cands, const unsigned lon
                                        const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t nseg,
                                        const uint32_t *seg_hashes, uint64_t U, uint32_t bucket_bits,
                                        const uint8_t *crowded, uint32_t *edges, unsigned long long *edge_count,
-                                       uint64_t edge_cap, unsigned long long *cand_need, hipStream_t st, uint32_t d);
+                                       uint64_t edge_cap, unsigned long long *cand_need, hipStream_t st, uint32_t d, uint32_t accept = 3);
 hipError_t launch_verify_candidates(const uint64_t *cands, const unsigned long long *cand_count, uint64_t cand_cap,
                                     const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t d, uint32_t seg,
                                     uint32_t nseg, uint32_t *edges, unsigned long long *edge_count, uint64_t edge_cap,

@@ -754,9 +754,15 @@ __device__ __forceinline__ uint32_t gp_fine_set(uint32_t d, uint32_t idx)
     return set;
 }
 
+// crowded[b]: 0 = an ordinary bucket; 1 = crowded, its keys are matched on finer pieces (list / counts[0..3]);
+// 2 = crowded and of at most tile_max items: all pairs in tiles (list2 / counts[4..6]) -- a family of a few thousand keys
+// that are all near each other (a jackpot key's one- and two-substitution copies) is cheap there and costly on the fine
+// pieces, where each of its keys meets hundreds of others under every set that holds its differences.
+// counts: [0] buckets, [1] items, [2] (keys that filed fine items), [3] sum of items^2 of list; [4], [5], [6] of list2.
 __global__ void gp_mark_crowded_kernel(const uint32_t *__restrict__ bucket_start, const uint32_t *__restrict__ bucket_end,
-                                       uint32_t n_buckets, uint32_t limit, uint8_t *__restrict__ crowded,
-                                       uint32_t *__restrict__ list, unsigned long long *__restrict__ counts /* buckets, items */)
+                                       uint32_t n_buckets, uint32_t limit, uint32_t tile_max, uint8_t *__restrict__ crowded,
+                                       uint32_t *__restrict__ list, uint32_t *__restrict__ list2,
+                                       unsigned long long *__restrict__ counts)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_buckets)
@@ -765,12 +771,13 @@ __global__ void gp_mark_crowded_kernel(const uint32_t *__restrict__ bucket_start
     if (bucket_end)
         hi = min(hi, bucket_end[b]);
     const uint32_t m = hi - bucket_start[b];
-    const bool big = m > limit;
-    crowded[b] = big ? 1 : 0;
+    const bool big = m > limit, small = big && m <= tile_max;
+    crowded[b] = big ? (small ? 2 : 1) : 0;
     if (big) {
-        list[atomicAdd(&counts[0], 1ull)] = b;
-        atomicAdd(&counts[1], (unsigned long long)m);
-        atomicAdd(&counts[3], (unsigned long long)m * m);      // (all pairs in tiles: that many compares, twice)
+        unsigned long long *cn = counts + (small ? 4 : 0);
+        (small ? list2 : list)[atomicAdd(&cn[0], 1ull)] = b;
+        atomicAdd(&cn[1], (unsigned long long)m);
+        atomicAdd(&cn[small ? 2 : 3], (unsigned long long)m * m);      // (all pairs in tiles: that many compares, twice)
     }
 }
 
@@ -846,7 +853,7 @@ __global__ __launch_bounds__(256) void gp_verify_refined_kernel(
     const uint32_t *__restrict__ urecs, const uint32_t *__restrict__ ulens, KeyShape sh, uint32_t nseg,
     const uint32_t *__restrict__ seg_hashes /* [nseg][U] */, uint64_t U, uint32_t bucket_bits,
     const uint8_t *__restrict__ crowded, uint32_t *__restrict__ edges, unsigned long long *__restrict__ edge_count,
-    uint64_t edge_cap, unsigned long long *__restrict__ cand_need, uint32_t d)
+    uint64_t edge_cap, unsigned long long *__restrict__ cand_need, uint32_t d, uint32_t accept /* bits of crowded[] values whose buckets this refinement answers for */)
 {
     const uint32_t list = blockIdx.x % GP_LISTS, part = blockIdx.x / GP_LISTS, parts = gridDim.x / GP_LISTS;
     const unsigned long long filled = cand_count[(size_t)list * 8];
@@ -948,7 +955,7 @@ __global__ __launch_bounds__(256) void gp_verify_refined_kernel(
                 first++;
             if (first >= nseg)
                 continue;                                  // (no segment agrees: cannot be within d of d + 1 segments)
-            if (!crowded[seg_hashes[(size_t)first * U + ua] >> (32u - bucket_bits)])
+            if (!(crowded[seg_hashes[(size_t)first * U + ua] >> (32u - bucket_bits)] & accept))
                 continue;                                  // the main pass of that segment has it
             s_edge[atomicAdd(&s_n, 1u)] = make_uint2(min(ua, ub), max(ua, ub));
         }
@@ -1319,11 +1326,11 @@ uint32_t group_fine_items(uint32_t d) { return gp_fine_sets(d); }       // fine 
 uint32_t group_fine_uid_bits() { return GP_FINE_SET_SHIFT; }
 
 hipError_t launch_group_mark_crowded(const uint32_t *bucket_start, const uint32_t *bucket_end, uint32_t n_buckets,
-                                     uint32_t limit, uint8_t *crowded, uint32_t *list, unsigned long long *counts,
-                                     hipStream_t st)
+                                     uint32_t limit, uint32_t tile_max, uint8_t *crowded, uint32_t *list, uint32_t *list2,
+                                     unsigned long long *counts, hipStream_t st)
 {
-    gp_mark_crowded_kernel<<<(n_buckets + 255) / 256, 256, 0, st>>>(bucket_start, bucket_end, n_buckets, limit, crowded,
-                                                                    list, counts);
+    gp_mark_crowded_kernel<<<(n_buckets + 255) / 256, 256, 0, st>>>(bucket_start, bucket_end, n_buckets, limit, tile_max,
+                                                                    crowded, list, list2, counts);
     return hipGetLastError();
 }
 
@@ -1377,13 +1384,15 @@ hipError_t launch_group_verify_refined(const uint64_t *cands, const unsigned lon
                                        const uint32_t *urecs, const uint32_t *ulens, KeyShape sh, uint32_t nseg,
                                        const uint32_t *seg_hashes, uint64_t U, uint32_t bucket_bits,
                                        const uint8_t *crowded, uint32_t *edges, unsigned long long *edge_count,
-                                       uint64_t edge_cap, unsigned long long *cand_need, hipStream_t st, uint32_t d)
+                                       uint64_t edge_cap, unsigned long long *cand_need, hipStream_t st, uint32_t d,
+                                       uint32_t accept)
 {
     if (!gp_fine_sets(d))
         return hipErrorInvalidValue;
     gp_verify_refined_kernel<<<GP_LISTS * 16, 256, 0, st>>>(reinterpret_cast<const uint2 *>(cands), cand_count,
                                                             cand_cap / GP_LISTS, urecs, ulens, sh, nseg, seg_hashes, U,
-                                                            bucket_bits, crowded, edges, edge_count, edge_cap, cand_need, d);
+                                                            bucket_bits, crowded, edges, edge_count, edge_cap, cand_need, d,
+                                                            accept);
     return hipGetLastError();
 }
 
