@@ -1,24 +1,24 @@
 #!/usr/bin/env python3
-"""Timeline of ONE step from a rocprofv3 --kernel-trace CSV: start, duration and gap of every
-dispatch between the last-but-one and last launches of a marker kernel (default pack_kernel)."""
-import csv, re, sys
-path = sys.argv[1]
-marker = sys.argv[2] if len(sys.argv) > 2 else "pack_kernel"
-back = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-rows = list(csv.DictReader(open(path)))
+"""One steady-state step of a rocprofv3 --kernel-trace CSV as a timeline: start (us from the step's first kernel),
+duration, and the gap since the end of whatever ended last (a negative gap: it ran beside something).
+    python tools/step_timeline.py <kernel_trace.csv> [pack_kernel]   # the step = from the last-but-one launch of the
+                                                                     # anchor kernel to the last one"""
+import csv
+import re
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+anchor = sys.argv[2] if len(sys.argv) > 2 else "pack_kernel"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
-a, b = marks[-back], marks[-back + 1]
-seg = rows[a:b]
-t0 = int(seg[0]["Start_Timestamp"])
-def short(n):
-    n = n.replace("(anonymous namespace)::", "")
-    n = re.sub(r"^void ", "", n)
-    return n[:70]
-busy, prev_end = 0, t0
-for r in seg:
+idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
+a, b = idx[-2], idx[-1]
+t0 = int(rows[a]["Start_Timestamp"])
+last_end = t0
+busy = 0
+for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:8.1f}  gap {(s - prev_end) / 1e3:7.1f}  {short(r['Kernel_Name'])}")
-    busy += e - s
-    prev_end = max(prev_end, e)
-print(f"span {(prev_end - t0) / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms, dispatches {len(seg)}")
+    name = re.sub(r"^void ", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).split("(")[0][:52]
+    print(f"{(s - t0) / 1e3:9.1f} us  {(e - s) / 1e3:8.1f} us  gap {(s - last_end) / 1e3:7.1f}  {name}")
+    busy += max(0, e - max(s, last_end))
+    last_end = max(last_end, e)
+print(f"step (anchor to anchor): {(int(rows[b]['Start_Timestamp']) - t0) / 1e3:.1f} us; some kernel running: {busy / 1e3:.1f} us")
