@@ -335,8 +335,9 @@ def test_a_family_inside_one_piece_goes_all_pairs(F, oracle, monkeypatch, L, d, 
     monkeypatch.setenv("FQD_EDGES", "grouped")
     if budget is not None:
         monkeypatch.setenv("FQD_GROUP_TILE_BUDGET", budget)
-    n = 120_000
-    keys = synth_keys(n, L, 12, 177, sub_rate=3e-3, n_rate=1e-4, skew={"hot": 0.02, "ladder": 0.15, "lowc_every": 100})
+        monkeypatch.setenv("FQD_GROUP_CAND_BUDGET", "300000")      # (so that the ladder keys left in one fine group are too many)
+    n = 80_000                # (the oracle's trie walks the ladder too: its time grows with the square of the ladder)
+    keys = synth_keys(n, L, 12, 177, sub_rate=3e-3, n_rate=1e-4, skew={"hot": 0.02, "ladder": 0.08, "lowc_every": 100})
     raw = np.ascontiguousarray(keys).reshape(-1)
     ctx = F.Context(0)
     for method in ("directional", "adjacency"):
