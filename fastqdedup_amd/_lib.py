@@ -55,18 +55,31 @@ EXPORTS = [
 _lib: Optional[C.CDLL] = None
 
 
+_pinned_live = [0]      # bytes of page-locked id arrays callers still hold
+
+
 def _host_ids(n: int) -> np.ndarray:
     """A host array for n read ids. Large lists land in PAGE-LOCKED memory out of torch's caching host allocator (the
     array keeps its tensor alive; a released block is reused by the next call): the device-to-host copy then runs at
     the link's rate -- into a fresh pageable array 100 MB of ids took 9.8 ms (page faults + the driver's staging), into
-    a pinned one 1.8 ms (tools/diag_e2e.py). FQD_NO_PINNED_IDS=1: always pageable."""
+    a pinned one 1.8 ms (tools/diag_e2e.py). A caller that KEEPS many results keeps that much memory locked: beyond
+    FQD_PINNED_IDS_CAP bytes of live pinned results (default 4 GiB) further ones are pageable. FQD_NO_PINNED_IDS=1:
+    always pageable."""
     if (1 << 17) <= n <= (1 << 27) and not os.environ.get("FQD_NO_PINNED_IDS"):
-        try:
-            import torch
-            if torch.cuda.is_available():
-                return torch.empty(n, dtype=torch.int64, pin_memory=True).numpy().view(np.uint64)
-        except Exception:       # (no torch, or no page-locked memory to be had)
-            pass
+        cap = int(os.environ.get("FQD_PINNED_IDS_CAP", 4 << 30))
+        if _pinned_live[0] + 8 * n <= cap:
+            try:
+                import torch
+                import weakref
+                if torch.cuda.is_available():
+                    arr = torch.empty(n, dtype=torch.int64, pin_memory=True).numpy()
+                    # (the array's base is the tensor object that keeps the block: it dies with the last view of the array)
+                    keeper = arr.base if arr.base is not None else arr
+                    _pinned_live[0] += 8 * n
+                    weakref.finalize(keeper, lambda b=8 * n: _pinned_live.__setitem__(0, _pinned_live[0] - b))
+                    return arr.view(np.uint64)
+            except Exception:       # (no torch, or no page-locked memory to be had)
+                pass
     return np.empty(n, dtype=np.uint64)
 
 

@@ -1501,6 +1501,29 @@ def test_ragged_keys_collapse_without_a_sort(F, oracle, monkeypatch):
             assert times["bucket_dedupe_kernel"][1] and not times["head_flags_kernel"][1], times
 
 
+def test_page_locked_id_arrays_are_capped(F, monkeypatch):
+    """Large kept-id lists come back in page-locked host memory (the copy runs at the link's rate); a caller that keeps
+    many results must not keep unbounded memory locked: beyond FQD_PINNED_IDS_CAP bytes of live results the arrays are
+    pageable, and a result that is dropped gives its share back."""
+    import gc
+    from fastqdedup_amd import _lib
+    gc.collect()
+    live0 = _lib._pinned_live[0]
+    n = 1 << 18
+    monkeypatch.setenv("FQD_PINNED_IDS_CAP", str(live0 + 8 * n + 8 * n // 2))      # (room for one and a half such arrays)
+    a = _lib._host_ids(n)
+    assert _lib._pinned_live[0] == live0 + 8 * n
+    b = _lib._host_ids(n)                   # over the cap: pageable, not counted
+    assert _lib._pinned_live[0] == live0 + 8 * n and a.shape == b.shape == (n,) and b.dtype == np.uint64
+    a[:] = 7
+    del a
+    gc.collect()
+    assert _lib._pinned_live[0] == live0
+    c = _lib._host_ids(n)                   # room again
+    assert _lib._pinned_live[0] == live0 + 8 * n
+    del c, b
+
+
 def test_host_keys_uploaded_in_pieces_under_the_pack(F, oracle, monkeypatch):
     """Keys in host memory, the fused way in: the bytes travel in pieces on the second stream and the pack kernel of a
     piece runs under the copy of the next (large jobs by default; FQD_UPLOAD_PIECES pins the number). The read indices
