@@ -609,9 +609,35 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
     const uint32_t n_buckets = 1u << B;
     uint32_t U32 = 0, overflow = 0;
     unsigned long long slab_over = 0;
+    const uint32_t q_per_rec = sh.stride / 4;
+    // fqd_cluster[_keys] announced a Hamming search with nseg segments: the compaction writes its
+    // segment hashes on the way (records whose uint4 count divides 64: their lanes sit side by side)
+    const bool want_seg = c->seg_hint && (!sh.ragged || d_lens) && q_per_rec <= 64 && !(q_per_rec & (q_per_rec - 1)) &&
+                          !getenv("FQD_NO_EARLY_SEG_HASHES");
+    uint32_t seg_written = 0;
+    // the compaction into the unique table as it stands (rows 0 .. row_cap); seg_out: the segment hashes too
+    auto compaction = [&](uint32_t n_buckets_, uint32_t row_cap, bool seg_out) -> int {
+        fqd::SegHashOut sho;
+        if (seg_out) {
+            sho.out = c->seg_hashes.as<uint32_t>();
+            sho.nseg = c->seg_hint;
+            sho.planes = sh.planes;
+            sho.kw = sh.planes * sh.words;
+            sho.len = sh.max_len;
+        }
+        KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_pairs_compact(
+                  c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets_, c->ld_tmp_rec.as<uint32_t>(),
+                  c->ld_tmp_count.as<uint32_t>(), c->ld_tmp_first.as<uint32_t>(), c->recs.as<uint32_t>(), sh.stride, d_ids,
+                  c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho, d_lens,
+                  c->ulens.as<uint32_t>(), row_cap));
+        seg_written = sho.nseg;
+        return FQD_OK;
+    };
+    uint64_t queued_cap = 0;           // != 0: the compaction of the last attempt is queued already, for this many rows
     for (int attempt = 0; attempt < 2; attempt++) {
         const bool slabs = attempt == 0 && !c->pairs_slab_off && !getenv("FQD_LDS_NO_SLABS");
         const uint32_t *items = nullptr, *bucket_end = nullptr;
+        queued_cap = 0;
         FQD_TRY(zero_ctr32(c, C_BAD, 3));         // ... C_COLLISIONS, C_CHANGED: the slices' counters below
         FQD_TRY(zero_ctr64(c, C64_SLAB));
         FQD_TRY(fqd_api_partition_pairs(c, c->hashes.as<uint32_t>(), n, B, slabs, &items, &bucket_end, nullptr));
@@ -641,7 +667,31 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
         FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
         FQD_TRY(queue_read_u32(c, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 0));
         FQD_TRY(queue_read_u32(c, c->d_ctr32.as<uint32_t>() + C_BAD, 1));
-        FQD_TRY(read_ctr64(c, C64_SLAB, &slab_over));
+        FQD_TRY(queue_read_ctr64(c, C64_SLAB, 1));
+        FQD_TRY(queued_reads_mark(c));
+        // The compaction goes out BEHIND the read-back without waiting for it, into the unique table the context's last
+        // job left, when that has room for as many keys as that job had (the kernel itself writes nothing if this job has
+        // more than fit): the GPU stood idle for ~50 us here -- three small copies, the host waking up, its launch --
+        // at every job of a long-key workload. (FQD_NO_OPTIMISTIC_COMPACT=1: wait first, as before.)
+        if (c->pairs_last_U && !getenv("FQD_NO_OPTIMISTIC_COMPACT")) {
+            HIP_TRY(c, c->urecs.reserve(16));      // (a borrowed table is let go of)
+            HIP_TRY(c, c->ulens.reserve(16));
+            HIP_TRY(c, c->ucounts.reserve(16));
+            HIP_TRY(c, c->ufirst.reserve(64));
+            uint64_t room = std::min<uint64_t>({c->urecs.cap / ((size_t)sh.stride * 4), c->ucounts.cap / 4, c->ufirst.cap / 8,
+                                                c->ulens.cap / 4});
+            if (want_seg) {
+                HIP_TRY(c, c->seg_hashes.reserve(16));
+                room = std::min<uint64_t>(room, c->seg_hashes.cap / ((size_t)c->seg_hint * 4));
+            }
+            room = room > 16 ? room - 16 : 0;
+            if (room >= c->pairs_last_U && room < 0xFFFFFFF0ull) {
+                FQD_TRY(compaction(n_buckets, (uint32_t)room, want_seg));
+                queued_cap = room;
+            }
+        }
+        FQD_TRY(queued_reads_wait(c));
+        taken_ctr64(c, &slab_over, 1);
         U32 = taken_u32(c, 0);
         overflow = taken_u32(c, 1);
         if (!slab_over)
@@ -653,29 +703,17 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
     if (overflow)
         return FQD_OK;                 // a bucket with more distinct keys than the LDS table holds
     const uint64_t U = U32;
-    HIP_TRY(c, c->urecs.reserve(U * sh.stride * 4 + 16));
-    HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
-    HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
-    HIP_TRY(c, c->ufirst.reserve(U * 8 + 64));
-    // fqd_cluster[_keys] announced a Hamming search with nseg segments: the compaction writes its
-    // segment hashes on the way (records whose uint4 count divides 64: their lanes sit side by side)
-    fqd::SegHashOut sho;
-    const uint32_t q_per_rec = sh.stride / 4;
-    if (c->seg_hint && U && (!sh.ragged || d_lens) && q_per_rec <= 64 && !(q_per_rec & (q_per_rec - 1)) &&
-        !getenv("FQD_NO_EARLY_SEG_HASHES")) {
-        HIP_TRY(c, c->seg_hashes.reserve((size_t)c->seg_hint * U * 4 + 16));
-        sho.out = c->seg_hashes.as<uint32_t>();
-        sho.nseg = c->seg_hint;
-        sho.planes = sh.planes;
-        sho.kw = sh.planes * sh.words;
-        sho.len = sh.max_len;
+    c->pairs_last_U = U;
+    if (!(queued_cap && U <= queued_cap)) {
+        HIP_TRY(c, c->urecs.reserve(U * sh.stride * 4 + 16));
+        HIP_TRY(c, c->ulens.reserve(U * 4 + 16));
+        HIP_TRY(c, c->ucounts.reserve(U * 4 + 16));
+        HIP_TRY(c, c->ufirst.reserve(U * 8 + 64));
+        if (want_seg && U)
+            HIP_TRY(c, c->seg_hashes.reserve((size_t)c->seg_hint * U * 4 + 16));
+        FQD_TRY(compaction(n_buckets, 0xFFFFFFFFu, want_seg && U));
     }
-    KTIME(c, FQD_K_COMPACT, fqd::launch_bucket_pairs_compact(
-              c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets, c->ld_tmp_rec.as<uint32_t>(),
-              c->ld_tmp_count.as<uint32_t>(), c->ld_tmp_first.as<uint32_t>(), c->recs.as<uint32_t>(), sh.stride, d_ids,
-              c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho, d_lens,
-              c->ulens.as<uint32_t>()));
-    c->seg_hashes_nseg = sho.nseg;
+    c->seg_hashes_nseg = U ? seg_written : 0;
     unsigned long long counted = n;
     if (d_w) {
         FQD_TRY(zero_ctr64(c, C64_SUM));

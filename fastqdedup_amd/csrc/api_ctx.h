@@ -117,6 +117,7 @@ struct fqd_ctx {
     bool search_force_sort = false;     // ... or after the crowded-bucket refinement gave up: that run takes the sort path
     bool search_keeps_edges = false;    // ... except the edge counter and the statistics: pass 0 of this search has run (fqd::Pass0)
     bool search_zero_pending = false;   // find_edges: the job counters and statistics are zeroed by the partition's first launch
+    uint64_t pairs_last_U = 0;     // collapse_pairs: the unique keys of the context's last job (the compaction is queued before this job's are known)
     DevBuf pairs_slices;           // collapse_pairs: the slices of very long buckets (fqd::PairsSlices)
     bool gp_fine_ok = false;       // the last grouped pass: its crowded keys can be matched on finer pieces
     bool gp_fine_used = false;     // the last grouped_refine filed fine items (its candidates count towards the budget)

@@ -381,10 +381,12 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
     const uint32_t *__restrict__ tmp_first, const uint4 *__restrict__ recs4, uint32_t q_per_rec, IdSource read_ids,
     uint4 *__restrict__ urecs4, uint32_t *__restrict__ ucounts, uint64_t *__restrict__ ufirst,
     fqd::SegHashOut sho /* nseg != 0 (q_per_rec a power of two): also the segment hashes of the search that follows */,
-    const uint32_t *__restrict__ lens, uint32_t *__restrict__ ulens /* ragged keys: their lengths travel too */)
+    const uint32_t *__restrict__ lens, uint32_t *__restrict__ ulens /* ragged keys: their lengths travel too */,
+    uint32_t row_cap /* the unique table has room for this many rows: a launch queued BEFORE the host knows the number of
+                        unique keys (api.hip collapse_pairs) writes nothing at all when they are more */)
 {
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (b >= n_buckets)
+    if (b >= n_buckets || unique_incl[n_buckets - 1] > row_cap)
         return;
     const uint32_t end = unique_incl[b], begin = b ? unique_incl[b - 1] : 0u;
     const uint32_t src = bucket_start[b], cnt = end - begin;
@@ -547,7 +549,7 @@ hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint3
                                        const uint32_t *tmp_rep, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                        const uint32_t *recs, uint32_t stride_words, IdSource read_ids, uint32_t *urecs,
                                        uint32_t *ucounts, uint64_t *ufirst, hipStream_t st, SegHashOut seg_hashes,
-                                       const uint32_t *lens, uint32_t *ulens)
+                                       const uint32_t *lens, uint32_t *ulens, uint32_t row_cap)
 {
     if (!n_buckets)
         return hipSuccess;
@@ -557,7 +559,7 @@ hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint3
     const uint64_t threads = (uint64_t)n_buckets * 64;
     bucket_pairs_compact_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
         bucket_start, unique_incl, n_buckets, tmp_rep, tmp_count, tmp_first, reinterpret_cast<const uint4 *>(recs),
-        stride_words / 4, read_ids, reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, lens, ulens);
+        stride_words / 4, read_ids, reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, lens, ulens, row_cap);
     return hipGetLastError();
 }
 

@@ -398,7 +398,8 @@ hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint3
                                        const uint32_t *recs, uint32_t stride_words, IdSource read_ids, uint32_t *urecs,
                                        uint32_t *ucounts, uint64_t *ufirst, hipStream_t st,
                                        SegHashOut seg_hashes = SegHashOut(), const uint32_t *lens = nullptr,
-                                       uint32_t *ulens = nullptr);
+                                       uint32_t *ulens = nullptr, uint32_t row_cap = 0xFFFFFFFFu /* more unique keys than
+                                       this: the launch writes nothing (the caller queued it before it knew) */);
 hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                 hipStream_t st);
 hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,

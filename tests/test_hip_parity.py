@@ -650,6 +650,32 @@ def test_long_record_collapse_without_sort_matches_oracle(F, oracle, monkeypatch
     assert np.array_equal(by_sort.kept_read_ids, got.kept_read_ids)
 
 
+def test_long_record_compaction_queued_before_the_count_is_known(F, oracle, monkeypatch):
+    """collapse_pairs queues the compaction behind its read-back WITHOUT waiting for the number of unique keys when the
+    unique table of the context's last job has room for as many keys as that job had; a job with MORE unique keys than
+    fit must come out right all the same (the queued launch writes nothing, the host launches again), and so must the
+    jobs after it. Three jobs on one context: few unique keys, many, few again; and once with the wait as before."""
+    from fastqdedup_amd.synth import fixed_offsets, synth_keys
+    monkeypatch.setenv("FQD_COLLAPSE", "pairs")
+    L = 100
+    jobs = [synth_keys(150_000, L, 12, 301, copies=8, sub_rate=1e-3, n_rate=1e-4),       # ~19 K molecules
+            synth_keys(150_000, L, L, 302, copies=1, sub_rate=2e-3, n_rate=1e-4),        # every read its own key
+            synth_keys(120_000, L, 12, 303, copies=4, sub_rate=2e-3, n_rate=1e-4)]
+    want = [oracle.dedup(np.ascontiguousarray(k).reshape(-1), fixed_offsets(k.shape[0], L), max_distance=1,
+                         method="directional") for k in jobs]
+    for wait_first in (False, True):
+        if wait_first:
+            monkeypatch.setenv("FQD_NO_OPTIMISTIC_COMPACT", "1")
+        ctx = F.Context(0)
+        for rounds in range(2):
+            for k, w in zip(jobs, want):
+                got = F.cluster_keys(np.ascontiguousarray(k).reshape(-1), key_len=L, max_distance=1, method="directional",
+                                     context=ctx)
+                assert (got.n_unique, got.n_clusters, got.n_kept) == (w["n_unique"], w["n_clusters"], len(w["kept_read_ids"]))
+                assert np.array_equal(got.kept_read_ids, w["kept_read_ids"]), (wait_first, rounds)
+                assert got.route["collapse_pairs"], got.route
+
+
 def test_every_fast_path_agrees_with_the_plain_paths(F, monkeypatch):
     """2 M reads through the default route (pack fused with level 1, slabs at every partition level,
     segment hashes written by the compaction, kept ids through id bins) and through every
