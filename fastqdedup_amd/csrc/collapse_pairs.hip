@@ -26,6 +26,7 @@ constexpr uint32_t PD_THREADS = 256;
 constexpr uint32_t PD_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t PD_AHEAD = 4;
 
+template <bool RAGGED>
 __global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
     const uint2 *__restrict__ items /* (hash, position) */, const uint32_t *__restrict__ bucket_start,
     const uint32_t *__restrict__ bucket_end /* NULL, or slab mode: where each bucket's cursor stopped */,
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
             // ... do them with q_per_rec lanes each, four rounds of loads in flight together ...
             for (uint32_t base = 0; base < qn; base += 4 * groups) {
                 uint4 xa[4], xb[4];
+                uint32_t la[4], lb[4];
                 bool valid[4];
 #pragma unroll
                 for (uint32_t t = 0; t < 4; t++) {
@@ -147,14 +149,21 @@ __global__ __launch_bounds__(PD_THREADS) void bucket_pairs_dedupe_kernel(
                     xa[t] = recs4[(size_t)s_qa[wave][ec] * q_per_rec + ql];
                     xb[t] = recs4[(size_t)s_qb[wave][ec] * q_per_rec + ql];
                 }
+                if (RAGGED) {
+                    // (ragged keys: the two lengths of a comparison, requested WITH its records -- behind them, under a
+                    // branch of their own, they were a second dependent round trip per round: the ragged dedupe of config 5's
+                    // variant took 1.71 ms where keys of one length take 1.14)
+#pragma unroll
+                    for (uint32_t t = 0; t < 4; t++) {
+                        const uint32_t ec = min(base + t * groups + min(gl, groups - 1), qn - 1);
+                        la[t] = lens[s_qa[wave][ec]];
+                        lb[t] = lens[s_qb[wave][ec]];
+                    }
+                }
 #pragma unroll
                 for (uint32_t t = 0; t < 4; t++) {
-                    bool diff = valid[t] && ((xa[t].x ^ xb[t].x) | (xa[t].y ^ xb[t].y) | (xa[t].z ^ xb[t].z) |
-                                             (xa[t].w ^ xb[t].w)) != 0;
-                    if (lens && valid[t] && ql == 0) {
-                        const uint32_t e = base + t * groups + gl;
-                        diff = diff || lens[s_qa[wave][e]] != lens[s_qb[wave][e]];
-                    }
+                    const bool diff = valid[t] && (((xa[t].x ^ xb[t].x) | (xa[t].y ^ xb[t].y) | (xa[t].z ^ xb[t].z) |
+                                                    (xa[t].w ^ xb[t].w)) != 0 || (RAGGED && la[t] != lb[t]));
                     const unsigned long long m = __ballot(diff);
                     if (valid[t] && ql == 0)      // the group's lanes are [lane, lane + q_per_rec)
                         s_qdiff[wave][base + t * groups + gl] =
@@ -526,11 +535,15 @@ hipError_t launch_bucket_pairs_dedupe(const uint32_t *items, const uint32_t *buc
         return n_buckets ? hipErrorInvalidValue : hipSuccess;
     if (sl.slice)
         pairs_slices_kernel<<<(n_buckets + 255) / 256, 256, 0, st>>>(bucket_start, bucket_end, n_buckets, sl);
-    bucket_pairs_dedupe_kernel<<<n_buckets + (sl.slice ? sl.cap : 0u), PD_THREADS, 0, st>>>(
-        reinterpret_cast<const uint2 *>(items), bucket_start, bucket_end, reinterpret_cast<const uint4 *>(recs),
-        stride_words / 4, weights, tmp_rep, tmp_count, tmp_first, bucket_unique, overflow,
-        getenv("FQD_PAIRS_TAG_MASK") ? (uint32_t)strtoul(getenv("FQD_PAIRS_TAG_MASK"), nullptr, 0) : 0xFFFFFFFFu, lens, sl,
-        n_buckets);
+    const uint32_t tag_mask = getenv("FQD_PAIRS_TAG_MASK") ? (uint32_t)strtoul(getenv("FQD_PAIRS_TAG_MASK"), nullptr, 0) : 0xFFFFFFFFu;
+    if (lens)
+        bucket_pairs_dedupe_kernel<true><<<n_buckets + (sl.slice ? sl.cap : 0u), PD_THREADS, 0, st>>>(
+            reinterpret_cast<const uint2 *>(items), bucket_start, bucket_end, reinterpret_cast<const uint4 *>(recs),
+            stride_words / 4, weights, tmp_rep, tmp_count, tmp_first, bucket_unique, overflow, tag_mask, lens, sl, n_buckets);
+    else
+        bucket_pairs_dedupe_kernel<false><<<n_buckets + (sl.slice ? sl.cap : 0u), PD_THREADS, 0, st>>>(
+            reinterpret_cast<const uint2 *>(items), bucket_start, bucket_end, reinterpret_cast<const uint4 *>(recs),
+            stride_words / 4, weights, tmp_rep, tmp_count, tmp_first, bucket_unique, overflow, tag_mask, lens, sl, n_buckets);
     if (sl.slice)
         pairs_merge_kernel<<<std::min(sl.cap, 256u), PD_THREADS, 0, st>>>(bucket_start, reinterpret_cast<const uint4 *>(recs),
                                                                          stride_words / 4, tmp_rep, tmp_count, tmp_first,
