@@ -604,6 +604,8 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
         return FQD_OK;
     // ragged keys (trimmed reads, --check-lengths past a read's end): the lengths are compared with the records
     const uint32_t *d_lens = sh.ragged ? c->lens.as<uint32_t>() : nullptr;
+    // (the records themselves hold the lengths: comparing records compares them, no gathers out of lens[])
+    const bool len_in_rec = d_lens && c->recs_len_pad && c->recs_valid;
     FQD_TRY(ensure_hashes(c));
     const uint32_t B = lds_bucket_bits(n);
     const uint32_t n_buckets = 1u << B;
@@ -629,7 +631,7 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
                   c->ld_start.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets_, c->ld_tmp_rec.as<uint32_t>(),
                   c->ld_tmp_count.as<uint32_t>(), c->ld_tmp_first.as<uint32_t>(), c->recs.as<uint32_t>(), sh.stride, d_ids,
                   c->urecs.as<uint32_t>(), c->ucounts.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->st, sho, d_lens,
-                  c->ulens.as<uint32_t>(), row_cap));
+                  c->ulens.as<uint32_t>(), row_cap, len_in_rec ? c->modal_len_hint : 0u));
         seg_written = sho.nseg;
         return FQD_OK;
     };
@@ -663,7 +665,7 @@ int collapse_pairs(fqd_ctx *c, const uint32_t *d_w, IdSource d_ids, bool *done)
         KTIME(c, FQD_K_DEDUPE, fqd::launch_bucket_pairs_dedupe(
                   items, c->ld_start.as<uint32_t>(), bucket_end, n_buckets, c->recs.as<uint32_t>(), sh.stride, d_w,
                   c->ld_tmp_rec.as<uint32_t>(), c->ld_tmp_count.as<uint32_t>(), c->ld_tmp_first.as<uint32_t>(),
-                  c->ld_unique.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st, d_lens, sl));
+                  c->ld_unique.as<uint32_t>(), c->d_ctr32.as<uint32_t>() + C_BAD, c->st, len_in_rec ? nullptr : d_lens, sl));
         FQD_TRY(scan_u32(c, c->ld_unique.as<uint32_t>(), c->ld_unique_incl.as<uint32_t>(), n_buckets));
         FQD_TRY(queue_read_u32(c, c->ld_unique_incl.as<uint32_t>() + (n_buckets - 1), 0));
         FQD_TRY(queue_read_u32(c, c->d_ctr32.as<uint32_t>() + C_BAD, 1));
@@ -966,6 +968,7 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
         memcpy(present, c->forced_present, 128);
         max_len = c->forced_max_len;
         ragged = c->forced_ragged;
+        c->modal_len_hint = offsets ? max_len : fixed_len;
         if (!offsets && fixed_len != max_len)
             ragged = 1;
     } else {
@@ -980,6 +983,7 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
             HIP_TRY(c, stream_wait(c->st));
             max_len = mm[1];
             ragged = mm[0] != mm[1];
+            c->modal_len_hint = (uint32_t)(((uint64_t)mm[0] + mm[1] + 1) / 2);
         } else if (!n) {
             max_len = 0;
         }
@@ -997,8 +1001,15 @@ int fqd_pack_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uin
             HIP_TRY(c, c->owners.reserve((size_t)n * 4 + 16));
         c->owners_done = fqd::OwnerRule{};
         FQD_TRY(zero_ctr32(c, C_BAD));
+        // ragged records with a padding word carry their key's length in the last one (not for the store, whose rows are
+        // of both kinds; not with an owner rule: the sender's read index rides there)
+        c->recs_len_pad = sh.ragged && sh.stride > sh.planes * sh.words && !c->owner_rule.parts && !c->no_len_pad &&
+                          c->modal_len_hint && !getenv("FQD_NO_LEN_IN_RECORD");
+        KeyShape shp = sh;
+        if (c->recs_len_pad)
+            shp.ragged |= 2u;
         StageTimer kernel_timer(c, FQD_T_PACK_KERNEL);
-        KTIME(c, FQD_K_PACK, fqd::launch_pack(d_bytes, n_bytes, d_off, n, fixed_len, sh, c->d_lut.as<uint8_t>(), lut,
+        KTIME(c, FQD_K_PACK, fqd::launch_pack(d_bytes, n_bytes, d_off, n, fixed_len, shp, c->d_lut.as<uint8_t>(), lut,
                                     c->recs.as<uint32_t>(), sh.ragged ? c->lens.as<uint32_t>() : nullptr,
                                     c->hashes.as<uint32_t>(), c->owner_rule.parts ? c->owners.as<uint32_t>() : nullptr,
                                     c->owner_rule, c->d_ctr32.as<uint32_t>() + C_BAD, c->st));

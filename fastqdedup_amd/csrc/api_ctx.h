@@ -106,6 +106,9 @@ struct fqd_ctx {
     DevBuf in_bytes, in_offsets, recs, lens, hashes, owners;
     bool compact_off = false;      // fqd_cluster_keys: the side slabs of the compact records overflowed once (many keys with an N) -- uint4 records from now on
     bool fused_off = false;        // fqd_cluster_keys: a level-1 slab of the fused pack overflowed once -- plain pack from now on
+    bool recs_len_pad = false;     // ragged records whose last padding word holds the key's length (fqd_pack_keys; see pack.hip)
+    bool no_len_pad = false;       // (the store: its rows come from jobs of either kind and are compared with lens[])
+    uint32_t modal_len_hint = 0;   // ... and a likely length of such keys: (shortest + longest + 1) / 2
     bool recs_valid = false;       // c->recs holds the packed reads in read order (not after the fused pack)
     bool pairs_slab_off = false;   // long-record collapse: same, for its (hash, position) partition
     // crowded buckets of a distance-1 search (group.hip): flags + list + counters, the fine items, the seen marks

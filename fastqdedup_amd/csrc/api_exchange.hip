@@ -202,6 +202,7 @@ int fqd_import_packed(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, ui
     c->n = n;
     c->hashes_valid = false;       // computed when somebody needs them (ensure_hashes)
     c->owners_done = fqd::OwnerRule{};
+    c->recs_len_pad = false;
     c->recs_valid = true;
     c->stage = ST_PACKED;
     return FQD_OK;

@@ -328,7 +328,10 @@ int fqd_store_add_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets
     const bool resident = c->stage >= ST_UNIQUE && c->U > 0;
     if (!resident) {
         // first batch: the plain way in
-        FQD_TRY(fqd_pack_keys(c, bytes, offsets, n, fixed_len, mem));
+        c->no_len_pad = true;
+        const int rc_pack = fqd_pack_keys(c, bytes, offsets, n, fixed_len, mem);
+        c->no_len_pad = false;
+        FQD_TRY(rc_pack);
         FQD_TRY(fqd_collapse(c, weights, read_ids, aux_mem, nullptr));
         FQD_TRY(reset_alive(c));
         if (!read_ids)
@@ -374,7 +377,9 @@ int fqd_store_add_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets
     const int forced_ragged = c->forced_ragged;
     int rc = fqd_configure(c, present, max_len, ragged);
     if (rc == FQD_OK)
+        c->no_len_pad = true;
         rc = fqd_pack_keys(c, bytes, offsets, n, fixed_len, mem);
+        c->no_len_pad = false;
     c->forced = was_forced;
     memcpy(c->forced_present, forced_present, 128);
     c->forced_max_len = forced_max_len;
@@ -452,6 +457,7 @@ int fqd_store_add_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets
     std::swap(c->lens, c->st_comb_lens);
     c->n = n_all;
     c->hashes_valid = false;
+    c->recs_len_pad = false;
     c->recs_valid = true;
     c->owners_done = fqd::OwnerRule{};
     c->stage = ST_PACKED;

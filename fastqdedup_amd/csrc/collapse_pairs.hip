@@ -392,17 +392,20 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
     fqd::SegHashOut sho /* nseg != 0 (q_per_rec a power of two): also the segment hashes of the search that follows */,
     const uint32_t *__restrict__ lens, uint32_t *__restrict__ ulens /* ragged keys: their lengths travel too */,
     uint32_t row_cap /* the unique table has room for this many rows: a launch queued BEFORE the host knows the number of
-                        unique keys (api.hip collapse_pairs) writes nothing at all when they are more */)
+                        unique keys (api.hip collapse_pairs) writes nothing at all when they are more */,
+    uint32_t len_hint /* != 0 (ragged keys): a record's last word IS its key's length (pack.hip): no gathers out of lens[];
+                         the value: a likely length, for the segment masks worked out once per wave */)
 {
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= n_buckets || unique_incl[n_buckets - 1] > row_cap)
         return;
     const uint32_t end = unique_incl[b], begin = b ? unique_incl[b - 1] : 0u;
     const uint32_t src = bucket_start[b], cnt = end - begin;
+    const bool len_in_rec = lens && len_hint;
     for (uint32_t j = fqd_lane(); j < cnt; j += 64) {
         ucounts[begin + j] = tmp_count[src + j];
         ufirst[begin + j] = read_ids.at(tmp_first[src + j]);
-        if (lens)
+        if (lens && !len_in_rec)
             ulens[begin + j] = lens[tmp_rep[src + j]];
     }
     const uint32_t n_unique = unique_incl[n_buckets - 1];
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
     // (ragged keys: the masks of the bucket's first key's length -- nearly every key of a FASTQ file has the modal
     // length --, a key of another length computes its own)
     const bool fixed_masks = sho.nseg && sho.nseg <= MAX_SEG && pow2 && cnt;
-    const uint32_t mask_len = fixed_masks && lens ? lens[tmp_rep[src]] : sho.len;
+    const uint32_t mask_len = fixed_masks && lens ? (len_in_rec ? len_hint : lens[tmp_rep[src]]) : sho.len;
     if (fixed_masks) {
         const uint32_t q = fqd_lane() & (q_per_rec - 1);
         for (uint32_t sg = 0; sg < MAX_SEG; sg++) {
@@ -464,7 +467,11 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
             const uint32_t xc = min(x0 + t * 64, total - 1);
             v[t] = recs4[(size_t)rep[t] * q_per_rec + (pow2 ? xc & (q_per_rec - 1) : xc % q_per_rec)];
         }
-        if (sho.nseg && lens) {              // (ragged keys: segments of the key's own length; one branch for the CP loads)
+        if (sho.nseg && len_in_rec) {        // (the length sits in the record's last word: the record's last lane has it)
+#pragma unroll
+            for (uint32_t t = 0; t < CP; t++)
+                klen_of[t] = __shfl(v[t].w, (int)(fqd_lane() | (q_per_rec - 1u)));
+        } else if (sho.nseg && lens) {       // (ragged keys: segments of the key's own length; one branch for the CP loads)
 #pragma unroll
             for (uint32_t t = 0; t < CP; t++)
                 klen_of[t] = lens[rep[t]];
@@ -480,6 +487,8 @@ __global__ __launch_bounds__(256) void bucket_pairs_compact_kernel(
                 continue;              // (a record's q_per_rec lanes stay or leave together: 64 is a multiple of it when hashes are asked for)
             const uint32_t j = pow2 ? x >> q_shift : x / q_per_rec, q = x - j * q_per_rec;
             urecs4[(size_t)(begin + j) * q_per_rec + q] = v[t];
+            if (len_in_rec && q == q_per_rec - 1u)
+                ulens[begin + j] = v[t].w;
             if (sho.nseg) {
                 // as segment_hashes_kernel (edges.hip): the record's q_per_rec lanes sit side by side in
                 // the wave (q_per_rec divides 64), each sums its four words' share of a segment
@@ -562,7 +571,7 @@ hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint3
                                        const uint32_t *tmp_rep, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                        const uint32_t *recs, uint32_t stride_words, IdSource read_ids, uint32_t *urecs,
                                        uint32_t *ucounts, uint64_t *ufirst, hipStream_t st, SegHashOut seg_hashes,
-                                       const uint32_t *lens, uint32_t *ulens, uint32_t row_cap)
+                                       const uint32_t *lens, uint32_t *ulens, uint32_t row_cap, uint32_t len_hint)
 {
     if (!n_buckets)
         return hipSuccess;
@@ -572,7 +581,8 @@ hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint3
     const uint64_t threads = (uint64_t)n_buckets * 64;
     bucket_pairs_compact_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(
         bucket_start, unique_incl, n_buckets, tmp_rep, tmp_count, tmp_first, reinterpret_cast<const uint4 *>(recs),
-        stride_words / 4, read_ids, reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, lens, ulens, row_cap);
+        stride_words / 4, read_ids, reinterpret_cast<uint4 *>(urecs), ucounts, ufirst, seg_hashes, lens, ulens, row_cap,
+        len_hint);
     return hipGetLastError();
 }
 

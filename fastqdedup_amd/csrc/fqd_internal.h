@@ -7,7 +7,10 @@
 // Base p lives in bit (p & 31) of 32-base word (p >> 5): LSB-first, which is what
 // a wave64 __ballot produces. Word w of plane k is rec[w * K + k]; positions
 // >= len hold code 0; words past K * W up to `stride` (a multiple of 4 u32, so
-// records are 16-byte aligned) are 0.
+// records are 16-byte aligned) are 0 -- except that a RAGGED record with such a padding word may carry its key's
+// length in the LAST one (pack.hip, fqd_ctx::recs_len_pad: comparing two whole records then compares the keys, no
+// look-up in lens[]), and a record on its way to another rank the sender's read index in the FIRST one (IdSource).
+// Nothing that reads key words looks past K * W.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -399,7 +402,8 @@ hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint3
                                        uint32_t *ucounts, uint64_t *ufirst, hipStream_t st,
                                        SegHashOut seg_hashes = SegHashOut(), const uint32_t *lens = nullptr,
                                        uint32_t *ulens = nullptr, uint32_t row_cap = 0xFFFFFFFFu /* more unique keys than
-                                       this: the launch writes nothing (the caller queued it before it knew) */);
+                                       this: the launch writes nothing (the caller queued it before it knew) */,
+                                       uint32_t len_hint = 0 /* != 0: ragged records hold their key's length in their last word */);
 hipError_t launch_matrix_starts(const uint32_t *matrix_incl, uint32_t n_bins, uint32_t n_tiles, uint32_t *start,
                                 hipStream_t st);
 hipError_t launch_bucket_starts(const uint32_t *hist_incl, uint32_t n_buckets, uint32_t *bucket_start,

@@ -347,7 +347,13 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     for (uint32_t item = tid; item < nk * (stride - W * K); item += PACK_THREADS) {
         const uint32_t pad = stride - W * K;
         const uint32_t k = item / pad, j = item - k * pad;
-        tile[k * stride + W * K + j] = 0;
+        uint32_t val = 0;
+        if ((sh.ragged & 2u) && j == pad - 1u)
+            // the key's LENGTH rides in the record's last padding word (api.hip recs_len_pad): two records are then equal
+            // exactly when the keys are, and the long-key collapse needs no gathers out of lens[]
+            val = koff_lds ? s_koff[k + 1] - s_koff[k]
+                           : offsets ? (uint32_t)(offsets[key0 + k + 1] - offsets[key0 + k]) : fixed_len;
+        tile[k * stride + W * K + j] = val;
     }
     __syncthreads();
 

@@ -1514,8 +1514,12 @@ def test_ragged_keys_collapse_without_a_sort(F, oracle, monkeypatch):
     strs += ["A" * k for k in range(1, 70)] * 3 + ["AC", "ACA", "ACAA", "AC"]
     raw, off = _pack(strs)
     want = oracle.dedup(raw, off, max_distance=1, method="directional")
-    for path in ("pairs", "pairs in slices of 64", "sort"):
+    for path in ("pairs", "pairs with lengths looked up", "pairs in slices of 64", "sort"):
         monkeypatch.setenv("FQD_COLLAPSE", path.split()[0])
+        if "looked up" in path:
+            monkeypatch.setenv("FQD_NO_LEN_IN_RECORD", "1")   # (by default a ragged record carries its key's length, pack.hip)
+        else:
+            monkeypatch.delenv("FQD_NO_LEN_IN_RECORD", raising=False)
         if "slices" in path:
             monkeypatch.setenv("FQD_PAIRS_SLICE", "64")       # (the rows of a bucket's slices joined by pairs_merge_kernel)
         ctx = F.Context(0)
