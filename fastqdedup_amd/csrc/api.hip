@@ -1083,12 +1083,14 @@ static int collapse_impl(fqd_ctx *c, const uint32_t *weights, int mem, IdSource 
     const uint32_t *d_w;
     FQD_TRY(to_device(c, weights, (size_t)n, mem, c->in_weights, &d_w));
 
+    c->urecs_len_pad = false;
     bool lds_done = false;
     FQD_TRY(collapse_lds(c, weights ? d_w : nullptr, ids, &lds_done));
     if (lds_done) {
         timer.stop();
         c->route |= FQD_ROUTE_COLLAPSE_LDS;
         c->collapse_path = 1;
+        c->urecs_len_pad = false;
         c->collapsed = true;
         c->first_distinct = true;
         set_id_range(c, read_ids ? id_limit : n);
@@ -1111,6 +1113,7 @@ static int collapse_impl(fqd_ctx *c, const uint32_t *weights, int mem, IdSource 
     FQD_TRY(collapse_pairs(c, weights ? d_w : nullptr, ids, &pairs_done));
     if (pairs_done) {
         timer.stop();
+        c->urecs_len_pad = c->ks.ragged && c->recs_len_pad && c->recs_valid && c->modal_len_hint < (1u << 24);
         c->route |= FQD_ROUTE_COLLAPSE_PAIRS;
         c->collapse_path = 3;
         c->collapsed = true;
@@ -1191,6 +1194,7 @@ static int collapse_impl(fqd_ctx *c, const uint32_t *weights, int mem, IdSource 
     timer.stop();
     c->U = U;
     c->n_counted = counted;
+    c->urecs_len_pad = false;
     c->collapsed = true;
     c->first_distinct = true;
     set_id_range(c, read_ids ? id_limit : n);
@@ -1511,6 +1515,7 @@ static int pack_collapse_fused_once(fqd_ctx *c, const uint8_t *bytes, uint64_t n
     c->route |= FQD_ROUTE_FUSED_PACK | FQD_ROUTE_COLLAPSE_LDS | (compact ? FQD_ROUTE_COMPACT_RECORDS : 0u) |
                 (c->pass0_done ? FQD_ROUTE_PASS0_IN_COLLAPSE : 0u) | (heavy ? FQD_ROUTE_SPILL_LIST : 0u);
     c->collapse_path = 1;
+    c->urecs_len_pad = false;
     c->collapsed = true;
     c->first_distinct = true;
     set_id_range(c, n);
@@ -1745,6 +1750,7 @@ int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *
     StageTimer timer(c, FQD_T_COLLAPSE);
     if (!n_reads) {
         timer.stop();
+        c->urecs_len_pad = false;
         c->collapsed = true;
         c->first_distinct = true;
         set_id_range(c, id_limit);
@@ -1877,6 +1883,7 @@ int fqd_collapse_owner_slabs(fqd_ctx *c, const uint32_t *slabs, const uint32_t *
     c->route = FQD_ROUTE_COLLAPSE_LDS | (f.compact ? FQD_ROUTE_COMPACT_RECORDS : 0u) |
                (c->pass0_done ? FQD_ROUTE_PASS0_IN_COLLAPSE : 0u);
     c->collapse_path = 1;
+    c->urecs_len_pad = false;
     c->collapsed = true;
     c->first_distinct = true;
     set_id_range(c, id_limit);

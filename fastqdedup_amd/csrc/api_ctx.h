@@ -106,6 +106,8 @@ struct fqd_ctx {
     DevBuf in_bytes, in_offsets, recs, lens, hashes, owners;
     bool compact_off = false;      // fqd_cluster_keys: the side slabs of the compact records overflowed once (many keys with an N) -- uint4 records from now on
     bool fused_off = false;        // fqd_cluster_keys: a level-1 slab of the fused pack overflowed once -- plain pack from now on
+    bool urecs_len_pad = false;    // ... and the unique table's rows still do (the long-key collapse copies whole rows): the search's
+                                   // verification and the graph's key comparisons take lengths from the rows they fetch anyway
     bool recs_len_pad = false;     // ragged records whose last padding word holds the key's length (fqd_pack_keys; see pack.hip)
     bool no_len_pad = false;       // (the store: its rows come from jobs of either kind and are compared with lens[])
     uint32_t modal_len_hint = 0;   // ... and a likely length of such keys: (shortest + longest + 1) / 2
@@ -291,6 +293,16 @@ int to_device(fqd_ctx *c, const T *src, size_t count, int mem, DevBuf &staging, 
 
 // Wait for the context's stream. (Polling hipStreamQuery instead gained 1.4 % while the counter
 // read-backs went through pageable memory and nothing once they were pinned: not worth a spinning core.)
+// the key shape as the kernels that can take a row's length from the row itself get it: bit 1 of `ragged` says so, the
+// bits from 8 up hold a likely length (see group.hip verify_candidates_kernel, graph.hip key_greater_inflight)
+inline KeyShape shape_with_row_lengths(const fqd_ctx *c)
+{
+    KeyShape sh = c->ks;
+    if (sh.ragged && c->urecs_len_pad && !getenv("FQD_NO_LEN_IN_RECORD"))
+        sh.ragged = 1u | 2u | (c->modal_len_hint << 8);
+    return sh;
+}
+
 inline hipError_t stream_wait(hipStream_t st) { return hipStreamSynchronize(st); }
 
 template <typename T>

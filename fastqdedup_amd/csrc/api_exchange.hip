@@ -275,6 +275,7 @@ int fqd_import_unique(fqd_ctx *c, const uint32_t *recs, const uint32_t *lens, co
         HIP_TRY(c, stream_wait(c->st));
     c->U = U;
     c->seg_hashes_nseg = 0;
+    c->urecs_len_pad = false;
     c->collapsed = false;  // imported rows may repeat a key (dissection of a caller's list)
     c->first_distinct = first_ids != nullptr;
     c->id_bits = 1;

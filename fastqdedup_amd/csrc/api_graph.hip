@@ -368,7 +368,7 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
                 }
                 KTIME(c, FQD_K_DISSECT_ROUND, fqd::launch_directional_closed(
                           c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(), c->urecs.as<uint32_t>(),
-                          c->ulens.as<uint32_t>(), sh, c->labels.as<uint32_t>(), c->state.as<uint8_t>(),
+                          c->ulens.as<uint32_t>(), shape_with_row_lengths(c), c->labels.as<uint32_t>(), c->state.as<uint8_t>(),
                           c->taint.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_CANDS,
                           c->root_taint.as<uint8_t>(), c->best.as<uint32_t>(), pass, c->st, c->stage_a.as<uint32_t>(),
                           split_unions ? c->taint.as<uint32_t>() + E : nullptr,
@@ -399,7 +399,7 @@ int fqd_dissect(fqd_ctx *c, int method, uint64_t *n_kept)
         HIP_TRY(c, hipMemsetAsync(c->blocked.p, 0, U * 4, c->st));
         // edges become (higher rank, lower rank); union-find and the other methods do not care
         HIP_TRY(c, fqd::launch_orient_edges(c->edges.as<uint32_t>(), E, c->ucounts.as<uint32_t>(),
-                                            c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, c->st));
+                                            c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), shape_with_row_lengths(c), c->st));
         // After the first two sweeps only the edges that can still matter are swept (their list is
         // made while the host waits for the "anything changed?" flag of those sweeps).
         const uint32_t *sweep_edges = c->edges.as<uint32_t>();

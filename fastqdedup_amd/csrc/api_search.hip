@@ -469,7 +469,7 @@ static int grouped_pass(fqd_ctx *c, const uint32_t *hashes, uint64_t U, uint32_t
                                                          c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,
                                                          c->st, 0, skip));
     KTIME(c, FQD_K_VERIFY, fqd::launch_verify_candidates(c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap,
-                                                         c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, s, nseg,
+                                                         c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), shape_with_row_lengths(c), d, s, nseg,
                                                          c->edges.as<uint32_t>(), ctr + C64_EDGES, c->edge_cap,
                                                          ctr + C64_CAND_NEED, c->d_stats.as<fqd::PairStats>(), c->st,
                                                          fused_U));
@@ -782,7 +782,7 @@ static int find_edges_impl(fqd_ctx *c, int max_distance, int metric, uint32_t sh
                 }
                 KTIME(c, FQD_K_PAIRS, fqd::launch_bucket_pairs(
                                c->sorted_hash.as<uint32_t>(), c->sorted_uid.as<uint32_t>(), m,
-                               c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, s, nseg, 0, 1,
+                               c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), shape_with_row_lengths(c), d, s, nseg, 0, 1,
                                c->edges.as<uint32_t>(), c->d_ctr64.as<unsigned long long>() + C64_EDGES, c->edge_cap,
                                c->d_stats.as<fqd::PairStats>(), c->st));
             }

@@ -366,6 +366,11 @@ int fqd_store_add_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets
         max_len = std::max(max_len, ml);
     }
     // ---- the resident rows step aside; the new keys are packed with the common geometry ----
+    if (c->urecs_len_pad && U0) {
+        // (a table a one-call job left: its rows hold their lengths in their last padding word, the store's do not)
+        HIP_TRY(c, fqd::launch_clear_last_word(c->urecs.as<uint32_t>(), U0, old_ks.stride, c->st));
+        c->urecs_len_pad = false;
+    }
     std::swap(c->urecs, c->st_recs);
     std::swap(c->ulens, c->st_lens);
     std::swap(c->ucounts, c->st_counts);
@@ -376,10 +381,11 @@ int fqd_store_add_keys(fqd_ctx *c, const uint8_t *bytes, const uint64_t *offsets
     const uint32_t forced_max_len = c->forced_max_len;
     const int forced_ragged = c->forced_ragged;
     int rc = fqd_configure(c, present, max_len, ragged);
-    if (rc == FQD_OK)
+    if (rc == FQD_OK) {
         c->no_len_pad = true;
         rc = fqd_pack_keys(c, bytes, offsets, n, fixed_len, mem);
         c->no_len_pad = false;
+    }
     c->forced = was_forced;
     memcpy(c->forced_present, forced_present, 128);
     c->forced_max_len = forced_max_len;

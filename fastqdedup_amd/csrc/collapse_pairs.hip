@@ -560,6 +560,22 @@ hipError_t launch_bucket_pairs_dedupe(const uint32_t *items, const uint32_t *buc
     return hipGetLastError();
 }
 
+// rows whose last padding word holds the key's length (pack.hip) as rows without: the store compares whole rows of
+// tables built either way
+__global__ void clear_last_word_kernel(uint32_t *__restrict__ recs, uint64_t n, uint32_t stride)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        recs[i * stride + stride - 1u] = 0u;
+}
+
+hipError_t launch_clear_last_word(uint32_t *recs, uint64_t n, uint32_t stride, hipStream_t st)
+{
+    if (n && stride)
+        clear_last_word_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(recs, n, stride);
+    return hipGetLastError();
+}
+
 uint32_t pairs_slice_items()
 {
     if (const char *e = getenv("FQD_PAIRS_SLICE"))       // tests: small slices; 0 = one workgroup per bucket whatever its size

@@ -396,6 +396,7 @@ hipError_t launch_bucket_pairs_dedupe(const uint32_t *items, const uint32_t *buc
                                       uint32_t *tmp_first, uint32_t *bucket_unique, uint32_t *overflow, hipStream_t st,
                                       const uint32_t *lens = nullptr, PairsSlices sl = PairsSlices());
 uint32_t pairs_slice_items();
+hipError_t launch_clear_last_word(uint32_t *recs, uint64_t n, uint32_t stride, hipStream_t st);
 hipError_t launch_bucket_pairs_compact(const uint32_t *bucket_start, const uint32_t *unique_incl, uint32_t n_buckets,
                                        const uint32_t *tmp_rep, const uint32_t *tmp_count, const uint32_t *tmp_first,
                                        const uint32_t *recs, uint32_t stride_words, IdSource read_ids, uint32_t *urecs,

@@ -944,9 +944,11 @@ __device__ __forceinline__ bool key_greater_inflight(uint32_t a, uint32_t b, con
             if (va[q].x != vb[q].x) first = 4u * q + 0u;
         }
     }
-    const uint32_t la = fqd_key_len(sh, ulens, a), lb = fqd_key_len(sh, ulens, b);
+    // (ragged & 2: the rows' last word holds the key's length -- va[7] is the row's last uint4, the clamp above -- no look-up)
+    const uint32_t la = (sh.ragged & 2u) ? va[7].w : fqd_key_len(sh, ulens, a);
+    const uint32_t lb = (sh.ragged & 2u) ? vb[7].w : fqd_key_len(sh, ulens, b);
     if (first == 0xFFFFFFFFu || first >= sh.planes * sh.words)
-        return la > lb;                              // (equal records: one is a prefix of the other, or padding differs -- never)
+        return la > lb;                              // (equal key words: one key is a prefix of the other)
     // (the words of that 32-base word again, from the cache: no register array indexed by a run-time value)
     const uint32_t w = first / sh.planes;
     const uint32_t d = fqd_diff_word_dyn(ra, rb, w, sh.planes);

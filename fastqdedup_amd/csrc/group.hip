@@ -533,14 +533,20 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
             // Keys of ONE length: which bits of this lane's 32-base words (ql, ql + Q: W <= 2 Q for records of up to
             // 16 uint4... else the general loop) lie in segment s2 does not depend on the candidate -- worked out once
             // per sweep, not per word, segment and candidate (two divisions by nseg each: the inner loop was mostly that)
-            const bool fixed = !sh.ragged && nseg <= 4 && W <= 2 * Q;
+            // Ragged keys whose rows hold their length in their last word (sh.ragged & 2; bits 8.. of sh.ragged: a likely
+            // length, api.hip modal_len_hint): no look-ups in ulens[] -- two sectors per candidate -- and the masks of that
+            // likely length serve every pair that has it (nearly all of a FASTQ file's keys); other pairs work theirs out.
+            const bool pow2q = (Q & (Q - 1)) == 0;
+            const bool len_pad = (sh.ragged & 2u) != 0 && pow2q;
+            const uint32_t fixed_len = sh.ragged ? (len_pad ? sh.ragged >> 8 : 0u) : sh.max_len;
+            const bool fixed = fixed_len != 0 && nseg <= 4 && W <= 2 * Q;
             uint32_t fm0[4] = {0, 0, 0, 0}, fm1[4] = {0, 0, 0, 0};
             if (fixed) {
 #pragma unroll
                 for (uint32_t s2 = 0; s2 < 4; s2++)
                     if (s2 < nseg) {
                         uint32_t slo, shi;
-                        fqd_segment(sh.max_len, s2, nseg, slo, shi);
+                        fqd_segment(fixed_len, s2, nseg, slo, shi);
                         fm0[s2] = ql < W ? fqd_range_mask(ql, slo, shi) : 0u;
                         fm1[s2] = ql + Q < W ? fqd_range_mask(ql + Q, slo, shi) : 0u;
                     }
@@ -561,12 +567,16 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
                     const uint32_t pu = __shfl(pr.x, cnd & 63u), pv = __shfl(pr.y, cnd & 63u);
                     lens2[t] = sh.max_len;
                     uint32_t len_v = sh.max_len;
-                    if (sh.ragged) {
+                    if (sh.ragged && !len_pad) {
                         lens2[t] = ulens[pu];
                         len_v = ulens[pv];
                     }
                     const uint32_t qc = min(ql, Q - 1);
                     const uint4 a = recs4[(size_t)pu * Q + qc], b = recs4[(size_t)pv * Q + qc];
+                    if (len_pad) {                       // (the group's last lane holds the rows' last uint4)
+                        lens2[t] = __shfl(a.w, (int)((lane - ql) + Q - 1));
+                        len_v = __shfl(b.w, (int)((lane - ql) + Q - 1));
+                    }
                     xs[t] = make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
                     on[t] = on[t] && len_v == lens2[t];
                 }
@@ -579,7 +589,7 @@ __global__ __launch_bounds__(GP_THREADS) void verify_candidates_kernel(
                         *reinterpret_cast<uint4 *>(&s_x[wave][(gl * Q + ql) * 4]) = xs[t];
                     __builtin_amdgcn_wave_barrier();
                     uint32_t dist = 0, seg_mis = 0;
-                    if (on[t] && fixed) {
+                    if (on[t] && fixed && lens2[t] == fixed_len) {
                         const uint32_t *x = &s_x[wave][gl * Q * 4];
                         uint32_t dw0 = 0, dw1 = 0;
                         if (ql < W) {

@@ -1554,6 +1554,29 @@ def test_page_locked_id_arrays_are_capped(F, monkeypatch):
     del c, b
 
 
+def test_a_table_with_lengths_in_its_rows_becomes_a_store(F, monkeypatch):
+    """Ragged long keys clustered in one call leave a unique table whose rows hold their key's length in their last
+    padding word (pack.hip); keys ADDED to that table through the store are packed without -- the store clears the word
+    of the resident rows first, or equal keys of the two kinds would not meet. 'AC' + 'A' * k against 'AC' + 'A' * (k+1):
+    the same key words when A is code 0."""
+    import random
+    monkeypatch.setenv("FQD_COLLAPSE", "pairs")
+    rng = random.Random(11)
+    mols = ["".join(rng.choice("ACGT") for _ in range(rng.randint(40, 70))) for _ in range(5_000)]
+    mols += ["AC" + "A" * k for k in range(30, 60)]
+    first = [rng.choice(mols) for _ in range(70_000)]
+    later = [rng.choice(mols) for _ in range(70_000)] + ["".join(rng.choice("ACGT") for _ in range(50)) for _ in range(500)]
+    ctx = F.Context(0)
+    raw, off = _pack(first)
+    got = F.cluster_keys(raw, off, max_distance=0, method="highest_count", context=ctx)
+    assert got.n_unique == len(set(first)) and got.route["collapse_pairs"], got.route
+    raw2, off2 = _pack(later)
+    assert ctx.store_add_keys(raw2, off2) == len(set(first) | set(later))
+    # ... and the other way round: a store first, then a one-call job on the same context
+    got = F.cluster_keys(raw, off, max_distance=0, method="highest_count", context=ctx)
+    assert got.n_unique == len(set(first))
+
+
 def test_host_keys_uploaded_in_pieces_under_the_pack(F, oracle, monkeypatch):
     """Keys in host memory, the fused way in: the bytes travel in pieces on the second stream and the pack kernel of a
     piece runs under the copy of the next (large jobs by default; FQD_UPLOAD_PIECES pins the number). The read indices
