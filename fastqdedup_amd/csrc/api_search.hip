@@ -202,8 +202,8 @@ int find_edges_edit_grouped(fqd_ctx *c, uint32_t d, bool *done, bool cross_only 
                                                              cross_only ? 0x80000000u : 0u));
         KTIME(c, FQD_K_VERIFY, fqd::launch_edit_grouped_verify(
                   c->gp_cands.as<uint64_t>(), cand_ctr, c->gp_cand_cap / fqd::group_cand_lists(), fqd::group_cand_lists(),
-                  c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), sh, d, d_mask, c->edges.as<uint32_t>(), ctr + C64_EDGES,
-                  c->edge_cap, ctr + C64_CAND_NEED, ctr + C64_SUM, cross_only ? 1 : 0, c->st));
+                  c->urecs.as<uint32_t>(), c->ulens.as<uint32_t>(), shape_with_row_lengths(c), d, d_mask, c->edges.as<uint32_t>(),
+                  ctr + C64_EDGES, c->edge_cap, ctr + C64_CAND_NEED, ctr + C64_SUM, cross_only ? 1 : 0, c->st));
         unsigned long long ctrs[C64_SLAB + 1] = {0};
         FQD_TRY(read_ctr64(c, 0, ctrs, C64_SLAB + 1));
         const unsigned long long now = ctrs[C64_EDGES], cand_need = ctrs[C64_CAND_NEED];

@@ -721,7 +721,10 @@ __global__ __launch_bounds__(256) void edit_grouped_verify_kernel(
                     ua = ub;
                     ub = tu;
                 }
-                const uint32_t la = fqd_key_len(sh, ulens, ua), lb = fqd_key_len(sh, ulens, ub);
+                // (sh.ragged & 2: a row's last word is its key's length -- the rows are about to be read anyway, a look-up in
+                // ulens[] is a sector of its own per key)
+                const uint32_t la = (sh.ragged & 2u) ? urecs[((uint64_t)ua + 1) * sh.stride - 1] : fqd_key_len(sh, ulens, ua);
+                const uint32_t lb = (sh.ragged & 2u) ? urecs[((uint64_t)ub + 1) * sh.stride - 1] : fqd_key_len(sh, ulens, ub);
                 const uint32_t gap = la > lb ? la - lb : lb - la;
                 const uint32_t seg = (pa >> EG_UID_BITS) & 3u;
                 const int delta = (int)((pa >> (EG_UID_BITS + 2)) & 7u) - 3;
