@@ -201,7 +201,9 @@ int fqd_get_unique_table(fqd_ctx *ctx, uint64_t *first_ids, uint32_t *counts, ui
                          uint8_t *kept, int mem);
 
 /* ---- exchange (multi-GPU: the caller moves these buffers with RCCL) -------- */
-/* Packed reads of stage 1: recs n*stride_words u32, lens n u32, hashes n u32. */
+/* Packed reads of stage 1: recs n*stride_words u32, lens n u32, hashes n u32. Words of a record past
+ * planes * words are padding: zero, except that a ragged key's record with such a word may hold the key's length in its
+ * LAST one (nothing that reads key words looks there; records that hold the same key hold the same length). */
 int fqd_export_packed(fqd_ctx *ctx, uint32_t *recs, uint32_t *lens, uint32_t *hashes, int mem);
 int fqd_import_packed(fqd_ctx *ctx, const uint32_t *recs, const uint32_t *lens, uint64_t n, int mem);
 /* The same reads grouped by owner = key_hash % n_parts (part 0 first), each part in read order:
